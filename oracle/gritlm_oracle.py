@@ -1,0 +1,309 @@
+"""CPU oracle for the GritLM embedding-encode / contrastive hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``gritlm_amd/`` may import this
+module: it is the *checker* for the HIP path (tests/, ``__graft_entry__.smoke``
+and the ``cpu_baseline`` leg of ``bench.py``), never the thing shipped or
+measured.  The product path fails loudly when ``libgritlm_hip.so`` is missing.
+
+It is a plain numpy restatement (fp32 storage, fp64 accumulation where cheap)
+of the reference algorithm; every function cites the reference file:line it
+follows (paths relative to the upstream checkout, ``/root/reference``).
+
+Parity pin: the reference ships no tests/golden vectors for this path
+(SURVEY.md §4), so the oracle is pinned against outputs of the reference's own
+Python run in the build container - ``tests/golden/make_golden.py`` imports
+``/root/reference`` (gritlm.GritLM.pooling, scripts/modeling_mistral_gritlm.py
+MistralModel(is_causal=False), training.model.DistributedContrastiveLoss,
+GradCache) and stores input/output fixtures under ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` replays them through this file.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+
+# ----------------------------------------------------------------------------
+# bf16 helpers (round-to-nearest-even, the rounding torch uses for .to(bf16))
+# ----------------------------------------------------------------------------
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round fp32 values to the nearest bf16 (RNE) and return them as fp32."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    u = x.view(np.uint32).astype(np.uint64)
+    lsb = (u >> 16) & 1
+    r = ((u + 0x7FFF + lsb) >> 16) << 16
+    out = r.astype(np.uint32).view(F32).reshape(x.shape)
+    nan = np.isnan(x)
+    if nan.any():
+        out = np.where(nan, x, out)
+    return out
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> uint16 bf16 bit pattern (RNE)."""
+    return (bf16_round(x).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(F32)
+
+
+# ----------------------------------------------------------------------------
+# Encoder pieces  (scripts/modeling_mistral_gritlm.py)
+# ----------------------------------------------------------------------------
+def rmsnorm(x: np.ndarray, weight: np.ndarray, eps: float, emulate_bf16: bool = False) -> np.ndarray:
+    """MistralRMSNorm.forward, scripts/modeling_mistral_gritlm.py:84-89.
+
+    fp32 ``x * rsqrt(mean(x^2) + eps)``, cast to the input dtype, THEN
+    multiply by the weight.  With ``emulate_bf16`` both casts are rounded to
+    bf16 exactly where the reference rounds them for a bf16 model.
+    """
+    x = x.astype(F32)
+    var = np.mean(x.astype(F64) ** 2, axis=-1, keepdims=True)
+    y = (x * (1.0 / np.sqrt(var + eps))).astype(F32)
+    if emulate_bf16:
+        y = bf16_round(y)
+        return bf16_round(weight.astype(F32) * y)
+    return weight.astype(F32) * y
+
+
+def rope_tables(seq_len: int, head_dim: int, theta: float) -> tuple[np.ndarray, np.ndarray]:
+    """MistralRotaryEmbedding, scripts/modeling_mistral_gritlm.py:93-126.
+
+    inv_freq = 1/theta^(2i/d); freqs = outer(arange(S), inv_freq);
+    emb = cat(freqs, freqs); cos/sin tables [S, d] fp32.
+    """
+    inv_freq = 1.0 / (theta ** (np.arange(0, head_dim, 2, dtype=F32) / head_dim))
+    t = np.arange(seq_len, dtype=F32)
+    freqs = np.outer(t, inv_freq).astype(F32)
+    emb = np.concatenate([freqs, freqs], axis=-1)
+    return np.cos(emb).astype(F32), np.sin(emb).astype(F32)
+
+
+def rotate_half(x: np.ndarray) -> np.ndarray:
+    """scripts/modeling_mistral_gritlm.py:130-134."""
+    h = x.shape[-1] // 2
+    return np.concatenate([-x[..., h:], x[..., :h]], axis=-1)
+
+
+def apply_rope(x: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
+    """apply_rotary_pos_emb, scripts/modeling_mistral_gritlm.py:138-163.
+
+    x: [B, heads, S, d]; positions are arange(S) (:984-989).
+    """
+    return x * cos[None, None] + rotate_half(x) * sin[None, None]
+
+
+def attention_bidirectional(q, k, v, key_mask):
+    """Attention core with is_causal=False and a key-padding mask.
+
+    MistralSdpaAttention.forward scripts/modeling_mistral_gritlm.py:627-705
+    (repeat_kv :182-191, SDPA :690-698) with the additive mask of
+    `_prepare_4d_attention_mask(_for_sdpa)` (:1017-1020, :1033-1036):
+    finfo.min on padded KEYS only, every query row (padded or not) is computed.
+
+    q: [B, Hq, S, d]; k, v: [B, Hkv, S, d]; key_mask: [B, S] (0/1).
+    Returns [B, S, Hq*d].
+    """
+    B, Hq, S, d = q.shape
+    Hkv = k.shape[1]
+    rep = Hq // Hkv
+    k = np.repeat(k, rep, axis=1)
+    v = np.repeat(v, rep, axis=1)
+    scores = np.einsum("bhqd,bhkd->bhqk", q.astype(F64), k.astype(F64)) / np.sqrt(d)
+    if key_mask is not None:
+        neg = np.where(key_mask.astype(bool), 0.0, -np.inf)[:, None, None, :]
+        scores = scores + neg
+    scores = scores - scores.max(axis=-1, keepdims=True)
+    p = np.exp(scores)
+    p = p / p.sum(axis=-1, keepdims=True)
+    out = np.einsum("bhqk,bhkd->bhqd", p, v.astype(F64))
+    return out.transpose(0, 2, 1, 3).reshape(B, S, Hq * d).astype(F32)
+
+
+def silu(x):
+    return x / (1.0 + np.exp(-x))
+
+
+def mlp(x, w_gate, w_up, w_down):
+    """MistralMLP.forward, scripts/modeling_mistral_gritlm.py:177-178."""
+    g = x @ w_gate.T
+    u = x @ w_up.T
+    return (silu(g) * u) @ w_down.T
+
+
+def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_mask: np.ndarray | None,
+                   emulate_bf16: bool = False, return_layers: bool = False):
+    """MistralModel.forward with is_causal=False, scripts/modeling_mistral_gritlm.py:936-1096.
+
+    ``weights`` uses the HF state_dict names of MistralModel (``embed_tokens.weight``,
+    ``layers.N.self_attn.q_proj.weight`` ... ``norm.weight``) as fp32 numpy arrays.
+    ``cfg``: hidden_size, num_hidden_layers, num_attention_heads, num_key_value_heads,
+    intermediate_size, rms_norm_eps, rope_theta (head_dim = hidden/heads).
+
+    ``emulate_bf16`` rounds to bf16 at the points where a bf16 reference model rounds
+    (after every Linear / norm / residual add / RoPE / attention output).
+    """
+    H = cfg["hidden_size"]; L = cfg["num_hidden_layers"]
+    nh = cfg["num_attention_heads"]; nkv = cfg["num_key_value_heads"]
+    d = cfg.get("head_dim") or H // nh
+    eps = cfg["rms_norm_eps"]; theta = cfg["rope_theta"]
+    rnd = bf16_round if emulate_bf16 else (lambda a: a.astype(F32))
+    B, S = input_ids.shape
+    h = weights["embed_tokens.weight"][input_ids].astype(F32)            # :994
+    cos, sin = rope_tables(S, d, theta)
+    if emulate_bf16:
+        cos, sin = bf16_round(cos), bf16_round(sin)                       # :124-125
+    layers = []
+    for li in range(L):                                                   # :1045-1071
+        p = f"layers.{li}."
+        res = h
+        x = rmsnorm(h, weights[p + "input_layernorm.weight"], eps, emulate_bf16)      # :757
+        q = rnd(x @ weights[p + "self_attn.q_proj.weight"].T)                          # :655-657
+        k = rnd(x @ weights[p + "self_attn.k_proj.weight"].T)
+        v = rnd(x @ weights[p + "self_attn.v_proj.weight"].T)
+        q = q.reshape(B, S, nh, d).transpose(0, 2, 1, 3)
+        k = k.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
+        v = v.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
+        q = rnd(apply_rope(q, cos, sin)); k = rnd(apply_rope(k, cos, sin))             # :666-668
+        a = rnd(attention_bidirectional(q, k, v, attention_mask))                      # :690-698
+        a = rnd(a @ weights[p + "self_attn.o_proj.weight"].T)                          # :703
+        h = rnd(res + a)                                                               # :769
+        res = h
+        x = rmsnorm(h, weights[p + "post_attention_layernorm.weight"], eps, emulate_bf16)  # :773
+        g = rnd(x @ weights[p + "mlp.gate_proj.weight"].T)
+        u = rnd(x @ weights[p + "mlp.up_proj.weight"].T)
+        m = rnd(rnd(silu(g)) * u)
+        m = rnd(m @ weights[p + "mlp.down_proj.weight"].T)                             # :177-178
+        h = rnd(res + m)                                                               # :775
+        if return_layers:
+            layers.append(h.copy())
+    out = rmsnorm(h, weights["norm.weight"], eps, emulate_bf16)                        # :1079
+    if return_layers:
+        return out, layers
+    return out
+
+
+# ----------------------------------------------------------------------------
+# Pooling + normalise  (gritlm/gritlm.py)
+# ----------------------------------------------------------------------------
+def pooling(hidden: np.ndarray, attention_mask: np.ndarray, method: str) -> np.ndarray:
+    """GritLM.pooling, gritlm/gritlm.py:178-218 (fp32 result, no recast).
+
+    hidden [b, n, d]; attention_mask [b, n] integer.  NOTE the reference mutates
+    the caller's mask in place for 'weightedmean' (:211); this restatement works
+    on a copy and the host wrapper reproduces the mutation.
+    """
+    hidden = hidden.astype(F32)
+    m = attention_mask.astype(np.int64).copy()
+    b, n, d = hidden.shape
+    if method == "cls":                                                   # :188
+        return hidden[:, 0].copy()
+    if method == "lasttoken":                                             # :190-208
+        rev = m[:, ::-1]
+        argmax_rev = np.argmax(rev, axis=1)
+        idx = np.clip(n - argmax_rev - 1, 0, None)
+        masked = hidden * m[..., None].astype(F32)
+        return masked[np.arange(b), idx]
+    if method in ("mean", "weightedmean"):                                # :209-214
+        if method == "weightedmean":
+            m = m * np.cumsum(m, axis=1)                                  # :211
+        s = np.sum(hidden.astype(F64) * m[..., None].astype(F64), axis=1)
+        den = m.sum(axis=1, keepdims=True).astype(F64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return (s / den).astype(F32)                                  # unguarded, :213-214
+    raise NotImplementedError(f"Unknown pooling method: {method}")       # :215
+
+
+def l2_normalize(x: np.ndarray, eps: float = 1e-12) -> np.ndarray:
+    """F.normalize(dim=-1), gritlm/gritlm.py:156-158, training/model.py:162-164."""
+    n = np.sqrt(np.sum(x.astype(F64) ** 2, axis=-1, keepdims=True))
+    return (x / np.maximum(n, eps)).astype(F32)
+
+
+def instruction_mask(attention_mask: np.ndarray, instruction_lens) -> np.ndarray:
+    """Pooling mask with the instruction tokens zeroed.
+
+    gritlm/gritlm.py:144-153 (same length for every row) and
+    gritlm/training/model.py:151-158 (per-row lengths).  Attention still sees
+    the instruction; only the pool excludes it.
+    """
+    m = attention_mask.copy()
+    if instruction_lens is None:
+        return m
+    if np.isscalar(instruction_lens):
+        m[:, : int(instruction_lens)] = 0
+        return m
+    for i, l in enumerate(instruction_lens):
+        m[i, : int(l)] = 0
+    return m
+
+
+def encode_core(weights, cfg, input_ids, attention_mask, pooling_method="mean", normalized=True,
+                instruction_lens=None, emulate_bf16=False):
+    """Device part of GritLM.encode (gritlm/gritlm.py:129-158) == GritLMTrainModel.encode
+    (gritlm/training/model.py:134-165): forward, instruction masking, pool, normalise."""
+    h = mistral_encode(weights, cfg, input_ids, attention_mask, emulate_bf16=emulate_bf16)
+    pm = instruction_mask(attention_mask, instruction_lens)
+    e = pooling(h, pm, pooling_method)
+    return l2_normalize(e) if normalized else e
+
+
+# ----------------------------------------------------------------------------
+# Contrastive loss  (gritlm/training/model.py)
+# ----------------------------------------------------------------------------
+def infonce(q: np.ndarray, p: np.ndarray, temperature: float):
+    """DistributedContrastiveLoss.__call__ after the gather, gritlm/training/model.py:42-47.
+
+    scores = q p^T / tau; target[i] = i * (Np // Nq); CrossEntropyLoss(mean).
+    Returns (loss, dq, dp, scores) with dq/dp the exact gradients of the loss.
+    """
+    q64, p64 = q.astype(F64), p.astype(F64)
+    nq, np_ = q.shape[0], p.shape[0]
+    g = np_ // nq
+    scores = q64 @ p64.T / temperature
+    tgt = np.arange(nq) * g
+    mx = scores.max(axis=1, keepdims=True)
+    lse = mx[:, 0] + np.log(np.exp(scores - mx).sum(axis=1))
+    loss = float(np.mean(lse - scores[np.arange(nq), tgt]))
+    soft = np.exp(scores - lse[:, None])
+    soft[np.arange(nq), tgt] -= 1.0
+    ds = soft / nq / temperature
+    dq = ds @ p64
+    dp = ds.T @ q64
+    return loss, dq.astype(F32), dp.astype(F32), scores.astype(F32)
+
+
+def gather_with_local(shards: list[np.ndarray], rank: int) -> np.ndarray:
+    """_dist_gather_tensor, gritlm/training/model.py:49-60: all_gather then torch.cat in
+    rank order; the local shard is re-inserted (it is the only one carrying grad)."""
+    return np.concatenate(shards, axis=0)
+
+
+def distributed_infonce(q_shards, p_shards, temperature, rank):
+    """What ONE rank computes with negatives_cross_device=True
+    (gritlm/training/model.py:36-47): the full global loss, gradients only for its
+    own rows (other ranks' shards are constants).  DDP then averages weight grads."""
+    q = gather_with_local(q_shards, rank); p = gather_with_local(p_shards, rank)
+    loss, dq, dp, _ = infonce(q, p, temperature)
+    bq, bp = q_shards[0].shape[0], p_shards[0].shape[0]
+    return loss, dq[rank * bq:(rank + 1) * bq], dp[rank * bp:(rank + 1) * bp]
+
+
+def pool_normalize_backward(hidden, pool_mask, method, normalized, grad_out):
+    """Analytic backward of pooling(:209-214)+normalize(:156-158) w.r.t. hidden (mean/weightedmean)."""
+    hidden = hidden.astype(F64)
+    m = pool_mask.astype(np.int64).copy()
+    if method == "weightedmean":
+        m = m * np.cumsum(m, axis=1)
+    den = m.sum(axis=1, keepdims=True).astype(F64)
+    w = m / den
+    pooled = np.einsum("bsd,bs->bd", hidden, w)
+    g = grad_out.astype(F64)
+    if normalized:
+        n = np.maximum(np.sqrt((pooled ** 2).sum(-1, keepdims=True)), 1e-12)
+        y = pooled / n
+        g = (g - y * (y * g).sum(-1, keepdims=True)) / n
+    return (w[..., None] * g[:, None, :]).astype(F32)

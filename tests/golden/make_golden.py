@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, CPU only, no network):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own Python -- gritlm.GritLM.pooling (gritlm/gritlm.py:178-218),
+the bidirectional Mistral of scripts/modeling_mistral_gritlm.py (loaded through an importlib
+package shim), GritLMTrainModel.encode / DistributedContrastiveLoss
+(gritlm/training/model.py) and the vendored GradCache -- on seeded synthetic models
+(tests/synth.py) and stores inputs + outputs as small .npz files.  The GPU box has no
+/root/reference; tests there replay these files against the oracle and the HIP path.
+"""
+import importlib.util
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "gritlm/training/GradCache/src"))
+warnings.filterwarnings("ignore")
+
+import synth  # noqa: E402
+
+
+def load_ref_mistral():
+    name = "transformers.models.mistral.modeling_mistral_gritlm"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "scripts/modeling_mistral_gritlm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+REFMOD = load_ref_mistral()
+
+
+def build_ref_model(cfg_name, seed=0, dtype=torch.float32, impl="sdpa"):
+    cfg = synth.CONFIGS[cfg_name]
+    hc = synth.hf_config(cfg)
+    hc.use_cache = False
+    hc._attn_implementation = impl
+    model = REFMOD.MistralModel(hc).eval()
+    w = synth.make_weights(cfg, seed)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary" in m or "inv_freq" in m for m in missing), missing
+    return model.to(dtype), cfg
+
+
+def ref_gritlm_shell(pooling_method, normalized=True):
+    from gritlm import GritLM
+    g = GritLM.__new__(GritLM)
+    torch.nn.Module.__init__(g)
+    g.pooling_method = pooling_method
+    g.normalized = normalized
+    return g
+
+
+@torch.no_grad()
+def gen_encoder(cfg_name, batch, seq, min_len, seed_w=0, seed_x=1234):
+    model, cfg = build_ref_model(cfg_name, seed_w)
+    ids, mask = synth.make_batch(cfg, batch, seq, seed_x, min_len)
+    tid, tmask = torch.from_numpy(ids), torch.from_numpy(mask)
+    h32 = model(input_ids=tid, attention_mask=tmask, is_causal=False)[0]
+    h_causal = model(input_ids=tid, attention_mask=tmask, is_causal=True)[0]
+    assert (h32 - h_causal).abs().max() > 1e-3, "is_causal flag is dead"
+    eager, _ = build_ref_model(cfg_name, seed_w, impl="eager")
+    he = eager(input_ids=tid, attention_mask=tmask, is_causal=False)[0]
+    print(f"  {cfg_name}: sdpa-vs-eager max diff {(h32 - he).abs().max().item():.2e}")
+    mb, _ = build_ref_model(cfg_name, seed_w, dtype=torch.bfloat16)
+    hb = mb(input_ids=tid, attention_mask=tmask, is_causal=False)[0].float()
+    out = dict(cfg_name=cfg_name, seed_w=seed_w, input_ids=ids, attention_mask=mask,
+               last_hidden_state=h32.numpy(), last_hidden_state_bf16=hb.numpy())
+    instr = np.array([0, 3, 1, 5] * ((batch + 3) // 4), dtype=np.int64)[:batch]
+    out["instruction_lens"] = instr
+    for method in ("mean", "weightedmean", "cls", "lasttoken"):
+        g = ref_gritlm_shell(method)
+        emb = g.pooling(h32, tmask.clone())
+        out[f"emb_{method}"] = torch.nn.functional.normalize(emb, dim=-1).numpy()
+        embb = g.pooling(hb.bfloat16(), tmask.clone()).float()
+        out[f"emb_{method}_bf16"] = torch.nn.functional.normalize(embb, dim=-1).numpy()
+    # GritLMTrainModel.encode with per-row instruction lens (gritlm/training/model.py:134-165)
+    from gritlm.training.model import GritLMTrainModel
+    for method in ("mean", "weightedmean"):
+        m = GritLMTrainModel.__new__(GritLMTrainModel)
+        torch.nn.Module.__init__(m)
+        wrap = torch.nn.Module(); wrap.model = model
+        m.model = wrap; m.embedding_attr = "model"; m.projection = None
+        m.normalized = True; m.pooling_method = method; m.attn = "bbcc"
+        reps = m.encode({"input_ids": tid, "attention_mask": tmask.clone(),
+                         "instruction_lens": torch.from_numpy(instr)})
+        out[f"train_reps_{method}"] = reps.numpy()
+    np.savez_compressed(os.path.join(HERE, f"encoder_{cfg_name}.npz"), **out)
+
+
+def gen_pooling():
+    rng = np.random.default_rng(7)
+    hidden = rng.standard_normal((5, 9, 24), dtype=np.float32)
+    mask = np.array([[1] * 9,
+                     [1] * 5 + [0] * 4,
+                     [0, 0, 1, 1, 1, 1, 0, 0, 0],     # zeros before the ones (instruction masked)
+                     [1] + [0] * 8,
+                     [0, 1, 0, 1, 1, 0, 1, 0, 0]], dtype=np.int64)  # holes
+    out = dict(hidden=hidden, mask=mask)
+    for method in ("mean", "weightedmean", "cls", "lasttoken"):
+        g = ref_gritlm_shell(method)
+        m = torch.from_numpy(mask.copy())
+        out[f"pool_{method}"] = g.pooling(torch.from_numpy(hidden), m).numpy()
+        out[f"mask_after_{method}"] = m.numpy()          # weightedmean mutates it (:211)
+        hb = torch.from_numpy(hidden).bfloat16()
+        out[f"pool_{method}_bf16in"] = g.pooling(hb, torch.from_numpy(mask.copy())).float().numpy()  # cls stays bf16 (:188)
+        out[f"pool_{method}_recast"] = g.pooling(hb, torch.from_numpy(mask.copy()), recast=True).float().numpy()
+    try:
+        ref_gritlm_shell("weighted_mean").pooling(torch.from_numpy(hidden), torch.from_numpy(mask.copy()))
+        raise AssertionError("expected NotImplementedError")
+    except NotImplementedError:
+        pass
+    np.savez_compressed(os.path.join(HERE, "pooling.npz"), **out)
+
+
+def gen_infonce():
+    from gritlm.training.model import DistributedContrastiveLoss
+    rng = np.random.default_rng(11)
+    out = {}
+    for tag, (nq, g, h, tau) in {"a": (8, 8, 64, 0.02), "b": (5, 2, 48, 1.0), "c": (16, 8, 256, 0.02)}.items():
+        q = rng.standard_normal((nq, h), dtype=np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        p = rng.standard_normal((nq * g, h), dtype=np.float32); p /= np.linalg.norm(p, axis=1, keepdims=True)
+        # make positives mildly aligned so the loss is not degenerate
+        p[::g] = 0.7 * p[::g] + 0.3 * q; p /= np.linalg.norm(p, axis=1, keepdims=True)
+        tq = torch.from_numpy(q).requires_grad_(); tp = torch.from_numpy(p).requires_grad_()
+        loss = DistributedContrastiveLoss(tau, False)(tq, tp)
+        loss.backward()
+        out.update({f"{tag}_q": q, f"{tag}_p": p, f"{tag}_tau": np.float32(tau), f"{tag}_loss": np.float32(loss.item()),
+                    f"{tag}_dq": tq.grad.numpy(), f"{tag}_dp": tp.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, "infonce.npz"), **out)
+
+
+def _dist_worker(rank, world, port, q, p, tau, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gritlm.training.model import DistributedContrastiveLoss
+    bq, bp = q.shape[0] // world, p.shape[0] // world
+    tq = torch.from_numpy(q[rank * bq:(rank + 1) * bq].copy()).requires_grad_()
+    tp = torch.from_numpy(p[rank * bp:(rank + 1) * bp].copy()).requires_grad_()
+    loss = DistributedContrastiveLoss(tau, True)(tq, tp)
+    loss.backward()
+    ret[rank] = (loss.item(), tq.grad.numpy(), tp.grad.numpy())
+    dist.destroy_process_group()
+
+
+def gen_infonce_dist():
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(13)
+    world, bq, g, h, tau = 2, 4, 8, 64, 0.02
+    q = rng.standard_normal((world * bq, h), dtype=np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    p = rng.standard_normal((world * bq * g, h), dtype=np.float32); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_dist_worker, args=(world, 29533, q, p, tau, ret), nprocs=world, join=True)
+    out = dict(q=q, p=p, tau=np.float32(tau), world=world)
+    for r in range(world):
+        out[f"loss_rank{r}"] = np.float32(ret[r][0]); out[f"dq_rank{r}"] = ret[r][1]; out[f"dp_rank{r}"] = ret[r][2]
+    assert abs(ret[0][0] - ret[1][0]) < 1e-6       # every rank computes the same global loss
+    np.savez_compressed(os.path.join(HERE, "infonce_dist2.npz"), **out)
+
+
+def gen_gradcache():
+    """GradCache step (grad_cache.py:244-280 driven as gradcache_trainer.py:373-400,691) vs the
+    direct forward/backward on the same batch: loss and parameter gradients."""
+    from grad_cache import GradCache
+    from gritlm.training.model import GritLMTrainModel, DistributedContrastiveLoss
+    model, cfg = build_ref_model("tiny", 0)
+    model.train()
+    m = GritLMTrainModel.__new__(GritLMTrainModel)
+    torch.nn.Module.__init__(m)
+    wrap = torch.nn.Module(); wrap.model = model
+    m.model = wrap; m.embedding_attr = "model"; m.projection = None
+    m.normalized = True; m.pooling_method = "mean"; m.attn = "bbcc"
+    m.emb_loss_fn = DistributedContrastiveLoss(0.02, False)
+    m.gen_loss_fn = None; m.gen_add_kwargs = {}
+    B, G, Sq, Sp = 4, 4, 24, 40
+    qi, qm = synth.make_batch(cfg, B, Sq, 21, min_len=8)
+    pi, pm = synth.make_batch(cfg, B * G, Sp, 22, min_len=10)
+    qd = {"input_ids": torch.from_numpy(qi), "attention_mask": torch.from_numpy(qm)}
+    pd = {"input_ids": torch.from_numpy(pi), "attention_mask": torch.from_numpy(pm)}
+    out = m(query=qd, passage=pd)
+    out.loss.backward()
+    names = ["layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight", "norm.weight",
+             "layers.0.input_layernorm.weight", "layers.1.self_attn.v_proj.weight", "embed_tokens.weight"]
+    sdp = dict(model.named_parameters())
+    res = dict(q_ids=qi, q_mask=qm, p_ids=pi, p_mask=pm, tau=np.float32(0.02), group=G,
+               loss_direct=np.float32(out.loss.item()), q_reps=out.q_reps.detach().numpy(),
+               p_reps=out.p_reps.detach().numpy())
+    for n in names:
+        res["grad_direct/" + n] = sdp[n].grad.numpy().copy()
+    res["gradnorm_direct"] = np.float32(torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters())).item())
+    model.zero_grad()
+    gc = GradCache(models=[m, m], chunk_sizes=2, loss_fn=m.emb_loss_fn, get_rep_fn=lambda x: x["q_reps"])
+    gc.model_call = (lambda self, mod, x: mod(x)).__get__(gc)
+    loss = gc(qd, pd, no_sync_except_last=False)
+    res["loss_gradcache"] = np.float32(loss.item())
+    for n in names:
+        res["grad_gradcache/" + n] = sdp[n].grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "gradcache_tiny.npz"), **res)
+    print(f"  gradcache: loss direct {out.loss.item():.6f} vs gc {loss.item():.6f}")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    print("pooling"); gen_pooling()
+    print("infonce"); gen_infonce()
+    print("infonce dist"); gen_infonce_dist()
+    print("encoder tiny"); gen_encoder("tiny", batch=4, seq=48, min_len=9)
+    print("encoder gqa"); gen_encoder("gqa", batch=3, seq=72, min_len=20)
+    print("gradcache"); gen_gradcache()
+    print("done")

@@ -1,0 +1,93 @@
+"""Deterministic synthetic models / inputs shared by the golden generator, the tests,
+``__graft_entry__.smoke`` and ``bench.py``'s cpu_baseline leg.
+
+Weights are drawn with numpy's ``default_rng`` (bit-stable across machines) and
+rounded to bf16-representable fp32, so the reference (fp32 or bf16), the oracle and
+the HIP path all see *identical* parameter values.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+CONFIGS = {
+    # head_dim is 128 everywhere: the shape of Mistral-7B (scripts/training/train_gritlm_7b.sh:54)
+    "tiny": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                 num_attention_heads=2, num_key_value_heads=1, rms_norm_eps=1e-5, rope_theta=10000.0),
+    "gqa": dict(vocab_size=384, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=10000.0),
+    # the true 7B layer shape, 2 layers (CPU baseline workload)
+    "7b-l2": dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_hidden_layers=2,
+                  num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=10000.0),
+    "7b": dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+               num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=10000.0),
+}
+
+
+def _bf16_round(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(x.shape)
+
+
+def make_weights(cfg: dict, seed: int = 0, std: float = 0.02) -> dict:
+    """HF ``MistralModel`` state_dict (fp32 numpy, bf16-representable values).
+
+    Linear/embedding ~ N(0, std^2) (HF _init_weights, scripts/modeling_mistral_gritlm.py:819-828);
+    RMSNorm weights 1 + 0.1 N(0,1) so a missing weight multiply cannot hide.
+    """
+    rng = np.random.default_rng(seed)
+    H, I, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    d = H // nh
+
+    def lin(o, i):
+        return _bf16_round(rng.standard_normal((o, i), dtype=np.float32) * std)
+
+    def nrm():
+        return _bf16_round(1.0 + 0.1 * rng.standard_normal(H, dtype=np.float32))
+
+    w = {"embed_tokens.weight": lin(V, H)}
+    for li in range(cfg["num_hidden_layers"]):
+        p = f"layers.{li}."
+        w[p + "self_attn.q_proj.weight"] = lin(nh * d, H)
+        w[p + "self_attn.k_proj.weight"] = lin(nkv * d, H)
+        w[p + "self_attn.v_proj.weight"] = lin(nkv * d, H)
+        w[p + "self_attn.o_proj.weight"] = lin(H, nh * d)
+        w[p + "mlp.gate_proj.weight"] = lin(I, H)
+        w[p + "mlp.up_proj.weight"] = lin(I, H)
+        w[p + "mlp.down_proj.weight"] = lin(H, I)
+        w[p + "input_layernorm.weight"] = nrm()
+        w[p + "post_attention_layernorm.weight"] = nrm()
+    w["norm.weight"] = nrm()
+    return w
+
+
+def make_batch(cfg: dict, batch: int, seq: int, seed: int = 1234, min_len: int | None = None):
+    """input_ids ~ U{3..V-1}, right-padded attention_mask (tokenizer padding_side='right',
+    gritlm/gritlm.py:61).  ``min_len=None`` -> all rows full length."""
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(3, cfg["vocab_size"], size=(batch, seq), dtype=np.int64)
+    mask = np.ones((batch, seq), dtype=np.int64)
+    if min_len is not None:
+        lens = rng.integers(min_len, seq + 1, size=batch)
+        lens[0] = seq
+        for i, l in enumerate(lens):
+            mask[i, l:] = 0
+            ids[i, l:] = 0
+    return ids, mask
+
+
+def hf_config(cfg: dict):
+    """transformers.MistralConfig for a synthetic config (tests that build HF model dirs)."""
+    from transformers import MistralConfig
+    c = MistralConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
+                      intermediate_size=cfg["intermediate_size"],
+                      num_hidden_layers=cfg["num_hidden_layers"],
+                      num_attention_heads=cfg["num_attention_heads"],
+                      num_key_value_heads=cfg["num_key_value_heads"],
+                      rms_norm_eps=cfg["rms_norm_eps"], max_position_embeddings=4096,
+                      sliding_window=None, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                      tie_word_embeddings=False)
+    c.rope_theta = cfg["rope_theta"]
+    return c

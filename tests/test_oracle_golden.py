@@ -1,0 +1,117 @@
+"""Pin the CPU oracle (oracle/gritlm_oracle.py) against fixtures produced by the reference's own
+Python (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import gritlm_oracle as O
+import synth
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("method", ["mean", "weightedmean", "cls", "lasttoken"])
+def test_pooling_matches_reference(golden_dir, method):
+    g = _load(golden_dir, "pooling.npz")
+    out = O.pooling(g["hidden"], g["mask"], method)
+    np.testing.assert_allclose(out, g[f"pool_{method}"], rtol=1e-5, atol=1e-6)
+    # bf16 hidden in, fp32 accumulate (gritlm/gritlm.py:212-214)
+    outb = O.pooling(O.bf16_round(g["hidden"]), g["mask"], method)
+    np.testing.assert_allclose(outb, g[f"pool_{method}_bf16in"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(O.bf16_round(outb), g[f"pool_{method}_recast"], rtol=0, atol=1e-2)
+
+
+def test_pooling_unknown_method_raises(golden_dir):
+    g = _load(golden_dir, "pooling.npz")
+    with pytest.raises(NotImplementedError):
+        O.pooling(g["hidden"], g["mask"], "weighted_mean")   # README's own typo, README.md:38
+
+
+def test_weightedmean_mask_mutation_recorded(golden_dir):
+    g = _load(golden_dir, "pooling.npz")
+    m = g["mask"]
+    np.testing.assert_array_equal(g["mask_after_weightedmean"], m * np.cumsum(m, axis=1))
+    np.testing.assert_array_equal(g["mask_after_mean"], m)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_infonce_matches_reference(golden_dir, tag):
+    g = _load(golden_dir, "infonce.npz")
+    loss, dq, dp, _ = O.infonce(g[f"{tag}_q"], g[f"{tag}_p"], float(g[f"{tag}_tau"]))
+    assert abs(loss - float(g[f"{tag}_loss"])) < 1e-4 * max(1.0, abs(loss))
+    np.testing.assert_allclose(dq, g[f"{tag}_dq"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dp, g[f"{tag}_dp"], rtol=2e-4, atol=2e-5)
+
+
+def test_distributed_infonce_matches_reference_gloo_run(golden_dir):
+    g = _load(golden_dir, "infonce_dist2.npz")
+    world = int(g["world"]); q, p, tau = g["q"], g["p"], float(g["tau"])
+    bq, bp = q.shape[0] // world, p.shape[0] // world
+    qs = [q[r * bq:(r + 1) * bq] for r in range(world)]
+    ps = [p[r * bp:(r + 1) * bp] for r in range(world)]
+    for r in range(world):
+        loss, dq, dp = O.distributed_infonce(qs, ps, tau, r)
+        assert abs(loss - float(g[f"loss_rank{r}"])) < 1e-4
+        np.testing.assert_allclose(dq, g[f"dq_rank{r}"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(dp, g[f"dp_rank{r}"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "gqa"])
+def test_encoder_matches_reference(golden_dir, cfg_name):
+    g = _load(golden_dir, f"encoder_{cfg_name}.npz")
+    cfg = synth.CONFIGS[cfg_name]
+    w = synth.make_weights(cfg, int(g["seed_w"]))
+    ids, mask = g["input_ids"], g["attention_mask"]
+    # regenerated inputs are the fixture's inputs (generator determinism)
+    h = O.mistral_encode(w, cfg, ids, mask)
+    ref = g["last_hidden_state"]
+    valid = mask.astype(bool)
+    err = np.abs(h - ref)[valid].max()
+    assert err < 2e-4, err
+    # padded query rows are computed too (mask is on keys only)
+    assert np.abs(h - ref)[~valid].max() < 2e-4 if (~valid).any() else True
+    for method in ("mean", "weightedmean", "cls", "lasttoken"):
+        e = O.l2_normalize(O.pooling(h, mask, method))
+        cos = np.sum(e * g[f"emb_{method}"], axis=1)
+        assert np.all(1 - cos < 1e-6), (method, cos)
+    for method in ("mean", "weightedmean"):
+        e = O.encode_core(w, cfg, ids, mask, method, True, g["instruction_lens"])
+        np.testing.assert_allclose(e, g[f"train_reps_{method}"], atol=2e-5)
+
+
+def test_encoder_bf16_emulation_tracks_bf16_reference(golden_dir):
+    g = _load(golden_dir, "encoder_tiny.npz")
+    cfg = synth.CONFIGS["tiny"]
+    w = synth.make_weights(cfg, int(g["seed_w"]))
+    h = O.mistral_encode(w, cfg, g["input_ids"], g["attention_mask"], emulate_bf16=True)
+    ref_b, ref_f = g["last_hidden_state_bf16"], g["last_hidden_state"]
+    valid = g["attention_mask"].astype(bool)
+    rel = lambda a, b: np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid])
+    # emulation is as close to the bf16 reference as the bf16 reference is to fp32
+    assert rel(h, ref_b) < 1.5 * rel(ref_b, ref_f) + 1e-3, (rel(h, ref_b), rel(ref_b, ref_f))
+
+
+def test_rope_tables_and_rotate_half():
+    cos, sin = O.rope_tables(8, 16, 10000.0)
+    assert cos.shape == (8, 16) and np.allclose(cos[:, :8], cos[:, 8:])
+    x = np.arange(16, dtype=np.float32)[None, None, None, :]
+    r = O.rotate_half(x)
+    assert np.array_equal(r[0, 0, 0, :8], -x[0, 0, 0, 8:]) and np.array_equal(r[0, 0, 0, 8:], x[0, 0, 0, :8])
+
+
+def test_pool_normalize_backward_finite_difference():
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal((2, 5, 6)).astype(np.float32)
+    m = np.array([[1, 1, 1, 0, 0], [0, 1, 1, 1, 1]])
+    go = rng.standard_normal((2, 6)).astype(np.float32)
+    for method in ("mean", "weightedmean"):
+        g = O.pool_normalize_backward(h, m, method, True, go)
+        f = lambda hh: float(np.sum(O.l2_normalize(O.pooling(hh, m, method)).astype(np.float64) * go))
+        eps = 1e-3
+        for idx in [(0, 1, 2), (1, 4, 5), (0, 4, 0)]:
+            hp = h.copy(); hp[idx] += eps; hm = h.copy(); hm[idx] -= eps
+            fd = (f(hp) - f(hm)) / (2 * eps)
+            assert abs(fd - g[idx]) < 2e-3, (method, idx, fd, g[idx])
