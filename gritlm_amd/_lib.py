@@ -1,0 +1,74 @@
+"""ctypes binding of libgritlm_hip.so (include/gritlm_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises.
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgritlm_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gritlm_hip.h")
+
+GRIT_OK, GRIT_E_BADARG, GRIT_E_UNSUPPORTED, GRIT_E_LAUNCH, GRIT_E_RCCL = 0, -1, -2, -3, -4
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
+POOL_MODES = {"mean": 0, "weightedmean": 1, "cls": 2, "lasttoken": 3}
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+_SIGNATURES = {
+    "grit_version": (C.c_int, []),
+    "grit_last_error_string": (C.c_char_p, []),
+    "grit_embed_gather": (_i, [_p, _p, _p, _l, _i, _l, _p]),
+    "grit_rmsnorm_fwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
+    "grit_rope_qk_inplace": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _l, _i, _p]),
+    "grit_gemm_bf16_nt": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
+    "grit_mask_pack": (_i, [_p, _p, _i, _i, _p]),
+    "grit_attn_bidir_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_pool_norm_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "grit_pool_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "grit_infonce_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "grit_transpose_bf16": (_i, [_p, _p, _l, _l, _p]),
+}
+
+_lib = None
+
+
+class GritHipError(RuntimeError):
+    pass
+
+
+def header_symbols(path: str = HEADER_PATH) -> list[str]:
+    """Every function declared in include/gritlm_hip.h (used by the ABI test)."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(grit_[a-z0-9_]+)\s*\(", src)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GritHipError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the native path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is absent -> loud
+        fn.restype = res
+        fn.argtypes = args
+    if lib.grit_version() != 1:
+        raise GritHipError(f"ABI version mismatch: library {lib.grit_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().grit_last_error_string().decode()
+        kind = {-1: "BADARG", -2: "UNSUPPORTED", -3: "LAUNCH", -4: "RCCL"}.get(rc, str(rc))
+        raise GritHipError(f"{what} failed (GRIT_E_{kind}): {msg}")

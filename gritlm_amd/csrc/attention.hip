@@ -1,0 +1,238 @@
+// Bidirectional (non-causal) flash attention forward for gfx950, GQA, head_dim 128, key-padding bitmask.
+//
+// Replaces repeat_kv + the additive [B,1,S,S] mask + F.scaled_dot_product_attention of
+// scripts/modeling_mistral_gritlm.py (:182-191, :1017-1036, :690-698).  No repeat_kv copy (the kv head is
+// index arithmetic), no mask tensor (one uint64 per 64 keys), no S x S score matrix.
+//
+// Structure: one 256-thread workgroup = 128 query rows of one (batch, head); each wave owns 32 rows.
+// KV tiles of 64 keys go HBM -> registers -> LDS (K row-major with a 16-B-slot XOR swizzle, V TRANSPOSED
+// to [d][key] with a 136-B row pitch) with the next tile's global loads in flight during the MFMAs.
+//   S^T = K Q^T     v_mfma_f32_32x32x16_bf16(A = K rows, B = Q)  -> lane (q = lane&31) holds 32 keys' scores
+//   O^T = V^T P^T   v_mfma_f32_32x32x16_bf16(A = V^T rows, B = P) -> lane (q = lane&31) holds 64 of its d's
+// Both products are "swapped" so that every softmax statistic (max, sum, rescale) is lane-local: the only
+// cross-lane traffic per tile is one shuffle with lane^32 for the row max.  The P operand needs no
+// permlane/LDS round trip: the MFMA contraction index is permuted identically on the V^T side
+// (key(kb,c,hi,j) = 32kb + 16c + 8(j>>2) + 4hi + (j&3)), which the transposed LDS image makes two
+// 8-byte reads.
+#include "common.h"
+
+namespace grit {
+
+constexpr int ATT_D = 128;
+constexpr int ATT_QB = 128;   // query rows per workgroup
+constexpr int ATT_KB = 64;    // keys per tile
+constexpr int VT_PITCH = 136; // bytes per d-row of the transposed V image (64 keys * 2 B + 8 pad)
+constexpr int K_LDS_BYTES = ATT_KB * ATT_D * 2;  // 16384
+constexpr int V_LDS_BYTES = ATT_D * VT_PITCH;    // 17408
+
+__device__ __forceinline__ uint32_t lo16(uint32_t w) { return w & 0xffffu; }
+__device__ __forceinline__ uint32_t hi16(uint32_t w) { return w >> 16; }
+
+__global__ void __launch_bounds__(256, 2)
+attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, uint16_t* __restrict__ out,
+                 float* __restrict__ lse, int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2) {
+  __shared__ __attribute__((aligned(16))) char smem[K_LDS_BYTES + V_LDS_BYTES];
+  char* k_lds = smem;
+  char* v_lds = smem + K_LDS_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (nq / nkv);
+  const int W = (S + 63) >> 6;
+  const uint64_t* bits = key_bits + (int64_t)b * W;
+
+  // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
+  int ntiles = 0;
+  for (int w = W - 1; w >= 0; --w)
+    if (bits[w] != 0) { ntiles = w + 1; break; }
+
+  const int64_t row0 = (int64_t)b * S;
+  const uint16_t* qbase = qkv + (int64_t)h * ATT_D;
+  const uint16_t* kbase = qkv + (int64_t)(nq + hk) * ATT_D;
+  const uint16_t* vbase = qkv + (int64_t)(nq + nkv + hk) * ATT_D;
+
+  const int ql = lane & 31, hi = lane >> 5;
+  const int q_row = qb * ATT_QB + wave * 32 + ql;
+  const int q_ld = q_row < S ? q_row : S - 1;
+
+  // ---- Q fragments (B operand): lane holds Q[q][16ks + 8hi .. +8]
+  bf16x8_t qf[8];
+  {
+    const uint16_t* qp = qbase + (row0 + q_ld) * qkv_stride + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+  }
+
+  // ---- staging roles
+  // K: 1024 16-B chunks per tile, 4 per thread: chunk = tid + 256*it -> row = (tid>>4) + 16*it, slot = tid&15
+  // V: 512 (key-pair, 8-d group) items, 2 per thread; inside each 32-lane half: 8 key pairs x 4 d-groups
+  const int lane32 = tid & 31, half = tid >> 5;
+  // per-thread staging constants (no arrays / lambdas: keeps the staging registers out of scratch)
+  const int k_row = tid >> 4, k_slot = tid & 15;                 // chunk it: row = k_row + 16*it
+  const int k_lds_off = k_row * 256 + ((k_slot ^ (k_row & 15)) << 4);  // (row+16it)&15 == row&15
+  const int v_kp0 = (half & 3) * 8 + (lane32 & 7), v_dg0 = (half >> 2) * 4 + (lane32 >> 3);  // it = 0: u = half
+  const int v_kp1 = v_kp0, v_dg1 = v_dg0 + 8;                                                  // it = 1: u = half + 8
+  uint4 kr0, kr1, kr2, kr3, va0, vc0, va1, vc1;
+
+#define ATT_KROW(it) ({ int key_ = key0_ + k_row + 16 * (it); key_ < S ? key_ : S - 1; })
+#define ATT_LOAD_TILE(t)                                                                                       \
+  do {                                                                                                         \
+    const int key0_ = (t) * ATT_KB;                                                                            \
+    kr0 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(0)) * qkv_stride + k_slot * 8);             \
+    kr1 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(1)) * qkv_stride + k_slot * 8);             \
+    kr2 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(2)) * qkv_stride + k_slot * 8);             \
+    kr3 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(3)) * qkv_stride + k_slot * 8);             \
+    int ka_ = key0_ + 2 * v_kp0, kc_ = ka_ + 1;                                                                \
+    ka_ = ka_ < S ? ka_ : S - 1; kc_ = kc_ < S ? kc_ : S - 1;                                                  \
+    va0 = *reinterpret_cast<const uint4*>(vbase + (row0 + ka_) * qkv_stride + v_dg0 * 8);                      \
+    vc0 = *reinterpret_cast<const uint4*>(vbase + (row0 + kc_) * qkv_stride + v_dg0 * 8);                      \
+    va1 = *reinterpret_cast<const uint4*>(vbase + (row0 + ka_) * qkv_stride + v_dg1 * 8);                      \
+    vc1 = *reinterpret_cast<const uint4*>(vbase + (row0 + kc_) * qkv_stride + v_dg1 * 8);                      \
+  } while (0)
+#define ATT_VT_STORE(a, c, kp, dg)                                                                             \
+  do {                                                                                                         \
+    uint32_t* dst_ = reinterpret_cast<uint32_t*>(v_lds + ((dg) * 8) * VT_PITCH + (kp) * 4);                    \
+    constexpr int P4 = VT_PITCH / 4;                                                                           \
+    dst_[0 * P4] = lo16((a).x) | (lo16((c).x) << 16); dst_[1 * P4] = hi16((a).x) | (hi16((c).x) << 16);        \
+    dst_[2 * P4] = lo16((a).y) | (lo16((c).y) << 16); dst_[3 * P4] = hi16((a).y) | (hi16((c).y) << 16);        \
+    dst_[4 * P4] = lo16((a).z) | (lo16((c).z) << 16); dst_[5 * P4] = hi16((a).z) | (hi16((c).z) << 16);        \
+    dst_[6 * P4] = lo16((a).w) | (lo16((c).w) << 16); dst_[7 * P4] = hi16((a).w) | (hi16((c).w) << 16);        \
+  } while (0)
+#define ATT_STORE_TILE()                                                                                       \
+  do {                                                                                                         \
+    *reinterpret_cast<uint4*>(k_lds + k_lds_off) = kr0;                                                        \
+    *reinterpret_cast<uint4*>(k_lds + k_lds_off + 16 * 256) = kr1;                                             \
+    *reinterpret_cast<uint4*>(k_lds + k_lds_off + 32 * 256) = kr2;                                             \
+    *reinterpret_cast<uint4*>(k_lds + k_lds_off + 48 * 256) = kr3;                                             \
+    ATT_VT_STORE(va0, vc0, v_kp0, v_dg0);                                                                      \
+    ATT_VT_STORE(va1, vc1, v_kp1, v_dg1);                                                                      \
+  } while (0)
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // K fragment address: row = 32kb + (lane&31), d-slot = 2ks + hi, swizzle by row&15 == lane&15
+  const int kf_row = ql * 256, kf_x = lane & 15;
+  // V^T fragment address: row d = 32db + (lane&31), keys 32kb + 16c + 4hi (+8)
+  const int vf_row = ql * VT_PITCH + hi * 8;
+
+  if (ntiles > 0) ATT_LOAD_TILE(0);
+  for (int t = 0; t < ntiles; ++t) {
+    ATT_STORE_TILE();
+    __syncthreads();
+    if (t + 1 < ntiles) ATT_LOAD_TILE(t + 1);
+
+    // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
+    f32x16_t sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + kb * 32 * 256 + kf_row + (((2 * ks + hi) ^ kf_x) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- mask + online softmax (all lane-local except one exchange with lane^32)
+    const uint64_t word = bits[t];
+    const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const uint32_t wsel = kb ? whi : wlo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kbit = (r & 3) + 8 * (r >> 2);  // key within the 32-block, minus 4*hi (already shifted)
+        const float s = ((wsel >> kbit) & 1u) ? sacc[kb][r] * scale_log2 : -INFINITY;
+        sacc[kb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8_t pb[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float p0 = __builtin_amdgcn_exp2f(sacc[kb][8 * c + 2 * jj] - m_use);
+          const float p1 = __builtin_amdgcn_exp2f(sacc[kb][8 * c + 2 * jj + 1] - m_use);
+          psum += p0 + p1;
+          pk[jj] = pack2bf(p0, p1);
+        }
+        pb[kb][c] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const char* vp = v_lds + db * 32 * VT_PITCH + vf_row + (kb * 32 + c * 16) * 2;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
+          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q_row < S) {
+    uint16_t* op = out + (row0 + q_row) * out_stride + (int64_t)h * ATT_D + 4 * hi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint2 pk = make_uint2(pack2bf(oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l),
+                                    pack2bf(oacc[db][4 * g + 2] * inv_l, oacc[db][4 * g + 3] * inv_l));
+        *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = pk;
+      }
+    if (lse != nullptr && hi == 0)
+      lse[((int64_t)b * nq + h) * S + q_row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+}
+
+}  // namespace grit
+
+using namespace grit;
+
+extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                   int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(qkv && key_bits && out, GRIT_E_BADARG, "grit_attn_bidir_fwd: null pointer");
+  GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_fwd: bad sizes");
+  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_fwd: head_dim=%d (only 128 is built)", d);
+  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_fwd: nq=%d not a multiple of nkv=%d", nq, nkv);
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 4 == 0 && out_stride >= (int64_t)nq * d,
+               GRIT_E_BADARG, "grit_attn_bidir_fwd: bad strides");
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "grit_attn_bidir_fwd: pointers must be 16-byte aligned");
+  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_fwd: grid too large");
+  const dim3 grid((unsigned)((S + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
+  hipLaunchKernelGGL(attn_bidir_fwd_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, (uint16_t*)out, lse, S,
+                     nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+  GRIT_CHECK_LAUNCH("grit_attn_bidir_fwd");
+  return GRIT_OK;
+}

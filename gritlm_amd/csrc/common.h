@@ -1,0 +1,59 @@
+// Shared device/host helpers for libgritlm_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gritlm_hip.h"
+
+namespace grit {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+void set_error(const char* fmt, ...);
+
+#define GRIT_REQUIRE(cond, code, ...)       \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::grit::set_error(__VA_ARGS__);       \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+#define GRIT_CHECK_LAUNCH(name)                                                 \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      ::grit::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return GRIT_E_LAUNCH;                                                     \
+    }                                                                           \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- bf16 <-> f32 (bit tricks; RNE like torch's .to(bfloat16)) ----
+__device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+__device__ __forceinline__ float round_bf(float f) { return __uint_as_float(f2bf(f) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace grit

@@ -1,0 +1,259 @@
+// HBM-bound pieces of the encoder forward: embedding gather, RMSNorm, RoPE, mask packing, transpose.
+// All loads/stores are 16 B per lane (8 bf16), one wave (64 lanes) covers 1 KiB contiguous.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace grit {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------- embedding gather
+// scripts/modeling_mistral_gritlm.py:994  inputs_embeds = self.embed_tokens(input_ids)
+__global__ void __launch_bounds__(256) embed_gather_k(const uint4* __restrict__ table, const int64_t* __restrict__ ids,
+                                                      uint4* __restrict__ out, int64_t T, int HC, int64_t V) {
+  const int64_t total = T * HC;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / HC;
+    const int c = (int)(i - t * HC);
+    int64_t id = ids[t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    out[i] = table[id * HC + c];
+  }
+}
+
+// ---------------------------------------------------------------- RMSNorm forward
+// scripts/modeling_mistral_gritlm.py:84-89.  One wave per row, row held in registers when H = NCH*512.
+__device__ __forceinline__ float sumsq8(const uint4& v) {
+  float s = 0.f, a;
+  a = bflo(v.x); s += a * a; a = bfhi(v.x); s += a * a;
+  a = bflo(v.y); s += a * a; a = bfhi(v.y); s += a * a;
+  a = bflo(v.z); s += a * a; a = bfhi(v.z); s += a * a;
+  a = bflo(v.w); s += a * a; a = bfhi(v.w); s += a * a;
+  return s;
+}
+__device__ __forceinline__ uint32_t norm2(uint32_t x, uint32_t w, float rs) {
+  // bf16(w * bf16(x*rs)) for both halves: the reference rounds after the normalise and after the weight
+  const float lo = bflo(w) * round_bf(bflo(x) * rs);
+  const float hi = bfhi(w) * round_bf(bfhi(x) * rs);
+  return pack2bf(lo, hi);
+}
+__device__ __forceinline__ uint4 norm8(const uint4& x, const uint4& w, float rs) {
+  uint4 o;
+  o.x = norm2(x.x, w.x, rs); o.y = norm2(x.y, w.y, rs); o.z = norm2(x.z, w.z, rs); o.w = norm2(x.w, w.w, rs);
+  return o;
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_fwd_reg_k(const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                         uint4* __restrict__ y, int64_t T, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const int HC = H >> 3;
+  const uint4* xr = x + row * HC;
+  uint4 v[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) v[c] = xr[c * 64 + lane];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) ss += sumsq8(v[c]);
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)H + eps);
+  uint4* yr = y + row * HC;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) yr[c * 64 + lane] = norm8(v[c], w[c * 64 + lane], rs);
+}
+
+__global__ void __launch_bounds__(256) rmsnorm_fwd_generic_k(const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                             uint4* __restrict__ y, int64_t T, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const int HC = H >> 3;
+  const uint4* xr = x + row * HC;
+  float ss = 0.f;
+  for (int c = lane; c < HC; c += 64) ss += sumsq8(xr[c]);
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)H + eps);
+  uint4* yr = y + row * HC;
+  for (int c = lane; c < HC; c += 64) yr[c] = norm8(xr[c], w[c], rs);
+}
+
+// ---------------------------------------------------------------- RoPE (in place on q,k of the fused qkv rows)
+// scripts/modeling_mistral_gritlm.py:138-163: x' = x*cos + rotate_half(x)*sin, fp32 math, one rounding.
+__device__ __forceinline__ void rot2(uint32_t a, uint32_t b, float c0, float s0, float c1, float s1, uint32_t& oa,
+                                     uint32_t& ob) {
+  const float a0 = bflo(a), a1 = bfhi(a), b0 = bflo(b), b1 = bfhi(b);
+  oa = pack2bf(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
+  ob = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+}
+__global__ void __launch_bounds__(256) rope_k(uint16_t* __restrict__ qkv, const float4* __restrict__ cos_tab,
+                                              const float4* __restrict__ sin_tab, int64_t T, int S, int nheads, int d,
+                                              int64_t row_stride, float sgn) {
+  const int jc_n = d >> 4;  // 16-byte chunks per half head
+  const int64_t total = T * nheads * jc_n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int jc = (int)(i % jc_n);
+    const int64_t r = i / jc_n;
+    const int head = (int)(r % nheads);
+    const int64_t t = r / nheads;
+    const int pos = (int)(t % S);
+    uint16_t* base = qkv + t * row_stride + (int64_t)head * d + jc * 8;
+    uint4 x1 = *reinterpret_cast<uint4*>(base);
+    uint4 x2 = *reinterpret_cast<uint4*>(base + (d >> 1));
+    const int64_t tb = ((int64_t)pos * (d >> 1) + jc * 8) >> 2;
+    const float4 c0 = cos_tab[tb], c1 = cos_tab[tb + 1];
+    float4 s0 = sin_tab[tb], s1 = sin_tab[tb + 1];
+    s0.x *= sgn; s0.y *= sgn; s0.z *= sgn; s0.w *= sgn; s1.x *= sgn; s1.y *= sgn; s1.z *= sgn; s1.w *= sgn;
+    uint4 o1, o2;
+    rot2(x1.x, x2.x, c0.x, s0.x, c0.y, s0.y, o1.x, o2.x);
+    rot2(x1.y, x2.y, c0.z, s0.z, c0.w, s0.w, o1.y, o2.y);
+    rot2(x1.z, x2.z, c1.x, s1.x, c1.y, s1.y, o1.z, o2.z);
+    rot2(x1.w, x2.w, c1.z, s1.z, c1.w, s1.w, o1.w, o2.w);
+    *reinterpret_cast<uint4*>(base) = o1;
+    *reinterpret_cast<uint4*>(base + (d >> 1)) = o2;
+  }
+}
+
+// ---------------------------------------------------------------- key-padding bitmask
+__global__ void __launch_bounds__(256) mask_pack_k(const int64_t* __restrict__ mask, uint64_t* __restrict__ bits, int B,
+                                                   int S, int W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (word >= (int64_t)B * W) return;
+  const int b = (int)(word / W), wi = (int)(word % W);
+  const int s = wi * 64 + lane;
+  const bool on = (s < S) && (mask[(int64_t)b * S + s] != 0);
+  const uint64_t m = __ballot(on);
+  if (lane == 0) bits[word] = m;
+}
+
+// ---------------------------------------------------------------- bf16 transpose [R,C] -> [C,R]
+__global__ void __launch_bounds__(256) transpose_k(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t R,
+                                                   int64_t C) {
+  __shared__ uint16_t tile[64][72];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 256;  // 512 chunks of 8
+    const int r = idx >> 3, cc = (idx & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < R && c0 + cc < C) v = *reinterpret_cast<const uint4*>(in + (r0 + r) * C + c0 + cc);
+    *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 256;
+    const int c = idx >> 3, rr = (idx & 7) * 8;  // output row = input column c, 8 consecutive input rows
+    if (c0 + c < C && r0 + rr < R) {
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[rr + 2 * k][c] | ((uint32_t)tile[rr + 2 * k + 1][c] << 16);
+      *reinterpret_cast<uint4*>(out + (c0 + c) * R + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+static inline int grid_for(int64_t items, int threads) {
+  int64_t g = (items + threads - 1) / threads;
+  const int64_t cap = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace grit
+
+using namespace grit;
+
+extern "C" {
+
+int grit_version(void) { return GRIT_ABI_VERSION; }
+const char* grit_last_error_string(void) { return g_err; }
+
+int grit_embed_gather(const void* table, const int64_t* ids, void* out, int64_t T, int H, int64_t V, void* stream) {
+  GRIT_REQUIRE(table && ids && out, GRIT_E_BADARG, "grit_embed_gather: null pointer");
+  GRIT_REQUIRE(T >= 0 && H > 0 && V > 0, GRIT_E_BADARG, "grit_embed_gather: bad sizes T=%lld H=%d V=%lld", (long long)T, H, (long long)V);
+  GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_embed_gather: H=%d must be a multiple of 8", H);
+  GRIT_REQUIRE(aligned16(table) && aligned16(out), GRIT_E_BADARG, "grit_embed_gather: pointers must be 16-byte aligned");
+  if (T == 0) return GRIT_OK;
+  const int HC = H / 8;
+  hipLaunchKernelGGL(embed_gather_k, dim3(grid_for(T * HC, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)table, ids,
+                     (uint4*)out, T, HC, V);
+  GRIT_CHECK_LAUNCH("grit_embed_gather");
+  return GRIT_OK;
+}
+
+int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, float eps, void* stream) {
+  GRIT_REQUIRE(x && w && y, GRIT_E_BADARG, "grit_rmsnorm_fwd: null pointer");
+  GRIT_REQUIRE(T >= 0 && H > 0, GRIT_E_BADARG, "grit_rmsnorm_fwd: bad sizes");
+  GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_rmsnorm_fwd: H=%d must be a multiple of 8", H);
+  GRIT_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), GRIT_E_BADARG, "grit_rmsnorm_fwd: pointers must be 16-byte aligned");
+  if (T == 0) return GRIT_OK;
+  const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const uint4 *xp = (const uint4*)x, *wp = (const uint4*)w;
+  uint4* yp = (uint4*)y;
+  if (H % 512 == 0 && H / 512 <= 16) {
+    switch (H / 512) {
+      case 1: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<1>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+      case 2: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<2>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+      case 4: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<4>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+      case 8: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<8>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+      case 16: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<16>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+      default: hipLaunchKernelGGL(rmsnorm_fwd_generic_k, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+    }
+  } else {
+    hipLaunchKernelGGL(rmsnorm_fwd_generic_k, grid, block, 0, st, xp, wp, yp, T, H, eps);
+  }
+  GRIT_CHECK_LAUNCH("grit_rmsnorm_fwd");
+  return GRIT_OK;
+}
+
+int grit_rope_qk_inplace(void* qkv, const float* cos_tab, const float* sin_tab, int64_t T, int S, int nq, int nkv, int d,
+                         int64_t row_stride, int inverse, void* stream) {
+  GRIT_REQUIRE(qkv && cos_tab && sin_tab, GRIT_E_BADARG, "grit_rope_qk_inplace: null pointer");
+  GRIT_REQUIRE(T >= 0 && S > 0 && nq > 0 && nkv >= 0 && d > 0, GRIT_E_BADARG, "grit_rope_qk_inplace: bad sizes");
+  GRIT_REQUIRE(d % 16 == 0, GRIT_E_UNSUPPORTED, "grit_rope_qk_inplace: head_dim=%d must be a multiple of 16", d);
+  GRIT_REQUIRE(row_stride % 8 == 0 && row_stride >= (int64_t)(nq + nkv) * d, GRIT_E_BADARG, "grit_rope_qk_inplace: bad row_stride");
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(cos_tab) && aligned16(sin_tab), GRIT_E_BADARG, "grit_rope_qk_inplace: pointers must be 16-byte aligned");
+  if (T == 0) return GRIT_OK;
+  const int nheads = nq + nkv;
+  const int64_t items = T * nheads * (d / 16);
+  hipLaunchKernelGGL(rope_k, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv,
+                     (const float4*)cos_tab, (const float4*)sin_tab, T, S, nheads, d, row_stride, inverse ? -1.0f : 1.0f);
+  GRIT_CHECK_LAUNCH("grit_rope_qk_inplace");
+  return GRIT_OK;
+}
+
+int grit_mask_pack(const int64_t* mask, uint64_t* bits, int B, int S, void* stream) {
+  GRIT_REQUIRE(mask && bits, GRIT_E_BADARG, "grit_mask_pack: null pointer");
+  GRIT_REQUIRE(B > 0 && S > 0, GRIT_E_BADARG, "grit_mask_pack: bad sizes");
+  const int W = (S + 63) / 64;
+  const int64_t words = (int64_t)B * W;
+  hipLaunchKernelGGL(mask_pack_k, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mask, bits, B, S, W);
+  GRIT_CHECK_LAUNCH("grit_mask_pack");
+  return GRIT_OK;
+}
+
+int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, void* stream) {
+  GRIT_REQUIRE(in && out, GRIT_E_BADARG, "grit_transpose_bf16: null pointer");
+  GRIT_REQUIRE(R > 0 && C > 0, GRIT_E_BADARG, "grit_transpose_bf16: bad sizes");
+  GRIT_REQUIRE(R % 8 == 0 && C % 8 == 0, GRIT_E_UNSUPPORTED, "grit_transpose_bf16: R=%lld C=%lld must be multiples of 8", (long long)R, (long long)C);
+  GRIT_REQUIRE(aligned16(in) && aligned16(out), GRIT_E_BADARG, "grit_transpose_bf16: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(transpose_k, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)in, (uint16_t*)out, R, C);
+  GRIT_CHECK_LAUNCH("grit_transpose_bf16");
+  return GRIT_OK;
+}
+
+}  // extern "C"

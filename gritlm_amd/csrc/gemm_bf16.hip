@@ -1,0 +1,199 @@
+// bf16 "NT" GEMM on MFMA for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  (nn.Linear without bias), fp32 accumulate.
+//
+// Replaces q/k/v/o_proj and the three MLP projections of scripts/modeling_mistral_gritlm.py
+// (:225-228, :655-657, :703, :177-178) -- 98 % of the encoder FLOPs.
+//
+// Structure (CDNA4-first, see DESIGN.md "GEMM"):
+//   * 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave),
+//     BK = 64, v_mfma_f32_16x16x32_bf16, 32 accumulator fragments (128 fp32 regs) per wave;
+//   * both operands are K-contiguous, staged HBM->LDS by direct LDS-DMA (global_load_lds, 16 B/lane,
+//     1 KiB per wave-instruction), two 64 KiB LDS stages, one barrier per K-tile;
+//   * LDS image is lane-linear; the bank-conflict swizzle (16-B slot ^= (row>>1)&7, two 128-B rows =
+//     one 256-B bank row) is applied to the per-lane SOURCE address and to the ds_read_b128 address;
+//   * the W fragment is the MFMA "A" operand and the activation fragment the "B" operand, so each lane
+//     ends up with 4 CONSECUTIVE output columns of one row -> 8-byte packed bf16 stores and a
+//     register-local SwiGLU (gate/up weight rows interleaved in blocks of 16);
+//   * XCD-aware block remap (block b runs on XCD b % 8): every XCD walks a contiguous range of tiles,
+//     8 m-tiles x 4 n-tiles in flight per XCD share A/W panels in that XCD's 4 MiB L2.
+#include "common.h"
+
+namespace grit {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
+constexpr int A_BYTES = BM * BK * 2;             // 32 KiB
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+template <int EPI>
+__global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                      uint16_t* C, const uint16_t* Rsd, int64_t M,
+                                                      int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
+                                                      int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- XCD-aware tile id (bijective remap, guide T1) + grouped ordering (8 m-tiles per group)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GM = 8;
+  const int group_sz = GM * tiles_n;
+  const int grp = wg / group_sz, first_m = grp * GM;
+  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int in_grp = wg - grp * group_sz;
+  const int tm = first_m + in_grp % gm, tn = in_grp / gm;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  // ---- staging addresses: wave `wid` fills chunks wid*4..wid*4+3 (8 rows x 128 B each) of A and of W
+  const int srow = lane >> 3;                                  // row inside the 8-row chunk
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = (wid * 4 + c) * 8 + srow;                    // tile row 0..255
+    const int slot = (lane & 7) ^ ((r >> 1) & 7);              // logical 16-B slot held by this physical slot
+    int64_t gm_row = m0 + r; if (gm_row > M - 1) gm_row = M - 1;
+    int gn_row = n0 + r; if (gn_row > N - 1) gn_row = N - 1;
+    a_src[c] = A + gm_row * lda + slot * 8;
+    w_src[c] = W + (int64_t)gn_row * ldw + slot * 8;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE_BYTES + wid * 4096;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[c] + (int64_t)kt * BK), (lptr_t)(base + c * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)kt * BK), (lptr_t)(base + A_BYTES + c * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside a stage); swizzle term is lane-constant because every
+  //      fragment starts at a multiple of 16 rows: (row>>1)&7 == (lane>>1)&7
+  const int frow = lane & 15, kq = lane >> 4, swz = (lane >> 1) & 7;
+  const int a_off = (wr * 128 + frow) * 128;            // + i*2048
+  const int w_off = A_BYTES + (wc * 64 + frow) * 128;   // + j*2048
+  const int s_off0 = ((kq) ^ swz) << 4, s_off1 = ((4 + kq) ^ swz) << 4;
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  stage(0, 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ks ? s_off1 : s_off0;
+      bf16x8_t wf[4], xf[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sb + w_off + j * 2048 + so);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(sb + a_off + i * 2048 + so);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
+  const int64_t mrow = m0 + wr * 128 + frow;
+  const int ncol = n0 + wc * 64 + kq * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t m = mrow + i * 16;
+    if (m >= M) continue;
+    if constexpr (EPI == GRIT_EPI_SWIGLU) {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int nb = n0 + wc * 64 + j * 16;  // multiple of 32: gate block j, up block j+1
+        if (nb >= N) continue;
+        const f32x4_t g = acc[i][j], u = acc[i][j + 1];
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = round_bf(silu_f(round_bf(g[r]))) * round_bf(u[r]);
+        uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        *reinterpret_cast<uint2*>(C + m * ldc + (nb >> 1) + kq * 4) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = ncol + j * 16;
+        if (n >= N) continue;
+        f32x4_t v = acc[i][j];
+        if constexpr (EPI == GRIT_EPI_RESIDUAL) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(Rsd + m * ldr + n);
+          // the reference rounds the Linear output to bf16 before the residual add (:769,:775)
+          v[0] = round_bf(v[0]) + bflo(rv.x); v[1] = round_bf(v[1]) + bfhi(rv.x);
+          v[2] = round_bf(v[2]) + bflo(rv.y); v[3] = round_bf(v[3]) + bfhi(rv.y);
+        }
+        uint2 pk = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        *reinterpret_cast<uint2*>(C + m * ldc + n) = pk;
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch_gemm(const void* A, const void* W, void* C, const void* R, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                       int64_t ldc, int64_t ldr, hipStream_t st) {
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
+  static bool attr_set = false;  // idempotent; benign race
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_nt_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A,
+                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n);
+  GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt");
+  return GRIT_OK;
+}
+
+}  // namespace grit
+
+using namespace grit;
+
+extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                                 int64_t ldc, int epilogue, const void* residual, int64_t ldr, void* stream) {
+  GRIT_REQUIRE(A && W && C, GRIT_E_BADARG, "grit_gemm_bf16_nt: null pointer");
+  GRIT_REQUIRE(M >= 0 && N > 0 && K > 0, GRIT_E_BADARG, "grit_gemm_bf16_nt: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+  GRIT_REQUIRE(K % 64 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: K=%d must be a multiple of 64", K);
+  GRIT_REQUIRE(N % 16 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: N=%d must be a multiple of 16", N);
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && lda >= K && ldw >= K, GRIT_E_BADARG,
+               "grit_gemm_bf16_nt: bad leading dimensions lda=%lld ldw=%lld ldc=%lld", (long long)lda, (long long)ldw, (long long)ldc);
+  GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C), GRIT_E_BADARG, "grit_gemm_bf16_nt: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: too many tiles");
+  if (M == 0) return GRIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case GRIT_EPI_STORE:
+      GRIT_REQUIRE(ldc >= N, GRIT_E_BADARG, "grit_gemm_bf16_nt: ldc < N");
+      return launch_gemm<GRIT_EPI_STORE>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    case GRIT_EPI_RESIDUAL:
+      GRIT_REQUIRE(residual && ldr % 4 == 0 && ldr >= N && ldc >= N && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_bf16_nt: RESIDUAL epilogue needs residual with ldr >= N");
+      return launch_gemm<GRIT_EPI_RESIDUAL>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
+    case GRIT_EPI_SWIGLU:
+      GRIT_REQUIRE(N % 32 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: SWIGLU epilogue needs N %% 32 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    default:
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt: unknown epilogue %d", epilogue);
+  }
+  return GRIT_OK;
+}

@@ -1,0 +1,159 @@
+// In-batch InfoNCE: temperature-scaled similarity matrix + cross-entropy, forward and backward.
+//
+// Replaces DistributedContrastiveLoss.__call__/compute_similarity (gritlm/training/model.py:36-47, :62-64)
+// after the cross-rank gather.  The representations stay fp32 (the reference pools/normalises in fp32,
+// gritlm/gritlm.py:212-214) and the products run on the exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32,
+// bitwise an fmaf chain): at tau = 0.02 a cosine error of 2e-5 already moves a logit by 1e-3, so a
+// bf16-input MFMA would miss the 1e-3 loss tolerance (SURVEY.md §7 hard part 3).
+//
+//   1. scores = (1/tau) q p^T                       strided f32 MFMA GEMM
+//   2. per row: lse, loss += (lse - s[i, i*G])/Nq;  scores <- (softmax - onehot) / (Nq tau)   (in place)
+//   3. dq = dS[q_off.., :] p ,  dp = dS[:, p_off..]^T q   for the caller's own rows only -- the rows
+//      that carry grad after `_dist_gather_tensor` re-inserts the local shard (:49-60).
+#include "common.h"
+
+namespace grit {
+
+constexpr int FB = 128;   // tile M = N
+constexpr int FK = 16;    // tile K
+constexpr int FP = FB + 4;
+
+// C[M,N] = alpha * sum_k A(m,k) B(k,n);  A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
+__global__ void __launch_bounds__(256) gemm_f32_strided_k(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                          int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+                                                          int64_t ldc, float alpha) {
+  __shared__ float As[FK][FP];
+  __shared__ float Bs[FK][FP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * FB, n0 = blockIdx.x * FB;
+  const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += FK) {
+#pragma unroll
+    for (int it = 0; it < (FB * FK) / 256; ++it) {
+      const int idx = tid + 256 * it;
+      {
+        const int k = a_kfast ? (idx & (FK - 1)) : (idx / FB);
+        const int m = a_kfast ? (idx / FK) : (idx & (FB - 1));
+        float v = 0.f;
+        if (m0 + m < M && k0 + k < K) v = A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak];
+        As[k][m] = v;
+      }
+      {
+        const int k = b_kfast ? (idx & (FK - 1)) : (idx / FB);
+        const int n = b_kfast ? (idx / FK) : (idx & (FB - 1));
+        float v = 0.f;
+        if (n0 + n < N && k0 + k < K) v = Bm[(int64_t)(k0 + k) * sbk + (int64_t)(n0 + n) * sbn];
+        Bs[k][n] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < FK / 2; ++ks) {
+      const int kk = ks * 2 + (lane >> 5);
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kk][wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kk][wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[row i][col j]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && n < N) C[(int64_t)m * ldc + n] = alpha * acc[i][j][r];
+      }
+    }
+}
+
+// one workgroup per query row: logsumexp, loss contribution, then d loss / d raw-scores in place
+__global__ void __launch_bounds__(256) infonce_ce_k(float* __restrict__ scores, float* __restrict__ loss, int Nq, int Np, int group,
+                                                    float inv_temperature, int want_grad) {
+  __shared__ float red[8];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* row = scores + (int64_t)i * Np;
+  float mx = -INFINITY;
+  for (int j = tid; j < Np; j += 256) mx = fmaxf(mx, row[j]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < Np; j += 256) sum += expf(row[j] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  const float lse = mx + logf(sum);
+  const int tgt = i * group;
+  if (tid == 0) atomicAdd(loss, (lse - row[tgt]) / (float)Nq);
+  if (!want_grad) return;
+  __syncthreads();  // row[tgt] read above before anyone overwrites it
+  const float sc = inv_temperature / (float)Nq;
+  for (int j = tid; j < Np; j += 256) {
+    const float p = expf(row[j] - lse);
+    row[j] = (p - (j == tgt ? 1.f : 0.f)) * sc;
+  }
+}
+
+static int launch_f32_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk,
+                           int64_t sbn, int64_t ldc, float alpha, hipStream_t st) {
+  dim3 grid((unsigned)((N + FB - 1) / FB), (unsigned)((M + FB - 1) / FB));
+  hipLaunchKernelGGL(gemm_f32_strided_k, grid, dim3(256), 0, st, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha);
+  GRIT_CHECK_LAUNCH("grit_infonce: f32 gemm");
+  return GRIT_OK;
+}
+
+}  // namespace grit
+
+using namespace grit;
+
+extern "C" int grit_infonce_fwd_bwd(const float* q, const float* p, float inv_temperature, float* scores, float* loss, float* dq,
+                                    float* dp, int Nq, int Np, int H, int q_off, int nq_loc, int p_off, int np_loc, void* stream) {
+  GRIT_REQUIRE(q && p && scores && loss, GRIT_E_BADARG, "grit_infonce_fwd_bwd: null pointer");
+  GRIT_REQUIRE(Nq > 0 && Np > 0 && H > 0, GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad sizes");
+  GRIT_REQUIRE(Np % Nq == 0, GRIT_E_BADARG, "grit_infonce_fwd_bwd: Np=%d is not a multiple of Nq=%d (target = i * Np/Nq)", Np, Nq);
+  GRIT_REQUIRE((dq == nullptr) || (q_off >= 0 && nq_loc > 0 && q_off + nq_loc <= Nq), GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad q range");
+  GRIT_REQUIRE((dp == nullptr) || (p_off >= 0 && np_loc > 0 && p_off + np_loc <= Np), GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad p range");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) {
+    set_error("grit_infonce_fwd_bwd: hipMemsetAsync failed");
+    return GRIT_E_LAUNCH;
+  }
+  // scores[i,j] = inv_t * sum_h q[i,h] p[j,h]
+  int rc = launch_f32_gemm(q, p, scores, Nq, Np, H, H, 1, 1, H, Np, inv_temperature, st);
+  if (rc) return rc;
+  const int want_grad = (dq != nullptr) || (dp != nullptr);
+  hipLaunchKernelGGL(infonce_ce_k, dim3(Nq), dim3(256), 0, st, scores, loss, Nq, Np, Np / Nq, inv_temperature, want_grad);
+  GRIT_CHECK_LAUNCH("grit_infonce_fwd_bwd: ce");
+  if (dq) {  // dq[m,h] = sum_j dS[q_off+m, j] p[j,h]
+    rc = launch_f32_gemm(scores + (int64_t)q_off * Np, p, dq, nq_loc, H, Np, Np, 1, H, 1, H, 1.0f, st);
+    if (rc) return rc;
+  }
+  if (dp) {  // dp[m,h] = sum_i dS[i, p_off+m] q[i,h]
+    rc = launch_f32_gemm(scores + p_off, q, dp, np_loc, H, Nq, 1, Np, H, 1, H, 1.0f, st);
+    if (rc) return rc;
+  }
+  return GRIT_OK;
+}

@@ -1,0 +1,210 @@
+"""Native bidirectional Mistral encoder: the host-side driver of the HIP kernels.
+
+Replaces ``MistralModel.forward(..., is_causal=False)`` of scripts/modeling_mistral_gritlm.py:936-1096 for
+the embedding path.  Per layer (reference: 3+1+3 nn.Linear GEMMs, ~20 elementwise kernels, repeat_kv,
+a [B,1,S,S] mask) it launches 8 kernels:
+
+    rmsnorm -> fused QKV GEMM -> RoPE (in place) -> flash attention (GQA, key bitmask)
+            -> o_proj GEMM + residual epilogue -> rmsnorm -> gate|up GEMM + SwiGLU epilogue
+            -> down GEMM + residual epilogue
+
+Weights are repacked once (QKV concatenated, gate/up rows interleaved in blocks of 16 so that the SwiGLU
+epilogue is register-local); activations live in a per-token-count workspace sized for 288 GB HBM.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from ._lib import EPI_RESIDUAL, EPI_SWIGLU, GritHipError
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class EncoderConfig:
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    vocab_size: int
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    head_dim: int | None = None
+
+    def __post_init__(self):
+        if self.head_dim is None:
+            self.head_dim = self.hidden_size // self.num_attention_heads
+
+    @classmethod
+    def from_hf(cls, hf):
+        theta = getattr(hf, "rope_theta", None)
+        if theta is None:  # transformers >= 5 moved it
+            rp = getattr(hf, "rope_parameters", None) or {}
+            theta = rp.get("rope_theta", 10000.0)
+        return cls(hf.hidden_size, hf.intermediate_size, hf.num_hidden_layers, hf.num_attention_heads,
+                   hf.num_key_value_heads, hf.vocab_size, hf.rms_norm_eps, float(theta), getattr(hf, "head_dim", None))
+
+    @classmethod
+    def from_dict(cls, d):
+        keys = cls.__dataclass_fields__.keys()
+        return cls(**{k: v for k, v in d.items() if k in keys})
+
+    def check_supported(self):
+        c = self
+        if c.head_dim != 128:
+            raise GritHipError(f"native encoder: head_dim={c.head_dim}; only 128 (Mistral-7B shape) is built")
+        if c.hidden_size % 64 or c.intermediate_size % 64 or (c.num_attention_heads * c.head_dim) % 64:
+            raise GritHipError("native encoder: hidden/intermediate sizes must be multiples of 64")
+        if c.num_attention_heads % c.num_key_value_heads:
+            raise GritHipError("native encoder: num_attention_heads must be a multiple of num_key_value_heads")
+
+
+def swiglu_interleave(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I,H],[I,H] -> [2I,H] with rows [16b,16b+16) of gate followed by the same rows of up (GRIT_EPI_SWIGLU)."""
+    I, H = gate.shape
+    assert I % 16 == 0
+    return torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], dim=1).reshape(2 * I, H).contiguous()
+
+
+def rope_tables(seq_len: int, head_dim: int, theta: float, round_bf16: bool, device) -> tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [S, d/2] fp32, built like MistralRotaryEmbedding (:93-126); the reference casts its tables to
+    the model dtype (:124-125), reproduced with ``round_bf16``."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.outer(torch.arange(seq_len, dtype=torch.float32), inv_freq)
+    cos, sin = freqs.cos(), freqs.sin()
+    if round_bf16:
+        cos, sin = cos.to(BF16).float(), sin.to(BF16).float()
+    return cos.contiguous().to(device), sin.contiguous().to(device)
+
+
+class _Layer:
+    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2")
+
+
+class MistralEncoderEngine:
+    """Forward-only native engine (inference / GradCache pass 1)."""
+
+    def __init__(self, cfg: EncoderConfig, device="cuda"):
+        cfg.check_supported()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.layers: list[_Layer] = []
+        self.embed = None
+        self.norm = None
+        self._ws = {}
+        self._rope = {}
+        self.rope_bf16 = True
+
+    # ------------------------------------------------------------------ weights
+    @classmethod
+    def from_state_dict(cls, cfg: EncoderConfig, sd: dict, device="cuda", prefix: str = ""):
+        """``sd``: HF MistralModel names (embed_tokens.weight, layers.N.self_attn.q_proj.weight, ...), any float dtype."""
+        eng = cls(cfg, device)
+        g = lambda k: sd[prefix + k].detach().to(device=eng.device, dtype=BF16)
+        eng.embed = g("embed_tokens.weight").contiguous()
+        for i in range(cfg.num_hidden_layers):
+            p = f"layers.{i}."
+            L = _Layer()
+            L.wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                g(p + "self_attn.v_proj.weight")], dim=0).contiguous()
+            L.wo = g(p + "self_attn.o_proj.weight").contiguous()
+            L.wgu = swiglu_interleave(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))
+            L.wdown = g(p + "mlp.down_proj.weight").contiguous()
+            L.ln1 = g(p + "input_layernorm.weight").contiguous()
+            L.ln2 = g(p + "post_attention_layernorm.weight").contiguous()
+            eng.layers.append(L)
+        eng.norm = g("norm.weight").contiguous()
+        return eng
+
+    @classmethod
+    def random_init(cls, cfg: EncoderConfig, device="cuda", seed: int = 0, std: float = 0.02):
+        """Random weights of the architecture, generated on the device (bench: no checkpoints offline)."""
+        eng = cls(cfg, device)
+        gen = torch.Generator(device=eng.device).manual_seed(seed)
+        H, I, d = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+        nq, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+
+        def lin(o, i):
+            return (torch.randn((o, i), generator=gen, device=eng.device, dtype=torch.float32) * std).to(BF16)
+
+        def nrm():
+            return (1.0 + 0.1 * torch.randn((H,), generator=gen, device=eng.device, dtype=torch.float32)).to(BF16)
+
+        eng.embed = lin(cfg.vocab_size, H)
+        for _ in range(cfg.num_hidden_layers):
+            L = _Layer()
+            L.wqkv = lin((nq + 2 * nkv) * d, H)
+            L.wo = lin(H, nq * d)
+            L.wgu = lin(2 * I, H)          # already "interleaved": random rows
+            L.wdown = lin(H, I)
+            L.ln1, L.ln2 = nrm(), nrm()
+            eng.layers.append(L)
+        eng.norm = nrm()
+        return eng
+
+    # ------------------------------------------------------------------ buffers
+    def _workspace(self, T: int):
+        ws = self._ws.get(T)
+        if ws is None:
+            c, dev = self.cfg, self.device
+            qkv_w = (c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim
+            mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
+            ws = dict(h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim),
+                      act=mk(c.intermediate_size))
+            if len(self._ws) >= 4:           # a few shapes at most (query / passage lengths)
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[T] = ws
+        return ws
+
+    def _rope_tables(self, S: int):
+        t = self._rope.get(S)
+        if t is None:
+            t = rope_tables(S, self.cfg.head_dim, self.cfg.rope_theta, self.rope_bf16, self.device)
+            self._rope[S] = t
+        return t
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None = None, borrow: bool = False) -> torch.Tensor:
+        """last_hidden_state [B,S,H] bf16 (after the final RMSNorm), is_causal=False semantics.
+
+        ``borrow=True`` returns a view of the engine's workspace (valid until the next forward)."""
+        c = self.cfg
+        B, S = input_ids.shape
+        T = B * S
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
+        if attention_mask is None:
+            attention_mask = torch.ones((B, S), dtype=torch.int64, device=self.device)
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        ws = self._workspace(T)
+        h, x, qkv, ctx, act = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["act"]
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        cos, sin = self._rope_tables(S)
+        bits = ops.mask_pack(mask)
+        ops.embed_gather(self.embed, ids, out=h)
+        for L in self.layers:
+            ops.rmsnorm(h, L.ln1, eps, out=x)
+            ops.gemm_nt(x, L.wqkv, out=qkv)
+            ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
+            ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx)
+            ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.rmsnorm(h, L.ln2, eps, out=x)
+            ops.gemm_nt(x, L.wgu, out=act, epilogue=EPI_SWIGLU)
+            ops.gemm_nt(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+        ops.rmsnorm(h, self.norm, eps, out=x)
+        out = x.view(B, S, c.hidden_size)
+        return out if borrow else out.clone()
+
+    __call__ = forward
+
+    def flops_per_token(self, S: int) -> float:
+        """Algorithmic forward FLOPs per token: projections + MLP + attention core."""
+        c = self
+        H, I, L = self.cfg.hidden_size, self.cfg.intermediate_size, self.cfg.num_hidden_layers
+        hkv = self.cfg.num_key_value_heads * self.cfg.head_dim
+        hq = self.cfg.num_attention_heads * self.cfg.head_dim
+        return 2.0 * L * (H * (hq + 2 * hkv) + hq * H + 3 * H * I) + 4.0 * L * S * hq

@@ -1,0 +1,139 @@
+"""Thin torch-tensor -> C-ABI adapters.  PyTorch is plumbing here: it owns device memory and streams;
+all arithmetic happens in libgritlm_hip.so.  Every function launches on torch's current HIP stream."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, POOL_MODES, check
+
+BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.GritHipError(f"{name}: tensor must live on the GPU (got {t.device}); the native path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def embed_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    V, H = table.shape
+    T = ids.numel()
+    if out is None:
+        out = torch.empty((T, H), dtype=BF16, device=table.device)
+    check(_lib.load().grit_embed_gather(_chk(table, BF16, "table"), _chk(ids, I64, "ids"), _chk(out, BF16, "out"), T, H, V, _stream()),
+          "grit_embed_gather")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    H = x.shape[-1]
+    T = x.numel() // H
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().grit_rmsnorm_fwd(_chk(x, BF16, "x"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), T, H, float(eps), _stream()),
+          "grit_rmsnorm_fwd")
+    return out
+
+
+def rope_qk_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, nq: int, nkv: int, d: int, inverse: bool = False):
+    T, stride = qkv.shape
+    check(_lib.load().grit_rope_qk_inplace(_chk(qkv, BF16, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"), T, S, nq, nkv, d,
+                                           stride, int(inverse), _stream()), "grit_rope_qk_inplace")
+    return qkv
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE,
+            residual: torch.Tensor | None = None) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue).  SWIGLU: w holds interleaved gate/up rows, out is [M, N/2]."""
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (a.shape, w.shape)
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=BF16, device=a.device)
+    assert out.shape == (M, n_out)
+    rp, ldr = 0, 0
+    if epilogue == EPI_RESIDUAL:
+        assert residual is not None and residual.shape == (M, N)
+        rp, ldr = _chk(residual, BF16, "residual"), residual.stride(0)
+    check(_lib.load().grit_gemm_bf16_nt(_chk(a, BF16, "a"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), M, N, K, a.stride(0),
+                                        w.stride(0), out.stride(0), epilogue, rp, ldr, _stream()), "grit_gemm_bf16_nt")
+    return out
+
+
+def mask_pack(mask: torch.Tensor) -> torch.Tensor:
+    B, S = mask.shape
+    bits = torch.empty((B, (S + 63) // 64), dtype=I64, device=mask.device)   # uint64 payload in int64 storage
+    check(_lib.load().grit_mask_pack(_chk(mask, I64, "mask"), _chk(bits, I64, "bits"), B, S, _stream()), "grit_mask_pack")
+    return bits
+
+
+def attn_bidir(qkv: torch.Tensor, key_bits: torch.Tensor, B: int, S: int, nq: int, nkv: int, d: int,
+               out: torch.Tensor | None = None, lse: torch.Tensor | None = None, scale: float | None = None) -> torch.Tensor:
+    T, stride = qkv.shape
+    assert T == B * S
+    if out is None:
+        out = torch.empty((T, nq * d), dtype=BF16, device=qkv.device)
+    if scale is None:
+        scale = d ** -0.5
+    check(_lib.load().grit_attn_bidir_fwd(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"),
+                                          0 if lse is None else _chk(lse, F32, "lse"), B, S, nq, nkv, d, stride, out.stride(0),
+                                          float(scale), _stream()), "grit_attn_bidir_fwd")
+    return out
+
+
+def pool_norm(hidden: torch.Tensor, mask: torch.Tensor, method: str, normalize: bool, instr_len: torch.Tensor | None = None,
+              inv_norm: torch.Tensor | None = None) -> torch.Tensor:
+    if method not in POOL_MODES:
+        raise NotImplementedError(f"Unknown pooling method: {method}")     # gritlm/gritlm.py:215
+    B, S, H = hidden.shape
+    out = torch.empty((B, H), dtype=F32, device=hidden.device)
+    check(_lib.load().grit_pool_norm_fwd(_chk(hidden, BF16, "hidden"), _chk(mask, I64, "mask"),
+                                         0 if instr_len is None else _chk(instr_len, I32, "instr_len"), _chk(out, F32, "out"),
+                                         0 if inv_norm is None else _chk(inv_norm, F32, "inv_norm"), B, S, H, POOL_MODES[method],
+                                         int(normalize), _stream()), "grit_pool_norm_fwd")
+    return out
+
+
+def pool_norm_bwd(y: torch.Tensor, dy: torch.Tensor, inv_norm: torch.Tensor | None, mask: torch.Tensor, method: str, normalize: bool,
+                  S: int, instr_len: torch.Tensor | None = None) -> torch.Tensor:
+    B, H = y.shape
+    dh = torch.empty((B, S, H), dtype=BF16, device=y.device)
+    check(_lib.load().grit_pool_norm_bwd(_chk(y, F32, "y"), _chk(dy, F32, "dy"), 0 if inv_norm is None else _chk(inv_norm, F32, "inv_norm"),
+                                         _chk(mask, I64, "mask"), 0 if instr_len is None else _chk(instr_len, I32, "instr_len"),
+                                         _chk(dh, BF16, "dhidden"), B, S, H, POOL_MODES[method], int(normalize), _stream()),
+          "grit_pool_norm_bwd")
+    return dh
+
+
+def infonce(q: torch.Tensor, p: torch.Tensor, temperature: float, q_off: int = 0, nq_loc: int | None = None, p_off: int = 0,
+            np_loc: int | None = None, want_grad: bool = True):
+    """Returns (loss[1] fp32, dq [nq_loc,H] | None, dp [np_loc,H] | None)."""
+    Nq, H = q.shape
+    Np = p.shape[0]
+    nq_loc = Nq if nq_loc is None else nq_loc
+    np_loc = Np if np_loc is None else np_loc
+    scores = torch.empty((Nq, Np), dtype=F32, device=q.device)
+    loss = torch.empty((1,), dtype=F32, device=q.device)
+    dq = torch.empty((nq_loc, H), dtype=F32, device=q.device) if want_grad else None
+    dp = torch.empty((np_loc, H), dtype=F32, device=q.device) if want_grad else None
+    check(_lib.load().grit_infonce_fwd_bwd(_chk(q, F32, "q"), _chk(p, F32, "p"), 1.0 / float(temperature), _chk(scores, F32, "scores"),
+                                           _chk(loss, F32, "loss"), 0 if dq is None else dq.data_ptr(), 0 if dp is None else dp.data_ptr(),
+                                           Nq, Np, H, q_off, nq_loc, p_off, np_loc, _stream()), "grit_infonce_fwd_bwd")
+    return loss, dq, dp
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    R, Cc = x.shape
+    out = torch.empty((Cc, R), dtype=BF16, device=x.device)
+    check(_lib.load().grit_transpose_bf16(_chk(x, BF16, "x"), _chk(out, BF16, "out"), R, Cc, _stream()), "grit_transpose_bf16")
+    return out

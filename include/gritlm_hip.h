@@ -1,0 +1,125 @@
+/*
+ * gritlm_hip.h -- C ABI of libgritlm_hip.so, the MI355X (gfx950 / CDNA4) native engine for the
+ * GritLM embedding-encode / contrastive-training hot path.
+ *
+ * The reference (ContextualAI/gritlm) is 100 % Python and has no FFI of its own:
+ * every "kernel" there is a PyTorch op.  This header therefore DEFINES the drop-in boundary; each
+ * entry point cites the reference op(s) it replaces (paths relative to the upstream checkout).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory + explicit sizes/strides; no torch types;
+ *   - `stream` is a hipStream_t passed as void*; NOTHING synchronises the device or allocates;
+ *   - bf16 tensors are passed as `const void*` to 16-bit storage, row-major, innermost contiguous;
+ *   - return 0 on success, negative GRIT_E_* on failure (then grit_last_error_string() explains);
+ *   - re-entrant and thread-safe for distinct streams (forward from the Python main thread,
+ *     backward from autograd worker threads).
+ */
+#ifndef GRITLM_HIP_H
+#define GRITLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRIT_ABI_VERSION 1
+
+enum {
+  GRIT_OK = 0,
+  GRIT_E_BADARG = -1,      /* null pointer / non-positive size / misaligned pointer            */
+  GRIT_E_UNSUPPORTED = -2, /* shape outside what the gfx950 kernels are built for              */
+  GRIT_E_LAUNCH = -3,      /* hipLaunchKernel / runtime error                                   */
+  GRIT_E_RCCL = -4
+};
+
+/* GEMM epilogues (grit_gemm_bf16_nt) */
+enum {
+  GRIT_EPI_STORE = 0,    /* C = bf16(acc)                                                       */
+  GRIT_EPI_RESIDUAL = 1, /* C = bf16(acc + residual)  (residual may alias C)                    */
+  GRIT_EPI_SWIGLU = 2    /* weight rows interleaved gate/up in blocks of 16 (grit_swiglu_pack_index);
+                            C[:, N/2] = bf16(silu(bf16(gate)) * bf16(up))                        */
+};
+
+/* pooling modes: gritlm/gritlm.py:188-214 */
+enum { GRIT_POOL_MEAN = 0, GRIT_POOL_WEIGHTEDMEAN = 1, GRIT_POOL_CLS = 2, GRIT_POOL_LASTTOKEN = 3 };
+
+int grit_version(void);
+/* thread-local message of the last failing call on this thread ("" if none) */
+const char* grit_last_error_string(void);
+
+/* ---- encoder forward: scripts/modeling_mistral_gritlm.py ------------------------------------ */
+
+/* embed_tokens(input_ids), :918,994.  table [V,H] bf16, ids [T] int64 -> out [T,H] bf16.
+ * ids outside [0,V) are clamped (the reference raises IndexError). */
+int grit_embed_gather(const void* table, const int64_t* ids, void* out, int64_t T, int H, int64_t V,
+                      void* stream);
+
+/* MistralRMSNorm.forward, :84-89: y = w * bf16(x * rsqrt(mean(x^2) + eps)), fp32 math. x,y [T,H] bf16. */
+int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, float eps, void* stream);
+
+/* apply_rotary_pos_emb, :138-163, in place on the q and k heads of a fused [T, row_stride] bf16 buffer
+ * (columns [0,(nq+nkv)*d) hold q heads then k heads); positions are t % S (:984-989).
+ * cos/sin: fp32 tables [S, d/2] (MistralRotaryEmbedding :93-126; cos[j] == cos[j+d/2]).
+ * inverse != 0 applies the transposed rotation (backward of RoPE). */
+int grit_rope_qk_inplace(void* qkv, const float* cos_tab, const float* sin_tab, int64_t T, int S, int nq,
+                         int nkv, int d, int64_t row_stride, int inverse, void* stream);
+
+/* nn.Linear without bias (q/k/v/o_proj :225-228,655-657,703; MLP :177-178):
+ *   C[M,N] = A[M,K] * W[N,K]^T, bf16 in, fp32 MFMA accumulate, bf16 out, with a fused epilogue.
+ * Requirements: K % 64 == 0, N % 16 == 0, lda/ldw/ldc/ldr % 8 == 0, pointers 16-byte aligned.
+ * SWIGLU: N counts the interleaved gate+up rows (2*I); C has N/2 columns. */
+int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda,
+                      int64_t ldw, int64_t ldc, int epilogue, const void* residual, int64_t ldr,
+                      void* stream);
+
+/* attention_mask [B,S] int64 (HF layout, 0 = padding) -> key bitmask [B, ceil(S/64)] uint64
+ * (replaces _prepare_4d_attention_mask(_for_sdpa), :1017-1020,1033-1036: no [B,1,S,S] tensor). */
+int grit_mask_pack(const int64_t* mask, uint64_t* bits, int B, int S, void* stream);
+
+/* Bidirectional (is_causal=False) attention core with key-padding mask and GQA, replacing
+ * repeat_kv + SDPA (:182-191, :690-698).  qkv: fused [B*S, qkv_stride] bf16 with q heads at column 0,
+ * k heads at nq*d, v heads at (nq+nkv)*d (RoPE already applied).  out [B*S, out_stride] bf16
+ * (= attn_output.transpose(1,2).reshape(B,S,nq*d)).  lse (nullable) [B, nq, S] fp32 = log-sum-exp of
+ * the scaled scores (saved for backward).  head_dim d must be 128. */
+int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
+                        int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale,
+                        void* stream);
+
+/* ---- pooling + normalise: gritlm/gritlm.py:178-218,156-158; training/model.py:151-165 --------- */
+
+/* hidden [B,S,H] bf16; mask [B,S] int64 (attention mask); instr_len (nullable) [B] int32: the first
+ * instr_len[b] positions are excluded from the pool but were attended to (gritlm.py:144-153).
+ * out [B,H] fp32 = pooled (and L2-normalised, eps 1e-12, if normalize != 0).
+ * inv_norm (nullable) [B] fp32 receives 1/max(||pooled||,eps) (saved for backward).
+ * An all-masked row divides by zero exactly like the reference (:213-214). */
+int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* instr_len, float* out,
+                       float* inv_norm, int B, int S, int H, int mode, int normalize, void* stream);
+
+/* backward of the above w.r.t. hidden: y = forward output [B,H] fp32, dy [B,H] fp32 -> dhidden [B,S,H] bf16 */
+int grit_pool_norm_bwd(const float* y, const float* dy, const float* inv_norm, const int64_t* mask,
+                       const int32_t* instr_len, void* dhidden, int B, int S, int H, int mode,
+                       int normalize, void* stream);
+
+/* ---- contrastive loss: gritlm/training/model.py:36-47,62-64 --------------------------------- */
+
+/* scores = q p^T / tau (fp32 MFMA, exact f32), target[i] = i * (Np / Nq), CrossEntropyLoss(mean).
+ * q [Nq,H] fp32, p [Np,H] fp32 (already gathered across ranks, rank order).
+ * scores: workspace fp32 [Nq,Np] (holds d loss / d scores afterwards); loss: 1 fp32.
+ * Gradients are produced only for the caller's local rows, exactly the rows that carry grad in the
+ * reference after `_dist_gather_tensor` (:49-60): dq [nq_loc,H] for q rows [q_off, q_off+nq_loc),
+ * dp [np_loc,H] for p rows [p_off, p_off+np_loc).  dq/dp may be NULL (forward only). */
+int grit_infonce_fwd_bwd(const float* q, const float* p, float inv_temperature, float* scores, float* loss,
+                         float* dq, float* dp, int Nq, int Np, int H, int q_off, int nq_loc, int p_off,
+                         int np_loc, void* stream);
+
+/* ---- helpers -------------------------------------------------------------------------------- */
+
+/* bf16 [R,C] -> [C,R] transpose (activations / weights for the dgrad / wgrad GEMMs). */
+int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRITLM_HIP_H */

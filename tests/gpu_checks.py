@@ -1,0 +1,314 @@
+"""GPU parity checks: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Each check returns a dict(name, ok, detail).  Used by tests/test_gpu_parity.py (pytest -m gpu) and by
+tools/gpu_diag.py (one table for a whole gpurun call)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+import gritlm_oracle as O
+import synth
+from gritlm_amd import ops
+from gritlm_amd._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU
+from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine, swiglu_interleave
+
+DEV = "cuda"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DUMP = os.environ.get("GRIT_DUMP_DIR")
+
+
+def bf(x: np.ndarray) -> torch.Tensor:
+    """bf16-representable fp32 numpy -> bf16 cuda tensor (exact)."""
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(DEV).to(torch.bfloat16)
+
+
+def f32(t: torch.Tensor) -> np.ndarray:
+    return t.detach().float().cpu().numpy()
+
+
+def _res(name, ok, **kw):
+    return dict(name=name, ok=bool(ok), detail=" ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in kw.items()))
+
+
+def _dump(name, **arrs):
+    if DUMP:
+        os.makedirs(DUMP, exist_ok=True)
+        np.savez_compressed(os.path.join(DUMP, name + ".npz"), **arrs)
+
+
+def rnd(shape, seed, scale=1.0):
+    return O.bf16_round(np.random.default_rng(seed).standard_normal(shape, dtype=np.float32) * scale)
+
+
+# ---------------------------------------------------------------------------------------------
+def check_embed():
+    tab = rnd((97, 64), 1)
+    ids = np.random.default_rng(2).integers(0, 97, size=(3, 11))
+    out = f32(ops.embed_gather(bf(tab), torch.from_numpy(ids).to(DEV).view(-1)))
+    return _res("embed_gather", np.array_equal(out, tab[ids.reshape(-1)]))
+
+
+def check_rmsnorm(T=37, H=4096):
+    x, w = rnd((T, H), 3, 2.0), O.bf16_round(1 + 0.1 * rnd((H,), 4))
+    out = f32(ops.rmsnorm(bf(x), bf(w), 1e-5))
+    ref = O.rmsnorm(x, w, 1e-5, emulate_bf16=True)
+    err = float(np.max(np.abs(out - ref) / (np.abs(ref) + 1e-3)))
+    exact = float(np.mean(out == ref))
+    return _res(f"rmsnorm[T={T},H={H}]", err < 1e-2 and exact > 0.98, max_rel=err, exact_frac=exact)
+
+
+def check_rope(B=2, S=50, nq=4, nkv=2, d=128, inverse=False):
+    width = (nq + 2 * nkv) * d
+    qkv = rnd((B * S, width), 5)
+    cos, sin = O.rope_tables(S, d, 10000.0)
+    t = bf(qkv)
+    ops.rope_qk_(t, torch.from_numpy(cos[:, : d // 2].copy()).to(DEV), torch.from_numpy(sin[:, : d // 2].copy()).to(DEV), S, nq, nkv, d,
+                 inverse=inverse)
+    out = f32(t)
+    x = qkv.reshape(B, S, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
+    sgn = -1.0 if inverse else 1.0
+    ref = x.copy()
+    ref[:, : nq + nkv] = O.apply_rope(x[:, : nq + nkv], cos, sgn * sin)
+    ref = O.bf16_round(ref.transpose(0, 2, 1, 3).reshape(B * S, width))
+    err = float(np.max(np.abs(out - ref)))
+    v_same = np.array_equal(out[:, (nq + nkv) * d:], qkv[:, (nq + nkv) * d:])
+    return _res(f"rope[inv={int(inverse)}]", err < 4e-2 and v_same and float(np.mean(out == ref)) > 0.97, max_abs=err, v_untouched=v_same,
+                exact_frac=float(np.mean(out == ref)))
+
+
+def check_gemm(M, N, K, epi=EPI_STORE, seed=7):
+    a, w = rnd((M, K), seed), rnd((N, K), seed + 1, 0.05)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    if epi == EPI_RESIDUAL:
+        r = rnd((M, N), seed + 2)
+        out = f32(ops.gemm_nt(bf(a), bf(w), epilogue=epi, residual=bf(r)))
+        ref = O.bf16_round(ref.astype(np.float32)).astype(np.float64) + r
+    elif epi == EPI_SWIGLU:
+        I = N // 2
+        wg, wu = w[:I], w[I:]
+        wi = swiglu_interleave(bf(wg), bf(wu))
+        out = f32(ops.gemm_nt(bf(a), wi, epilogue=epi))
+        g = O.bf16_round((a.astype(np.float64) @ wg.astype(np.float64).T).astype(np.float32))
+        u = O.bf16_round((a.astype(np.float64) @ wu.astype(np.float64).T).astype(np.float32))
+        ref = (O.bf16_round(O.silu(g.astype(np.float64)).astype(np.float32)) * u).astype(np.float64)
+    else:
+        out = f32(ops.gemm_nt(bf(a), bf(w)))
+    scale = float(np.sqrt(np.mean(ref ** 2))) + 1e-9
+    err = float(np.max(np.abs(out - ref))) / scale
+    ok = err < 2.5e-2
+    if not ok:
+        _dump(f"gemm_{M}_{N}_{K}_{epi}", a=a, w=w, out=out, ref=ref.astype(np.float32))
+    return _res(f"gemm[M={M},N={N},K={K},epi={epi}]", ok, max_err_over_rms=err)
+
+
+def check_mask_pack():
+    rng = np.random.default_rng(9)
+    m = (rng.random((5, 200)) < 0.6).astype(np.int64)
+    m[1] = 1; m[2] = 0; m[3, 130:] = 0
+    bits = ops.mask_pack(torch.from_numpy(m).to(DEV)).cpu().numpy().view(np.uint64)
+    ok = True
+    for b in range(5):
+        for s in range(256):
+            want = int(m[b, s]) if s < 200 else 0
+            ok &= ((int(bits[b, s // 64]) >> (s % 64)) & 1) == (1 if want else 0)
+    return _res("mask_pack", ok)
+
+
+def check_attention(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=11):
+    d = 128
+    width = (nq + 2 * nkv) * d
+    qkv = rnd((B * S, width), seed)
+    rng = np.random.default_rng(seed + 1)
+    mask = np.ones((B, S), dtype=np.int64)
+    if mask_kind == "ragged":
+        for b in range(1, B):
+            mask[b, rng.integers(S // 3, S):] = 0
+    elif mask_kind == "holes":
+        mask = (rng.random((B, S)) < 0.7).astype(np.int64); mask[:, 0] = 1
+    elif mask_kind == "left":          # instruction-style: leading zeros, first 64-key tile fully masked
+        mask[:, :70] = 0
+    x = qkv.reshape(B, S, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
+    q, k, v = x[:, :nq], x[:, nq:nq + nkv], x[:, nq + nkv:]
+    ref = O.attention_bidirectional(q, k, v, mask)
+    lse_t = torch.empty((B, nq, S), dtype=torch.float32, device=DEV)
+    bits = ops.mask_pack(torch.from_numpy(mask).to(DEV))
+    out = f32(ops.attn_bidir(bf(qkv), bits, B, S, nq, nkv, d, lse=lse_t)).reshape(B, S, nq * d)
+    # reference lse
+    kk = np.repeat(k, nq // nkv, axis=1)
+    sc = np.einsum("bhqd,bhkd->bhqk", q.astype(np.float64), kk.astype(np.float64)) / np.sqrt(d)
+    sc = sc + np.where(mask.astype(bool), 0.0, -np.inf)[:, None, None, :]
+    mx = sc.max(-1, keepdims=True)
+    lse_ref = (mx[..., 0] + np.log(np.exp(sc - mx).sum(-1)))
+    err = float(np.max(np.abs(out - ref)))
+    lerr = float(np.max(np.abs(f32(lse_t) - lse_ref)))
+    ok = err < 2e-2 and lerr < 2e-3 and not np.isnan(out).any()
+    if not ok:
+        _dump(f"attn_{mask_kind}_{S}", qkv=qkv, mask=mask, out=out, ref=ref, lse=f32(lse_t), lse_ref=lse_ref.astype(np.float32))
+    return _res(f"attention[B={B},S={S},nq={nq},nkv={nkv},{mask_kind}]", ok, max_abs=err, lse_abs=lerr)
+
+
+def check_pool(method, normalize=True, B=5, S=70, H=256):
+    hid = rnd((B, S, H), 13)
+    rng = np.random.default_rng(14)
+    mask = np.ones((B, S), dtype=np.int64)
+    mask[1, 40:] = 0
+    mask[2] = (rng.random(S) < 0.5); mask[2, 5] = 1
+    mask[3, 1:] = 0
+    instr = np.array([0, 3, 0, 0, 17], dtype=np.int32) if method in ("mean", "weightedmean") else None
+    pm = O.instruction_mask(mask, instr)
+    ref = O.pooling(hid, pm, method)
+    if normalize:
+        ref = O.l2_normalize(ref)
+    inv = torch.empty((B,), dtype=torch.float32, device=DEV)
+    out = f32(ops.pool_norm(bf(hid), torch.from_numpy(mask).to(DEV), method, normalize,
+                            None if instr is None else torch.from_numpy(instr).to(DEV), inv_norm=inv))
+    err = float(np.max(np.abs(out - ref)))
+    ok = err < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    return _res(f"pool[{method},norm={int(normalize)}]", ok, max_abs=err)
+
+
+def check_pool_bwd(method, normalize=True, B=3, S=40, H=256):
+    hid = rnd((B, S, H), 15)
+    mask = np.ones((B, S), dtype=np.int64); mask[1, 25:] = 0; mask[2, :7] = 0
+    instr = np.array([2, 0, 9], dtype=np.int32)
+    pm = O.instruction_mask(mask, instr)
+    go = np.random.default_rng(16).standard_normal((B, H)).astype(np.float32)
+    ref = O.pool_normalize_backward(hid, pm, method, normalize, go)
+    tm, ti = torch.from_numpy(mask).to(DEV), torch.from_numpy(instr).to(DEV)
+    inv = torch.empty((B,), dtype=torch.float32, device=DEV)
+    y = ops.pool_norm(bf(hid), tm, method, normalize, ti, inv_norm=inv)
+    dh = f32(ops.pool_norm_bwd(y, torch.from_numpy(go).to(DEV), inv, tm, method, normalize, S, ti))
+    err = float(np.max(np.abs(dh - ref))) / (float(np.abs(ref).max()) + 1e-12)
+    return _res(f"pool_bwd[{method},norm={int(normalize)}]", err < 1e-2, max_rel_to_peak=err)
+
+
+def check_infonce(tag):
+    g = np.load(os.path.join(GOLDEN, "infonce.npz"))
+    q, p, tau = g[f"{tag}_q"], g[f"{tag}_p"], float(g[f"{tag}_tau"])
+    loss, dq, dp = ops.infonce(torch.from_numpy(q).to(DEV), torch.from_numpy(p).to(DEV), tau)
+    lerr = abs(float(loss.item()) - float(g[f"{tag}_loss"]))
+    e1 = float(np.max(np.abs(f32(dq) - g[f"{tag}_dq"]))) / (float(np.abs(g[f"{tag}_dq"]).max()) + 1e-12)
+    e2 = float(np.max(np.abs(f32(dp) - g[f"{tag}_dp"]))) / (float(np.abs(g[f"{tag}_dp"]).max()) + 1e-12)
+    return _res(f"infonce[{tag}] vs reference golden", lerr < 1e-3 and e1 < 1e-3 and e2 < 1e-3, loss_abs=lerr, dq_rel=e1, dp_rel=e2)
+
+
+def check_infonce_local_rows():
+    g = np.load(os.path.join(GOLDEN, "infonce_dist2.npz"))
+    q, p, tau, world = g["q"], g["p"], float(g["tau"]), int(g["world"])
+    bq, bp = q.shape[0] // world, p.shape[0] // world
+    ok, worst = True, 0.0
+    for r in range(world):
+        loss, dq, dp = ops.infonce(torch.from_numpy(q).to(DEV), torch.from_numpy(p).to(DEV), tau, r * bq, bq, r * bp, bp)
+        e = max(abs(float(loss.item()) - float(g[f"loss_rank{r}"])),
+                float(np.max(np.abs(f32(dq) - g[f"dq_rank{r}"]))), float(np.max(np.abs(f32(dp) - g[f"dp_rank{r}"]))))
+        worst = max(worst, e); ok &= e < 1e-3
+    return _res("infonce local rows vs 2-rank gloo reference", ok, worst_abs=worst)
+
+
+def check_infonce_big(nq=256, group=8, H=512, tau=0.02):
+    rng = np.random.default_rng(21)
+    q = O.l2_normalize(rng.standard_normal((nq, H), dtype=np.float32))
+    p = O.l2_normalize(rng.standard_normal((nq * group, H), dtype=np.float32))
+    loss_ref, dq_ref, dp_ref, _ = O.infonce(q, p, tau)
+    loss, dq, dp = ops.infonce(torch.from_numpy(q).to(DEV), torch.from_numpy(p).to(DEV), tau)
+    lerr = abs(float(loss.item()) - loss_ref)
+    e1 = float(np.max(np.abs(f32(dq) - dq_ref))) / float(np.abs(dq_ref).max())
+    e2 = float(np.max(np.abs(f32(dp) - dp_ref))) / float(np.abs(dp_ref).max())
+    return _res(f"infonce[Nq={nq},G={group},H={H}] vs oracle", lerr < 1e-3 and e1 < 2e-3 and e2 < 2e-3, loss_abs=lerr, dq_rel=e1, dp_rel=e2)
+
+
+def check_transpose(R=136, Cc=200):
+    x = rnd((R, Cc), 23)
+    return _res("transpose", np.array_equal(f32(ops.transpose(bf(x))), x.T))
+
+
+def build_engine(cfg_name, seed=0):
+    cfg = synth.CONFIGS[cfg_name]
+    w = synth.make_weights(cfg, seed)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    eng = MistralEncoderEngine.from_state_dict(EncoderConfig.from_dict(cfg), sd, DEV)
+    return eng, cfg, w
+
+
+def check_encoder_golden(cfg_name):
+    """End-to-end encoder vs the fixture produced by the REFERENCE modeling file (fp32 and bf16 runs)."""
+    g = np.load(os.path.join(GOLDEN, f"encoder_{cfg_name}.npz"))
+    eng, cfg, w = build_engine(cfg_name, int(g["seed_w"]))
+    ids, mask = g["input_ids"], g["attention_mask"]
+    h = f32(eng.forward(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)))
+    valid = mask.astype(bool)
+    ref32, refb = g["last_hidden_state"], g["last_hidden_state_bf16"]
+    rel = lambda a, b: float(np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid]))
+    r_ours, r_refb = rel(h, ref32), rel(refb, ref32)
+    out = dict(rel_ours_vs_fp32=r_ours, rel_refbf16_vs_fp32=r_refb)
+    ok = r_ours < max(2.0 * r_refb, 1.5e-2) and not np.isnan(h).any()
+    tm = torch.from_numpy(mask).to(DEV)
+    hb = torch.from_numpy(h).to(DEV).to(torch.bfloat16)
+    for method in ("mean", "weightedmean"):
+        e = f32(ops.pool_norm(hb, tm, method, True))
+        ref = g[f"emb_{method}"]
+        one_minus_cos = float(np.max(1 - np.sum(e * ref, axis=1)))
+        cs_delta = float(np.max(np.abs(e @ e.T - ref @ ref.T)))
+        out[f"{method}_1-cos"] = one_minus_cos; out[f"{method}_cossim_delta"] = cs_delta
+        ok &= one_minus_cos < 1e-4 and cs_delta < 1e-4
+    if not ok:
+        _dump(f"encoder_{cfg_name}", h=h, ref=ref32)
+    return _res(f"encoder[{cfg_name}] vs reference golden", ok, **out)
+
+
+def check_encoder_vs_oracle_bf16(cfg_name="tiny", B=3, S=130):
+    """Different shape than the golden (S not a multiple of 64), against the bf16-emulating oracle."""
+    eng, cfg, w = build_engine(cfg_name, 5)
+    ids, mask = synth.make_batch(cfg, B, S, seed=77, min_len=33)
+    h = f32(eng.forward(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)))
+    ref = O.mistral_encode(w, cfg, ids, mask, emulate_bf16=True)
+    ref32 = O.mistral_encode(w, cfg, ids, mask)
+    valid = mask.astype(bool)
+    rel = lambda a, b: float(np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid]))
+    r1, r2, r3 = rel(h, ref), rel(h, ref32), rel(ref, ref32)
+    return _res(f"encoder[{cfg_name},B={B},S={S}] vs oracle", r2 < max(2.0 * r3, 1.5e-2), rel_vs_bf16_oracle=r1, rel_vs_fp32_oracle=r2,
+                bf16_oracle_vs_fp32=r3)
+
+
+ALL_CHECKS = [
+    ("embed", check_embed, {}),
+    ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
+    ("rmsnorm_256", check_rmsnorm, dict(T=9, H=256)),
+    ("rmsnorm_1024", check_rmsnorm, dict(T=130, H=1024)),
+    ("rope", check_rope, {}),
+    ("rope_inv", check_rope, dict(inverse=True)),
+    ("gemm_256", check_gemm, dict(M=256, N=256, K=64)),
+    ("gemm_edge", check_gemm, dict(M=300, N=272, K=128)),
+    ("gemm_big", check_gemm, dict(M=1024, N=768, K=512)),
+    ("gemm_small_m", check_gemm, dict(M=17, N=1536, K=256)),
+    ("gemm_residual", check_gemm, dict(M=520, N=512, K=192, epi=EPI_RESIDUAL)),
+    ("gemm_swiglu", check_gemm, dict(M=300, N=1024, K=256, epi=EPI_SWIGLU)),
+    ("gemm_swiglu_edge", check_gemm, dict(M=70, N=608, K=64, epi=EPI_SWIGLU)),
+    ("mask_pack", check_mask_pack, {}),
+    ("attn_ragged", check_attention, dict(mask_kind="ragged")),
+    ("attn_holes", check_attention, dict(mask_kind="holes", S=257)),
+    ("attn_left", check_attention, dict(mask_kind="left", S=192)),
+    ("attn_full_512", check_attention, dict(B=1, S=512, nq=8, nkv=2, mask_kind="none")),
+    ("attn_short", check_attention, dict(B=3, S=33, nq=2, nkv=1, mask_kind="ragged")),
+    ("pool_mean", check_pool, dict(method="mean")),
+    ("pool_weightedmean", check_pool, dict(method="weightedmean")),
+    ("pool_cls", check_pool, dict(method="cls")),
+    ("pool_lasttoken", check_pool, dict(method="lasttoken")),
+    ("pool_mean_nonorm", check_pool, dict(method="mean", normalize=False)),
+    ("pool_mean_4096", check_pool, dict(method="mean", B=2, S=19, H=4096)),
+    ("pool_bwd_mean", check_pool_bwd, dict(method="mean")),
+    ("pool_bwd_weightedmean", check_pool_bwd, dict(method="weightedmean")),
+    ("pool_bwd_nonorm", check_pool_bwd, dict(method="mean", normalize=False)),
+    ("infonce_a", check_infonce, dict(tag="a")),
+    ("infonce_b", check_infonce, dict(tag="b")),
+    ("infonce_c", check_infonce, dict(tag="c")),
+    ("infonce_local", check_infonce_local_rows, {}),
+    ("infonce_big", check_infonce_big, {}),
+    ("transpose", check_transpose, {}),
+    ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
+    ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
+    ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
+]
