@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the GritLM embedding-encode hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: GritLM-7B (Mistral-7B shape, 32 layers, bf16,
+random-init weights) bidirectional encode of 256 docs x 512 tokens, masked mean pooling, L2-normalise
+(BASELINE.json configs[1]).  Token ids are synthetic and already resident in HBM when the timed region
+starts.  N > 1: one replica per GPU, every rank encodes its own 256-doc batch (documents are independent:
+no data-path collective, weak scaling); value = docs of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline:     dominant kernel (gemm_bf16_nt, bf16 MFMA bound) measured live with HIP events,
+  cpu_baseline: the numpy oracle ("port") timed on this host's cores on a bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+DOCS, SEQ = 256, 512
+
+
+def cpu_baseline(sample_docs=4, seq=SEQ, layers=2):
+    """The oracle on host cores: 7B layer shape, `layers` of 32 layers, fp32 numpy/OpenBLAS."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import gritlm_oracle as O
+    import synth
+    cfg = dict(synth.CONFIGS["7b"]); cfg["num_hidden_layers"] = layers; cfg["vocab_size"] = 2048
+    rng = np.random.default_rng(0)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    d = H // cfg["num_attention_heads"]; nkv = cfg["num_key_value_heads"]
+    lin = lambda o, i: (rng.random((o, i), dtype=np.float32) - 0.5) * 0.07
+    w = {"embed_tokens.weight": lin(cfg["vocab_size"], H), "norm.weight": np.ones(H, np.float32)}
+    base = {"self_attn.q_proj.weight": lin(H, H), "self_attn.k_proj.weight": lin(nkv * d, H),
+            "self_attn.v_proj.weight": lin(nkv * d, H), "self_attn.o_proj.weight": lin(H, H),
+            "mlp.gate_proj.weight": lin(I, H), "mlp.up_proj.weight": lin(I, H), "mlp.down_proj.weight": lin(H, I),
+            "input_layernorm.weight": np.ones(H, np.float32), "post_attention_layernorm.weight": np.ones(H, np.float32)}
+    for li in range(layers):           # same arrays for every layer: timing only
+        for k, v in base.items():
+            w[f"layers.{li}.{k}"] = v
+    ids, mask = synth.make_batch(cfg, sample_docs, seq, seed=1234)
+    O.encode_core(w, cfg, ids[:1, :64], mask[:1, :64], "mean", True, acc_dtype=np.float32)   # warm BLAS threads
+    t0 = time.perf_counter()
+    O.encode_core(w, cfg, ids, mask, "mean", True, acc_dtype=np.float32)
+    dt = time.perf_counter() - t0
+    raw = sample_docs / dt
+    cores = len(os.sched_getaffinity(0))
+    return {"value": raw * layers / 32.0, "unit": "docs/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_docs} docs x {seq} tok through {layers} of 32 layers at the 7B layer shape, fp32 numpy/OpenBLAS "
+                      f"oracle (oracle/gritlm_oracle.py), {dt:.2f} s; value = measured {raw:.3f} docs/s x {layers}/32 layer extrapolation",
+            "raw_docs_per_s_reduced_model": raw, "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=32, help="debug only; anything but 32 marks the line invalid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" == RCCL on ROCm
+
+    from gritlm_amd import ops
+    from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine
+
+    cfg = EncoderConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
+                        num_key_value_heads=8, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=10000.0)
+    eng = MistralEncoderEngine.random_init(cfg, dev, seed=0)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    ids = torch.randint(3, cfg.vocab_size, (DOCS, SEQ), generator=gen, device=dev, dtype=torch.int64)
+    mask = torch.ones((DOCS, SEQ), dtype=torch.int64, device=dev)
+
+    def step():
+        h = eng.forward(ids, mask, borrow=True)
+        return ops.pool_norm(h, mask, "mean", True)
+
+    for _ in range(args.warmup):
+        emb = step()
+    timer = ops.KernelTimer()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_timer(None)
+    assert torch.isfinite(emb).all(), "non-finite embeddings"
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    if rank == 0:
+        ks = timer.summary()
+        g = ks["gemm_bf16_nt"]
+        achieved = g["work"] / (g["total_ms"] * 1e-3) / 1e12           # TFLOP/s over all launches == avg flops / avg duration
+        docs_per_s = world * DOCS * args.steps / dt_max
+        flops_per_doc = eng.flops_per_token(SEQ) * SEQ
+        line = {
+            "metric": "encoded docs/sec @ seq512", "value": docs_per_s, "unit": "docs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "GritLM-7B (Mistral-7B shape, 32L, random-init) bf16 bidirectional encode, batch 256 x seq512, "
+                                   "mean pooling + L2 normalise, per GPU", "docs_per_step_per_gpu": DOCS, "seq_len": SEQ,
+                       "layers": args.layers, "parallelism": f"replicas x{world} (no data-path collective)"},
+            "model_flops_utilisation": docs_per_s / world * flops_per_doc / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_k", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
+                         "avg_flops_per_launch": g["work"] / g["launches"]},
+            "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
+                            "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()},
+        }
+        if args.layers != 32:
+            line["INVALID"] = "debug run with --layers != 32"
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,21 +99,27 @@ __global__ void __launch_bounds__(256) infonce_ce_k(float* __restrict__ scores, 
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
+  // sum of exp over the NON-target columns only: when the positive dominates (a trained model) both the
+  // loss (log1p form) and d/ds_target = -(sum_others / sum) keep full relative precision, where
+  // softmax - 1 (what torch computes) cancels catastrophically in fp32
+  const int tgt = i * group;
   float sum = 0.f;
-  for (int j = tid; j < Np; j += 256) sum += expf(row[j] - mx);
+  for (int j = tid; j < Np; j += 256) sum += (j == tgt) ? 0.f : expf(row[j] - mx);
   sum = wave_sum(sum);
   if (lane == 0) red[wave] = sum;
   __syncthreads();
-  sum = red[0] + red[1] + red[2] + red[3];
-  const float lse = mx + logf(sum);
-  const int tgt = i * group;
-  if (tid == 0) atomicAdd(loss, (lse - row[tgt]) / (float)Nq);
+  const float sum_others = red[0] + red[1] + red[2] + red[3];
+  const float s_t = row[tgt];
+  const float e_t = expf(s_t - mx);
+  const float tot = sum_others + e_t;
+  const float li = (s_t == mx) ? log1pf(sum_others) : (mx - s_t) + logf(tot);
+  if (tid == 0) atomicAdd(loss, li / (float)Nq);
   if (!want_grad) return;
   __syncthreads();  // row[tgt] read above before anyone overwrites it
-  const float sc = inv_temperature / (float)Nq;
+  const float sc = inv_temperature / (float)Nq, inv_tot = 1.0f / tot;
   for (int j = tid; j < Np; j += 256) {
-    const float p = expf(row[j] - lse);
-    row[j] = (p - (j == tgt ? 1.f : 0.f)) * sc;
+    const float pj = (j == tgt) ? -sum_others * inv_tot : expf(row[j] - mx) * inv_tot;
+    row[j] = pj * sc;
   }
 }
 

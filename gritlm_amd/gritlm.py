@@ -1,0 +1,250 @@
+"""``GritLM`` -- drop-in for the reference inference wrapper (gritlm/gritlm.py:9-218) with the
+embedding hot path (bidirectional Mistral forward, pooling, L2-normalise) on the native MI355X engine.
+
+Call-compatible surface: constructor arguments, ``encode`` / ``encode_queries`` /
+``encode_corpus`` / ``pooling`` signatures, attributes ``model, tokenizer, device, generate, projection,
+pooling_method, normalized, attn, embed_eos, num_gpus, embedding_attr``, error behaviour
+(``ValueError`` for mixed attention strings, ``NotImplementedError`` for unknown pooling methods).
+
+What runs where:
+  * CUDA(HIP) device + Mistral backbone in bf16 + bidirectional attention ('bb..'): tokenise on the host,
+    then ``MistralEncoderEngine`` (HIP kernels through the C ABI) + fused pool/normalise kernel.
+    A missing ``libgritlm_hip.so`` raises -- there is no silent fallback on this path.
+  * anything else (CPU plumbing config "SGPT-125M weightedmean", non-Mistral backbones, causal 'cc'
+    embedding, ``get_cache=True``): the Hugging Face module computes the hidden states exactly as in the
+    reference; pooling still uses the HIP kernel when the hidden states are bf16 on the GPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Union
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from ._lib import POOL_MODES
+
+_VALID_ATTN = ("bbcc", "cccc", "bb", "cc")
+
+
+def _torch_pool(hidden: torch.Tensor, mask: torch.Tensor, method: str) -> torch.Tensor:
+    """Plain-torch pooling for tensors the HIP kernel does not take (CPU / fp32 hidden states).
+    Semantics of gritlm/gritlm.py:188-214, including the in-place mask update of 'weightedmean'."""
+    rows = torch.arange(hidden.shape[0], device=hidden.device)
+    if method == "cls":
+        return hidden[:, 0]
+    if method == "lasttoken":
+        n = mask.shape[1]
+        last = (n - 1 - torch.argmax(mask.flip(dims=(1,)), dim=1)).clamp_min(0)
+        return hidden[rows, last] * mask[rows, last].unsqueeze(-1).float()
+    if method in ("mean", "weightedmean"):
+        if method == "weightedmean":
+            mask.mul_(mask.cumsum(dim=1))
+        w = mask.unsqueeze(-1).float()
+        return (hidden * w).sum(dim=1) / mask.sum(dim=1, keepdim=True).float()
+    raise NotImplementedError(f"Unknown pooling method: {method}")
+
+
+class GritLM(torch.nn.Module):
+    def __init__(
+        self,
+        model_name_or_path: str = None,
+        mode: str = "unified",            # 'unified' | 'embedding' | 'generative'
+        pooling_method: str = "mean",     # 'cls' | 'lasttoken' | 'mean' | 'weightedmean'
+        normalized: bool = True,
+        projection: int = None,
+        is_inference: bool = True,
+        embed_eos: str = "",
+        attn: str = "bbcc",
+        device: str = "cuda" if torch.cuda.is_available() else "cpu",
+        **kwargs,                          # forwarded to from_pretrained (torch_dtype, attn_implementation, ...)
+    ) -> None:
+        super().__init__()
+        from transformers import AutoModel, AutoModelForCausalLM, AutoTokenizer
+
+        native = kwargs.pop("native", "auto")   # "auto" | True | False  (extension over the reference)
+        if mode == "embedding":
+            if any(tag in model_name_or_path for tag in ("gtr", "t5", "instructor")):
+                from transformers import T5EncoderModel
+                self.model = T5EncoderModel.from_pretrained(model_name_or_path, **kwargs)
+            else:
+                self.model = AutoModel.from_pretrained(model_name_or_path, trust_remote_code=True, **kwargs)
+            self.embedding_attr = None
+        else:
+            self.model = AutoModelForCausalLM.from_pretrained(model_name_or_path, trust_remote_code=True, **kwargs)
+            self.generate = self.model.generate
+            if hasattr(self.model, "model"):            # Llama / Mistral
+                self.embedding_attr = "model"
+            elif hasattr(self.model, "transformer"):    # GPT-Neo / GPT-J
+                self.embedding_attr = "transformer"
+            else:
+                raise ValueError("Could not find attribute to use for embedding: ", self.model)
+
+        self.projection = None
+        if projection is not None:
+            self.projection = torch.nn.Linear(self.model.config.hidden_size, int(projection), dtype=self.model.dtype)
+        self.normalized = normalized
+        self.pooling_method = pooling_method
+        self.device = device
+        self.num_gpus = 1            # one process per GPU; multi-GPU encode shards the sentence list per rank
+        self.embed_eos = embed_eos
+        self.attn = attn
+        if (attn is not None) and attn not in _VALID_ATTN:
+            raise ValueError(f"Mixed attention no longer supported: {self.attn}. Only bbcc, cccc, bb, cc are supported")
+        self.engine = None
+        self._native = native
+
+        print(f"Created GritLM: {self.model.dtype} dtype, {pooling_method} pool, {mode} mode, {attn} attn")
+
+        if is_inference:
+            # right padding: instruction masking indexes from the left (reference :60-61)
+            self.tokenizer = AutoTokenizer.from_pretrained(model_name_or_path, padding_side="right", trust_remote_code=True)
+            if not self.tokenizer.pad_token and self.tokenizer.eos_token:
+                self.tokenizer.pad_token = self.tokenizer.eos_token
+                print("Set pad token to eos token: " + self.tokenizer.pad_token)
+            if self.embed_eos:
+                assert self.embed_eos in self.tokenizer.vocab, f"EOS token {self.embed_eos} not in vocab"
+            self.model.eval()
+            if "device_map" not in kwargs and not kwargs.get("load_in_4bit", False) and not kwargs.get("load_in_8bit", False):
+                self.model.to(self.device)
+            self._maybe_build_engine()
+
+    # ------------------------------------------------------------------ native engine
+    def _backbone(self):
+        return getattr(self.model, self.embedding_attr) if self.embedding_attr else self.model
+
+    def _maybe_build_engine(self):
+        """Bind the HIP encoder to the backbone weights when the configuration is one it implements."""
+        if self._native is False:
+            return
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        cfg = self.model.config
+        eligible = (dev.type == "cuda" and getattr(cfg, "model_type", "") == "mistral" and self.attn is not None
+                    and self.attn[:2] == "bb" and self.model.dtype == torch.bfloat16)
+        if not eligible:
+            if self._native is True:
+                raise RuntimeError("native=True but this configuration is not implemented by the HIP engine "
+                                   f"(device={dev}, model_type={getattr(cfg, 'model_type', None)}, attn={self.attn}, dtype={self.model.dtype})")
+            return
+        from .encoder import EncoderConfig, MistralEncoderEngine   # raises if libgritlm_hip.so is missing
+        from . import _lib
+        _lib.load()
+        ecfg = EncoderConfig.from_hf(cfg)
+        ecfg.check_supported()
+        self.engine = MistralEncoderEngine.from_state_dict(ecfg, self._backbone().state_dict(), dev)
+
+    # ------------------------------------------------------------------ API
+    def encode_queries(self, queries: Union[List[str], str], **kwargs) -> np.ndarray:
+        """Queries of retrieval / reranking tasks."""
+        return self.encode(queries, **kwargs)
+
+    def encode_corpus(self, corpus: Union[List[str], str, List[Dict[str, str]]], **kwargs) -> np.ndarray:
+        """Corpus of retrieval tasks; dict documents are flattened to 'title text'."""
+        if isinstance(corpus, dict):
+            corpus = [corpus]
+        if isinstance(corpus, list) and isinstance(corpus[0], dict):
+            corpus = [(doc["title"] + " " + doc["text"]) if "title" in doc else doc["text"] for doc in corpus]
+        return self.encode(corpus, **kwargs)
+
+    def _hidden_states(self, inputs, get_cache: bool):
+        """(last_hidden_state, kv_cache|None) for one tokenised batch."""
+        if self.engine is not None and not get_cache:
+            return self.engine.forward(inputs["input_ids"], inputs["attention_mask"], borrow=True), None
+        kw = dict(inputs)
+        if (self.attn is not None) and (self.attn[:2] == "bb"):
+            kw["is_causal"] = False
+        if get_cache:
+            kw["use_cache"] = True
+        out = self._backbone()(**kw)
+        return out[0], (out[1] if get_cache else None)
+
+    @torch.no_grad()
+    def encode(
+        self,
+        sentences: Union[List[str], str],
+        batch_size: int = 256,
+        max_length: int = 512,
+        instruction: str = "",
+        embed_instruction: bool = False,
+        get_cache: bool = False,
+        convert_to_tensor: bool = False,
+        recast: bool = False,
+        add_special_tokens: bool = True,
+        **kwargs,
+    ) -> np.ndarray:
+        if self.num_gpus > 1:
+            batch_size *= self.num_gpus
+        single = isinstance(sentences, str)
+        if single:
+            sentences = [sentences]
+
+        n_instr = None
+        if instruction and (embed_instruction is False) and ("mean" in self.pooling_method):
+            # token count of the instruction tokenised ALONE with the same special-token setting (:146-152)
+            n_instr = len(self.tokenizer(instruction, padding=False, truncation=True, max_length=max_length,
+                                         add_special_tokens=add_special_tokens)["input_ids"])
+
+        chunks, kv_caches = [], []
+        for start in tqdm(range(0, len(sentences), batch_size), desc="Batches", disable=len(sentences) < 256):
+            texts = [instruction + s + self.embed_eos for s in sentences[start:start + batch_size]]
+            inputs = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length,
+                                    add_special_tokens=add_special_tokens).to(self.device)
+            hidden, cache = self._hidden_states(inputs, get_cache)
+            if get_cache:
+                assert len(kv_caches) == 0, "Can only get cache for one batch at a time"
+                kv_caches = cache
+            if self.projection:
+                hidden = self.projection(hidden)
+            if n_instr is not None:
+                inputs["attention_mask"][:, :n_instr] = 0      # attended to, but not pooled
+            emb = self._pool_normalize(hidden, inputs["attention_mask"], recast)
+            chunks.append(emb)
+
+        if convert_to_tensor:
+            result = torch.cat(chunks, dim=0)
+        else:
+            # ONE device->host copy for the whole call (the reference syncs per batch, :164)
+            result = torch.cat(chunks, dim=0).to(torch.float32).cpu().numpy()
+        if single:
+            result = result[0]
+        if get_cache:
+            return result, kv_caches
+        return result
+
+    # ------------------------------------------------------------------ pooling
+    def _native_poolable(self, hidden: torch.Tensor, mask: torch.Tensor) -> bool:
+        return (hidden.is_cuda and hidden.dtype == torch.bfloat16 and hidden.dim() == 3 and hidden.shape[-1] % 8 == 0
+                and mask is not None and self.pooling_method in POOL_MODES)
+
+    def _pool_normalize(self, hidden, mask, recast):
+        """pooling + (optional) F.normalize fused in one kernel when possible (reference :154-158)."""
+        if self._native_poolable(hidden, mask):
+            from . import ops
+            m = mask.to(device=hidden.device, dtype=torch.int64).contiguous()
+            emb = ops.pool_norm(hidden.contiguous(), m, self.pooling_method, bool(self.normalized))
+            if self.pooling_method == "weightedmean":
+                mask.mul_(mask.cumsum(dim=1))                 # keep the reference's side effect (:211)
+            if recast or self.pooling_method == "cls":        # 'cls' never leaves the hidden dtype (:188)
+                emb = emb.to(hidden.dtype)
+            return emb
+        emb = self.pooling(hidden, mask, recast=recast)
+        if self.normalized:
+            emb = torch.nn.functional.normalize(emb, dim=-1).to(emb.dtype)
+        return emb
+
+    def pooling(self, hidden_state: torch.Tensor, attention_mask: torch.Tensor = None, recast: bool = False) -> torch.Tensor:
+        """hidden_state [b, n, d], attention_mask [b, n] -> [b, d] (fp32 unless ``recast`` / 'cls')."""
+        hidden_state = hidden_state.to(attention_mask.device)
+        if self.pooling_method not in POOL_MODES:
+            raise NotImplementedError(f"Unknown pooling method: {self.pooling_method}")
+        if self._native_poolable(hidden_state, attention_mask):
+            from . import ops
+            m = attention_mask.to(torch.int64).contiguous()
+            emb = ops.pool_norm(hidden_state.contiguous(), m, self.pooling_method, False)
+            if self.pooling_method == "weightedmean":
+                attention_mask.mul_(attention_mask.cumsum(dim=1))
+            if self.pooling_method == "cls":
+                emb = emb.to(hidden_state.dtype)
+        else:
+            emb = _torch_pool(hidden_state, attention_mask, self.pooling_method)
+        return emb.to(hidden_state.dtype) if recast else emb

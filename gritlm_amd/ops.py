@@ -14,6 +14,38 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-kernel-class HIP-event timing (bench.py's live roofline measurement).
+
+    Events are recorded on torch's current stream -- the stream every kernel here is launched on."""
+
+    def __init__(self):
+        self.pairs: dict[str, list] = {}
+        self.work: dict[str, float] = {}
+
+    def span(self, name: str, work: float = 0.0):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.setdefault(name, []).append((a, b))
+        self.work[name] = self.work.get(name, 0.0) + work
+        return a, b
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.pairs.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), work=self.work[name])
+        return out
+
+
+_timer: KernelTimer | None = None
+
+
+def set_timer(t: KernelTimer | None):
+    global _timer
+    _timer = t
+
+
 def _chk(t: torch.Tensor, dtype, name: str):
     if not t.is_cuda:
         raise _lib.GritHipError(f"{name}: tensor must live on the GPU (got {t.device}); the native path has no CPU fallback")
@@ -65,8 +97,13 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     if epilogue == EPI_RESIDUAL:
         assert residual is not None and residual.shape == (M, N)
         rp, ldr = _chk(residual, BF16, "residual"), residual.stride(0)
+    ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K) if _timer is not None else None
+    if ev:
+        ev[0].record()
     check(_lib.load().grit_gemm_bf16_nt(_chk(a, BF16, "a"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), M, N, K, a.stride(0),
                                         w.stride(0), out.stride(0), epilogue, rp, ldr, _stream()), "grit_gemm_bf16_nt")
+    if ev:
+        ev[1].record()
     return out
 
 
@@ -85,9 +122,14 @@ def attn_bidir(qkv: torch.Tensor, key_bits: torch.Tensor, B: int, S: int, nq: in
         out = torch.empty((T, nq * d), dtype=BF16, device=qkv.device)
     if scale is None:
         scale = d ** -0.5
+    ev = _timer.span("attn_bidir_fwd", 4.0 * B * nq * S * S * d) if _timer is not None else None
+    if ev:
+        ev[0].record()
     check(_lib.load().grit_attn_bidir_fwd(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"),
                                           0 if lse is None else _chk(lse, F32, "lse"), B, S, nq, nkv, d, stride, out.stride(0),
                                           float(scale), _stream()), "grit_attn_bidir_fwd")
+    if ev:
+        ev[1].record()
     return out
 
 

@@ -96,7 +96,7 @@ def apply_rope(x: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
     return x * cos[None, None] + rotate_half(x) * sin[None, None]
 
 
-def attention_bidirectional(q, k, v, key_mask):
+def attention_bidirectional(q, k, v, key_mask, acc_dtype=F64):
     """Attention core with is_causal=False and a key-padding mask.
 
     MistralSdpaAttention.forward scripts/modeling_mistral_gritlm.py:627-705
@@ -105,21 +105,21 @@ def attention_bidirectional(q, k, v, key_mask):
     finfo.min on padded KEYS only, every query row (padded or not) is computed.
 
     q: [B, Hq, S, d]; k, v: [B, Hkv, S, d]; key_mask: [B, S] (0/1).
-    Returns [B, S, Hq*d].
+    Returns [B, S, Hq*d].  ``acc_dtype`` float64 for tests, float32 for the timed CPU baseline.
     """
     B, Hq, S, d = q.shape
     Hkv = k.shape[1]
     rep = Hq // Hkv
-    k = np.repeat(k, rep, axis=1)
-    v = np.repeat(v, rep, axis=1)
-    scores = np.einsum("bhqd,bhkd->bhqk", q.astype(F64), k.astype(F64)) / np.sqrt(d)
+    k = np.repeat(k, rep, axis=1).astype(acc_dtype)
+    v = np.repeat(v, rep, axis=1).astype(acc_dtype)
+    scores = np.matmul(q.astype(acc_dtype), k.transpose(0, 1, 3, 2)) / np.sqrt(d).astype(acc_dtype)
     if key_mask is not None:
-        neg = np.where(key_mask.astype(bool), 0.0, -np.inf)[:, None, None, :]
+        neg = np.where(key_mask.astype(bool), 0.0, -np.inf).astype(acc_dtype)[:, None, None, :]
         scores = scores + neg
     scores = scores - scores.max(axis=-1, keepdims=True)
     p = np.exp(scores)
     p = p / p.sum(axis=-1, keepdims=True)
-    out = np.einsum("bhqk,bhkd->bhqd", p, v.astype(F64))
+    out = np.matmul(p, v)
     return out.transpose(0, 2, 1, 3).reshape(B, S, Hq * d).astype(F32)
 
 
@@ -135,7 +135,7 @@ def mlp(x, w_gate, w_up, w_down):
 
 
 def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_mask: np.ndarray | None,
-                   emulate_bf16: bool = False, return_layers: bool = False):
+                   emulate_bf16: bool = False, return_layers: bool = False, acc_dtype=F64):
     """MistralModel.forward with is_causal=False, scripts/modeling_mistral_gritlm.py:936-1096.
 
     ``weights`` uses the HF state_dict names of MistralModel (``embed_tokens.weight``,
@@ -168,7 +168,7 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
         k = k.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
         v = v.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
         q = rnd(apply_rope(q, cos, sin)); k = rnd(apply_rope(k, cos, sin))             # :666-668
-        a = rnd(attention_bidirectional(q, k, v, attention_mask))                      # :690-698
+        a = rnd(attention_bidirectional(q, k, v, attention_mask, acc_dtype))                      # :690-698
         a = rnd(a @ weights[p + "self_attn.o_proj.weight"].T)                          # :703
         h = rnd(res + a)                                                               # :769
         res = h
@@ -242,10 +242,10 @@ def instruction_mask(attention_mask: np.ndarray, instruction_lens) -> np.ndarray
 
 
 def encode_core(weights, cfg, input_ids, attention_mask, pooling_method="mean", normalized=True,
-                instruction_lens=None, emulate_bf16=False):
+                instruction_lens=None, emulate_bf16=False, acc_dtype=F64):
     """Device part of GritLM.encode (gritlm/gritlm.py:129-158) == GritLMTrainModel.encode
     (gritlm/training/model.py:134-165): forward, instruction masking, pool, normalise."""
-    h = mistral_encode(weights, cfg, input_ids, attention_mask, emulate_bf16=emulate_bf16)
+    h = mistral_encode(weights, cfg, input_ids, attention_mask, emulate_bf16=emulate_bf16, acc_dtype=acc_dtype)
     pm = instruction_mask(attention_mask, instruction_lens)
     e = pooling(h, pm, pooling_method)
     return l2_normalize(e) if normalized else e

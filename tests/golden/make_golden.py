@@ -215,6 +215,40 @@ def gen_gradcache():
     print(f"  gradcache: loss direct {out.loss.item():.6f} vs gc {loss.item():.6f}")
 
 
+def gen_gritlm_encode():
+    """The reference's own GritLM(...).encode() end to end on CPU (tokenise -> forward -> pool -> normalise):
+    (a) BASELINE.json configs[0] plumbing case: GPT-Neo, weightedmean, attn=None, 32 docs @ max_length 128;
+    (b) tiny Mistral, 'bbcc' + mean pooling with an instruction, fp32 and bf16."""
+    import tempfile
+    from gritlm import GritLM
+    out = {}
+    sents = synth.make_sentences(32, seed=5, max_words=150)
+    out["sentences"] = np.array(sents)
+    with tempfile.TemporaryDirectory() as td:
+        d = synth.build_gptneo_dir(os.path.join(td, "neo"), seed=0)
+        m = GritLM(d, pooling_method="weightedmean", attn=None, device="cpu")
+        out["neo_weightedmean"] = m.encode(sents, batch_size=8, max_length=128)
+        m.pooling_method = "lasttoken"
+        out["neo_lasttoken"] = m.encode(sents[:8], batch_size=8, max_length=128)
+        instr = "w1 w2 w3 w4"
+        out["instruction"] = np.array(instr)
+        d32 = synth.build_mistral_dir(os.path.join(td, "m32"), "tiny", 0, "float32")
+        m = GritLM(d32, pooling_method="mean", attn="bbcc", device="cpu")
+        out["mistral_fp32_mean_instr"] = m.encode(sents[:12], batch_size=5, max_length=64, instruction=instr + " ")
+        out["mistral_fp32_mean"] = m.encode(sents[:12], batch_size=5, max_length=64)
+        out["mistral_fp32_mean_embed_instr"] = m.encode(sents[:4], batch_size=5, max_length=64, instruction=instr + " ", embed_instruction=True)
+        single = m.encode(sents[0], max_length=64)
+        assert single.shape == (256,)
+        m2 = GritLM(d32, pooling_method="weightedmean", attn="cccc", device="cpu")
+        out["mistral_fp32_wmean_causal"] = m2.encode(sents[:6], batch_size=6, max_length=64)
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        mb = GritLM(d16, pooling_method="mean", attn="bbcc", device="cpu", torch_dtype=torch.bfloat16)
+        assert mb.model.dtype == torch.bfloat16
+        out["mistral_bf16_mean_instr"] = mb.encode(sents[:12], batch_size=5, max_length=64, instruction=instr + " ")
+        out["mistral_bf16_mean"] = mb.encode(sents[:12], batch_size=5, max_length=64)
+    np.savez_compressed(os.path.join(HERE, "gritlm_encode.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -224,4 +258,5 @@ if __name__ == "__main__":
     print("encoder tiny"); gen_encoder("tiny", batch=4, seq=48, min_len=9)
     print("encoder gqa"); gen_encoder("gqa", batch=3, seq=72, min_len=20)
     print("gradcache"); gen_gradcache()
+    print("gritlm encode"); gen_gritlm_encode()
     print("done")

@@ -97,11 +97,12 @@ def check_gemm(M, N, K, epi=EPI_STORE, seed=7):
     else:
         out = f32(ops.gemm_nt(bf(a), bf(w)))
     scale = float(np.sqrt(np.mean(ref ** 2))) + 1e-9
-    err = float(np.max(np.abs(out - ref))) / scale
-    ok = err < 2.5e-2
+    # outputs are bf16: 1 ulp = 2^-8 relative; allow ~2 ulp of the value + a small absolute floor
+    err = float(np.max(np.abs(out - ref) / (1.2e-2 * np.abs(ref) + 1e-2 * scale)))
+    ok = err < 1.0
     if not ok:
         _dump(f"gemm_{M}_{N}_{K}_{epi}", a=a, w=w, out=out, ref=ref.astype(np.float32))
-    return _res(f"gemm[M={M},N={N},K={K},epi={epi}]", ok, max_err_over_rms=err)
+    return _res(f"gemm[M={M},N={N},K={K},epi={epi}]", ok, max_err_over_tol=err)
 
 
 def check_mask_pack():
@@ -154,10 +155,12 @@ def check_pool(method, normalize=True, B=5, S=70, H=256):
     hid = rnd((B, S, H), 13)
     rng = np.random.default_rng(14)
     mask = np.ones((B, S), dtype=np.int64)
-    mask[1, 40:] = 0
-    mask[2] = (rng.random(S) < 0.5); mask[2, 5] = 1
-    mask[3, 1:] = 0
-    instr = np.array([0, 3, 0, 0, 17], dtype=np.int32) if method in ("mean", "weightedmean") else None
+    mask[1, S // 2:] = 0
+    if B > 2:
+        mask[2] = (rng.random(S) < 0.5); mask[2, 5] = 1
+    if B > 3:
+        mask[3, 1:] = 0
+    instr = np.array([0, 3, 0, 0, 17][:B], dtype=np.int32) if method in ("mean", "weightedmean") else None
     pm = O.instruction_mask(mask, instr)
     ref = O.pooling(hid, pm, method)
     if normalize:
@@ -192,7 +195,13 @@ def check_infonce(tag):
     lerr = abs(float(loss.item()) - float(g[f"{tag}_loss"]))
     e1 = float(np.max(np.abs(f32(dq) - g[f"{tag}_dq"]))) / (float(np.abs(g[f"{tag}_dq"]).max()) + 1e-12)
     e2 = float(np.max(np.abs(f32(dp) - g[f"{tag}_dp"]))) / (float(np.abs(g[f"{tag}_dp"]).max()) + 1e-12)
-    return _res(f"infonce[{tag}] vs reference golden", lerr < 1e-3 and e1 < 1e-3 and e2 < 1e-3, loss_abs=lerr, dq_rel=e1, dp_rel=e2)
+    # the fp32 torch golden itself loses digits in (softmax - onehot) when the positive dominates (tag c);
+    # the fp64 oracle is the tight comparison, the golden the loose one
+    _, dq64, dp64, _ = O.infonce(q, p, tau)
+    o1 = float(np.max(np.abs(f32(dq) - dq64))) / (float(np.abs(dq64).max()) + 1e-12)
+    o2 = float(np.max(np.abs(f32(dp) - dp64))) / (float(np.abs(dp64).max()) + 1e-12)
+    ok = lerr < 1e-3 and e1 < 1e-2 and e2 < 1e-2 and o1 < 1e-3 and o2 < 1e-3
+    return _res(f"infonce[{tag}] vs reference golden", ok, loss_abs=lerr, dq_rel=e1, dp_rel=e2, dq_rel_fp64=o1, dp_rel_fp64=o2)
 
 
 def check_infonce_local_rows():
@@ -244,16 +253,20 @@ def check_encoder_golden(cfg_name):
     rel = lambda a, b: float(np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid]))
     r_ours, r_refb = rel(h, ref32), rel(refb, ref32)
     out = dict(rel_ours_vs_fp32=r_ours, rel_refbf16_vs_fp32=r_refb)
-    ok = r_ours < max(2.0 * r_refb, 1.5e-2) and not np.isnan(h).any()
+    # hidden states: no further from the fp32 reference than the reference's own bf16 run is
+    ok = r_ours < 1.25 * r_refb + 1e-3 and not np.isnan(h).any()
     tm = torch.from_numpy(mask).to(DEV)
     hb = torch.from_numpy(h).to(DEV).to(torch.bfloat16)
     for method in ("mean", "weightedmean"):
         e = f32(ops.pool_norm(hb, tm, method, True))
-        ref = g[f"emb_{method}"]
-        one_minus_cos = float(np.max(1 - np.sum(e * ref, axis=1)))
-        cs_delta = float(np.max(np.abs(e @ e.T - ref @ ref.T)))
-        out[f"{method}_1-cos"] = one_minus_cos; out[f"{method}_cossim_delta"] = cs_delta
-        ok &= one_minus_cos < 1e-4 and cs_delta < 1e-4
+        ref, refb16 = g[f"emb_{method}"], g[f"emb_{method}_bf16"]
+        one_minus_cos = float(np.max(1 - np.sum(e * ref, axis=1)))            # stated tolerance: < 1e-4
+        one_minus_cos_b = float(np.max(1 - np.sum(e * refb16, axis=1)))       # vs the reference run in bf16
+        cs_delta = float(np.max(np.abs(e @ e.T - ref @ ref.T)))               # pairwise q.d^T cosines
+        cs_delta_ref = float(np.max(np.abs(refb16 @ refb16.T - ref @ ref.T)))  # the bf16 reference's own noise
+        out[f"{method}_1-cos"] = one_minus_cos; out[f"{method}_1-cos_vs_bf16ref"] = one_minus_cos_b
+        out[f"{method}_pair_delta"] = cs_delta; out[f"{method}_pair_delta_of_bf16ref"] = cs_delta_ref
+        ok &= one_minus_cos < 1e-4 and one_minus_cos_b < 1e-4 and cs_delta < 1.5 * cs_delta_ref + 1e-4
     if not ok:
         _dump(f"encoder_{cfg_name}", h=h, ref=ref32)
     return _res(f"encoder[{cfg_name}] vs reference golden", ok, **out)
@@ -271,6 +284,37 @@ def check_encoder_vs_oracle_bf16(cfg_name="tiny", B=3, S=130):
     r1, r2, r3 = rel(h, ref), rel(h, ref32), rel(ref, ref32)
     return _res(f"encoder[{cfg_name},B={B},S={S}] vs oracle", r2 < max(2.0 * r3, 1.5e-2), rel_vs_bf16_oracle=r1, rel_vs_fp32_oracle=r2,
                 bf16_oracle_vs_fp32=r3)
+
+
+def check_gritlm_native_encode():
+    """gritlm_amd.GritLM(...).encode() on the GPU (tokenise -> native engine -> fused pool/normalise) vs the
+    REFERENCE GritLM.encode() outputs recorded on CPU in fp32 and in bf16 (tests/golden/gritlm_encode.npz)."""
+    import tempfile
+    from gritlm_amd import GritLM
+    g = np.load(os.path.join(GOLDEN, "gritlm_encode.npz"))
+    sents = [str(x) for x in g["sentences"]]
+    instr = str(g["instruction"]) + " "
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        m = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16)
+        ok &= m.engine is not None
+        for key, kw in (("mean_instr", dict(instruction=instr)), ("mean", {})):
+            e = m.encode(sents[:12], batch_size=5, max_length=64, **kw)
+            ok &= e.dtype == np.float32 and e.shape == (12, 256)
+            r32, r16 = g[f"mistral_fp32_{key}"], g[f"mistral_bf16_{key}"]
+            c32 = float(np.max(1 - np.sum(e * r32, axis=1))); c16 = float(np.max(1 - np.sum(e * r16, axis=1)))
+            pd = float(np.max(np.abs(e @ e.T - r32 @ r32.T))); pd_ref = float(np.max(np.abs(r16 @ r16.T - r32 @ r32.T)))
+            out[f"{key}_1-cos_fp32ref"] = c32; out[f"{key}_1-cos_bf16ref"] = c16
+            out[f"{key}_pair_delta"] = pd; out[f"{key}_pair_delta_of_bf16ref"] = pd_ref
+            ok &= c32 < 1e-4 and c16 < 1e-4 and pd < 1.5 * pd_ref + 1e-4
+        t = m.encode(sents[:3], max_length=64, convert_to_tensor=True)
+        ok &= t.is_cuda and t.dtype == torch.float32
+        m.pooling_method = "weightedmean"
+        mask = torch.ones((2, 5), dtype=torch.int64, device="cuda"); mask[1, 3:] = 0
+        m.pooling(torch.randn((2, 5, 256), device="cuda").to(torch.bfloat16), mask)
+        ok &= mask.cpu().tolist() == [[1, 2, 3, 4, 5], [1, 2, 3, 0, 0]]        # in-place side effect kept (:211)
+    return _res("GritLM.encode native vs reference GritLM.encode goldens", ok, **out)
 
 
 ALL_CHECKS = [
@@ -311,4 +355,5 @@ ALL_CHECKS = [
     ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
+    ("gritlm_native_encode", check_gritlm_native_encode, {}),
 ]

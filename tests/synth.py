@@ -91,3 +91,79 @@ def hf_config(cfg: dict):
                       tie_word_embeddings=False)
     c.rope_theta = cfg["rope_theta"]
     return c
+
+
+# ---------------------------------------------------------------------------------------------
+# Offline model directories (no network): WordLevel tokenizer + save_pretrained model
+# ---------------------------------------------------------------------------------------------
+WORDS = [f"w{i}" for i in range(400)]
+
+
+def make_tokenizer(path: str):
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3}
+    for w in WORDS:
+        vocab[w] = len(vocab)
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", 1)])   # add_bos_token=True
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>", pad_token="<pad>")
+    fast.save_pretrained(path)
+    return fast
+
+
+def make_sentences(n: int, seed: int = 5, min_words: int = 3, max_words: int = 100) -> list[str]:
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(min_words, max_words + 1))
+        out.append(" ".join(WORDS[int(j)] for j in rng.integers(0, len(WORDS), size=k)))
+    return out
+
+
+def build_mistral_dir(path: str, cfg_name: str = "tiny", seed: int = 0, dtype="float32") -> str:
+    """MistralForCausalLM with the synthetic weights of make_weights + tokenizer, saved to ``path``."""
+    import torch
+    from transformers import MistralForCausalLM
+    cfg = CONFIGS[cfg_name]
+    hc = hf_config(cfg)
+    model = MistralForCausalLM(hc)
+    w = make_weights(cfg, seed)
+    sd = {"model." + k: torch.from_numpy(v) for k, v in w.items()}
+    rng = np.random.default_rng(seed + 99)
+    sd["lm_head.weight"] = torch.from_numpy(_bf16_round(rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"]), dtype=np.float32) * 0.02))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    model = model.to(getattr(torch, dtype))
+    model.save_pretrained(path)
+    make_tokenizer(path)
+    return path
+
+
+def build_gptneo_dir(path: str, seed: int = 0) -> str:
+    """Tiny GPT-Neo (architecture of SGPT-125M-weightedmean, README.md:38; BASELINE.json configs[0] plumbing case)."""
+    import torch
+    from transformers import GPTNeoConfig, GPTNeoForCausalLM
+    hc = GPTNeoConfig(vocab_size=len(WORDS) + 4, hidden_size=64, num_layers=2, num_heads=4, intermediate_size=128,
+                      attention_types=[[["global", "local"], 1]], max_position_embeddings=256, window_size=64,
+                      bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    model = GPTNeoForCausalLM(hc)
+    rng = np.random.default_rng(seed)
+    sd = model.state_dict()
+    new = {}
+    for k in sorted(sd.keys()):
+        t = sd[k]
+        if not t.dtype.is_floating_point or "masked_bias" in k or k.endswith(".attn.attention.bias"):
+            continue
+        if "ln_" in k and k.endswith("weight"):
+            v = 1.0 + 0.1 * rng.standard_normal(tuple(t.shape), dtype=np.float32)
+        elif k.endswith("bias"):
+            v = 0.02 * rng.standard_normal(tuple(t.shape), dtype=np.float32)
+        else:
+            v = 0.05 * rng.standard_normal(tuple(t.shape), dtype=np.float32)
+        new[k] = torch.from_numpy(v)
+    model.load_state_dict(new, strict=False)
+    model.save_pretrained(path)
+    make_tokenizer(path)
+    return path

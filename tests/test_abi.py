@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gritlm_hip.h declares; argument validation
+(no compute, no GPU) returns the documented error codes; the product path fails loudly without the library."""
+import ctypes
+import os
+
+import pytest
+
+from gritlm_amd import _lib
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    lib = _lib.load()
+    syms = _lib.header_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/gritlm_hip.h but not exported"
+    assert set(syms) == set(_lib._SIGNATURES), "ctypes signature table out of sync with the header"
+    assert lib.grit_version() == 1
+
+
+def test_header_cites_reference_for_each_entry_point():
+    src = open(_lib.HEADER_PATH).read()
+    for needle in ("modeling_mistral_gritlm.py", "gritlm/gritlm.py", "training/model.py"):
+        assert needle in src
+
+
+def test_bad_arguments_are_rejected_without_touching_the_device():
+    lib = _lib.load()
+    rc = lib.grit_gemm_bf16_nt(None, None, None, 4, 16, 64, 64, 64, 16, 0, None, 0, None)
+    assert rc == _lib.GRIT_E_BADARG
+    assert b"null pointer" in lib.grit_last_error_string()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    assert lib.grit_gemm_bf16_nt(p16, p16, p16, 4, 16, 48, 48, 48, 16, 0, None, 0, None) == _lib.GRIT_E_UNSUPPORTED   # K % 64
+    assert b"multiple of 64" in lib.grit_last_error_string()
+    assert lib.grit_gemm_bf16_nt(p16, p16, p16, 4, 24, 64, 64, 64, 24, 0, None, 0, None) == _lib.GRIT_E_UNSUPPORTED   # N % 16
+    assert lib.grit_gemm_bf16_nt(p16 + 2, p16, p16, 4, 16, 64, 64, 64, 16, 0, None, 0, None) == _lib.GRIT_E_BADARG    # alignment
+    assert lib.grit_gemm_bf16_nt(p16, p16, p16, 4, 16, 64, 64, 64, 16, 7, None, 0, None) == _lib.GRIT_E_BADARG        # epilogue
+    assert lib.grit_attn_bidir_fwd(p16, p16, p16, None, 1, 8, 2, 1, 64, 256, 128, 0.1, None) == _lib.GRIT_E_UNSUPPORTED  # head_dim
+    assert lib.grit_pool_norm_fwd(p16, p16, None, p16, None, 1, 8, 64, 9, 1, None) == _lib.GRIT_E_BADARG             # pooling mode
+    assert lib.grit_infonce_fwd_bwd(p16, p16, 50.0, p16, p16, None, None, 3, 7, 8, 0, 3, 0, 7, None) == _lib.GRIT_E_BADARG  # Np % Nq
+    with pytest.raises(_lib.GritHipError):
+        _lib.check(-2, "x")
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    import torch
+    from gritlm_amd import ops
+    x = torch.zeros((4, 64), dtype=torch.bfloat16)
+    with pytest.raises(_lib.GritHipError, match="no CPU fallback"):
+        ops.rmsnorm(x, torch.ones(64, dtype=torch.bfloat16), 1e-5)
+    with pytest.raises(NotImplementedError):
+        ops.pool_norm(torch.zeros((1, 2, 8), dtype=torch.bfloat16), torch.ones((1, 2), dtype=torch.int64), "weighted_mean", True)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.GritHipError, match="not built"):
+        _lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, files in os.walk(os.path.join(root, "gritlm_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "gritlm_oracle" not in src and "oracle." not in src, f"{f} references the oracle"

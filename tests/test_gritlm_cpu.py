@@ -1,0 +1,75 @@
+"""CPU plumbing parity: gritlm_amd.GritLM reproduces the REFERENCE GritLM.encode() outputs (tests/golden/gritlm_encode.npz)
+on the host path -- BASELINE.json configs[0] (GPT-Neo / SGPT shape, weightedmean, 32 docs @ seq128) and a tiny Mistral."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gritlm_amd import GritLM
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "gritlm_encode.npz"))
+
+
+@pytest.fixture(scope="module")
+def dirs(tmp_path_factory):
+    td = tmp_path_factory.mktemp("models")
+    return dict(neo=synth.build_gptneo_dir(str(td / "neo"), 0), m32=synth.build_mistral_dir(str(td / "m32"), "tiny", 0, "float32"))
+
+
+def test_config1_sgpt_weightedmean_plumbing(gold, dirs):
+    sents = [str(s) for s in gold["sentences"]]
+    m = GritLM(dirs["neo"], pooling_method="weightedmean", attn=None, device="cpu")
+    assert m.engine is None and m.embedding_attr == "transformer"
+    e = m.encode(sents, batch_size=8, max_length=128)
+    assert e.dtype == np.float32 and e.shape == (32, 64)
+    np.testing.assert_allclose(e, gold["neo_weightedmean"], atol=2e-6)
+    m.pooling_method = "lasttoken"
+    np.testing.assert_allclose(m.encode(sents[:8], batch_size=8, max_length=128), gold["neo_lasttoken"], atol=2e-6)
+
+
+def test_mistral_cpu_matches_reference_including_instruction_masking(gold, dirs):
+    sents = [str(s) for s in gold["sentences"]]
+    instr = str(gold["instruction"]) + " "
+    m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu")
+    np.testing.assert_allclose(m.encode(sents[:12], batch_size=5, max_length=64, instruction=instr), gold["mistral_fp32_mean_instr"], atol=5e-6)
+    np.testing.assert_allclose(m.encode(sents[:12], batch_size=5, max_length=64), gold["mistral_fp32_mean"], atol=5e-6)
+    np.testing.assert_allclose(m.encode(sents[:4], batch_size=5, max_length=64, instruction=instr, embed_instruction=True),
+                               gold["mistral_fp32_mean_embed_instr"], atol=5e-6)
+    one = m.encode(sents[0], max_length=64)
+    assert one.shape == (256,)                                   # str in -> 1-D out (gritlm.py:169-170)
+    t = m.encode(sents[:3], max_length=64, convert_to_tensor=True)
+    assert isinstance(t, torch.Tensor) and t.dtype == torch.float32
+    tb = m.encode(sents[:3], max_length=64, convert_to_tensor=True, recast=True)
+    assert tb.dtype == m.model.dtype
+    c = GritLM(dirs["m32"], pooling_method="weightedmean", attn="cccc", device="cpu")
+    np.testing.assert_allclose(c.encode(sents[:6], batch_size=6, max_length=64), gold["mistral_fp32_wmean_causal"], atol=5e-6)
+    corp = m.encode_corpus([{"title": "w1", "text": "w2 w3"}, {"text": "w4"}], max_length=16)
+    np.testing.assert_allclose(corp, m.encode(["w1 w2 w3", "w4"], max_length=16), atol=1e-7)
+
+
+def test_constructor_contract(dirs):
+    with pytest.raises(ValueError, match="Mixed attention"):
+        GritLM(dirs["m32"], attn="bbcb", device="cpu")
+    m = GritLM(dirs["m32"], pooling_method="weighted_mean", device="cpu")     # README.md:38 typo -> NotImplementedError at pool
+    with pytest.raises(NotImplementedError):
+        m.encode(["w1 w2"], max_length=8)
+    with pytest.raises(RuntimeError, match="native=True"):
+        GritLM(dirs["m32"], device="cpu", native=True)
+    for a in ("model", "tokenizer", "device", "generate", "projection", "pooling_method", "normalized", "attn", "embed_eos", "num_gpus"):
+        assert hasattr(m, a), a
+
+
+def test_pooling_mutates_mask_like_the_reference(golden_dir, dirs):
+    g = np.load(os.path.join(golden_dir, "pooling.npz"))
+    m = GritLM(dirs["m32"], device="cpu")
+    for method in ("mean", "weightedmean", "cls", "lasttoken"):
+        m.pooling_method = method
+        mask = torch.from_numpy(g["mask"].copy())
+        out = m.pooling(torch.from_numpy(g["hidden"]), mask)
+        np.testing.assert_allclose(out.numpy(), g[f"pool_{method}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(mask.numpy(), g[f"mask_after_{method}"])
