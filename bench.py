@@ -27,10 +27,24 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def measured_traffic():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, each collected in its own --pmc run: profiles/rNN_gemm_pmc.json).  bench.py cannot run PMC
+    collection itself; None if no profile of this kernel generation is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["avg_traffic_bytes_per_gemm_launch_in_forward"]
+    except Exception:  # noqa: BLE001
+        return None
 DOCS, SEQ = 256, 512
 
 
-def cpu_baseline(sample_docs=4, seq=SEQ, layers=2):
+def cpu_baseline(sample_docs=16, seq=SEQ, layers=2):
     """The oracle on host cores: 7B layer shape, `layers` of 32 layers, fp32 numpy/OpenBLAS."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -139,7 +153,7 @@ def main():
                        "layers": args.layers, "parallelism": f"replicas x{world} (no data-path collective)"},
             "model_flops_utilisation": docs_per_s / world * flops_per_doc / (MFMA_BF16_PEAK_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_k", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(),
                          "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
                          "avg_flops_per_launch": g["work"] / g["launches"]},
             "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
