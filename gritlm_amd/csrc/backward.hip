@@ -1,0 +1,210 @@
+// HBM-bound backward pieces of the contrastive training step (autograd of the ops in elementwise.hip /
+// the MLP activation): RMSNorm backward (+ fused residual-gradient add), SwiGLU forward/backward on the
+// concatenated [gate | up] layout used by the training engine, embedding scatter-add, small helpers.
+#include "common.h"
+
+namespace grit {
+
+// ---------------------------------------------------------------- RMSNorm backward
+// y = w * (x * rs),  rs = rsqrt(mean(x^2) + eps)   (scripts/modeling_mistral_gritlm.py:84-89)
+//   dx = rs * (dy*w) - x * rs^3 * mean(dy*w*x)  (+ dres),   dw += sum_t dy * x * rs
+// One wave per row (grid-stride); the block's dw contribution is accumulated in LDS and written to
+// dw_partial[blockIdx]; rmsnorm_dw_reduce_k sums the partials.
+__global__ void __launch_bounds__(256) rmsnorm_bwd_k(const uint4* __restrict__ dy, const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                     const uint4* dres, uint4* dx, float* __restrict__ dw_partial, int64_t T, int H,
+                                                     float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* acc = reinterpret_cast<float*>(smem);  // [H]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HC = H >> 3;
+  for (int i = tid; i < H; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T; row += (int64_t)gridDim.x * 4) {
+    const uint4* xr = x + row * HC;
+    const uint4* gr = dy + row * HC;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < HC; c += 64) {
+      const uint4 xv = xr[c], gv = gr[c], wv = w[c];
+      const uint32_t xa[4] = {xv.x, xv.y, xv.z, xv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w}, wa[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = bflo(xa[e]), x1 = bfhi(xa[e]);
+        ss += x0 * x0 + x1 * x1;
+        dot += bflo(ga[e]) * bflo(wa[e]) * x0 + bfhi(ga[e]) * bfhi(wa[e]) * x1;
+      }
+    }
+    ss = wave_sum(ss); dot = wave_sum(dot);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    const float k2 = rs * rs * rs * dot / (float)H;
+    for (int c = lane; c < HC; c += 64) {
+      const uint4 xv = xr[c], gv = gr[c], wv = w[c];
+      uint4 rv = make_uint4(0, 0, 0, 0);
+      if (dres != nullptr) rv = dres[row * HC + c];
+      const uint32_t xa[4] = {xv.x, xv.y, xv.z, xv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w}, wa[4] = {wv.x, wv.y, wv.z, wv.w},
+                     ra[4] = {rv.x, rv.y, rv.z, rv.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = bflo(xa[e]), x1 = bfhi(xa[e]), g0 = bflo(ga[e]), g1 = bfhi(ga[e]);
+        const float d0 = rs * g0 * bflo(wa[e]) - x0 * k2 + bflo(ra[e]);
+        const float d1 = rs * g1 * bfhi(wa[e]) - x1 * k2 + bfhi(ra[e]);
+        o[e] = pack2bf(d0, d1);
+        atomicAdd(&acc[c * 8 + 2 * e], g0 * x0 * rs);
+        atomicAdd(&acc[c * 8 + 2 * e + 1], g1 * x1 * rs);
+      }
+      dx[row * HC + c] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  __syncthreads();
+  float* outp = dw_partial + (int64_t)blockIdx.x * H;
+  for (int i = tid; i < H; i += 256) outp[i] = acc[i];
+}
+
+__global__ void __launch_bounds__(256) rmsnorm_dw_reduce_k(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int H) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * H + i];
+  dw[i] += s;
+}
+
+// ---------------------------------------------------------------- SwiGLU on the concatenated layout gu = [gate | up], [T, 2I]
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ void __launch_bounds__(256) swiglu_fwd_k(const uint16_t* __restrict__ gu, uint16_t* __restrict__ act, int64_t T, int I) {
+  const int IC = I >> 3;
+  const int64_t total = T * IC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / IC; const int c = (int)(i - t * IC);
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + t * 2 * I + c * 8);
+    const uint4 u = *reinterpret_cast<const uint4*>(gu + t * 2 * I + I + c * 8);
+    const uint32_t ga[4] = {g.x, g.y, g.z, g.w}, ua[4] = {u.x, u.y, u.z, u.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g0 = bflo(ga[e]), g1 = bfhi(ga[e]);
+      o[e] = pack2bf(round_bf(g0 * sigmoid_f(g0)) * bflo(ua[e]), round_bf(g1 * sigmoid_f(g1)) * bfhi(ua[e]));
+    }
+    *reinterpret_cast<uint4*>(act + t * I + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ void __launch_bounds__(256) swiglu_bwd_k(const uint16_t* __restrict__ gu, const uint16_t* __restrict__ dact,
+                                                    uint16_t* __restrict__ dgu, int64_t T, int I) {
+  const int IC = I >> 3;
+  const int64_t total = T * IC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / IC; const int c = (int)(i - t * IC);
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + t * 2 * I + c * 8);
+    const uint4 u = *reinterpret_cast<const uint4*>(gu + t * 2 * I + I + c * 8);
+    const uint4 d = *reinterpret_cast<const uint4*>(dact + t * I + c * 8);
+    const uint32_t ga[4] = {g.x, g.y, g.z, g.w}, ua[4] = {u.x, u.y, u.z, u.w}, da[4] = {d.x, d.y, d.z, d.w};
+    uint32_t og[4], ou[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g0 = bflo(ga[e]), g1 = bfhi(ga[e]), u0 = bflo(ua[e]), u1 = bfhi(ua[e]), d0 = bflo(da[e]), d1 = bfhi(da[e]);
+      const float s0 = sigmoid_f(g0), s1 = sigmoid_f(g1);
+      og[e] = pack2bf(d0 * u0 * s0 * (1.f + g0 * (1.f - s0)), d1 * u1 * s1 * (1.f + g1 * (1.f - s1)));
+      ou[e] = pack2bf(d0 * g0 * s0, d1 * g1 * s1);
+    }
+    *reinterpret_cast<uint4*>(dgu + t * 2 * I + c * 8) = make_uint4(og[0], og[1], og[2], og[3]);
+    *reinterpret_cast<uint4*>(dgu + t * 2 * I + I + c * 8) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+  }
+}
+
+// ---------------------------------------------------------------- embedding backward: dtable[ids[t]] += dh[t]  (fp32 atomics)
+__global__ void __launch_bounds__(256) embed_scatter_add_k(const uint4* __restrict__ dh, const int64_t* __restrict__ ids,
+                                                           float* __restrict__ dtable, int64_t T, int HC, int64_t V) {
+  const int64_t total = T * HC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / HC; const int c = (int)(i - t * HC);
+    int64_t id = ids[t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const uint4 v = dh[i];
+    float* dst = dtable + (id * HC + c) * 8;
+    atomicAdd(dst + 0, bflo(v.x)); atomicAdd(dst + 1, bfhi(v.x)); atomicAdd(dst + 2, bflo(v.y)); atomicAdd(dst + 3, bfhi(v.y));
+    atomicAdd(dst + 4, bflo(v.z)); atomicAdd(dst + 5, bfhi(v.z)); atomicAdd(dst + 6, bflo(v.w)); atomicAdd(dst + 7, bfhi(v.w));
+  }
+}
+
+// acc_bf16[i] = bf16(acc_bf16[i] + x_f32[i])  : fold an fp32 gradient into a bf16 .grad buffer
+__global__ void __launch_bounds__(256) accum_bf16_from_f32_k(uint16_t* __restrict__ acc, const float* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc[i] = (uint16_t)f2bf(bf2f(acc[i]) + x[i]);
+}
+
+static inline int grid_for(int64_t items) {
+  int64_t g = (items + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace grit
+
+using namespace grit;
+
+extern "C" {
+
+int64_t grit_rmsnorm_bwd_workspace_rows(int64_t T) {
+  int64_t g = (T + 3) / 4;
+  return g < 1 ? 1 : (g > 512 ? 512 : g);
+}
+
+int grit_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw_partial, float* dw, int64_t T,
+                     int H, float eps, void* stream) {
+  GRIT_REQUIRE(dy && x && w && dx && dw_partial && dw, GRIT_E_BADARG, "grit_rmsnorm_bwd: null pointer");
+  GRIT_REQUIRE(T > 0 && H > 0, GRIT_E_BADARG, "grit_rmsnorm_bwd: bad sizes");
+  GRIT_REQUIRE(H % 8 == 0 && H <= 32768, GRIT_E_UNSUPPORTED, "grit_rmsnorm_bwd: H=%d must be a multiple of 8 and <= 32768", H);
+  GRIT_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w) && aligned16(dx) && (dres == nullptr || aligned16(dres)), GRIT_E_BADARG,
+               "grit_rmsnorm_bwd: pointers must be 16-byte aligned");
+  const int nblk = (int)grit_rmsnorm_bwd_workspace_rows(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)rmsnorm_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rmsnorm_bwd_k, dim3(nblk), dim3(256), (size_t)H * 4, st, (const uint4*)dy, (const uint4*)x, (const uint4*)w,
+                     (const uint4*)dres, (uint4*)dx, dw_partial, T, H, eps);
+  GRIT_CHECK_LAUNCH("grit_rmsnorm_bwd");
+  hipLaunchKernelGGL(rmsnorm_dw_reduce_k, dim3((H + 255) / 256), dim3(256), 0, st, (const float*)dw_partial, dw, nblk, H);
+  GRIT_CHECK_LAUNCH("grit_rmsnorm_bwd: reduce");
+  return GRIT_OK;
+}
+
+int grit_swiglu_fwd(const void* gu, void* act, int64_t T, int I, void* stream) {
+  GRIT_REQUIRE(gu && act, GRIT_E_BADARG, "grit_swiglu_fwd: null pointer");
+  GRIT_REQUIRE(T > 0 && I > 0 && I % 8 == 0, GRIT_E_UNSUPPORTED, "grit_swiglu_fwd: I=%d must be a positive multiple of 8", I);
+  GRIT_REQUIRE(aligned16(gu) && aligned16(act), GRIT_E_BADARG, "grit_swiglu_fwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(swiglu_fwd_k, dim3(grid_for(T * (I / 8))), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)gu, (uint16_t*)act, T, I);
+  GRIT_CHECK_LAUNCH("grit_swiglu_fwd");
+  return GRIT_OK;
+}
+
+int grit_swiglu_bwd(const void* gu, const void* dact, void* dgu, int64_t T, int I, void* stream) {
+  GRIT_REQUIRE(gu && dact && dgu, GRIT_E_BADARG, "grit_swiglu_bwd: null pointer");
+  GRIT_REQUIRE(T > 0 && I > 0 && I % 8 == 0, GRIT_E_UNSUPPORTED, "grit_swiglu_bwd: I=%d must be a positive multiple of 8", I);
+  GRIT_REQUIRE(aligned16(gu) && aligned16(dact) && aligned16(dgu), GRIT_E_BADARG, "grit_swiglu_bwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(swiglu_bwd_k, dim3(grid_for(T * (I / 8))), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)gu,
+                     (const uint16_t*)dact, (uint16_t*)dgu, T, I);
+  GRIT_CHECK_LAUNCH("grit_swiglu_bwd");
+  return GRIT_OK;
+}
+
+int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream) {
+  GRIT_REQUIRE(dh && ids && dtable, GRIT_E_BADARG, "grit_embed_scatter_add: null pointer");
+  GRIT_REQUIRE(T > 0 && H > 0 && V > 0 && H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_embed_scatter_add: bad sizes");
+  GRIT_REQUIRE(aligned16(dh), GRIT_E_BADARG, "grit_embed_scatter_add: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(embed_scatter_add_k, dim3(grid_for(T * (H / 8))), dim3(256), 0, (hipStream_t)stream, (const uint4*)dh, ids, dtable, T,
+                     H / 8, V);
+  GRIT_CHECK_LAUNCH("grit_embed_scatter_add");
+  return GRIT_OK;
+}
+
+int grit_accum_bf16_from_f32(void* acc, const float* x, int64_t n, void* stream) {
+  GRIT_REQUIRE(acc && x, GRIT_E_BADARG, "grit_accum_bf16_from_f32: null pointer");
+  GRIT_REQUIRE(n > 0, GRIT_E_BADARG, "grit_accum_bf16_from_f32: bad size");
+  hipLaunchKernelGGL(accum_bf16_from_f32_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)acc, x, n);
+  GRIT_CHECK_LAUNCH("grit_accum_bf16_from_f32");
+  return GRIT_OK;
+}
+
+}  // extern "C"

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) mask_pack_k(const int64_t* __restrict__ m
 
 // ---------------------------------------------------------------- bf16 transpose [R,C] -> [C,R]
 __global__ void __launch_bounds__(256) transpose_k(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t R,
-                                                   int64_t C) {
+                                                   int64_t C, int64_t ld_in, int64_t ld_out) {
   __shared__ uint16_t tile[64][72];
   const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) transpose_k(const uint16_t* __restrict__ 
     const int idx = tid + it * 256;  // 512 chunks of 8
     const int r = idx >> 3, cc = (idx & 7) * 8;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + r < R && c0 + cc < C) v = *reinterpret_cast<const uint4*>(in + (r0 + r) * C + c0 + cc);
+    if (r0 + r < R && c0 + cc < C) v = *reinterpret_cast<const uint4*>(in + (r0 + r) * ld_in + c0 + cc);
     *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
   }
   __syncthreads();
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) transpose_k(const uint16_t* __restrict__ 
       uint32_t w[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[rr + 2 * k][c] | ((uint32_t)tile[rr + 2 * k + 1][c] << 16);
-      *reinterpret_cast<uint4*>(out + (c0 + c) * R + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(out + (c0 + c) * ld_out + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
 }
@@ -245,13 +245,14 @@ int grit_mask_pack(const int64_t* mask, uint64_t* bits, int B, int S, void* stre
   return GRIT_OK;
 }
 
-int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, void* stream) {
+int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, void* stream) {
   GRIT_REQUIRE(in && out, GRIT_E_BADARG, "grit_transpose_bf16: null pointer");
   GRIT_REQUIRE(R > 0 && C > 0, GRIT_E_BADARG, "grit_transpose_bf16: bad sizes");
   GRIT_REQUIRE(R % 8 == 0 && C % 8 == 0, GRIT_E_UNSUPPORTED, "grit_transpose_bf16: R=%lld C=%lld must be multiples of 8", (long long)R, (long long)C);
+  GRIT_REQUIRE(ld_in >= C && ld_out >= R && ld_in % 8 == 0 && ld_out % 8 == 0, GRIT_E_BADARG, "grit_transpose_bf16: bad leading dimensions");
   GRIT_REQUIRE(aligned16(in) && aligned16(out), GRIT_E_BADARG, "grit_transpose_bf16: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(transpose_k, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)in, (uint16_t*)out, R, C);
+                     (const uint16_t*)in, (uint16_t*)out, R, C, ld_in, ld_out);
   GRIT_CHECK_LAUNCH("grit_transpose_bf16");
   return GRIT_OK;
 }

@@ -156,7 +156,7 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
   static bool attr_set = false;  // idempotent; benign race
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     attr_set = true;
   }
   hipLaunchKernelGGL(gemm_bf16_nt_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A,

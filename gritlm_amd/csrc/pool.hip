@@ -196,7 +196,7 @@ int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* i
   const size_t lds = 8 * (size_t)S + 64;
   static bool attr_set_f = false;
   if (!attr_set_f) {
-    hipFuncSetAttribute((const void*)pool_norm_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pool_norm_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set_f = true;
   }
   hipLaunchKernelGGL(pool_norm_fwd_k, dim3(B), dim3(POOL_THREADS), lds, (hipStream_t)stream, (const uint16_t*)hidden, mask, instr_len,
@@ -218,7 +218,7 @@ int grit_pool_norm_bwd(const float* y, const float* dy, const float* inv_norm, c
   if (B == 0) return GRIT_OK;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)pool_norm_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pool_norm_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(pool_norm_bwd_k, dim3(B), dim3(POOL_THREADS), lds, (hipStream_t)stream, y, dy, inv_norm, mask, instr_len,

@@ -174,8 +174,75 @@ def infonce(q: torch.Tensor, p: torch.Tensor, temperature: float, q_off: int = 0
     return loss, dq, dp
 
 
-def transpose(x: torch.Tensor) -> torch.Tensor:
+def transpose(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """[R,C] -> [C,R]; ``out`` may be a wider buffer [C, >=R] (zero-padded K for the wgrad GEMM)."""
     R, Cc = x.shape
-    out = torch.empty((Cc, R), dtype=BF16, device=x.device)
-    check(_lib.load().grit_transpose_bf16(_chk(x, BF16, "x"), _chk(out, BF16, "out"), R, Cc, _stream()), "grit_transpose_bf16")
+    if out is None:
+        out = torch.empty((Cc, R), dtype=BF16, device=x.device)
+    assert out.shape[0] == Cc and out.shape[1] >= R and x.stride(1) == 1 and out.stride(1) == 1
+    if x.dtype != BF16 or out.dtype != BF16 or not x.is_cuda:
+        raise TypeError("transpose: bf16 CUDA tensors expected")
+    check(_lib.load().grit_transpose_bf16(x.data_ptr(), out.data_ptr(), R, Cc, x.stride(0), out.stride(0), _stream()),
+          "grit_transpose_bf16")
     return out
+
+
+def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float, dw: torch.Tensor, dres: torch.Tensor | None = None,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    """dx (+ dres) -> out; dw [H] fp32 += sum_t dy * xhat."""
+    H = x.shape[-1]
+    T = x.numel() // H
+    if out is None:
+        out = torch.empty_like(x)
+    rows = _lib.load().grit_rmsnorm_bwd_workspace_rows(T)
+    part = torch.empty((rows, H), dtype=F32, device=x.device)
+    check(_lib.load().grit_rmsnorm_bwd(_chk(dy, BF16, "dy"), _chk(x, BF16, "x"), _chk(w, BF16, "w"),
+                                       0 if dres is None else _chk(dres, BF16, "dres"), _chk(out, BF16, "dx"), part.data_ptr(),
+                                       _chk(dw, F32, "dw"), T, H, float(eps), _stream()), "grit_rmsnorm_bwd")
+    return out
+
+
+def swiglu(gu: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    T, I2 = gu.shape
+    I = I2 // 2
+    if out is None:
+        out = torch.empty((T, I), dtype=BF16, device=gu.device)
+    check(_lib.load().grit_swiglu_fwd(_chk(gu, BF16, "gu"), _chk(out, BF16, "act"), T, I, _stream()), "grit_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(gu: torch.Tensor, dact: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    T, I2 = gu.shape
+    if out is None:
+        out = torch.empty_like(gu)
+    check(_lib.load().grit_swiglu_bwd(_chk(gu, BF16, "gu"), _chk(dact, BF16, "dact"), _chk(out, BF16, "dgu"), T, I2 // 2, _stream()),
+          "grit_swiglu_bwd")
+    return out
+
+
+def attn_bidir_bwd(qkv: torch.Tensor, key_bits: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, S: int,
+                   nq: int, nkv: int, d: int, dqkv: torch.Tensor | None = None, scale: float | None = None) -> torch.Tensor:
+    T, stride = qkv.shape
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if scale is None:
+        scale = d ** -0.5
+    delta = torch.empty((B, nq, S), dtype=F32, device=qkv.device)
+    check(_lib.load().grit_attn_bidir_bwd(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"),
+                                          _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"), delta.data_ptr(), _chk(dqkv, BF16, "dqkv"),
+                                          B, S, nq, nkv, d, stride, out.stride(0), float(scale), _stream()), "grit_attn_bidir_bwd")
+    return dqkv
+
+
+def embed_scatter_add(dh: torch.Tensor, ids: torch.Tensor, dtable: torch.Tensor):
+    V, H = dtable.shape
+    T = ids.numel()
+    check(_lib.load().grit_embed_scatter_add(_chk(dh, BF16, "dh"), _chk(ids, I64, "ids"), _chk(dtable, F32, "dtable"), T, H, V, _stream()),
+          "grit_embed_scatter_add")
+    return dtable
+
+
+def accum_bf16_from_f32(acc: torch.Tensor, x: torch.Tensor):
+    assert acc.numel() == x.numel()
+    check(_lib.load().grit_accum_bf16_from_f32(_chk(acc, BF16, "acc"), _chk(x, F32, "x"), acc.numel(), _stream()), "grit_accum_bf16_from_f32")
+    return acc

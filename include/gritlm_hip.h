@@ -116,8 +116,36 @@ int grit_infonce_fwd_bwd(const float* q, const float* p, float inv_temperature, 
 
 /* ---- helpers -------------------------------------------------------------------------------- */
 
-/* bf16 [R,C] -> [C,R] transpose (activations / weights for the dgrad / wgrad GEMMs). */
-int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, void* stream);
+/* bf16 [R,C] (row stride ld_in) -> [C,R] (row stride ld_out): operands of the dgrad / wgrad GEMMs
+ * (autograd of nn.Linear: dX = dY W needs W^T K-contiguous, dW = dY^T X needs dY^T and X^T). R, C % 8 == 0. */
+int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, void* stream);
+
+/* ---- backward of the encoder (contrastive step, GradCache pass 2: grad_cache.py:213-242) ------ */
+
+/* RMSNorm backward (+ optional residual-gradient add: dx = dres + d/dx).  dy,x [T,H] bf16, w [H] bf16 ->
+ * dx [T,H] bf16 (may alias dres); dw [H] fp32 is ACCUMULATED (+=).  dw_partial: fp32 workspace
+ * [grit_rmsnorm_bwd_workspace_rows(T), H]. */
+int64_t grit_rmsnorm_bwd_workspace_rows(int64_t T);
+int grit_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, float* dw_partial, float* dw,
+                     int64_t T, int H, float eps, void* stream);
+
+/* MistralMLP activation (:177-178) on the training engine's layout gu = [gate | up] ([T,2I] bf16, output of ONE GEMM
+ * against the concatenated weight): act[T,I] = silu(gate)*up, and its backward d(gu) from d(act). */
+int grit_swiglu_fwd(const void* gu, void* act, int64_t T, int I, void* stream);
+int grit_swiglu_bwd(const void* gu, const void* dact, void* dgu, int64_t T, int I, void* stream);
+
+/* Attention backward (flash-style recompute, deterministic, no atomics).  qkv/out/lse as in grit_attn_bidir_fwd,
+ * dout [B*S,out_stride] bf16 -> dqkv [B*S,qkv_stride] bf16 (gradients w.r.t. post-RoPE q, k and v; apply
+ * grit_rope_qk_inplace(inverse=1) afterwards).  delta: fp32 workspace [B,nq,S]. */
+int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+                        float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
+                        int64_t out_stride, float scale, void* stream);
+
+/* embedding backward: dtable[ids[t], :] += dh[t, :]  (dtable fp32 [V,H], fp32 atomics) */
+int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream);
+
+/* acc (bf16, n values) += x (fp32): folds an fp32 gradient into a bf16 .grad buffer */
+int grit_accum_bf16_from_f32(void* acc, const float* x, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -307,3 +307,52 @@ def pool_normalize_backward(hidden, pool_mask, method, normalized, grad_out):
         y = pooled / n
         g = (g - y * (y * g).sum(-1, keepdims=True)) / n
     return (w[..., None] * g[:, None, :]).astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# Analytic backward restatements (fp64) -- what torch autograd computes for the
+# reference ops; used to check the HIP backward kernels op by op.  The end-to-end
+# pin is tests/golden/gradcache_tiny.npz (parameter gradients of the reference).
+# ----------------------------------------------------------------------------
+def rmsnorm_backward(dy, x, weight, eps):
+    """d/dx, d/dw of MistralRMSNorm.forward (:84-89), roundings treated as identity."""
+    x = x.astype(F64); dy = dy.astype(F64); w = weight.astype(F64)
+    H = x.shape[-1]
+    rs = 1.0 / np.sqrt(np.mean(x ** 2, axis=-1, keepdims=True) + eps)
+    xhat = x * rs
+    dxhat = dy * w
+    dx = rs * (dxhat - xhat * np.mean(dxhat * xhat, axis=-1, keepdims=True))
+    dw = np.sum(dy * xhat, axis=tuple(range(x.ndim - 1)))
+    return dx.astype(F32), dw.astype(F32)
+
+
+def swiglu_backward(g, u, dact):
+    """d/dgate, d/dup of act_fn(gate) * up (:177-178, silu)."""
+    g = g.astype(F64); u = u.astype(F64); d = dact.astype(F64)
+    s = 1.0 / (1.0 + np.exp(-g))
+    return (d * u * s * (1.0 + g * (1.0 - s))).astype(F32), (d * g * s).astype(F32)
+
+
+def attention_bidirectional_backward(q, k, v, key_mask, dout):
+    """Backward of attention_bidirectional.  q [B,Hq,S,d], k,v [B,Hkv,S,d], dout [B,S,Hq*d]
+    -> dq [B,Hq,S,d], dk, dv [B,Hkv,S,d] (GQA: kv gradients summed over the group)."""
+    B, Hq, S, d = q.shape
+    Hkv = k.shape[1]
+    rep = Hq // Hkv
+    q64 = q.astype(F64)
+    kk = np.repeat(k, rep, axis=1).astype(F64); vv = np.repeat(v, rep, axis=1).astype(F64)
+    scale = 1.0 / np.sqrt(d)
+    sc = np.matmul(q64, kk.transpose(0, 1, 3, 2)) * scale
+    if key_mask is not None:
+        sc = sc + np.where(key_mask.astype(bool), 0.0, -np.inf)[:, None, None, :]
+    sc = sc - sc.max(-1, keepdims=True)
+    p = np.exp(sc); p /= p.sum(-1, keepdims=True)
+    do = dout.astype(F64).reshape(B, S, Hq, d).transpose(0, 2, 1, 3)
+    dv_full = np.matmul(p.transpose(0, 1, 3, 2), do)
+    dp = np.matmul(do, vv.transpose(0, 1, 3, 2))
+    ds = p * (dp - np.sum(dp * p, axis=-1, keepdims=True))
+    dq = np.matmul(ds, kk) * scale
+    dk_full = np.matmul(ds.transpose(0, 1, 3, 2), q64) * scale
+    dk = dk_full.reshape(B, Hkv, rep, S, d).sum(2)
+    dv = dv_full.reshape(B, Hkv, rep, S, d).sum(2)
+    return dq.astype(F32), dk.astype(F32), dv.astype(F32)

@@ -231,7 +231,84 @@ def check_infonce_big(nq=256, group=8, H=512, tau=0.02):
 
 def check_transpose(R=136, Cc=200):
     x = rnd((R, Cc), 23)
-    return _res("transpose", np.array_equal(f32(ops.transpose(bf(x))), x.T))
+    ok = np.array_equal(f32(ops.transpose(bf(x))), x.T)
+    wide = torch.zeros((Cc, 192), dtype=torch.bfloat16, device=DEV)          # padded-K wgrad operand
+    ops.transpose(bf(x), out=wide)
+    ok &= np.array_equal(f32(wide)[:, :R], x.T) and float(wide[:, R:].abs().max()) == 0.0
+    return _res("transpose", ok)
+
+
+def check_rmsnorm_bwd(T=50, H=256, with_res=True):
+    x, dy = rnd((T, H), 31, 1.5), rnd((T, H), 32)
+    w = O.bf16_round(1 + 0.1 * rnd((H,), 33))
+    dres = rnd((T, H), 34) if with_res else None
+    dx_ref, dw_ref = O.rmsnorm_backward(dy, x, w, 1e-5)
+    if with_res:
+        dx_ref = dx_ref + dres
+    dw = torch.full((H,), 0.5, dtype=torch.float32, device=DEV)              # accumulate semantics
+    dx = f32(ops.rmsnorm_bwd(bf(dy), bf(x), bf(w), 1e-5, dw, None if dres is None else bf(dres)))
+    e1 = float(np.max(np.abs(dx - dx_ref) / (1.2e-2 * np.abs(dx_ref) + 1e-2 * np.sqrt(np.mean(dx_ref ** 2)))))
+    e2 = float(np.max(np.abs(f32(dw) - 0.5 - dw_ref))) / float(np.abs(dw_ref).max())
+    return _res(f"rmsnorm_bwd[T={T},H={H},res={int(with_res)}]", e1 < 1.0 and e2 < 1e-3, dx_err_over_tol=e1, dw_rel=e2)
+
+
+def check_swiglu(T=37, I=512):
+    gu = rnd((T, 2 * I), 35, 1.5)
+    dact = rnd((T, I), 36)
+    g, u = gu[:, :I], gu[:, I:]
+    act_ref = O.bf16_round(O.silu(g.astype(np.float64)).astype(np.float32)) * u
+    dg, du = O.swiglu_backward(g, u, dact)
+    act = f32(ops.swiglu(bf(gu)))
+    dgu = f32(ops.swiglu_bwd(bf(gu), bf(dact)))
+    tol = lambda a, r: float(np.max(np.abs(a - r) / (1.2e-2 * np.abs(r) + 1e-2 * np.sqrt(np.mean(r ** 2)))))
+    e = max(tol(act, act_ref), tol(dgu[:, :I], dg), tol(dgu[:, I:], du))
+    return _res("swiglu fwd/bwd (concat layout)", e < 1.0, err_over_tol=e)
+
+
+def check_attention_bwd(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=41):
+    d = 128
+    width = (nq + 2 * nkv) * d
+    qkv = rnd((B * S, width), seed, 0.7)
+    dout = rnd((B * S, nq * d), seed + 3)
+    rng = np.random.default_rng(seed + 1)
+    mask = np.ones((B, S), dtype=np.int64)
+    if mask_kind == "ragged":
+        for b in range(1, B):
+            mask[b, rng.integers(S // 3, S):] = 0
+    elif mask_kind == "holes":
+        mask = (rng.random((B, S)) < 0.7).astype(np.int64); mask[:, 0] = 1
+    x = qkv.reshape(B, S, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
+    q, k, v = x[:, :nq], x[:, nq:nq + nkv], x[:, nq + nkv:]
+    dq, dk, dv = O.attention_bidirectional_backward(q, k, v, mask, dout.reshape(B, S, nq * d))
+    ref = np.concatenate([dq, dk, dv], axis=1).transpose(0, 2, 1, 3).reshape(B * S, width)
+    tq, bits = bf(qkv), ops.mask_pack(torch.from_numpy(mask).to(DEV))
+    lse = torch.empty((B, nq, S), dtype=torch.float32, device=DEV)
+    out = ops.attn_bidir(tq, bits, B, S, nq, nkv, d, lse=lse)
+    got = f32(ops.attn_bidir_bwd(tq, bits, out, bf(dout), lse, B, S, nq, nkv, d))
+    errs = {}
+    ok = not np.isnan(got).any()
+    for name, sl in (("dq", slice(0, nq * d)), ("dk", slice(nq * d, (nq + nkv) * d)), ("dv", slice((nq + nkv) * d, width))):
+        r, g_ = ref[:, sl], got[:, sl]
+        e = float(np.max(np.abs(g_ - r))) / (float(np.sqrt(np.mean(r ** 2))) + 1e-12)
+        errs[name + "_maxerr_over_rms"] = e
+        ok &= e < 6e-2
+    if not ok:
+        _dump(f"attn_bwd_{mask_kind}_{S}", qkv=qkv, mask=mask, dout=dout, got=got, ref=ref)
+    return _res(f"attention_bwd[B={B},S={S},nq={nq},nkv={nkv},{mask_kind}]", ok, **errs)
+
+
+def check_embed_scatter():
+    ids = np.array([[3, 5, 3, 7], [7, 7, 0, 3]], dtype=np.int64)
+    dh = rnd((8, 64), 43)
+    ref = np.zeros((9, 64), dtype=np.float64)
+    for t, i in enumerate(ids.reshape(-1)):
+        ref[i] += dh[t]
+    tab = torch.zeros((9, 64), dtype=torch.float32, device=DEV)
+    ops.embed_scatter_add(bf(dh), torch.from_numpy(ids).to(DEV).view(-1), tab)
+    acc = bf(rnd((9, 64), 44))
+    want = O.bf16_round(f32(acc) + f32(tab))
+    ops.accum_bf16_from_f32(acc, tab)
+    return _res("embed_scatter_add + accum_bf16", float(np.max(np.abs(f32(tab) - ref))) < 1e-5 and np.array_equal(f32(acc), want))
 
 
 def build_engine(cfg_name, seed=0):
@@ -352,6 +429,13 @@ ALL_CHECKS = [
     ("infonce_local", check_infonce_local_rows, {}),
     ("infonce_big", check_infonce_big, {}),
     ("transpose", check_transpose, {}),
+    ("rmsnorm_bwd", check_rmsnorm_bwd, {}),
+    ("rmsnorm_bwd_4096", check_rmsnorm_bwd, dict(T=21, H=4096, with_res=False)),
+    ("swiglu", check_swiglu, {}),
+    ("attn_bwd_ragged", check_attention_bwd, {}),
+    ("attn_bwd_holes", check_attention_bwd, dict(mask_kind="holes", S=130, B=2, nq=2, nkv=1)),
+    ("attn_bwd_full", check_attention_bwd, dict(mask_kind="none", S=256, B=1, nq=8, nkv=2)),
+    ("embed_scatter", check_embed_scatter, {}),
     ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
