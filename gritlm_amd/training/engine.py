@@ -1,0 +1,242 @@
+"""Native forward+backward engine for the contrastive training step (GradCache pass 1 / pass 2).
+
+Binds to the parameters of a Hugging Face ``MistralModel`` WITHOUT copying them: the fused QKV and [gate | up]
+weights live in packed storage and the module's ``q_proj/k_proj/v_proj`` and ``gate_proj/up_proj`` parameters are
+re-pointed to row-slices of it (views), so ``state_dict()`` keeps the reference names (checkpoints stay
+interchangeable), the optimizer updates the packed storage in place, and the kernels see ONE [N,K] weight.
+Gradients are written by the wgrad GEMMs straight into packed ``.grad`` storage (bf16, accumulated across GradCache
+chunks by the GEMM's residual epilogue), exactly what ``param.grad`` accumulation does in the reference.
+
+Replaces, for the embedding tower: torch autograd through scripts/modeling_mistral_gritlm.py + HF gradient
+checkpointing (gritlm/training/run.py:83-84).  Memory is laid out for 288 GB HBM: pass 2 keeps every intermediate of
+the chunk (no recompute => 3x forward FLOPs per chunk instead of the reference's 4x).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from .._lib import EPI_RESIDUAL, EPI_STORE
+from ..encoder import EncoderConfig, rope_tables
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class _LayerParams:
+    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "gqkv", "go", "ggu", "gdown", "mods")
+
+
+class SavedForward:
+    """Everything pass 2 keeps from the forward of one chunk."""
+    __slots__ = ("ids", "mask", "bits", "B", "S", "layers", "h_final", "x_final")
+
+
+class MistralTrainEngine:
+    def __init__(self, backbone: torch.nn.Module, hf_config, device):
+        self.cfg = EncoderConfig.from_hf(hf_config)
+        self.cfg.check_supported()
+        self.device = torch.device(device)
+        self.backbone = backbone
+        self.rope_bf16 = True
+        self._rope = {}
+        self._tbuf = {}
+        self._wT = {}
+        self.cache_transposed_weights = False
+        c = self.cfg
+        if any(p.dtype != BF16 for p in backbone.parameters()):
+            raise RuntimeError("MistralTrainEngine: parameters must be bfloat16 (load the model with torch_dtype=bfloat16)")
+        self.embed = backbone.embed_tokens.weight
+        self.norm = backbone.norm.weight
+        self.layers: list[_LayerParams] = []
+        for layer in backbone.layers:
+            L = _LayerParams()
+            at, mlp = layer.self_attn, layer.mlp
+            L.wqkv = self._pack([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight])
+            L.wgu = self._pack([mlp.gate_proj.weight, mlp.up_proj.weight])
+            L.wo, L.wdown = at.o_proj.weight, mlp.down_proj.weight
+            L.ln1, L.ln2 = layer.input_layernorm.weight, layer.post_attention_layernorm.weight
+            L.mods = (at, mlp, layer)
+            L.gqkv = L.ggu = L.go = L.gdown = None
+            self.layers.append(L)
+        self._g_embed = None
+        self._g_norm = None
+        self._f32_norm_grads = None
+        self._f32_embed_grad = None
+
+    # ------------------------------------------------------------------ parameter packing
+    def _pack(self, params):
+        rows = sum(p.shape[0] for p in params)
+        packed = torch.empty((rows, params[0].shape[1]), dtype=BF16, device=self.device)
+        r = 0
+        for p in params:
+            n = p.shape[0]
+            packed[r:r + n].copy_(p.data)
+            p.data = packed[r:r + n]          # the module parameter is now a view of the packed storage
+            r += n
+        return packed
+
+    def _packed_grad(self, params, current):
+        """(Re)attach ``.grad`` views of one packed gradient buffer; zero it when the optimizer cleared the grads."""
+        rows = sum(p.shape[0] for p in params)
+        fresh = current is None or any(p.grad is None for p in params)
+        if current is None:
+            current = torch.zeros((rows, params[0].shape[1]), dtype=BF16, device=self.device)
+        elif fresh:
+            current.zero_()
+        if fresh:
+            r = 0
+            for p in params:
+                n = p.shape[0]
+                p.grad = current[r:r + n]
+                r += n
+        return current
+
+    def prepare_grads(self):
+        c = self.cfg
+        for L in self.layers:
+            at, mlp, layer = L.mods
+            L.gqkv = self._packed_grad([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], L.gqkv)
+            L.ggu = self._packed_grad([mlp.gate_proj.weight, mlp.up_proj.weight], L.ggu)
+            L.go = self._packed_grad([at.o_proj.weight], L.go)
+            L.gdown = self._packed_grad([mlp.down_proj.weight], L.gdown)
+        # 1-D parameters and the embedding: plain .grad tensors
+        for p in [self.embed, self.norm] + [x for L in self.layers for x in (L.ln1, L.ln2)]:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        if self._f32_norm_grads is None:
+            self._f32_norm_grads = torch.zeros((2 * len(self.layers) + 1, c.hidden_size), dtype=F32, device=self.device)
+
+    def weights_updated(self):
+        """Call after optimizer.step(): transposed-weight cache is stale."""
+        self._wT.clear()
+
+    # ------------------------------------------------------------------ helpers
+    def _rope_tables(self, S):
+        t = self._rope.get(S)
+        if t is None:
+            t = rope_tables(S, self.cfg.head_dim, self.cfg.rope_theta, self.rope_bf16, self.device)
+            self._rope[S] = t
+        return t
+
+    def _transposed_act(self, x: torch.Tensor, tag: str) -> torch.Tensor:
+        """x [T,N] -> x^T in a zero-padded [N, pad64(T)] buffer (K operand of the wgrad GEMM)."""
+        T, N = x.shape
+        key = (tag, N, _pad64(T))
+        buf = self._tbuf.get(key)
+        if buf is None:
+            buf = torch.zeros((N, _pad64(T)), dtype=BF16, device=self.device)
+            self._tbuf[key] = buf
+        elif buf.shape[1] != T:
+            buf[:, T:].zero_()
+        ops.transpose(x, out=buf)
+        return buf
+
+    def _wt(self, li: int, name: str, w: torch.Tensor) -> torch.Tensor:
+        key = (li, name)
+        t = self._wT.get(key) if self.cache_transposed_weights else None
+        if t is None:
+            t = ops.transpose(w.data)
+            if self.cache_transposed_weights:
+                self._wT[key] = t
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool):
+        """Returns (last_hidden_state [B,S,H] bf16, SavedForward | None)."""
+        c = self.cfg
+        B, S = input_ids.shape
+        T = B * S
+        dev = self.device
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+        mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        H, I = c.hidden_size, c.intermediate_size
+        cos, sin = self._rope_tables(S)
+        bits = ops.mask_pack(mask)
+        mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
+        h = ops.embed_gather(self.embed.data, ids, out=mk(H))
+        saved = SavedForward() if save else None
+        if save:
+            saved.ids, saved.mask, saved.bits, saved.B, saved.S, saved.layers = ids, mask, bits, B, S, []
+        x1 = qkv = ctx = x2 = gu = act = None
+        for L in self.layers:
+            if save or x1 is None:
+                x1, qkv, ctx, x2, gu, act = mk(H), mk((nq + 2 * nkv) * d), mk(nq * d), mk(H), mk(2 * I), mk(I)
+            lse = torch.empty((B, nq, S), dtype=F32, device=dev) if save else None
+            ops.rmsnorm(h, L.ln1.data, eps, out=x1)
+            ops.gemm_nt(x1, L.wqkv, out=qkv)
+            ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
+            ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, lse=lse)
+            h_mid = mk(H) if save else h
+            ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
+            ops.rmsnorm(h_mid, L.ln2.data, eps, out=x2)
+            ops.gemm_nt(x2, L.wgu, out=gu)
+            ops.swiglu(gu, out=act)
+            h_out = mk(H) if save else h_mid
+            ops.gemm_nt(act, L.wdown.data, out=h_out, epilogue=EPI_RESIDUAL, residual=h_mid)
+            if save:
+                saved.layers.append(dict(h_in=h, x1=x1, qkv=qkv, ctx=ctx, lse=lse, h_mid=h_mid, x2=x2, gu=gu, act=act))
+            h = h_out
+        xf = ops.rmsnorm(h, self.norm.data, eps, out=mk(H))
+        if save:
+            saved.h_final, saved.x_final = h, xf
+        return xf.view(B, S, H), saved
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, saved: SavedForward, d_last_hidden: torch.Tensor):
+        """Accumulate parameter gradients for d loss / d last_hidden_state = ``d_last_hidden`` [B,S,H] bf16."""
+        c = self.cfg
+        self.prepare_grads()
+        B, S = saved.B, saved.S
+        T = B * S
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        H = c.hidden_size
+        cos, sin = self._rope_tables(S)
+        ng = self._f32_norm_grads
+        nL = len(self.layers)
+        dy = d_last_hidden.reshape(T, H).contiguous()
+        dh = ops.rmsnorm_bwd(dy, saved.h_final, self.norm.data, eps, ng[2 * nL])
+        for li in range(nL - 1, -1, -1):
+            L, sv = self.layers[li], saved.layers[li]
+            # ---- MLP: h_out = h_mid + down(silu(gate) * up)
+            dact = ops.gemm_nt(dh, self._wt(li, "down", L.wdown))                       # [T,I] = dh @ Wdown
+            dhT = self._transposed_act(dh, "dh")
+            ops.gemm_nt(dhT, self._transposed_act(sv["act"], "act"), out=L.gdown, epilogue=EPI_RESIDUAL, residual=L.gdown)
+            dgu = ops.swiglu_bwd(sv["gu"], dact)
+            dx2 = ops.gemm_nt(dgu, self._wt(li, "gu", L.wgu))                           # [T,H]
+            ops.gemm_nt(self._transposed_act(dgu, "dgu"), self._transposed_act(sv["x2"], "x"), out=L.ggu, epilogue=EPI_RESIDUAL,
+                        residual=L.ggu)
+            dh_mid = ops.rmsnorm_bwd(dx2, sv["h_mid"], L.ln2.data, eps, ng[2 * li + 1], dres=dh)
+            # ---- attention: h_mid = h_in + o_proj(attn(rope(qkv(x1))))
+            dctx = ops.gemm_nt(dh_mid, self._wt(li, "o", L.wo))                         # [T,nq*d]
+            ops.gemm_nt(self._transposed_act(dh_mid, "dh"), self._transposed_act(sv["ctx"], "ctx"), out=L.go, epilogue=EPI_RESIDUAL,
+                        residual=L.go)
+            dqkv = ops.attn_bidir_bwd(sv["qkv"], saved.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d)
+            ops.rope_qk_(dqkv, cos, sin, S, nq, nkv, d, inverse=True)
+            dx1 = ops.gemm_nt(dqkv, self._wt(li, "qkv", L.wqkv))                        # [T,H]
+            ops.gemm_nt(self._transposed_act(dqkv, "dqkv"), self._transposed_act(sv["x1"], "x"), out=L.gqkv, epilogue=EPI_RESIDUAL,
+                        residual=L.gqkv)
+            dh = ops.rmsnorm_bwd(dx1, sv["h_in"], L.ln1.data, eps, ng[2 * li], dres=dh_mid)
+        # ---- embedding + fold the fp32 side accumulators into the bf16 .grad tensors
+        if self._f32_embed_grad is None:
+            self._f32_embed_grad = torch.zeros(tuple(self.embed.shape), dtype=F32, device=self.device)
+        ops.embed_scatter_add(dh, saved.ids, self._f32_embed_grad)
+        ops.accum_bf16_from_f32(self.embed.grad, self._f32_embed_grad)
+        self._f32_embed_grad.zero_()
+        for li, L in enumerate(self.layers):
+            ops.accum_bf16_from_f32(L.ln1.grad, ng[2 * li])
+            ops.accum_bf16_from_f32(L.ln2.grad, ng[2 * li + 1])
+        ops.accum_bf16_from_f32(self.norm.grad, ng[2 * nL])
+        ng.zero_()
+
+    def grad_buffers(self) -> list[torch.Tensor]:
+        """Flat list of gradient storages (few, large): the buckets of the data-parallel all-reduce."""
+        self.prepare_grads()
+        out = []
+        for L in self.layers:
+            out += [L.gqkv, L.go, L.ggu, L.gdown, L.ln1.grad, L.ln2.grad]
+        return out + [self.embed.grad, self.norm.grad]

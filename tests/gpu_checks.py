@@ -394,6 +394,50 @@ def check_gritlm_native_encode():
     return _res("GritLM.encode native vs reference GritLM.encode goldens", ok, **out)
 
 
+_NAMES = ["layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight", "norm.weight", "layers.0.input_layernorm.weight",
+          "layers.1.self_attn.v_proj.weight", "embed_tokens.weight"]
+
+
+def check_train_step(mode="direct"):
+    """Native contrastive step (HIP forward + backward + InfoNCE kernel) vs the REFERENCE's loss and parameter gradients
+    (tests/golden/gradcache_tiny.npz: GritLMTrainModel.forward + backward, and the vendored GradCache, fp32 on CPU)."""
+    import tempfile
+    from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+    g = np.load(os.path.join(GOLDEN, "gradcache_tiny.npz"))
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        m = GritLMTrainModel(model_name_or_path=d16, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=0.02, negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16)
+        m.enable_native()
+        q = {"input_ids": torch.from_numpy(g["q_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["q_mask"]).to(DEV)}
+        p = {"input_ids": torch.from_numpy(g["p_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["p_mask"]).to(DEV)}
+        if mode == "direct":
+            o = m(query=q, passage=p)
+            loss = o.loss
+            loss.backward()
+            qr = f32(o.q_reps)
+            out["q_reps_1-cos"] = float(np.max(1 - np.sum(qr * g["q_reps"], axis=1)))
+            ok &= out["q_reps_1-cos"] < 1e-4
+        else:
+            loss = GradCacheStep(m, chunk_size=2)(q, p)
+        ref_loss = float(g["loss_direct" if mode == "direct" else "loss_gradcache"])
+        out["loss"] = float(loss.item()); out["loss_ref"] = ref_loss
+        ok &= abs(out["loss"] - ref_loss) < 2e-2 * max(1.0, abs(ref_loss))
+        sd = dict(m._backbone().named_parameters())
+        worst = 0.0
+        for n in _NAMES:
+            ref = g[("grad_direct/" if mode == "direct" else "grad_gradcache/") + n]
+            got = f32(sd[n].grad)
+            rel = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-20))
+            out[n.replace("layers.", "L").replace(".weight", "")] = rel
+            worst = max(worst, rel)
+        ok &= worst < 6e-2
+        # state_dict keeps the reference names although q/k/v and gate/up live in packed storage
+        ok &= all(k in m.model.state_dict() for k in ("layers.0.self_attn.k_proj.weight", "layers.1.mlp.up_proj.weight"))
+    return _res(f"native train step [{mode}] vs reference loss+grads", ok, **out)
+
+
 ALL_CHECKS = [
     ("embed", check_embed, {}),
     ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
@@ -440,4 +484,6 @@ ALL_CHECKS = [
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
     ("gritlm_native_encode", check_gritlm_native_encode, {}),
+    ("train_direct", check_train_step, dict(mode="direct")),
+    ("train_gradcache", check_train_step, dict(mode="gradcache")),
 ]
