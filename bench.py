@@ -77,6 +77,61 @@ def cpu_baseline(sample_docs=16, seq=SEQ, layers=2):
             "raw_docs_per_s_reduced_model": raw, "seconds": dt}
 
 
+def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, steps=2, warmup=1):
+    """Second headline metric: contrastive pairs/s.  One step = GradCache contrastive step on (q, pos, 7 neg) @ seq512:
+    pass 1 (no grad) -> packed all-gather of the reps (N > 1) -> fused InfoNCE -> pass 2 forward+backward per chunk ->
+    gradient all-reduce (N > 1) -> AdamW.  `pairs` per rank is reduced from BASELINE configs[2]'s 256 to keep the default
+    run short (per-pair work is identical: every pair is 9 sequences x 512 tokens through the same kernels)."""
+    from gritlm_amd.training.engine import MistralTrainEngine, SyntheticBackbone
+    from gritlm_amd.training.gradcache import GradCacheStep
+    from gritlm_amd.training.model import DistributedContrastiveLoss, GritLMTrainModel
+    bb = SyntheticBackbone(cfg, dev, seed=1)
+    m = GritLMTrainModel.__new__(GritLMTrainModel)
+    torch.nn.Module.__init__(m)
+    m.model, m.embedding_attr, m.projection, m.normalized, m.pooling_method, m.attn = bb, None, None, True, "mean", "bbcc"
+    m.emb_loss_fn = DistributedContrastiveLoss(0.02, world > 1)
+    m.train_engine = MistralTrainEngine(bb, cfg, dev)
+    opt = torch.optim.AdamW(bb.parameters(), lr=1e-5, fused=True)
+    gc = GradCacheStep(m, chunk)
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    mk = lambda n: {"input_ids": torch.randint(3, cfg.vocab_size, (n, SEQ), generator=gen, device=dev, dtype=torch.int64),
+                    "attention_mask": torch.ones((n, SEQ), dtype=torch.int64, device=dev)}
+    q, p = mk(pairs), mk(pairs * group)
+
+    def step():
+        loss = gc(q, p)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        m.train_engine.weights_updated()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    pairs_per_s = world * pairs * steps / dt
+    eng_flops = 2.0 * cfg.num_hidden_layers * (cfg.hidden_size * (6144) + 4096 * cfg.hidden_size + 3 * cfg.hidden_size * cfg.intermediate_size) \
+        + 4.0 * cfg.num_hidden_layers * SEQ * 4096
+    alg_flops_per_pair = 3.0 * eng_flops * SEQ * (1 + group)          # fwd + bwd = 3 x forward; recompute passes are overhead
+    return {"metric": "contrastive pairs/sec @ seq512", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
+            "global_batch": world * pairs, "loss": float(loss),
+            "includes": "GradCache pass 1 + InfoNCE + pass 2 fwd/bwd + grad all-reduce + AdamW",
+            "mfma_roofline_frac": pairs_per_s / world * alg_flops_per_pair / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=32, help="debug only; anything but 32 marks the line invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-contrastive", action="store_true", help="skip the contrastive pairs/s leg")
+    ap.add_argument("--pairs", type=int, default=16, help="contrastive pairs per GPU per step (BASELINE configs[2]: 256)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,18 +189,25 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_timer(None)
     assert torch.isfinite(emb).all(), "non-finite embeddings"
+    flops_per_token = eng.flops_per_token(SEQ)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    contrastive = None
+    if not args.no_contrastive:
+        del eng, emb
+        torch.cuda.empty_cache()
+        contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs)
+
     if rank == 0:
         ks = timer.summary()
         g = ks["gemm_bf16_nt"]
         achieved = g["work"] / (g["total_ms"] * 1e-3) / 1e12           # TFLOP/s over all launches == avg flops / avg duration
         docs_per_s = world * DOCS * args.steps / dt_max
-        flops_per_doc = eng.flops_per_token(SEQ) * SEQ
+        flops_per_doc = flops_per_token * SEQ
         line = {
             "metric": "encoded docs/sec @ seq512", "value": docs_per_s, "unit": "docs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -159,6 +223,8 @@ def main():
             "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                             "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()},
         }
+        if contrastive is not None:
+            line["contrastive"] = contrastive
         if args.layers != 32:
             line["INVALID"] = "debug run with --layers != 32"
         if world == 1 and not args.no_cpu_baseline:

@@ -37,7 +37,7 @@ class SavedForward:
 
 class MistralTrainEngine:
     def __init__(self, backbone: torch.nn.Module, hf_config, device):
-        self.cfg = EncoderConfig.from_hf(hf_config)
+        self.cfg = hf_config if isinstance(hf_config, EncoderConfig) else EncoderConfig.from_hf(hf_config)
         self.cfg.check_supported()
         self.device = torch.device(device)
         self.backbone = backbone
@@ -240,3 +240,40 @@ class MistralTrainEngine:
         for L in self.layers:
             out += [L.gqkv, L.go, L.ggu, L.gdown, L.ln1.grad, L.ln2.grad]
         return out + [self.embed.grad, self.norm.grad]
+
+
+class SyntheticBackbone(torch.nn.Module):
+    """Parameter container with the attribute layout of HF ``MistralModel`` (embed_tokens, layers[i].self_attn.{q,k,v,o}_proj,
+    layers[i].mlp.{gate,up,down}_proj, layers[i].{input,post_attention}_layernorm, norm), random-initialised directly on the
+    device in bf16.  For benchmarks / tests that need the 7B shape without materialising a Hugging Face model on the host."""
+
+    def __init__(self, cfg: EncoderConfig, device, seed: int = 0, std: float = 0.02):
+        super().__init__()
+        gen = torch.Generator(device=device).manual_seed(seed)
+        H, I, d = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+        nq, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+
+        def lin(o, i):
+            m = torch.nn.Linear(i, o, bias=False, device=device, dtype=BF16)
+            m.weight.data.copy_((torch.randn((o, i), generator=gen, device=device, dtype=F32) * std).to(BF16))
+            return m
+
+        class _Norm(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.weight = torch.nn.Parameter((1.0 + 0.1 * torch.randn((H,), generator=gen, device=device, dtype=F32)).to(BF16))
+
+        self.embed_tokens = torch.nn.Embedding(cfg.vocab_size, H, device=device, dtype=BF16)
+        self.embed_tokens.weight.data.copy_((torch.randn((cfg.vocab_size, H), generator=gen, device=device, dtype=F32) * std).to(BF16))
+        self.layers = torch.nn.ModuleList()
+        for _ in range(cfg.num_hidden_layers):
+            layer = torch.nn.Module()
+            layer.self_attn = torch.nn.Module()
+            layer.self_attn.q_proj, layer.self_attn.k_proj = lin(nq * d, H), lin(nkv * d, H)
+            layer.self_attn.v_proj, layer.self_attn.o_proj = lin(nkv * d, H), lin(H, nq * d)
+            layer.mlp = torch.nn.Module()
+            layer.mlp.gate_proj, layer.mlp.up_proj, layer.mlp.down_proj = lin(I, H), lin(I, H), lin(H, I)
+            layer.input_layernorm, layer.post_attention_layernorm = _Norm(), _Norm()
+            self.layers.append(layer)
+        self.norm = _Norm()
+        self.config = cfg

@@ -37,8 +37,9 @@ def packed_all_gather(q: Tensor, p: Tensor, world_size: int):
     in rank order (= the ``torch.cat`` order of the reference, :57-58, which the targets ``arange(B) * G`` rely on)."""
     bq, bp = q.shape[0], p.shape[0]
     packed = torch.cat([q, p], dim=0).contiguous()
-    out = torch.empty((world_size,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed)
+    flat = torch.empty((world_size * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(flat, packed)           # concatenated layout: works on RCCL and gloo alike
+    out = flat.view((world_size,) + tuple(packed.shape))
     return out[:, :bq].reshape(world_size * bq, -1).contiguous(), out[:, bq:].reshape(world_size * bp, -1).contiguous()
 
 
@@ -94,8 +95,9 @@ class DistributedContrastiveLoss:
         if t is None:
             return None
         t = t.contiguous()
-        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t.detach())
+        flat = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(flat, t.detach())
+        out = flat.view((self.world_size,) + tuple(t.shape))
         parts = [out[r] for r in range(self.world_size)]
         parts[self.rank] = t
         return torch.cat(parts, dim=0)

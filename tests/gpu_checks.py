@@ -438,6 +438,31 @@ def check_train_step(mode="direct"):
     return _res(f"native train step [{mode}] vs reference loss+grads", ok, **out)
 
 
+def check_cli_native():
+    """python -m gritlm.training.run on the GPU: bf16 tiny Mistral, (instruction, text) rows, GradCache switch, native engine."""
+    import json
+    import tempfile
+    from gritlm.training.run import main
+    W = synth.WORDS
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        rows = []
+        for i in range(0, 64, 2):
+            negs = [["w3", " ".join(W[j:j + 7])] for j in range(i + 20, i + 27)]
+            rows.append({"query": ["w1 w2", " ".join(W[i:i + 5])], "pos": [["w3", " ".join(W[i + 1:i + 9])]], "neg": negs})
+        data = os.path.join(td, "toy.jsonl")
+        open(data, "w").write("\n".join(json.dumps(r) for r in rows))
+        out = os.path.join(td, "out")
+        common = ["--model_name_or_path", d16, "--train_data", data, "--output_dir", out, "--bf16", "--per_device_train_batch_size", "2",
+                  "--gradient_accumulation_steps", "4", "--no_gen_gas", "--no_emb_gas", "--train_group_size", "8", "--pooling_method", "mean",
+                  "--learning_rate", "2e-4", "--query_max_len", "24", "--passage_max_len", "40", "--report_to", "none", "--logging_steps", "1"]
+        l1 = main(common + ["--max_steps", "1"])
+        l8 = main(common + ["--max_steps", "8"])
+        files = os.listdir(out)
+    ok = np.isfinite(l1) and np.isfinite(l8) and l8 < l1 and "config.json" in files
+    return _res("CLI gritlm.training.run native (loss decreases over 8 steps)", ok, loss_step1=float(l1), loss_step8=float(l8))
+
+
 ALL_CHECKS = [
     ("embed", check_embed, {}),
     ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
@@ -486,4 +511,5 @@ ALL_CHECKS = [
     ("gritlm_native_encode", check_gritlm_native_encode, {}),
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
+    ("cli_native", check_cli_native, {}),
 ]

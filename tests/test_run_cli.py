@@ -1,0 +1,61 @@
+"""CPU: the training entry point end to end on reference-format jsonl rows (query / pos / neg, 7 negatives like
+gritlm/training/toy_data) through the drop-in module path ``gritlm.training.run``; GradCache switch; outputs."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import synth
+
+
+def _toy(path, instruct=False):
+    W = synth.WORDS
+    rows = []
+    for i in range(0, 40, 2):
+        q, pos, negs = " ".join(W[i:i + 5]), " ".join(W[i + 1:i + 9]), [" ".join(W[j:j + 7]) for j in range(i + 20, i + 27)]
+        if instruct:
+            rows.append({"query": ["w1 w2", q], "pos": [["w3", pos]], "neg": [["w3", n] for n in negs]})
+        else:
+            rows.append({"query": q, "pos": [pos], "neg": negs})
+    with open(path, "w") as f:
+        f.write("\n".join(json.dumps(r) for r in rows))
+    return path
+
+
+def test_cli_gradcache_two_steps(tmp_path):
+    from gritlm.training.run import main          # the drop-in alias
+    d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
+    data = _toy(str(tmp_path / "toy.jsonl"))
+    out = str(tmp_path / "out")
+    loss = main(["--model_name_or_path", d, "--train_data", data, "--output_dir", out, "--per_device_train_batch_size", "2",
+                 "--gradient_accumulation_steps", "2", "--no_gen_gas", "--no_emb_gas", "--train_group_size", "8", "--pooling_method", "mean",
+                 "--max_steps", "2", "--learning_rate", "1e-4", "--query_max_len", "16", "--passage_max_len", "24", "--report_to", "none",
+                 "--use_cpu"])
+    assert np.isfinite(loss)
+    files = set(os.listdir(out))
+    assert {"config.json", "dataset_num_samples.json", "tokenizer.json"} <= files
+    assert json.load(open(os.path.join(out, "dataset_num_samples.json"))) == {"toy.jsonl": 20}
+    from safetensors import safe_open
+    wfile = [f for f in files if f.endswith(".safetensors") or f.endswith(".bin")][0]
+    if wfile.endswith(".safetensors"):
+        with safe_open(os.path.join(out, wfile), "pt") as f:
+            keys = set(f.keys())
+    else:
+        keys = set(torch.load(os.path.join(out, wfile)).keys())
+    assert any(k.endswith("layers.0.self_attn.k_proj.weight") for k in keys)      # reference parameter names
+
+
+def test_collator_instruction_format(tmp_path):
+    from transformers import AutoTokenizer
+    from gritlm_amd.training.data import EmbeddingCollator, EmbeddingDataset, load_embedding_rows
+    synth.make_tokenizer(str(tmp_path / "tok"))
+    tok = AutoTokenizer.from_pretrained(str(tmp_path / "tok"), padding_side="right")
+    rows = load_embedding_rows(_toy(str(tmp_path / "toy_i.jsonl"), instruct=True))
+    ds = EmbeddingDataset(rows, train_group_size=4, max_char_len=1000, seed=0)
+    batch = EmbeddingCollator(tok, 32, 48)([ds[0], ds[1], ds[2]])
+    assert batch["query"]["input_ids"].shape[0] == 3 and batch["passage"]["input_ids"].shape[0] == 12
+    assert batch["query"]["instruction_lens"].shape == (3,) and batch["passage"]["instruction_lens"].shape == (12,)
+    # the instruction prefix is a strict prefix of the row: there is text left to embed
+    for i, l in enumerate(batch["query"]["instruction_lens"].tolist()):
+        assert batch["query"]["attention_mask"][i, l] == 1
