@@ -60,12 +60,17 @@ __global__ void __launch_bounds__(256) rmsnorm_bwd_k(const uint4* __restrict__ d
   for (int i = tid; i < H; i += 256) outp[i] = acc[i];
 }
 
+// one workgroup per 64 columns: 4 waves split the partial rows, lanes are consecutive columns (coalesced 256-B rows)
 __global__ void __launch_bounds__(256) rmsnorm_dw_reduce_k(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int H) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * H + i];
-  dw[i] += s;
+  if (i < H)
+    for (int b = wave; b < nblk; b += 4) s += partial[(int64_t)b * H + i];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && i < H) dw[i] += red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 // ---------------------------------------------------------------- SwiGLU on the concatenated layout gu = [gate | up], [T, 2I]
@@ -165,7 +170,7 @@ int grit_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* d
   hipLaunchKernelGGL(rmsnorm_bwd_k, dim3(nblk), dim3(256), (size_t)H * 4, st, (const uint4*)dy, (const uint4*)x, (const uint4*)w,
                      (const uint4*)dres, (uint4*)dx, dw_partial, T, H, eps);
   GRIT_CHECK_LAUNCH("grit_rmsnorm_bwd");
-  hipLaunchKernelGGL(rmsnorm_dw_reduce_k, dim3((H + 255) / 256), dim3(256), 0, st, (const float*)dw_partial, dw, nblk, H);
+  hipLaunchKernelGGL(rmsnorm_dw_reduce_k, dim3((H + 63) / 64), dim3(256), 0, st, (const float*)dw_partial, dw, nblk, H);
   GRIT_CHECK_LAUNCH("grit_rmsnorm_bwd: reduce");
   return GRIT_OK;
 }

@@ -248,8 +248,10 @@ int grit_mask_pack(const int64_t* mask, uint64_t* bits, int B, int S, void* stre
 int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, void* stream) {
   GRIT_REQUIRE(in && out, GRIT_E_BADARG, "grit_transpose_bf16: null pointer");
   GRIT_REQUIRE(R > 0 && C > 0, GRIT_E_BADARG, "grit_transpose_bf16: bad sizes");
-  GRIT_REQUIRE(R % 8 == 0 && C % 8 == 0, GRIT_E_UNSUPPORTED, "grit_transpose_bf16: R=%lld C=%lld must be multiples of 8", (long long)R, (long long)C);
-  GRIT_REQUIRE(ld_in >= C && ld_out >= R && ld_in % 8 == 0 && ld_out % 8 == 0, GRIT_E_BADARG, "grit_transpose_bf16: bad leading dimensions");
+  GRIT_REQUIRE(C % 8 == 0, GRIT_E_UNSUPPORTED, "grit_transpose_bf16: C=%lld must be a multiple of 8", (long long)C);
+  // output rows are written in 16-byte groups of 8 source rows: the tail group is zero-filled up to the next multiple of 8
+  GRIT_REQUIRE(ld_in >= C && ld_out >= (R + 7) / 8 * 8 && ld_in % 8 == 0 && ld_out % 8 == 0, GRIT_E_BADARG,
+               "grit_transpose_bf16: bad leading dimensions (ld_out must cover R rounded up to 8)");
   GRIT_REQUIRE(aligned16(in) && aligned16(out), GRIT_E_BADARG, "grit_transpose_bf16: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(transpose_k, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)in, (uint16_t*)out, R, C, ld_in, ld_out);

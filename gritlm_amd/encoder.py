@@ -63,11 +63,15 @@ class EncoderConfig:
             raise GritHipError("native encoder: num_attention_heads must be a multiple of num_key_value_heads")
 
 
-def swiglu_interleave(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
-    """[I,H],[I,H] -> [2I,H] with rows [16b,16b+16) of gate followed by the same rows of up (GRIT_EPI_SWIGLU)."""
+def swiglu_interleave(gate: torch.Tensor, up: torch.Tensor, block: int | None = None) -> torch.Tensor:
+    """[I,H],[I,H] -> [2I,H]: ``block`` rows of gate followed by the same rows of up, repeated (GRIT_EPI_SWIGLU layout;
+    ``block`` = grit_swiglu_block() of the built kernel)."""
+    from . import _lib
+    if block is None:
+        block = _lib.load().grit_swiglu_block()
     I, H = gate.shape
-    assert I % 16 == 0
-    return torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], dim=1).reshape(2 * I, H).contiguous()
+    assert I % block == 0, f"intermediate size {I} must be a multiple of {block}"
+    return torch.stack([gate.view(I // block, block, H), up.view(I // block, block, H)], dim=1).reshape(2 * I, H).contiguous()
 
 
 def rope_tables(seq_len: int, head_dim: int, theta: float, round_bf16: bool, device) -> tuple[torch.Tensor, torch.Tensor]:

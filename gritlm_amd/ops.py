@@ -177,14 +177,16 @@ def infonce(q: torch.Tensor, p: torch.Tensor, temperature: float, q_off: int = 0
 def transpose(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """[R,C] -> [C,R]; ``out`` may be a wider buffer [C, >=R] (zero-padded K for the wgrad GEMM)."""
     R, Cc = x.shape
+    ret_view = None
     if out is None:
-        out = torch.empty((Cc, R), dtype=BF16, device=x.device)
+        out = torch.empty((Cc, (R + 7) // 8 * 8), dtype=BF16, device=x.device)
+        ret_view = out if out.shape[1] == R else out[:, :R]
     assert out.shape[0] == Cc and out.shape[1] >= R and x.stride(1) == 1 and out.stride(1) == 1
     if x.dtype != BF16 or out.dtype != BF16 or not x.is_cuda:
         raise TypeError("transpose: bf16 CUDA tensors expected")
     check(_lib.load().grit_transpose_bf16(x.data_ptr(), out.data_ptr(), R, Cc, x.stride(0), out.stride(0), _stream()),
           "grit_transpose_bf16")
-    return out
+    return out if ret_view is None else ret_view
 
 
 def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float, dw: torch.Tensor, dres: torch.Tensor | None = None,

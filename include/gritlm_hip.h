@@ -38,7 +38,7 @@ enum {
 enum {
   GRIT_EPI_STORE = 0,    /* C = bf16(acc)                                                       */
   GRIT_EPI_RESIDUAL = 1, /* C = bf16(acc + residual)  (residual may alias C)                    */
-  GRIT_EPI_SWIGLU = 2    /* weight rows interleaved gate/up in blocks of 16 (grit_swiglu_pack_index);
+  GRIT_EPI_SWIGLU = 2    /* weight rows interleaved gate/up in blocks of grit_swiglu_block() rows;
                             C[:, N/2] = bf16(silu(bf16(gate)) * bf16(up))                        */
 };
 
@@ -69,10 +69,14 @@ int grit_rope_qk_inplace(void* qkv, const float* cos_tab, const float* sin_tab, 
 /* nn.Linear without bias (q/k/v/o_proj :225-228,655-657,703; MLP :177-178):
  *   C[M,N] = A[M,K] * W[N,K]^T, bf16 in, fp32 MFMA accumulate, bf16 out, with a fused epilogue.
  * Requirements: K % 64 == 0, N % 16 == 0, lda/ldw/ldc/ldr % 8 == 0, pointers 16-byte aligned.
- * SWIGLU: N counts the interleaved gate+up rows (2*I); C has N/2 columns. */
+ * SWIGLU: N counts the interleaved gate+up rows (2*I), N % 64 == 0; C has N/2 columns. */
 int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda,
                       int64_t ldw, int64_t ldc, int epilogue, const void* residual, int64_t ldr,
                       void* stream);
+
+/* Row-interleave granularity the SWIGLU epilogue expects: packed row r = 2*blk*(r/blk) + r%blk holds gate row r,
+ * the next blk rows the matching up rows (blk = 32 for the 32x32x16 kernel generation). */
+int grit_swiglu_block(void);
 
 /* attention_mask [B,S] int64 (HF layout, 0 = padding) -> key bitmask [B, ceil(S/64)] uint64
  * (replaces _prepare_4d_attention_mask(_for_sdpa), :1017-1020,1033-1036: no [B,1,S,S] tensor). */
@@ -117,7 +121,8 @@ int grit_infonce_fwd_bwd(const float* q, const float* p, float inv_temperature, 
 /* ---- helpers -------------------------------------------------------------------------------- */
 
 /* bf16 [R,C] (row stride ld_in) -> [C,R] (row stride ld_out): operands of the dgrad / wgrad GEMMs
- * (autograd of nn.Linear: dX = dY W needs W^T K-contiguous, dW = dY^T X needs dY^T and X^T). R, C % 8 == 0. */
+ * (autograd of nn.Linear: dX = dY W needs W^T K-contiguous, dW = dY^T X needs dY^T and X^T).  C % 8 == 0; R is
+ * arbitrary, ld_out >= roundup(R, 8): columns R..roundup(R,8) of the output are zero-filled. */
 int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, void* stream);
 
 /* ---- backward of the encoder (contrastive step, GradCache pass 2: grad_cache.py:213-242) ------ */
