@@ -31,6 +31,11 @@ def split_inputs(model_input: Dict, chunk_size: int) -> List[Dict]:
     return out
 
 
+def _rows(chunk: Dict) -> int:
+    v = next(iter(chunk.values()))
+    return v.shape[0] if isinstance(v, torch.Tensor) else len(v)
+
+
 def sync_gradients(model) -> None:
     """Average gradients over ranks (DDP semantics: the effective gradient is (1/W) * grad of the global loss)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -44,23 +49,76 @@ def sync_gradients(model) -> None:
         b.div_(w)
 
 
+class ChunkGather:
+    """Cross-rank gather of pooled representations, issued chunk by chunk as pass 1 produces them.
+
+    Every chunk's all-gather is asynchronous (RCCL runs it on its own stream over xGMI) and lands directly in the rank-major
+    [W, n_local, H] buffer, so the exchange overlaps the forward of the following chunks -- the query tower's gather
+    overlaps the whole document tower, and only the last passage chunk's gather is exposed.  Replaces the two blocking
+    list-API gathers + torch.cat of ``_dist_gather_tensor`` (gritlm/training/model.py:49-60); result order is identical."""
+
+    def __init__(self, n_local: int, width: int, dtype, device):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.buf = torch.empty((self.world, n_local, width), dtype=dtype, device=device)
+        self.handles, self.keep, self.row = [], [], 0
+
+    def add(self, reps: torch.Tensor):
+        reps = reps.detach().contiguous()
+        n = reps.shape[0]
+        views = [self.buf[r, self.row:self.row + n] for r in range(self.world)]
+        self.handles.append(dist.all_gather(views, reps, async_op=True))
+        self.keep.append(reps)
+        self.row += n
+
+    def finish(self) -> torch.Tensor:
+        for h in self.handles:
+            h.wait()
+        self.keep.clear()
+        return self.buf.view(self.world * self.buf.shape[1], self.buf.shape[2])
+
+
 class GradCacheStep:
     def __init__(self, model, chunk_size: int):
         self.model = model
         self.chunk_size = int(chunk_size)
 
     @torch.no_grad()
-    def _reps_no_grad(self, chunks):
-        return torch.cat([self.model.encode(c) for c in chunks], dim=0)
+    def _reps_no_grad(self, chunks, gather: "ChunkGather | None" = None):
+        out = []
+        for c in chunks:
+            r = self.model.encode(c)
+            if gather is not None:
+                gather.add(r)
+            out.append(r)
+        return torch.cat(out, dim=0)
 
     def __call__(self, query: Dict, passage: Dict, sync: bool = True) -> torch.Tensor:
         model = self.model
         q_chunks, p_chunks = split_inputs(query, self.chunk_size), split_inputs(passage, self.chunk_size)
-        # pass 1
-        q_reps, p_reps = self._reps_no_grad(q_chunks), self._reps_no_grad(p_chunks)
+        loss_fn = model.emb_loss_fn
+        cross = bool(getattr(loss_fn, "negatives_cross_device", False))
+        nq = sum(_rows(c) for c in q_chunks); npas = sum(_rows(c) for c in p_chunks)
+        # pass 1 (the cross-rank exchange rides along, chunk by chunk)
+        gq = gp = None
+        q_list, p_list = [], []
+        with torch.no_grad():
+            for chunks, lst, which in ((q_chunks, q_list, "q"), (p_chunks, p_list, "p")):
+                for c in chunks:
+                    r = model.encode(c)
+                    if cross:
+                        if which == "q" and gq is None:
+                            gq = ChunkGather(nq, r.shape[1], r.dtype, r.device)
+                        if which == "p" and gp is None:
+                            gp = ChunkGather(npas, r.shape[1], r.dtype, r.device)
+                        (gq if which == "q" else gp).add(r)
+                    lst.append(r)
+        q_reps, p_reps = torch.cat(q_list, dim=0), torch.cat(p_list, dim=0)
         # loss + representation-gradient cache
         q_leaf, p_leaf = q_reps.detach().requires_grad_(), p_reps.detach().requires_grad_()
-        loss = model.emb_loss_fn(q_leaf, p_leaf)
+        if cross:
+            loss = loss_fn.with_gathered(q_leaf, p_leaf, gq.finish(), gp.finish())
+        else:
+            loss = loss_fn(q_leaf, p_leaf)
         loss.backward()
         caches = (q_leaf.grad, p_leaf.grad)
         # pass 2

@@ -90,6 +90,21 @@ class DistributedContrastiveLoss:
         target = torch.arange(scores.size(0), device=scores.device, dtype=torch.long) * (p_reps.size(0) // q_reps.size(0))
         return self.cross_entropy(scores, target)
 
+    def with_gathered(self, q_local: Tensor, p_local: Tensor, q_all: Tensor, p_all: Tensor) -> Tensor:
+        """Loss when the cross-rank exchange already happened (GradCacheStep overlaps it with pass 1):
+        ``q_all`` / ``p_all`` are the rank-ordered gathers, the local shards are the only rows carrying grad."""
+        bq, bp = q_local.shape[0], p_local.shape[0]
+        if q_local.is_cuda:
+            return _InfoNCEFn.apply(q_local.float().contiguous(), p_local.float().contiguous(), q_all.detach().float().contiguous(),
+                                    p_all.detach().float().contiguous(), float(self.temperature), self.rank * bq, self.rank * bp)
+        qs = [q_all[r * bq:(r + 1) * bq].detach() for r in range(self.world_size)]
+        ps = [p_all[r * bp:(r + 1) * bp].detach() for r in range(self.world_size)]
+        qs[self.rank], ps[self.rank] = q_local, p_local
+        q, p = torch.cat(qs, dim=0), torch.cat(ps, dim=0)
+        scores = (self.compute_similarity(q, p) / self.temperature).view(q.size(0), -1)
+        target = torch.arange(scores.size(0), device=scores.device, dtype=torch.long) * (p.size(0) // q.size(0))
+        return self.cross_entropy(scores, target)
+
     def _dist_gather_tensor(self, t: Optional[Tensor]):
         """all_gather whose local slot keeps the grad-carrying tensor (:49-60)."""
         if t is None:
