@@ -128,10 +128,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(wf[j]));
       } else {
+        if (ABL == 5) __builtin_amdgcn_s_setprio(1);
+        if (ABL == 6) __builtin_amdgcn_iglp_opt(0);
+        if (ABL == 7) __builtin_amdgcn_iglp_opt(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        if (ABL == 5) __builtin_amdgcn_s_setprio(0);
       }
     }
     lds_dma_barrier();
@@ -469,7 +473,11 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else GRIT_LAUNCH_ABL(3);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
+    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else GRIT_LAUNCH_ABL(7);
   } else if (gemm_variant() == 4 && N % 32 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v4_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
     hipLaunchKernelGGL(gemm_bf16_nt_v4_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
