@@ -196,6 +196,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    # ---- ragged batch (SURVEY §8d "C2 padded variant"): lengths ~ U{64..512}, right-padded; padded vs packed (un-padded) path
+    ragged = None
+    if rank == 0 or world > 1:
+        g2 = torch.Generator(device=dev).manual_seed(99 + rank)
+        lens = torch.randint(64, SEQ + 1, (DOCS,), generator=g2, device=dev)
+        lens[0] = SEQ
+        rmask = (torch.arange(SEQ, device=dev).unsqueeze(0) < lens.unsqueeze(1)).to(torch.int64)
+
+        def timed(packed):
+            for _ in range(1):
+                eng.encode_pooled(ids, rmask, "mean", True, packed=packed)
+            torch.cuda.synchronize()
+            t0r = time.perf_counter()
+            for _ in range(2):
+                e = eng.encode_pooled(ids, rmask, "mean", True, packed=packed)
+            torch.cuda.synchronize()
+            return 2 * DOCS / (time.perf_counter() - t0r), e
+
+        dps_pad, e_pad = timed(False)
+        dps_pack, e_pack = timed(True)
+        ragged = {"lengths": "U{64..512} right-padded to 512", "mean_len": float(lens.float().mean().item()),
+                  "docs_per_s_padded_path": dps_pad, "docs_per_s_packed_path": dps_pack,
+                  "bit_identical": bool(torch.equal(e_pad, e_pack))}
+
     contrastive = None
     if not args.no_contrastive:
         del eng, emb
@@ -223,6 +247,8 @@ def main():
             "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                             "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()},
         }
+        if ragged is not None:
+            line["ragged_batch"] = ragged
         if contrastive is not None:
             line["contrastive"] = contrastive
         if args.layers != 32:

@@ -28,9 +28,13 @@ constexpr int V_LDS_BYTES = ATT_D * VT_PITCH;    // 17408
 __device__ __forceinline__ uint32_t lo16(uint32_t w) { return w & 0xffffu; }
 __device__ __forceinline__ uint32_t hi16(uint32_t w) { return w >> 16; }
 
+// VARLEN: sequences are packed back to back (no padding rows at all); cu_seqlens[b] is the first row of sequence b and
+// every key of a sequence is valid, so the key bitmask is synthesised from the length.
+template <bool VARLEN>
 __global__ void __launch_bounds__(256, 2)
-attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, uint16_t* __restrict__ out,
-                 float* __restrict__ lse, int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2) {
+attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
+                 uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride,
+                 int64_t out_stride, float scale_log2) {
   __shared__ __attribute__((aligned(16))) char smem[K_LDS_BYTES + V_LDS_BYTES];
   char* k_lds = smem;
   char* v_lds = smem + K_LDS_BYTES;
@@ -38,15 +42,23 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (nq / nkv);
-  const int W = (S + 63) >> 6;
-  const uint64_t* bits = key_bits + (int64_t)b * W;
-
-  // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
+  int S = S_arg;
+  int64_t row0 = (int64_t)b * S_arg;
   int ntiles = 0;
-  for (int w = W - 1; w >= 0; --w)
-    if (bits[w] != 0) { ntiles = w + 1; break; }
+  const uint64_t* bits = nullptr;
+  if constexpr (VARLEN) {
+    row0 = cu_seqlens[b];
+    S = cu_seqlens[b + 1] - cu_seqlens[b];
+    if (qb * ATT_QB >= S) return;              // uniform per workgroup
+    ntiles = (S + 63) >> 6;
+  } else {
+    const int W = (S + 63) >> 6;
+    bits = key_bits + (int64_t)b * W;
+    // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
+    for (int w = W - 1; w >= 0; --w)
+      if (bits[w] != 0) { ntiles = w + 1; break; }
+  }
 
-  const int64_t row0 = (int64_t)b * S;
   const uint16_t* qbase = qkv + (int64_t)h * ATT_D;
   const uint16_t* kbase = qkv + (int64_t)(nq + hk) * ATT_D;
   const uint16_t* vbase = qkv + (int64_t)(nq + nkv + hk) * ATT_D;
@@ -140,7 +152,13 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     }
 
     // ---- mask + online softmax (all lane-local except one exchange with lane^32)
-    const uint64_t word = bits[t];
+    uint64_t word;
+    if constexpr (VARLEN) {
+      const int rem = S - t * ATT_KB;
+      word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    } else {
+      word = bits[t];
+    }
     const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
     float mx = -INFINITY;
 #pragma unroll
@@ -211,8 +229,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
                                     pack2bf(oacc[db][4 * g + 2] * inv_l, oacc[db][4 * g + 3] * inv_l));
         *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = pk;
       }
-    if (lse != nullptr && hi == 0)
-      lse[((int64_t)b * nq + h) * S + q_row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    if (lse != nullptr && hi == 0) {
+      if constexpr (VARLEN) lse[(row0 + q_row) * nq + h] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;  // [T, nq]
+      else lse[((int64_t)b * nq + h) * S + q_row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    }
   }
 }
 
@@ -231,8 +251,25 @@ extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, vo
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "grit_attn_bidir_fwd: pointers must be 16-byte aligned");
   GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_fwd: grid too large");
   const dim3 grid((unsigned)((S + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
-  hipLaunchKernelGGL(attn_bidir_fwd_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, (uint16_t*)out, lse, S,
-                     nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+  hipLaunchKernelGGL(attn_bidir_fwd_k<false>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits,
+                     (const int32_t*)nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
   GRIT_CHECK_LAUNCH("grit_attn_bidir_fwd");
+  return GRIT_OK;
+}
+
+extern "C" int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                          int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(qkv && cu_seqlens && out, GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: null pointer");
+  GRIT_REQUIRE(B > 0 && max_len > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: bad sizes");
+  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_fwd: head_dim=%d (only 128 is built)", d);
+  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: nq=%d not a multiple of nkv=%d", nq, nkv);
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 4 == 0 && out_stride >= (int64_t)nq * d,
+               GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: bad strides");
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: pointers must be 16-byte aligned");
+  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_fwd: grid too large");
+  const dim3 grid((unsigned)((max_len + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
+  hipLaunchKernelGGL(attn_bidir_fwd_k<true>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (const uint64_t*)nullptr,
+                     cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+  GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_fwd");
   return GRIT_OK;
 }

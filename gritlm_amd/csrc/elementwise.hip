@@ -97,8 +97,8 @@ __device__ __forceinline__ void rot2(uint32_t a, uint32_t b, float c0, float s0,
   ob = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
 }
 __global__ void __launch_bounds__(256) rope_k(uint16_t* __restrict__ qkv, const float4* __restrict__ cos_tab,
-                                              const float4* __restrict__ sin_tab, int64_t T, int S, int nheads, int d,
-                                              int64_t row_stride, float sgn) {
+                                              const float4* __restrict__ sin_tab, const int32_t* __restrict__ positions, int64_t T,
+                                              int S, int nheads, int d, int64_t row_stride, float sgn) {
   const int jc_n = d >> 4;  // 16-byte chunks per half head
   const int64_t total = T * nheads * jc_n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) rope_k(uint16_t* __restrict__ qkv, const 
     const int64_t r = i / jc_n;
     const int head = (int)(r % nheads);
     const int64_t t = r / nheads;
-    const int pos = (int)(t % S);
+    const int pos = positions ? positions[t] : (int)(t % S);
     uint16_t* base = qkv + t * row_stride + (int64_t)head * d + jc * 8;
     uint4 x1 = *reinterpret_cast<uint4*>(base);
     uint4 x2 = *reinterpret_cast<uint4*>(base + (d >> 1));
@@ -219,8 +219,22 @@ int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, fl
   return GRIT_OK;
 }
 
+static int rope_launch(void* qkv, const float* cos_tab, const float* sin_tab, const int32_t* positions, int64_t T, int S, int nq, int nkv,
+                       int d, int64_t row_stride, int inverse, void* stream);
+
 int grit_rope_qk_inplace(void* qkv, const float* cos_tab, const float* sin_tab, int64_t T, int S, int nq, int nkv, int d,
                          int64_t row_stride, int inverse, void* stream) {
+  return rope_launch(qkv, cos_tab, sin_tab, nullptr, T, S, nq, nkv, d, row_stride, inverse, stream);
+}
+
+int grit_rope_qk_inplace_pos(void* qkv, const float* cos_tab, const float* sin_tab, const int32_t* positions, int64_t T, int table_rows,
+                             int nq, int nkv, int d, int64_t row_stride, int inverse, void* stream) {
+  GRIT_REQUIRE(positions, GRIT_E_BADARG, "grit_rope_qk_inplace_pos: null positions");
+  return rope_launch(qkv, cos_tab, sin_tab, positions, T, table_rows, nq, nkv, d, row_stride, inverse, stream);
+}
+
+static int rope_launch(void* qkv, const float* cos_tab, const float* sin_tab, const int32_t* positions, int64_t T, int S, int nq, int nkv,
+                       int d, int64_t row_stride, int inverse, void* stream) {
   GRIT_REQUIRE(qkv && cos_tab && sin_tab, GRIT_E_BADARG, "grit_rope_qk_inplace: null pointer");
   GRIT_REQUIRE(T >= 0 && S > 0 && nq > 0 && nkv >= 0 && d > 0, GRIT_E_BADARG, "grit_rope_qk_inplace: bad sizes");
   GRIT_REQUIRE(d % 16 == 0, GRIT_E_UNSUPPORTED, "grit_rope_qk_inplace: head_dim=%d must be a multiple of 16", d);
@@ -230,7 +244,7 @@ int grit_rope_qk_inplace(void* qkv, const float* cos_tab, const float* sin_tab, 
   const int nheads = nq + nkv;
   const int64_t items = T * nheads * (d / 16);
   hipLaunchKernelGGL(rope_k, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv,
-                     (const float4*)cos_tab, (const float4*)sin_tab, T, S, nheads, d, row_stride, inverse ? -1.0f : 1.0f);
+                     (const float4*)cos_tab, (const float4*)sin_tab, positions, T, S, nheads, d, row_stride, inverse ? -1.0f : 1.0f);
   GRIT_CHECK_LAUNCH("grit_rope_qk_inplace");
   return GRIT_OK;
 }

@@ -128,6 +128,63 @@ __global__ void __launch_bounds__(POOL_THREADS) pool_norm_fwd_k(const uint16_t* 
   }
 }
 
+// Packed (un-padded) batches: document b occupies rows [cu[b], cu[b+1]) of hidden [T,H]; every row is a real token, the first
+// instr_len[b] of them are attended to but not pooled.  Same arithmetic as pool_norm_fwd_k with mask == 1 on [instr, len).
+__global__ void __launch_bounds__(POOL_THREADS) pool_norm_varlen_fwd_k(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ cu,
+                                                                       const int32_t* __restrict__ instr_len, float* __restrict__ out,
+                                                                       float* __restrict__ inv_norm, int H, int mode, int normalize) {
+  __shared__ float red[POOL_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t start = cu[b];
+  const int len = cu[b + 1] - cu[b];
+  int instr = instr_len ? instr_len[b] : 0;
+  instr = instr < len ? instr : len;
+  int s0 = instr, s1 = len;
+  float den = (float)(len - instr);
+  if (mode == GRIT_POOL_WEIGHTEDMEAN) { const float n = (float)(len - instr); den = 0.5f * n * (n + 1.f); }
+  if (mode == GRIT_POOL_CLS) { s0 = 0; s1 = len > 0 ? 1 : 0; den = 1.f; }
+  if (mode == GRIT_POOL_LASTTOKEN) { s0 = len > 0 ? len - 1 : 0; s1 = len; den = 1.f; }
+  const bool ramp = (mode == GRIT_POOL_WEIGHTEDMEAN);
+  const int HC = H >> 3;
+  const uint4* hb = reinterpret_cast<const uint4*>(hidden) + start * HC;
+  float* ob = out + (int64_t)b * H;
+  float ssq = 0.f;
+  for (int cc = tid; cc < HC; cc += POOL_THREADS) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      const uint4 v0 = hb[(int64_t)s * HC + cc], v1 = hb[(int64_t)(s + 1) * HC + cc];
+      const uint4 v2 = hb[(int64_t)(s + 2) * HC + cc], v3 = hb[(int64_t)(s + 3) * HC + cc];
+      const float w0 = ramp ? (float)(s - instr + 1) : 1.f;
+      fma8(a, v0, w0); fma8(a, v1, ramp ? w0 + 1.f : 1.f); fma8(a, v2, ramp ? w0 + 2.f : 1.f); fma8(a, v3, ramp ? w0 + 3.f : 1.f);
+    }
+    for (; s < s1; ++s) fma8(a, hb[(int64_t)s * HC + cc], ramp ? (float)(s - instr + 1) : 1.f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = a[e] / den; ssq += a[e] * a[e]; }
+    float4* o4 = reinterpret_cast<float4*>(ob + cc * 8);
+    o4[0] = make_float4(a[0], a[1], a[2], a[3]);
+    o4[1] = make_float4(a[4], a[5], a[6], a[7]);
+  }
+  if (!normalize) {
+    if (inv_norm && tid == 0) inv_norm[b] = 1.f;
+    return;
+  }
+  ssq = wave_sum(ssq);
+  if (lane == 0) red[wave] = ssq;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < POOL_THREADS / 64; ++w) tot += red[w];
+  const float inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+  if (inv_norm && tid == 0) inv_norm[b] = inv;
+  for (int cc = tid; cc < HC; cc += POOL_THREADS) {
+    float4* o4 = reinterpret_cast<float4*>(ob + cc * 8);
+    float4 x = o4[0], y = o4[1];
+    x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv; y.x *= inv; y.y *= inv; y.z *= inv; y.w *= inv;
+    o4[0] = x; o4[1] = y;
+  }
+}
+
 // dhidden[b,s,:] = (w[s]/den) * g,  g = (dy - y (y.dy)) * inv_norm  (normalize)  or dy
 __global__ void __launch_bounds__(POOL_THREADS) pool_norm_bwd_k(const float* __restrict__ y, const float* __restrict__ dy,
                                                                 const float* __restrict__ inv_norm, const int64_t* __restrict__ mask,
@@ -202,6 +259,20 @@ int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* i
   hipLaunchKernelGGL(pool_norm_fwd_k, dim3(B), dim3(POOL_THREADS), lds, (hipStream_t)stream, (const uint16_t*)hidden, mask, instr_len,
                      out, inv_norm, S, H, mode, normalize);
   GRIT_CHECK_LAUNCH("grit_pool_norm_fwd");
+  return GRIT_OK;
+}
+
+int grit_pool_norm_varlen_fwd(const void* hidden, const int32_t* cu_seqlens, const int32_t* instr_len, float* out, float* inv_norm, int B,
+                              int H, int mode, int normalize, void* stream) {
+  GRIT_REQUIRE(hidden && cu_seqlens && out, GRIT_E_BADARG, "grit_pool_norm_varlen_fwd: null pointer");
+  GRIT_REQUIRE(B >= 0 && H > 0, GRIT_E_BADARG, "grit_pool_norm_varlen_fwd: bad sizes");
+  GRIT_REQUIRE(mode >= GRIT_POOL_MEAN && mode <= GRIT_POOL_LASTTOKEN, GRIT_E_BADARG, "grit_pool_norm_varlen_fwd: unknown pooling mode %d", mode);
+  GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_pool_norm_varlen_fwd: H=%d must be a multiple of 8", H);
+  GRIT_REQUIRE(aligned16(hidden) && aligned16(out), GRIT_E_BADARG, "grit_pool_norm_varlen_fwd: pointers must be 16-byte aligned");
+  if (B == 0) return GRIT_OK;
+  hipLaunchKernelGGL(pool_norm_varlen_fwd_k, dim3(B), dim3(POOL_THREADS), 0, (hipStream_t)stream, (const uint16_t*)hidden, cu_seqlens,
+                     instr_len, out, inv_norm, H, mode, normalize);
+  GRIT_CHECK_LAUNCH("grit_pool_norm_varlen_fwd");
   return GRIT_OK;
 }
 

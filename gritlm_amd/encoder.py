@@ -152,17 +152,17 @@ class MistralEncoderEngine:
 
     # ------------------------------------------------------------------ buffers
     def _workspace(self, T: int):
-        ws = self._ws.get(T)
-        if ws is None:
+        """Activation buffers for T token rows: one allocation sized for the largest T seen, handed out as row-slices
+        (ragged / packed batches change T every call)."""
+        cap = self._ws.get("cap", 0)
+        if cap < T:
             c, dev = self.cfg, self.device
             qkv_w = (c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim
+            self._ws.clear()
             mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
-            ws = dict(h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim),
-                      act=mk(c.intermediate_size))
-            if len(self._ws) >= 4:           # a few shapes at most (query / passage lengths)
-                self._ws.pop(next(iter(self._ws)))
-            self._ws[T] = ws
-        return ws
+            self._ws.update(cap=T, h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim),
+                            act=mk(c.intermediate_size))
+        return {k: v[:T] for k, v in self._ws.items() if k != "cap"}
 
     def _rope_tables(self, S: int):
         t = self._rope.get(S)
@@ -204,6 +204,55 @@ class MistralEncoderEngine:
         return out if borrow else out.clone()
 
     __call__ = forward
+
+    # ------------------------------------------------------------------ packed (un-padded) forward
+    @staticmethod
+    def is_right_padded(attention_mask: torch.Tensor) -> bool:
+        """True when every row of the mask is 1...10...0 (what a right-padding tokenizer produces)."""
+        m = attention_mask != 0
+        lens = m.sum(dim=1, keepdim=True)
+        ar = torch.arange(m.shape[1], device=m.device).unsqueeze(0)
+        return bool(((ar < lens) == m).all())
+
+    @torch.no_grad()
+    def encode_pooled(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, method: str, normalize: bool,
+                      instr_len: torch.Tensor | None = None, packed: bool | None = None) -> torch.Tensor:
+        """pool(normalise(encoder(ids))) -> [B,H] fp32.  With a right-padded batch the padding is dropped before the first
+        kernel ("packed" rows, cu_seqlens): GEMMs, norms and attention only ever see real tokens -- the reference's SDPA path
+        computes every padded row.  Results are bit-identical to the padded path."""
+        c = self.cfg
+        B, S = input_ids.shape
+        mask = attention_mask.to(device=self.device, dtype=torch.int64)
+        ids = input_ids.to(device=self.device, dtype=torch.int64)
+        if packed is None:
+            packed = self.is_right_padded(mask) and bool((mask.sum(dim=1) > 0).all())
+        if not packed:
+            h = self.forward(ids, mask, borrow=True)
+            return ops.pool_norm(h, mask.contiguous(), method, normalize, instr_len)
+        lens = mask.sum(dim=1).to(torch.int32)
+        cu = torch.zeros((B + 1,), dtype=torch.int32, device=self.device)
+        cu[1:] = torch.cumsum(lens, dim=0)
+        keep = mask.bool()
+        pids = ids[keep].contiguous()                                        # row-major order == sequence order
+        pos = (torch.arange(S, device=self.device, dtype=torch.int32).unsqueeze(0).expand(B, S))[keep].contiguous()
+        T = int(pids.numel())
+        max_len = int(lens.max().item())
+        ws = self._workspace(T)
+        h, x, qkv, ctx, act = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["act"]
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        cos, sin = self._rope_tables(S)
+        ops.embed_gather(self.embed, pids, out=h)
+        for L in self.layers:
+            ops.rmsnorm(h, L.ln1, eps, out=x)
+            ops.gemm_nt(x, L.wqkv, out=qkv)
+            ops.rope_qk_pos_(qkv, cos, sin, pos, nq, nkv, d)
+            ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx)
+            ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.rmsnorm(h, L.ln2, eps, out=x)
+            ops.gemm_nt(x, L.wgu, out=act, epilogue=EPI_SWIGLU)
+            ops.gemm_nt(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+        ops.rmsnorm(h, self.norm, eps, out=x)
+        return ops.pool_norm_varlen(x, cu, method, normalize, instr_len)
 
     def flops_per_token(self, S: int) -> float:
         """Algorithmic forward FLOPs per token: projections + MLP + attention core."""

@@ -189,6 +189,16 @@ class GritLM(torch.nn.Module):
             texts = [instruction + s + self.embed_eos for s in sentences[start:start + batch_size]]
             inputs = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length,
                                     add_special_tokens=add_special_tokens).to(self.device)
+            if self.engine is not None and not get_cache and self.projection is None and self.pooling_method in POOL_MODES:
+                # native fast path: padding dropped before the first kernel, pool + normalise fused (engine.encode_pooled)
+                il = None
+                if n_instr is not None:
+                    il = torch.full((inputs["input_ids"].shape[0],), n_instr, dtype=torch.int32, device=self.engine.device)
+                emb = self.engine.encode_pooled(inputs["input_ids"], inputs["attention_mask"], self.pooling_method, bool(self.normalized), il)
+                if recast or self.pooling_method == "cls":
+                    emb = emb.to(self.model.dtype)
+                chunks.append(emb)
+                continue
             hidden, cache = self._hidden_states(inputs, get_cache)
             if get_cache:
                 assert len(kv_caches) == 0, "Can only get cache for one batch at a time"

@@ -83,6 +83,47 @@ def rope_qk_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, nq
     return qkv
 
 
+def rope_qk_pos_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, positions: torch.Tensor, nq: int, nkv: int, d: int):
+    """RoPE for packed rows: positions[t] (int32) = index of token t inside its own sequence."""
+    T, stride = qkv.shape
+    check(_lib.load().grit_rope_qk_inplace_pos(_chk(qkv, BF16, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"),
+                                               _chk(positions, I32, "positions"), T, cos.shape[0], nq, nkv, d, stride, 0, _stream()),
+          "grit_rope_qk_inplace_pos")
+    return qkv
+
+
+def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, nq: int, nkv: int, d: int,
+                      out: torch.Tensor | None = None, scale: float | None = None) -> torch.Tensor:
+    T, stride = qkv.shape
+    B = cu_seqlens.numel() - 1
+    if out is None:
+        out = torch.empty((T, nq * d), dtype=BF16, device=qkv.device)
+    if scale is None:
+        scale = d ** -0.5
+    ev = _timer.span("attn_bidir_fwd", 0.0) if _timer is not None else None
+    if ev:
+        ev[0].record()
+    check(_lib.load().grit_attn_bidir_varlen_fwd(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"), 0, B,
+                                                 int(max_len), nq, nkv, d, stride, out.stride(0), float(scale), _stream()),
+          "grit_attn_bidir_varlen_fwd")
+    if ev:
+        ev[1].record()
+    return out
+
+
+def pool_norm_varlen(hidden: torch.Tensor, cu_seqlens: torch.Tensor, method: str, normalize: bool,
+                     instr_len: torch.Tensor | None = None) -> torch.Tensor:
+    if method not in POOL_MODES:
+        raise NotImplementedError(f"Unknown pooling method: {method}")
+    T, H = hidden.shape
+    B = cu_seqlens.numel() - 1
+    out = torch.empty((B, H), dtype=F32, device=hidden.device)
+    check(_lib.load().grit_pool_norm_varlen_fwd(_chk(hidden, BF16, "hidden"), _chk(cu_seqlens, I32, "cu_seqlens"),
+                                                0 if instr_len is None else _chk(instr_len, I32, "instr_len"), _chk(out, F32, "out"), 0, B, H,
+                                                POOL_MODES[method], int(normalize), _stream()), "grit_pool_norm_varlen_fwd")
+    return out
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE,
             residual: torch.Tensor | None = None) -> torch.Tensor:
     """out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue).  SWIGLU: w holds interleaved gate/up rows, out is [M, N/2]."""

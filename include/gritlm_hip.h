@@ -66,6 +66,11 @@ int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, fl
 int grit_rope_qk_inplace(void* qkv, const float* cos_tab, const float* sin_tab, int64_t T, int S, int nq,
                          int nkv, int d, int64_t row_stride, int inverse, void* stream);
 
+/* same with explicit positions (packed / un-padded batches: positions[t] = index of token t inside its sequence);
+ * tables have table_rows rows. */
+int grit_rope_qk_inplace_pos(void* qkv, const float* cos_tab, const float* sin_tab, const int32_t* positions, int64_t T,
+                             int table_rows, int nq, int nkv, int d, int64_t row_stride, int inverse, void* stream);
+
 /* nn.Linear without bias (q/k/v/o_proj :225-228,655-657,703; MLP :177-178):
  *   C[M,N] = A[M,K] * W[N,K]^T, bf16 in, fp32 MFMA accumulate, bf16 out, with a fused epilogue.
  * Requirements: K % 64 == 0, N % 16 == 0, lda/ldw/ldc/ldr % 8 == 0, pointers 16-byte aligned.
@@ -91,6 +96,13 @@ int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, fl
                         int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale,
                         void* stream);
 
+/* Packed (un-padded) variant: sequence b occupies rows [cu_seqlens[b], cu_seqlens[b+1]) of qkv/out ([T, stride]), every row
+ * is a real token (the reference pads to the batch maximum and masks, gritlm/gritlm.py:120-127; its flash-attention path
+ * un-pads the same way, modeling_mistral_gritlm.py:575-615).  cu_seqlens: int32 [B+1] on the device; max_len sizes the grid.
+ * lse (nullable) is [T, nq]. */
+int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                               int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+
 /* ---- pooling + normalise: gritlm/gritlm.py:178-218,156-158; training/model.py:151-165 --------- */
 
 /* hidden [B,S,H] bf16; mask [B,S] int64 (attention mask); instr_len (nullable) [B] int32: the first
@@ -100,6 +112,11 @@ int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, fl
  * An all-masked row divides by zero exactly like the reference (:213-214). */
 int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* instr_len, float* out,
                        float* inv_norm, int B, int S, int H, int mode, int normalize, void* stream);
+
+/* Packed variant: hidden [T,H] bf16 with document b at rows [cu_seqlens[b], cu_seqlens[b+1]) (all real tokens);
+ * the first instr_len[b] rows of a document are excluded from mean / weightedmean pools. */
+int grit_pool_norm_varlen_fwd(const void* hidden, const int32_t* cu_seqlens, const int32_t* instr_len, float* out,
+                              float* inv_norm, int B, int H, int mode, int normalize, void* stream);
 
 /* backward of the above w.r.t. hidden: y = forward output [B,H] fp32, dy [B,H] fp32 -> dhidden [B,S,H] bf16 */
 int grit_pool_norm_bwd(const float* y, const float* dy, const float* inv_norm, const int64_t* mask,

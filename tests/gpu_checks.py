@@ -465,6 +465,29 @@ def check_cli_native():
     return _res("CLI gritlm.training.run native (loss decreases over 8 steps)", ok, loss_step1=float(l1), loss_step8=float(l8))
 
 
+def check_packed_encode(cfg_name="gqa", B=5, S=150):
+    """Un-padded (packed / varlen) encode == padded encode, bit for bit, and both match the oracle."""
+    eng, cfg, w = build_engine(cfg_name, 3)
+    ids, mask = synth.make_batch(cfg, B, S, seed=91, min_len=7)
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    instr = torch.tensor([0, 2, 5, 1, 0][:B], dtype=torch.int32, device=DEV)
+    ok, out = True, {}
+    ok &= MistralEncoderEngine.is_right_padded(tm)
+    holes = tm.clone(); holes[1, 3] = 0
+    ok &= not MistralEncoderEngine.is_right_padded(holes)
+    for method in ("mean", "weightedmean", "cls", "lasttoken"):
+        il = instr if "mean" in method else None
+        a = f32(eng.encode_pooled(tid, tm, method, True, il, packed=False))
+        b = f32(eng.encode_pooled(tid, tm, method, True, il, packed=True))
+        out[f"{method}_maxdiff"] = float(np.max(np.abs(a - b)))
+        ok &= np.array_equal(a, b)
+        ref = O.encode_core(w, cfg, ids, mask, method, True, None if il is None else instr.cpu().numpy())
+        c = float(np.max(1 - np.sum(b * ref, axis=1)))
+        out[f"{method}_1-cos_oracle"] = c
+        ok &= c < 1e-4
+    return _res(f"packed (un-padded) encode == padded encode [{cfg_name},B={B},S={S}]", ok, **out)
+
+
 ALL_CHECKS = [
     ("embed", check_embed, {}),
     ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
@@ -510,6 +533,8 @@ ALL_CHECKS = [
     ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
+    ("packed_encode", check_packed_encode, {}),
+    ("packed_encode_tiny", check_packed_encode, dict(cfg_name="tiny", B=3, S=260)),
     ("gritlm_native_encode", check_gritlm_native_encode, {}),
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
