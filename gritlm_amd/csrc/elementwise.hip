@@ -181,6 +181,7 @@ int grit_version(void) { return GRIT_ABI_VERSION; }
 const char* grit_last_error_string(void) { return g_err; }
 
 int grit_embed_gather(const void* table, const int64_t* ids, void* out, int64_t T, int H, int64_t V, void* stream) {
+  if (T == 0) return GRIT_OK;  // empty batch: nothing to do (empty tensors have null data pointers)
   GRIT_REQUIRE(table && ids && out, GRIT_E_BADARG, "grit_embed_gather: null pointer");
   GRIT_REQUIRE(T >= 0 && H > 0 && V > 0, GRIT_E_BADARG, "grit_embed_gather: bad sizes T=%lld H=%d V=%lld", (long long)T, H, (long long)V);
   GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_embed_gather: H=%d must be a multiple of 8", H);
@@ -194,6 +195,7 @@ int grit_embed_gather(const void* table, const int64_t* ids, void* out, int64_t 
 }
 
 int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, float eps, void* stream) {
+  if (T == 0) return GRIT_OK;
   GRIT_REQUIRE(x && w && y, GRIT_E_BADARG, "grit_rmsnorm_fwd: null pointer");
   GRIT_REQUIRE(T >= 0 && H > 0, GRIT_E_BADARG, "grit_rmsnorm_fwd: bad sizes");
   GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_rmsnorm_fwd: H=%d must be a multiple of 8", H);
@@ -235,6 +237,7 @@ int grit_rope_qk_inplace_pos(void* qkv, const float* cos_tab, const float* sin_t
 
 static int rope_launch(void* qkv, const float* cos_tab, const float* sin_tab, const int32_t* positions, int64_t T, int S, int nq, int nkv,
                        int d, int64_t row_stride, int inverse, void* stream) {
+  if (T == 0) return GRIT_OK;
   GRIT_REQUIRE(qkv && cos_tab && sin_tab, GRIT_E_BADARG, "grit_rope_qk_inplace: null pointer");
   GRIT_REQUIRE(T >= 0 && S > 0 && nq > 0 && nkv >= 0 && d > 0, GRIT_E_BADARG, "grit_rope_qk_inplace: bad sizes");
   GRIT_REQUIRE(d % 16 == 0, GRIT_E_UNSUPPORTED, "grit_rope_qk_inplace: head_dim=%d must be a multiple of 16", d);

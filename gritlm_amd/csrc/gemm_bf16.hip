@@ -496,10 +496,11 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
 
 using namespace grit;
 
-extern "C" int grit_swiglu_block(void) { return gemm_variant() >= 4 ? 32 : 16; }
+extern "C" int grit_swiglu_block(void) { return (gemm_variant() == 4 || gemm_variant() == 5) ? 32 : 16; }
 
 extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                                  int64_t ldc, int epilogue, const void* residual, int64_t ldr, void* stream) {
+  if (M == 0) return GRIT_OK;  // empty batch (empty tensors have null data pointers)
   GRIT_REQUIRE(A && W && C, GRIT_E_BADARG, "grit_gemm_bf16_nt: null pointer");
   GRIT_REQUIRE(M >= 0 && N > 0 && K > 0, GRIT_E_BADARG, "grit_gemm_bf16_nt: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
   GRIT_REQUIRE(K % 64 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: K=%d must be a multiple of 64", K);

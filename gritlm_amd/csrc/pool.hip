@@ -243,6 +243,7 @@ extern "C" {
 
 int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* instr_len, float* out, float* inv_norm, int B, int S,
                        int H, int mode, int normalize, void* stream) {
+  if (B == 0) return GRIT_OK;
   GRIT_REQUIRE(hidden && mask && out, GRIT_E_BADARG, "grit_pool_norm_fwd: null pointer");
   GRIT_REQUIRE(B >= 0 && S > 0 && H > 0, GRIT_E_BADARG, "grit_pool_norm_fwd: bad sizes");
   GRIT_REQUIRE(mode >= GRIT_POOL_MEAN && mode <= GRIT_POOL_LASTTOKEN, GRIT_E_BADARG, "grit_pool_norm_fwd: unknown pooling mode %d", mode);
@@ -264,6 +265,7 @@ int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* i
 
 int grit_pool_norm_varlen_fwd(const void* hidden, const int32_t* cu_seqlens, const int32_t* instr_len, float* out, float* inv_norm, int B,
                               int H, int mode, int normalize, void* stream) {
+  if (B == 0) return GRIT_OK;
   GRIT_REQUIRE(hidden && cu_seqlens && out, GRIT_E_BADARG, "grit_pool_norm_varlen_fwd: null pointer");
   GRIT_REQUIRE(B >= 0 && H > 0, GRIT_E_BADARG, "grit_pool_norm_varlen_fwd: bad sizes");
   GRIT_REQUIRE(mode >= GRIT_POOL_MEAN && mode <= GRIT_POOL_LASTTOKEN, GRIT_E_BADARG, "grit_pool_norm_varlen_fwd: unknown pooling mode %d", mode);

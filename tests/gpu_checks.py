@@ -129,6 +129,8 @@ def check_attention(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=11):
             mask[b, rng.integers(S // 3, S):] = 0
     elif mask_kind == "holes":
         mask = (rng.random((B, S)) < 0.7).astype(np.int64); mask[:, 0] = 1
+    elif mask_kind == "ragged_long":
+        mask[0, S - 700:] = 0
     elif mask_kind == "left":          # instruction-style: leading zeros, first 64-key tile fully masked
         mask[:, :70] = 0
     x = qkv.reshape(B, S, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
@@ -488,6 +490,64 @@ def check_packed_encode(cfg_name="gqa", B=5, S=150):
     return _res(f"packed (un-padded) encode == padded encode [{cfg_name},B={B},S={S}]", ok, **out)
 
 
+def check_edge_cases():
+    """Empty / minimal / degenerate inputs the host can hand over (reference behaviour noted per case)."""
+    ok, notes = True, {}
+    eng, cfg, w = build_engine("tiny", 0)
+    # one document, one token
+    ids = np.array([[7]], dtype=np.int64); mask = np.ones((1, 1), dtype=np.int64)
+    e = f32(eng.encode_pooled(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV), "mean", True))
+    ref = O.encode_core(w, cfg, ids, mask, "mean", True)
+    notes["1x1_1-cos"] = float(1 - np.sum(e * ref)); ok &= notes["1x1_1-cos"] < 1e-4
+    # empty batch: zero rows in, zero rows out, no launch failure
+    z = ops.rmsnorm(torch.empty((0, 256), dtype=torch.bfloat16, device=DEV), torch.ones(256, dtype=torch.bfloat16, device=DEV), 1e-5)
+    ok &= z.shape == (0, 256)
+    ok &= ops.gemm_nt(torch.empty((0, 64), dtype=torch.bfloat16, device=DEV), torch.zeros((16, 64), dtype=torch.bfloat16, device=DEV)).shape == (0, 16)
+    ok &= ops.pool_norm(torch.empty((0, 4, 64), dtype=torch.bfloat16, device=DEV), torch.empty((0, 4), dtype=torch.int64, device=DEV), "mean", True).shape == (0, 64)
+    # an all-masked pooling row divides by zero exactly like the unguarded reference (gritlm.py:213-214): NaN, other rows intact
+    hid = rnd((2, 6, 64), 3); m = np.array([[1, 1, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0]], dtype=np.int64)
+    out = f32(ops.pool_norm(bf(hid), torch.from_numpy(m).to(DEV), "mean", False))
+    with np.errstate(all="ignore"):
+        refp = O.pooling(hid, m, "mean")
+    ok &= np.allclose(out[0], refp[0], atol=1e-6) and np.isnan(out[1]).all() and np.isnan(refp[1]).all()
+    # unsupported shapes are refused loudly, never computed wrongly
+    from gritlm_amd._lib import GritHipError
+    for fn in (lambda: ops.gemm_nt(torch.zeros((4, 48), dtype=torch.bfloat16, device=DEV), torch.zeros((16, 48), dtype=torch.bfloat16, device=DEV)),
+               lambda: ops.attn_bidir(torch.zeros((8, 3 * 64), dtype=torch.bfloat16, device=DEV), torch.ones((1, 1), dtype=torch.int64, device=DEV), 1, 8, 1, 1, 64)):
+        try:
+            fn(); ok = False
+        except GritHipError:
+            pass
+    return _res("edge cases (1 token, empty batch, all-masked row, unsupported shapes)", ok, **notes)
+
+
+def check_long_sequence(S=4096):
+    """Maximum sequence length the reference evaluates with (rag/eval.py:283 tokenises up to 4096): flash attention vs oracle."""
+    return check_attention(B=1, S=S, nq=2, nkv=1, mask_kind="ragged_long", seed=5)
+
+
+def check_full_shape_properties(B=24, S=512):
+    """Size-independent properties at the true GritLM-7B LAYER shape (H 4096, 32/8 heads, I 14336; 2 layers) where the oracle is
+    too slow for a direct comparison: (1) documents are independent -- permuting the batch permutes the embeddings bit for bit;
+    (2) padding invariance -- appending pad tokens never changes an embedding (packed == padded, bitwise);
+    (3) unit norm; (4) a document's embedding does not depend on its batch mates."""
+    cfg = EncoderConfig.from_dict(dict(synth.CONFIGS["7b"], num_hidden_layers=2))
+    eng = MistralEncoderEngine.random_init(cfg, DEV, seed=11)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ids = torch.randint(3, cfg.vocab_size, (B, S), generator=g, device=DEV)
+    lens = torch.randint(40, S + 1, (B,), generator=g, device=DEV); lens[0] = S
+    mask = (torch.arange(S, device=DEV).unsqueeze(0) < lens.unsqueeze(1)).to(torch.int64)
+    e = eng.encode_pooled(ids, mask, "mean", True, packed=True)
+    perm = torch.randperm(B, generator=g, device=DEV)
+    e_perm = eng.encode_pooled(ids[perm], mask[perm], "mean", True, packed=True)
+    e_pad = eng.encode_pooled(ids, mask, "mean", True, packed=False)
+    e_sub = eng.encode_pooled(ids[:5], mask[:5], "mean", True, packed=True)
+    norms = e.norm(dim=1)
+    ok = torch.equal(e[perm], e_perm) and torch.equal(e, e_pad) and torch.equal(e[:5], e_sub)
+    ok &= bool(((norms - 1).abs() < 1e-5).all()) and bool(torch.isfinite(e).all())
+    return _res(f"full layer shape properties [B={B},S={S},H=4096,L=2]", ok, max_norm_dev=float((norms - 1).abs().max()))
+
+
 ALL_CHECKS = [
     ("embed", check_embed, {}),
     ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
@@ -533,6 +593,9 @@ ALL_CHECKS = [
     ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
+    ("edge_cases", check_edge_cases, {}),
+    ("long_sequence_4096", check_long_sequence, {}),
+    ("full_shape_properties", check_full_shape_properties, {}),
     ("packed_encode", check_packed_encode, {}),
     ("packed_encode_tiny", check_packed_encode, dict(cfg_name="tiny", B=3, S=260)),
     ("gritlm_native_encode", check_gritlm_native_encode, {}),
