@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       __builtin_amdgcn_global_load_lds((gptr_t)(a_src[c] + (int64_t)kt * BK), (lptr_t)(base + c * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)kt * BK), (lptr_t)(base + A_BYTES + c * 1024), 16, 0, 0);
+      if (ABL != 10 || kt == 0)
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)kt * BK), (lptr_t)(base + A_BYTES + c * 1024), 16, 0, 0);
     }
   };
 
@@ -105,7 +106,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk && ABL != 1) stage(cur ^ 1, kt + 1);
+    if (ABL == 0 || ABL == 8 || ABL == 9) stage(cur ^ 1, kt + 1 < nk ? kt + 1 : kt);   // branch-free body (re-stages the last tile once, harmless)
+    else if (kt + 1 < nk && ABL != 1) stage(cur ^ 1, kt + 1);
     const char* sb = smem + (ABL == 2 ? 0 : cur * STAGE_BYTES);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -137,6 +139,44 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         if (ABL == 5) __builtin_amdgcn_s_setprio(0);
       }
+    }
+    if (ABL == 8) {
+      // explicit issue order for the K-tile body (LLVM sched_group_barrier: 0x10 VMEM, 0x100 DS read, 0x8 MFMA): every pair of
+      // activation fragments is read one 8-MFMA group AHEAD of the group that consumes it, so the lgkmcnt waits are counted
+      // instead of lgkmcnt(0) right behind the read
+      __builtin_amdgcn_sched_group_barrier(0x10, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // w0-3, x0-3 (ks 0)
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G0: x0,x1
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // x4,x5
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G1: x2,x3
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // x6,x7
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G2: x4,x5
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // ks 1: w0-3, x0,x1
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G3: x6,x7
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G4
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G5
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G6
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G7
+    }
+    if (ABL == 0 || ABL == 9) {  // default: fragment reads issued two MFMA groups ahead of their consumers
+      __builtin_amdgcn_sched_group_barrier(0x10, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // w0-3, x0-5 (ks 0)
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G0
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // x6,x7
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G1
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // ks 1: w0-3, x0,x1
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G2
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G3
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G4
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G5
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G6
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G7
     }
     lds_dma_barrier();
   }
@@ -179,157 +219,20 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   }
 }
 
-// ======================================================================================================
-// Variant 4: continuous LDS-DMA stream through a 4-slot ring of K-HALVES (256 rows x 32 k of A and of W = 32 KiB per slot),
-// v_mfma_f32_32x32x16_bf16, one phase = one K-half = 12 ds_read_b128 + 16 MFMA per wave, ONE barrier per phase and a
-// COUNTED vmcnt (8 in steady state, never 0): three K-halves are always in flight / landed ahead of the MFMAs, so the
-// ~1.5 us issue->landed latency and the L2-miss tail (ablation: +1 ms on the data side) hide behind 3 phases of MFMAs.
-//   ring slot = phase & 3;  phase h: issue DMA(h+3) into the slot freed by the barrier of phase h-1,
-//   read the 12 fragments of slot h, 16 MFMAs, wait until K-half h+1 has landed (in-order return), barrier.
-// LDS image of a K-half: row = 64 B (4 slots of 16 B), lane-linear per 1 KiB chunk (16 rows), 16-B slot ^= (row>>2)&3
-// on the DMA source address and on the ds_read address (4 rows share a 256-B bank row -> conflict-free b128 reads).
-// ======================================================================================================
-constexpr int KH = 32;                        // k per ring slot
+constexpr int KH = 32;                          // k per ring slot (variant 8)
 constexpr int SLOT_BYTES = (BM + BN) * KH * 2;  // 32 KiB
 constexpr int SLOT_A = BM * KH * 2;             // 16 KiB
 
-template <int EPI>
-__global__ void __launch_bounds__(512) gemm_bf16_nt_v4_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* C,
-                                                         const uint16_t* Rsd, int64_t M, int N, int K, int64_t lda, int64_t ldw,
-                                                         int64_t ldc, int64_t ldr, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GM = 8;
-  const int group_sz = GM * tiles_n;
-  const int grp = wg / group_sz, first_m = grp * GM;
-  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-  const int in_grp = wg - grp * group_sz;
-  const int tm = first_m + in_grp % gm, tn = in_grp / gm;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
-
-  // DMA roles: wave `wid` fills 16-row chunks 2*wid, 2*wid+1 of the A half and of the W half (4 x 1 KiB per phase)
-  const uint16_t* a_src[2];
-  const uint16_t* w_src[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int r = (wid * 2 + c) * 16 + (lane >> 2);
-    const int slot = (lane & 3) ^ ((r >> 2) & 3);
-    int64_t gm_row = m0 + r; if (gm_row > M - 1) gm_row = M - 1;
-    int gn_row = n0 + r; if (gn_row > N - 1) gn_row = N - 1;
-    a_src[c] = A + gm_row * lda + slot * 8;
-    w_src[c] = W + (int64_t)gn_row * ldw + slot * 8;
-  }
-  auto stage = [&](int h) {
-    char* base = smem + (h & 3) * SLOT_BYTES + wid * 2048;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[c] + (int64_t)h * KH), (lptr_t)(base + c * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)h * KH), (lptr_t)(base + SLOT_A + c * 1024), 16, 0, 0);
-    }
-  };
-
-  const int frow = lane & 31, hi = lane >> 5, swz = (frow >> 2) & 3;
-  const int x_off = (wr * 128 + frow) * 64;            // + i*2048 (32 rows x 64 B)
-  const int w_off = SLOT_A + (wc * 64 + frow) * 64;    // + j*2048
-  const int so0 = ((0 + hi) ^ swz) << 4, so1 = ((2 + hi) ^ swz) << 4;
-
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nh = K / KH;
-  stage(0);
-  if (nh > 1) stage(1);
-  if (nh > 2) stage(2);
-  if (nh > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (nh > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  for (int h = 0; h < nh; ++h) {
-    if (h + 3 < nh) stage(h + 3);
-    const char* sb = smem + (h & 3) * SLOT_BYTES;
-    bf16x8_t wf[2][2], xf[2][4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int so = s ? so1 : so0;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[s][j] = *reinterpret_cast<const bf16x8_t*>(sb + w_off + j * 2048 + so);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xf[s][i] = *reinterpret_cast<const bf16x8_t*>(sb + x_off + i * 2048 + so);
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    // K-half h+1 must have landed; h+2 / h+3 may stay in flight (loads return in order)
-    const int ahead = nh - 2 - h;
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-
-  // ---- epilogue (32x32 C layout: lane holds C[m = 32i + (lane&31)][n = 32j + 8g + 4hi + 0..3])
-  const int64_t mrow = m0 + wr * 128 + frow;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = mrow + i * 32;
-    if (m >= M) continue;
-    if constexpr (EPI == GRIT_EPI_SWIGLU) {
-      const int nb = n0 + wc * 64;
-      if (nb < N) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = round_bf(silu_f(round_bf(acc[i][0][4 * g + e]))) * round_bf(acc[i][1][4 * g + e]);
-          *reinterpret_cast<uint2*>(C + m * ldc + (nb >> 1) + 8 * g + 4 * hi) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int nb = n0 + wc * 64 + j * 32;
-        if (nb >= N) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g + 4 * hi;
-          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if constexpr (EPI == GRIT_EPI_RESIDUAL) {
-            const uint2 rv = *reinterpret_cast<const uint2*>(Rsd + m * ldr + n);
-            v[0] = round_bf(v[0]) + bflo(rv.x); v[1] = round_bf(v[1]) + bfhi(rv.x);
-            v[2] = round_bf(v[2]) + bflo(rv.y); v[3] = round_bf(v[3]) + bfhi(rv.y);
-          }
-          *reinterpret_cast<uint2*>(C + m * ldc + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        }
-      }
-    }
-  }
-}
-
 // ======================================================================================================
-// Variant 5: variant 1's loop (two 64 KiB stages, one barrier per K-tile, compiler-scheduled reads) on 32x32x16 MFMAs.
+// Variant 8: K-half ring (4 x 32 KiB slots) + tile-level REGISTER double buffering + explicit issue order.
+//   iteration h:  LDS-DMA of K-half h+4 into the slot whose fragments already sit in registers (slot h&3),
+//                 12 ds_read_b128 of K-half h+1 interleaved (sched_group_barrier) with the 32 MFMAs (16x16x32) of K-half h,
+//                 counted vmcnt(8) (K-half h+2 landed; h+3, h+4 stay in flight), ONE barrier.
+// DMA issue -> first use is 3 iterations (~1.5 us of MFMAs), fragment reads never wait behind the barrier, and the
+// body is branch-free (tail indices are clamped: the last K-half is re-staged into slots nobody reads).
 // ======================================================================================================
 template <int EPI>
-__global__ void __launch_bounds__(512) gemm_bf16_nt_v5_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* C,
+__global__ void __launch_bounds__(512) gemm_bf16_nt_v8_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* C,
                                                          const uint16_t* Rsd, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                                                          int64_t ldc, int64_t ldr, int tiles_m, int tiles_n, int GM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -346,106 +249,144 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_v5_k(const uint16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  const int srow = lane >> 3;
-  const uint16_t* a_src[4];
-  const uint16_t* w_src[4];
+
+  // DMA roles: 16-row chunks 2*wid, 2*wid+1 of the A half and of the W half; 64-B rows, slot ^= (-(row>>2))&3
+  const uint16_t* a_src[2];
+  const uint16_t* w_src[2];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int r = (wid * 4 + c) * 8 + srow;
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);
+  for (int c = 0; c < 2; ++c) {
+    const int r = (wid * 2 + c) * 16 + (lane >> 2);
+    const int slot = (lane & 3) ^ ((0 - (r >> 2)) & 3);   // f(row) = (-(row>>2)) & 3: conflict-free for the 16x16x32 lane groups
     int64_t gm_row = m0 + r; if (gm_row > M - 1) gm_row = M - 1;
     int gn_row = n0 + r; if (gn_row > N - 1) gn_row = N - 1;
     a_src[c] = A + gm_row * lda + slot * 8;
     w_src[c] = W + (int64_t)gn_row * ldw + slot * 8;
   }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE_BYTES + wid * 4096;
+  const int nh = K / KH;
+  auto stage = [&](int h) {   // h may exceed nh-1 near the tail: clamp the SOURCE, keep the slot
+    const int hs = h < nh ? h : nh - 1;
+    char* base = smem + (h & 3) * SLOT_BYTES + wid * 2048;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[c] + (int64_t)kt * BK), (lptr_t)(base + c * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)kt * BK), (lptr_t)(base + A_BYTES + c * 1024), 16, 0, 0);
+    for (int c = 0; c < 2; ++c) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[c] + (int64_t)hs * KH), (lptr_t)(base + c * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)hs * KH), (lptr_t)(base + SLOT_A + c * 1024), 16, 0, 0);
     }
   };
-  const int frow = lane & 31, hi = lane >> 5, swz = (frow >> 1) & 7;
-  const int x_off = (wr * 128 + frow) * 128;
-  const int w_off = A_BYTES + (wc * 64 + frow) * 128;
-  f32x16_t acc[4][2];
+  // fragments (16x16x32): row = 16f + (lane&15); the 32-k slice of a row is 4 slots; lane reads slot kq ^ ((row>>2)&3)
+  const int frow = lane & 15, kq = lane >> 4, swz = (0 - (frow >> 2)) & 3;
+  const int x_off = (wr * 128 + frow) * 64 + ((kq ^ swz) << 4);          // + i*1024 (16 rows x 64 B)
+  const int w_off = SLOT_A + (wc * 64 + frow) * 64 + ((kq ^ swz) << 4);  // + j*1024
+
+  f32x4_t acc[8][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int nk = K / BK;
-  stage(0, 0);
-  lds_dma_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sb = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int so = ((2 * s4 + hi) ^ swz) << 4;
-      bf16x8_t wf[2], xf[4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sb + w_off + j * 4096 + so);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(sb + x_off + i * 4096 + so);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    }
-    lds_dma_barrier();
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8_t wa[4], xa[8], wb[4], xb[8];
+#define V8_READ(WF, XF, SLOT)                                                                        \
+  do {                                                                                               \
+    const char* sb_ = smem + (SLOT) * SLOT_BYTES;                                                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) WF[j] = *reinterpret_cast<const bf16x8_t*>(sb_ + w_off + j * 1024); \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) XF[i] = *reinterpret_cast<const bf16x8_t*>(sb_ + x_off + i * 1024); \
+  } while (0)
+#define V8_MMA(WF, XF)                                                                               \
+  do {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], XF[i], acc[i][j], 0, 0, 0);       \
+  } while (0)
+#define V8_SCHED()                                                                                   \
+  do {                                                                                               \
+    __builtin_amdgcn_sched_group_barrier(0x10, 4, 0);                                                \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                               \
+    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
+    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
+    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
+    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
+    __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);                                                 \
+  } while (0)
+#define V8_SYNC()                                                                                    \
+  do {                                                                                               \
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    asm volatile("" ::: "memory");                                                                   \
+  } while (0)
+
+  stage(0); stage(1); stage(2); stage(3);
+  V8_SYNC();                               // K-halves 0 and 1 have landed, 2 and 3 in flight
+  V8_READ(wa, xa, 0);
+  for (int h = 0; h < nh; h += 2) {
+    // even half-step: compute K-half h (registers A), fetch K-half h+1 into registers B, refill slot h&3 with K-half h+4
+    stage(h + 4);
+    V8_READ(wb, xb, (h + 1) & 3);
+    V8_MMA(wa, xa);
+    V8_SCHED();
+    V8_SYNC();
+    // odd half-step
+    stage(h + 5);
+    V8_READ(wa, xa, (h + 2) & 3);
+    V8_MMA(wb, xb);
+    V8_SCHED();
+    V8_SYNC();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail DMAs before the LDS is released
+#undef V8_READ
+#undef V8_MMA
+#undef V8_SCHED
+#undef V8_SYNC
+
   const int64_t mrow = m0 + wr * 128 + frow;
+  const int ncol = n0 + wc * 64 + kq * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = mrow + i * 32;
+  for (int i = 0; i < 8; ++i) {
+    const int64_t m = mrow + i * 16;
     if (m >= M) continue;
     if constexpr (EPI == GRIT_EPI_SWIGLU) {
-      const int nb = n0 + wc * 64;
-      if (nb < N) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float o[4];
+      for (int j = 0; j < 4; j += 2) {
+        const int nb = n0 + wc * 64 + j * 16;
+        if (nb >= N) continue;
+        const f32x4_t g = acc[i][j], u = acc[i][j + 1];
+        float o[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = round_bf(silu_f(round_bf(acc[i][0][4 * g + e]))) * round_bf(acc[i][1][4 * g + e]);
-          *reinterpret_cast<uint2*>(C + m * ldc + (nb >> 1) + 8 * g + 4 * hi) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-        }
+        for (int r = 0; r < 4; ++r) o[r] = round_bf(silu_f(round_bf(g[r]))) * round_bf(u[r]);
+        *reinterpret_cast<uint2*>(C + m * ldc + (nb >> 1) + kq * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int nb = n0 + wc * 64 + j * 32;
-        if (nb >= N) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g + 4 * hi;
-          float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if constexpr (EPI == GRIT_EPI_RESIDUAL) {
-            const uint2 rv = *reinterpret_cast<const uint2*>(Rsd + m * ldr + n);
-            v[0] = round_bf(v[0]) + bflo(rv.x); v[1] = round_bf(v[1]) + bfhi(rv.x);
-            v[2] = round_bf(v[2]) + bflo(rv.y); v[3] = round_bf(v[3]) + bfhi(rv.y);
-          }
-          *reinterpret_cast<uint2*>(C + m * ldc + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      for (int j = 0; j < 4; ++j) {
+        const int n = ncol + j * 16;
+        if (n >= N) continue;
+        f32x4_t v = acc[i][j];
+        if constexpr (EPI == GRIT_EPI_RESIDUAL) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(Rsd + m * ldr + n);
+          v[0] = round_bf(v[0]) + bflo(rv.x); v[1] = round_bf(v[1]) + bfhi(rv.x);
+          v[2] = round_bf(v[2]) + bflo(rv.y); v[3] = round_bf(v[3]) + bfhi(rv.y);
         }
+        *reinterpret_cast<uint2*>(C + m * ldc + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       }
     }
   }
 }
 
-// kernel generation: 1 = 16x16x32, one barrier per K-tile (default, fastest measured); 4 = K-half ring with counted vmcnt on
-// 32x32x16 (GRIT_GEMM_VARIANT=4, kept for A/B: correct, 13 % slower -- see DESIGN.md "GEMM experiments").
-// GRIT_GEMM_ABLATE=1|2|3 (variant 1, STORE epilogue only; timing experiments, WRONG results):
-// 1 = no LDS-DMA inside the K loop, 2 = no ds_read inside the K loop, 3 = no MFMA.
+// kernel generation: 1 = two 64 KiB stages, one barrier per K-tile (default); 8 = K-half ring + register double buffering
+// (GRIT_GEMM_VARIANT=8: ties variant 1).  Removed after measurement (DESIGN.md "GEMM experiments"): 32x32x16 variants,
+// burst-read / ring variants, one-wave-per-SIMD, weights-direct-to-registers.
+// GRIT_GEMM_ABLATE=<n> (variant 1, STORE epilogue; timing experiments, results WRONG for 1,2,3,10):
+//   1 no LDS-DMA in the K loop, 2 no ds_read, 3 no MFMA, 10 weight half of the DMA skipped; 5 setprio, 6/7 iglp_opt(0/1),
+//   8 explicit issue order one group ahead, 0/9 = default (reads two MFMA groups ahead).
 // GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4: 4 m x 8 n tiles in flight per XCD; measured 2/4/8/16/32 ->
 // 5.41/5.33/5.47/6.03/6.66 ms on the QKV shape, no remap 5.65 ms), GRIT_GEMM_NOREMAP=1 disables the XCD remap (A/B only).
 static int gemm_variant() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("GRIT_GEMM_VARIANT");
-    v = (e != nullptr && (e[0] == '4' || e[0] == '5')) ? (e[0] - '0') : 1;
+    v = (e != nullptr && e[0] == '8') ? 8 : 1;
   }
   return v;
 }
@@ -476,15 +417,14 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
-    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else GRIT_LAUNCH_ABL(7);
-  } else if (gemm_variant() == 4 && N % 32 == 0) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v4_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
-    hipLaunchKernelGGL(gemm_bf16_nt_v4_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
-                       (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n);
-  } else if (gemm_variant() == 5 && N % 32 == 0) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v5_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    hipLaunchKernelGGL(gemm_bf16_nt_v5_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A,
+    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else GRIT_LAUNCH_ABL(10);
+  } else if (gemm_variant() == 8) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v8_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
+    hipLaunchKernelGGL(gemm_bf16_nt_v8_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
                        (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob);
   } else
     GRIT_LAUNCH_ABL(0);
@@ -496,7 +436,7 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
 
 using namespace grit;
 
-extern "C" int grit_swiglu_block(void) { return (gemm_variant() == 4 || gemm_variant() == 5) ? 32 : 16; }
+extern "C" int grit_swiglu_block(void) { return 16; }
 
 extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                                  int64_t ldc, int epilogue, const void* residual, int64_t ldr, void* stream) {
