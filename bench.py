@@ -155,7 +155,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" == RCCL on ROCm
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))     # "nccl" == RCCL on ROCm
 
     from gritlm_amd import ops
     from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine
@@ -224,7 +225,10 @@ def main():
     if not args.no_contrastive:
         del eng, emb
         torch.cuda.empty_cache()
-        contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs)
+        try:
+            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs)
+        except Exception as e:  # noqa: BLE001  -- never lose the primary metric line to the secondary leg
+            contrastive = {"error": repr(e)[:300]}
 
     if rank == 0:
         ks = timer.summary()

@@ -173,10 +173,14 @@ class MistralEncoderEngine:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None = None, borrow: bool = False) -> torch.Tensor:
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None = None, borrow: bool = False,
+                return_kv: bool = False):
         """last_hidden_state [B,S,H] bf16 (after the final RMSNorm), is_causal=False semantics.
 
-        ``borrow=True`` returns a view of the engine's workspace (valid until the next forward)."""
+        ``borrow=True`` returns a view of the engine's workspace (valid until the next forward).
+        ``return_kv=True`` additionally returns, per layer, the post-RoPE keys and the values as
+        ``(k [B,nkv,S,d], v [B,nkv,S,d])`` -- what ``use_cache=True`` hands back in the reference
+        (gritlm/gritlm.py:131-140; RAG doc caching, rag/eval.py:132-142)."""
         c = self.cfg
         B, S = input_ids.shape
         T = B * S
@@ -190,10 +194,14 @@ class MistralEncoderEngine:
         cos, sin = self._rope_tables(S)
         bits = ops.mask_pack(mask)
         ops.embed_gather(self.embed, ids, out=h)
+        kv = []
         for L in self.layers:
             ops.rmsnorm(h, L.ln1, eps, out=x)
             ops.gemm_nt(x, L.wqkv, out=qkv)
             ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
+            if return_kv:
+                kvw = qkv.view(B, S, nq + 2 * nkv, d)
+                kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).contiguous(), kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).contiguous()))
             ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
@@ -201,7 +209,8 @@ class MistralEncoderEngine:
             ops.gemm_nt(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
         ops.rmsnorm(h, self.norm, eps, out=x)
         out = x.view(B, S, c.hidden_size)
-        return out if borrow else out.clone()
+        out = out if borrow else out.clone()
+        return (out, kv) if return_kv else out
 
     __call__ = forward
 

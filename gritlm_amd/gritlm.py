@@ -150,6 +150,15 @@ class GritLM(torch.nn.Module):
         """(last_hidden_state, kv_cache|None) for one tokenised batch."""
         if self.engine is not None and not get_cache:
             return self.engine.forward(inputs["input_ids"], inputs["attention_mask"], borrow=True), None
+        if self.engine is not None and get_cache:
+            # native pass that also emits the per-layer post-RoPE K / V (doc caching for RAG), packaged as the cache type the
+            # installed transformers hands back for use_cache=True
+            from transformers import DynamicCache
+            hidden, kv = self.engine.forward(inputs["input_ids"], inputs["attention_mask"], borrow=True, return_kv=True)
+            cache = DynamicCache()
+            for li, (k, v) in enumerate(kv):
+                cache.update(k, v, li)
+            return hidden, cache
         kw = dict(inputs)
         if (self.attn is not None) and (self.attn[:2] == "bb"):
             kw["is_causal"] = False

@@ -548,6 +548,34 @@ def check_full_shape_properties(B=24, S=512):
     return _res(f"full layer shape properties [B={B},S={S},H=4096,L=2]", ok, max_norm_dev=float((norms - 1).abs().max()))
 
 
+def check_get_cache():
+    """encode(get_cache=True): embeddings + per-layer KV of the bidirectional pass, vs the Hugging Face module on the same GPU
+    (the reference path: gritlm/gritlm.py:131-140 hands back outputs[1])."""
+    import tempfile
+    from gritlm_amd import GritLM
+    g = np.load(os.path.join(GOLDEN, "gritlm_encode.npz"))
+    sents = [str(x) for x in g["sentences"]][:5]
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        m = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16)
+        emb, cache = m.encode(sents, max_length=48, get_cache=True)
+        hf = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, native=False)
+        emb_hf, cache_hf = hf.encode(sents, max_length=48, get_cache=True)
+    ok = hf.engine is None and m.engine is not None
+    one_minus_cos = float(np.max(1 - np.sum(emb * emb_hf, axis=1)))
+    ok &= one_minus_cos < 1e-4
+    worst = 0.0
+    get = lambda c, li: (c.layers[li].keys, c.layers[li].values) if hasattr(c, "layers") else (c[li][0], c[li][1])
+    for li in range(2):
+        (k1, v1), (k2, v2) = get(cache, li), get(cache_hf, li)
+        ok &= tuple(k1.shape) == tuple(k2.shape)
+        for a, b in ((k1, k2), (v1, v2)):
+            e = float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-9))
+            worst = max(worst, e)
+    ok &= worst < 3e-2
+    return _res("encode(get_cache=True): native KV vs Hugging Face KV", ok, emb_1_minus_cos=one_minus_cos, kv_max_rel=worst)
+
+
 ALL_CHECKS = [
     ("embed", check_embed, {}),
     ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
@@ -599,6 +627,7 @@ ALL_CHECKS = [
     ("packed_encode", check_packed_encode, {}),
     ("packed_encode_tiny", check_packed_encode, dict(cfg_name="tiny", B=3, S=260)),
     ("gritlm_native_encode", check_gritlm_native_encode, {}),
+    ("get_cache", check_get_cache, {}),
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
     ("cli_native", check_cli_native, {}),
