@@ -91,6 +91,7 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, st
     m.model, m.embedding_attr, m.projection, m.normalized, m.pooling_method, m.attn = bb, None, None, True, "mean", "bbcc"
     m.emb_loss_fn = DistributedContrastiveLoss(0.02, world > 1)
     m.train_engine = MistralTrainEngine(bb, cfg, dev)
+    m.train_engine.cache_transposed_weights = True      # W^T reused by every GradCache chunk of a step (invalidated after AdamW)
     opt = torch.optim.AdamW(bb.parameters(), lr=1e-5, fused=True)
     gc = GradCacheStep(m, chunk)
     gen = torch.Generator(device=dev).manual_seed(4321 + rank)

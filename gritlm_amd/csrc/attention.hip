@@ -159,20 +159,27 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     } else {
       word = bits[t];
     }
-    const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
     float mx = -INFINITY;
+    if (word == ~0ull) {          // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const uint32_t wsel = kb ? whi : wlo;
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kbit = (r & 3) + 8 * (r >> 2);  // key within the 32-block, minus 4*hi (already shifted)
-        const float s = ((wsel >> kbit) & 1u) ? sacc[kb][r] * scale_log2 : -INFINITY;
-        sacc[kb][r] = s;
-        mx = fmaxf(mx, s);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+    } else {
+      const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const uint32_t wsel = kb ? whi : wlo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kbit = (r & 3) + 8 * (r >> 2);  // key within the 32-block, minus 4*hi (already shifted)
+          const float s = ((wsel >> kbit) & 1u) ? sacc[kb][r] : -INFINITY;
+          sacc[kb][r] = s;
+          mx = fmaxf(mx, s);
+        }
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with the scaling
     const float m_new = fmaxf(m_run, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
@@ -186,10 +193,11 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         uint32_t pk[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          const float p0 = __builtin_amdgcn_exp2f(sacc[kb][8 * c + 2 * jj] - m_use);
-          const float p1 = __builtin_amdgcn_exp2f(sacc[kb][8 * c + 2 * jj + 1] - m_use);
+          // exp2(s*scale - m): one fma + one v_exp per score (masked scores are -inf -> 0)
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj], scale_log2, -m_use));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj + 1], scale_log2, -m_use));
           psum += p0 + p1;
-          pk[jj] = pack2bf(p0, p1);
+          pk[jj] = pack2bf_hw(p0, p1);
         }
         pb[kb][c] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       }

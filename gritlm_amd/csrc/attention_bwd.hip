@@ -65,8 +65,8 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* tr, int db, int rb, int 
   return __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
 }
 __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& v, int c) {
-  return __builtin_bit_cast(bf16x8_t, make_uint4(pack2bf(v[8 * c + 0], v[8 * c + 1]), pack2bf(v[8 * c + 2], v[8 * c + 3]),
-                                                  pack2bf(v[8 * c + 4], v[8 * c + 5]), pack2bf(v[8 * c + 6], v[8 * c + 7])));
+  return __builtin_bit_cast(bf16x8_t, make_uint4(pack2bf_hw(v[8 * c + 0], v[8 * c + 1]), pack2bf_hw(v[8 * c + 2], v[8 * c + 3]),
+                                                  pack2bf_hw(v[8 * c + 4], v[8 * c + 5]), pack2bf_hw(v[8 * c + 6], v[8 * c + 7])));
 }
 
 // ------------------------------------------------------------------ delta = rowsum(dO * O) per (b, head, q)

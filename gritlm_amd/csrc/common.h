@@ -43,6 +43,13 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
   return u >> 16;
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+// hardware pack (v_cvt_pk_bf16_f32, RNE): one instruction for two conversions -- used in the attention inner loops where the
+// bit-trick version above (8 VALU per pair) showed up next to the MFMAs
+__device__ __forceinline__ uint32_t pack2bf_hw(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
 __device__ __forceinline__ float round_bf(float f) { return __uint_as_float(f2bf(f) << 16); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -74,7 +74,7 @@ def main(argv=None):
     model.model.to(device)
     model.model.train()
     if use_cuda and dtype == torch.bfloat16 and getattr(model.model.config, "model_type", "") == "mistral" and model_args.attn[:2] == "bb":
-        model.enable_native(device)
+        model.enable_native(device).cache_transposed_weights = True      # invalidated by weights_updated() after every step
         logger.info("native MI355X engine bound to %s", model_args.model_name_or_path)
     params = [p for p in model.model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, betas=(args.adam_beta1, args.adam_beta2),
