@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32, help="debug only; anything but 32 marks the line invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-contrastive", action="store_true", help="skip the contrastive pairs/s leg")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-batch (padded vs packed) leg")
     ap.add_argument("--pairs", type=int, default=16, help="contrastive pairs per GPU per step (BASELINE configs[2]: 256)")
     args = ap.parse_args()
 
@@ -200,7 +201,7 @@ def main():
 
     # ---- ragged batch (SURVEY §8d "C2 padded variant"): lengths ~ U{64..512}, right-padded; padded vs packed (un-padded) path
     ragged = None
-    if rank == 0 or world > 1:
+    if not args.no_ragged:
         g2 = torch.Generator(device=dev).manual_seed(99 + rank)
         lens = torch.randint(64, SEQ + 1, (DOCS,), generator=g2, device=dev)
         lens[0] = SEQ

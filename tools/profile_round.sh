@@ -6,7 +6,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-rocprofv3 --kernel-trace --stats -d $OUT/bench_stats -o bench --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/bench_stats -o bench --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-contrastive --no-ragged > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o gemm --output-format csv -- python tools/gemm_probe.py > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o gemm --output-format csv -- python tools/gemm_probe.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o gemm --output-format csv -- python tools/gemm_probe.py > $OUT/pmc_write.log 2>&1

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ (tools/profile_round.sh) -> profiles/<tag>_*: kernel stats CSV, bench line under rocprof, GEMM PMC summary."""
+import collections
+import csv
+import json
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+shutil.copy(f"{src}/bench_stats/bench_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
+shutil.copy(f"{src}/bench_stats.json", f"profiles/{tag}_bench_under_rocprof.json")
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"]
+        if "gemm_bf16" not in name:
+            continue
+        key = name.split("(")[0].replace("void ", "")
+        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    return agg, dur
+
+
+out, durs = {}, {}
+for f in ("pmc_sq", "pmc_mfma", "pmc_fetch", "pmc_write"):
+    agg, dur = load(f"{src}/{f}/gemm_counter_collection.csv")
+    for key, c in agg.items():
+        out.setdefault(key, {}).update({k: sum(v) / len(v) for k, v in c.items()})
+    durs.update({k: sum(v) / len(v) for k, v in dur.items() if v})
+shapes = {"0": "qkv M=131072 N=6144 K=4096 (STORE)", "1": "o_proj N=4096 K=4096 and down N=4096 K=14336 averaged (RESIDUAL)",
+          "2": "gate|up N=28672 K=4096 (SWIGLU)"}
+weights = {}
+for k, v in out.items():
+    epi = k.split("<")[1].split(",")[0].strip(">")
+    v["shape"] = shapes.get(epi, "?")
+    weights[k] = 2 if epi == "1" else 1
+    g = v["GRBM_GUI_ACTIVE"] / 8            # the counter is summed over the 8 XCDs
+    v["avg_duration_s_under_pmc"] = durs[k]
+    v["effective_clock_ghz"] = g / durs[k] / 1e9
+    v["mfma_busy_frac_of_simd_cycles"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (g * 1024)
+    v["hbm_side_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024   # guide: FETCH_SIZE x2 on gfx950, KB units
+avg = sum(out[k]["hbm_side_bytes_per_launch"] * weights[k] for k in out) / sum(weights.values())
+res = {"note": "rocprofv3 --pmc passes (SQ / MFMA+GRBM / FETCH_SIZE / WRITE_SIZE each in its own run, --kernel-trace only) on tools/gemm_probe.py, "
+               "M=131072, 3 launches per shape; GRBM_GUI_ACTIVE is summed over the 8 XCDs; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (chip cycles x 1024 SIMDs)",
+       "kernels": out, "avg_traffic_bytes_per_gemm_launch_in_forward": avg}
+json.dump(res, open(f"profiles/{tag}_gemm_pmc.json", "w"), indent=1)
+for k, v in out.items():
+    print(k, f"dur={v['avg_duration_s_under_pmc']*1e3:.2f}ms clock={v['effective_clock_ghz']:.2f}GHz mfma_busy={v['mfma_busy_frac_of_simd_cycles']:.3f} "
+             f"traffic={v['hbm_side_bytes_per_launch']/1e9:.1f}GB lds_conflicts={v['SQ_LDS_BANK_CONFLICT']:.0f}")
+print("avg traffic per launch (GB):", avg / 1e9)
+rows = list(csv.DictReader(open(f"profiles/{tag}_bench_kernel_stats.csv")))
+for r in rows[:8]:
+    print(r["Name"][:60].ljust(60), r["Calls"].rjust(5), f'{float(r["TotalDurationNs"])/1e6:9.1f} ms', r["Percentage"])
