@@ -61,6 +61,79 @@ __global__ void __launch_bounds__(256) rmsnorm_bwd_k(const uint4* __restrict__ d
 }
 
 // one workgroup per 64 columns: 4 waves split the partial rows, lanes are consecutive columns (coalesced 256-B rows)
+// Fast path for H = NCH * 512 (every lane owns the same 8*NCH columns in every row): the row stays in registers between the two
+// sweeps and the weight gradient accumulates in registers; one LDS reduction per workgroup at the end instead of LDS atomics per row.
+template <int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_bwd_reg_k(const uint4* __restrict__ dy, const uint4* __restrict__ x, const uint4* __restrict__ w,
+                                                         const uint4* dres, uint4* dx, float* __restrict__ dw_partial, int64_t T, int H,
+                                                         float eps) {
+  __shared__ float red[3][NCH * 512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HC = H >> 3;
+  float dwa[NCH][8];
+  uint4 wv[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    wv[c] = w[c * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dwa[c][e] = 0.f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T; row += (int64_t)gridDim.x * 4) {
+    uint4 xv[NCH], gv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { xv[c] = x[row * HC + c * 64 + lane]; gv[c] = dy[row * HC + c * 64 + lane]; }
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint32_t xa[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w}, ga[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w},
+                     wa[4] = {wv[c].x, wv[c].y, wv[c].z, wv[c].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = bflo(xa[e]), x1 = bfhi(xa[e]);
+        ss += x0 * x0 + x1 * x1;
+        dot += bflo(ga[e]) * bflo(wa[e]) * x0 + bfhi(ga[e]) * bfhi(wa[e]) * x1;
+      }
+    }
+    ss = wave_sum(ss); dot = wave_sum(dot);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    const float k2 = rs * rs * rs * dot / (float)H;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      uint4 rv = make_uint4(0, 0, 0, 0);
+      if (dres != nullptr) rv = dres[row * HC + c * 64 + lane];
+      const uint32_t xa[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w}, ga[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w},
+                     wa[4] = {wv[c].x, wv[c].y, wv[c].z, wv[c].w}, ra[4] = {rv.x, rv.y, rv.z, rv.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = bflo(xa[e]), x1 = bfhi(xa[e]), g0 = bflo(ga[e]), g1 = bfhi(ga[e]);
+        o[e] = pack2bf(rs * g0 * bflo(wa[e]) - x0 * k2 + bflo(ra[e]), rs * g1 * bfhi(wa[e]) - x1 * k2 + bfhi(ra[e]));
+        dwa[c][2 * e] += g0 * x0 * rs;
+        dwa[c][2 * e + 1] += g1 * x1 * rs;
+      }
+      dx[row * HC + c * 64 + lane] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  // waves 1..3 park their partial sums in LDS, wave 0 adds them up and writes the workgroup's row of dw_partial
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave - 1][(c * 64 + lane) * 8 + e] = dwa[c][e];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* outp = dw_partial + (int64_t)blockIdx.x * H;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = (c * 64 + lane) * 8 + e;
+        outp[col] = dwa[c][e] + red[0][col] + red[1][col] + red[2][col];
+      }
+  }
+}
+
 __global__ void __launch_bounds__(256) rmsnorm_dw_reduce_k(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int H) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,8 +240,16 @@ int grit_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* d
     attr_set = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rmsnorm_bwd_k, dim3(nblk), dim3(256), (size_t)H * 4, st, (const uint4*)dy, (const uint4*)x, (const uint4*)w,
-                     (const uint4*)dres, (uint4*)dx, dw_partial, T, H, eps);
+#define GRIT_RMSBWD_REG(NCH_)                                                                                                   \
+  hipLaunchKernelGGL(rmsnorm_bwd_reg_k<NCH_>, dim3(nblk), dim3(256), 0, st, (const uint4*)dy, (const uint4*)x, (const uint4*)w,      \
+                     (const uint4*)dres, (uint4*)dx, dw_partial, T, H, eps)
+  if (H == 512) GRIT_RMSBWD_REG(1);
+  else if (H == 1024) GRIT_RMSBWD_REG(2);
+  else if (H == 2048) GRIT_RMSBWD_REG(4);
+  else if (H == 4096) GRIT_RMSBWD_REG(8);
+  else
+    hipLaunchKernelGGL(rmsnorm_bwd_k, dim3(nblk), dim3(256), (size_t)H * 4, st, (const uint4*)dy, (const uint4*)x, (const uint4*)w,
+                       (const uint4*)dres, (uint4*)dx, dw_partial, T, H, eps);
   GRIT_CHECK_LAUNCH("grit_rmsnorm_bwd");
   hipLaunchKernelGGL(rmsnorm_dw_reduce_k, dim3((H + 63) / 64), dim3(256), 0, st, (const float*)dw_partial, dw, nblk, H);
   GRIT_CHECK_LAUNCH("grit_rmsnorm_bwd: reduce");

@@ -96,8 +96,18 @@ def main(argv=None):
             p = {k: v.to(device) for k, v in batch["passage"].items()}
             if gc is not None:
                 loss = gc(q, p)
+            elif args.split_emb:
+                # two half-steps (gradcache_trainer.py:584-605): queries with grad vs frozen passages, then the converse;
+                # both see the same scores, so the two losses agree
+                lq = model(query=q, passage=p, p_grad=False).loss
+                lq.backward()
+                lp = model(query=q, passage=p, q_grad=False).loss
+                lp.backward()
+                assert torch.allclose(lq.detach(), lp.detach(), rtol=1e-3, atol=1e-4), (float(lq), float(lp))
+                loss = lp
+                sync_gradients(model)
             else:
-                loss = model(query=q, passage=p).loss
+                loss = model(query=q, passage=p, q_grad=not args.emb_p_only, p_grad=not args.emb_q_only).loss
                 loss.backward()
                 sync_gradients(model)
             if args.max_grad_norm and args.max_grad_norm > 0:

@@ -59,3 +59,18 @@ def test_collator_instruction_format(tmp_path):
     # the instruction prefix is a strict prefix of the row: there is text left to embed
     for i, l in enumerate(batch["query"]["instruction_lens"].tolist()):
         assert batch["query"]["attention_mask"][i, l] == 1
+
+
+def test_cli_direct_step_variants(tmp_path):
+    """non-GradCache step and the reference's q-only / p-only / split_emb variants (gradcache_trainer.py:584-605, 656-718)."""
+    from gritlm_amd.training.run import main
+    d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
+    data = _toy(str(tmp_path / "toy.jsonl"))
+    base = ["--model_name_or_path", d, "--train_data", data, "--per_device_train_batch_size", "3", "--train_group_size", "4",
+            "--pooling_method", "weightedmean", "--max_steps", "1", "--learning_rate", "1e-4", "--query_max_len", "16", "--passage_max_len", "24",
+            "--report_to", "none", "--use_cpu"]
+    losses = []
+    for i, extra in enumerate(([], ["--emb_q_only"], ["--emb_p_only"], ["--split_emb"])):
+        losses.append(main(base + ["--output_dir", str(tmp_path / f"o{i}")] + extra))
+    assert all(np.isfinite(l) for l in losses)
+    assert max(losses) - min(losses) < 1e-4            # same seed, same first batch: the forward loss is identical in all variants
