@@ -136,12 +136,20 @@ class MistralTrainEngine:
         return buf
 
     def _wt(self, li: int, name: str, w: torch.Tensor) -> torch.Tensor:
+        """W^T for the dgrad GEMM.  With ``cache_transposed_weights`` it is reused by every GradCache chunk of a step; the cache is
+        keyed on the owning Parameters' version counters, so an in-place optimizer update invalidates it even
+        if ``weights_updated()`` is never called."""
         key = (li, name)
-        t = self._wT.get(key) if self.cache_transposed_weights else None
-        if t is None:
-            t = ops.transpose(w.data)
-            if self.cache_transposed_weights:
-                self._wT[key] = t
+        at, mlp, _ = self.layers[li].mods
+        owners = {"qkv": (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), "o": (at.o_proj.weight,),
+                  "gu": (mlp.gate_proj.weight, mlp.up_proj.weight), "down": (mlp.down_proj.weight,)}[name]
+        ver = tuple(p._version for p in owners)       # the Parameters' counters (the packed base tensor's own counter does not see them)
+        hit = self._wT.get(key) if self.cache_transposed_weights else None
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        t = ops.transpose(w.data)
+        if self.cache_transposed_weights:
+            self._wT[key] = (ver, t)
         return t
 
     # ------------------------------------------------------------------ forward

@@ -437,6 +437,16 @@ def check_train_step(mode="direct"):
             out[n.replace("layers.", "L").replace(".weight", "")] = rel
             worst = max(worst, rel)
         ok &= worst < 6e-2
+        if mode == "gradcache":
+            # transposed-weight cache follows in-place parameter updates without an explicit weights_updated()
+            eng = m.train_engine
+            eng.cache_transposed_weights = True
+            L0 = eng.layers[0]
+            t1 = eng._wt(0, "qkv", L0.wqkv); t1b = eng._wt(0, "qkv", L0.wqkv)
+            with torch.no_grad():
+                L0.mods[0].k_proj.weight.add_(1.0)
+            t2 = eng._wt(0, "qkv", L0.wqkv)
+            ok &= (t1 is t1b) and (t2 is not t1) and bool(torch.equal(t2, L0.wqkv.t().contiguous()))
         # state_dict keeps the reference names although q/k/v and gate/up live in packed storage
         ok &= all(k in m.model.state_dict() for k in ("layers.0.self_attn.k_proj.weight", "layers.1.mlp.up_proj.weight"))
     return _res(f"native train step [{mode}] vs reference loss+grads", ok, **out)
