@@ -195,8 +195,11 @@ class MistralTrainEngine:
         return xf.view(B, S, H), saved
 
     # ------------------------------------------------------------------ backward
-    def backward(self, saved: SavedForward, d_last_hidden: torch.Tensor):
-        """Accumulate parameter gradients for d loss / d last_hidden_state = ``d_last_hidden`` [B,S,H] bf16."""
+    def backward(self, saved: SavedForward, d_last_hidden: torch.Tensor, on_layer_done=None):
+        """Accumulate parameter gradients for d loss / d last_hidden_state = ``d_last_hidden`` [B,S,H] bf16.
+
+        ``on_layer_done(list_of_grad_buffers)`` is called as soon as a layer's four weight-gradient buffers are final for this
+        call (data-parallel training passes a callback that starts their all-reduce, overlapping it with the remaining layers)."""
         c = self.cfg
         self.prepare_grads()
         B, S = saved.B, saved.S
@@ -229,6 +232,8 @@ class MistralTrainEngine:
             ops.gemm_nt(self._transposed_act(dqkv, "dqkv"), self._transposed_act(sv["x1"], "x"), out=L.gqkv, epilogue=EPI_RESIDUAL,
                         residual=L.gqkv)
             dh = ops.rmsnorm_bwd(dx1, sv["h_in"], L.ln1.data, eps, ng[2 * li], dres=dh_mid)
+            if on_layer_done is not None:
+                on_layer_done([L.gqkv, L.go, L.ggu, L.gdown])
         # ---- embedding + fold the fp32 side accumulators into the bf16 .grad tensors
         if self._f32_embed_grad is None:
             self._f32_embed_grad = torch.zeros(tuple(self.embed.shape), dtype=F32, device=self.device)
@@ -241,12 +246,13 @@ class MistralTrainEngine:
         ops.accum_bf16_from_f32(self.norm.grad, ng[2 * nL])
         ng.zero_()
 
-    def grad_buffers(self) -> list[torch.Tensor]:
-        """Flat list of gradient storages (few, large): the buckets of the data-parallel all-reduce."""
+    def grad_buffers(self, small_only: bool = False) -> list[torch.Tensor]:
+        """Flat list of gradient storages (few, large): the buckets of the data-parallel all-reduce.
+        ``small_only``: just the 1-D norm weights and the embedding (the rest was reduced layer by layer during backward)."""
         self.prepare_grads()
         out = []
         for L in self.layers:
-            out += [L.gqkv, L.go, L.ggu, L.gdown, L.ln1.grad, L.ln2.grad]
+            out += ([] if small_only else [L.gqkv, L.go, L.ggu, L.gdown]) + [L.ln1.grad, L.ln2.grad]
         return out + [self.embed.grad, self.norm.grad]
 
 

@@ -36,6 +36,34 @@ def _rows(chunk: Dict) -> int:
     return v.shape[0] if isinstance(v, torch.Tensor) else len(v)
 
 
+class OverlappedGradSync:
+    """Data-parallel gradient averaging overlapped with the backward of the LAST GradCache chunk (what DDP does when ``no_sync`` is
+    lifted on the last chunk, grad_cache.py:230-236): the native engine reports each layer's packed gradient buffers as soon as
+    they are final and their all-reduce (RCCL, own stream) runs under the remaining layers' backward kernels."""
+
+    def __init__(self, model):
+        self.model, self.pending = model, []
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 \
+            and getattr(model, "train_engine", None) is not None
+
+    def arm(self):
+        if self.active:
+            self.model._on_layer_done = lambda bufs: self.pending.extend((b, dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True)) for b in bufs)
+
+    def finish(self):
+        if not self.active:
+            sync_gradients(self.model)
+            return
+        self.model._on_layer_done = None
+        w = dist.get_world_size()
+        small = self.model.train_engine.grad_buffers(small_only=True)
+        self.pending.extend((b, dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True)) for b in small)
+        for b, h in self.pending:
+            h.wait()
+            b.div_(w)
+        self.pending.clear()
+
+
 def sync_gradients(model) -> None:
     """Average gradients over ranks (DDP semantics: the effective gradient is (1/W) * grad of the global loss)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -121,13 +149,17 @@ class GradCacheStep:
             loss = loss_fn(q_leaf, p_leaf)
         loss.backward()
         caches = (q_leaf.grad, p_leaf.grad)
-        # pass 2
-        for chunks, cache in ((q_chunks, caches[0]), (p_chunks, caches[1])):
-            row = 0
-            for c in chunks:
-                reps = model.encode(c)
-                reps.backward(gradient=cache[row:row + reps.shape[0]].to(reps.dtype))
-                row += reps.shape[0]
-        if sync:
-            sync_gradients(model)
+        # pass 2 (the gradient all-reduce of the data-parallel ranks rides under the last chunk's backward)
+        gsync = OverlappedGradSync(model) if sync else None
+        work = [(c, caches[0], "q") for c in q_chunks] + [(c, caches[1], "p") for c in p_chunks]
+        rows = {"q": 0, "p": 0}
+        for idx, (c, cache, which) in enumerate(work):
+            if gsync is not None and idx == len(work) - 1:
+                gsync.arm()
+            reps = model.encode(c)
+            r0 = rows[which]
+            reps.backward(gradient=cache[r0:r0 + reps.shape[0]].to(reps.dtype))
+            rows[which] = r0 + reps.shape[0]
+        if gsync is not None:
+            gsync.finish()
         return loss.detach()

@@ -166,7 +166,7 @@ class _NativeEncodeFn(torch.autograd.Function):
         S = ctx.saved.S
         dh = ops.pool_norm_bwd(ctx.reps, d_reps.float().contiguous(), ctx.inv, ctx.mask, model.pooling_method, bool(model.normalized), S,
                                ctx.instr)
-        model.train_engine.backward(ctx.saved, dh)
+        model.train_engine.backward(ctx.saved, dh, on_layer_done=getattr(model, "_on_layer_done", None))
         ctx.saved = None
         return None, None, None, None, None
 

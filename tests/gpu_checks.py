@@ -586,6 +586,83 @@ def check_get_cache():
     return _res("encode(get_cache=True): native KV vs Hugging Face KV", ok, emb_1_minus_cos=one_minus_cos, kv_max_rel=worst)
 
 
+def _overlap_worker(rank, world, port, model_dir, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo all_reduce accepts device tensors: enough for this path
+    try:
+        torch.cuda.set_device(0)
+        from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+        g = np.load(os.path.join(GOLDEN, "gradcache_tiny.npz"))
+        m = GritLMTrainModel(model_name_or_path=model_dir, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=0.02, negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16)
+        m.enable_native()
+        bq, G = 2, int(g["group"])
+        sq, sp = slice(rank * bq, (rank + 1) * bq), slice(rank * bq * G, (rank + 1) * bq * G)
+        q = {"input_ids": torch.from_numpy(g["q_ids"][sq]).cuda(), "attention_mask": torch.from_numpy(g["q_mask"][sq]).cuda()}
+        p = {"input_ids": torch.from_numpy(g["p_ids"][sp]).cuda(), "attention_mask": torch.from_numpy(g["p_mask"][sp]).cuda()}
+        GradCacheStep(m, chunk_size=2)(q, p, sync=(world > 1))
+        sd = dict(m._backbone().named_parameters())
+        ret[(world, rank)] = {n: sd[n].grad.float().cpu().numpy() for n in ("layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight",
+                                                                            "norm.weight", "embed_tokens.weight")}
+    finally:
+        dist.destroy_process_group()
+
+
+def check_overlapped_grad_sync():
+    """Data-parallel gradient averaging overlapped with the last chunk's backward (OverlappedGradSync + engine.backward callback):
+    2 processes on this GPU, each with half of the batch (local negatives), must end with the mean of the two single-process grads."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    def port():
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); p_ = s_.getsockname()[1]; s_.close(); return p_
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        mgr = mp.Manager(); ret = mgr.dict()
+        mp.spawn(_overlap_worker, args=(2, port(), d16, ret), nprocs=2, join=True)
+        solo = mgr.dict()
+        for r in range(2):        # the same two half-batches, no averaging: world "1" runs that reuse the rank's slice
+            mp.spawn(_solo_worker, args=(r, port(), d16, solo), nprocs=1, join=True)
+    worst, ok = 0.0, True
+    for n in ret[(2, 0)]:
+        mean = 0.5 * (solo[0][n] + solo[1][n])
+        for r in range(2):
+            e = float(np.linalg.norm(ret[(2, r)][n] - mean) / (np.linalg.norm(mean) + 1e-20))
+            worst = max(worst, e)
+        ok &= np.array_equal(ret[(2, 0)][n], ret[(2, 1)][n])
+    return _res("overlapped data-parallel gradient sync (2 processes)", ok and worst < 2e-2, worst_rel=worst)
+
+
+def _solo_worker(_, rank, port, model_dir, ret):
+    tmp = {}
+    _overlap_worker_solo(rank, port, model_dir, tmp)
+    ret[rank] = tmp["g"]
+
+
+def _overlap_worker_solo(rank, port, model_dir, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.cuda.set_device(0)
+        from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+        g = np.load(os.path.join(GOLDEN, "gradcache_tiny.npz"))
+        m = GritLMTrainModel(model_name_or_path=model_dir, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=0.02, negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16)
+        m.enable_native()
+        bq, G = 2, int(g["group"])
+        sq, sp = slice(rank * bq, (rank + 1) * bq), slice(rank * bq * G, (rank + 1) * bq * G)
+        q = {"input_ids": torch.from_numpy(g["q_ids"][sq]).cuda(), "attention_mask": torch.from_numpy(g["q_mask"][sq]).cuda()}
+        p = {"input_ids": torch.from_numpy(g["p_ids"][sp]).cuda(), "attention_mask": torch.from_numpy(g["p_mask"][sp]).cuda()}
+        GradCacheStep(m, chunk_size=2)(q, p, sync=False)
+        sd = dict(m._backbone().named_parameters())
+        out["g"] = {n: sd[n].grad.float().cpu().numpy() for n in ("layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight",
+                                                                  "norm.weight", "embed_tokens.weight")}
+    finally:
+        dist.destroy_process_group()
+
+
 ALL_CHECKS = [
     ("embed", check_embed, {}),
     ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
@@ -641,4 +718,5 @@ ALL_CHECKS = [
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
     ("cli_native", check_cli_native, {}),
+    ("overlapped_grad_sync", check_overlapped_grad_sync, {}),
 ]
