@@ -189,31 +189,48 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     const int64_t m = mrow + i * 16;
     if (m >= M) continue;
     if constexpr (EPI == GRIT_EPI_SWIGLU) {
+      // fragments (0,1) and (2,3) are (gate, up) pairs -> two 16-column output blocks; the same permlane16 exchange gives every
+      // lane 8 consecutive output columns
+      const int nb = n0 + wc * 64;             // multiple of 64
+      if (nb < N) {
+        float o0[4], o1[4];
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int nb = n0 + wc * 64 + j * 16;  // multiple of 32: gate block j, up block j+1
-        if (nb >= N) continue;
-        const f32x4_t g = acc[i][j], u = acc[i][j + 1];
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = round_bf(silu_f(round_bf(g[r]))) * round_bf(u[r]);
-        uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-        *reinterpret_cast<uint2*>(C + m * ldc + (nb >> 1) + kq * 4) = pk;
+        for (int r = 0; r < 4; ++r) {
+          o0[r] = round_bf(silu_f(round_bf(acc[i][0][r]))) * round_bf(acc[i][1][r]);
+          o1[r] = round_bf(silu_f(round_bf(acc[i][2][r]))) * round_bf(acc[i][3][r]);
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o0[r]), __float_as_uint(o1[r]), false, false);
+          o0[r] = __uint_as_float(sw[0]); o1[r] = __uint_as_float(sw[1]);
+        }
+        const int oc = (nb >> 1) + (kq & 1) * 16 + (kq >> 1) * 8;
+        if (2 * oc < N)
+          *reinterpret_cast<uint4*>(C + m * ldc + oc) = make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]),
+                                                                  pack2bf(o1[2], o1[3]));
       }
     } else {
+      // 16-byte stores: v_permlane16_swap exchanges the 16-lane rows of two adjacent n-fragments so that every lane ends up with
+      // 8 CONSECUTIVE columns (rows 0/2 of the wave keep fragment j, rows 1/3 take fragment j+1) -- half the store (and residual
+      // load) instructions of the natural 4-columns-per-lane layout; the store tail is issue-bound (guide T21)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = ncol + j * 16;
-        if (n >= N) continue;
-        f32x4_t v = acc[i][j];
-        if constexpr (EPI == GRIT_EPI_RESIDUAL) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(Rsd + m * ldr + n);
-          // the reference rounds the Linear output to bf16 before the residual add (:769,:775)
-          v[0] = round_bf(v[0]) + bflo(rv.x); v[1] = round_bf(v[1]) + bfhi(rv.x);
-          v[2] = round_bf(v[2]) + bflo(rv.y); v[3] = round_bf(v[3]) + bfhi(rv.y);
+      for (int jp = 0; jp < 4; jp += 2) {
+        f32x4_t lo = acc[i][jp], hi4 = acc[i][jp + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo[r]), __float_as_uint(hi4[r]), false, false);
+          lo[r] = __uint_as_float(sw[0]); hi4[r] = __uint_as_float(sw[1]);
         }
-        uint2 pk = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        *reinterpret_cast<uint2*>(C + m * ldc + n) = pk;
+        const int n = n0 + wc * 64 + (jp + (kq & 1)) * 16 + (kq >> 1) * 8;
+        if (n >= N) continue;
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        if constexpr (EPI == GRIT_EPI_RESIDUAL) {
+          // the reference rounds the Linear output to bf16 before the residual add (:769,:775)
+          const uint4 rv = *reinterpret_cast<const uint4*>(Rsd + m * ldr + n);
+          const uint32_t ra[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] = round_bf(v[2 * e]) + bflo(ra[e]); v[2 * e + 1] = round_bf(v[2 * e + 1]) + bfhi(ra[e]); }
+        }
+        const uint4 pk = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        if (ABL == 11) { asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w)); continue; }   // timing experiment: no stores
+        *reinterpret_cast<uint4*>(C + m * ldc + n) = pk;
       }
     }
   }
@@ -420,8 +437,9 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
-    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else GRIT_LAUNCH_ABL(10);
+    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else GRIT_LAUNCH_ABL(11);
   } else if (gemm_variant() == 8) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v8_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
     hipLaunchKernelGGL(gemm_bf16_nt_v8_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
@@ -445,7 +463,7 @@ extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t 
   GRIT_REQUIRE(M >= 0 && N > 0 && K > 0, GRIT_E_BADARG, "grit_gemm_bf16_nt: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
   GRIT_REQUIRE(K % 64 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: K=%d must be a multiple of 64", K);
   GRIT_REQUIRE(N % 16 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: N=%d must be a multiple of 16", N);
-  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && lda >= K && ldw >= K, GRIT_E_BADARG,
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K, GRIT_E_BADARG,
                "grit_gemm_bf16_nt: bad leading dimensions lda=%lld ldw=%lld ldc=%lld", (long long)lda, (long long)ldw, (long long)ldc);
   GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C), GRIT_E_BADARG, "grit_gemm_bf16_nt: pointers must be 16-byte aligned");
   GRIT_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: too many tiles");
@@ -456,7 +474,7 @@ extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t 
       GRIT_REQUIRE(ldc >= N, GRIT_E_BADARG, "grit_gemm_bf16_nt: ldc < N");
       return launch_gemm<GRIT_EPI_STORE>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
     case GRIT_EPI_RESIDUAL:
-      GRIT_REQUIRE(residual && ldr % 4 == 0 && ldr >= N && ldc >= N && aligned16(residual), GRIT_E_BADARG,
+      GRIT_REQUIRE(residual && ldr % 8 == 0 && ldr >= N && ldc >= N && aligned16(residual), GRIT_E_BADARG,
                    "grit_gemm_bf16_nt: RESIDUAL epilogue needs residual with ldr >= N");
       return launch_gemm<GRIT_EPI_RESIDUAL>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
     case GRIT_EPI_SWIGLU:
