@@ -94,3 +94,31 @@ def test_two_rank_gradcache_step_equals_reference_global_batch(tmp_path):
             np.testing.assert_allclose(world * got, ref, atol=3e-3 * np.abs(ref).max())
     for n in ret[0]["grads"]:
         np.testing.assert_array_equal(ret[0]["grads"][n], ret[1]["grads"][n])      # replicas stay in lock-step
+
+
+def _enc_worker(rank, world, port, model_dir, sents, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from gritlm_amd import GritLM
+        from gritlm_amd.distributed import encode_sharded
+        m = GritLM(model_dir, pooling_method="mean", attn="bbcc", device="cpu")
+        ret[rank] = encode_sharded(m, sents, batch_size=4, max_length=32)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_encode_equals_single_process(tmp_path):
+    """Encode shards by contiguous document slices (replicas, no data-path collective); the gathered result is the single-process result."""
+    import synth
+    from gritlm_amd import GritLM
+    from gritlm_amd.distributed import shard_bounds
+    assert [shard_bounds(7, 3, r) for r in range(3)] == [(0, 3), (3, 5), (5, 7)]
+    d = synth.build_mistral_dir(str(tmp_path / "m32"), "tiny", 0, "float32")
+    sents = synth.make_sentences(7, seed=9, max_words=25)
+    ref = GritLM(d, pooling_method="mean", attn="bbcc", device="cpu").encode(sents, batch_size=4, max_length=32)
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_enc_worker, args=(2, _free_port(), d, sents, ret), nprocs=2, join=True)
+    for r in range(2):
+        np.testing.assert_allclose(ret[r], ref, atol=2e-6)
