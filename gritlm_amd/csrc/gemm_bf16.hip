@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (ABL == 0 || ABL == 8 || ABL == 9) stage(cur ^ 1, kt + 1 < nk ? kt + 1 : kt);   // branch-free body (re-stages the last tile once, harmless)
+    if (ABL == 0 || ABL == 8 || ABL == 9 || ABL == 12 || ABL == 13) stage(cur ^ 1, kt + 1 < nk ? kt + 1 : kt);   // branch-free body (re-stages the last tile once, harmless)
     else if (kt + 1 < nk && ABL != 1) stage(cur ^ 1, kt + 1);
     const char* sb = smem + (ABL == 2 ? 0 : cur * STAGE_BYTES);
 #pragma unroll
@@ -160,6 +160,34 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G6
       __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G7
+    }
+    if (ABL == 12) {  // LDS-DMA spread: one per 8-MFMA group
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 10, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+    }
+    if (ABL == 13) {  // LDS-DMA spread over the first half: one per 4 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
     }
     if (ABL == 0 || ABL == 9) {  // default: fragment reads issued two MFMA groups ahead of their consumers
       __builtin_amdgcn_sched_group_barrier(0x10, 8, 0);
@@ -438,8 +466,10 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
-    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else GRIT_LAUNCH_ABL(11);
+    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else if (abl == 11) GRIT_LAUNCH_ABL(11); else if (abl == 12) GRIT_LAUNCH_ABL(12); else GRIT_LAUNCH_ABL(13);
   } else if (gemm_variant() == 8) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v8_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
     hipLaunchKernelGGL(gemm_bf16_nt_v8_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
