@@ -424,7 +424,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_v8_k(const uint16_t* __restr
 // burst-read / ring variants, one-wave-per-SIMD, weights-direct-to-registers.
 // GRIT_GEMM_ABLATE=<n> (variant 1, STORE epilogue; timing experiments, results WRONG for 1,2,3,10):
 //   1 no LDS-DMA in the K loop, 2 no ds_read, 3 no MFMA, 10 weight half of the DMA skipped; 5 setprio, 6/7 iglp_opt(0/1),
-//   8 explicit issue order one group ahead, 0/9 = default (reads two MFMA groups ahead).
+//   8 explicit issue order one group ahead, 0/9 = default (reads two MFMA groups ahead), 11 no epilogue stores,
+//   12/13 LDS-DMA issue spread over the MFMAs (1 per 8 / 1 per 4).
 // GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4: 4 m x 8 n tiles in flight per XCD; measured 2/4/8/16/32 ->
 // 5.41/5.33/5.47/6.03/6.66 ms on the QKV shape, no remap 5.65 ms), GRIT_GEMM_NOREMAP=1 disables the XCD remap (A/B only).
 static int gemm_variant() {

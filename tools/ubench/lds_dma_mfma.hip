@@ -28,8 +28,16 @@ __global__ void __launch_bounds__(512) k(const char* __restrict__ src, float* __
   for (int j = 0; j < 4; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, j, 1, 2));
 #pragma unroll
   for (int i = 0; i < 8; ++i) xf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(lane, i, 3, 4));
+  uint4 stg[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) stg[c] = make_uint4(0, 0, 0, 0);
   for (int it = 0; it < iters; ++it) {
     const int buf = it & 1;
+    if (MODE & 32) {  // register staging instead of LDS-DMA: 8 x global_load_dwordx4 now, 8 x ds_write_b128 at the end of the iteration
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        stg[c] = *reinterpret_cast<const uint4*>(base + ((size_t)(it & 63) * 65536 + (wid * 8 + c) * 1024 + lane * 16) % window);
+    }
     if ((MODE & 1) && !(MODE & 16)) {  // DMA: 8 per wave, 1 KiB each, into the other buffer
 #pragma unroll
       for (int c = 0; c < 8; ++c)
@@ -61,6 +69,10 @@ __global__ void __launch_bounds__(512) k(const char* __restrict__ src, float* __
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(wf[j]));
       }
+    }
+    if (MODE & 32) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(smem + (buf ^ 1) * 65536 + (wid * 8 + c) * 1024 + lane * 16) = stg[c];
     }
     if (MODE & 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // deferred: only the PREVIOUS iteration's DMA must have landed
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -107,6 +119,9 @@ int main() {
     printf("  D+R+M deferred wait      %6.3f us | interleaved issue %6.3f us | both %6.3f us\n", run<7 + 8>(src, sink, iters, w, blocks) * 1e3 / iters,
            run<7 + 16>(src, sink, iters, w, blocks) * 1e3 / iters, run<7 + 24>(src, sink, iters, w, blocks) * 1e3 / iters);
     printf("  D     deferred wait      %6.3f us\n", run<1 + 8>(src, sink, iters, w, blocks) * 1e3 / iters);
+    printf("  register staging (global_load_dwordx4 -> ds_write_b128):  G %6.3f us | G+R %6.3f us | G+M %6.3f us | G+R+M %6.3f us\n",
+           run<32>(src, sink, iters, w, blocks) * 1e3 / iters, run<32 + 2>(src, sink, iters, w, blocks) * 1e3 / iters,
+           run<32 + 4>(src, sink, iters, w, blocks) * 1e3 / iters, run<32 + 6>(src, sink, iters, w, blocks) * 1e3 / iters);
   }
   return 0;
 }
