@@ -77,7 +77,7 @@ def cpu_baseline(sample_docs=16, seq=SEQ, layers=2):
             "raw_docs_per_s_reduced_model": raw, "seconds": dt}
 
 
-def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, steps=2, warmup=1):
+def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, steps=2, warmup=1, ragged_too=True):
     """Second headline metric: contrastive pairs/s.  One step = GradCache contrastive step on (q, pos, 7 neg) @ seq512:
     pass 1 (no grad) -> packed all-gather of the reps (N > 1) -> fused InfoNCE -> pass 2 forward+backward per chunk ->
     gradient all-reduce (N > 1) -> AdamW.  `pairs` per rank is reduced from BASELINE configs[2]'s 256 to keep the default
@@ -123,6 +123,31 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, st
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     pairs_per_s = world * pairs * steps / dt
+
+    # ragged training batch (rank-local, outside the timed region above): lengths U{64..512} right-padded to 512 --
+    # padded rows through every kernel (what the reference's SDPA path does) vs the packed (un-padded) training path
+    ragged = None
+    if ragged_too:
+        def rag(n):
+            b = mk(n)
+            lens = torch.randint(64, SEQ + 1, (n,), generator=gen, device=dev)
+            b["attention_mask"] = (torch.arange(SEQ, device=dev).unsqueeze(0) < lens.unsqueeze(1)).to(torch.int64)
+            return b, float(lens.float().mean().item())
+        (rq, lq), (rp, lp) = rag(pairs), rag(pairs * group)
+        rates, losses = {}, {}
+        for packed in (False, True):
+            m.native_packed = packed
+            loss_r = gc(rq, rp); opt.zero_grad(set_to_none=True)          # warm-up (buffers sized for this layout)
+            torch.cuda.synchronize()
+            t0r = time.perf_counter()
+            loss_r = gc(rq, rp)
+            opt.step(); opt.zero_grad(set_to_none=True); m.train_engine.weights_updated()
+            torch.cuda.synchronize()
+            rates[packed], losses[packed] = pairs / (time.perf_counter() - t0r), float(loss_r)
+        m.native_packed = True
+        ragged = {"lengths": "U{64..512} right-padded to 512", "mean_len": (lq + group * lp) / (1 + group),
+                  "pairs_per_s_per_gpu_padded_path": rates[False], "pairs_per_s_per_gpu_packed_path": rates[True],
+                  "loss_padded": losses[False], "loss_packed_after_one_more_update": losses[True]}
     eng_flops = 2.0 * cfg.num_hidden_layers * (cfg.hidden_size * (6144) + 4096 * cfg.hidden_size + 3 * cfg.hidden_size * cfg.intermediate_size) \
         + 4.0 * cfg.num_hidden_layers * SEQ * 4096
     alg_flops_per_pair = 3.0 * eng_flops * SEQ * (1 + group)          # fwd + bwd = 3 x forward; recompute passes are overhead
@@ -130,7 +155,8 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, st
             "ms_per_step": dt / steps * 1e3, "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
             "global_batch": world * pairs, "loss": float(loss),
             "includes": "GradCache pass 1 + InfoNCE + pass 2 fwd/bwd + grad all-reduce + AdamW",
-            "mfma_roofline_frac": pairs_per_s / world * alg_flops_per_pair / (MFMA_BF16_PEAK_TFLOPS * 1e12)}
+            "mfma_roofline_frac": pairs_per_s / world * alg_flops_per_pair / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+            **({"ragged_batch": ragged} if ragged is not None else {})}
 
 
 def main():
@@ -228,7 +254,7 @@ def main():
         del eng, emb
         torch.cuda.empty_cache()
         try:
-            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs)
+            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, ragged_too=not args.no_ragged)
         except Exception as e:  # noqa: BLE001  -- never lose the primary metric line to the secondary leg
             contrastive = {"error": repr(e)[:300]}
 

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "grit_attn_bidir_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_pool_norm_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_pool_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "grit_pool_norm_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "grit_infonce_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "grit_transpose_bf16": (_i, [_p, _p, _l, _l, _l, _l, _p]),
     "grit_rmsnorm_bwd_workspace_rows": (_l, [_l]),
@@ -41,6 +42,7 @@ _SIGNATURES = {
     "grit_swiglu_fwd": (_i, [_p, _p, _l, _i, _p]),
     "grit_swiglu_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
     "grit_attn_bidir_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_bidir_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _i, _l, _l, _f, _p]),
     "grit_embed_scatter_add": (_i, [_p, _p, _p, _l, _i, _l, _p]),
     "grit_accum_bf16_from_f32": (_i, [_p, _p, _l, _p]),
 }

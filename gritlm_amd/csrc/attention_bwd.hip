@@ -70,6 +70,7 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& v, int c) {
 }
 
 // ------------------------------------------------------------------ delta = rowsum(dO * O) per (b, head, q)
+// padded layout: delta [B, nq, S];  varlen (S == 0): delta [T, nq]
 __global__ void __launch_bounds__(256) attn_delta_k(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
                                                     float* __restrict__ delta, int64_t T, int S, int nq, int64_t out_stride) {
   const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;  // (token, head), 16 lanes each
@@ -87,16 +88,21 @@ __global__ void __launch_bounds__(256) attn_delta_k(const uint16_t* __restrict__
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (on && sub == 0) {
-    const int64_t b = t / S; const int s = (int)(t - b * S);
-    delta[(b * nq + h) * S + s] = acc;
+    if (S == 0) {
+      delta[t * nq + h] = acc;
+    } else {
+      const int64_t b = t / S; const int s = (int)(t - b * S);
+      delta[(b * nq + h) * S + s] = acc;
+    }
   }
 }
 
 // ------------------------------------------------------------------ dK, dV
+template <bool VARLEN>
 __global__ void __launch_bounds__(256)
-attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const uint16_t* __restrict__ dout,
-                const float* __restrict__ lse, const float* __restrict__ delta, uint16_t* __restrict__ dqkv, int S, int nq, int nkv,
-                int64_t qkv_stride, int64_t out_stride, float scale) {
+attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
+                const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+                uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_rm = smem; char* q_tr = q_rm + AB_RM; char* d_rm = q_tr + AB_TR; char* d_tr = d_rm + AB_RM;
   float* st = reinterpret_cast<float*>(d_tr + AB_TR);  // [64] lse (log2 domain), [64] delta
@@ -104,10 +110,19 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int kblk = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int group = nq / nkv;
-  const int W = (S + 63) >> 6;
-  const int64_t row0 = (int64_t)b * S;
+  int S = S_arg;
+  int64_t row0 = (int64_t)b * S_arg;
+  if constexpr (VARLEN) {
+    row0 = cu_seqlens[b];
+    S = cu_seqlens[b + 1] - cu_seqlens[b];
+    if (kblk * 128 >= S) return;
+  }
   const int key = kblk * 128 + wave * 32 + (lane & 31);
-  const bool key_ok = key < S && ((key_bits[(int64_t)b * W + (key >> 6)] >> (key & 63)) & 1ull);
+  bool key_ok = key < S;
+  if constexpr (!VARLEN) {
+    const int W = (S + 63) >> 6;
+    key_ok = key_ok && ((key_bits[(int64_t)b * W + (key >> 6)] >> (key & 63)) & 1ull);
+  }
   const int key_ld = key < S ? key : S - 1;
   const float scale_log2 = scale * 1.4426950408889634f;
 
@@ -133,15 +148,17 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     const int h = hk * group + g;
     const uint16_t* qbase = qkv + row0 * qkv_stride + (int64_t)h * AB_D;
     const uint16_t* dobase = dout + row0 * out_stride + (int64_t)h * AB_D;
-    const float* lrow = lse + ((int64_t)b * nq + h) * S;
-    const float* drow = delta + ((int64_t)b * nq + h) * S;
+    // statistics of query q of head h: padded layout [B,nq,S] (stride 1 over q), packed layout [T,nq] (stride nq over q)
+    const float* lrow = VARLEN ? lse + row0 * nq + h : lse + ((int64_t)b * nq + h) * S;
+    const float* drow = VARLEN ? delta + row0 * nq + h : delta + ((int64_t)b * nq + h) * S;
+    const int64_t qs = VARLEN ? nq : 1;
     for (int qt = 0; qt < nqt; ++qt) {
       stage_pairs(qbase, qkv_stride, qt * 64, S, q_rm, q_tr);
       stage_pairs(dobase, out_stride, qt * 64, S, d_rm, d_tr);
       if (tid < 64) {
         const int q = qt * 64 + tid;
-        st[tid] = q < S ? lrow[q] * 1.4426950408889634f : INFINITY;  // +inf -> P = 0 for rows past the sequence
-        st[64 + tid] = q < S ? drow[q] : 0.f;
+        st[tid] = q < S ? lrow[q * qs] * 1.4426950408889634f : INFINITY;  // +inf -> P = 0 for rows past the sequence
+        st[64 + tid] = q < S ? drow[q * qs] : 0.f;
       }
       __syncthreads();
 #pragma unroll
@@ -197,27 +214,38 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
 }
 
 // ------------------------------------------------------------------ dQ
+template <bool VARLEN>
 __global__ void __launch_bounds__(256)
-attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const uint16_t* __restrict__ dout,
-              const float* __restrict__ lse, const float* __restrict__ delta, uint16_t* __restrict__ dqkv, int S, int nq, int nkv,
-              int64_t qkv_stride, int64_t out_stride, float scale) {
+attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
+              const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+              uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem; char* k_tr = k_rm + AB_RM; char* v_rm = k_tr + AB_TR;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (nq / nkv);
-  const int W = (S + 63) >> 6;
-  const uint64_t* bits = key_bits + (int64_t)b * W;
+  int S = S_arg;
+  int64_t row0 = (int64_t)b * S_arg;
+  const uint64_t* bits = nullptr;
   int ntiles = 0;
-  for (int w = W - 1; w >= 0; --w)
-    if (bits[w] != 0) { ntiles = w + 1; break; }
-  const int64_t row0 = (int64_t)b * S;
+  if constexpr (VARLEN) {
+    row0 = cu_seqlens[b];
+    S = cu_seqlens[b + 1] - cu_seqlens[b];
+    if (qblk * 128 >= S) return;
+    ntiles = (S + 63) >> 6;
+  } else {
+    const int W = (S + 63) >> 6;
+    bits = key_bits + (int64_t)b * W;
+    for (int w = W - 1; w >= 0; --w)
+      if (bits[w] != 0) { ntiles = w + 1; break; }
+  }
   const int q = qblk * 128 + wave * 32 + (lane & 31);
   const int q_ld = q < S ? q : S - 1;
   const float scale_log2 = scale * 1.4426950408889634f;
-  const float lse2 = lse[((int64_t)b * nq + h) * S + q_ld] * 1.4426950408889634f;
-  const float dlt = delta[((int64_t)b * nq + h) * S + q_ld];
+  const int64_t sidx = VARLEN ? (row0 + q_ld) * nq + h : ((int64_t)b * nq + h) * S + q_ld;
+  const float lse2 = lse[sidx] * 1.4426950408889634f;
+  const float dlt = delta[sidx];
 
   bf16x8_t qf[8], dof[8];
   {
@@ -241,7 +269,13 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
     stage_pairs(kbase, qkv_stride, t * 64, S, k_rm, k_tr);
     stage_pairs(vbase, qkv_stride, t * 64, S, v_rm, nullptr);
     __syncthreads();
-    const uint64_t word = bits[t];
+    uint64_t word;
+    if constexpr (VARLEN) {
+      const int rem = S - t * 64;
+      word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    } else {
+      word = bits[t];
+    }
     const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -285,6 +319,41 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
 
 using namespace grit;
 
+static int attn_bwd_launch(bool varlen, const void* qkv, const uint64_t* key_bits, const int32_t* cu, const void* out, const void* dout,
+                           const float* lse, float* delta, void* dqkv, int B, int S_or_maxlen, int64_t T, int nq, int nkv,
+                           int64_t qkv_stride, int64_t out_stride, float scale, hipStream_t st) {
+  const int64_t items = T * nq;
+  hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((items * 16 + 255) / 256)), dim3(256), 0, st, (const uint16_t*)out,
+                     (const uint16_t*)dout, delta, T, varlen ? 0 : S_or_maxlen, nq, out_stride);
+  GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: delta");
+  static bool attr_set = false;
+  const int lds_kv = 2 * AB_RM + 2 * AB_TR + 512, lds_q = 2 * AB_RM + AB_TR;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+    attr_set = true;
+  }
+  const unsigned nblk = (unsigned)((S_or_maxlen + 127) / 128);
+  if (varlen) {
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<true>, dim3(nblk, (unsigned)nkv, (unsigned)B), dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+    GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dkdv");
+    hipLaunchKernelGGL(attn_bwd_dq_k<true>, dim3(nblk, (unsigned)nq, (unsigned)B), dim3(256), lds_q, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+    GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dq");
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<false>, dim3(nblk, (unsigned)nkv, (unsigned)B), dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+    GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dkdv");
+    hipLaunchKernelGGL(attn_bwd_dq_k<false>, dim3(nblk, (unsigned)nq, (unsigned)B), dim3(256), lds_q, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+    GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dq");
+  }
+  return GRIT_OK;
+}
+
 extern "C" int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
                                    float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
                                    int64_t out_stride, float scale, void* stream) {
@@ -297,25 +366,22 @@ extern "C" int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, co
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
                "grit_attn_bidir_bwd: pointers must be 16-byte aligned");
   GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: grid too large");
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t T = (int64_t)B * S;
-  const int64_t items = T * nq;
-  hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((items * 16 + 255) / 256)), dim3(256), 0, st, (const uint16_t*)out,
-                     (const uint16_t*)dout, delta, T, S, nq, out_stride);
-  GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: delta");
-  static bool attr_set = false;
-  const int lds_kv = 2 * AB_RM + 2 * AB_TR + 512, lds_q = 2 * AB_RM + AB_TR;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    attr_set = true;
-  }
-  const unsigned nblk = (unsigned)((S + 127) / 128);
-  hipLaunchKernelGGL(attn_bwd_dkdv_k, dim3(nblk, (unsigned)nkv, (unsigned)B), dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits,
-                     (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S, nq, nkv, qkv_stride, out_stride, scale);
-  GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dkdv");
-  hipLaunchKernelGGL(attn_bwd_dq_k, dim3(nblk, (unsigned)nq, (unsigned)B), dim3(256), lds_q, st, (const uint16_t*)qkv, key_bits,
-                     (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S, nq, nkv, qkv_stride, out_stride, scale);
-  GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dq");
-  return GRIT_OK;
+  return attn_bwd_launch(false, qkv, key_bits, nullptr, out, dout, lse, delta, dqkv, B, S, (int64_t)B * S, nq, nkv, qkv_stride, out_stride,
+                         scale, (hipStream_t)stream);
+}
+
+extern "C" int grit_attn_bidir_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+                                          float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
+                                          int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(qkv && cu_seqlens && out && dout && lse && delta && dqkv, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: null pointer");
+  GRIT_REQUIRE(B > 0 && max_len > 0 && T > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: bad sizes");
+  GRIT_REQUIRE(d == AB_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: head_dim=%d (only 128 is built)", d);
+  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: nq not a multiple of nkv");
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
+               GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: bad strides");
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
+               "grit_attn_bidir_varlen_bwd: pointers must be 16-byte aligned");
+  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: grid too large");
+  return attn_bwd_launch(true, qkv, nullptr, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, qkv_stride, out_stride, scale,
+                         (hipStream_t)stream);
 }

@@ -235,6 +235,57 @@ __global__ void __launch_bounds__(POOL_THREADS) pool_norm_bwd_k(const float* __r
   }
 }
 
+// packed rows: dhidden[cu[b]+s, :] = w(s) * g with the weights of pool_norm_varlen_fwd_k (no mask: every packed row is a token)
+__global__ void __launch_bounds__(POOL_THREADS) pool_norm_varlen_bwd_k(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                       const float* __restrict__ inv_norm, const int32_t* __restrict__ cu,
+                                                                       const int32_t* __restrict__ instr_len,
+                                                                       uint16_t* __restrict__ dhidden, int H, int mode, int normalize) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* g = reinterpret_cast<float*>(smem);  // [H]
+  float* red = g + H;                         // [POOL_THREADS/64]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t start = cu[b];
+  const int len = cu[b + 1] - cu[b];
+  int instr = instr_len ? instr_len[b] : 0;
+  instr = instr < len ? instr : len;
+  int s0 = instr, s1 = len;
+  float den = (float)(len - instr);
+  if (mode == GRIT_POOL_WEIGHTEDMEAN) { const float n = (float)(len - instr); den = 0.5f * n * (n + 1.f); }
+  if (mode == GRIT_POOL_CLS) { s0 = 0; s1 = len > 0 ? 1 : 0; den = 1.f; }
+  if (mode == GRIT_POOL_LASTTOKEN) { s0 = len > 0 ? len - 1 : 0; s1 = len; den = 1.f; }
+  const bool ramp = (mode == GRIT_POOL_WEIGHTEDMEAN);
+  const float* yb = y + (int64_t)b * H;
+  const float* dyb = dy + (int64_t)b * H;
+  float dot = 0.f;
+  if (normalize)
+    for (int i = tid; i < H; i += POOL_THREADS) dot += yb[i] * dyb[i];
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < POOL_THREADS / 64; ++w) tot += red[w];
+  const float inv = normalize ? inv_norm[b] : 1.f;
+  for (int i = tid; i < H; i += POOL_THREADS) g[i] = normalize ? (dyb[i] - yb[i] * tot) * inv : dyb[i];
+  __syncthreads();
+  const float inv_den = 1.0f / den;
+  const int HC = H >> 3;
+  uint4* db = reinterpret_cast<uint4*>(dhidden) + start * HC;
+  for (int s = wave; s < len; s += POOL_THREADS / 64) {
+    float w = 0.f;
+    if (s >= s0 && s < s1) w = (ramp ? (float)(s - instr + 1) : 1.f) * inv_den;
+    for (int cc = lane; cc < HC; cc += 64) {
+      uint4 o = make_uint4(0, 0, 0, 0);
+      if (w != 0.f) {
+        const float4 g0 = *reinterpret_cast<const float4*>(g + cc * 8), g1 = *reinterpret_cast<const float4*>(g + cc * 8 + 4);
+        o.x = pack2bf(w * g0.x, w * g0.y); o.y = pack2bf(w * g0.z, w * g0.w);
+        o.z = pack2bf(w * g1.x, w * g1.y); o.w = pack2bf(w * g1.z, w * g1.w);
+      }
+      db[(int64_t)s * HC + cc] = o;
+    }
+  }
+}
+
 }  // namespace grit
 
 using namespace grit;
@@ -300,4 +351,24 @@ int grit_pool_norm_bwd(const float* y, const float* dy, const float* inv_norm, c
   return GRIT_OK;
 }
 
+int grit_pool_norm_varlen_bwd(const float* y, const float* dy, const float* inv_norm, const int32_t* cu_seqlens, const int32_t* instr_len,
+                              void* dhidden, int B, int H, int mode, int normalize, void* stream) {
+  if (B == 0) return GRIT_OK;
+  GRIT_REQUIRE(y && dy && cu_seqlens && dhidden, GRIT_E_BADARG, "grit_pool_norm_varlen_bwd: null pointer");
+  GRIT_REQUIRE(!normalize || inv_norm, GRIT_E_BADARG, "grit_pool_norm_varlen_bwd: inv_norm required when normalize");
+  GRIT_REQUIRE(B >= 0 && H > 0, GRIT_E_BADARG, "grit_pool_norm_varlen_bwd: bad sizes");
+  GRIT_REQUIRE(mode >= GRIT_POOL_MEAN && mode <= GRIT_POOL_LASTTOKEN, GRIT_E_BADARG, "grit_pool_norm_varlen_bwd: unknown pooling mode %d", mode);
+  GRIT_REQUIRE(H % 8 == 0 && H <= 32768, GRIT_E_UNSUPPORTED, "grit_pool_norm_varlen_bwd: H=%d must be a multiple of 8, <= 32768", H);
+  GRIT_REQUIRE(aligned16(dhidden), GRIT_E_BADARG, "grit_pool_norm_varlen_bwd: pointers must be 16-byte aligned");
+  const size_t lds = 4 * (size_t)H + 64;
+  static bool attr_set_vb = false;
+  if (!attr_set_vb) {
+    (void)hipFuncSetAttribute((const void*)pool_norm_varlen_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set_vb = true;
+  }
+  hipLaunchKernelGGL(pool_norm_varlen_bwd_k, dim3(B), dim3(POOL_THREADS), lds, (hipStream_t)stream, y, dy, inv_norm, cu_seqlens, instr_len,
+                     (uint16_t*)dhidden, H, mode, normalize);
+  GRIT_CHECK_LAUNCH("grit_pool_norm_varlen_bwd");
+  return GRIT_OK;
+}
 }  // extern "C"

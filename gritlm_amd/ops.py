@@ -56,6 +56,17 @@ def _chk(t: torch.Tensor, dtype, name: str):
     return t.data_ptr()
 
 
+def _chk2d(t: torch.Tensor, dtype, name: str):
+    """Row-strided 2-D operand (unit column stride, leading dimension = stride(0)): what the GEMM entry point takes."""
+    if not t.is_cuda:
+        raise _lib.GritHipError(f"{name}: tensor must live on the GPU (got {t.device}); the native path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: 2-D tensor with unit column stride expected")
+    return t.data_ptr()
+
+
 def embed_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     V, H = table.shape
     T = ids.numel()
@@ -83,17 +94,20 @@ def rope_qk_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, S: int, nq
     return qkv
 
 
-def rope_qk_pos_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, positions: torch.Tensor, nq: int, nkv: int, d: int):
+def rope_qk_pos_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, positions: torch.Tensor, nq: int, nkv: int, d: int,
+                 inverse: bool = False):
     """RoPE for packed rows: positions[t] (int32) = index of token t inside its own sequence."""
     T, stride = qkv.shape
     check(_lib.load().grit_rope_qk_inplace_pos(_chk(qkv, BF16, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"),
-                                               _chk(positions, I32, "positions"), T, cos.shape[0], nq, nkv, d, stride, 0, _stream()),
+                                               _chk(positions, I32, "positions"), T, cos.shape[0], nq, nkv, d, stride, int(inverse),
+                                               _stream()),
           "grit_rope_qk_inplace_pos")
     return qkv
 
 
 def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, nq: int, nkv: int, d: int,
-                      out: torch.Tensor | None = None, scale: float | None = None) -> torch.Tensor:
+                      out: torch.Tensor | None = None, scale: float | None = None, lse: torch.Tensor | None = None) -> torch.Tensor:
+    """lse (optional, fp32 [T, nq]) receives the log-sum-exp rows for grit_attn_bidir_varlen_bwd."""
     T, stride = qkv.shape
     B = cu_seqlens.numel() - 1
     if out is None:
@@ -103,7 +117,8 @@ def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
     ev = _timer.span("attn_bidir_fwd", 0.0) if _timer is not None else None
     if ev:
         ev[0].record()
-    check(_lib.load().grit_attn_bidir_varlen_fwd(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"), 0, B,
+    check(_lib.load().grit_attn_bidir_varlen_fwd(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"),
+                                                 0 if lse is None else _chk(lse, F32, "lse"), B,
                                                  int(max_len), nq, nkv, d, stride, out.stride(0), float(scale), _stream()),
           "grit_attn_bidir_varlen_fwd")
     if ev:
@@ -112,16 +127,29 @@ def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
 
 
 def pool_norm_varlen(hidden: torch.Tensor, cu_seqlens: torch.Tensor, method: str, normalize: bool,
-                     instr_len: torch.Tensor | None = None) -> torch.Tensor:
+                     instr_len: torch.Tensor | None = None, inv_norm: torch.Tensor | None = None) -> torch.Tensor:
     if method not in POOL_MODES:
         raise NotImplementedError(f"Unknown pooling method: {method}")
     T, H = hidden.shape
     B = cu_seqlens.numel() - 1
     out = torch.empty((B, H), dtype=F32, device=hidden.device)
     check(_lib.load().grit_pool_norm_varlen_fwd(_chk(hidden, BF16, "hidden"), _chk(cu_seqlens, I32, "cu_seqlens"),
-                                                0 if instr_len is None else _chk(instr_len, I32, "instr_len"), _chk(out, F32, "out"), 0, B, H,
+                                                0 if instr_len is None else _chk(instr_len, I32, "instr_len"), _chk(out, F32, "out"),
+                                                0 if inv_norm is None else _chk(inv_norm, F32, "inv_norm"), B, H,
                                                 POOL_MODES[method], int(normalize), _stream()), "grit_pool_norm_varlen_fwd")
     return out
+
+
+def pool_norm_varlen_bwd(y: torch.Tensor, dy: torch.Tensor, inv_norm: torch.Tensor | None, cu_seqlens: torch.Tensor, T: int, method: str,
+                         normalize: bool, instr_len: torch.Tensor | None = None) -> torch.Tensor:
+    B, H = y.shape
+    dh = torch.empty((T, H), dtype=BF16, device=y.device)
+    check(_lib.load().grit_pool_norm_varlen_bwd(_chk(y, F32, "y"), _chk(dy, F32, "dy"),
+                                                0 if inv_norm is None else _chk(inv_norm, F32, "inv_norm"),
+                                                _chk(cu_seqlens, I32, "cu_seqlens"),
+                                                0 if instr_len is None else _chk(instr_len, I32, "instr_len"), _chk(dh, BF16, "dhidden"),
+                                                B, H, POOL_MODES[method], int(normalize), _stream()), "grit_pool_norm_varlen_bwd")
+    return dh
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE,
@@ -137,11 +165,11 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     rp, ldr = 0, 0
     if epilogue == EPI_RESIDUAL:
         assert residual is not None and residual.shape == (M, N)
-        rp, ldr = _chk(residual, BF16, "residual"), residual.stride(0)
+        rp, ldr = _chk2d(residual, BF16, "residual"), residual.stride(0)
     ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K) if _timer is not None else None
     if ev:
         ev[0].record()
-    check(_lib.load().grit_gemm_bf16_nt(_chk(a, BF16, "a"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), M, N, K, a.stride(0),
+    check(_lib.load().grit_gemm_bf16_nt(_chk2d(a, BF16, "a"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), M, N, K, a.stride(0),
                                         w.stride(0), out.stride(0), epilogue, rp, ldr, _stream()), "grit_gemm_bf16_nt")
     if ev:
         ev[1].record()
@@ -274,6 +302,23 @@ def attn_bidir_bwd(qkv: torch.Tensor, key_bits: torch.Tensor, out: torch.Tensor,
     check(_lib.load().grit_attn_bidir_bwd(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"),
                                           _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"), delta.data_ptr(), _chk(dqkv, BF16, "dqkv"),
                                           B, S, nq, nkv, d, stride, out.stride(0), float(scale), _stream()), "grit_attn_bidir_bwd")
+    return dqkv
+
+
+def attn_bidir_varlen_bwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, out: torch.Tensor, dout: torch.Tensor,
+                          lse: torch.Tensor, nq: int, nkv: int, d: int, dqkv: torch.Tensor | None = None,
+                          scale: float | None = None) -> torch.Tensor:
+    T, stride = qkv.shape
+    B = cu_seqlens.numel() - 1
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if scale is None:
+        scale = d ** -0.5
+    delta = torch.empty((T, nq), dtype=F32, device=qkv.device)
+    check(_lib.load().grit_attn_bidir_varlen_bwd(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"),
+                                                 _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"), delta.data_ptr(),
+                                                 _chk(dqkv, BF16, "dqkv"), B, int(max_len), T, nq, nkv, d, stride, out.stride(0),
+                                                 float(scale), _stream()), "grit_attn_bidir_varlen_bwd")
     return dqkv
 
 

@@ -32,7 +32,43 @@ class _LayerParams:
 
 class SavedForward:
     """Everything pass 2 keeps from the forward of one chunk."""
-    __slots__ = ("ids", "mask", "bits", "B", "S", "layers", "h_final", "x_final")
+    __slots__ = ("ids", "mask", "geom", "B", "S", "layers", "h_final", "x_final")
+
+
+class _Geometry:
+    """Row layout of one chunk.  Padded: T = B*S rows, key-padding bitmask.  Packed: only the real tokens of a right-padded
+    batch (rows of sequence b at [cu[b], cu[b+1])), per-row RoPE positions -- GEMMs, norms and attention never see padding
+    (the reference computes every padded position)."""
+    __slots__ = ("packed", "B", "S", "T", "bits", "cu", "pos", "max_len", "keep")
+
+    @staticmethod
+    def padded(mask: torch.Tensor):
+        g = _Geometry()
+        g.packed, (g.B, g.S) = False, mask.shape
+        g.T = g.B * g.S
+        g.bits = ops.mask_pack(mask)
+        g.cu = g.pos = g.keep = None
+        g.max_len = g.S
+        return g
+
+    @staticmethod
+    def from_mask(mask: torch.Tensor):
+        """Packed geometry when the mask is right-padded with no empty row, else None."""
+        B, S = mask.shape
+        keep = mask != 0
+        lens = keep.sum(dim=1)
+        ar = torch.arange(S, device=mask.device)
+        # one host sync decides the layout: (right-padded?, no empty rows?, longest row, number of tokens)
+        ok, max_len, T = torch.stack([(((ar.unsqueeze(0) < lens.unsqueeze(1)) == keep).all() & (lens > 0).all()).to(torch.int64),
+                                      lens.max(), lens.sum()]).tolist()
+        if not ok:
+            return None
+        g = _Geometry()
+        g.packed, g.B, g.S, g.T, g.max_len, g.keep, g.bits = True, B, S, int(T), int(max_len), keep, None
+        g.cu = torch.zeros((B + 1,), dtype=torch.int32, device=mask.device)
+        g.cu[1:] = torch.cumsum(lens, dim=0)
+        g.pos = ar.to(torch.int32).unsqueeze(0).expand(B, S)[keep].contiguous()
+        return g
 
 
 class MistralTrainEngine:
@@ -125,15 +161,17 @@ class MistralTrainEngine:
     def _transposed_act(self, x: torch.Tensor, tag: str) -> torch.Tensor:
         """x [T,N] -> x^T in a zero-padded [N, pad64(T)] buffer (K operand of the wgrad GEMM)."""
         T, N = x.shape
-        key = (tag, N, _pad64(T))
+        Tp = _pad64(T)
+        key = (tag, N)
         buf = self._tbuf.get(key)
-        if buf is None:
-            buf = torch.zeros((N, _pad64(T)), dtype=BF16, device=self.device)
+        if buf is None or buf.shape[1] < Tp:               # grow-only: packed chunks have a different T every time
+            buf = torch.zeros((N, Tp), dtype=BF16, device=self.device)
             self._tbuf[key] = buf
-        elif buf.shape[1] != T:
-            buf[:, T:].zero_()
-        ops.transpose(x, out=buf)
-        return buf
+        view = buf if buf.shape[1] == Tp else buf[:, :Tp]
+        if Tp != T:
+            view[:, T:].zero_()                            # K padding of the wgrad GEMM
+        ops.transpose(x, out=view)
+        return view
 
     def _wt(self, li: int, name: str, w: torch.Tensor) -> torch.Tensor:
         """W^T for the dgrad GEMM.  With ``cache_transposed_weights`` it is reused by every GradCache chunk of a step; the cache is
@@ -153,32 +191,41 @@ class MistralTrainEngine:
         return t
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool):
-        """Returns (last_hidden_state [B,S,H] bf16, SavedForward | None)."""
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool, packed: bool = False):
+        """Returns (last_hidden_state, SavedForward | None).  Padded layout: last_hidden_state is [B,S,H] bf16.
+        ``packed=True`` (and a right-padded mask without empty rows): [T_real,H] rows of the real tokens only; the geometry is in
+        ``SavedForward.geom`` (returned even with ``save=False`` so the caller can pool)."""
         c = self.cfg
         B, S = input_ids.shape
-        T = B * S
         dev = self.device
-        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous().view(-1)
         mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        geom = _Geometry.from_mask(mask) if packed else None
+        if geom is None:
+            geom = _Geometry.padded(mask)
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        ids = ids[geom.keep].contiguous() if geom.packed else ids.view(-1)
+        T = geom.T
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         H, I = c.hidden_size, c.intermediate_size
         cos, sin = self._rope_tables(S)
-        bits = ops.mask_pack(mask)
         mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
         h = ops.embed_gather(self.embed.data, ids, out=mk(H))
-        saved = SavedForward() if save else None
-        if save:
-            saved.ids, saved.mask, saved.bits, saved.B, saved.S, saved.layers = ids, mask, bits, B, S, []
+        saved = SavedForward()
+        saved.ids, saved.mask, saved.geom, saved.B, saved.S, saved.layers = ids, mask, geom, B, S, []
         x1 = qkv = ctx = x2 = gu = act = None
         for L in self.layers:
             if save or x1 is None:
                 x1, qkv, ctx, x2, gu, act = mk(H), mk((nq + 2 * nkv) * d), mk(nq * d), mk(H), mk(2 * I), mk(I)
-            lse = torch.empty((B, nq, S), dtype=F32, device=dev) if save else None
             ops.rmsnorm(h, L.ln1.data, eps, out=x1)
             ops.gemm_nt(x1, L.wqkv, out=qkv)
-            ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
-            ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, lse=lse)
+            if geom.packed:
+                lse = torch.empty((T, nq), dtype=F32, device=dev) if save else None
+                ops.rope_qk_pos_(qkv, cos, sin, geom.pos, nq, nkv, d)
+                ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse)
+            else:
+                lse = torch.empty((B, nq, S), dtype=F32, device=dev) if save else None
+                ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
+                ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse)
             h_mid = mk(H) if save else h
             ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h_mid, L.ln2.data, eps, out=x2)
@@ -192,18 +239,39 @@ class MistralTrainEngine:
         xf = ops.rmsnorm(h, self.norm.data, eps, out=mk(H))
         if save:
             saved.h_final, saved.x_final = h, xf
-        return xf.view(B, S, H), saved
+        return (xf if geom.packed else xf.view(B, S, H)), saved
+
+    def forward_pooled(self, input_ids, attention_mask, method: str, normalize: bool, instr_len=None, save: bool = False,
+                       packed: bool = True):
+        """reps [B,H] fp32 = normalise(pool(encoder(ids))) (gritlm/training/model.py:134-165) + what backward_pooled needs."""
+        hidden, saved = self.forward(input_ids, attention_mask, save=save, packed=packed)
+        inv = torch.empty((saved.B,), dtype=F32, device=self.device)
+        if saved.geom.packed:
+            reps = ops.pool_norm_varlen(hidden, saved.geom.cu, method, normalize, instr_len, inv_norm=inv)
+        else:
+            reps = ops.pool_norm(hidden, saved.mask, method, normalize, instr_len, inv_norm=inv)
+        return reps, ((saved, inv, reps, method, normalize, instr_len) if save else None)
+
+    def backward_pooled(self, state, d_reps: torch.Tensor, on_layer_done=None):
+        saved, inv, reps, method, normalize, instr_len = state
+        d_reps = d_reps.to(F32).contiguous()
+        if saved.geom.packed:
+            dh = ops.pool_norm_varlen_bwd(reps, d_reps, inv, saved.geom.cu, saved.geom.T, method, normalize, instr_len)
+        else:
+            dh = ops.pool_norm_bwd(reps, d_reps, inv, saved.mask, method, normalize, saved.S, instr_len)
+        self.backward(saved, dh, on_layer_done=on_layer_done)
 
     # ------------------------------------------------------------------ backward
     def backward(self, saved: SavedForward, d_last_hidden: torch.Tensor, on_layer_done=None):
-        """Accumulate parameter gradients for d loss / d last_hidden_state = ``d_last_hidden`` [B,S,H] bf16.
+        """Accumulate parameter gradients for d loss / d last_hidden_state = ``d_last_hidden`` ([B,S,H], or [T_real,H] for a
+        packed chunk) bf16.
 
         ``on_layer_done(list_of_grad_buffers)`` is called as soon as a layer's four weight-gradient buffers are final for this
         call (data-parallel training passes a callback that starts their all-reduce, overlapping it with the remaining layers)."""
         c = self.cfg
         self.prepare_grads()
-        B, S = saved.B, saved.S
-        T = B * S
+        B, S, geom = saved.B, saved.S, saved.geom
+        T = geom.T
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         H = c.hidden_size
         cos, sin = self._rope_tables(S)
@@ -226,8 +294,12 @@ class MistralTrainEngine:
             dctx = ops.gemm_nt(dh_mid, self._wt(li, "o", L.wo))                         # [T,nq*d]
             ops.gemm_nt(self._transposed_act(dh_mid, "dh"), self._transposed_act(sv["ctx"], "ctx"), out=L.go, epilogue=EPI_RESIDUAL,
                         residual=L.go)
-            dqkv = ops.attn_bidir_bwd(sv["qkv"], saved.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d)
-            ops.rope_qk_(dqkv, cos, sin, S, nq, nkv, d, inverse=True)
+            if geom.packed:
+                dqkv = ops.attn_bidir_varlen_bwd(sv["qkv"], geom.cu, geom.max_len, sv["ctx"], dctx, sv["lse"], nq, nkv, d)
+                ops.rope_qk_pos_(dqkv, cos, sin, geom.pos, nq, nkv, d, inverse=True)
+            else:
+                dqkv = ops.attn_bidir_bwd(sv["qkv"], geom.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d)
+                ops.rope_qk_(dqkv, cos, sin, S, nq, nkv, d, inverse=True)
             dx1 = ops.gemm_nt(dqkv, self._wt(li, "qkv", L.wqkv))                        # [T,H]
             ops.gemm_nt(self._transposed_act(dqkv, "dqkv"), self._transposed_act(sv["x1"], "x"), out=L.gqkv, epilogue=EPI_RESIDUAL,
                         residual=L.gqkv)

@@ -148,26 +148,19 @@ class _NativeEncodeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, input_ids, attention_mask, instr_len):
-        from .. import ops
         eng = model.train_engine
         grad = bool(ctx.needs_input_grad[0])      # grad mode + anchor.requires_grad at apply() time
-        hidden, saved = eng.forward(input_ids, attention_mask, save=grad)
-        mask = attention_mask.to(device=hidden.device, dtype=torch.int64).contiguous()
-        inv = torch.empty((hidden.shape[0],), dtype=torch.float32, device=hidden.device)
-        reps = ops.pool_norm(hidden, mask, model.pooling_method, bool(model.normalized), instr_len, inv_norm=inv)
+        reps, state = eng.forward_pooled(input_ids, attention_mask, model.pooling_method, bool(model.normalized), instr_len, save=grad,
+                                         packed=getattr(model, "native_packed", True))
         if grad:
-            ctx.model, ctx.saved, ctx.mask, ctx.instr, ctx.inv, ctx.reps = model, saved, mask, instr_len, inv, reps
+            ctx.model, ctx.state = model, state
         return reps
 
     @staticmethod
     def backward(ctx, d_reps):
-        from .. import ops
         model = ctx.model
-        S = ctx.saved.S
-        dh = ops.pool_norm_bwd(ctx.reps, d_reps.float().contiguous(), ctx.inv, ctx.mask, model.pooling_method, bool(model.normalized), S,
-                               ctx.instr)
-        model.train_engine.backward(ctx.saved, dh, on_layer_done=getattr(model, "_on_layer_done", None))
-        ctx.saved = None
+        model.train_engine.backward_pooled(ctx.state, d_reps, on_layer_done=getattr(model, "_on_layer_done", None))
+        ctx.state = None
         return None, None, None, None, None
 
 

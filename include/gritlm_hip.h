@@ -123,6 +123,11 @@ int grit_pool_norm_bwd(const float* y, const float* dy, const float* inv_norm, c
                        const int32_t* instr_len, void* dhidden, int B, int S, int H, int mode,
                        int normalize, void* stream);
 
+/* packed variant of the backward: dhidden [T,H] bf16 (rows of document b at [cu_seqlens[b], cu_seqlens[b+1])) */
+int grit_pool_norm_varlen_bwd(const float* y, const float* dy, const float* inv_norm, const int32_t* cu_seqlens,
+                              const int32_t* instr_len, void* dhidden, int B, int H, int mode, int normalize,
+                              void* stream);
+
 /* ---- contrastive loss: gritlm/training/model.py:36-47,62-64 --------------------------------- */
 
 /* scores = q p^T / tau (fp32 MFMA, exact f32), target[i] = i * (Np / Nq), CrossEntropyLoss(mean).
@@ -162,6 +167,12 @@ int grit_swiglu_bwd(const void* gu, const void* dact, void* dgu, int64_t T, int 
 int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
                         int64_t out_stride, float scale, void* stream);
+
+/* Packed variant (layouts of grit_attn_bidir_varlen_fwd: qkv/out/dout/dqkv [T, stride], lse and the delta workspace
+ * [T, nq]); T = cu_seqlens[B]. */
+int grit_attn_bidir_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+                               float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
+                               int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
 
 /* embedding backward: dtable[ids[t], :] += dh[t, :]  (dtable fp32 [V,H], fp32 atomics) */
 int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream);

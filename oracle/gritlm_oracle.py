@@ -293,11 +293,18 @@ def distributed_infonce(q_shards, p_shards, temperature, rank):
 
 
 def pool_normalize_backward(hidden, pool_mask, method, normalized, grad_out):
-    """Analytic backward of pooling(:209-214)+normalize(:156-158) w.r.t. hidden (mean/weightedmean)."""
+    """Analytic backward of pooling(:188-214)+normalize(:156-158) w.r.t. hidden: every method is a per-row weighting of the
+    positions (cls: position 0, :188-189; lasttoken: last position when left-padded else mask.sum-1, :190-207)."""
     hidden = hidden.astype(F64)
     m = pool_mask.astype(np.int64).copy()
     if method == "weightedmean":
         m = m * np.cumsum(m, axis=1)
+    elif method == "cls":
+        m = np.zeros_like(m); m[:, 0] = 1
+    elif method == "lasttoken":
+        left = bool(pool_mask[:, -1].sum() == pool_mask.shape[0])
+        idx = np.full((m.shape[0],), m.shape[1] - 1) if left else pool_mask.sum(axis=1) - 1
+        m = np.zeros_like(m); m[np.arange(m.shape[0]), idx] = 1
     den = m.sum(axis=1, keepdims=True).astype(F64)
     w = m / den
     pooled = np.einsum("bsd,bs->bd", hidden, w)

@@ -301,6 +301,73 @@ def check_attention_bwd(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=41):
     return _res(f"attention_bwd[B={B},S={S},nq={nq},nkv={nkv},{mask_kind}]", ok, **errs)
 
 
+def check_attention_bwd_varlen(lens=(200, 71, 128, 1, 300), nq=4, nkv=2, seed=47):
+    """Packed attention backward vs (1) the oracle per sequence and (2) the padded kernel on the same rows (bit-identical:
+    padded query rows / masked keys only ever add exact zeros)."""
+    d = 128
+    width = (nq + 2 * nkv) * d
+    B, S, T = len(lens), max(lens), sum(lens)
+    qkv = rnd((T, width), seed, 0.7)
+    dout = rnd((T, nq * d), seed + 3)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    tcu = torch.from_numpy(cu).to(DEV)
+    tq, tdo = bf(qkv), bf(dout)
+    lse = torch.empty((T, nq), dtype=torch.float32, device=DEV)
+    out = ops.attn_bidir_varlen(tq, tcu, S, nq, nkv, d, lse=lse)
+    got = f32(ops.attn_bidir_varlen_bwd(tq, tcu, S, out, tdo, lse, nq, nkv, d))
+    # padded twin
+    mask = np.zeros((B, S), dtype=np.int64)
+    pq = np.zeros((B, S, width), dtype=np.float32); pdo = np.zeros((B, S, nq * d), dtype=np.float32)
+    for b, L in enumerate(lens):
+        mask[b, :L] = 1
+        pq[b, :L] = f32(tq)[cu[b]:cu[b + 1]]; pdo[b, :L] = f32(tdo)[cu[b]:cu[b + 1]]
+    tpq, bits = bf(pq.reshape(B * S, width)), ops.mask_pack(torch.from_numpy(mask).to(DEV))
+    plse = torch.empty((B, nq, S), dtype=torch.float32, device=DEV)
+    pout = ops.attn_bidir(tpq, bits, B, S, nq, nkv, d, lse=plse)
+    pgot = f32(ops.attn_bidir_bwd(tpq, bits, pout, bf(pdo.reshape(B * S, nq * d)), plse, B, S, nq, nkv, d)).reshape(B, S, width)
+    ok = not np.isnan(got).any()
+    same = all(np.array_equal(got[cu[b]:cu[b + 1]], pgot[b, :L]) for b, L in enumerate(lens))
+    same_fwd = all(np.array_equal(f32(out)[cu[b]:cu[b + 1]], f32(pout).reshape(B, S, -1)[b, :L]) for b, L in enumerate(lens))
+    worst = 0.0
+    for b, L in enumerate(lens):
+        x = f32(tq)[cu[b]:cu[b + 1]].reshape(1, L, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
+        dq, dk, dv = O.attention_bidirectional_backward(x[:, :nq], x[:, nq:nq + nkv], x[:, nq + nkv:], np.ones((1, L), dtype=np.int64),
+                                                        f32(tdo)[cu[b]:cu[b + 1]].reshape(1, L, nq * d))
+        ref = np.concatenate([dq, dk, dv], axis=1).transpose(0, 2, 1, 3).reshape(L, width)
+        worst = max(worst, float(np.max(np.abs(got[cu[b]:cu[b + 1]] - ref))) / (float(np.sqrt(np.mean(ref ** 2))) + 1e-12))
+    ok &= same and same_fwd and worst < 6e-2
+    return _res(f"attention_bwd varlen [lens={list(lens)}]", ok, identical_to_padded=bool(same), fwd_identical=bool(same_fwd),
+                maxerr_over_rms_vs_oracle=worst)
+
+
+def check_pool_bwd_varlen(method="mean", normalize=True, lens=(40, 25, 33, 1), H=256):
+    """Packed pool+normalise forward/backward == padded kernels on the same documents (bit for bit)."""
+    B, S, T = len(lens), max(lens), sum(lens)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    hid = rnd((T, H), 18)
+    go = np.random.default_rng(19).standard_normal((B, H)).astype(np.float32)
+    instr = np.array([2, 0, 9, 0][:B], dtype=np.int32) if "mean" in method else None
+    ti = None if instr is None else torch.from_numpy(instr).to(DEV)
+    tcu, th, tgo = torch.from_numpy(cu).to(DEV), bf(hid), torch.from_numpy(go).to(DEV)
+    inv = torch.empty((B,), dtype=torch.float32, device=DEV)
+    y = ops.pool_norm_varlen(th, tcu, method, normalize, ti, inv_norm=inv)
+    dh = f32(ops.pool_norm_varlen_bwd(y, tgo, inv, tcu, T, method, normalize, ti))
+    mask = np.zeros((B, S), dtype=np.int64); ph = np.zeros((B, S, H), dtype=np.float32)
+    for b, L in enumerate(lens):
+        mask[b, :L] = 1; ph[b, :L] = f32(th)[cu[b]:cu[b + 1]]
+    tm = torch.from_numpy(mask).to(DEV)
+    pinv = torch.empty((B,), dtype=torch.float32, device=DEV)
+    py = ops.pool_norm(bf(ph), tm, method, normalize, ti, inv_norm=pinv)
+    pdh = f32(ops.pool_norm_bwd(py, tgo, pinv, tm, method, normalize, S, ti))
+    ok = np.array_equal(f32(y), f32(py)) and np.array_equal(f32(inv), f32(pinv))
+    ok &= all(np.array_equal(dh[cu[b]:cu[b + 1]], pdh[b, :L]) for b, L in enumerate(lens))
+    pm = O.instruction_mask(mask, instr) if instr is not None else mask
+    ref = O.pool_normalize_backward(ph, pm, method, normalize, go)
+    err = max(float(np.max(np.abs(dh[cu[b]:cu[b + 1]] - ref[b, :L]))) for b, L in enumerate(lens)) / (float(np.abs(ref).max()) + 1e-12)
+    ok &= err < 1e-2
+    return _res(f"pool_bwd varlen[{method},norm={int(normalize)}]", ok, max_rel_to_peak_vs_oracle=err)
+
+
 def check_embed_scatter():
     ids = np.array([[3, 5, 3, 7], [7, 7, 0, 3]], dtype=np.int64)
     dh = rnd((8, 64), 43)
@@ -450,6 +517,43 @@ def check_train_step(mode="direct"):
         # state_dict keeps the reference names although q/k/v and gate/up live in packed storage
         ok &= all(k in m.model.state_dict() for k in ("layers.0.self_attn.k_proj.weight", "layers.1.mlp.up_proj.weight"))
     return _res(f"native train step [{mode}] vs reference loss+grads", ok, **out)
+
+
+def check_train_packed_vs_padded(cfg_name="gqa"):
+    """One contrastive step with the packed (un-padded) training path vs the padded one: identical reps and loss, parameter
+    gradients equal up to the bf16 accumulation order of the wgrad GEMMs (K = tokens, padded rows contribute exact zeros)."""
+    from gritlm_amd.training.engine import MistralTrainEngine, SyntheticBackbone
+    from gritlm_amd.training.model import DistributedContrastiveLoss, GritLMTrainModel
+    cfg = EncoderConfig.from_dict(synth.CONFIGS[cfg_name])
+    idq, mq = synth.make_batch(synth.CONFIGS[cfg_name], 4, 48, seed=5, min_len=9)
+    idp, mp_ = synth.make_batch(synth.CONFIGS[cfg_name], 8, 150, seed=6, min_len=20)
+    q = {"input_ids": torch.from_numpy(idq).to(DEV), "attention_mask": torch.from_numpy(mq).to(DEV), "instruction_lens": [3, 0, 5, 2]}
+    p = {"input_ids": torch.from_numpy(idp).to(DEV), "attention_mask": torch.from_numpy(mp_).to(DEV)}
+    res = {}
+    for packed in (False, True):
+        bb = SyntheticBackbone(cfg, DEV, seed=3)
+        m = GritLMTrainModel.__new__(GritLMTrainModel)
+        torch.nn.Module.__init__(m)
+        m.model, m.projection, m.pooling_method, m.normalized, m.attn, m.embedding_attr = bb, None, "mean", True, "bbcc", None
+        m.emb_loss_fn = DistributedContrastiveLoss(0.02, False)
+        m.train_engine = MistralTrainEngine(bb, cfg, DEV)
+        m.native_packed = packed
+        o = m(query=dict(q), passage=dict(p))
+        o.loss.backward()
+        res[packed] = (float(o.loss.item()), f32(o.q_reps), f32(o.p_reps),
+                       {n: f32(t.grad) for n, t in bb.named_parameters()}, m.train_engine)
+    out, ok = {}, True
+    ok &= res[True][0] == res[False][0] and np.array_equal(res[True][1], res[False][1]) and np.array_equal(res[True][2], res[False][2])
+    out["loss"] = res[True][0]
+    worst = 0.0
+    for n, g_pad in res[False][3].items():
+        g_pk = res[True][3][n]
+        rel = float(np.linalg.norm(g_pk - g_pad) / (np.linalg.norm(g_pad) + 1e-20))
+        worst = max(worst, rel)
+    out["worst_grad_rel_l2"] = worst
+    ok &= worst < 1e-2
+    ok &= res[True][4]._tbuf and all(k[1] > 0 for k in res[True][4]._tbuf)
+    return _res(f"packed training step == padded training step [{cfg_name}]", bool(ok), **out)
 
 
 def check_cli_native():
@@ -704,6 +808,11 @@ ALL_CHECKS = [
     ("attn_bwd_ragged", check_attention_bwd, {}),
     ("attn_bwd_holes", check_attention_bwd, dict(mask_kind="holes", S=130, B=2, nq=2, nkv=1)),
     ("attn_bwd_full", check_attention_bwd, dict(mask_kind="none", S=256, B=1, nq=8, nkv=2)),
+    ("attn_bwd_varlen", check_attention_bwd_varlen, {}),
+    ("attn_bwd_varlen_gqa4", check_attention_bwd_varlen, dict(lens=(129, 64, 257), nq=8, nkv=2)),
+    ("pool_bwd_varlen_mean", check_pool_bwd_varlen, dict(method="mean")),
+    ("pool_bwd_varlen_weightedmean", check_pool_bwd_varlen, dict(method="weightedmean")),
+    ("pool_bwd_varlen_lasttoken", check_pool_bwd_varlen, dict(method="lasttoken", normalize=False)),
     ("embed_scatter", check_embed_scatter, {}),
     ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
@@ -717,6 +826,7 @@ ALL_CHECKS = [
     ("get_cache", check_get_cache, {}),
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
+    ("train_packed_vs_padded", check_train_packed_vs_padded, {}),
     ("cli_native", check_cli_native, {}),
     ("overlapped_grad_sync", check_overlapped_grad_sync, {}),
 ]
