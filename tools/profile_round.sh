@@ -11,4 +11,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o gemm --output-format csv -- python tools/gemm_probe.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o gemm --output-format csv -- python tools/gemm_probe.py > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA -d $OUT/pmc_mfma -o gemm --output-format csv -- python tools/gemm_probe.py > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/bench_contrastive -o bench --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ragged > $OUT/bench_contrastive.json 2> $OUT/bench_contrastive.err
 find $OUT -name "*.csv" | xargs ls -la

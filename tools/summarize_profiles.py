@@ -10,6 +10,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 shutil.copy(f"{src}/bench_stats/bench_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy(f"{src}/bench_stats.json", f"profiles/{tag}_bench_under_rocprof.json")
+import os
+if os.path.exists(f"{src}/bench_contrastive/bench_kernel_stats.csv"):      # encode + one contrastive (GradCache) step
+    shutil.copy(f"{src}/bench_contrastive/bench_kernel_stats.csv", f"profiles/{tag}_bench_with_contrastive_kernel_stats.csv")
 
 
 def load(path):
