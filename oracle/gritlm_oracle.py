@@ -157,6 +157,7 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
     if emulate_bf16:
         cos, sin = bf16_round(cos), bf16_round(sin)                       # :124-125
     layers = []
+    routing = []
     for li in range(L):                                                   # :1045-1071
         p = f"layers.{li}."
         res = h
@@ -173,17 +174,60 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
         h = rnd(res + a)                                                               # :769
         res = h
         x = rmsnorm(h, weights[p + "post_attention_layernorm.weight"], eps, emulate_bf16)  # :773
-        g = rnd(x @ weights[p + "mlp.gate_proj.weight"].T)
-        u = rnd(x @ weights[p + "mlp.up_proj.weight"].T)
-        m = rnd(rnd(silu(g)) * u)
-        m = rnd(m @ weights[p + "mlp.down_proj.weight"].T)                             # :177-178
+        if (p + "block_sparse_moe.gate.weight") in weights:                            # Mixtral: modeling_mixtral_gritlm.py:943
+            m, sel = moe_block(x.reshape(B * S, H), weights, p + "block_sparse_moe.", cfg.get("num_experts_per_tok", 2), emulate_bf16)
+            m = m.reshape(B, S, H)
+            routing.append(sel.reshape(B, S, -1))
+        else:
+            g = rnd(x @ weights[p + "mlp.gate_proj.weight"].T)
+            u = rnd(x @ weights[p + "mlp.up_proj.weight"].T)
+            m = rnd(rnd(silu(g)) * u)
+            m = rnd(m @ weights[p + "mlp.down_proj.weight"].T)                         # :177-178
         h = rnd(res + m)                                                               # :775
         if return_layers:
             layers.append(h.copy())
     out = rmsnorm(h, weights["norm.weight"], eps, emulate_bf16)                        # :1079
+    if return_layers == "routing":
+        return out, routing
     if return_layers:
         return out, layers
     return out
+
+
+def moe_router(x: np.ndarray, gate_w: np.ndarray, top_k: int = 2, emulate_bf16: bool = False):
+    """MixtralSparseMoeBlock routing, scripts/modeling_mixtral_gritlm.py:843-850: gate Linear (model dtype) -> softmax in
+    fp32 -> top-k (descending, lowest index first on ties like torch.topk on CPU) -> renormalise -> cast to the model dtype.
+    x [T,H] -> (weights [T,k] fp32 (bf16-representable when emulate_bf16), experts [T,k] int64, logits [T,E])."""
+    rnd = bf16_round if emulate_bf16 else (lambda a: a.astype(F32))
+    logits = rnd(x.astype(F32) @ gate_w.astype(F32).T)                                  # :843
+    z = logits.astype(F32) - logits.max(axis=1, keepdims=True)
+    pr = np.exp(z); pr = (pr / pr.sum(axis=1, keepdims=True)).astype(F32)               # :845 softmax(dtype=float)
+    sel = np.argsort(-pr, axis=1, kind="stable")[:, :top_k]                             # :846
+    w = np.take_along_axis(pr, sel, axis=1)
+    w = (w / w.sum(axis=1, keepdims=True)).astype(F32)                                  # :847
+    return rnd(w), sel.astype(np.int64), logits                                         # :849
+
+
+def moe_block(x: np.ndarray, weights: dict, prefix: str, top_k: int = 2, emulate_bf16: bool = False):
+    """MixtralSparseMoeBlock.forward (:839-882) with MixtralBLockSparseTop2MLP experts (:809-812): every token goes through its
+    top-k experts, each output is scaled by the routing weight (rounded in the model dtype) and the expert outputs are
+    accumulated in expert order by index_add_ (:880).  x [T,H] -> ([T,H], selected experts [T,k])."""
+    rnd = bf16_round if emulate_bf16 else (lambda a: a.astype(F32))
+    T, H = x.shape
+    w, sel, _ = moe_router(x, weights[prefix + "gate.weight"], top_k, emulate_bf16)
+    E = weights[prefix + "gate.weight"].shape[0]
+    out = np.zeros((T, H), dtype=F32)
+    for e in range(E):                                                                  # :859
+        tok, slot = np.nonzero(sel == e)
+        if tok.size == 0:
+            continue
+        xe = x[tok].astype(F32)
+        g = rnd(xe @ weights[f"{prefix}experts.{e}.w1.weight"].T)
+        u = rnd(xe @ weights[f"{prefix}experts.{e}.w3.weight"].T)
+        y = rnd(rnd(rnd(silu(g)) * u) @ weights[f"{prefix}experts.{e}.w2.weight"].T)    # :810-811
+        y = rnd(y * w[tok, slot][:, None])                                              # :876
+        out[tok] = rnd(out[tok] + y)                                                    # :880 index_add_ (a token meets an expert once)
+    return out, sel
 
 
 # ----------------------------------------------------------------------------

@@ -43,6 +43,60 @@ def load_ref_mistral():
 REFMOD = load_ref_mistral()
 
 
+def load_ref_mixtral():
+    """scripts/modeling_mixtral_gritlm.py under the installed transformers (two helper names it imports were removed upstream)."""
+    import transformers.pytorch_utils as pu
+    import transformers.utils.import_utils as iu
+    if not hasattr(iu, "is_torch_fx_available"):
+        iu.is_torch_fx_available = lambda: False
+    if not hasattr(pu, "is_torch_greater_or_equal_than_1_13"):
+        pu.is_torch_greater_or_equal_than_1_13 = True
+    name = "transformers.models.mixtral.modeling_mixtral_gritlm"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "scripts/modeling_mixtral_gritlm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@torch.no_grad()
+def gen_mixtral(cfg_name, batch, seq, min_len, seed_w=0, seed_x=4321):
+    """Bidirectional Mixtral encode of the reference (MixtralModel.forward is_causal=False) + the routing it took."""
+    mod = load_ref_mixtral()
+    cfg = synth.CONFIGS[cfg_name]
+    hc = synth.hf_config(cfg)
+    hc.use_cache = False
+    hc._attn_implementation = "sdpa"
+    model = mod.MixtralModel(hc).eval()
+    w = synth.make_weights(cfg, seed_w)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    ids, mask = synth.make_batch(cfg, batch, seq, seed_x, min_len)
+    tid, tmask = torch.from_numpy(ids), torch.from_numpy(mask)
+
+    def run(m):
+        sel = []
+        hooks = [layer.block_sparse_moe.register_forward_hook(
+            lambda _m, _i, o: sel.append(torch.topk(torch.softmax(o[1].float(), dim=1), 2, dim=-1)[1])) for layer in m.layers]
+        h = m(input_ids=tid, attention_mask=tmask, is_causal=False)[0]
+        for hk in hooks:
+            hk.remove()
+        return h.float(), torch.stack(sel).reshape(len(m.layers), batch, seq, 2)
+
+    h32, sel32 = run(model)
+    h_causal = model(input_ids=tid, attention_mask=tmask, is_causal=True)[0]
+    assert (h32 - h_causal).abs().max() > 1e-3, "is_causal flag is dead"
+    hb, selb = run(model.to(torch.bfloat16))
+    print(f"  {cfg_name}: bf16-vs-fp32 routing agreement {(sel32.sort(-1)[0] == selb.sort(-1)[0]).all(-1).float().mean().item():.4f}")
+    out = dict(cfg_name=cfg_name, seed_w=seed_w, input_ids=ids, attention_mask=mask, last_hidden_state=h32.numpy(),
+               last_hidden_state_bf16=hb.numpy(), routing=sel32.numpy(), routing_bf16=selb.numpy())
+    for method in ("mean", "weightedmean"):
+        g = ref_gritlm_shell(method)
+        out[f"emb_{method}"] = torch.nn.functional.normalize(g.pooling(h32, tmask.clone()), dim=-1).numpy()
+        out[f"emb_{method}_bf16"] = torch.nn.functional.normalize(g.pooling(hb.bfloat16(), tmask.clone()).float(), dim=-1).numpy()
+    np.savez_compressed(os.path.join(HERE, f"encoder_{cfg_name}.npz"), **out)
+
+
 def build_ref_model(cfg_name, seed=0, dtype=torch.float32, impl="sdpa"):
     cfg = synth.CONFIGS[cfg_name]
     hc = synth.hf_config(cfg)
@@ -252,6 +306,9 @@ def gen_gritlm_encode():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
+        gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
+        sys.exit(0)
     print("pooling"); gen_pooling()
     print("infonce"); gen_infonce()
     print("infonce dist"); gen_infonce_dist()
@@ -259,4 +316,5 @@ if __name__ == "__main__":
     print("encoder gqa"); gen_encoder("gqa", batch=3, seq=72, min_len=20)
     print("gradcache"); gen_gradcache()
     print("gritlm encode"); gen_gritlm_encode()
+    print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
     print("done")

@@ -20,6 +20,16 @@ CONFIGS = {
                   num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=10000.0),
     "7b": dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
                num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=10000.0),
+    # Mixtral family (scripts/modeling_mixtral_gritlm.py): sparse MoE MLP, 8 experts, top-2
+    "moe-tiny": dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                     num_attention_heads=2, num_key_value_heads=1, rms_norm_eps=1e-5, rope_theta=1e6,
+                     num_local_experts=8, num_experts_per_tok=2),
+    "moe-gqa": dict(vocab_size=384, hidden_size=512, intermediate_size=768, num_hidden_layers=3,
+                    num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=1e6,
+                    num_local_experts=8, num_experts_per_tok=2),
+    "8x7b": dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=1e6,
+                 num_local_experts=8, num_experts_per_tok=2),
 }
 
 
@@ -54,9 +64,17 @@ def make_weights(cfg: dict, seed: int = 0, std: float = 0.02) -> dict:
         w[p + "self_attn.k_proj.weight"] = lin(nkv * d, H)
         w[p + "self_attn.v_proj.weight"] = lin(nkv * d, H)
         w[p + "self_attn.o_proj.weight"] = lin(H, nh * d)
-        w[p + "mlp.gate_proj.weight"] = lin(I, H)
-        w[p + "mlp.up_proj.weight"] = lin(I, H)
-        w[p + "mlp.down_proj.weight"] = lin(H, I)
+        if "num_local_experts" in cfg:
+            # router weights drawn wide (std 0.5): clear top-2 margins, so bf16 noise flips the routing of few tokens
+            w[p + "block_sparse_moe.gate.weight"] = _bf16_round(rng.standard_normal((cfg["num_local_experts"], H), dtype=np.float32) * 0.5)
+            for e in range(cfg["num_local_experts"]):
+                w[p + f"block_sparse_moe.experts.{e}.w1.weight"] = lin(I, H)
+                w[p + f"block_sparse_moe.experts.{e}.w2.weight"] = lin(H, I)
+                w[p + f"block_sparse_moe.experts.{e}.w3.weight"] = lin(I, H)
+        else:
+            w[p + "mlp.gate_proj.weight"] = lin(I, H)
+            w[p + "mlp.up_proj.weight"] = lin(I, H)
+            w[p + "mlp.down_proj.weight"] = lin(H, I)
         w[p + "input_layernorm.weight"] = nrm()
         w[p + "post_attention_layernorm.weight"] = nrm()
     w["norm.weight"] = nrm()
@@ -79,9 +97,12 @@ def make_batch(cfg: dict, batch: int, seq: int, seed: int = 1234, min_len: int |
 
 
 def hf_config(cfg: dict):
-    """transformers.MistralConfig for a synthetic config (tests that build HF model dirs)."""
-    from transformers import MistralConfig
-    c = MistralConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
+    """transformers.MistralConfig / MixtralConfig for a synthetic config (tests that build HF model dirs)."""
+    from transformers import MistralConfig, MixtralConfig
+    cls, extra = MistralConfig, {}
+    if "num_local_experts" in cfg:
+        cls, extra = MixtralConfig, dict(num_local_experts=cfg["num_local_experts"], num_experts_per_tok=cfg["num_experts_per_tok"])
+    c = cls(**extra, vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
                       intermediate_size=cfg["intermediate_size"],
                       num_hidden_layers=cfg["num_hidden_layers"],
                       num_attention_heads=cfg["num_attention_heads"],

@@ -94,6 +94,42 @@ def test_encoder_bf16_emulation_tracks_bf16_reference(golden_dir):
     assert rel(h, ref_b) < 1.5 * rel(ref_b, ref_f) + 1e-3, (rel(h, ref_b), rel(ref_b, ref_f))
 
 
+@pytest.mark.parametrize("cfg_name", ["moe-tiny", "moe-gqa"])
+def test_mixtral_encoder_matches_reference(golden_dir, cfg_name):
+    """Sparse-MoE (Mixtral) bidirectional encode of the oracle vs scripts/modeling_mixtral_gritlm.py (fp32): hidden states,
+    the routing decisions of every layer, pooled embeddings; and the bf16 emulation tracks the bf16 reference."""
+    g = _load(golden_dir, f"encoder_{cfg_name}.npz")
+    cfg = synth.CONFIGS[cfg_name]
+    w = synth.make_weights(cfg, int(g["seed_w"]))
+    ids, mask = g["input_ids"], g["attention_mask"]
+    h, routing = O.mistral_encode(w, cfg, ids, mask, return_layers="routing")
+    valid = mask.astype(bool)
+    assert np.abs(h - g["last_hidden_state"])[valid].max() < 3e-4
+    got = np.sort(np.stack(routing), axis=-1)[:, valid]
+    want = np.sort(g["routing"], axis=-1)[:, valid]
+    assert (got == want).all(-1).mean() > 0.999          # fp32 vs fp32: only exact near-ties may differ
+    for method in ("mean", "weightedmean"):
+        e = O.l2_normalize(O.pooling(h, mask, method))
+        assert np.all(1 - np.sum(e * g[f"emb_{method}"], axis=1) < 1e-6)
+    hb = O.mistral_encode(w, cfg, ids, mask, emulate_bf16=True)
+    ref_b, ref_f = g["last_hidden_state_bf16"], g["last_hidden_state"]
+    rel = lambda a, b: np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid])
+    assert rel(hb, ref_b) < 1.5 * rel(ref_b, ref_f) + 1e-3, (rel(hb, ref_b), rel(ref_b, ref_f))
+
+
+def test_moe_router_topk_and_renormalisation():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((64, 32)).astype(np.float32)
+    gw = rng.standard_normal((8, 32)).astype(np.float32)
+    w, sel, logits = O.moe_router(x, gw)
+    assert np.allclose(w.sum(axis=1), 1.0, atol=1e-6) and (w[:, 0] >= w[:, 1]).all()
+    assert (sel[:, 0] == np.argmax(logits, axis=1)).all() and (sel[:, 0] != sel[:, 1]).all()
+    import torch
+    pr = torch.softmax(torch.from_numpy(x @ gw.T), dim=1, dtype=torch.float)
+    tw, ts = torch.topk(pr, 2, dim=-1)
+    assert np.array_equal(ts.numpy(), sel) and np.allclose((tw / tw.sum(-1, keepdim=True)).numpy(), w, atol=1e-6)
+
+
 def test_rope_tables_and_rotate_half():
     cos, sin = O.rope_tables(8, 16, 10000.0)
     assert cos.shape == (8, 16) and np.allclose(cos[:, :8], cos[:, 8:])
