@@ -40,11 +40,22 @@ __device__ __forceinline__ void lds_dma_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Grouped ("MoE") mode: the M rows are the concatenation of n_groups row ranges (counts[g] rows each, read from DEVICE memory so
+// the host never syncs on the routing), group g multiplies against W + g * w_stride.  tiles_m is then an upper bound
+// (sum_g ceil(counts[g]/256) <= floor(M/256) + n_groups); surplus workgroups exit.  a_rows (optional) gathers the A rows:
+// sorted row r is A[a_rows[r]] -- the token permutation is folded into the per-lane LDS-DMA source address.
+struct GemmGroups {
+  const int32_t* counts;
+  const int32_t* a_rows;
+  int64_t w_stride;
+  int n_groups;
+};
+
 template <int EPI, int ABL = 0>
-__global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-                                                      uint16_t* C, const uint16_t* Rsd, int64_t M,
+__global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W_all,
+                                                      uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
-                                                      int tiles_m, int tiles_n, int GM, int remap) {
+                                                      int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- XCD-aware tile id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group)
@@ -56,7 +67,21 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
   const int in_grp = wg - grp * group_sz;
   const int tm = first_m + in_grp % gm, tn = in_grp / gm;
-  const int64_t m0 = (int64_t)tm * BM;
+  int64_t m0 = (int64_t)tm * BM, M = M_all;
+  const uint16_t* W = W_all;
+  if (groups.counts != nullptr) {
+    int t = tm, g = 0;
+    int64_t off = 0;
+    for (; g < groups.n_groups; ++g) {
+      const int c = groups.counts[g], nt = (c + BM - 1) / BM;
+      if (t < nt) break;
+      t -= nt; off += c;
+    }
+    if (g == groups.n_groups) return;                             // surplus tile of the upper-bound grid
+    m0 = off + (int64_t)t * BM;
+    M = off + groups.counts[g];                                    // row limit of this group
+    W = W_all + (int64_t)g * groups.w_stride;
+  }
   const int n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -72,6 +97,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     const int r = (wid * 4 + c) * 8 + srow;                    // tile row 0..255
     const int slot = (lane & 7) ^ ((r >> 1) & 7);              // logical 16-B slot held by this physical slot
     int64_t gm_row = m0 + r; if (gm_row > M - 1) gm_row = M - 1;
+    if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
     int gn_row = n0 + r; if (gn_row > N - 1) gn_row = N - 1;
     a_src[c] = A + gm_row * lda + slot * 8;
     w_src[c] = W + (int64_t)gn_row * ldw + slot * 8;
@@ -439,8 +465,8 @@ static int gemm_variant() {
 
 template <int EPI>
 static int launch_gemm(const void* A, const void* W, void* C, const void* R, int64_t M, int N, int K, int64_t lda, int64_t ldw,
-                       int64_t ldc, int64_t ldr, hipStream_t st) {
-  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
+                       int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0}) {
+  const int tiles_m = grp.counts ? (int)(M / BM) + grp.n_groups : (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
   static bool attr_set = false;  // idempotent; benign race
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
@@ -455,7 +481,7 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
   }
 #define GRIT_LAUNCH_ABL(A_)                                                                                                          \
   hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, A_>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, \
-                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob, remap_knob)
+                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob, remap_knob, grp)
   if (abl > 0 && EPI == GRIT_EPI_STORE && gemm_variant() == 1) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
@@ -471,7 +497,7 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
     else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else if (abl == 11) GRIT_LAUNCH_ABL(11); else if (abl == 12) GRIT_LAUNCH_ABL(12); else GRIT_LAUNCH_ABL(13);
-  } else if (gemm_variant() == 8) {
+  } else if (gemm_variant() == 8 && grp.counts == nullptr) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v8_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
     hipLaunchKernelGGL(gemm_bf16_nt_v8_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
                        (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob);
@@ -486,6 +512,33 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
 using namespace grit;
 
 extern "C" int grit_swiglu_block(void) { return 16; }
+
+extern "C" int grit_gemm_bf16_nt_grouped(const void* A, const int32_t* a_rows, const void* W, void* C, const int32_t* group_counts,
+                                         int num_groups, int64_t M_total, int N, int K, int64_t lda, int64_t ldw, int64_t w_group_stride,
+                                         int64_t ldc, int epilogue, void* stream) {
+  if (M_total == 0) return GRIT_OK;
+  GRIT_REQUIRE(A && W && C && group_counts, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped: null pointer");
+  GRIT_REQUIRE(M_total >= 0 && N > 0 && K > 0 && num_groups > 0 && num_groups <= 1024, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped: bad sizes");
+  GRIT_REQUIRE(K % 64 == 0 && N % 16 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_grouped: K=%d must be a multiple of 64, N=%d of 16", K, N);
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && w_group_stride % 8 == 0 && lda >= K && ldw >= K, GRIT_E_BADARG,
+               "grit_gemm_bf16_nt_grouped: bad leading dimensions");
+  GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C), GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((int64_t)(M_total / BM + num_groups) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "grit_gemm_bf16_nt_grouped: too many tiles");
+  const GemmGroups grp{group_counts, a_rows, w_group_stride, num_groups};
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case GRIT_EPI_STORE:
+      GRIT_REQUIRE(ldc >= N, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped: ldc < N");
+      return launch_gemm<GRIT_EPI_STORE>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    case GRIT_EPI_SWIGLU:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_grouped: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    default:
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped: epilogue %d not available (STORE, SWIGLU)", epilogue);
+  }
+  return GRIT_OK;
+}
 
 extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                                  int64_t ldc, int epilogue, const void* residual, int64_t ldr, void* stream) {

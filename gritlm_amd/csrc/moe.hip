@@ -1,0 +1,193 @@
+// Sparse-MoE plumbing around the grouped GEMM (Mixtral's MixtralSparseMoeBlock, scripts/modeling_mixtral_gritlm.py:839-882):
+//   router  : gate Linear (bf16-rounded logits) -> softmax fp32 -> top-2 -> renormalise -> bf16     (:843-849)
+//   index   : stable counting sort of the (token, k) pairs by expert -> per-expert row ranges        (replaces the per-expert
+//             torch.where + .tolist() host round trips of :859-870; counts stay on the device)
+//   combine : out = residual + (w_a * y_a  (+)  w_b * y_b) with the reference's bf16 rounding points (:876, :880, decoder :945)
+// The expert MLPs themselves are two launches of grit_gemm_bf16_nt_grouped (gathered A rows, SwiGLU epilogue; then w2).
+// All three kernels are HBM/latency-bound byte work; no MFMA.
+#include "common.h"
+
+namespace grit {
+
+constexpr int MOE_MAX_E = 16;
+
+// ---- router: one wave per token, gate weights staged in LDS ([E,H] bf16)
+template <int E>
+__global__ void __launch_bounds__(256) moe_router_top2_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gate_w, int64_t T,
+                                                         int H, int32_t* __restrict__ experts, float* __restrict__ weights) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* gw = reinterpret_cast<uint4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HC = H >> 3;
+  for (int i = tid; i < E * HC; i += 256) gw[i] = reinterpret_cast<const uint4*>(gate_w)[i];
+  __syncthreads();
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < T; t += (int64_t)gridDim.x * 4) {
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    const uint4* xr = reinterpret_cast<const uint4*>(x) + t * HC;
+    for (int c = lane; c < HC; c += 64) {
+      const uint4 xv = xr[c];
+      const float xf[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint4 wv = gw[e * HC + c];
+        acc[e] += xf[0] * bflo(wv.x) + xf[1] * bfhi(wv.x) + xf[2] * bflo(wv.y) + xf[3] * bfhi(wv.y) + xf[4] * bflo(wv.z) +
+                  xf[5] * bfhi(wv.z) + xf[6] * bflo(wv.w) + xf[7] * bfhi(wv.w);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { acc[e] = round_bf(wave_sum(acc[e])); mx = fmaxf(mx, acc[e]); }   // nn.Linear output in the model dtype
+    float p[E], den = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { p[e] = expf(acc[e] - mx); den += p[e]; }
+    int e0 = 0, e1 = -1;
+    float p0 = -1.f, p1 = -1.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {                    // descending, lowest index first on ties (torch.topk on equal values)
+      const float pe = p[e] / den;
+      if (pe > p0) { p1 = p0; e1 = e0; p0 = pe; e0 = e; }
+      else if (pe > p1) { p1 = pe; e1 = e; }
+    }
+    if (lane == 0) {
+      const float s = p0 + p1;
+      experts[2 * t] = e0; experts[2 * t + 1] = e1;
+      weights[2 * t] = round_bf(p0 / s); weights[2 * t + 1] = round_bf(p1 / s);
+    }
+  }
+}
+
+// ---- index: ONE workgroup; thread i owns a contiguous range of the 2T (token, k) entries -> per-thread expert histogram ->
+//      block-wide exclusive scans -> second walk assigns positions.  Stable: inside an expert the rows are ordered by token, the
+//      order torch.where produces in the reference (:861).
+constexpr int IDX_THREADS = 512;
+__global__ void __launch_bounds__(IDX_THREADS) moe_index_k(const int32_t* __restrict__ experts, int64_t n, int E, int32_t* __restrict__ counts,
+                                                            int32_t* __restrict__ row_token, int32_t* __restrict__ rows) {
+  __shared__ int32_t hist[MOE_MAX_E][IDX_THREADS + 1];
+  __shared__ int32_t base[MOE_MAX_E + 1];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + IDX_THREADS - 1) / IDX_THREADS;
+  const int64_t lo = (int64_t)tid * per, hi = lo + per < n ? lo + per : n;
+  int32_t c[MOE_MAX_E];
+#pragma unroll
+  for (int e = 0; e < MOE_MAX_E; ++e) c[e] = 0;
+  for (int64_t i = lo; i < hi; ++i) {
+    const int e = experts[i];
+#pragma unroll
+    for (int k = 0; k < MOE_MAX_E; ++k) c[k] += (k == e);
+  }
+#pragma unroll
+  for (int e = 0; e < MOE_MAX_E; ++e)
+    if (e < E) hist[e][tid] = c[e];
+  __syncthreads();
+  // exclusive scan over the threads, one wave per expert round-robin (8 waves)
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int e = wave; e < E; e += IDX_THREADS / 64) {
+    int32_t run = 0;
+    for (int b = 0; b < IDX_THREADS; b += 64) {
+      const int32_t v = hist[e][b + lane];
+      int32_t inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+      hist[e][b + lane] = run + inc - v;
+      run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) hist[e][IDX_THREADS] = run;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int32_t off = 0;
+    for (int e = 0; e < E; ++e) { base[e] = off; counts[e] = hist[e][IDX_THREADS]; off += hist[e][IDX_THREADS]; }
+    base[E] = off;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < MOE_MAX_E; ++e) c[e] = e < E ? base[e] + hist[e][tid] : 0;
+  for (int64_t i = lo; i < hi; ++i) {
+    const int e = experts[i];
+    int32_t pos = 0;
+#pragma unroll
+    for (int k = 0; k < MOE_MAX_E; ++k)
+      if (k == e) { pos = c[k]; c[k] += 1; }
+    rows[i] = pos;
+    row_token[pos] = (int32_t)(i >> 1);
+  }
+}
+
+// ---- combine: out[t] = bf16(res[t] + bf16(bf16(w0 * y[r0]) + bf16(w1 * y[r1])))
+__global__ void __launch_bounds__(256) moe_combine_k(const uint16_t* __restrict__ y, const int32_t* __restrict__ rows,
+                                                     const float* __restrict__ weights, const uint16_t* __restrict__ res,
+                                                     uint16_t* __restrict__ out, int64_t T, int H) {
+  const int HC = H >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * HC) return;
+  const int64_t t = i / HC;
+  const int c = (int)(i - t * HC);
+  const int r0 = rows[2 * t], r1 = rows[2 * t + 1];
+  const float w0 = weights[2 * t], w1 = weights[2 * t + 1];
+  const uint4 a = reinterpret_cast<const uint4*>(y)[(int64_t)r0 * HC + c];
+  const uint4 b = reinterpret_cast<const uint4*>(y)[(int64_t)r1 * HC + c];
+  const uint4 r = res ? reinterpret_cast<const uint4*>(res)[i] : make_uint4(0, 0, 0, 0);
+  const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, rv[4] = {r.x, r.y, r.z, r.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float lo = round_bf(round_bf(w0 * bflo(av[k])) + round_bf(w1 * bflo(bv[k])));
+    const float hi = round_bf(round_bf(w0 * bfhi(av[k])) + round_bf(w1 * bfhi(bv[k])));
+    o[k] = res ? pack2bf(lo + bflo(rv[k]), hi + bfhi(rv[k])) : pack2bf(lo, hi);
+  }
+  reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+}  // namespace grit
+
+using namespace grit;
+
+extern "C" int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* experts, float* weights, int64_t T, int H, int E,
+                                    void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && gate_w && experts && weights, GRIT_E_BADARG, "grit_moe_router_top2: null pointer");
+  GRIT_REQUIRE(T > 0 && H > 0 && H % 8 == 0, GRIT_E_BADARG, "grit_moe_router_top2: bad sizes T=%lld H=%d", (long long)T, H);
+  GRIT_REQUIRE(E == 4 || E == 8 || E == 16, GRIT_E_UNSUPPORTED, "grit_moe_router_top2: num_experts=%d (4, 8 and 16 are built)", E);
+  GRIT_REQUIRE((size_t)E * H * 2 <= 160 * 1024, GRIT_E_UNSUPPORTED, "grit_moe_router_top2: gate [%d,%d] exceeds LDS", E, H);
+  GRIT_REQUIRE(aligned16(x) && aligned16(gate_w), GRIT_E_BADARG, "grit_moe_router_top2: pointers must be 16-byte aligned");
+  const size_t lds = (size_t)E * H * 2;
+  int64_t nb = (T + 3) / 4;
+  if (nb > 1024) nb = 1024;
+  hipStream_t st = (hipStream_t)stream;
+#define GRIT_ROUTER(E_)                                                                                                       \
+  do {                                                                                                                        \
+    static bool set_ = false;                                                                                                 \
+    if (!set_) { (void)hipFuncSetAttribute((const void*)moe_router_top2_k<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
+    hipLaunchKernelGGL(moe_router_top2_k<E_>, dim3((unsigned)nb), dim3(256), lds, st, (const uint16_t*)x, (const uint16_t*)gate_w, T, H,  \
+                       experts, weights);                                                                                     \
+  } while (0)
+  if (E == 4) GRIT_ROUTER(4); else if (E == 8) GRIT_ROUTER(8); else GRIT_ROUTER(16);
+  GRIT_CHECK_LAUNCH("grit_moe_router_top2");
+  return GRIT_OK;
+}
+
+extern "C" int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t* counts, int32_t* row_token, int32_t* rows, void* stream) {
+  GRIT_REQUIRE(counts, GRIT_E_BADARG, "grit_moe_index: null pointer");
+  GRIT_REQUIRE(E > 0 && E <= MOE_MAX_E, GRIT_E_UNSUPPORTED, "grit_moe_index: num_experts=%d (max %d)", E, MOE_MAX_E);
+  GRIT_REQUIRE(T >= 0 && 2 * T < (1ll << 31), GRIT_E_BADARG, "grit_moe_index: bad T");
+  GRIT_REQUIRE(T == 0 || (experts && row_token && rows), GRIT_E_BADARG, "grit_moe_index: null pointer");
+  hipLaunchKernelGGL(moe_index_k, dim3(1), dim3(IDX_THREADS), 0, (hipStream_t)stream, experts, 2 * T, E, counts, row_token, rows);
+  GRIT_CHECK_LAUNCH("grit_moe_index");
+  return GRIT_OK;
+}
+
+extern "C" int grit_moe_combine(const void* y, const int32_t* rows, const float* weights, const void* residual, void* out, int64_t T, int H,
+                                void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(y && rows && weights && out, GRIT_E_BADARG, "grit_moe_combine: null pointer");
+  GRIT_REQUIRE(T > 0 && H > 0 && H % 8 == 0, GRIT_E_BADARG, "grit_moe_combine: bad sizes");
+  GRIT_REQUIRE(aligned16(y) && aligned16(out) && (!residual || aligned16(residual)), GRIT_E_BADARG,
+               "grit_moe_combine: pointers must be 16-byte aligned");
+  const int64_t n = T * (H >> 3);
+  hipLaunchKernelGGL(moe_combine_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, rows, weights,
+                     (const uint16_t*)residual, (uint16_t*)out, T, H);
+  GRIT_CHECK_LAUNCH("grit_moe_combine");
+  return GRIT_OK;
+}

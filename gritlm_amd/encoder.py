@@ -1,4 +1,4 @@
-"""Native bidirectional Mistral encoder: the host-side driver of the HIP kernels.
+"""Native bidirectional Mistral / Mixtral encoder: the host-side driver of the HIP kernels.
 
 Replaces ``MistralModel.forward(..., is_causal=False)`` of scripts/modeling_mistral_gritlm.py:936-1096 for
 the embedding path.  Per layer (reference: 3+1+3 nn.Linear GEMMs, ~20 elementwise kernels, repeat_kv,
@@ -7,6 +7,10 @@ a [B,1,S,S] mask) it launches 8 kernels:
     rmsnorm -> fused QKV GEMM -> RoPE (in place) -> flash attention (GQA, key bitmask)
             -> o_proj GEMM + residual epilogue -> rmsnorm -> gate|up GEMM + SwiGLU epilogue
             -> down GEMM + residual epilogue
+
+Mixtral (scripts/modeling_mixtral_gritlm.py: same attention, sparse-MoE MLP :815-882) swaps the last two launches for
+router -> index -> grouped w1|w3 GEMM + SwiGLU (token gather folded into the A loads) -> grouped w2 GEMM -> weighted combine
++ residual; the per-expert Python loop with its ``.tolist()`` host syncs is gone (expert row counts stay on the device).
 
 Weights are repacked once (QKV concatenated, gate/up rows interleaved in blocks of 16 so that the SwiGLU
 epilogue is register-local); activations live in a per-token-count workspace sized for 288 GB HBM.
@@ -34,6 +38,8 @@ class EncoderConfig:
     rms_norm_eps: float = 1e-5
     rope_theta: float = 10000.0
     head_dim: int | None = None
+    num_local_experts: int = 0          # > 0: Mixtral sparse-MoE MLP
+    num_experts_per_tok: int = 2
 
     def __post_init__(self):
         if self.head_dim is None:
@@ -46,7 +52,8 @@ class EncoderConfig:
             rp = getattr(hf, "rope_parameters", None) or {}
             theta = rp.get("rope_theta", 10000.0)
         return cls(hf.hidden_size, hf.intermediate_size, hf.num_hidden_layers, hf.num_attention_heads,
-                   hf.num_key_value_heads, hf.vocab_size, hf.rms_norm_eps, float(theta), getattr(hf, "head_dim", None))
+                   hf.num_key_value_heads, hf.vocab_size, hf.rms_norm_eps, float(theta), getattr(hf, "head_dim", None),
+                   int(getattr(hf, "num_local_experts", 0) or 0), int(getattr(hf, "num_experts_per_tok", 2) or 2))
 
     @classmethod
     def from_dict(cls, d):
@@ -61,6 +68,9 @@ class EncoderConfig:
             raise GritHipError("native encoder: hidden/intermediate sizes must be multiples of 64")
         if c.num_attention_heads % c.num_key_value_heads:
             raise GritHipError("native encoder: num_attention_heads must be a multiple of num_key_value_heads")
+        if c.num_local_experts and (c.num_local_experts not in (4, 8, 16) or c.num_experts_per_tok != 2):
+            raise GritHipError(f"native encoder: MoE with {c.num_local_experts} experts / top-{c.num_experts_per_tok}; "
+                               "4, 8 or 16 experts with top-2 routing (Mixtral) are built")
 
 
 def swiglu_interleave(gate: torch.Tensor, up: torch.Tensor, block: int | None = None) -> torch.Tensor:
@@ -86,7 +96,7 @@ def rope_tables(seq_len: int, head_dim: int, theta: float, round_bf16: bool, dev
 
 
 class _Layer:
-    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2")
+    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "wgate", "w13", "w2")
 
 
 class MistralEncoderEngine:
@@ -102,6 +112,7 @@ class MistralEncoderEngine:
         self._ws = {}
         self._rope = {}
         self.rope_bf16 = True
+        self.record_routing = None      # tests: set to a list to collect every MoE layer's selected experts [T,2]
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -116,8 +127,21 @@ class MistralEncoderEngine:
             L.wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
                                 g(p + "self_attn.v_proj.weight")], dim=0).contiguous()
             L.wo = g(p + "self_attn.o_proj.weight").contiguous()
-            L.wgu = swiglu_interleave(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))
-            L.wdown = g(p + "mlp.down_proj.weight").contiguous()
+            if cfg.num_local_experts and (prefix + p + "mlp.experts.gate_up_proj") in sd:
+                # transformers >= 5 layout: fused [E, 2I, H] = [gate rows | up rows] per expert, down_proj [E, H, I]
+                gu, I = g(p + "mlp.experts.gate_up_proj"), cfg.intermediate_size
+                L.wgate = g(p + "mlp.gate.weight").contiguous()
+                L.w13 = torch.stack([swiglu_interleave(gu[e, :I], gu[e, I:]) for e in range(cfg.num_local_experts)]).contiguous()
+                L.w2 = g(p + "mlp.experts.down_proj").contiguous()
+            elif cfg.num_local_experts:
+                m = p + "block_sparse_moe."        # reference / checkpoint layout (modeling_mixtral_gritlm.py:803-805, :834-836)
+                L.wgate = g(m + "gate.weight").contiguous()
+                L.w13 = torch.stack([swiglu_interleave(g(f"{m}experts.{e}.w1.weight"), g(f"{m}experts.{e}.w3.weight"))
+                                     for e in range(cfg.num_local_experts)]).contiguous()                     # [E, 2I, H]
+                L.w2 = torch.stack([g(f"{m}experts.{e}.w2.weight") for e in range(cfg.num_local_experts)]).contiguous()   # [E, H, I]
+            else:
+                L.wgu = swiglu_interleave(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))
+                L.wdown = g(p + "mlp.down_proj.weight").contiguous()
             L.ln1 = g(p + "input_layernorm.weight").contiguous()
             L.ln2 = g(p + "post_attention_layernorm.weight").contiguous()
             eng.layers.append(L)
@@ -143,8 +167,16 @@ class MistralEncoderEngine:
             L = _Layer()
             L.wqkv = lin((nq + 2 * nkv) * d, H)
             L.wo = lin(H, nq * d)
-            L.wgu = lin(2 * I, H)          # already "interleaved": random rows
-            L.wdown = lin(H, I)
+            if cfg.num_local_experts:
+                E = cfg.num_local_experts
+                L.wgate = (torch.randn((E, H), generator=gen, device=eng.device, dtype=torch.float32) * 0.5).to(BF16)
+                L.w13 = torch.empty((E, 2 * I, H), dtype=BF16, device=eng.device)
+                L.w2 = torch.empty((E, H, I), dtype=BF16, device=eng.device)
+                for e in range(E):            # expert by expert: the fp32 staging tensor stays small
+                    L.w13[e].copy_(lin(2 * I, H)); L.w2[e].copy_(lin(H, I))
+            else:
+                L.wgu = lin(2 * I, H)          # already "interleaved": random rows
+                L.wdown = lin(H, I)
             L.ln1, L.ln2 = nrm(), nrm()
             eng.layers.append(L)
         eng.norm = nrm()
@@ -160,9 +192,27 @@ class MistralEncoderEngine:
             qkv_w = (c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim
             self._ws.clear()
             mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
-            self._ws.update(cap=T, h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim),
-                            act=mk(c.intermediate_size))
-        return {k: v[:T] for k, v in self._ws.items() if k != "cap"}
+            self._ws.update(cap=T, h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim))
+            if c.num_local_experts:           # every token visits two experts: 2T rows of expert activations
+                self._ws.update(act2=torch.empty((2 * T, c.intermediate_size), dtype=BF16, device=dev),
+                                y2=torch.empty((2 * T, c.hidden_size), dtype=BF16, device=dev))
+            else:
+                self._ws.update(act=mk(c.intermediate_size))
+        return {k: (v[:2 * T] if k in ("act2", "y2") else v[:T]) for k, v in self._ws.items() if k != "cap"}
+
+    def _mlp(self, L: _Layer, x: torch.Tensor, h: torch.Tensor, ws: dict):
+        """h += MLP(x) in place (x = post-attention RMSNorm output): dense SwiGLU MLP or Mixtral's sparse-MoE block."""
+        if not self.cfg.num_local_experts:
+            ops.gemm_nt(x, L.wgu, out=ws["act"], epilogue=EPI_SWIGLU)
+            ops.gemm_nt(ws["act"], L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            return
+        T = x.shape[0]
+        experts, weights, counts, row_token, rows = ops.moe_route(x, L.wgate)
+        if self.record_routing is not None:
+            self.record_routing.append(experts.clone())
+        ops.gemm_nt_grouped(x, L.w13, counts, 2 * T, out=ws["act2"], epilogue=EPI_SWIGLU, a_rows=row_token)
+        ops.gemm_nt_grouped(ws["act2"], L.w2, counts, 2 * T, out=ws["y2"])
+        ops.moe_combine(ws["y2"], rows, weights, h, out=h)
 
     def _rope_tables(self, S: int):
         t = self._rope.get(S)
@@ -189,7 +239,7 @@ class MistralEncoderEngine:
             attention_mask = torch.ones((B, S), dtype=torch.int64, device=self.device)
         mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
         ws = self._workspace(T)
-        h, x, qkv, ctx, act = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["act"]
+        h, x, qkv, ctx = ws["h"], ws["x"], ws["qkv"], ws["ctx"]
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         cos, sin = self._rope_tables(S)
         bits = ops.mask_pack(mask)
@@ -205,8 +255,7 @@ class MistralEncoderEngine:
             ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
-            ops.gemm_nt(x, L.wgu, out=act, epilogue=EPI_SWIGLU)
-            ops.gemm_nt(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            self._mlp(L, x, h, ws)
         ops.rmsnorm(h, self.norm, eps, out=x)
         out = x.view(B, S, c.hidden_size)
         out = out if borrow else out.clone()
@@ -247,7 +296,7 @@ class MistralEncoderEngine:
         T = int(pids.numel())
         max_len = int(lens.max().item())
         ws = self._workspace(T)
-        h, x, qkv, ctx, act = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["act"]
+        h, x, qkv, ctx = ws["h"], ws["x"], ws["qkv"], ws["ctx"]
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         cos, sin = self._rope_tables(S)
         ops.embed_gather(self.embed, pids, out=h)
@@ -258,8 +307,7 @@ class MistralEncoderEngine:
             ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
-            ops.gemm_nt(x, L.wgu, out=act, epilogue=EPI_SWIGLU)
-            ops.gemm_nt(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            self._mlp(L, x, h, ws)
         ops.rmsnorm(h, self.norm, eps, out=x)
         return ops.pool_norm_varlen(x, cu, method, normalize, instr_len)
 
@@ -269,4 +317,5 @@ class MistralEncoderEngine:
         H, I, L = self.cfg.hidden_size, self.cfg.intermediate_size, self.cfg.num_hidden_layers
         hkv = self.cfg.num_key_value_heads * self.cfg.head_dim
         hq = self.cfg.num_attention_heads * self.cfg.head_dim
-        return 2.0 * L * (H * (hq + 2 * hkv) + hq * H + 3 * H * I) + 4.0 * L * S * hq
+        mlp = 3 * H * I * (self.cfg.num_experts_per_tok if self.cfg.num_local_experts else 1) + H * self.cfg.num_local_experts
+        return 2.0 * L * (H * (hq + 2 * hkv) + hq * H + mlp) + 4.0 * L * S * hq

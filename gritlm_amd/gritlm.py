@@ -119,7 +119,7 @@ class GritLM(torch.nn.Module):
             return
         dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
         cfg = self.model.config
-        eligible = (dev.type == "cuda" and getattr(cfg, "model_type", "") == "mistral" and self.attn is not None
+        eligible = (dev.type == "cuda" and getattr(cfg, "model_type", "") in ("mistral", "mixtral") and self.attn is not None
                     and self.attn[:2] == "bb" and self.model.dtype == torch.bfloat16)
         if not eligible:
             if self._native is True:

@@ -176,6 +176,56 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     return out
 
 
+def gemm_nt_grouped(a: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, m_total: int, out: torch.Tensor | None = None,
+                    epilogue: int = EPI_STORE, a_rows: torch.Tensor | None = None) -> torch.Tensor:
+    """Grouped GEMM over ``w [E,N,K]``: sorted row r (group by group, ``counts`` int32 [E] on the device) is
+    a[a_rows[r]] @ w[g]^T.  ``m_total`` = number of sorted rows (2T for top-2 routing)."""
+    E, N, K = w.shape
+    assert a.shape[1] == K
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((m_total, n_out), dtype=BF16, device=a.device)
+    assert out.shape == (m_total, n_out)
+    ev = _timer.span("gemm_bf16_nt_grouped", 2.0 * m_total * N * K) if _timer is not None else None
+    if ev:
+        ev[0].record()
+    check(_lib.load().grit_gemm_bf16_nt_grouped(_chk2d(a, BF16, "a"), 0 if a_rows is None else _chk(a_rows, I32, "a_rows"),
+                                                _chk(w, BF16, "w"), _chk2d(out, BF16, "out"), _chk(counts, I32, "counts"), E, m_total, N, K,
+                                                a.stride(0), w.stride(1), w.stride(0), out.stride(0), epilogue, _stream()),
+          "grit_gemm_bf16_nt_grouped")
+    if ev:
+        ev[1].record()
+    return out
+
+
+def moe_route(x: torch.Tensor, gate_w: torch.Tensor):
+    """Top-2 routing of x [T,H] -> (experts [T,2] i32, weights [T,2] f32, counts [E] i32, row_token [2T] i32, rows [T,2] i32)."""
+    T, H = x.shape
+    E = gate_w.shape[0]
+    dev = x.device
+    experts = torch.empty((T, 2), dtype=I32, device=dev)
+    weights = torch.empty((T, 2), dtype=F32, device=dev)
+    counts = torch.empty((E,), dtype=I32, device=dev)
+    row_token = torch.empty((2 * T,), dtype=I32, device=dev)
+    rows = torch.empty((T, 2), dtype=I32, device=dev)
+    check(_lib.load().grit_moe_router_top2(_chk(x, BF16, "x"), _chk(gate_w, BF16, "gate_w"), experts.data_ptr(), weights.data_ptr(), T, H, E,
+                                           _stream()), "grit_moe_router_top2")
+    check(_lib.load().grit_moe_index(experts.data_ptr(), T, E, counts.data_ptr(), row_token.data_ptr(), rows.data_ptr(), _stream()),
+          "grit_moe_index")
+    return experts, weights, counts, row_token, rows
+
+
+def moe_combine(y: torch.Tensor, rows: torch.Tensor, weights: torch.Tensor, residual: torch.Tensor | None, out: torch.Tensor | None = None):
+    T = rows.shape[0]
+    H = y.shape[1]
+    if out is None:
+        out = torch.empty((T, H), dtype=BF16, device=y.device)
+    check(_lib.load().grit_moe_combine(_chk(y, BF16, "y"), _chk(rows, I32, "rows"), _chk(weights, F32, "weights"),
+                                       0 if residual is None else _chk(residual, BF16, "residual"), _chk(out, BF16, "out"), T, H, _stream()),
+          "grit_moe_combine")
+    return out
+
+
 def mask_pack(mask: torch.Tensor) -> torch.Tensor:
     B, S = mask.shape
     bits = torch.empty((B, (S + 63) // 64), dtype=I64, device=mask.device)   # uint64 payload in int64 storage

@@ -103,6 +103,32 @@ int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, fl
 int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
                                int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
 
+/* ---- sparse MoE MLP (Mixtral): scripts/modeling_mixtral_gritlm.py:797-882 ---------------------- */
+
+/* Grouped GEMM: the M_total rows of A (and C) are the concatenation of num_groups row ranges, group g has
+ * group_counts[g] rows (int32, DEVICE memory: the host never waits for the routing) and multiplies against
+ * W + g * w_group_stride ([N,K] each):  C[r,:] = A[a_rows ? a_rows[r] : r, :] * W_g^T.   a_rows (nullable, int32
+ * [M_total], device) gathers the A rows, i.e. the token permutation of :861-873 without materialising it.
+ * Epilogues: GRIT_EPI_STORE, GRIT_EPI_SWIGLU (w1/w3 rows interleaved per expert, grit_swiglu_block()). */
+int grit_gemm_bf16_nt_grouped(const void* A, const int32_t* a_rows, const void* W, void* C, const int32_t* group_counts,
+                              int num_groups, int64_t M_total, int N, int K, int64_t lda, int64_t ldw,
+                              int64_t w_group_stride, int64_t ldc, int epilogue, void* stream);
+
+/* Router (:843-849): logits = bf16(x gate_w^T), softmax in fp32, top-2 (ties: lower index), renormalise, round to bf16.
+ * x [T,H] bf16, gate_w [E,H] bf16 (E in {4,8,16}) -> experts [T,2] int32, weights [T,2] fp32 (bf16-representable). */
+int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* experts, float* weights, int64_t T, int H, int E,
+                         void* stream);
+
+/* Stable counting sort of the 2T (token,k) pairs by expert (replaces torch.where/.tolist() per expert, :859-870):
+ * counts [E] int32, row_token [2T] int32 (sorted row -> token), rows [T,2] int32 ((token,k) -> sorted row). */
+int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t* counts, int32_t* row_token, int32_t* rows,
+                   void* stream);
+
+/* out[t] = residual[t] + (weights[t,0]*y[rows[t,0]] + weights[t,1]*y[rows[t,1]]) with the bf16 roundings of :876, :880 and
+ * the decoder's residual add (:945).  y [2T,H] bf16, residual (nullable) / out [T,H] bf16 (out may alias residual). */
+int grit_moe_combine(const void* y, const int32_t* rows, const float* weights, const void* residual, void* out, int64_t T,
+                     int H, void* stream);
+
 /* ---- pooling + normalise: gritlm/gritlm.py:178-218,156-158; training/model.py:151-165 --------- */
 
 /* hidden [B,S,H] bf16; mask [B,S] int64 (attention mask); instr_len (nullable) [B] int32: the first

@@ -420,6 +420,120 @@ def check_encoder_golden(cfg_name):
     return _res(f"encoder[{cfg_name}] vs reference golden", ok, **out)
 
 
+# ---------------------------------------------------------------------------------------------- sparse MoE (Mixtral)
+def check_moe_router(T=777, H=512, E=8):
+    x = rnd((T, H), 61)
+    gw = O.bf16_round(np.random.default_rng(62).standard_normal((E, H)).astype(np.float32) * 0.5)
+    experts, weights, counts, row_token, rows = ops.moe_route(bf(x), bf(gw))
+    xb = f32(bf(x))
+    w_ref, sel_ref, logits = O.moe_router(xb, gw, 2, emulate_bf16=True)
+    sel, wt = experts.cpu().numpy(), f32(weights)
+    # a logit that lands within one bf16 ulp of a rounding boundary may round differently (different fp32 summation order):
+    # judge the selection only where the top-3 probabilities are separated by more than that
+    pr = np.sort(np.exp(logits - logits.max(1, keepdims=True)) / np.exp(logits - logits.max(1, keepdims=True)).sum(1, keepdims=True), axis=1)[:, ::-1]
+    clear = (pr[:, 1] - pr[:, 2] > 0.02 * pr[:, 1]) & (pr[:, 0] - pr[:, 1] > 0.02 * pr[:, 0])
+    same = (sel == sel_ref).all(1)
+    ok = bool(same[clear].all()) and clear.mean() > 0.8
+    werr = float(np.max(np.abs(wt - w_ref)[same])) if same.any() else 1.0
+    ok &= werr <= 2 ** -7                                   # one bf16 ulp of a weight < 1
+    # index: counts, stable sort, inverse map
+    flat = sel.reshape(-1)
+    cnt = counts.cpu().numpy()
+    ok &= np.array_equal(cnt, np.bincount(flat, minlength=E))
+    order = np.argsort(flat, kind="stable")
+    ok &= np.array_equal(row_token.cpu().numpy(), (order // 2).astype(np.int32))
+    inv = np.empty_like(order); inv[order] = np.arange(order.size)
+    ok &= np.array_equal(rows.cpu().numpy().reshape(-1), inv.astype(np.int32))
+    return _res(f"moe router+index [T={T},H={H},E={E}]", bool(ok), clear_frac=float(clear.mean()), agree_all=float(same.mean()), max_weight_err=werr)
+
+
+def check_gemm_grouped(counts=(300, 0, 17, 256, 513, 1, 0, 64), N=384, K=256, epi=EPI_STORE, seed=65):
+    """Grouped GEMM (device-side counts, gathered A rows) vs fp64 numpy per group; empty and tiny groups included."""
+    E, M = len(counts), int(sum(counts))
+    Tsrc = M // 2 + 5
+    a = rnd((Tsrc, K), seed)
+    w = rnd((E, N, K), seed + 1, 0.05)
+    rng = np.random.default_rng(seed + 2)
+    a_rows = rng.integers(0, Tsrc, size=M).astype(np.int32)
+    tcounts = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    ta, trows = bf(a), torch.from_numpy(a_rows).to(DEV)
+    if epi == EPI_SWIGLU:
+        I = N // 2
+        wi = torch.stack([swiglu_interleave(bf(w[e, :I]), bf(w[e, I:])) for e in range(E)]).contiguous()
+        out = f32(ops.gemm_nt_grouped(ta, wi, tcounts, M, epilogue=epi, a_rows=trows))
+    else:
+        out = f32(ops.gemm_nt_grouped(ta, bf(w), tcounts, M, a_rows=trows))
+    ref = np.zeros(out.shape, dtype=np.float64)
+    off = 0
+    for e, c in enumerate(counts):
+        xa = a[a_rows[off:off + c]].astype(np.float64)
+        full = xa @ w[e].astype(np.float64).T
+        if epi == EPI_SWIGLU:
+            g, u = O.bf16_round(full[:, :N // 2].astype(np.float32)), O.bf16_round(full[:, N // 2:].astype(np.float32))
+            full = (O.bf16_round(O.silu(g.astype(np.float64)).astype(np.float32)) * u).astype(np.float64)
+        ref[off:off + c] = full
+        off += c
+    scale = float(np.sqrt(np.mean(ref ** 2))) + 1e-9
+    err = float(np.max(np.abs(out - ref) / (1.2e-2 * np.abs(ref) + 1e-2 * scale)))
+    # un-gathered variant == gathered variant on pre-permuted rows
+    out2 = f32(ops.gemm_nt_grouped(bf(a[a_rows]), wi if epi == EPI_SWIGLU else bf(w), tcounts, M, epilogue=epi))
+    ok = err < 1.0 and np.array_equal(out, out2)
+    return _res(f"gemm_grouped[counts={list(counts)},N={N},K={K},epi={epi}]", bool(ok), max_err_over_tol=err)
+
+
+def check_moe_block(cfg_name="moe-tiny", T=333):
+    """Router -> index -> grouped w1|w3 + SwiGLU -> grouped w2 -> combine(+residual) vs the oracle's MixtralSparseMoeBlock on the
+    same bf16 input, token by token where the routing agrees."""
+    cfg = synth.CONFIGS[cfg_name]
+    w = synth.make_weights(cfg, 2)
+    eng = MistralEncoderEngine.from_state_dict(EncoderConfig.from_dict(cfg), {k: torch.from_numpy(v) for k, v in w.items()}, DEV)
+    H = cfg["hidden_size"]
+    x, res = rnd((T, H), 71), rnd((T, H), 72)
+    tx, h = bf(x), bf(res)
+    eng.record_routing = []
+    eng._mlp(eng.layers[0], tx, h, eng._workspace(T))
+    got = f32(h)
+    sel = np.sort(eng.record_routing[0].cpu().numpy(), axis=1)
+    ref, sel_ref = O.moe_block(f32(tx), w, "layers.0.block_sparse_moe.", 2, emulate_bf16=True)
+    ref = O.bf16_round(f32(bf(res)) + ref)
+    same = (sel == np.sort(sel_ref, axis=1)).all(1)
+    err = np.abs(got - ref)[same]
+    scale = float(np.sqrt(np.mean(ref ** 2)))
+    # bf16 outputs: the MoE term is a sum of two rounded products, the residual add rounds once more -> ~2 ulp of the result
+    ok = same.mean() > 0.97 and float(err.max()) < 3 * 2 ** -8 * float(np.abs(ref).max()) and float(np.sqrt(np.mean(err ** 2))) < 4e-3 * scale
+    return _res(f"moe block [{cfg_name},T={T}] vs oracle", bool(ok), routing_agree=float(same.mean()), max_abs_err=float(err.max()),
+                rms_err_over_rms=float(np.sqrt(np.mean(err ** 2))) / scale)
+
+
+def check_mixtral_golden(cfg_name="moe-tiny"):
+    """Mixtral bidirectional encode vs the fixture produced by the reference's modeling_mixtral_gritlm.py: hidden states no further
+    from the fp32 reference than the reference's own bf16 run, routing agreement, embeddings within 1e-4 cosine, packed == padded."""
+    g = np.load(os.path.join(GOLDEN, f"encoder_{cfg_name}.npz"))
+    eng, cfg, w = build_engine(cfg_name, int(g["seed_w"]))
+    ids, mask = g["input_ids"], g["attention_mask"]
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    eng.record_routing = []
+    h = f32(eng.forward(tid, tm))
+    routing = np.sort(np.stack([r.cpu().numpy() for r in eng.record_routing]).reshape(len(eng.layers), *ids.shape, 2), axis=-1)
+    eng.record_routing = None
+    valid = mask.astype(bool)
+    ref32, refb = g["last_hidden_state"], g["last_hidden_state_bf16"]
+    rel = lambda a, b: float(np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid]))
+    out = dict(rel_ours_vs_fp32=rel(h, ref32), rel_refbf16_vs_fp32=rel(refb, ref32))
+    agree = float((routing == np.sort(g["routing"], axis=-1)).all(-1)[:, valid].mean())
+    agree_ref = float((np.sort(g["routing_bf16"], axis=-1) == np.sort(g["routing"], axis=-1)).all(-1)[:, valid].mean())
+    out["routing_agree_with_fp32_ref"], out["routing_agree_of_bf16_ref"] = agree, agree_ref
+    ok = out["rel_ours_vs_fp32"] < 1.5 * out["rel_refbf16_vs_fp32"] + 2e-3 and not np.isnan(h).any() and agree > agree_ref - 0.02
+    for method in ("mean", "weightedmean"):
+        e = f32(eng.encode_pooled(tid, tm, method, True, packed=False))
+        ep = f32(eng.encode_pooled(tid, tm, method, True, packed=True))
+        c32 = float(np.max(1 - np.sum(e * g[f"emb_{method}"], axis=1)))
+        cref = float(np.max(1 - np.sum(g[f"emb_{method}_bf16"] * g[f"emb_{method}"], axis=1)))     # the bf16 reference's own distance
+        out[f"{method}_1-cos"] = c32; out[f"{method}_1-cos_of_bf16ref"] = cref
+        ok &= c32 < max(1e-4, 2 * cref) and np.array_equal(e, ep)
+    return _res(f"mixtral encoder[{cfg_name}] vs reference golden", bool(ok), **out)
+
+
 def check_encoder_vs_oracle_bf16(cfg_name="tiny", B=3, S=130):
     """Different shape than the golden (S not a multiple of 64), against the bf16-emulating oracle."""
     eng, cfg, w = build_engine(cfg_name, 5)
@@ -463,6 +577,30 @@ def check_gritlm_native_encode():
         m.pooling(torch.randn((2, 5, 256), device="cuda").to(torch.bfloat16), mask)
         ok &= mask.cpu().tolist() == [[1, 2, 3, 4, 5], [1, 2, 3, 0, 0]]        # in-place side effect kept (:211)
     return _res("GritLM.encode native vs reference GritLM.encode goldens", ok, **out)
+
+
+def check_gritlm_native_mixtral():
+    """gritlm_amd.GritLM on a (tiny) Mixtral checkpoint directory: model_type 'mixtral' binds the native MoE engine (from the
+    installed transformers' fused expert parameters) and encode() matches the oracle on the same tokens."""
+    import tempfile
+    from gritlm_amd import GritLM
+    sents = synth.make_sentences(10, seed=3)
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mixtral_dir(os.path.join(td, "x16"), "moe-tiny", 0, "bfloat16")
+        m = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16)
+        ok &= m.engine is not None and m.engine.cfg.num_local_experts == 8
+        e = m.encode(sents, batch_size=4, max_length=64)
+        tok = m.tokenizer(sents, padding=True, truncation=True, return_tensors="np", max_length=64, add_special_tokens=True)
+        ids, mask = tok["input_ids"].astype(np.int64), tok["attention_mask"].astype(np.int64)
+    cfg = synth.CONFIGS["moe-tiny"]
+    w = synth.make_weights(cfg, 0)
+    ref = O.encode_core(w, cfg, ids, mask, "mean", True)
+    refb = O.l2_normalize(O.pooling(O.mistral_encode(w, cfg, ids, mask, emulate_bf16=True), mask, "mean"))
+    out["1-cos_vs_fp32_oracle"] = float(np.max(1 - np.sum(e * ref, axis=1)))
+    out["1-cos_of_bf16_oracle"] = float(np.max(1 - np.sum(refb * ref, axis=1)))
+    ok &= e.shape == (10, 256) and out["1-cos_vs_fp32_oracle"] < max(1e-4, 2 * out["1-cos_of_bf16_oracle"])
+    return _res("GritLM.encode native on a Mixtral directory vs oracle", bool(ok), **out)
 
 
 _NAMES = ["layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight", "norm.weight", "layers.0.input_layernorm.weight",
@@ -817,12 +955,20 @@ ALL_CHECKS = [
     ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
+    ("moe_router", check_moe_router, {}),
+    ("moe_router_e4_4096", check_moe_router, dict(T=130, H=4096, E=4)),
+    ("gemm_grouped", check_gemm_grouped, {}),
+    ("gemm_grouped_swiglu", check_gemm_grouped, dict(counts=(70, 5, 0, 260), N=512, K=128, epi=EPI_SWIGLU)),
+    ("moe_block", check_moe_block, {}),
+    ("mixtral_tiny", check_mixtral_golden, dict(cfg_name="moe-tiny")),
+    ("mixtral_gqa", check_mixtral_golden, dict(cfg_name="moe-gqa")),
     ("edge_cases", check_edge_cases, {}),
     ("long_sequence_4096", check_long_sequence, {}),
     ("full_shape_properties", check_full_shape_properties, {}),
     ("packed_encode", check_packed_encode, {}),
     ("packed_encode_tiny", check_packed_encode, dict(cfg_name="tiny", B=3, S=260)),
     ("gritlm_native_encode", check_gritlm_native_encode, {}),
+    ("gritlm_native_mixtral", check_gritlm_native_mixtral, {}),
     ("get_cache", check_get_cache, {}),
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),

@@ -162,6 +162,35 @@ def build_mistral_dir(path: str, cfg_name: str = "tiny", seed: int = 0, dtype="f
     return path
 
 
+def build_mixtral_dir(path: str, cfg_name: str = "moe-tiny", seed: int = 0, dtype="float32") -> str:
+    """MixtralForCausalLM with the synthetic weights of make_weights (reference names block_sparse_moe.experts.N.w1/w2/w3 mapped to the
+    installed transformers' fused gate_up_proj / down_proj parameters) + tokenizer, saved to ``path``."""
+    import torch
+    from transformers import MixtralForCausalLM
+    cfg = CONFIGS[cfg_name]
+    model = MixtralForCausalLM(hf_config(cfg))
+    w = make_weights(cfg, seed)
+    E = cfg["num_local_experts"]
+    sd = {}
+    for k, v in w.items():
+        if "block_sparse_moe" not in k:
+            sd["model." + k] = torch.from_numpy(v)
+    for li in range(cfg["num_hidden_layers"]):
+        p = f"layers.{li}.block_sparse_moe."
+        sd[f"model.layers.{li}.mlp.gate.weight"] = torch.from_numpy(w[p + "gate.weight"])
+        sd[f"model.layers.{li}.mlp.experts.gate_up_proj"] = torch.from_numpy(np.stack(
+            [np.concatenate([w[f"{p}experts.{e}.w1.weight"], w[f"{p}experts.{e}.w3.weight"]], axis=0) for e in range(E)]))
+        sd[f"model.layers.{li}.mlp.experts.down_proj"] = torch.from_numpy(np.stack([w[f"{p}experts.{e}.w2.weight"] for e in range(E)]))
+    rng = np.random.default_rng(seed + 99)
+    sd["lm_head.weight"] = torch.from_numpy(_bf16_round(rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"]), dtype=np.float32) * 0.02))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    model = model.to(getattr(torch, dtype))
+    model.save_pretrained(path)
+    make_tokenizer(path)
+    return path
+
+
 def build_gptneo_dir(path: str, seed: int = 0) -> str:
     """Tiny GPT-Neo (architecture of SGPT-125M-weightedmean, README.md:38; BASELINE.json configs[0] plumbing case)."""
     import torch
