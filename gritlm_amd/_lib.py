@@ -27,11 +27,13 @@ _SIGNATURES = {
     "grit_rope_qk_inplace": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _l, _i, _p]),
     "grit_rope_qk_inplace_pos": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _l, _i, _p]),
     "grit_attn_bidir_varlen_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_causal_varlen_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_pool_norm_varlen_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
     "grit_swiglu_block": (_i, []),
     "grit_mask_pack": (_i, [_p, _p, _i, _i, _p]),
     "grit_attn_bidir_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_causal_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_pool_norm_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_pool_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt_grouped": (_i, [_p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _i, _p]),
@@ -46,7 +48,9 @@ _SIGNATURES = {
     "grit_swiglu_fwd": (_i, [_p, _p, _l, _i, _p]),
     "grit_swiglu_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
     "grit_attn_bidir_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_causal_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_attn_bidir_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_causal_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _i, _l, _l, _f, _p]),
     "grit_embed_scatter_add": (_i, [_p, _p, _p, _l, _i, _l, _p]),
     "grit_accum_bf16_from_f32": (_i, [_p, _p, _l, _p]),
 }

@@ -30,7 +30,9 @@ __device__ __forceinline__ uint32_t hi16(uint32_t w) { return w >> 16; }
 
 // VARLEN: sequences are packed back to back (no padding rows at all); cu_seqlens[b] is the first row of sequence b and
 // every key of a sequence is valid, so the key bitmask is synthesised from the length.
-template <bool VARLEN>
+// CAUSAL: additionally key <= query (the generative branch of unified training, MistralSdpaAttention with is_causal=True,
+// modeling_mistral_gritlm.py:690-698 / :1017-1036); tiles past the workgroup's last query are skipped.
+template <bool VARLEN, bool CAUSAL>
 __global__ void __launch_bounds__(256, 2)
 attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                  uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride,
@@ -57,6 +59,11 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
     for (int w = W - 1; w >= 0; --w)
       if (bits[w] != 0) { ntiles = w + 1; break; }
+  }
+
+  if constexpr (CAUSAL) {
+    const int lim = 2 * qb + 2;                 // tiles holding keys <= the last query of this workgroup
+    ntiles = ntiles < lim ? ntiles : lim;
   }
 
   const uint16_t* qbase = qkv + (int64_t)h * ATT_D;
@@ -159,8 +166,16 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     } else {
       word = bits[t];
     }
+    bool fast = (word == ~0ull);
+    if constexpr (CAUSAL) {
+      if (t * ATT_KB + ATT_KB - 1 > qb * ATT_QB + wave * 32) {   // tile reaches past this wave's first query: per-lane bound
+        const int n = q_row - t * ATT_KB + 1;                    // keys of this tile the lane's query may see
+        word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+        fast = false;
+      }
+    }
     float mx = -INFINITY;
-    if (word == ~0ull) {          // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
+    if (fast) {                   // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -248,36 +263,63 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
 using namespace grit;
 
-extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
-                                   int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  GRIT_REQUIRE(qkv && key_bits && out, GRIT_E_BADARG, "grit_attn_bidir_fwd: null pointer");
-  GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_fwd: bad sizes");
-  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_fwd: head_dim=%d (only 128 is built)", d);
-  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_fwd: nq=%d not a multiple of nkv=%d", nq, nkv);
+static int attn_fwd_padded(const char* name, bool causal, const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
+                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(qkv && key_bits && out, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
+  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
   GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 4 == 0 && out_stride >= (int64_t)nq * d,
-               GRIT_E_BADARG, "grit_attn_bidir_fwd: bad strides");
-  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "grit_attn_bidir_fwd: pointers must be 16-byte aligned");
-  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_fwd: grid too large");
+               GRIT_E_BADARG, "%s: bad strides", name);
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "%s: grid too large", name);
   const dim3 grid((unsigned)((S + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
-  hipLaunchKernelGGL(attn_bidir_fwd_k<false>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits,
-                     (const int32_t*)nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
-  GRIT_CHECK_LAUNCH("grit_attn_bidir_fwd");
+  if (causal)
+    hipLaunchKernelGGL((attn_bidir_fwd_k<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits,
+                       (const int32_t*)nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+  else
+    hipLaunchKernelGGL((attn_bidir_fwd_k<false, false>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits,
+                       (const int32_t*)nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+  GRIT_CHECK_LAUNCH(name);
   return GRIT_OK;
 }
 
+static int attn_fwd_varlen(const char* name, bool causal, const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len,
+                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(qkv && cu_seqlens && out, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && max_len > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
+  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 4 == 0 && out_stride >= (int64_t)nq * d,
+               GRIT_E_BADARG, "%s: bad strides", name);
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "%s: grid too large", name);
+  const dim3 grid((unsigned)((max_len + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
+  if (causal)
+    hipLaunchKernelGGL((attn_bidir_fwd_k<true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (const uint64_t*)nullptr,
+                       cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+  else
+    hipLaunchKernelGGL((attn_bidir_fwd_k<true, false>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (const uint64_t*)nullptr,
+                       cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+  GRIT_CHECK_LAUNCH(name);
+  return GRIT_OK;
+}
+
+extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                   int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_padded("grit_attn_bidir_fwd", false, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+extern "C" int grit_attn_causal_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_padded("grit_attn_causal_fwd", true, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
 extern "C" int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
                                           int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  GRIT_REQUIRE(qkv && cu_seqlens && out, GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: null pointer");
-  GRIT_REQUIRE(B > 0 && max_len > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: bad sizes");
-  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_fwd: head_dim=%d (only 128 is built)", d);
-  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: nq=%d not a multiple of nkv=%d", nq, nkv);
-  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 4 == 0 && out_stride >= (int64_t)nq * d,
-               GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: bad strides");
-  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "grit_attn_bidir_varlen_fwd: pointers must be 16-byte aligned");
-  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_fwd: grid too large");
-  const dim3 grid((unsigned)((max_len + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
-  hipLaunchKernelGGL(attn_bidir_fwd_k<true>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (const uint64_t*)nullptr,
-                     cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
-  GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_fwd");
-  return GRIT_OK;
+  return attn_fwd_varlen("grit_attn_bidir_varlen_fwd", false, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream);
+}
+extern "C" int grit_attn_causal_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                           int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_varlen("grit_attn_causal_varlen_fwd", true, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream);
 }

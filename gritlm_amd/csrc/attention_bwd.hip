@@ -102,7 +102,7 @@ template <bool VARLEN>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                 const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
-                uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale) {
+                uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_rm = smem; char* q_tr = q_rm + AB_RM; char* d_rm = q_tr + AB_TR; char* d_tr = d_rm + AB_RM;
   float* st = reinterpret_cast<float*>(d_tr + AB_TR);  // [64] lse (log2 domain), [64] delta
@@ -152,7 +152,7 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     const float* lrow = VARLEN ? lse + row0 * nq + h : lse + ((int64_t)b * nq + h) * S;
     const float* drow = VARLEN ? delta + row0 * nq + h : delta + ((int64_t)b * nq + h) * S;
     const int64_t qs = VARLEN ? nq : 1;
-    for (int qt = 0; qt < nqt; ++qt) {
+    for (int qt = causal ? 2 * kblk : 0; qt < nqt; ++qt) {   // causal: query tiles before this key block see none of its keys
       stage_pairs(qbase, qkv_stride, qt * 64, S, q_rm, q_tr);
       stage_pairs(dobase, out_stride, qt * 64, S, d_rm, d_tr);
       if (tid < 64) {
@@ -180,7 +180,8 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * gq + e;
-            const float p = key_ok ? __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[e]) : 0.f;
+            const bool seen = key_ok && (!causal || key <= qt * 64 + qb * 32 + 8 * gq + 4 * hi + e);
+            const float p = seen ? __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[e]) : 0.f;
             s[r] = p;
             dp[r] = p * (dp[r] - dl[e]);
           }
@@ -218,7 +219,7 @@ template <bool VARLEN>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
               const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
-              uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale) {
+              uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem; char* k_tr = k_rm + AB_RM; char* v_rm = k_tr + AB_TR;
 
@@ -240,6 +241,7 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
     for (int w = W - 1; w >= 0; --w)
       if (bits[w] != 0) { ntiles = w + 1; break; }
   }
+  if (causal) ntiles = ntiles < 2 * qblk + 2 ? ntiles : 2 * qblk + 2;
   const int q = qblk * 128 + wave * 32 + (lane & 31);
   const int q_ld = q < S ? q : S - 1;
   const float scale_log2 = scale * 1.4426950408889634f;
@@ -275,6 +277,10 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
       word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     } else {
       word = bits[t];
+    }
+    if (causal) {
+      const int n = q - t * 64 + 1;
+      word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
     }
     const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
 #pragma unroll
@@ -319,7 +325,7 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
 
 using namespace grit;
 
-static int attn_bwd_launch(bool varlen, const void* qkv, const uint64_t* key_bits, const int32_t* cu, const void* out, const void* dout,
+static int attn_bwd_launch(bool varlen, int causal, const void* qkv, const uint64_t* key_bits, const int32_t* cu, const void* out, const void* dout,
                            const float* lse, float* delta, void* dqkv, int B, int S_or_maxlen, int64_t T, int nq, int nkv,
                            int64_t qkv_stride, int64_t out_stride, float scale, hipStream_t st) {
   const int64_t items = T * nq;
@@ -338,25 +344,25 @@ static int attn_bwd_launch(bool varlen, const void* qkv, const uint64_t* key_bit
   const unsigned nblk = (unsigned)((S_or_maxlen + 127) / 128);
   if (varlen) {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<true>, dim3(nblk, (unsigned)nkv, (unsigned)B), dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dkdv");
     hipLaunchKernelGGL(attn_bwd_dq_k<true>, dim3(nblk, (unsigned)nq, (unsigned)B), dim3(256), lds_q, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dq");
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<false>, dim3(nblk, (unsigned)nkv, (unsigned)B), dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dkdv");
     hipLaunchKernelGGL(attn_bwd_dq_k<false>, dim3(nblk, (unsigned)nq, (unsigned)B), dim3(256), lds_q, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dq");
   }
   return GRIT_OK;
 }
 
-extern "C" int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
-                                   float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
-                                   int64_t out_stride, float scale, void* stream) {
+static int attn_bwd_padded(int causal, const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+                           float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
+                           int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && key_bits && out && dout && lse && delta && dqkv, GRIT_E_BADARG, "grit_attn_bidir_bwd: null pointer");
   GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_bwd: bad sizes");
   GRIT_REQUIRE(d == AB_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: head_dim=%d (only 128 is built)", d);
@@ -366,13 +372,23 @@ extern "C" int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, co
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
                "grit_attn_bidir_bwd: pointers must be 16-byte aligned");
   GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: grid too large");
-  return attn_bwd_launch(false, qkv, key_bits, nullptr, out, dout, lse, delta, dqkv, B, S, (int64_t)B * S, nq, nkv, qkv_stride, out_stride,
-                         scale, (hipStream_t)stream);
+  return attn_bwd_launch(false, causal, qkv, key_bits, nullptr, out, dout, lse, delta, dqkv, B, S, (int64_t)B * S, nq, nkv, qkv_stride,
+                         out_stride, scale, (hipStream_t)stream);
+}
+extern "C" int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+                                   float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
+                                   int64_t out_stride, float scale, void* stream) {
+  return attn_bwd_padded(0, qkv, key_bits, out, dout, lse, delta, dqkv, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+extern "C" int grit_attn_causal_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+                                    float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
+                                    int64_t out_stride, float scale, void* stream) {
+  return attn_bwd_padded(1, qkv, key_bits, out, dout, lse, delta, dqkv, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }
 
-extern "C" int grit_attn_bidir_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
-                                          float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
-                                          int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+static int attn_bwd_varlen(int causal, const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+                           float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
+                           int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && cu_seqlens && out && dout && lse && delta && dqkv, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: null pointer");
   GRIT_REQUIRE(B > 0 && max_len > 0 && T > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: bad sizes");
   GRIT_REQUIRE(d == AB_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: head_dim=%d (only 128 is built)", d);
@@ -382,6 +398,16 @@ extern "C" int grit_attn_bidir_varlen_bwd(const void* qkv, const int32_t* cu_seq
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
                "grit_attn_bidir_varlen_bwd: pointers must be 16-byte aligned");
   GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: grid too large");
-  return attn_bwd_launch(true, qkv, nullptr, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, qkv_stride, out_stride, scale,
-                         (hipStream_t)stream);
+  return attn_bwd_launch(true, causal, qkv, nullptr, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, qkv_stride, out_stride,
+                         scale, (hipStream_t)stream);
+}
+extern "C" int grit_attn_bidir_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+                                          float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
+                                          int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_bwd_varlen(0, qkv, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+extern "C" int grit_attn_causal_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+                                           float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
+                                           int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_bwd_varlen(1, qkv, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }

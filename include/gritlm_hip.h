@@ -129,6 +129,13 @@ int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t* counts, in
 int grit_moe_combine(const void* y, const int32_t* rows, const float* weights, const void* residual, void* out, int64_t T,
                      int H, void* stream);
 
+/* Causal variants (key <= query in addition to the key-padding mask): the generative branch of unified training
+ * (MistralSdpaAttention with is_causal=True; causal mask :1005-1031).  Same layouts as the bidirectional entry points. */
+int grit_attn_causal_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
+                         int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+int grit_attn_causal_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+
 /* ---- pooling + normalise: gritlm/gritlm.py:178-218,156-158; training/model.py:151-165 --------- */
 
 /* hidden [B,S,H] bf16; mask [B,S] int64 (attention mask); instr_len (nullable) [B] int32: the first
@@ -199,6 +206,13 @@ int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, const void* o
 int grit_attn_bidir_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
                                float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
                                int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+
+int grit_attn_causal_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+                         float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
+                         int64_t out_stride, float scale, void* stream);
+int grit_attn_causal_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+                                float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
+                                int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
 
 /* embedding backward: dtable[ids[t], :] += dh[t, :]  (dtable fp32 [V,H], fp32 atomics) */
 int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream);

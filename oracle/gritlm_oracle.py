@@ -96,8 +96,9 @@ def apply_rope(x: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
     return x * cos[None, None] + rotate_half(x) * sin[None, None]
 
 
-def attention_bidirectional(q, k, v, key_mask, acc_dtype=F64):
-    """Attention core with is_causal=False and a key-padding mask.
+def attention_bidirectional(q, k, v, key_mask, acc_dtype=F64, causal=False):
+    """Attention core with is_causal=False and a key-padding mask (``causal=True``: additionally key <= query, the mask of
+    `_prepare_4d_causal_attention_mask(_for_sdpa)`, :1005-1016 / :1021-1031 -- the generative branch).
 
     MistralSdpaAttention.forward scripts/modeling_mistral_gritlm.py:627-705
     (repeat_kv :182-191, SDPA :690-698) with the additive mask of
@@ -116,6 +117,8 @@ def attention_bidirectional(q, k, v, key_mask, acc_dtype=F64):
     if key_mask is not None:
         neg = np.where(key_mask.astype(bool), 0.0, -np.inf).astype(acc_dtype)[:, None, None, :]
         scores = scores + neg
+    if causal:
+        scores = scores + np.where(np.tril(np.ones((S, S), dtype=bool)), 0.0, -np.inf).astype(acc_dtype)[None, None]
     scores = scores - scores.max(axis=-1, keepdims=True)
     p = np.exp(scores)
     p = p / p.sum(axis=-1, keepdims=True)
@@ -135,7 +138,7 @@ def mlp(x, w_gate, w_up, w_down):
 
 
 def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_mask: np.ndarray | None,
-                   emulate_bf16: bool = False, return_layers: bool = False, acc_dtype=F64):
+                   emulate_bf16: bool = False, return_layers: bool = False, acc_dtype=F64, causal: bool = False):
     """MistralModel.forward with is_causal=False, scripts/modeling_mistral_gritlm.py:936-1096.
 
     ``weights`` uses the HF state_dict names of MistralModel (``embed_tokens.weight``,
@@ -169,7 +172,7 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
         k = k.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
         v = v.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
         q = rnd(apply_rope(q, cos, sin)); k = rnd(apply_rope(k, cos, sin))             # :666-668
-        a = rnd(attention_bidirectional(q, k, v, attention_mask, acc_dtype))                      # :690-698
+        a = rnd(attention_bidirectional(q, k, v, attention_mask, acc_dtype, causal))              # :690-698
         a = rnd(a @ weights[p + "self_attn.o_proj.weight"].T)                          # :703
         h = rnd(res + a)                                                               # :769
         res = h
@@ -384,7 +387,7 @@ def swiglu_backward(g, u, dact):
     return (d * u * s * (1.0 + g * (1.0 - s))).astype(F32), (d * g * s).astype(F32)
 
 
-def attention_bidirectional_backward(q, k, v, key_mask, dout):
+def attention_bidirectional_backward(q, k, v, key_mask, dout, causal=False):
     """Backward of attention_bidirectional.  q [B,Hq,S,d], k,v [B,Hkv,S,d], dout [B,S,Hq*d]
     -> dq [B,Hq,S,d], dk, dv [B,Hkv,S,d] (GQA: kv gradients summed over the group)."""
     B, Hq, S, d = q.shape
@@ -396,6 +399,8 @@ def attention_bidirectional_backward(q, k, v, key_mask, dout):
     sc = np.matmul(q64, kk.transpose(0, 1, 3, 2)) * scale
     if key_mask is not None:
         sc = sc + np.where(key_mask.astype(bool), 0.0, -np.inf)[:, None, None, :]
+    if causal:
+        sc = sc + np.where(np.tril(np.ones((S, S), dtype=bool)), 0.0, -np.inf)[None, None]
     sc = sc - sc.max(-1, keepdims=True)
     p = np.exp(sc); p /= p.sum(-1, keepdims=True)
     do = dout.astype(F64).reshape(B, S, Hq, d).transpose(0, 2, 1, 3)
