@@ -379,6 +379,25 @@ def attn_bidir_varlen_bwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: 
     return dqkv
 
 
+def ce_fwd(logits: torch.Tensor, labels: torch.Tensor):
+    """(lse [T], loss_row [T]) fp32 of bf16 logits [T,V] against int64 labels (-100 ignored)."""
+    T, V = logits.shape
+    lse = torch.empty((T,), dtype=F32, device=logits.device)
+    loss_row = torch.empty((T,), dtype=F32, device=logits.device)
+    check(_lib.load().grit_ce_fwd(_chk2d(logits, BF16, "logits"), logits.stride(0), _chk(labels, I64, "labels"), lse.data_ptr(),
+                                  loss_row.data_ptr(), T, V, _stream()), "grit_ce_fwd")
+    return lse, loss_row
+
+
+def ce_bwd_(logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, scale: float, dev_scale: torch.Tensor | None = None):
+    """In place: logits <- (softmax - onehot) * scale * dev_scale (bf16)."""
+    T, V = logits.shape
+    check(_lib.load().grit_ce_bwd(_chk2d(logits, BF16, "logits"), logits.stride(0), _chk(labels, I64, "labels"), _chk(lse, F32, "lse"),
+                                  0 if dev_scale is None else _chk(dev_scale, F32, "dev_scale"), float(scale), T, V, _stream()),
+          "grit_ce_bwd")
+    return logits
+
+
 def embed_scatter_add(dh: torch.Tensor, ids: torch.Tensor, dtable: torch.Tensor):
     V, H = dtable.shape
     T = ids.numel()

@@ -1,4 +1,4 @@
-"""Host-side data path of the embedding objective: (query, pos, negs) sampling and the GRIT prompt format.
+"""Host-side data path: (query, pos, negs) sampling, generative (instruction, response, ...) turns and the GRIT prompt format.
 
 Out of the accelerated scope -- string / tokeniser work on the host.  It exists so that
 ``python -m gritlm_amd.training.run`` is self-contained; the batch layout it emits is the one the reference's collator
@@ -16,6 +16,7 @@ from dataclasses import dataclass
 import torch
 
 BASE_BOS, USER_BOS, USER_EOS, EMBED_BOS, EMBED_EOS = "<s>", "<|user|>\n", "", "\n<|embed|>\n", ""
+TURN_SEP, ASSISTANT_BOS, ASSISTANT_EOS = "\n", "\n<|assistant|>\n", "</s>"        # gritlm/training/run.py:18-30
 
 
 def load_embedding_rows(path: str, limit: int | None = None) -> list[dict]:
@@ -27,6 +28,50 @@ def load_embedding_rows(path: str, limit: int | None = None) -> list[dict]:
         part = [r for r in part if "query" in r]
         rows += part[:limit] if limit else part
     return rows
+
+
+def load_generative_rows(path: str, limit: int | None = None) -> list:
+    """Rows with a "text" field: a string, or [instruction, response, instruction, response, ...] (run.py:166-179)."""
+    files = sorted(os.path.join(path, f) for f in os.listdir(path)) if os.path.isdir(path) else [path]
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            part = [json.loads(line) for line in fh if line.strip()]
+        part = [r["text"] for r in part if "text" in r]
+        rows += part[:limit] if limit else part
+    return rows
+
+
+@dataclass
+class GenerativeCollator:
+    """The generative half of the reference's CustomCollator (gritlm/training/data.py:214-228, :248-282): chat formatting of
+    multi-turn samples, labels = input_ids with padding (except position 0) and every instruction turn set to -100
+    (``prefixlm``: every turn before the last assistant utterance, :279)."""
+    tokenizer: object
+    generative_max_len: int = 128
+    prefixlm: bool = False
+
+    def __call__(self, samples):
+        tok = self.tokenizer
+        lens = None
+        if isinstance(samples[0], (tuple, list)):
+            lens = [[len(tok.tokenize((BASE_BOS if i == 0 else "") + USER_BOS + z + USER_EOS + ASSISTANT_BOS)) if i % 2 == 0
+                     else len(tok.tokenize(z.strip() + ASSISTANT_EOS)) for i, z in enumerate(f[:-1])] for f in samples]
+            samples = [BASE_BOS + TURN_SEP.join(USER_BOS + f[i] + USER_EOS + ASSISTANT_BOS + f[i + 1].strip() + ASSISTANT_EOS
+                                                for i in range(0, len(f), 2)) for f in samples]
+        feats = dict(tok(samples, padding=True, truncation=True, max_length=self.generative_max_len, return_tensors="pt",
+                         add_special_tokens=False))
+        labels = feats["input_ids"].clone()
+        labels[:, 1:][labels[:, 1:] == tok.pad_token_id] = -100          # position 0 may legitimately be the pad (= bos) token
+        if lens:
+            for i, turn_lens in enumerate(lens):
+                cur = 0
+                for j, l in enumerate(turn_lens):
+                    if (j % 2 == 0) or self.prefixlm:
+                        labels[i, cur:cur + l] = -100
+                    cur += l
+        feats["labels"] = labels
+        return feats
 
 
 class EmbeddingDataset(torch.utils.data.Dataset):

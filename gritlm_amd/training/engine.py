@@ -39,12 +39,12 @@ class _Geometry:
     """Row layout of one chunk.  Padded: T = B*S rows, key-padding bitmask.  Packed: only the real tokens of a right-padded
     batch (rows of sequence b at [cu[b], cu[b+1])), per-row RoPE positions -- GEMMs, norms and attention never see padding
     (the reference computes every padded position)."""
-    __slots__ = ("packed", "B", "S", "T", "bits", "cu", "pos", "max_len", "keep")
+    __slots__ = ("packed", "B", "S", "T", "bits", "cu", "pos", "max_len", "keep", "causal")
 
     @staticmethod
     def padded(mask: torch.Tensor):
         g = _Geometry()
-        g.packed, (g.B, g.S) = False, mask.shape
+        g.packed, (g.B, g.S), g.causal = False, mask.shape, False
         g.T = g.B * g.S
         g.bits = ops.mask_pack(mask)
         g.cu = g.pos = g.keep = None
@@ -64,7 +64,7 @@ class _Geometry:
         if not ok:
             return None
         g = _Geometry()
-        g.packed, g.B, g.S, g.T, g.max_len, g.keep, g.bits = True, B, S, int(T), int(max_len), keep, None
+        g.packed, g.B, g.S, g.T, g.max_len, g.keep, g.bits, g.causal = True, B, S, int(T), int(max_len), keep, None, False
         g.cu = torch.zeros((B + 1,), dtype=torch.int32, device=mask.device)
         g.cu[1:] = torch.cumsum(lens, dim=0)
         g.pos = ar.to(torch.int32).unsqueeze(0).expand(B, S)[keep].contiguous()
@@ -72,7 +72,12 @@ class _Geometry:
 
 
 class MistralTrainEngine:
-    def __init__(self, backbone: torch.nn.Module, hf_config, device):
+    def __init__(self, backbone: torch.nn.Module, hf_config, device, lm_head: torch.nn.Module | None = None):
+        """``lm_head`` (optional, nn.Linear [V,H] without bias): enables the generative branch (forward_lm / backward_lm)."""
+        self.lm_head = lm_head.weight if lm_head is not None else None
+        if self.lm_head is not None and self.lm_head.dtype != BF16:
+            raise RuntimeError("MistralTrainEngine: lm_head must be bfloat16")
+        self.sliding_window = getattr(hf_config, "sliding_window", None)
         self.cfg = hf_config if isinstance(hf_config, EncoderConfig) else EncoderConfig.from_hf(hf_config)
         self.cfg.check_supported()
         self.device = torch.device(device)
@@ -191,8 +196,9 @@ class MistralTrainEngine:
         return t
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool, packed: bool = False):
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool, packed: bool = False, causal: bool = False):
         """Returns (last_hidden_state, SavedForward | None).  Padded layout: last_hidden_state is [B,S,H] bf16.
+        ``causal``: causal attention (the generative branch, 'cc' in the reference's attn string) instead of bidirectional.
         ``packed=True`` (and a right-padded mask without empty rows): [T_real,H] rows of the real tokens only; the geometry is in
         ``SavedForward.geom`` (returned even with ``save=False`` so the caller can pool)."""
         c = self.cfg
@@ -202,6 +208,9 @@ class MistralTrainEngine:
         geom = _Geometry.from_mask(mask) if packed else None
         if geom is None:
             geom = _Geometry.padded(mask)
+        geom.causal = bool(causal)
+        if causal and self.sliding_window is not None and S > self.sliding_window:
+            raise NotImplementedError(f"causal attention with sliding_window={self.sliding_window} < sequence length {S}")
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         ids = ids[geom.keep].contiguous() if geom.packed else ids.view(-1)
         T = geom.T
@@ -221,11 +230,11 @@ class MistralTrainEngine:
             if geom.packed:
                 lse = torch.empty((T, nq), dtype=F32, device=dev) if save else None
                 ops.rope_qk_pos_(qkv, cos, sin, geom.pos, nq, nkv, d)
-                ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse)
+                ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
             else:
                 lse = torch.empty((B, nq, S), dtype=F32, device=dev) if save else None
                 ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
-                ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse)
+                ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
             h_mid = mk(H) if save else h
             ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h_mid, L.ln2.data, eps, out=x2)
@@ -261,6 +270,48 @@ class MistralTrainEngine:
             dh = ops.pool_norm_bwd(reps, d_reps, inv, saved.mask, method, normalize, saved.S, instr_len)
         self.backward(saved, dh, on_layer_done=on_layer_done)
 
+    # ------------------------------------------------------------------ generative branch
+    def forward_lm(self, input_ids, attention_mask, labels, loss_gen_type: str = "mixed", loss_gen_factor: float = 1.0, save: bool = True,
+                   packed: bool = True):
+        """NextTokenLoss(labels, lm_head(model(ids, causal))) -- gritlm/training/model.py:66-107,185-194 -- as a device scalar,
+        plus the state backward_lm needs.  'mixed': mean over the non-ignored shifted tokens of this call; 'token': sum / batch."""
+        if self.lm_head is None:
+            raise RuntimeError("forward_lm: the engine was built without an lm_head")
+        if loss_gen_type not in ("mixed", "token"):
+            raise ValueError(f"Invalid loss_gen_type: {loss_gen_type}")
+        B, S = input_ids.shape
+        hidden, saved = self.forward(input_ids, attention_mask, save=save, packed=packed, causal=True)
+        geom = saved.geom
+        x = hidden if geom.packed else hidden.view(B * S, -1)
+        # "tokens < n predict n" (:94-96): row (b, s) is scored against labels[b, s+1]; the last position of a row has no target
+        lab = labels.to(device=self.device, dtype=torch.int64)
+        shifted = torch.full_like(lab, -100)
+        shifted[:, :-1] = lab[:, 1:]
+        shifted = shifted[geom.keep].contiguous() if geom.packed else shifted.reshape(-1).contiguous()
+        logits = ops.gemm_nt(x, self.lm_head.data)                                  # [T, V] bf16
+        lse, loss_row = ops.ce_fwd(logits, shifted)
+        n_valid = (shifted >= 0).sum().to(F32)
+        if loss_gen_type == "mixed":
+            inv = 1.0 / n_valid                                                     # CrossEntropyLoss(reduction="mean")
+        else:
+            inv = torch.full((), 1.0 / B, dtype=F32, device=self.device)            # reduction="sum" / labels.size(0)
+        loss = loss_row.sum() * inv * loss_gen_factor
+        state = (saved, x, logits, shifted, lse, inv.reshape(1).contiguous(), float(loss_gen_factor)) if save else None
+        return loss, state
+
+    def backward_lm(self, state, d_loss: torch.Tensor | float = 1.0, on_layer_done=None):
+        """Accumulate the parameter gradients (backbone + lm_head) of d_loss * loss."""
+        saved, x, logits, shifted, lse, inv, factor = state
+        dev_scale = inv * d_loss if torch.is_tensor(d_loss) else inv * float(d_loss)
+        dlogits = ops.ce_bwd_(logits, shifted, lse, factor, dev_scale.to(F32).reshape(1).contiguous())
+        self.prepare_grads()
+        if self.lm_head.grad is None:
+            self.lm_head.grad = torch.zeros_like(self.lm_head)
+        dx = ops.gemm_nt(dlogits, ops.transpose(self.lm_head.data))                                     # [T,H] = dlogits @ W_lm
+        g = self.lm_head.grad
+        ops.gemm_nt(self._transposed_act(dlogits, "dlogits"), self._transposed_act(x, "x"), out=g, epilogue=EPI_RESIDUAL, residual=g)
+        self.backward(saved, dx, on_layer_done=on_layer_done)
+
     # ------------------------------------------------------------------ backward
     def backward(self, saved: SavedForward, d_last_hidden: torch.Tensor, on_layer_done=None):
         """Accumulate parameter gradients for d loss / d last_hidden_state = ``d_last_hidden`` ([B,S,H], or [T_real,H] for a
@@ -295,10 +346,10 @@ class MistralTrainEngine:
             ops.gemm_nt(self._transposed_act(dh_mid, "dh"), self._transposed_act(sv["ctx"], "ctx"), out=L.go, epilogue=EPI_RESIDUAL,
                         residual=L.go)
             if geom.packed:
-                dqkv = ops.attn_bidir_varlen_bwd(sv["qkv"], geom.cu, geom.max_len, sv["ctx"], dctx, sv["lse"], nq, nkv, d)
+                dqkv = ops.attn_bidir_varlen_bwd(sv["qkv"], geom.cu, geom.max_len, sv["ctx"], dctx, sv["lse"], nq, nkv, d, causal=geom.causal)
                 ops.rope_qk_pos_(dqkv, cos, sin, geom.pos, nq, nkv, d, inverse=True)
             else:
-                dqkv = ops.attn_bidir_bwd(sv["qkv"], geom.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d)
+                dqkv = ops.attn_bidir_bwd(sv["qkv"], geom.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d, causal=geom.causal)
                 ops.rope_qk_(dqkv, cos, sin, S, nq, nkv, d, inverse=True)
             dx1 = ops.gemm_nt(dqkv, self._wt(li, "qkv", L.wqkv))                        # [T,H]
             ops.gemm_nt(self._transposed_act(dqkv, "dqkv"), self._transposed_act(sv["x1"], "x"), out=L.gqkv, epilogue=EPI_RESIDUAL,
@@ -325,6 +376,8 @@ class MistralTrainEngine:
         out = []
         for L in self.layers:
             out += ([] if small_only else [L.gqkv, L.go, L.ggu, L.gdown]) + [L.ln1.grad, L.ln2.grad]
+        if self.lm_head is not None and self.lm_head.grad is not None:
+            out.append(self.lm_head.grad)
         return out + [self.embed.grad, self.norm.grad]
 
 

@@ -122,7 +122,8 @@ class DistributedContrastiveLoss:
 
 
 class NextTokenLoss:
-    """Generative objective of unified training (:66-107). Not on the native path: plain torch."""
+    """Generative objective of unified training (:66-107), torch restatement (CPU / non-native path; the native path computes the
+    same quantity in MistralTrainEngine.forward_lm with grit_ce_fwd / grit_ce_bwd)."""
 
     def __init__(self, vocab_size: int, loss_gen_type: str = "mixed", loss_gen_factor: float = 1.0):
         self.vocab_size, self.loss_gen_factor, self.loss_gen_type = vocab_size, loss_gen_factor, loss_gen_type
@@ -164,6 +165,28 @@ class _NativeEncodeFn(torch.autograd.Function):
         return None, None, None, None, None
 
 
+class _NativeGenFn(torch.autograd.Function):
+    """loss_gen = NextTokenLoss(labels, lm_head(model(ids, causal))) on the HIP engine (causal attention, lm_head GEMM, fused cross
+    entropy); backward accumulates backbone + lm_head gradients into ``.grad`` and returns no tensor gradients."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, input_ids, attention_mask, labels):
+        eng = model.train_engine
+        grad = bool(ctx.needs_input_grad[0])
+        fn = model.gen_loss_fn
+        loss, state = eng.forward_lm(input_ids, attention_mask, labels, fn.loss_gen_type, fn.loss_gen_factor, save=grad,
+                                     packed=getattr(model, "native_packed", True))
+        if grad:
+            ctx.model, ctx.state = model, state
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        ctx.model.train_engine.backward_lm(ctx.state, d_loss, on_layer_done=getattr(ctx.model, "_on_layer_done", None))
+        ctx.state = None
+        return None, None, None, None, None
+
+
 class GritLMTrainModel(GritLM):
     def __init__(
         self,
@@ -197,7 +220,8 @@ class GritLMTrainModel(GritLM):
             raise RuntimeError(f"native training engine needs a bf16 Mistral on a HIP device with 'bb' attention "
                                f"(got device={dev}, model_type={getattr(cfg, 'model_type', None)}, attn={self.attn}, dtype={self.model.dtype})")
         self.model.to(dev)
-        self.train_engine = MistralTrainEngine(self._backbone(), cfg, dev)
+        # a causal-LM wrapper (mode unified / generative) also hands its lm_head to the engine: generative branch on HIP kernels
+        self.train_engine = MistralTrainEngine(self._backbone(), cfg, dev, lm_head=getattr(self.model, "lm_head", None))
         return self.train_engine
 
     def encode(self, features):
@@ -244,7 +268,11 @@ class GritLMTrainModel(GritLM):
         """query [b, n]; passage [b*s, m] (s = group size); generative [b, m]."""
         loss_gen = None
         if generative is not None:      # generative first, as in the reference (:185-194)
-            if self.gen_loss_fn is not None:
+            if (self.train_engine is not None and self.train_engine.lm_head is not None and self.gen_loss_fn is not None
+                    and self.attn[2:4] == "cc"):
+                labels = generative.pop("labels")
+                loss_gen = _NativeGenFn.apply(self.train_engine.embed, self, generative["input_ids"], generative["attention_mask"], labels)
+            elif self.gen_loss_fn is not None:
                 loss_gen = self.gen_loss_fn(generative.pop("labels"), self.model(**generative, **self.gen_add_kwargs).logits)
             else:
                 loss_gen = self.model(**generative, **self.gen_add_kwargs).loss

@@ -22,7 +22,8 @@ import torch.distributed as dist
 from transformers import AutoTokenizer, HfArgumentParser, get_scheduler, set_seed
 
 from .arguments import CustomTrainingArguments, DataArguments, ModelArguments
-from .data import EmbeddingCollator, EmbeddingDataset, load_embedding_rows
+from .data import EmbeddingCollator, EmbeddingDataset, GenerativeCollator, load_embedding_rows, load_generative_rows
+from .gradcache import split_inputs
 from .gradcache import GradCacheStep, sync_gradients
 from .model import GritLMTrainModel
 
@@ -32,8 +33,8 @@ logger = logging.getLogger(__name__)
 def main(argv=None):
     model_args, data_args, args = HfArgumentParser((ModelArguments, DataArguments, CustomTrainingArguments)).parse_args_into_dataclasses(argv)
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", level=logging.INFO)
-    if args.mode != "embedding":
-        raise NotImplementedError("only --mode embedding runs on the native engine (generative/unified: SURVEY §8 f4)")
+    if args.mode not in ("embedding", "unified", "generative"):
+        raise NotImplementedError(args.mode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -57,19 +58,27 @@ def main(argv=None):
     if not tok.pad_token and tok.bos_token:
         tok.pad_token = tok.bos_token          # training pads with BOS (run.py:118-120), inference with EOS
 
-    rows = load_embedding_rows(data_args.train_data, data_args.max_example_num_per_dataset)
+    do_emb, do_gen = args.mode in ("embedding", "unified"), args.mode in ("unified", "generative")
+    rows = load_embedding_rows(data_args.train_data, data_args.max_example_num_per_dataset) if do_emb else []
+    gen_rows = load_generative_rows(data_args.train_data, data_args.max_example_num_per_dataset) if do_gen else []
+    if do_gen and not gen_rows:
+        raise ValueError(f"--mode {args.mode} needs rows with a 'text' field in {data_args.train_data}")
+    if do_gen and isinstance(gen_rows[0], (tuple, list)):       # too long instructions leave nothing to learn from (run.py:166-176)
+        gen_rows = [r for r in gen_rows if len(tok.tokenize("<|user|>\n" + r[0] + "\n<|assistant|>\n")) < data_args.generative_max_len]
     os.makedirs(args.output_dir, exist_ok=True)
     if rank == 0:
         with open(os.path.join(args.output_dir, "dataset_num_samples.json"), "w") as f:
-            json.dump({os.path.basename(data_args.train_data.rstrip("/")): len(rows)}, f)
-    max_len = max(data_args.query_max_len, data_args.passage_max_len)
-    ds = EmbeddingDataset(rows, data_args.train_group_size, max_char_len=max_len * 10, seed=args.seed + rank)
+            json.dump({os.path.basename(data_args.train_data.rstrip("/")): len(rows) + len(gen_rows)}, f)
+    max_len = max(data_args.query_max_len or 0, data_args.passage_max_len or 0, data_args.generative_max_len or 0)
+    ds = EmbeddingDataset(rows, data_args.train_group_size, max_char_len=max_len * 10, seed=args.seed + rank) if do_emb else None
     collate = EmbeddingCollator(tok, data_args.query_max_len, data_args.passage_max_len)
+    collate_gen = GenerativeCollator(tok, data_args.generative_max_len or 128, data_args.prefixlm) if do_gen else None
+    gen_bs = args.per_device_generative_bs          # smaller generative batch: every (bs // gen_bs)-th sample (data.py:49-54,137-144)
 
     dtype = torch.bfloat16 if args.bf16 else torch.float32
     model = GritLMTrainModel(model_name_or_path=model_args.model_name_or_path, normalized=model_args.normalized,
                              pooling_method=model_args.pooling_method, negatives_cross_device=args.negatives_cross_device and world > 1,
-                             temperature=args.temperature, mode=args.mode, projection=model_args.projection, attn=model_args.attn,
+                             temperature=args.temperature, loss_gen_type=args.loss_gen_type, loss_gen_factor=args.loss_gen_factor, mode=args.mode, projection=model_args.projection, attn=model_args.attn,
                              attn_implementation=model_args.attn_implementation, torch_dtype=dtype, device=device)
     model.model.to(device)
     model.model.train()
@@ -80,7 +89,10 @@ def main(argv=None):
     opt = torch.optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, betas=(args.adam_beta1, args.adam_beta2),
                             eps=args.adam_epsilon)
     bs = args.per_device_train_batch_size
-    steps_per_epoch = max(len(ds) // (bs * world), 1)
+    if gen_bs is not None:
+        assert bs >= gen_bs and bs % gen_bs == 0, "Full batch size must be divisible by the generative batch size"
+    n_items = max(len(rows), len(gen_rows))         # unified: the longer data set drives the epoch (data.py:33)
+    steps_per_epoch = max(n_items // (bs * world), 1)
     total = args.max_steps if args.max_steps > 0 else int(steps_per_epoch * args.num_train_epochs)
     sched = get_scheduler(args.lr_scheduler_type, opt, num_warmup_steps=args.get_warmup_steps(total), num_training_steps=total)
     gc = GradCacheStep(model, gc_chunk) if gc_chunk else None
@@ -88,13 +100,37 @@ def main(argv=None):
     gen = torch.Generator().manual_seed(args.seed)
     step, t0 = 0, time.time()
     while step < total:
-        order = torch.randperm(len(ds), generator=gen).tolist()
+        order = torch.randperm(n_items, generator=gen).tolist()
         order = order[rank::world]                                  # disjoint shards per rank
         for s in range(0, len(order) - bs + 1, bs):
-            batch = collate([ds[i] for i in order[s:s + bs]])
-            q = {k: v.to(device) for k, v in batch["query"].items()}
-            p = {k: v.to(device) for k, v in batch["passage"].items()}
-            if gc is not None:
+            idx = order[s:s + bs]
+            loss_gen = None
+            if do_gen:
+                # generative first (gradcache_trainer.py:551-579): it has no collective, the embedding step does
+                take = idx if gen_bs is None else idx[::bs // gen_bs]
+                gb = collate_gen([gen_rows[i % len(gen_rows)] for i in take])
+                gb = {k: v.to(device) for k, v in gb.items()}
+                if args.no_gen_gas or gc_chunk is None:
+                    loss_gen = model(generative=gb).loss_gen
+                    loss_gen.backward()
+                    loss_gen = loss_gen.detach()
+                else:
+                    chunks = split_inputs(gb, gc_chunk)
+                    loss_gen = torch.zeros((), device=device)
+                    for ch in chunks:
+                        lg = model(generative=ch).loss_gen / len(chunks)
+                        lg.backward()
+                        loss_gen += lg.detach()
+                if not do_emb:
+                    loss = loss_gen
+                    sync_gradients(model)
+            if do_emb:
+                batch = collate([ds[i % len(ds)] for i in idx])
+                q = {k: v.to(device) for k, v in batch["query"].items()}
+                p = {k: v.to(device) for k, v in batch["passage"].items()}
+            if not do_emb:
+                pass
+            elif gc is not None:
                 loss = gc(q, p)
             elif args.split_emb:
                 # two half-steps (gradcache_trainer.py:584-605): queries with grad vs frozen passages, then the converse;
@@ -117,7 +153,8 @@ def main(argv=None):
                 model.train_engine.weights_updated()
             step += 1
             if rank == 0 and step % max(args.logging_steps, 1) == 0:
-                logger.info("step %d/%d loss %.4f lr %.3e %.2f s/it", step, total, float(loss), sched.get_last_lr()[0], (time.time() - t0) / step)
+                logger.info("step %d/%d loss %.4f%s lr %.3e %.2f s/it", step, total, float(loss),
+                            "" if loss_gen is None else " loss_gen %.4f" % float(loss_gen), sched.get_last_lr()[0], (time.time() - t0) / step)
             if step >= total:
                 break
         if len(order) < bs:
@@ -127,7 +164,8 @@ def main(argv=None):
         tok.save_pretrained(args.output_dir)
     if dist.is_initialized():
         dist.barrier()
-    return float(loss)
+    main.last_loss_gen = None if loss_gen is None else float(loss_gen)
+    return float(loss.detach()) if torch.is_tensor(loss) else float(loss)
 
 
 if __name__ == "__main__":

@@ -214,6 +214,17 @@ int grit_attn_causal_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, cons
                                 float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
                                 int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
 
+/* ---- generative branch: NextTokenLoss, gritlm/training/model.py:66-107 -------------------------- */
+
+/* Cross entropy over the vocabulary on logits [T,V] bf16 (leading dimension ld; the lm_head GEMM output, upcast to fp32 on the
+ * fly like logits.float(), modeling_mistral_gritlm.py:1177).  labels [T] int64, -100 = ignore_index (rows already shifted by the
+ * caller: label[t] = token t+1).  lse [T], loss_row [T] fp32 (0 for ignored rows); the caller reduces (sum / count). */
+int grit_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* lse, float* loss_row, int64_t T, int V, void* stream);
+/* In place: logits <- d loss / d logits = (softmax - onehot) * scale * (*dev_scale) as bf16 (ignored rows: 0).
+ * dev_scale (nullable) is a device scalar, e.g. 1 / #valid tokens, so the host never waits for the count. */
+int grit_ce_bwd(void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* dev_scale, float scale, int64_t T,
+                int V, void* stream);
+
 /* embedding backward: dtable[ids[t], :] += dh[t, :]  (dtable fp32 [V,H], fp32 atomics) */
 int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream);
 

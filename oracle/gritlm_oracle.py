@@ -197,6 +197,24 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
     return out
 
 
+def next_token_loss(logits: np.ndarray, labels: np.ndarray, loss_gen_type: str = "mixed", loss_gen_factor: float = 1.0) -> float:
+    """NextTokenLoss.__call__, gritlm/training/model.py:93-107: tokens < n predict n, ignore_index -100;
+    'mixed' = mean over the scored tokens of the batch, 'token' = sum / batch size; times loss_gen_factor.
+    logits [B,S,V] (fp32, as after logits.float()), labels [B,S]."""
+    sl = logits[:, :-1].astype(F64).reshape(-1, logits.shape[-1])
+    tl = labels[:, 1:].reshape(-1)
+    keep = tl != -100
+    z = sl[keep]
+    mx = z.max(axis=1, keepdims=True)
+    lse = mx[:, 0] + np.log(np.exp(z - mx).sum(axis=1))
+    nll = lse - z[np.arange(z.shape[0]), tl[keep]]
+    if loss_gen_type == "token":
+        return float(nll.sum() / labels.shape[0] * loss_gen_factor)
+    if loss_gen_type == "mixed":
+        return float(nll.mean() * loss_gen_factor)
+    raise ValueError(f"Invalid loss_gen_type: {loss_gen_type}")
+
+
 def moe_router(x: np.ndarray, gate_w: np.ndarray, top_k: int = 2, emulate_bf16: bool = False):
     """MixtralSparseMoeBlock routing, scripts/modeling_mixtral_gritlm.py:843-850: gate Linear (model dtype) -> softmax in
     fp32 -> top-k (descending, lowest index first on ties like torch.topk on CPU) -> renormalise -> cast to the model dtype.

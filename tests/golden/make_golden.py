@@ -269,6 +269,74 @@ def gen_gradcache():
     print(f"  gradcache: loss direct {out.loss.item():.6f} vs gc {loss.item():.6f}")
 
 
+def gen_generative():
+    """Generative branch of unified training on the reference: GritLMTrainModel.forward(generative=...) with the reference's
+    MistralForCausalLM (is_causal default True), NextTokenLoss 'mixed' and 'token' (gritlm/training/model.py:66-107,185-194):
+    loss_gen and parameter gradients (backbone + lm_head)."""
+    from gritlm.training.model import GritLMTrainModel, NextTokenLoss
+    cfg = synth.CONFIGS["tiny"]
+    hc = synth.hf_config(cfg)
+    hc.use_cache = False
+    hc._attn_implementation = "sdpa"
+    lm = REFMOD.MistralForCausalLM(hc)
+    w = synth.make_weights(cfg, 0)
+    sd = {"model." + k: torch.from_numpy(v) for k, v in w.items()}
+    rng = np.random.default_rng(99)
+    sd["lm_head.weight"] = torch.from_numpy(synth._bf16_round(rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"]), dtype=np.float32) * 0.02))
+    missing, unexpected = lm.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    lm.train()
+    B, S = 5, 56
+    ids, mask = synth.make_batch(cfg, B, S, 31, min_len=12)
+    labels = ids.copy()
+    labels[mask == 0] = -100
+    for b, n_instr in enumerate([7, 0, 11, 3, 20]):          # instruction turns are not scored (data.py:271-282)
+        labels[b, :n_instr] = -100
+    names = ["model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.norm.weight",
+             "model.layers.0.input_layernorm.weight", "model.layers.1.self_attn.k_proj.weight", "model.embed_tokens.weight", "lm_head.weight"]
+    res = dict(input_ids=ids, attention_mask=mask, labels=labels, lm_head=sd["lm_head.weight"].numpy())
+    for kind, factor in (("mixed", 1.0), ("token", 0.25)):
+        m = GritLMTrainModel.__new__(GritLMTrainModel)
+        torch.nn.Module.__init__(m)
+        m.model = lm; m.embedding_attr = "model"; m.projection = None
+        m.gen_loss_fn = NextTokenLoss(cfg["vocab_size"], kind, factor); m.gen_add_kwargs = {"return_dict": True}
+        m.emb_loss_fn = None
+        lm.zero_grad()
+        out = m(generative={"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "labels": torch.from_numpy(labels)})
+        out.loss_gen.backward()
+        res[f"loss_gen_{kind}"] = np.float32(out.loss_gen.item()); res[f"factor_{kind}"] = np.float32(factor)
+        sdp = dict(lm.named_parameters())
+        for n in names:
+            res[f"grad_{kind}/" + n] = sdp[n].grad.numpy().copy()
+        print(f"  generative[{kind}]: loss_gen {out.loss_gen.item():.6f}")
+    with torch.no_grad():
+        res["logits"] = lm(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits.numpy()
+    # the reference's CustomCollator on multi-turn generative samples (gritlm/training/data.py:214-228,248-282) with run.py's format strings
+    import json
+    import tempfile
+    from transformers import AutoTokenizer
+    from gritlm.training.data import CustomCollator
+    from gritlm.training import run as ref_run
+    W = synth.WORDS
+    samples = [[" ".join(W[3:9]), " ".join(W[20:31])], [" ".join(W[1:4]), " ".join(W[40:44]), " ".join(W[50:58]), " ".join(W[60:75])],
+               [" ".join(W[5:25]), " ".join(W[80:83])]]
+    with tempfile.TemporaryDirectory() as td:
+        synth.make_tokenizer(td)
+        tok = AutoTokenizer.from_pretrained(td, padding_side="right")
+        if not tok.pad_token and tok.bos_token:
+            tok.pad_token = tok.bos_token
+        for prefixlm in (False, True):
+            coll = CustomCollator(tok, generative_max_len=40, base_bos=ref_run.BASE_BOS, turn_sep=ref_run.TURN_SEP, user_bos=ref_run.USER_BOS,
+                                  user_eos=ref_run.USER_EOS, embed_bos=ref_run.EMBED_BOS, embed_eos=ref_run.EMBED_EOS,
+                                  assistant_bos=ref_run.ASSISTANT_BOS, assistant_eos=ref_run.ASSISTANT_EOS, prefixlm=prefixlm)
+            feats = coll([(None, None, s_) for s_ in samples])["generative"]
+            tag = "_prefixlm" if prefixlm else ""
+            res["coll_input_ids" + tag] = feats["input_ids"].numpy(); res["coll_labels" + tag] = feats["labels"].numpy()
+            res["coll_attention_mask" + tag] = feats["attention_mask"].numpy()
+    res["coll_samples"] = np.array(json.dumps(samples))
+    np.savez_compressed(os.path.join(HERE, "generative_tiny.npz"), **res)
+
+
 def gen_gritlm_encode():
     """The reference's own GritLM(...).encode() end to end on CPU (tokenise -> forward -> pool -> normalise):
     (a) BASELINE.json configs[0] plumbing case: GPT-Neo, weightedmean, attn=None, 32 docs @ max_length 128;
@@ -306,6 +374,8 @@ def gen_gritlm_encode():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["generative"]:
+        gen_generative(); sys.exit(0)
     if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
         gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
         sys.exit(0)
@@ -316,5 +386,6 @@ if __name__ == "__main__":
     print("encoder gqa"); gen_encoder("gqa", batch=3, seq=72, min_len=20)
     print("gradcache"); gen_gradcache()
     print("gritlm encode"); gen_gritlm_encode()
+    print("generative"); gen_generative()
     print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
     print("done")

@@ -700,6 +700,73 @@ def check_train_packed_vs_padded(cfg_name="gqa"):
     return _res(f"packed training step == padded training step [{cfg_name}]", bool(ok), **out)
 
 
+def check_ce(T=300, V=1003):
+    """Fused vocabulary cross entropy (grit_ce_fwd / grit_ce_bwd) vs fp64 numpy; ignore_index rows, V not a multiple of 8 via ld."""
+    rng = np.random.default_rng(81)
+    ld = (V + 7) // 8 * 8
+    logits = (rng.standard_normal((T, ld)) * 3).astype(np.float32)
+    labels = rng.integers(0, V, size=T).astype(np.int64)
+    labels[::7] = -100
+    tl = bf(logits)
+    view = tl[:, :V]
+    tlab = torch.from_numpy(labels).to(DEV)
+    lse, loss_row = ops.ce_fwd(view, tlab)
+    z = f32(tl)[:, :V].astype(np.float64)
+    mx = z.max(1, keepdims=True)
+    lse_ref = mx[:, 0] + np.log(np.exp(z - mx).sum(1))
+    keep = labels >= 0
+    nll_ref = np.where(keep, lse_ref - z[np.arange(T), np.where(keep, labels, 0)], 0.0)
+    e1 = float(np.max(np.abs(f32(lse) - lse_ref))); e2 = float(np.max(np.abs(f32(loss_row) - nll_ref)))
+    dev_scale = torch.tensor([0.5], dtype=torch.float32, device=DEV)
+    ops.ce_bwd_(view, tlab, lse, 3.0, dev_scale)
+    p = np.exp(z - lse_ref[:, None]); p[np.arange(T), np.where(keep, labels, 0)] -= keep
+    gref = p * 1.5 * keep[:, None]
+    got = f32(tl)[:, :V]
+    e3 = float(np.max(np.abs(got - gref) / (2.0 ** -8 * np.abs(gref) + 1e-6)))
+    return _res(f"cross entropy fwd/bwd [T={T},V={V}]", e1 < 1e-4 and e2 < 1e-4 and e3 < 1.01, lse_abs=e1, nll_abs=e2, grad_err_over_ulp=e3)
+
+
+def check_generative_step(kind="mixed"):
+    """Native generative branch (causal attention fwd/bwd, lm_head GEMMs, fused CE) vs the REFERENCE's loss_gen and parameter
+    gradients (tests/golden/generative_tiny.npz: GritLMTrainModel.forward(generative=...) on the reference's MistralForCausalLM)."""
+    import tempfile
+    from gritlm_amd.training import GritLMTrainModel
+    g = np.load(os.path.join(GOLDEN, "generative_tiny.npz"))
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        m = GritLMTrainModel(model_name_or_path=d16, mode="unified", pooling_method="mean", normalized=True, attn="bbcc", temperature=0.02,
+                             negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16, loss_gen_type=kind,
+                             loss_gen_factor=float(g[f"factor_{kind}"]))
+        m.enable_native()
+        ok &= m.train_engine.lm_head is not None
+        for packed in (True, False):
+            m.native_packed = packed
+            m.model.zero_grad(set_to_none=True)
+            gen = {"input_ids": torch.from_numpy(g["input_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["attention_mask"]).to(DEV),
+                   "labels": torch.from_numpy(g["labels"]).to(DEV)}
+            o = m(generative=gen)
+            o.loss_gen.backward()
+            ref_loss = float(g[f"loss_gen_{kind}"])
+            tag = "packed" if packed else "padded"
+            out[f"loss_{tag}"] = float(o.loss_gen.item()); out["loss_ref"] = ref_loss
+            ok &= abs(out[f"loss_{tag}"] - ref_loss) < 1e-2 * max(1.0, abs(ref_loss))
+            sd = dict(m.model.named_parameters())
+            worst = 0.0
+            for key in g.files:
+                if not key.startswith(f"grad_{kind}/"):
+                    continue
+                n = key.split("/", 1)[1]
+                ref = g[key]; got = f32(sd[n].grad)
+                rel = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-20))
+                worst = max(worst, rel)
+                if packed:
+                    out[n.replace("model.", "").replace("layers.", "L").replace(".weight", "")] = rel
+            out[f"worst_grad_rel_{tag}"] = worst
+            ok &= worst < 6e-2
+    return _res(f"native generative step [{kind}] vs reference loss_gen+grads", bool(ok), **out)
+
+
 def check_cli_native():
     """python -m gritlm.training.run on the GPU: bf16 tiny Mistral, (instruction, text) rows, GradCache switch, native engine."""
     import json
@@ -723,6 +790,35 @@ def check_cli_native():
         files = os.listdir(out)
     ok = np.isfinite(l1) and np.isfinite(l8) and l8 < l1 and "config.json" in files
     return _res("CLI gritlm.training.run native (loss decreases over 8 steps)", ok, loss_step1=float(l1), loss_step8=float(l8))
+
+
+def check_cli_unified_native():
+    """python -m gritlm.training.run --mode unified on the GPU: generative branch (causal kernels + lm_head + CE) and the GradCache
+    embedding step both on the native engine; both losses fall over 8 steps."""
+    import json
+    import tempfile
+    from gritlm.training import run
+    W = synth.WORDS
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        os.makedirs(os.path.join(td, "data"))
+        rows = []
+        for i in range(0, 64, 2):
+            negs = [["w3", " ".join(W[j:j + 7])] for j in range(i + 20, i + 27)]
+            rows.append({"query": ["w1 w2", " ".join(W[i:i + 5])], "pos": [["w3", " ".join(W[i + 1:i + 9])]], "neg": negs})
+        open(os.path.join(td, "data", "emb.jsonl"), "w").write("\n".join(json.dumps(r) for r in rows))
+        gen = [{"text": [" ".join(W[i:i + 4]), " ".join(W[(7 * i) % 300:(7 * i) % 300 + 12])]} for i in range(32)]
+        open(os.path.join(td, "data", "gen.jsonl"), "w").write("\n".join(json.dumps(r) for r in gen))
+        common = ["--model_name_or_path", d16, "--train_data", os.path.join(td, "data"), "--output_dir", os.path.join(td, "out"), "--bf16",
+                  "--mode", "unified", "--per_device_train_batch_size", "2", "--gradient_accumulation_steps", "4", "--no_gen_gas",
+                  "--no_emb_gas", "--per_device_generative_bs", "4", "--train_group_size", "8", "--pooling_method", "mean",
+                  "--learning_rate", "3e-4", "--query_max_len", "24", "--passage_max_len", "40", "--generative_max_len", "48",
+                  "--report_to", "none", "--logging_steps", "1"]
+        l1 = run.main(common + ["--max_steps", "1"]); g1 = run.main.last_loss_gen
+        l8 = run.main(common + ["--max_steps", "8"]); g8 = run.main.last_loss_gen
+    ok = all(np.isfinite(v) for v in (l1, l8, g1, g8)) and l8 < l1 and g8 < g1
+    return _res("CLI --mode unified native (emb + gen losses decrease over 8 steps)", bool(ok), loss_emb_1=float(l1), loss_emb_8=float(l8),
+                loss_gen_1=float(g1), loss_gen_8=float(g8))
 
 
 def check_packed_encode(cfg_name="gqa", B=5, S=150):
@@ -987,6 +1083,11 @@ ALL_CHECKS = [
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
     ("train_packed_vs_padded", check_train_packed_vs_padded, {}),
+    ("ce", check_ce, {}),
+    ("ce_vocab32000", check_ce, dict(T=40, V=32000)),
+    ("generative_mixed", check_generative_step, dict(kind="mixed")),
+    ("generative_token", check_generative_step, dict(kind="token")),
     ("cli_native", check_cli_native, {}),
+    ("cli_unified_native", check_cli_unified_native, {}),
     ("overlapped_grad_sync", check_overlapped_grad_sync, {}),
 ]

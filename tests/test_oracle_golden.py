@@ -117,6 +117,22 @@ def test_mixtral_encoder_matches_reference(golden_dir, cfg_name):
     assert rel(hb, ref_b) < 1.5 * rel(ref_b, ref_f) + 1e-3, (rel(hb, ref_b), rel(ref_b, ref_f))
 
 
+def test_generative_branch_matches_reference(golden_dir):
+    """Causal encode + lm_head + NextTokenLoss of the oracle vs the reference's MistralForCausalLM / GritLMTrainModel(generative=...)."""
+    g = _load(golden_dir, "generative_tiny.npz")
+    cfg = synth.CONFIGS["tiny"]
+    w = synth.make_weights(cfg, 0)
+    h = O.mistral_encode(w, cfg, g["input_ids"], g["attention_mask"], causal=True)
+    logits = h @ g["lm_head"].T
+    valid = g["attention_mask"].astype(bool)
+    assert np.abs(logits - g["logits"])[valid].max() < 3e-4
+    hb = O.mistral_encode(w, cfg, g["input_ids"], g["attention_mask"], causal=False)
+    assert np.abs(hb - h)[valid].max() > 1e-2                      # the causal flag does something
+    for kind in ("mixed", "token"):
+        got = O.next_token_loss(logits, g["labels"], kind, float(g[f"factor_{kind}"]))
+        assert abs(got - float(g[f"loss_gen_{kind}"])) < 2e-4 * max(1.0, abs(got)), (kind, got, float(g[f"loss_gen_{kind}"]))
+
+
 def test_moe_router_topk_and_renormalisation():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((64, 32)).astype(np.float32)

@@ -74,3 +74,40 @@ def test_cli_direct_step_variants(tmp_path):
         losses.append(main(base + ["--output_dir", str(tmp_path / f"o{i}")] + extra))
     assert all(np.isfinite(l) for l in losses)
     assert max(losses) - min(losses) < 1e-4            # same seed, same first batch: the forward loss is identical in all variants
+
+
+def test_generative_collator_matches_reference(tmp_path):
+    """GenerativeCollator vs the reference's CustomCollator outputs recorded in tests/golden/generative_tiny.npz (multi-turn
+    samples, instruction turns masked to -100, prefixlm variant)."""
+    from transformers import AutoTokenizer
+    from gritlm_amd.training.data import GenerativeCollator
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "generative_tiny.npz"))
+    samples = json.loads(str(g["coll_samples"]))
+    synth.make_tokenizer(str(tmp_path / "tok"))
+    tok = AutoTokenizer.from_pretrained(str(tmp_path / "tok"), padding_side="right")
+    if not tok.pad_token and tok.bos_token:
+        tok.pad_token = tok.bos_token
+    for prefixlm, tag in ((False, ""), (True, "_prefixlm")):
+        feats = GenerativeCollator(tok, 40, prefixlm)(samples)
+        assert np.array_equal(feats["input_ids"].numpy(), g["coll_input_ids" + tag])
+        assert np.array_equal(feats["attention_mask"].numpy(), g["coll_attention_mask" + tag])
+        assert np.array_equal(feats["labels"].numpy(), g["coll_labels" + tag])
+    assert (g["coll_labels"] != g["coll_labels_prefixlm"]).any()
+
+
+def test_cli_unified_two_steps(tmp_path):
+    """--mode unified on CPU (Hugging Face path): generative rows ("text") + embedding rows in one directory, generative step first,
+    then the GradCache embedding step; both losses finite."""
+    from gritlm.training import run
+    d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
+    os.makedirs(tmp_path / "data")
+    _toy(str(tmp_path / "data" / "emb.jsonl"))
+    W = synth.WORDS
+    with open(tmp_path / "data" / "gen.jsonl", "w") as f:
+        f.write("\n".join(json.dumps({"text": [" ".join(W[i:i + 4]), " ".join(W[i + 30:i + 42])]}) for i in range(24)))
+    loss = run.main(["--model_name_or_path", d, "--train_data", str(tmp_path / "data"), "--output_dir", str(tmp_path / "out"), "--mode", "unified",
+                     "--per_device_train_batch_size", "2", "--gradient_accumulation_steps", "2", "--no_gen_gas", "--no_emb_gas",
+                     "--per_device_generative_bs", "2", "--train_group_size", "8", "--pooling_method", "mean", "--max_steps", "2",
+                     "--learning_rate", "1e-4", "--query_max_len", "16", "--passage_max_len", "24", "--generative_max_len", "32",
+                     "--loss_gen_type", "mixed", "--report_to", "none", "--use_cpu"])
+    assert np.isfinite(loss) and run.main.last_loss_gen is not None and np.isfinite(run.main.last_loss_gen)
