@@ -113,6 +113,8 @@ class MistralEncoderEngine:
         self._rope = {}
         self.rope_bf16 = True
         self.record_routing = None      # tests: set to a list to collect every MoE layer's selected experts [T,2]
+        self.causal = False             # True: causal attention ('cc' embedding attention of the reference's attn string)
+        self.sliding_window = None      # causal + S > window is not built (bidirectional attention ignores the window, as the reference)
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -214,6 +216,10 @@ class MistralEncoderEngine:
         ops.gemm_nt_grouped(ws["act2"], L.w2, counts, 2 * T, out=ws["y2"])
         ops.moe_combine(ws["y2"], rows, weights, h, out=h)
 
+    def _check_window(self, S: int):
+        if self.causal and self.sliding_window is not None and S > self.sliding_window:
+            raise NotImplementedError(f"causal attention with sliding_window={self.sliding_window} < sequence length {S} is not built")
+
     def _rope_tables(self, S: int):
         t = self._rope.get(S)
         if t is None:
@@ -234,6 +240,7 @@ class MistralEncoderEngine:
         c = self.cfg
         B, S = input_ids.shape
         T = B * S
+        self._check_window(S)
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
         if attention_mask is None:
             attention_mask = torch.ones((B, S), dtype=torch.int64, device=self.device)
@@ -252,7 +259,7 @@ class MistralEncoderEngine:
             if return_kv:
                 kvw = qkv.view(B, S, nq + 2 * nkv, d)
                 kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).contiguous(), kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).contiguous()))
-            ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx)
+            ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, causal=self.causal)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)
@@ -280,6 +287,7 @@ class MistralEncoderEngine:
         computes every padded row.  Results are bit-identical to the padded path."""
         c = self.cfg
         B, S = input_ids.shape
+        self._check_window(S)
         mask = attention_mask.to(device=self.device, dtype=torch.int64)
         ids = input_ids.to(device=self.device, dtype=torch.int64)
         if packed is None:
@@ -304,7 +312,7 @@ class MistralEncoderEngine:
             ops.rmsnorm(h, L.ln1, eps, out=x)
             ops.gemm_nt(x, L.wqkv, out=qkv)
             ops.rope_qk_pos_(qkv, cos, sin, pos, nq, nkv, d)
-            ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx)
+            ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)

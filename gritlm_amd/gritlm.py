@@ -120,7 +120,7 @@ class GritLM(torch.nn.Module):
         dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
         cfg = self.model.config
         eligible = (dev.type == "cuda" and getattr(cfg, "model_type", "") in ("mistral", "mixtral") and self.attn is not None
-                    and self.attn[:2] == "bb" and self.model.dtype == torch.bfloat16)
+                    and self.attn[:2] in ("bb", "cc") and self.model.dtype == torch.bfloat16)
         if not eligible:
             if self._native is True:
                 raise RuntimeError("native=True but this configuration is not implemented by the HIP engine "
@@ -132,6 +132,8 @@ class GritLM(torch.nn.Module):
         ecfg = EncoderConfig.from_hf(cfg)
         ecfg.check_supported()
         self.engine = MistralEncoderEngine.from_state_dict(ecfg, self._backbone().state_dict(), dev)
+        self.engine.causal = self.attn[:2] == "cc"       # 'cc..': causal embedding attention (e.g. lasttoken / weightedmean models)
+        self.engine.sliding_window = getattr(cfg, "sliding_window", None)
 
     # ------------------------------------------------------------------ API
     def encode_queries(self, queries: Union[List[str], str], **kwargs) -> np.ndarray:

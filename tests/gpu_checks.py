@@ -844,6 +844,27 @@ def check_packed_encode(cfg_name="gqa", B=5, S=150):
     return _res(f"packed (un-padded) encode == padded encode [{cfg_name},B={B},S={S}]", ok, **out)
 
 
+def check_causal_encode(cfg_name="gqa", B=4, S=150):
+    """attn='cc..' embedding models (causal attention + lasttoken / weightedmean pooling): engine.causal vs the oracle, packed == padded."""
+    eng, cfg, w = build_engine(cfg_name, 4)
+    eng.causal = True
+    ids, mask = synth.make_batch(cfg, B, S, seed=93, min_len=17)
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    ok, out = True, {}
+    h_ref = O.mistral_encode(w, cfg, ids, mask, causal=True)
+    for method in ("lasttoken", "weightedmean", "mean"):
+        a = f32(eng.encode_pooled(tid, tm, method, True, packed=False))
+        b = f32(eng.encode_pooled(tid, tm, method, True, packed=True))
+        ref = O.l2_normalize(O.pooling(h_ref, mask, method))
+        c = float(np.max(1 - np.sum(b * ref, axis=1)))
+        out[f"{method}_1-cos_oracle"] = c
+        ok &= np.array_equal(a, b) and c < 1e-4
+    eng.causal = False
+    e_bi = f32(eng.encode_pooled(tid, tm, "mean", True))
+    ok &= float(np.max(1 - np.sum(e_bi * ref, axis=1))) > 1e-3          # and it differs from the bidirectional embedding
+    return _res(f"causal ('cc') embedding encode [{cfg_name}] vs oracle", bool(ok), **out)
+
+
 def check_edge_cases():
     """Empty / minimal / degenerate inputs the host can hand over (reference behaviour noted per case)."""
     ok, notes = True, {}
@@ -1072,6 +1093,7 @@ ALL_CHECKS = [
     ("moe_block", check_moe_block, {}),
     ("mixtral_tiny", check_mixtral_golden, dict(cfg_name="moe-tiny")),
     ("mixtral_gqa", check_mixtral_golden, dict(cfg_name="moe-gqa")),
+    ("causal_encode", check_causal_encode, {}),
     ("edge_cases", check_edge_cases, {}),
     ("long_sequence_4096", check_long_sequence, {}),
     ("full_shape_properties", check_full_shape_properties, {}),
