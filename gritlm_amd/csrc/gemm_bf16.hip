@@ -99,11 +99,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     int64_t gm_row = m0 + r; if (gm_row > M - 1) gm_row = M - 1;
     if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
     int gn_row = n0 + r; if (gn_row > N - 1) gn_row = N - 1;
+    if (ABL == 14) { gm_row &= 255; gn_row &= 255; }           // timing experiment: L2-resident operands (256 rows x 512 k each)
     a_src[c] = A + gm_row * lda + slot * 8;
     w_src[c] = W + (int64_t)gn_row * ldw + slot * 8;
   }
 
   auto stage = [&](int buf, int kt) {
+    if (ABL == 14) kt &= 7;
     char* base = smem + buf * STAGE_BYTES + wid * 4096;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (ABL == 0 || ABL == 8 || ABL == 9 || ABL == 12 || ABL == 13) stage(cur ^ 1, kt + 1 < nk ? kt + 1 : kt);   // branch-free body (re-stages the last tile once, harmless)
+    if (ABL == 0 || ABL == 8 || ABL == 9 || ABL == 12 || ABL == 13 || ABL == 14) stage(cur ^ 1, kt + 1 < nk ? kt + 1 : kt);   // branch-free body (re-stages the last tile once, harmless)
     else if (kt + 1 < nk && ABL != 1) stage(cur ^ 1, kt + 1);
     const char* sb = smem + (ABL == 2 ? 0 : cur * STAGE_BYTES);
 #pragma unroll
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
       __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
     }
-    if (ABL == 0 || ABL == 9) {  // default: fragment reads issued two MFMA groups ahead of their consumers
+    if (ABL == 0 || ABL == 9 || ABL == 14) {  // default: fragment reads issued two MFMA groups ahead of their consumers
       __builtin_amdgcn_sched_group_barrier(0x10, 8, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // w0-3, x0-5 (ks 0)
       __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G0
@@ -451,7 +453,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_v8_k(const uint16_t* __restr
 // GRIT_GEMM_ABLATE=<n> (variant 1, STORE epilogue; timing experiments, results WRONG for 1,2,3,10):
 //   1 no LDS-DMA in the K loop, 2 no ds_read, 3 no MFMA, 10 weight half of the DMA skipped; 5 setprio, 6/7 iglp_opt(0/1),
 //   8 explicit issue order one group ahead, 0/9 = default (reads two MFMA groups ahead), 11 no epilogue stores,
-//   12/13 LDS-DMA issue spread over the MFMAs (1 per 8 / 1 per 4).
+//   12/13 LDS-DMA issue spread over the MFMAs (1 per 8 / 1 per 4), 14 operands made L2-resident (rows & 255, k-tiles & 7).
 // GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4: 4 m x 8 n tiles in flight per XCD; measured 2/4/8/16/32 ->
 // 5.41/5.33/5.47/6.03/6.66 ms on the QKV shape, no remap 5.65 ms), GRIT_GEMM_NOREMAP=1 disables the XCD remap (A/B only).
 static int gemm_variant() {
@@ -495,8 +497,9 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
-    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else if (abl == 11) GRIT_LAUNCH_ABL(11); else if (abl == 12) GRIT_LAUNCH_ABL(12); else GRIT_LAUNCH_ABL(13);
+    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else if (abl == 11) GRIT_LAUNCH_ABL(11); else if (abl == 12) GRIT_LAUNCH_ABL(12); else if (abl == 14) GRIT_LAUNCH_ABL(14); else GRIT_LAUNCH_ABL(13);
   } else if (gemm_variant() == 8 && grp.counts == nullptr) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v8_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
     hipLaunchKernelGGL(gemm_bf16_nt_v8_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,

@@ -67,6 +67,17 @@ def _chk2d(t: torch.Tensor, dtype, name: str):
     return t.data_ptr()
 
 
+def _chk3d(t: torch.Tensor, dtype, name: str):
+    """[E,N,K] stack of row-strided matrices (unit column stride; leading dimension stride(1), matrix stride stride(0))."""
+    if not t.is_cuda:
+        raise _lib.GritHipError(f"{name}: tensor must live on the GPU (got {t.device}); the native path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError(f"{name}: 3-D tensor with unit column stride expected")
+    return t.data_ptr()
+
+
 def embed_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     V, H = table.shape
     T = ids.numel()
@@ -192,7 +203,7 @@ def gemm_nt_grouped(a: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, m_to
     if ev:
         ev[0].record()
     check(_lib.load().grit_gemm_bf16_nt_grouped(_chk2d(a, BF16, "a"), 0 if a_rows is None else _chk(a_rows, I32, "a_rows"),
-                                                _chk(w, BF16, "w"), _chk2d(out, BF16, "out"), _chk(counts, I32, "counts"), E, m_total, N, K,
+                                                _chk3d(w, BF16, "w"), _chk2d(out, BF16, "out"), _chk(counts, I32, "counts"), E, m_total, N, K,
                                                 a.stride(0), w.stride(1), w.stride(0), out.stride(0), epilogue, _stream()),
           "grit_gemm_bf16_nt_grouped")
     if ev:
