@@ -47,7 +47,7 @@ counts = torch.stack([torch.bincount(r.reshape(-1).long(), minlength=8) for r in
 docs_per_s = a.docs * a.steps / dt
 flops_doc = eng.flops_per_token(a.seq) * a.seq
 print(json.dumps({
-    "metric": "encoded docs/sec @ seq512 (Mixtral-8x7B shape, sparse MoE top-2)", "value": docs_per_s, "unit": "docs/s", "n_gpus": 1,
+    "metric": f"encoded docs/sec @ seq{a.seq} (Mixtral-8x7B shape, sparse MoE top-2)", "value": docs_per_s, "unit": "docs/s", "n_gpus": 1,
     "steps": a.steps, "ms_per_step": dt / a.steps * 1e3, "dtype": "bf16", "data": "synthetic, random-init weights",
     "config": {"workload": f"Mixtral-8x7B shape, {a.layers}L, 8 experts top-2, batch {a.docs} x seq{a.seq}, mean pool + normalise"},
     "model_flops_utilisation": docs_per_s * flops_doc / 2.5e15, "weights_init_s": t_init, "hbm_allocated_gb": torch.cuda.max_memory_allocated() / 1e9,
