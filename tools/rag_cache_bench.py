@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] "RAG doc-caching": encode passages with get_cache=True (native bidirectional pass that also emits the per-layer
+post-RoPE K/V, gritlm/gritlm.py:131-140, rag/eval.py:124-150) and generate tokens for a query REUSING a passage's KV (rag/eval.py:237-246,
+cache == "doc").  Encoding + KV emission run on the HIP engine; the token-by-token decode is the Hugging Face module (causal decode
+kernels are not built).   python tools/rag_cache_bench.py [--passages 512 --seq 2048 --new-tokens 128] [--tiny --cpu]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth  # noqa: E402
+from gritlm_amd import GritLM  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--passages", type=int, default=512)
+ap.add_argument("--seq", type=int, default=2048)
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--new-tokens", type=int, default=128)
+ap.add_argument("--queries", type=int, default=4)
+ap.add_argument("--tiny", action="store_true", help="tiny synthetic model (logic check)")
+ap.add_argument("--cpu", action="store_true")
+a = ap.parse_args()
+dev = "cpu" if a.cpu else "cuda"
+dtype = torch.float32 if a.cpu else torch.bfloat16
+
+import tempfile  # noqa: E402
+from transformers import AutoTokenizer, MistralConfig, MistralForCausalLM  # noqa: E402
+
+td = tempfile.mkdtemp()
+synth.make_tokenizer(td)
+tok = AutoTokenizer.from_pretrained(td, padding_side="right")
+if a.tiny:
+    hc = synth.hf_config(synth.CONFIGS["tiny"])
+else:
+    hc = MistralConfig(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                       num_key_value_heads=8, rms_norm_eps=1e-5, max_position_embeddings=32768, sliding_window=None, pad_token_id=0,
+                       bos_token_id=1, eos_token_id=2, tie_word_embeddings=False)
+    hc.rope_theta = 10000.0
+t0 = time.perf_counter()
+with torch.device(dev):
+    lm = MistralForCausalLM(hc)
+lm = lm.to(dtype).eval()
+m = GritLM.__new__(GritLM)
+torch.nn.Module.__init__(m)
+m.model, m.tokenizer, m.device, m.embedding_attr, m.projection = lm, tok, dev, "model", None
+m.pooling_method, m.normalized, m.attn, m.embed_eos, m.num_gpus, m.engine, m._native = "mean", True, "bbcc", "", 1, None, None
+m.generate = lm.generate
+m._maybe_build_engine()
+t_init = time.perf_counter() - t0
+
+passages = synth.make_sentences(a.passages, seed=11, min_words=a.seq, max_words=a.seq + 50)      # truncated to --seq tokens
+if dev == "cuda":
+    torch.cuda.synchronize()
+t0 = time.perf_counter()
+emb, caches = [], []
+for s in range(0, a.passages, a.batch):
+    e, c = m.encode(passages[s:s + a.batch], batch_size=a.batch, max_length=a.seq, get_cache=True, convert_to_tensor=True,
+                    add_special_tokens=False)
+    emb.append(e); caches.append(c)
+if dev == "cuda":
+    torch.cuda.synchronize()
+t_enc = time.perf_counter() - t0
+
+# per-layer (k, v) of one passage -> the installed transformers' cache object
+from transformers import DynamicCache  # noqa: E402
+
+
+def passage_cache(i):
+    c = caches[i // a.batch]
+    j = i % a.batch
+    out = DynamicCache()
+    layers = c.layers if hasattr(c, "layers") else None
+    for li in range(hc.num_hidden_layers):
+        k, v = (layers[li].keys, layers[li].values) if layers is not None else (c[li][0], c[li][1])
+        out.update(k[j:j + 1].clone(), v[j:j + 1].clone(), li)
+    return out
+
+
+q_ids = tok(synth.make_sentences(a.queries, seed=12, min_words=20, max_words=20), return_tensors="pt", add_special_tokens=False)["input_ids"].to(dev)
+if dev == "cuda":
+    torch.cuda.synchronize()
+t0 = time.perf_counter()
+n_new = 0
+for qi in range(a.queries):
+    pc = passage_cache(qi)
+    plen = pc.get_seq_length()
+    ids = q_ids[qi:qi + 1]
+    mask = torch.ones((1, plen + ids.shape[1]), dtype=torch.long, device=dev)
+    # the prompt = [cached passage tokens (placeholders, never re-encoded)] + query tokens, as rag/eval.py hands `past_key_values` to generate
+    full = torch.cat([torch.zeros((1, plen), dtype=torch.long, device=dev), ids], dim=1)
+    out = lm.generate(input_ids=full, attention_mask=mask, past_key_values=pc, max_new_tokens=a.new_tokens, min_new_tokens=a.new_tokens,
+                      do_sample=False, pad_token_id=0)
+    n_new += out.shape[1] - full.shape[1]
+if dev == "cuda":
+    torch.cuda.synchronize()
+t_gen = time.perf_counter() - t0
+tokens = a.passages * a.seq
+kv_gb = sum(sum(x.numel() * x.element_size() for x in ((l.keys, l.values) if hasattr(l, "keys") else l)) for c in caches
+            for l in (c.layers if hasattr(c, "layers") else c)) / 1e9
+print(json.dumps({"metric": "RAG doc-caching: encode passages (+KV) and generate from the cached KV", "passages": a.passages, "seq": a.seq,
+                  "encode_s": t_enc, "passages_per_s": a.passages / t_enc, "encode_tokens_per_s": tokens / t_enc, "kv_cache_gb": kv_gb,
+                  "native_engine": m.engine is not None, "generate_s_per_query": t_gen / a.queries, "new_tokens_per_query": n_new / a.queries,
+                  "decode_tokens_per_s": n_new / t_gen, "decode_path": "Hugging Face generate() on the spliced cache (not native)",
+                  "model_init_s": t_init, "hbm_allocated_gb": torch.cuda.max_memory_allocated() / 1e9 if dev == "cuda" else None}))
