@@ -37,6 +37,11 @@ _SIGNATURES = {
     "grit_pool_norm_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_pool_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt_grouped": (_i, [_p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _i, _p]),
+    "grit_gemv_bf16": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
+    "grit_kv_append": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _p]),
+    "grit_attn_decode_workspace_floats": (_l, [_i, _i, _i, _i]),
+    "grit_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_argmax_advance": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _i, _p]),
     "grit_ce_fwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _p]),
     "grit_ce_bwd": (_i, [_p, _l, _p, _p, _p, _f, _l, _i, _p]),
     "grit_moe_router_top2": (_i, [_p, _p, _p, _p, _l, _i, _i, _p]),

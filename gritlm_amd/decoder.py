@@ -1,0 +1,142 @@
+"""Native greedy generation on the encoder engine's weights: prompt prefill + token-by-token decode on HIP kernels.
+
+Replaces, for the RAG doc-caching flow of the reference (rag/eval.py:237-302: ``model.generate(inputs, past_key_values=kv_cache)`` where
+``kv_cache`` came from ``encode(..., get_cache=True)``, gritlm/gritlm.py:131-140), the Hugging Face decode loop: every projection of a
+decode step is an HBM-bound GEMV (``grit_gemv_bf16``), attention reads the sequence's KV once (``grit_attn_decode``), the new token's
+K/V are appended in place, sampling is a device-side argmax -- and the whole step (~290 launches at 32 layers) is captured in ONE HIP
+graph, so the host only replays it.  Greedy decoding only (``do_sample=False``), batch <= 8, head_dim 128.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import EPI_RESIDUAL, EPI_SWIGLU
+from .encoder import MistralEncoderEngine, rope_tables
+
+BF16, I32, I64 = torch.bfloat16, torch.int32, torch.int64
+
+
+def _layers_of(cache):
+    """per-layer (k, v) [B, nkv, S, d] from the installed transformers' cache object or a legacy tuple of tuples."""
+    if hasattr(cache, "layers"):
+        return [(l.keys, l.values) for l in cache.layers]
+    return [(l[0], l[1]) for l in cache]
+
+
+class MistralDecoder:
+    def __init__(self, engine: MistralEncoderEngine, lm_head: torch.Tensor):
+        if engine.cfg.num_local_experts:
+            raise NotImplementedError("native decode is built for the dense (Mistral) MLP")
+        self.eng, self.cfg, self.device = engine, engine.cfg, engine.device
+        self.lm_head = lm_head.detach().to(device=self.device, dtype=BF16).contiguous()
+        self.use_graph = True
+
+    # ------------------------------------------------------------------ one decode step (all sizes static, lengths on the device)
+    def _step(self, st):
+        c, e = self.cfg, self.eng
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        h, x, qkv, ctx, act = st["h"], st["x"], st["qkv"], st["ctx"], st["act"]
+        ops.embed_gather(e.embed, st["next"], out=h)
+        for li, L in enumerate(e.layers):
+            ck, cv = st["cache"][li]
+            ops.rmsnorm(h, L.ln1, eps, out=x)
+            ops.gemv(x, L.wqkv, out=qkv)
+            ops.rope_qk_pos_(qkv, st["cos"], st["sin"], st["lens"], nq, nkv, d)
+            ops.kv_append(qkv, ck, cv, st["lens"], nq, nkv, d)
+            ops.attn_decode(qkv, ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)
+            ops.gemv(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.rmsnorm(h, L.ln2, eps, out=x)
+            ops.gemv(x, L.wgu, out=act, epilogue=EPI_SWIGLU)
+            ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+        ops.rmsnorm(h, e.norm, eps, out=x)
+        ops.gemv(x, self.lm_head, out=st["logits"])
+
+    def _sample(self, st):
+        ops.argmax_advance(st["logits"], st["next"], st["lens"], st["history"], st["step"])
+
+    def _state(self, B: int, Lmax: int):
+        c, dev = self.cfg, self.device
+        nq, nkv, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        mk = lambda n: torch.empty((B, n), dtype=BF16, device=dev)
+        cos, sin = rope_tables(Lmax, d, c.rope_theta, self.eng.rope_bf16, dev)
+        return dict(h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk((nq + 2 * nkv) * d), ctx=mk(nq * d), act=mk(c.intermediate_size),
+                    logits=mk(self.lm_head.shape[0]), next=torch.zeros((B,), dtype=I64, device=dev), lens=torch.zeros((B,), dtype=I32, device=dev),
+                    step=torch.zeros((1,), dtype=I32, device=dev), cos=cos, sin=sin, ws=ops.attn_decode_workspace(B, nq, nkv, Lmax, dev),
+                    cache=[(torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev), torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev))
+                           for _ in range(c.num_hidden_layers)])
+
+    # ------------------------------------------------------------------ API
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, max_new_tokens: int, attention_mask: torch.Tensor | None = None, past_key_values=None,
+                 past_lens: torch.Tensor | None = None, eos_token_id: int | None = None, return_logits: bool = False):
+        """Greedy continuation.  ``input_ids`` [B,P]: the NEW prompt tokens (right-padded rows need ``attention_mask``; with
+        ``past_key_values`` all rows must be full length).  ``past_key_values``: per-layer K/V [B,nkv,S,d] of an already encoded
+        prefix, e.g. the bidirectional document pass of ``encode(get_cache=True)``; ``past_lens`` [B] = valid prefix tokens per row
+        (default S).  Returns the generated ids [B, max_new_tokens] (int64; positions after ``eos_token_id`` keep that id) and, with
+        ``return_logits``, the bf16 logits of every generated position [B, max_new_tokens, V]."""
+        dev, c = self.device, self.cfg
+        ids = input_ids.to(device=dev, dtype=I64)
+        B, P = ids.shape
+        if B > 8:
+            raise NotImplementedError("native decode: batch <= 8")
+        nq, nkv, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        past = _layers_of(past_key_values) if past_key_values is not None else None
+        S0 = past[0][0].shape[2] if past is not None else 0
+        Lmax = (S0 + P + max_new_tokens + 255) // 256 * 256
+        st = self._state(B, Lmax)
+        st["history"] = torch.zeros((B, max_new_tokens), dtype=I64, device=dev)
+        logits_all = torch.empty((B, max_new_tokens, self.lm_head.shape[0]), dtype=BF16, device=dev) if return_logits else None
+        if past is None:
+            # prefill: one causal pass over the prompt that also emits the post-RoPE K/V (the encoder engine's forward)
+            mask = torch.ones((B, P), dtype=I64, device=dev) if attention_mask is None else attention_mask.to(device=dev, dtype=I64)
+            was = self.eng.causal
+            self.eng.causal = True
+            try:
+                hidden, kv = self.eng.forward(ids, mask, borrow=True, return_kv=True)
+            finally:
+                self.eng.causal = was
+            for li, (k, v) in enumerate(kv):
+                st["cache"][li][0][:, :, :P].copy_(k); st["cache"][li][1][:, :, :P].copy_(v)
+            plen = mask.sum(dim=1).to(I32)
+            st["lens"].copy_(plen)
+            last = hidden[torch.arange(B, device=dev), (plen - 1).long()].contiguous()              # [B,H] final-norm output of the last prompt token
+            ops.gemv(last, self.lm_head, out=st["logits"])
+        else:
+            if attention_mask is not None and not bool((attention_mask != 0).all()):
+                raise NotImplementedError("native decode: padded prompt rows on top of past_key_values")
+            for li, (k, v) in enumerate(past):
+                st["cache"][li][0][:, :, :S0].copy_(k.to(dev)); st["cache"][li][1][:, :, :S0].copy_(v.to(dev))
+            st["lens"].copy_(torch.full((B,), S0, dtype=I32, device=dev) if past_lens is None else past_lens.to(device=dev, dtype=I32))
+            # the prompt rides on the decode path, one token per step (teacher forced): its K/V land behind the cached prefix
+            for t in range(P):
+                st["next"].copy_(ids[:, t])
+                self._step(st)
+                st["lens"] += 1
+        # first generated token from the prefill logits, then decode steps (graph replay)
+        if return_logits:
+            logits_all[:, 0].copy_(st["logits"])
+        ops.argmax_advance(st["logits"], st["next"], None, st["history"], st["step"])
+        graph = None
+        for t in range(1, max_new_tokens):
+            if graph is not None:
+                graph.replay()
+            else:
+                self._step(st)
+                self._sample_step(st, logits_all, t)
+                if self.use_graph and logits_all is None and t + 1 < max_new_tokens:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._step(st)
+                        self._sample(st)
+        out = st["history"]
+        if eos_token_id is not None:
+            hit = (out == eos_token_id).long().cumsum(dim=1) > 0
+            out = torch.where(hit, torch.full_like(out, eos_token_id), out)
+        return (out, logits_all) if return_logits else out
+
+    def _sample_step(self, st, logits_all, t):
+        if logits_all is not None:
+            logits_all[:, t].copy_(st["logits"])
+        self._sample(st)

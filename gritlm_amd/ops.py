@@ -390,6 +390,49 @@ def attn_bidir_varlen_bwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: 
     return dqkv
 
 
+def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE,
+         residual: torch.Tensor | None = None) -> torch.Tensor:
+    """out[B,N] = x[B,K] @ w[N,K]^T for B <= 8 rows (decode); same epilogues as gemm_nt."""
+    B, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((B, n_out), dtype=BF16, device=x.device)
+    check(_lib.load().grit_gemv_bf16(_chk2d(x, BF16, "x"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), B, N, K, x.stride(0), w.stride(0),
+                                     out.stride(0), epilogue, 0 if residual is None else _chk2d(residual, BF16, "residual"),
+                                     0 if residual is None else residual.stride(0), _stream()), "grit_gemv_bf16")
+    return out
+
+
+def kv_append(qkv: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor, nq: int, nkv: int, d: int):
+    B, _, Lmax, _ = cache_k.shape
+    check(_lib.load().grit_kv_append(_chk2d(qkv, BF16, "qkv"), _chk(cache_k, BF16, "cache_k"), _chk(cache_v, BF16, "cache_v"),
+                                     _chk(lens, I32, "lens"), B, nq, nkv, d, Lmax, qkv.stride(0), _stream()), "grit_kv_append")
+
+
+def attn_decode_workspace(B: int, nq: int, nkv: int, Lmax: int, device) -> torch.Tensor:
+    return torch.empty((int(_lib.load().grit_attn_decode_workspace_floats(B, nq, nkv, Lmax)),), dtype=F32, device=device)
+
+
+def attn_decode(q: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor,
+                nq: int, nkv: int, d: int, scale: float | None = None):
+    B, _, Lmax, _ = cache_k.shape
+    check(_lib.load().grit_attn_decode(_chk2d(q, BF16, "q"), _chk(cache_k, BF16, "cache_k"), _chk(cache_v, BF16, "cache_v"), _chk(lens, I32, "lens"),
+                                       _chk2d(out, BF16, "out"), _chk(workspace, F32, "workspace"), B, nq, nkv, d, Lmax, q.stride(0), out.stride(0),
+                                       float(d ** -0.5 if scale is None else scale), _stream()), "grit_attn_decode")
+    return out
+
+
+def argmax_advance(logits: torch.Tensor, next_ids: torch.Tensor, lens: torch.Tensor | None = None, history: torch.Tensor | None = None,
+                   step: torch.Tensor | None = None):
+    B, V = logits.shape
+    check(_lib.load().grit_argmax_advance(_chk2d(logits, BF16, "logits"), logits.stride(0), V, _chk(next_ids, I64, "next"),
+                                          0 if lens is None else _chk(lens, I32, "lens"), 0 if history is None else _chk(history, I64, "history"),
+                                          0 if history is None else history.stride(0), 0 if step is None else _chk(step, I32, "step"), B,
+                                          _stream()), "grit_argmax_advance")
+    return next_ids
+
+
 def ce_fwd(logits: torch.Tensor, labels: torch.Tensor):
     """(lse [T], loss_row [T]) fp32 of bf16 logits [T,V] against int64 labels (-100 ignored)."""
     T, V = logits.shape

@@ -225,6 +225,26 @@ int grit_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* ls
 int grit_ce_bwd(void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* dev_scale, float scale, int64_t T,
                 int V, void* stream);
 
+/* ---- token-by-token decode (generation from cached document KV): rag/eval.py:237-302, gritlm.py:131-140 ---------- */
+
+/* out[b,:] = x[b,:] W^T for 1..8 rows (HBM-bound GEMV; larger batches: grit_gemm_bf16_nt).  Epilogues as the GEMM:
+ * STORE, RESIDUAL (out = bf16(xW^T) + residual), SWIGLU (W = interleaved gate/up rows, out [B, N/2]). */
+int grit_gemv_bf16(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
+                   int epilogue, const void* residual, int64_t ldr, void* stream);
+/* Append the (already rotated) k, v of one new token per sequence: qkv [B, qkv_stride] -> cache_{k,v}[b, h, lens[b], :],
+ * caches [B, nkv, Lmax, d] bf16 (the layout encode(get_cache=True) returns per layer), lens int32 [B] on the device. */
+int grit_kv_append(const void* qkv, void* cache_k, void* cache_v, const int32_t* lens, int B, int nq, int nkv, int d, int Lmax,
+                   int64_t qkv_stride, void* stream);
+/* One query row per sequence and head against keys 0..lens[b] of the cache (flash-decoding split + combine), head_dim 128.
+ * q [B, q_stride] (heads at h*d), out [B, out_stride]; workspace: grit_attn_decode_workspace_floats(...) fp32. */
+int64_t grit_attn_decode_workspace_floats(int B, int nq, int nkv, int Lmax);
+int grit_attn_decode(const void* q, const void* cache_k, const void* cache_v, const int32_t* lens, void* out, float* workspace,
+                     int B, int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale, void* stream);
+/* Greedy step: next[b] = argmax_v logits[b,v] (bf16 logits, lowest index on ties); optionally history[b, *step] = next[b],
+ * *step += 1 and lens[b] += 1 -- all on the device, so a whole decode step is one HIP graph. */
+int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history,
+                        int64_t hist_stride, int32_t* step, int B, void* stream);
+
 /* embedding backward: dtable[ids[t], :] += dh[t, :]  (dtable fp32 [V,H], fp32 atomics) */
 int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream);
 

@@ -161,6 +161,7 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
         cos, sin = bf16_round(cos), bf16_round(sin)                       # :124-125
     layers = []
     routing = []
+    kv_layers = []
     for li in range(L):                                                   # :1045-1071
         p = f"layers.{li}."
         res = h
@@ -172,6 +173,7 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
         k = k.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
         v = v.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
         q = rnd(apply_rope(q, cos, sin)); k = rnd(apply_rope(k, cos, sin))             # :666-668
+        kv_layers.append((k.copy(), v.copy()))                                         # what use_cache=True hands back (:671-673)
         a = rnd(attention_bidirectional(q, k, v, attention_mask, acc_dtype, causal))              # :690-698
         a = rnd(a @ weights[p + "self_attn.o_proj.weight"].T)                          # :703
         h = rnd(res + a)                                                               # :769
@@ -192,9 +194,49 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
     out = rmsnorm(h, weights["norm.weight"], eps, emulate_bf16)                        # :1079
     if return_layers == "routing":
         return out, routing
+    if return_layers == "kv":
+        return out, kv_layers
     if return_layers:
         return out, layers
     return out
+
+
+def mistral_continue(weights: dict, cfg: dict, prefix_kv: list, prefix_len: int, cont_ids: np.ndarray, lm_head: np.ndarray):
+    """Causal continuation on top of a cached prefix, one sequence: what ``model.generate(cont_ids, past_key_values=prefix_kv)`` computes
+    in the reference's RAG flow (rag/eval.py:237-246, :296-302) -- the prefix K/V (per layer [1,Hkv,S,d], post-RoPE; e.g. from the
+    bidirectional document pass, gritlm.py:131-140) are attended to in full, the continuation tokens causally, positions continue at
+    prefix_len.  Returns the fp32 logits [P, V] of every continuation position."""
+    H = cfg["hidden_size"]; L = cfg["num_hidden_layers"]
+    nh = cfg["num_attention_heads"]; nkv = cfg["num_key_value_heads"]
+    d = cfg.get("head_dim") or H // nh
+    eps = cfg["rms_norm_eps"]
+    P = int(cont_ids.shape[0])
+    h = weights["embed_tokens.weight"][cont_ids][None].astype(F32)                       # [1,P,H]
+    cos, sin = rope_tables(prefix_len + P, d, cfg["rope_theta"])
+    cos, sin = cos[prefix_len:], sin[prefix_len:]
+    for li in range(L):
+        p = f"layers.{li}."
+        x = rmsnorm(h, weights[p + "input_layernorm.weight"], eps)
+        q = (x @ weights[p + "self_attn.q_proj.weight"].T).reshape(1, P, nh, d).transpose(0, 2, 1, 3)
+        k = (x @ weights[p + "self_attn.k_proj.weight"].T).reshape(1, P, nkv, d).transpose(0, 2, 1, 3)
+        v = (x @ weights[p + "self_attn.v_proj.weight"].T).reshape(1, P, nkv, d).transpose(0, 2, 1, 3)
+        q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+        pk, pv = prefix_kv[li]
+        kk = np.concatenate([pk[:, :, :prefix_len].astype(F64), k.astype(F64)], axis=2)
+        vv = np.concatenate([pv[:, :, :prefix_len].astype(F64), v.astype(F64)], axis=2)
+        kk, vv = np.repeat(kk, nh // nkv, axis=1), np.repeat(vv, nh // nkv, axis=1)
+        sc = np.matmul(q.astype(F64), kk.transpose(0, 1, 3, 2)) / np.sqrt(d)            # [1,nh,P,prefix+P]
+        allowed = np.concatenate([np.ones((P, prefix_len), dtype=bool), np.tril(np.ones((P, P), dtype=bool))], axis=1)
+        sc = sc + np.where(allowed, 0.0, -np.inf)[None, None]
+        sc = sc - sc.max(-1, keepdims=True)
+        pr = np.exp(sc); pr /= pr.sum(-1, keepdims=True)
+        a = np.matmul(pr, vv).transpose(0, 2, 1, 3).reshape(1, P, nh * d).astype(F32)
+        h = h + a @ weights[p + "self_attn.o_proj.weight"].T
+        x = rmsnorm(h, weights[p + "post_attention_layernorm.weight"], eps)
+        m = (silu(x @ weights[p + "mlp.gate_proj.weight"].T) * (x @ weights[p + "mlp.up_proj.weight"].T)) @ weights[p + "mlp.down_proj.weight"].T
+        h = (h + m).astype(F32)
+    out = rmsnorm(h, weights["norm.weight"], eps)
+    return (out[0] @ lm_head.T).astype(F32)
 
 
 def next_token_loss(logits: np.ndarray, labels: np.ndarray, loss_gen_type: str = "mixed", loss_gen_factor: float = 1.0) -> float:

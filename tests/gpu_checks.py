@@ -767,6 +767,96 @@ def check_generative_step(kind="mixed"):
     return _res(f"native generative step [{kind}] vs reference loss_gen+grads", bool(ok), **out)
 
 
+def check_gemv(B=3, N=1030, K=512, epi=EPI_STORE, seed=85):
+    x, w = rnd((B, K), seed), rnd((N, K), seed + 1, 0.05)
+    ref = f32(bf(x)).astype(np.float64) @ f32(bf(w)).astype(np.float64).T
+    if epi == EPI_RESIDUAL:
+        r = rnd((B, N), seed + 2)
+        out = f32(ops.gemv(bf(x), bf(w), epilogue=epi, residual=bf(r)))
+        ref = O.bf16_round(ref.astype(np.float32)).astype(np.float64) + f32(bf(r))
+    elif epi == EPI_SWIGLU:
+        I = N // 2
+        wi = swiglu_interleave(bf(w[:I]), bf(w[I:]))
+        out = f32(ops.gemv(bf(x), wi, epilogue=epi))
+        gq, uq = O.bf16_round(ref[:, :I].astype(np.float32)), O.bf16_round(ref[:, I:].astype(np.float32))
+        ref = (O.bf16_round(O.silu(gq.astype(np.float64)).astype(np.float32)) * uq).astype(np.float64)
+        # the fused GEMM epilogue must agree with the GEMV on the same rows (the prefill and the decode path of one model)
+        big = f32(ops.gemm_nt(bf(np.repeat(x, 8, axis=0)), wi, epilogue=epi))[::8]
+        same = float(np.max(np.abs(big - out)))
+    else:
+        out = f32(ops.gemv(bf(x), bf(w)))
+    scale = float(np.sqrt(np.mean(ref ** 2))) + 1e-9
+    err = float(np.max(np.abs(out - ref) / (1.2e-2 * np.abs(ref) + 1e-2 * scale)))
+    return _res(f"gemv[B={B},N={N},K={K},epi={epi}]", err < 1.0, max_err_over_tol=err)
+
+
+def check_attn_decode(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
+    d = 128
+    rng = np.random.default_rng(87)
+    ck, cv = rnd((B, nkv, Lmax, d), 88, 0.7), rnd((B, nkv, Lmax, d), 89)
+    q = rnd((B, (nq + 2 * nkv) * d), 90, 0.7)
+    tl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    tck, tcv, tq = bf(ck), bf(cv), bf(q)
+    out = torch.empty((B, nq * d), dtype=torch.bfloat16, device=DEV)
+    ops.attn_decode(tq, tck, tcv, tl, out, ops.attn_decode_workspace(B, nq, nkv, Lmax, DEV), nq, nkv, d)
+    got = f32(out).reshape(B, nq, d)
+    worst = 0.0
+    for b in range(B):
+        L = lens[b] + 1
+        for h in range(nq):
+            kk, vv = f32(tck)[b, h // (nq // nkv), :L].astype(np.float64), f32(tcv)[b, h // (nq // nkv), :L].astype(np.float64)
+            sc = kk @ f32(tq)[b, h * d:(h + 1) * d].astype(np.float64) / np.sqrt(d)
+            p = np.exp(sc - sc.max()); p /= p.sum()
+            worst = max(worst, float(np.max(np.abs(got[b, h] - p @ vv))))
+    return _res(f"attn_decode[B={B},nq={nq},nkv={nkv},lens={list(lens)}]", worst < 1e-2 and not np.isnan(got).any(), max_abs=worst)
+
+
+def check_native_generate(cfg_name="tiny", P=21, new=10):
+    """Greedy generation on the native decoder: logits of every generated position vs the fp32 oracle run over the same token
+    sequence (a) from a plain prompt (causal prefill), (b) on top of the cached K/V of a bidirectionally encoded document (the RAG
+    doc-caching flow); tokens agree with the oracle's argmax wherever its top-2 margin is clear; HIP-graph replay == eager launches."""
+    from gritlm_amd.decoder import MistralDecoder
+    eng, cfg, w = build_engine(cfg_name, 6)
+    rng = np.random.default_rng(97)
+    lm = O.bf16_round((rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"])) * 0.05).astype(np.float32))
+    dec = MistralDecoder(eng, torch.from_numpy(lm))
+    prompt = rng.integers(3, cfg["vocab_size"], size=(2, P)).astype(np.int64)
+    ok, out = True, {}
+
+    def judge(tag, toks, logits, ref_logits):
+        nonlocal ok
+        err = float(np.max(np.abs(logits - ref_logits)))
+        srt = np.sort(ref_logits, axis=-1)
+        clear = (srt[..., -1] - srt[..., -2]) > 4 * err + 1e-3
+        agree = (toks == ref_logits.argmax(-1))[clear]
+        out[f"{tag}_logit_abs_err"] = err; out[f"{tag}_logit_std"] = float(ref_logits.std()); out[f"{tag}_clear_frac"] = float(clear.mean())
+        ok &= err < 0.06 * float(ref_logits.std()) + 2e-2 and bool(agree.all())
+
+    # (a) plain prompt
+    toks, lg = dec.generate(torch.from_numpy(prompt).to(DEV), new, return_logits=True)
+    toks, lg = toks.cpu().numpy(), f32(lg)
+    for b in range(2):
+        seq = np.concatenate([prompt[b], toks[b]])[None]
+        h = O.mistral_encode(w, cfg, seq, np.ones_like(seq), causal=True)
+        judge(f"prompt{b}", toks[b], lg[b], (h[0] @ lm.T)[P - 1:P - 1 + new])
+    dec.use_graph = True
+    t_graph = dec.generate(torch.from_numpy(prompt).to(DEV), new).cpu().numpy()
+    dec.use_graph = False
+    t_eager = dec.generate(torch.from_numpy(prompt).to(DEV), new).cpu().numpy()
+    ok &= np.array_equal(t_graph, toks) and np.array_equal(t_eager, toks)
+    # (b) document prefix (bidirectional) + query continuation
+    doc = rng.integers(3, cfg["vocab_size"], size=(1, 70)).astype(np.int64)
+    _, kv = eng.forward(torch.from_numpy(doc).to(DEV), torch.ones((1, 70), dtype=torch.int64, device=DEV), return_kv=True)
+    toks2, lg2 = dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, past_key_values=kv, return_logits=True)
+    toks2, lg2 = toks2.cpu().numpy()[0], f32(lg2)[0]
+    _, kv_ref = O.mistral_encode(w, cfg, doc, np.ones_like(doc), return_layers="kv")
+    ref2 = O.mistral_continue(w, cfg, kv_ref, 70, np.concatenate([prompt[0], toks2]), lm)[P - 1:P - 1 + new]
+    judge("doc_prefix", toks2, lg2, ref2)
+    dec.use_graph = True
+    ok &= np.array_equal(dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, past_key_values=kv).cpu().numpy()[0], toks2)
+    return _res(f"native greedy generation [{cfg_name}] vs oracle (prompt prefill, document-KV prefix, graph replay)", bool(ok), **out)
+
+
 def check_cli_native():
     """python -m gritlm.training.run on the GPU: bf16 tiny Mistral, (instruction, text) rows, GradCache switch, native engine."""
     import json
@@ -1109,6 +1199,14 @@ ALL_CHECKS = [
     ("ce_vocab32000", check_ce, dict(T=40, V=32000)),
     ("generative_mixed", check_generative_step, dict(kind="mixed")),
     ("generative_token", check_generative_step, dict(kind="token")),
+    ("gemv", check_gemv, {}),
+    ("gemv_b1_7b", check_gemv, dict(B=1, N=6144, K=4096)),
+    ("gemv_b8_residual", check_gemv, dict(B=8, N=515, K=1024, epi=EPI_RESIDUAL)),
+    ("gemv_swiglu", check_gemv, dict(B=2, N=1024, K=256, epi=EPI_SWIGLU)),
+    ("attn_decode", check_attn_decode, {}),
+    ("attn_decode_gqa4_b1", check_attn_decode, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
+    ("native_generate", check_native_generate, {}),
+    ("native_generate_gqa", check_native_generate, dict(cfg_name="gqa", P=9, new=6)),
     ("cli_native", check_cli_native, {}),
     ("cli_unified_native", check_cli_unified_native, {}),
     ("overlapped_grad_sync", check_overlapped_grad_sync, {}),

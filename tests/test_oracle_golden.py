@@ -133,6 +133,24 @@ def test_generative_branch_matches_reference(golden_dir):
         assert abs(got - float(g[f"loss_gen_{kind}"])) < 2e-4 * max(1.0, abs(got)), (kind, got, float(g[f"loss_gen_{kind}"]))
 
 
+def test_prefix_continuation_consistent_with_pinned_causal_encode(golden_dir):
+    """mistral_continue (generation on top of cached K/V) == the causal encode pinned by generative_tiny.npz when the prefix K/V
+    come from a causal pass; a bidirectional (document) prefix gives different logits."""
+    g = _load(golden_dir, "generative_tiny.npz")
+    cfg = synth.CONFIGS["tiny"]
+    w = synth.make_weights(cfg, 0)
+    ids = g["input_ids"][:1, :40]
+    ones = np.ones_like(ids)
+    h, kv = O.mistral_encode(w, cfg, ids, ones, causal=True, return_layers="kv")
+    full = h[0] @ g["lm_head"].T
+    assert np.abs(full - g["logits"][0, :40]).max() < 3e-4          # (prefix of a causal sequence is independent of what follows)
+    cont = O.mistral_continue(w, cfg, kv, 25, ids[0, 25:], g["lm_head"])
+    assert np.abs(cont - full[25:]).max() < 1e-4
+    _, kv_bi = O.mistral_encode(w, cfg, ids[:, :25], ones[:, :25], causal=False, return_layers="kv")
+    cont_bi = O.mistral_continue(w, cfg, kv_bi, 25, ids[0, 25:], g["lm_head"])
+    assert np.abs(cont_bi - cont).max() > 1e-2
+
+
 def test_moe_router_topk_and_renormalisation():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((64, 32)).astype(np.float32)
