@@ -18,20 +18,22 @@ __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
          bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
 }
 
-constexpr int GV_ROWS = 4;  // weight rows per wave (loads of 4 rows in flight per lane)
+constexpr int GV_ROWS = 4;  // weight rows per workgroup; its 4 waves each take a quarter of K (split-K, LDS reduce)
 
-// MODE 0: store, 1: + residual, 2: SwiGLU pairs (rows r, r+16 of the interleaved layout)
-template <int NB, int MODE>
+// MODE 0: store, 1: + residual, 2: SwiGLU pairs (rows r, r+16 of the interleaved layout).
+// PRENORM: x is the raw residual stream and the kernel applies MistralRMSNorm on the fly (x_n = bf16(w_ln * bf16(x * rsqrt(mean x^2 + eps))),
+// modeling_mistral_gritlm.py:84-89) -- saves the separate RMSNorm launch of a decode step (a 1-row kernel is pure launch latency).
+template <int NB, int MODE, bool PRENORM>
 __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
-                                                   const uint16_t* __restrict__ res, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
-                                                   int64_t ldr) {
+                                                   const uint16_t* __restrict__ res, const uint16_t* __restrict__ ln_w, float eps, int B, int N,
+                                                   int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr) {
+  __shared__ float red[4][GV_ROWS][NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wave;                     // one unit = GV_ROWS weight rows
+  const int unit = blockIdx.x;                                // one unit = GV_ROWS weight rows
   int rows[GV_ROWS];
   if (MODE == 2) {
     // unit covers 2 (gate, up) pairs: pair p -> gate row (p/16)*32 + p%16, up row = gate row + 16
     const int p0 = unit * 2;
-    if (p0 >= N / 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int p = p0 + i; if (p > N / 2 - 1) p = N / 2 - 1;
@@ -40,23 +42,45 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     }
   } else {
     const int r0 = unit * GV_ROWS;
-    if (r0 >= N) return;
 #pragma unroll
     for (int i = 0; i < GV_ROWS; ++i) rows[i] = r0 + i < N ? r0 + i : N - 1;
+  }
+  const int KC = K >> 3;
+  float inv[NB];
+  if (PRENORM) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float ss = 0.f;
+      const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)(b < B ? b : 0) * ldx);
+      for (int c = lane; c < KC; c += 64) {
+        const uint4 v = xr[c];
+        ss += bflo(v.x) * bflo(v.x) + bfhi(v.x) * bfhi(v.x) + bflo(v.y) * bflo(v.y) + bfhi(v.y) * bfhi(v.y) + bflo(v.z) * bflo(v.z) +
+              bfhi(v.z) * bfhi(v.z) + bflo(v.w) * bflo(v.w) + bfhi(v.w) * bfhi(v.w);
+      }
+      inv[b] = rsqrtf(wave_sum(ss) / (float)K + eps);
+    }
   }
   float acc[GV_ROWS][NB];
 #pragma unroll
   for (int i = 0; i < GV_ROWS; ++i)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
-  const int KC = K >> 3;
-  for (int c = lane; c < KC; c += 64) {
+  for (int c = wave * 64 + lane; c < KC; c += 256) {
     uint4 wv[GV_ROWS];
 #pragma unroll
     for (int i = 0; i < GV_ROWS; ++i) wv[i] = reinterpret_cast<const uint4*>(W + (int64_t)rows[i] * ldw)[c];
+    uint4 lw = make_uint4(0, 0, 0, 0);
+    if (PRENORM) lw = reinterpret_cast<const uint4*>(ln_w)[c];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const uint4 xv = reinterpret_cast<const uint4*>(x + (int64_t)(b < B ? b : 0) * ldx)[c];
+      uint4 xv = reinterpret_cast<const uint4*>(x + (int64_t)(b < B ? b : 0) * ldx)[c];
+      if (PRENORM) {
+        const float s_ = inv[b];
+        xv.x = pack2bf(round_bf(bflo(xv.x) * s_) * bflo(lw.x), round_bf(bfhi(xv.x) * s_) * bfhi(lw.x));
+        xv.y = pack2bf(round_bf(bflo(xv.y) * s_) * bflo(lw.y), round_bf(bfhi(xv.y) * s_) * bfhi(lw.y));
+        xv.z = pack2bf(round_bf(bflo(xv.z) * s_) * bflo(lw.z), round_bf(bfhi(xv.z) * s_) * bfhi(lw.z));
+        xv.w = pack2bf(round_bf(bflo(xv.w) * s_) * bflo(lw.w), round_bf(bfhi(xv.w) * s_) * bfhi(lw.w));
+      }
 #pragma unroll
       for (int i = 0; i < GV_ROWS; ++i) acc[i][b] += dot8(wv[i], xv);
     }
@@ -64,29 +88,70 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
 #pragma unroll
   for (int i = 0; i < GV_ROWS; ++i)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[i][b] = wave_sum(acc[i][b]);
-  if (lane != 0) return;
-  if (MODE == 2) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p = unit * 2 + i;
-      if (p >= N / 2) break;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        if (b < B) out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_d(round_bf(acc[2 * i][b]))) * round_bf(acc[2 * i + 1][b]));
+    for (int b = 0; b < NB; ++b) {
+      const float v = wave_sum(acc[i][b]);
+      if (lane == 0) red[wave][i][b] = v;
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < GV_ROWS; ++i) {
-      const int n = unit * GV_ROWS + i;
-      if (n >= N) break;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (b >= B) continue;
-        float v = acc[i][b];
-        if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
-        out[(int64_t)b * ldo + n] = (uint16_t)f2bf(v);
+  __syncthreads();
+  // thread t < GV_ROWS*NB finishes output (row i, batch b)
+  const int t = threadIdx.x;
+  if (MODE == 2) {
+    if (t < 2 * NB) {
+      const int i = t / NB, b = t - i * NB, p = unit * 2 + i;
+      if (p < N / 2 && b < B) {
+        const float g = red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b];
+        const float u = red[0][2 * i + 1][b] + red[1][2 * i + 1][b] + red[2][2 * i + 1][b] + red[3][2 * i + 1][b];
+        out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_d(round_bf(g))) * round_bf(u));
       }
+    }
+  } else if (t < GV_ROWS * NB) {
+    const int i = t / NB, b = t - i * NB, n = unit * GV_ROWS + i;
+    if (n < N && b < B) {
+      float v = red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b];
+      if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
+      out[(int64_t)b * ldo + n] = (uint16_t)f2bf(v);
+    }
+  }
+}
+
+// ---- RoPE of the new token's q, k (at position lens[b]) + append of its k, v to the cache, one launch.
+//      qkv [B, qkv_stride] (q rotated in place), cache [B, nkv, Lmax, d], tables [Lmax, d/2] fp32 (rounded like the encoder's).
+__global__ void __launch_bounds__(256) rope_kv_append_k(uint16_t* __restrict__ qkv, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                        uint16_t* __restrict__ ck, uint16_t* __restrict__ cv, const int32_t* __restrict__ lens, int nq,
+                                                        int nkv, int d, int Lmax, int64_t qkv_stride) {
+  const int b = blockIdx.x;
+  const int pos = lens[b];
+  if (pos >= Lmax) return;
+  const int half = d >> 1, jc_n = d >> 4;               // 16-B chunks per half head
+  uint16_t* row = qkv + (int64_t)b * qkv_stride;
+  const int rot_items = (nq + nkv) * jc_n, cp_items = nkv * (d >> 3);
+  for (int i = threadIdx.x; i < rot_items + cp_items; i += 256) {
+    if (i < rot_items) {
+      const int head = i / jc_n, jc = i - head * jc_n;
+      uint16_t* base = row + (int64_t)head * d + jc * 8;
+      const uint4 x1 = *reinterpret_cast<const uint4*>(base), x2 = *reinterpret_cast<const uint4*>(base + half);
+      const float* ct = cos_tab + (int64_t)pos * half + jc * 8;
+      const float* stb = sin_tab + (int64_t)pos * half + jc * 8;
+      const uint32_t a[4] = {x1.x, x1.y, x1.z, x1.w}, bb[4] = {x2.x, x2.y, x2.z, x2.w};
+      uint32_t o1[4], o2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c0 = ct[2 * e], c1 = ct[2 * e + 1], s0 = stb[2 * e], s1 = stb[2 * e + 1];
+        const float a0 = bflo(a[e]), a1 = bfhi(a[e]), b0 = bflo(bb[e]), b1 = bfhi(bb[e]);
+        o1[e] = pack2bf(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);      // x*cos + rotate_half(x)*sin, first half: -x2 * sin
+        o2[e] = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);      // second half: +x1 * sin
+      }
+      const uint4 r1 = make_uint4(o1[0], o1[1], o1[2], o1[3]), r2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+      if (head < nq) {
+        *reinterpret_cast<uint4*>(base) = r1; *reinterpret_cast<uint4*>(base + half) = r2;
+      } else {
+        uint16_t* dst = ck + (((int64_t)b * nkv + (head - nq)) * Lmax + pos) * d + jc * 8;
+        *reinterpret_cast<uint4*>(dst) = r1; *reinterpret_cast<uint4*>(dst + half) = r2;
+      }
+    } else {
+      const int j = i - rot_items, h = j / (d >> 3), c = j - h * (d >> 3);
+      const uint4 v = reinterpret_cast<const uint4*>(row + (int64_t)(nq + nkv + h) * d)[c];
+      reinterpret_cast<uint4*>(cv + (((int64_t)b * nkv + h) * Lmax + pos) * d)[c] = v;
     }
   }
 }
@@ -107,40 +172,42 @@ __global__ void __launch_bounds__(256) kv_append_k(const uint16_t* __restrict__ 
   }
 }
 
-// ---- decode attention, head_dim 128.  grid (splits, nkv, B), 256 threads = 4 waves x 64 keys = 256 keys per workgroup.
-constexpr int AD_D = 128, AD_CH = 256, AD_G = 8;   // up to 8 query heads per kv head
-__global__ void __launch_bounds__(256) attn_decode_k(const uint16_t* __restrict__ q, const uint16_t* __restrict__ ck,
-                                                     const uint16_t* __restrict__ cv, const int32_t* __restrict__ lens, float* __restrict__ part,
-                                                     int nq, int nkv, int Lmax, int64_t q_stride, float scale, int max_splits) {
+// ---- decode attention, head_dim 128.  grid (splits of 64 keys, nkv, B), ONE wave per workgroup: at 1-8 sequences the work is tiny, what
+//      matters is that every 64-key slice of the cache is read by its own wave somewhere on the chip (2 k keys x 8 kv heads = 264 waves).
+constexpr int AD_D = 128, AD_CH = 64, AD_G = 8;   // up to 8 query heads per kv head
+__global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__ q, const uint16_t* __restrict__ ck,
+                                                    const uint16_t* __restrict__ cv, const int32_t* __restrict__ lens, float* __restrict__ part,
+                                                    int nq, int nkv, int Lmax, int64_t q_stride, float scale, int max_splits) {
   __shared__ float qs[AD_G][AD_D];           // query heads of this kv head, pre-scaled
-  __shared__ float ps[4][AD_G][64];          // per wave: probabilities of its 64 keys
-  __shared__ float ws_m[4][AD_G], ws_l[4][AD_G];
-  __shared__ float wo[4][AD_G][AD_D];
+  __shared__ float ps[AD_G][64];             // probabilities of the 64 keys
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x;
   const int G = nq / nkv;
   const int L = lens[b] + 1;                 // keys 0 .. lens[b] (the new token was appended)
   const int k0 = split * AD_CH;
   float* pbase = part + (((int64_t)b * nkv + hk) * max_splits + split) * G * (AD_D + 2);
   if (k0 >= L) {                             // empty split: neutral element
-    for (int i = tid; i < G * (AD_D + 2); i += 256) pbase[i] = (i % (AD_D + 2) == 0) ? -INFINITY : 0.f;
+    for (int i = lane; i < G * (AD_D + 2); i += 64) pbase[i] = (i % (AD_D + 2) == 0) ? -INFINITY : 0.f;
     return;
   }
-  for (int i = tid; i < G * AD_D; i += 256) {
+  for (int i = lane; i < G * AD_D; i += 64) {
     const int g = i / AD_D, e = i - g * AD_D;
     qs[g][e] = bf2f(q[(int64_t)b * q_stride + (int64_t)(hk * G + g) * AD_D + e]) * scale;
   }
   __syncthreads();
-  const int key = k0 + wave * 64 + lane;
+  const int key = k0 + lane;
   const bool live = key < L;
   float s[AD_G];
 #pragma unroll
   for (int g = 0; g < AD_G; ++g) s[g] = 0.f;
   {
     const uint4* kr = reinterpret_cast<const uint4*>(ck + (((int64_t)b * nkv + hk) * Lmax + (live ? key : L - 1)) * AD_D);
-#pragma unroll 4
+    uint4 kreg[AD_D / 8];
+#pragma unroll
+    for (int c = 0; c < AD_D / 8; ++c) kreg[c] = kr[c];       // 16 independent loads in flight
+#pragma unroll
     for (int c = 0; c < AD_D / 8; ++c) {
-      const uint4 kv = kr[c];
+      const uint4 kv = kreg[c];
       const float kf[8] = {bflo(kv.x), bfhi(kv.x), bflo(kv.y), bfhi(kv.y), bflo(kv.z), bfhi(kv.z), bflo(kv.w), bfhi(kv.w)};
 #pragma unroll
       for (int g = 0; g < AD_G; ++g) {
@@ -150,70 +217,84 @@ __global__ void __launch_bounds__(256) attn_decode_k(const uint16_t* __restrict_
       }
     }
   }
+  float mg[AD_G], lg[AD_G];
 #pragma unroll
   for (int g = 0; g < AD_G; ++g) {
     if (g >= G) break;
     const float sv = live ? s[g] : -INFINITY;
-    const float m = wave_max(sv);
-    const float p = live ? __expf(sv - m) : 0.f;
-    const float l = wave_sum(p);
-    ps[wave][g][lane] = p;
-    if (lane == 0) { ws_m[wave][g] = m; ws_l[wave][g] = l; }
+    mg[g] = wave_max(sv);
+    const float p = live ? __expf(sv - mg[g]) : 0.f;
+    lg[g] = wave_sum(p);
+    ps[g][lane] = p;
   }
   __syncthreads();
-  // O partial of this wave: lane owns dims 2*lane, 2*lane+1
-  float o[AD_G][2];
+  // O partial: lane = (key group kg = lane>>4, dim chunk dc = lane&15): 16 INDEPENDENT 16-byte loads per lane (keys kg*16 .. +15, dims
+  // 8dc .. +7), then the 4 key groups are folded with two shuffles -- one memory latency instead of one per key
+  const int kg = lane >> 4, dc = lane & 15;
+  const int nk = min(64, L - k0);
+  const uint16_t* vbase = cv + (((int64_t)b * nkv + hk) * Lmax + k0) * AD_D;
+  uint4 vreg[16];
 #pragma unroll
-  for (int g = 0; g < AD_G; ++g) { o[g][0] = 0.f; o[g][1] = 0.f; }
-  const int nk = min(64, L - (k0 + wave * 64));
-  const uint32_t* vr = reinterpret_cast<const uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + k0 + wave * 64) * AD_D) + lane;
-  for (int j = 0; j < nk; ++j) {
-    const uint32_t vv = vr[(int64_t)j * (AD_D / 2)];
-    const float v0 = bflo(vv), v1 = bfhi(vv);
-#pragma unroll
-    for (int g = 0; g < AD_G; ++g) {
-      if (g >= G) break;
-      const float p = ps[wave][g][j];
-      o[g][0] += p * v0; o[g][1] += p * v1;
-    }
+  for (int j = 0; j < 16; ++j) {
+    const int kk = kg * 16 + j;
+    vreg[j] = reinterpret_cast<const uint4*>(vbase + (int64_t)(kk < nk ? kk : nk - 1) * AD_D)[dc];
   }
 #pragma unroll
   for (int g = 0; g < AD_G; ++g) {
     if (g >= G) break;
-    wo[wave][g][2 * lane] = o[g][0]; wo[wave][g][2 * lane + 1] = o[g][1];
-  }
-  __syncthreads();
-  // combine the 4 waves -> one partial per (head): [m, l, o[128]]
-  for (int i = tid; i < G * AD_D; i += 256) {
-    const int g = i / AD_D, e = i - g * AD_D;
-    float m = -INFINITY;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 4; ++w) m = fmaxf(m, ws_m[w][g]);
-    float l = 0.f, acc = 0.f;
+    for (int j = 0; j < 16; ++j) {
+      const float p = ps[g][kg * 16 + j];            // 0 for keys past the sequence
+      const uint4 v = vreg[j];
+      o[0] += p * bflo(v.x); o[1] += p * bfhi(v.x); o[2] += p * bflo(v.y); o[3] += p * bfhi(v.y);
+      o[4] += p * bflo(v.z); o[5] += p * bfhi(v.z); o[6] += p * bflo(v.w); o[7] += p * bfhi(v.w);
+    }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float f = ws_m[w][g] == -INFINITY ? 0.f : __expf(ws_m[w][g] - m);
-      l += ws_l[w][g] * f; acc += wo[w][g][e] * f;
+    for (int e = 0; e < 8; ++e) {
+      o[e] += __shfl_xor(o[e], 16, 64);
+      o[e] += __shfl_xor(o[e], 32, 64);
     }
     float* pg = pbase + g * (AD_D + 2);
-    pg[2 + e] = acc;
-    if (e == 0) { pg[0] = m; pg[1] = l; }
+    if (kg == 0) {
+      *reinterpret_cast<float4*>(pg + 2 + 8 * dc) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(pg + 2 + 8 * dc + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (lane == 0) { pg[0] = mg[g]; pg[1] = lg[g]; }
   }
 }
 
 __global__ void __launch_bounds__(128) attn_decode_combine_k(const float* __restrict__ part, uint16_t* __restrict__ out, int nq, int nkv,
                                                              int max_splits, int64_t out_stride) {
+  __shared__ float fs[512];                  // per split: exp(m_s - m) ; [max_splits] then l in fs[max_splits]
+  __shared__ float red[2];
   const int h = blockIdx.x, b = blockIdx.y, e = threadIdx.x;
   const int G = nq / nkv, hk = h / G, g = h - hk * G;
-  const float* base = part + ((int64_t)b * nkv + hk) * max_splits * G * (AD_D + 2) + g * (AD_D + 2);
+  const int64_t sstride = (int64_t)G * (AD_D + 2);
+  const float* base = part + ((int64_t)b * nkv + hk) * max_splits * sstride + g * (AD_D + 2);
+  // pass 1 (parallel over the splits): global max and the per-split rescale factors
   float m = -INFINITY;
-  for (int s = 0; s < max_splits; ++s) m = fmaxf(m, base[(int64_t)s * G * (AD_D + 2)]);
-  float l = 0.f, acc = 0.f;
-  for (int s = 0; s < max_splits; ++s) {
-    const float* ps_ = base + (int64_t)s * G * (AD_D + 2);
-    const float f = ps_[0] == -INFINITY ? 0.f : __expf(ps_[0] - m);
-    l += ps_[1] * f; acc += ps_[2 + e] * f;
+  for (int s = e; s < max_splits; s += 128) m = fmaxf(m, base[s * sstride]);
+  m = wave_max(m);
+  if ((e & 63) == 0) red[e >> 6] = m;
+  __syncthreads();
+  m = fmaxf(red[0], red[1]);
+  float l = 0.f;
+  for (int s = e; s < max_splits; s += 128) {
+    const float ms = base[s * sstride];
+    const float f = ms == -INFINITY ? 0.f : __expf(ms - m);
+    fs[s] = f;
+    l += base[s * sstride + 1] * f;
   }
+  l = wave_sum(l);
+  __syncthreads();
+  if ((e & 63) == 0) red[e >> 6] = l;
+  __syncthreads();
+  l = red[0] + red[1];
+  // pass 2: thread e owns output dim e; the loads of different splits are independent
+  float acc = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < max_splits; ++s) acc += base[s * sstride + 2 + e] * fs[s];
   out[(int64_t)b * out_stride + (int64_t)h * AD_D + e] = (uint16_t)f2bf(l > 0.f ? acc / l : 0.f);
 }
 
@@ -253,36 +334,63 @@ __global__ void bump_k(int32_t* v) { v[0] += 1; }
 
 using namespace grit;
 
-template <int MODE>
-static int launch_gemv(const void* x, const void* W, void* out, const void* res, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
-                       int64_t ldr, hipStream_t st) {
+template <int MODE, bool PRENORM>
+static int launch_gemv(const void* x, const void* W, void* out, const void* res, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
+                       int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st) {
   const int units = MODE == 2 ? (N / 2 + 1) / 2 : (N + GV_ROWS - 1) / GV_ROWS;
-  const dim3 grid((unsigned)((units + 3) / 4));
-#define GRIT_GEMV(NB_)                                                                                                                   \
-  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out, (const uint16_t*)res, \
-                     B, N, K, ldx, ldw, ldo, ldr)
+  const dim3 grid((unsigned)units);
+#define GRIT_GEMV(NB_)                                                                                                                    \
+  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out,   \
+                     (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr)
   if (B == 1) GRIT_GEMV(1); else if (B == 2) GRIT_GEMV(2); else if (B <= 4) GRIT_GEMV(4); else GRIT_GEMV(8);
+#undef GRIT_GEMV
   GRIT_CHECK_LAUNCH("grit_gemv_bf16");
+  return GRIT_OK;
+}
+
+static int gemv_entry(const char* name, const void* x, const void* W, void* out, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
+                      int64_t ldw, int64_t ldo, int epilogue, const void* residual, int64_t ldr, void* stream) {
+  if (B == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && W && out, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && B <= 8, GRIT_E_UNSUPPORTED, "%s: B=%d rows (1..8; larger batches use grit_gemm_bf16_nt)", name, B);
+  GRIT_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(aligned16(x) && aligned16(W) && (!ln_w || aligned16(ln_w)), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  hipStream_t st = (hipStream_t)stream;
+  const bool pn = ln_w != nullptr;
+  switch (epilogue) {
+    case GRIT_EPI_STORE: GRIT_REQUIRE(ldo >= N, GRIT_E_BADARG, "%s: ldo < N", name);
+      return pn ? launch_gemv<0, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                : launch_gemv<0, false>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+    case GRIT_EPI_RESIDUAL: GRIT_REQUIRE(residual && ldo >= N && ldr >= N && !pn, GRIT_E_BADARG, "%s: RESIDUAL needs residual, ldo, ldr >= N (no pre-norm)", name);
+      return launch_gemv<1, false>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
+    case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "%s: SWIGLU needs N %% 32 == 0, ldo >= N/2", name);
+      return pn ? launch_gemv<2, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                : launch_gemv<2, false>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+    default: GRIT_REQUIRE(false, GRIT_E_BADARG, "%s: unknown epilogue %d", name, epilogue);
+  }
   return GRIT_OK;
 }
 
 extern "C" int grit_gemv_bf16(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int epilogue,
                               const void* residual, int64_t ldr, void* stream) {
+  return gemv_entry("grit_gemv_bf16", x, W, out, nullptr, 0.f, B, N, K, ldx, ldw, ldo, epilogue, residual, ldr, stream);
+}
+
+extern "C" int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K, int64_t ldx,
+                                      int64_t ldw, int64_t ldo, int epilogue, void* stream) {
+  GRIT_REQUIRE(ln_weight, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16: null pointer");
+  return gemv_entry("grit_rmsnorm_gemv_bf16", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream);
+}
+
+extern "C" int grit_rope_kv_append(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens, int B,
+                                   int nq, int nkv, int d, int Lmax, int64_t qkv_stride, void* stream) {
   if (B == 0) return GRIT_OK;
-  GRIT_REQUIRE(x && W && out, GRIT_E_BADARG, "grit_gemv_bf16: null pointer");
-  GRIT_REQUIRE(B > 0 && B <= 8, GRIT_E_UNSUPPORTED, "grit_gemv_bf16: B=%d rows (1..8; larger batches use grit_gemm_bf16_nt)", B);
-  GRIT_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K, GRIT_E_BADARG, "grit_gemv_bf16: bad sizes");
-  GRIT_REQUIRE(aligned16(x) && aligned16(W), GRIT_E_BADARG, "grit_gemv_bf16: pointers must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  switch (epilogue) {
-    case GRIT_EPI_STORE: GRIT_REQUIRE(ldo >= N, GRIT_E_BADARG, "grit_gemv_bf16: ldo < N");
-      return launch_gemv<0>(x, W, out, nullptr, B, N, K, ldx, ldw, ldo, 0, st);
-    case GRIT_EPI_RESIDUAL: GRIT_REQUIRE(residual && ldo >= N && ldr >= N, GRIT_E_BADARG, "grit_gemv_bf16: RESIDUAL needs residual, ldo, ldr >= N");
-      return launch_gemv<1>(x, W, out, residual, B, N, K, ldx, ldw, ldo, ldr, st);
-    case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemv_bf16: SWIGLU needs N %% 32 == 0, ldo >= N/2");
-      return launch_gemv<2>(x, W, out, nullptr, B, N, K, ldx, ldw, ldo, 0, st);
-    default: GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemv_bf16: unknown epilogue %d", epilogue);
-  }
+  GRIT_REQUIRE(qkv && cos_tab && sin_tab && cache_k && cache_v && lens, GRIT_E_BADARG, "grit_rope_kv_append: null pointer");
+  GRIT_REQUIRE(B > 0 && nq > 0 && nkv > 0 && d % 16 == 0 && Lmax > 0 && qkv_stride % 8 == 0, GRIT_E_BADARG, "grit_rope_kv_append: bad sizes");
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(cache_k) && aligned16(cache_v), GRIT_E_BADARG, "grit_rope_kv_append: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(rope_kv_append_k, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv, cos_tab, sin_tab, (uint16_t*)cache_k,
+                     (uint16_t*)cache_v, lens, nq, nkv, d, Lmax, qkv_stride);
+  GRIT_CHECK_LAUNCH("grit_rope_kv_append");
   return GRIT_OK;
 }
 
@@ -310,9 +418,10 @@ extern "C" int grit_attn_decode(const void* q, const void* cache_k, const void* 
   GRIT_REQUIRE(d == AD_D, GRIT_E_UNSUPPORTED, "grit_attn_decode: head_dim=%d (only 128 is built)", d);
   GRIT_REQUIRE(nq % nkv == 0 && nq / nkv <= AD_G, GRIT_E_UNSUPPORTED, "grit_attn_decode: %d query heads per kv head (max %d)", nq / nkv, AD_G);
   GRIT_REQUIRE(B > 0 && Lmax > 0 && B <= 65535 && nkv <= 65535, GRIT_E_BADARG, "grit_attn_decode: bad sizes");
+  GRIT_REQUIRE((Lmax + AD_CH - 1) / AD_CH <= 512, GRIT_E_UNSUPPORTED, "grit_attn_decode: Lmax=%d > %d", Lmax, 512 * AD_CH);
   const int splits = (Lmax + AD_CH - 1) / AD_CH;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_decode_k, dim3((unsigned)splits, (unsigned)nkv, (unsigned)B), dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)cache_k,
+  hipLaunchKernelGGL(attn_decode_k, dim3((unsigned)splits, (unsigned)nkv, (unsigned)B), dim3(64), 0, st, (const uint16_t*)q, (const uint16_t*)cache_k,
                      (const uint16_t*)cache_v, lens, workspace, nq, nkv, Lmax, q_stride, scale, splits);
   GRIT_CHECK_LAUNCH("grit_attn_decode");
   hipLaunchKernelGGL(attn_decode_combine_k, dim3((unsigned)nq, (unsigned)B), dim3(AD_D), 0, st, (const float*)workspace, (uint16_t*)out, nq, nkv,

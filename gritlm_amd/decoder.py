@@ -3,7 +3,7 @@
 Replaces, for the RAG doc-caching flow of the reference (rag/eval.py:237-302: ``model.generate(inputs, past_key_values=kv_cache)`` where
 ``kv_cache`` came from ``encode(..., get_cache=True)``, gritlm/gritlm.py:131-140), the Hugging Face decode loop: every projection of a
 decode step is an HBM-bound GEMV (``grit_gemv_bf16``), attention reads the sequence's KV once (``grit_attn_decode``), the new token's
-K/V are appended in place, sampling is a device-side argmax -- and the whole step (~290 launches at 32 layers) is captured in ONE HIP
+K/V are appended in place, sampling is a device-side argmax -- and the whole step (6 launches per layer) is captured in ONE HIP
 graph, so the host only replays it.  Greedy decoding only (``do_sample=False``), batch <= 8, head_dim 128.
 """
 from __future__ import annotations
@@ -36,21 +36,17 @@ class MistralDecoder:
     def _step(self, st):
         c, e = self.cfg, self.eng
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
-        h, x, qkv, ctx, act = st["h"], st["x"], st["qkv"], st["ctx"], st["act"]
+        h, qkv, ctx, act = st["h"], st["qkv"], st["ctx"], st["act"]
         ops.embed_gather(e.embed, st["next"], out=h)
         for li, L in enumerate(e.layers):
             ck, cv = st["cache"][li]
-            ops.rmsnorm(h, L.ln1, eps, out=x)
-            ops.gemv(x, L.wqkv, out=qkv)
-            ops.rope_qk_pos_(qkv, st["cos"], st["sin"], st["lens"], nq, nkv, d)
-            ops.kv_append(qkv, ck, cv, st["lens"], nq, nkv, d)
+            ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv)                      # input_layernorm + q/k/v projections
+            ops.rope_kv_append(qkv, st["cos"], st["sin"], ck, cv, st["lens"], nq, nkv, d)
             ops.attn_decode(qkv, ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)
             ops.gemv(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
-            ops.rmsnorm(h, L.ln2, eps, out=x)
-            ops.gemv(x, L.wgu, out=act, epilogue=EPI_SWIGLU)
+            ops.rmsnorm_gemv(h, L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU)   # post_attention_layernorm + gate/up + SwiGLU
             ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
-        ops.rmsnorm(h, e.norm, eps, out=x)
-        ops.gemv(x, self.lm_head, out=st["logits"])
+        ops.rmsnorm_gemv(h, e.norm, eps, self.lm_head, out=st["logits"])           # final norm + lm_head
 
     def _sample(self, st):
         ops.argmax_advance(st["logits"], st["next"], st["lens"], st["history"], st["step"])

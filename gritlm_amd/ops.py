@@ -404,6 +404,28 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epil
     return out
 
 
+def rmsnorm_gemv(x: torch.Tensor, ln_w: torch.Tensor, eps: float, w: torch.Tensor, out: torch.Tensor | None = None,
+                 epilogue: int = EPI_STORE) -> torch.Tensor:
+    """gemv(rmsnorm(x, ln_w, eps), w) in one launch (decode step)."""
+    B, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((B, n_out), dtype=BF16, device=x.device)
+    check(_lib.load().grit_rmsnorm_gemv_bf16(_chk2d(x, BF16, "x"), _chk(ln_w, BF16, "ln_w"), float(eps), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"),
+                                             B, N, K, x.stride(0), w.stride(0), out.stride(0), epilogue, _stream()), "grit_rmsnorm_gemv_bf16")
+    return out
+
+
+def rope_kv_append(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor,
+                   nq: int, nkv: int, d: int):
+    B, _, Lmax, _ = cache_k.shape
+    assert cos.shape[0] >= Lmax
+    check(_lib.load().grit_rope_kv_append(_chk2d(qkv, BF16, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"), _chk(cache_k, BF16, "cache_k"),
+                                          _chk(cache_v, BF16, "cache_v"), _chk(lens, I32, "lens"), B, nq, nkv, d, Lmax, qkv.stride(0), _stream()),
+          "grit_rope_kv_append")
+
+
 def kv_append(qkv: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor, nq: int, nkv: int, d: int):
     B, _, Lmax, _ = cache_k.shape
     check(_lib.load().grit_kv_append(_chk2d(qkv, BF16, "qkv"), _chk(cache_k, BF16, "cache_k"), _chk(cache_v, BF16, "cache_v"),

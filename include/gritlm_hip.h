@@ -231,6 +231,14 @@ int grit_ce_bwd(void* logits, int64_t ld, const int64_t* labels, const float* ls
  * STORE, RESIDUAL (out = bf16(xW^T) + residual), SWIGLU (W = interleaved gate/up rows, out [B, N/2]). */
 int grit_gemv_bf16(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
                    int epilogue, const void* residual, int64_t ldr, void* stream);
+/* The same GEMV with MistralRMSNorm (:84-89) applied to x on the fly (x is the raw residual stream, ln_weight [K] bf16): saves the
+ * separate 1-row RMSNorm launch of a decode step.  Epilogues STORE and SWIGLU. */
+int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K,
+                           int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
+/* RoPE (:138-163) of the new token's q and k at position lens[b] + append of its k, v to the cache, one launch: q is rotated in place in
+ * qkv [B, qkv_stride]; cos/sin tables [Lmax, d/2] fp32 as grit_rope_qk_inplace. */
+int grit_rope_kv_append(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens, int B,
+                        int nq, int nkv, int d, int Lmax, int64_t qkv_stride, void* stream);
 /* Append the (already rotated) k, v of one new token per sequence: qkv [B, qkv_stride] -> cache_{k,v}[b, h, lens[b], :],
  * caches [B, nkv, Lmax, d] bf16 (the layout encode(get_cache=True) returns per layer), lens int32 [B] on the device. */
 int grit_kv_append(const void* qkv, void* cache_k, void* cache_v, const int32_t* lens, int B, int nq, int nkv, int d, int Lmax,

@@ -790,6 +790,29 @@ def check_gemv(B=3, N=1030, K=512, epi=EPI_STORE, seed=85):
     return _res(f"gemv[B={B},N={N},K={K},epi={epi}]", err < 1.0, max_err_over_tol=err)
 
 
+def check_decode_fused_ops(B=2, H=512, N=768, nq=4, nkv=2, Lmax=256):
+    """rmsnorm+gemv == gemv(rmsnorm) bit for bit; rope+kv-append == rope_qk_pos_ + kv_append bit for bit."""
+    d = 128
+    x, lnw, w = bf(rnd((B, H), 91)), bf(1.0 + 0.1 * rnd((H,), 92)), bf(rnd((N, H), 93, 0.05))
+    a = ops.rmsnorm_gemv(x, lnw, 1e-5, w)
+    b = ops.gemv(ops.rmsnorm(x, lnw, 1e-5), w)
+    ok = bool(torch.equal(a, b))
+    wi = swiglu_interleave(w[:N // 2], w[N // 2:])
+    ok &= bool(torch.equal(ops.rmsnorm_gemv(x, lnw, 1e-5, wi, epilogue=EPI_SWIGLU), ops.gemv(ops.rmsnorm(x, lnw, 1e-5), wi, epilogue=EPI_SWIGLU)))
+    from gritlm_amd.encoder import rope_tables
+    cos, sin = rope_tables(Lmax, d, 10000.0, True, DEV)
+    qkv = bf(rnd((B, (nq + 2 * nkv) * d), 94))
+    lens = torch.tensor([200, 7][:B], dtype=torch.int32, device=DEV)
+    ck1, cv1 = torch.zeros((B, nkv, Lmax, d), dtype=torch.bfloat16, device=DEV), torch.zeros((B, nkv, Lmax, d), dtype=torch.bfloat16, device=DEV)
+    ck2, cv2 = ck1.clone(), cv1.clone()
+    q1, q2 = qkv.clone(), qkv.clone()
+    ops.rope_kv_append(q1, cos, sin, ck1, cv1, lens, nq, nkv, d)
+    ops.rope_qk_pos_(q2, cos, sin, lens, nq, nkv, d)
+    ops.kv_append(q2, ck2, cv2, lens, nq, nkv, d)
+    ok &= bool(torch.equal(q1[:, :nq * d], q2[:, :nq * d])) and bool(torch.equal(ck1, ck2)) and bool(torch.equal(cv1, cv2)) and float(ck1.abs().sum()) > 0
+    return _res("decode fused ops (rmsnorm+gemv, rope+kv-append) == unfused kernels", ok)
+
+
 def check_attn_decode(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
     d = 128
     rng = np.random.default_rng(87)
@@ -1203,6 +1226,7 @@ ALL_CHECKS = [
     ("gemv_b1_7b", check_gemv, dict(B=1, N=6144, K=4096)),
     ("gemv_b8_residual", check_gemv, dict(B=8, N=515, K=1024, epi=EPI_RESIDUAL)),
     ("gemv_swiglu", check_gemv, dict(B=2, N=1024, K=256, epi=EPI_SWIGLU)),
+    ("decode_fused_ops", check_decode_fused_ops, {}),
     ("attn_decode", check_attn_decode, {}),
     ("attn_decode_gqa4_b1", check_attn_decode, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
     ("native_generate", check_native_generate, {}),

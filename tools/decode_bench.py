@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Decode-step microbenchmark at the GritLM-7B shape: ms per generated token on top of a cached prefix (native decoder, HIP graph).
+python tools/decode_bench.py [--prefix 2048 --new 128 --batch 1]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from gritlm_amd.decoder import MistralDecoder  # noqa: E402
+from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--prefix", type=int, default=2048)
+ap.add_argument("--new", type=int, default=128)
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--layers", type=int, default=32)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+cfg = EncoderConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=a.layers, num_attention_heads=32, num_key_value_heads=8, vocab_size=32000)
+eng = MistralEncoderEngine.random_init(cfg, dev, seed=0)
+lm_head = (torch.randn((32000, 4096), device=dev) * 0.02).to(torch.bfloat16)
+dec = MistralDecoder(eng, lm_head)
+g = torch.Generator(device=dev).manual_seed(3)
+doc = torch.randint(3, 32000, (a.batch, a.prefix), generator=g, device=dev)
+_, kv = eng.forward(doc, torch.ones_like(doc), return_kv=True)
+q = torch.randint(3, 32000, (a.batch, 4), generator=g, device=dev)
+dec.generate(q, 8, past_key_values=kv)
+torch.cuda.synchronize()
+res = {}
+for n in (a.new, 3 * a.new):
+    t0 = time.perf_counter()
+    dec.generate(q, n, past_key_values=kv)
+    torch.cuda.synchronize()
+    res[n] = time.perf_counter() - t0
+ms = (res[3 * a.new] - res[a.new]) / (2 * a.new) * 1e3
+wbytes = (sum(sum(getattr(L, k).numel() for k in ("wqkv", "wo", "wgu", "wdown")) for L in eng.layers) + lm_head.numel()) * 2
+print(json.dumps({"metric": "native decode ms per token (7B shape)", "ms_per_token": ms, "tokens_per_s": a.batch * 1e3 / ms, "batch": a.batch,
+                  "prefix": a.prefix, "weight_gb_per_token": wbytes / 1e9, "hbm_roofline_ms": wbytes / 8e12 * 1e3, "frac_of_hbm_roofline": wbytes / 8e12 * 1e3 / ms}))
