@@ -32,10 +32,10 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
   const int unit = blockIdx.x;                                // one unit = GV_ROWS weight rows
   int rows[GV_ROWS];
   if (MODE == 2) {
-    // unit covers 2 (gate, up) pairs: pair p -> gate row (p/16)*32 + p%16, up row = gate row + 16
-    const int p0 = unit * 2;
+    // unit covers GV_ROWS/2 (gate, up) pairs: pair p -> gate row (p/16)*32 + p%16, up row = gate row + 16
+    const int p0 = unit * (GV_ROWS / 2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < GV_ROWS / 2; ++i) {
       int p = p0 + i; if (p > N / 2 - 1) p = N / 2 - 1;
       rows[2 * i] = (p >> 4) * 32 + (p & 15);
       rows[2 * i + 1] = rows[2 * i] + 16;
@@ -96,8 +96,8 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
   // thread t < GV_ROWS*NB finishes output (row i, batch b)
   const int t = threadIdx.x;
   if (MODE == 2) {
-    if (t < 2 * NB) {
-      const int i = t / NB, b = t - i * NB, p = unit * 2 + i;
+    if (t < (GV_ROWS / 2) * NB) {
+      const int i = t / NB, b = t - i * NB, p = unit * (GV_ROWS / 2) + i;
       if (p < N / 2 && b < B) {
         const float g = red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b];
         const float u = red[0][2 * i + 1][b] + red[1][2 * i + 1][b] + red[2][2 * i + 1][b] + red[3][2 * i + 1][b];
@@ -337,7 +337,7 @@ using namespace grit;
 template <int MODE, bool PRENORM>
 static int launch_gemv(const void* x, const void* W, void* out, const void* res, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
                        int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st) {
-  const int units = MODE == 2 ? (N / 2 + 1) / 2 : (N + GV_ROWS - 1) / GV_ROWS;
+  const int units = MODE == 2 ? (N / 2 + GV_ROWS / 2 - 1) / (GV_ROWS / 2) : (N + GV_ROWS - 1) / GV_ROWS;
   const dim3 grid((unsigned)units);
 #define GRIT_GEMV(NB_)                                                                                                                    \
   hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out,   \

@@ -38,6 +38,8 @@ class MistralDecoder:
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         h, qkv, ctx, act = st["h"], st["qkv"], st["ctx"], st["act"]
         ops.embed_gather(e.embed, st["next"], out=h)
+        if h.shape[0] > 2:
+            return self._step_unfused_norm(st)
         for li, L in enumerate(e.layers):
             ck, cv = st["cache"][li]
             ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv)                      # input_layernorm + q/k/v projections
@@ -47,6 +49,24 @@ class MistralDecoder:
             ops.rmsnorm_gemv(h, L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU)   # post_attention_layernorm + gate/up + SwiGLU
             ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
         ops.rmsnorm_gemv(h, e.norm, eps, self.lm_head, out=st["logits"])           # final norm + lm_head
+
+    def _step_unfused_norm(self, st):
+        """More than 2 rows: every workgroup of the fused kernel would re-derive each row's RMS, so the norm gets its own launch."""
+        c, e = self.cfg, self.eng
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        h, x, qkv, ctx, act = st["h"], st["x"], st["qkv"], st["ctx"], st["act"]
+        for li, L in enumerate(e.layers):
+            ck, cv = st["cache"][li]
+            ops.rmsnorm(h, L.ln1, eps, out=x)
+            ops.gemv(x, L.wqkv, out=qkv)
+            ops.rope_kv_append(qkv, st["cos"], st["sin"], ck, cv, st["lens"], nq, nkv, d)
+            ops.attn_decode(qkv, ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)
+            ops.gemv(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.rmsnorm(h, L.ln2, eps, out=x)
+            ops.gemv(x, L.wgu, out=act, epilogue=EPI_SWIGLU)
+            ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+        ops.rmsnorm(h, e.norm, eps, out=x)
+        ops.gemv(x, self.lm_head, out=st["logits"])
 
     def _sample(self, st):
         ops.argmax_advance(st["logits"], st["next"], st["lens"], st["history"], st["step"])

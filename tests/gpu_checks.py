@@ -834,7 +834,7 @@ def check_attn_decode(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
     return _res(f"attn_decode[B={B},nq={nq},nkv={nkv},lens={list(lens)}]", worst < 1e-2 and not np.isnan(got).any(), max_abs=worst)
 
 
-def check_native_generate(cfg_name="tiny", P=21, new=10):
+def check_native_generate(cfg_name="tiny", P=21, new=10, rows=2):
     """Greedy generation on the native decoder: logits of every generated position vs the fp32 oracle run over the same token
     sequence (a) from a plain prompt (causal prefill), (b) on top of the cached K/V of a bidirectionally encoded document (the RAG
     doc-caching flow); tokens agree with the oracle's argmax wherever its top-2 margin is clear; HIP-graph replay == eager launches."""
@@ -843,7 +843,7 @@ def check_native_generate(cfg_name="tiny", P=21, new=10):
     rng = np.random.default_rng(97)
     lm = O.bf16_round((rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"])) * 0.05).astype(np.float32))
     dec = MistralDecoder(eng, torch.from_numpy(lm))
-    prompt = rng.integers(3, cfg["vocab_size"], size=(2, P)).astype(np.int64)
+    prompt = rng.integers(3, cfg["vocab_size"], size=(rows, P)).astype(np.int64)      # rows > 2: the un-fused RMSNorm decode step
     ok, out = True, {}
 
     def judge(tag, toks, logits, ref_logits):
@@ -858,7 +858,7 @@ def check_native_generate(cfg_name="tiny", P=21, new=10):
     # (a) plain prompt
     toks, lg = dec.generate(torch.from_numpy(prompt).to(DEV), new, return_logits=True)
     toks, lg = toks.cpu().numpy(), f32(lg)
-    for b in range(2):
+    for b in range(rows):
         seq = np.concatenate([prompt[b], toks[b]])[None]
         h = O.mistral_encode(w, cfg, seq, np.ones_like(seq), causal=True)
         judge(f"prompt{b}", toks[b], lg[b], (h[0] @ lm.T)[P - 1:P - 1 + new])
@@ -1230,7 +1230,7 @@ ALL_CHECKS = [
     ("attn_decode", check_attn_decode, {}),
     ("attn_decode_gqa4_b1", check_attn_decode, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
     ("native_generate", check_native_generate, {}),
-    ("native_generate_gqa", check_native_generate, dict(cfg_name="gqa", P=9, new=6)),
+    ("native_generate_gqa", check_native_generate, dict(cfg_name="gqa", P=9, new=6, rows=3)),
     ("cli_native", check_cli_native, {}),
     ("cli_unified_native", check_cli_unified_native, {}),
     ("overlapped_grad_sync", check_overlapped_grad_sync, {}),
