@@ -135,6 +135,16 @@ class GritLM(torch.nn.Module):
         self.engine.causal = self.attn[:2] == "cc"       # 'cc..': causal embedding attention (e.g. lasttoken / weightedmean models)
         self.engine.sliding_window = getattr(cfg, "sliding_window", None)
 
+    def native_decoder(self):
+        """Greedy decoder on the HIP kernels (gritlm_amd.decoder.MistralDecoder) sharing the engine's weights; use it where the reference
+        calls ``model.generate(..., past_key_values=kv_cache)`` on the cache returned by ``encode(get_cache=True)`` (rag/eval.py:296-302)."""
+        if self.engine is None or not hasattr(self.model, "lm_head"):
+            raise RuntimeError("native_decoder: needs the native engine and a causal-LM checkpoint (mode 'unified' or 'generative')")
+        if getattr(self, "_decoder", None) is None:
+            from .decoder import MistralDecoder
+            self._decoder = MistralDecoder(self.engine, self.model.lm_head.weight)
+        return self._decoder
+
     # ------------------------------------------------------------------ API
     def encode_queries(self, queries: Union[List[str], str], **kwargs) -> np.ndarray:
         """Queries of retrieval / reranking tasks."""

@@ -1061,7 +1061,24 @@ def check_get_cache():
             e = float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-9))
             worst = max(worst, e)
     ok &= worst < 3e-2
-    return _res("encode(get_cache=True): native KV vs Hugging Face KV", ok, emb_1_minus_cos=one_minus_cos, kv_max_rel=worst)
+    # the RAG flow end to end on the drop-in: document cache -> native greedy continuation vs Hugging Face generate() on the same cache
+    # (first-position logits; later tokens of a random-init model are decided by near-ties)
+    with torch.no_grad():
+        from transformers import DynamicCache
+        q = m.tokenizer([" ".join(synth.WORDS[5:12])], return_tensors="pt", add_special_tokens=False)["input_ids"].to(DEV)
+        one = [(get(cache, li)[0][:1], get(cache, li)[1][:1]) for li in range(2)]
+        plen = int(m.tokenizer([sents[0]], return_tensors="pt", truncation=True, max_length=48)["input_ids"].shape[1])
+        one = [(k[:, :, :plen].contiguous(), v[:, :, :plen].contiguous()) for k, v in one]
+        toks, lg = m.native_decoder().generate(q, 3, past_key_values=one, return_logits=True)
+        pc = DynamicCache()
+        for li, (k, v) in enumerate(one):
+            pc.update(k.clone(), v.clone(), li)
+        hf_lg = m.model(input_ids=q, past_key_values=pc, attention_mask=torch.ones((1, plen + q.shape[1]), dtype=torch.long, device=DEV),
+                        position_ids=torch.arange(plen, plen + q.shape[1], device=DEV).unsqueeze(0)).logits[0, -1].float()
+    dl = float((lg[0, 0].float() - hf_lg).abs().max())
+    ok &= dl < 0.05 * float(hf_lg.std()) + 2e-2 and tuple(toks.shape) == (1, 3)
+    return _res("encode(get_cache=True): native KV vs Hugging Face KV; native decode from the cache vs HF", ok, emb_1_minus_cos=one_minus_cos,
+                kv_max_rel=worst, decode_logit_abs_vs_hf=dl, hf_logit_std=float(hf_lg.std()))
 
 
 def _overlap_worker(rank, world, port, model_dir, ret):
