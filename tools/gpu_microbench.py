@@ -87,4 +87,5 @@ if __name__ == "__main__":
     gemm_case(8192, 8192, 8192, EPI_STORE, "square8k")
     attn_case(256, 512)
     attn_case(16, 2048)
+    attn_case(4, 8192)
     hbm_cases()
