@@ -255,16 +255,28 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  // 16-byte stores: v_permlane32_swap exchanges the two 32-lane halves of the register groups g and g+1, so that a lane ends up with
+  // 8 CONSECUTIVE dims of its row (half 0: group g, half 1: group g+1) -- 8 stores per lane instead of 16 eight-byte ones (guide T21)
+  uint4 ost[4][2];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      float a[4], bq[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[db][8 * gp + e] * inv_l), __float_as_uint(oacc[db][8 * gp + 4 + e] * inv_l),
+                                                         false, false);
+        a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
+      }
+      ost[db][gp] = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(bq[0], bq[1]), pack2bf(bq[2], bq[3]));
+    }
   if (q_row < S) {
-    uint16_t* op = out + (row0 + q_row) * out_stride + (int64_t)h * ATT_D + 4 * hi;
+    uint16_t* op = out + (row0 + q_row) * out_stride + (int64_t)h * ATT_D + 8 * hi;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint2 pk = make_uint2(pack2bf(oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l),
-                                    pack2bf(oacc[db][4 * g + 2] * inv_l, oacc[db][4 * g + 3] * inv_l));
-        *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = pk;
-      }
+      for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4*>(op + db * 32 + gp * 16) = ost[db][gp];
     if (lse != nullptr && hi == 0) {
       if constexpr (VARLEN) lse[(row0 + q_row) * nq + h] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;  // [T, nq]
       else lse[((int64_t)b * nq + h) * S + q_row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
@@ -282,7 +294,7 @@ static int attn_fwd_padded(const char* name, bool causal, const void* qkv, const
   GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "%s: bad sizes", name);
   GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
-  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 4 == 0 && out_stride >= (int64_t)nq * d,
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "%s: bad strides", name);
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
   GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "%s: grid too large", name);
@@ -303,7 +315,7 @@ static int attn_fwd_varlen(const char* name, bool causal, const void* qkv, const
   GRIT_REQUIRE(B > 0 && max_len > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "%s: bad sizes", name);
   GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
-  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 4 == 0 && out_stride >= (int64_t)nq * d,
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "%s: bad strides", name);
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
   GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "%s: grid too large", name);
