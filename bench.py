@@ -263,6 +263,10 @@ def main():
         ks = timer.summary()
         g = ks["gemm_bf16_nt"]
         achieved = g["work"] / (g["total_ms"] * 1e-3) / 1e12           # TFLOP/s over all launches == avg flops / avg duration
+        shapes = {t: {"launches": v["launches"], "avg_ms": v["total_ms"] / v["launches"], "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12}
+                  for t, v in g.get("by_tag", {}).items()}
+        att = [v for t, v in g.get("by_tag", {}).items() if t.startswith("N=6144,K=4096") or t.startswith("N=4096,K=4096")]
+        att_tf = sum(v["work"] for v in att) / (sum(v["total_ms"] for v in att) * 1e-3) / 1e12 if att else None
         docs_per_s = world * DOCS * args.steps / dt_max
         flops_per_doc = flops_per_token * SEQ
         line = {
@@ -276,7 +280,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_k", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(),
                          "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
-                         "avg_flops_per_launch": g["work"] / g["launches"]},
+                         "avg_flops_per_launch": g["work"] / g["launches"], "by_shape": shapes,
+                         "attention_gemms_qkv_oproj": None if att_tf is None else
+                         {"achieved": att_tf, "frac": att_tf / MFMA_BF16_PEAK_TFLOPS}},
             "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                             "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()},
         }

@@ -240,6 +240,19 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
   const int64_t mrow = m0 + wr * 128 + frow;
   const int ncol = n0 + wc * 64 + kq * 4;
+  // RESIDUAL: all 16 residual loads of the lane are issued up front (the fragment registers are dead by now), so the epilogue pays one
+  // memory latency instead of one per output row
+  uint4 rpre[8][2];
+  if constexpr (EPI == GRIT_EPI_RESIDUAL) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) {
+        const int64_t m = mrow + i * 16;
+        const int n = n0 + wc * 64 + (2 * jq + (kq & 1)) * 16 + (kq >> 1) * 8;
+        rpre[i][jq] = (m < M && n < N) ? *reinterpret_cast<const uint4*>(Rsd + m * ldr + n) : make_uint4(0, 0, 0, 0);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t m = mrow + i * 16;
@@ -279,7 +292,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
         if constexpr (EPI == GRIT_EPI_RESIDUAL) {
           // the reference rounds the Linear output to bf16 before the residual add (:769,:775)
-          const uint4 rv = *reinterpret_cast<const uint4*>(Rsd + m * ldr + n);
+          const uint4 rv = rpre[i][jp >> 1];
           const uint32_t ra[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[2 * e] = round_bf(v[2 * e]) + bflo(ra[e]); v[2 * e + 1] = round_bf(v[2 * e + 1]) + bfhi(ra[e]); }

@@ -22,10 +22,12 @@ class KernelTimer:
     def __init__(self):
         self.pairs: dict[str, list] = {}
         self.work: dict[str, float] = {}
+        self.tags: dict[str, list] = {}
 
-    def span(self, name: str, work: float = 0.0):
+    def span(self, name: str, work: float = 0.0, tag: str | None = None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.pairs.setdefault(name, []).append((a, b))
+        self.tags.setdefault(name, []).append((tag, work))
         self.work[name] = self.work.get(name, 0.0) + work
         return a, b
 
@@ -35,6 +37,13 @@ class KernelTimer:
         for name, pairs in self.pairs.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
             out[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), work=self.work[name])
+            by_tag = {}
+            for t, (tag, work) in zip(ms, self.tags[name]):
+                if tag is not None:
+                    d = by_tag.setdefault(tag, dict(launches=0, total_ms=0.0, work=0.0))
+                    d["launches"] += 1; d["total_ms"] += t; d["work"] += work
+            if by_tag:
+                out[name]["by_tag"] = by_tag
         return out
 
 
@@ -179,7 +188,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     if epilogue == EPI_RESIDUAL:
         assert residual is not None and residual.shape == (M, N)
         rp, ldr = _chk2d(residual, BF16, "residual"), residual.stride(0)
-    ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K) if _timer is not None else None
+    ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K, tag=f"N={N},K={K},epi={epilogue}") if _timer is not None else None
     if ev:
         ev[0].record()
     check(_lib.load().grit_gemm_bf16_nt(_chk2d(a, BF16, "a"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), M, N, K, a.stride(0),
