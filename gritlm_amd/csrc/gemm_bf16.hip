@@ -265,15 +265,18 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
         float o0[4], o1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          o0[r] = round_bf(silu_f(round_bf(acc[i][0][r]))) * round_bf(acc[i][1][r]);
-          o1[r] = round_bf(silu_f(round_bf(acc[i][2][r]))) * round_bf(acc[i][3][r]);
+          // bf16 roundings through v_cvt_pk_bf16_f32 (RNE, two per instruction) instead of the 5-op bit trick
+          const uint32_t gu0 = pack2bf_hw(acc[i][0][r], acc[i][1][r]), gu1 = pack2bf_hw(acc[i][2][r], acc[i][3][r]);
+          const uint32_t ss = pack2bf_hw(silu_f(bflo(gu0)), silu_f(bflo(gu1)));
+          o0[r] = bflo(ss) * bfhi(gu0);
+          o1[r] = bfhi(ss) * bfhi(gu1);
           const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o0[r]), __float_as_uint(o1[r]), false, false);
           o0[r] = __uint_as_float(sw[0]); o1[r] = __uint_as_float(sw[1]);
         }
         const int oc = (nb >> 1) + (kq & 1) * 16 + (kq >> 1) * 8;
         if (2 * oc < N)
-          *reinterpret_cast<uint4*>(C + m * ldc + oc) = make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]),
-                                                                  pack2bf(o1[2], o1[3]));
+          *reinterpret_cast<uint4*>(C + m * ldc + oc) = make_uint4(pack2bf_hw(o0[0], o0[1]), pack2bf_hw(o0[2], o0[3]), pack2bf_hw(o1[0], o1[1]),
+                                                                  pack2bf_hw(o1[2], o1[3]));
       }
     } else {
       // 16-byte stores: v_permlane16_swap exchanges the 16-lane rows of two adjacent n-fragments so that every lane ends up with
@@ -295,9 +298,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           const uint4 rv = rpre[i][jp >> 1];
           const uint32_t ra[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] = round_bf(v[2 * e]) + bflo(ra[e]); v[2 * e + 1] = round_bf(v[2 * e + 1]) + bfhi(ra[e]); }
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t rr = pack2bf_hw(v[2 * e], v[2 * e + 1]);
+            v[2 * e] = bflo(rr) + bflo(ra[e]); v[2 * e + 1] = bfhi(rr) + bfhi(ra[e]);
+          }
         }
-        const uint4 pk = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        const uint4 pk = make_uint4(pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3]), pack2bf_hw(v[4], v[5]), pack2bf_hw(v[6], v[7]));
         if (ABL == 11) { asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w)); continue; }   // timing experiment: no stores
         *reinterpret_cast<uint4*>(C + m * ldc + n) = pk;
       }
