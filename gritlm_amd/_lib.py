@@ -44,6 +44,8 @@ _SIGNATURES = {
     "grit_attn_decode_workspace_floats": (_l, [_i, _i, _i, _i]),
     "grit_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_argmax_advance": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _i, _p]),
+    "grit_knn_workspace_bytes": (_l, [_i, _l, _i]),
+    "grit_knn_topk": (_i, [_p, _p, _i, _l, _i, _l, _l, _i, _p, _p, _p, _p]),
     "grit_ce_fwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _p]),
     "grit_ce_bwd": (_i, [_p, _l, _p, _p, _p, _f, _l, _i, _p]),
     "grit_moe_router_top2": (_i, [_p, _p, _p, _p, _l, _i, _i, _p]),

@@ -131,6 +131,12 @@ static int launch_f32_gemm(const float* A, const float* B, float* C, int M, int 
   return GRIT_OK;
 }
 
+// shared with knn.hip (brute-force index search = the same similarity GEMM)
+int launch_f32_gemm_strided(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+                            int64_t ldc, float alpha, hipStream_t st) {
+  return launch_f32_gemm(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, st);
+}
+
 }  // namespace grit
 
 using namespace grit;

@@ -464,6 +464,25 @@ def argmax_advance(logits: torch.Tensor, next_ids: torch.Tensor, lens: torch.Ten
     return next_ids
 
 
+def knn_topk(queries: torch.Tensor, embeddings: torch.Tensor, k: int, transposed: bool = False):
+    """Brute-force inner-product search: (scores [Q,k] fp32 descending, indices [Q,k] int64).  ``embeddings`` is [N,H], or with
+    ``transposed=True`` the reference index layout [H,N] (rag/index.py:141); any strides."""
+    if queries.dtype != F32 or embeddings.dtype != F32:
+        raise TypeError("knn_topk: fp32 tensors expected")
+    Q, H = queries.shape
+    N = embeddings.shape[1] if transposed else embeddings.shape[0]
+    assert (embeddings.shape[0] if transposed else embeddings.shape[1]) == H
+    sn, sh = (embeddings.stride(1), embeddings.stride(0)) if transposed else (embeddings.stride(0), embeddings.stride(1))
+    ws = torch.empty((int(_lib.load().grit_knn_workspace_bytes(Q, N, k)),), dtype=torch.uint8, device=queries.device)
+    scores = torch.empty((Q, k), dtype=F32, device=queries.device)
+    index = torch.empty((Q, k), dtype=I64, device=queries.device)
+    if not embeddings.is_cuda:
+        raise _lib.GritHipError("knn_topk: tensors must live on the GPU; the native path has no CPU fallback")
+    check(_lib.load().grit_knn_topk(_chk(queries, F32, "queries"), embeddings.data_ptr(), Q, N, H, sn, sh, int(k), ws.data_ptr(), scores.data_ptr(),
+                                    index.data_ptr(), _stream()), "grit_knn_topk")
+    return scores, index
+
+
 def ce_fwd(logits: torch.Tensor, labels: torch.Tensor):
     """(lse [T], loss_row [T]) fp32 of bf16 logits [T,V] against int64 labels (-100 ignored)."""
     T, V = logits.shape

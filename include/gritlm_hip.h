@@ -253,6 +253,16 @@ int grit_attn_decode(const void* q, const void* cache_k, const void* cache_v, co
 int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history,
                         int64_t hist_stride, int32_t* step, int B, void* stream);
 
+/* ---- RAG index search: rag/index.py:97-104 (scores = queries @ embeddings; torch.topk) ------------------------ */
+
+/* Brute-force kNN by inner product.  queries [Q,H] fp32 (contiguous); embeddings: element (n,h) at n*emb_stride_n + h*emb_stride_h, so
+ * both the [N,H] layout and the reference's [H,N] index layout (index.py:141) are accepted; exact-f32 MFMA scores, then the k best per
+ * query (descending, lower index first on ties): out_scores [Q,k] fp32, out_index [Q,k] int64.  k <= 1024.
+ * workspace: grit_knn_workspace_bytes(Q, N, k) bytes of device memory. */
+int64_t grit_knn_workspace_bytes(int Q, int64_t N, int k);
+int grit_knn_topk(const float* queries, const float* embeddings, int Q, int64_t N, int H, int64_t emb_stride_n, int64_t emb_stride_h,
+                  int k, void* workspace, float* out_scores, int64_t* out_index, void* stream);
+
 /* embedding backward: dtable[ids[t], :] += dh[t, :]  (dtable fp32 [V,H], fp32 atomics) */
 int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream);
 

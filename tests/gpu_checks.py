@@ -880,6 +880,33 @@ def check_native_generate(cfg_name="tiny", P=21, new=10, rows=2):
     return _res(f"native greedy generation [{cfg_name}] vs oracle (prompt prefill, document-KV prefix, graph replay)", bool(ok), **out)
 
 
+def check_knn_topk(Q=5, N=10000, H=256, k=10, transposed=False):
+    """Index search (rag/index.py:97-104: queries @ embeddings, torch.topk) on the f32-MFMA similarity GEMM + chunked bitonic top-k vs
+    numpy: same neighbours (scores compared; indices wherever the score has no tie), descending order, both index layouts."""
+    rng = np.random.default_rng(101)
+    q = rng.standard_normal((Q, H)).astype(np.float32)
+    e = rng.standard_normal((N, H)).astype(np.float32)
+    e[7] = e[3]                                             # an exact tie: the lower index must come first
+    tq = torch.from_numpy(q).to(DEV)
+    te = torch.from_numpy(np.ascontiguousarray(e.T) if transposed else e).to(DEV)
+    sc, ix = ops.knn_topk(tq, te, k, transposed=transposed)
+    sc, ix = f32(sc), ix.cpu().numpy()
+    ref = q.astype(np.float64) @ e.astype(np.float64).T
+    order = np.argsort(-ref, axis=1, kind="stable")[:, :k]
+    ref_sc = np.take_along_axis(ref, order, axis=1)
+    ok = float(np.max(np.abs(sc - ref_sc))) < 1e-3 and bool((np.diff(sc, axis=1) <= 0).all())
+    gap = np.abs(np.diff(np.sort(ref, axis=1)[:, ::-1][:, :k + 1], axis=1)).min(axis=1) > 1e-4        # rows whose top-(k+1) has no near-tie
+    ok &= bool((ix[gap] == order[gap]).all()) and (gap.any() or k == N)      # k == N: the planted tie is in every row
+    got_sc = np.take_along_axis(ref, ix, axis=1)
+    ok &= float(np.max(np.abs(got_sc - ref_sc))) < 1e-3    # every returned index really has a top-k score
+    # tie order: wherever both 3 and 7 are returned, 3 precedes 7
+    for r in range(Q):
+        a, b = np.where(ix[r] == 3)[0], np.where(ix[r] == 7)[0]
+        if a.size and b.size:
+            ok &= a[0] < b[0]
+    return _res(f"knn_topk[Q={Q},N={N},H={H},k={k},transposed={transposed}]", bool(ok), max_score_err=float(np.max(np.abs(sc - ref_sc))))
+
+
 def check_cli_native():
     """python -m gritlm.training.run on the GPU: bf16 tiny Mistral, (instruction, text) rows, GradCache switch, native engine."""
     import json
@@ -1248,6 +1275,9 @@ ALL_CHECKS = [
     ("attn_decode_gqa4_b1", check_attn_decode, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
     ("native_generate", check_native_generate, {}),
     ("native_generate_gqa", check_native_generate, dict(cfg_name="gqa", P=9, new=6, rows=3)),
+    ("knn_topk", check_knn_topk, {}),
+    ("knn_topk_transposed_big", check_knn_topk, dict(Q=3, N=300000, H=128, k=100, transposed=True)),
+    ("knn_topk_small", check_knn_topk, dict(Q=2, N=37, H=64, k=37)),
     ("cli_native", check_cli_native, {}),
     ("cli_unified_native", check_cli_unified_native, {}),
     ("overlapped_grad_sync", check_overlapped_grad_sync, {}),
