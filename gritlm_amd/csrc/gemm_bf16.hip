@@ -61,11 +61,24 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // ---- XCD-aware tile id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group)
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3) : bid;
   const int group_sz = GM * tiles_n;
-  const int grp = wg / group_sz, first_m = grp * GM;
+  int grp, in_grp;
+  if (remap == 2) {
+    // grouped (MoE) launches: tile groups are dealt round-robin to the XCDs (XCD x runs groups x, x+8, ...), so the eight XCDs work
+    // on neighbouring row blocks -- i.e. on the SAME expert -- at any time and that expert's weights stay in the Infinity Cache;
+    // contiguous per-XCD ranges would keep all experts' weights (1.9 GB at the 8x7B shape) live at once
+    const int li = bid >> 3;
+    grp = (li / group_sz) * 8 + xcd;
+    in_grp = li - (li / group_sz) * group_sz;
+  } else {
+    const int wg = remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3) : bid;
+    grp = wg / group_sz;
+    in_grp = wg - grp * group_sz;
+  }
+  const int first_m = grp * GM;
+  if (first_m >= tiles_m) return;                             // (remap == 2: surplus workgroups of the rounded-up grid)
   const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-  const int in_grp = wg - grp * group_sz;
+  if (in_grp >= gm * tiles_n) return;
   const int tm = first_m + in_grp % gm, tn = in_grp / gm;
   int64_t m0 = (int64_t)tm * BM, M = M_all;
   const uint16_t* W = W_all;
@@ -500,9 +513,16 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     const char* e = getenv("GRIT_GEMM_GM"); gm_knob = (e && atoi(e) > 0) ? atoi(e) : 4;
     remap_knob = getenv("GRIT_GEMM_NOREMAP") ? 0 : 1;
   }
+  // grouped launches: round-robin tile groups over the XCDs (remap 2) on a grid rounded up to 8 x whole groups
+  const int total_groups = (tiles_m + gm_knob - 1) / gm_knob;
+  static int rr_all = -1;
+  if (rr_all < 0) rr_all = getenv("GRIT_GEMM_RR") ? 1 : 0;     // experiment: round-robin groups for the dense launches too
+  const bool rr = (grp.counts || rr_all) && remap_knob;
+  const unsigned nblocks = rr ? (unsigned)(8 * ((total_groups + 7) / 8) * gm_knob * tiles_n) : (unsigned)(tiles_m * tiles_n);
+  const int remap_mode = rr ? 2 : remap_knob;
 #define GRIT_LAUNCH_ABL(A_)                                                                                                          \
-  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, A_>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, \
-                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob, remap_knob, grp)
+  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, A_>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, \
+                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob, remap_mode, grp)
   if (abl > 0 && EPI == GRIT_EPI_STORE && gemm_variant() == 1) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
