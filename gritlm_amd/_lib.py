@@ -49,7 +49,8 @@ _SIGNATURES = {
     "grit_ce_fwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _p]),
     "grit_ce_bwd": (_i, [_p, _l, _p, _p, _p, _f, _l, _i, _p]),
     "grit_moe_router_top2": (_i, [_p, _p, _p, _p, _l, _i, _i, _p]),
-    "grit_moe_index": (_i, [_p, _l, _i, _p, _p, _p, _p]),
+    "grit_moe_index_workspace_ints": (_l, [_l, _i]),
+    "grit_moe_index": (_i, [_p, _l, _i, _p, _p, _p, _p, _p]),
     "grit_moe_combine": (_i, [_p, _p, _p, _p, _p, _l, _i, _p]),
     "grit_pool_norm_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "grit_infonce_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

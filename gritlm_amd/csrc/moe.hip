@@ -10,6 +10,7 @@
 namespace grit {
 
 constexpr int MOE_MAX_E = 16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 // ---- router: one wave per token, gate weights staged in LDS ([E,H] bf16)
 template <int E>
@@ -26,14 +27,27 @@ __global__ void __launch_bounds__(256) moe_router_top2_k(const uint16_t* __restr
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
     const uint4* xr = reinterpret_cast<const uint4*>(x) + t * HC;
-    for (int c = lane; c < HC; c += 64) {
-      const uint4 xv = xr[c];
-      const float xf[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
+    for (int c0 = lane; c0 < HC; c0 += 8 * 64) {
+      // eight 16-byte loads of the token row in flight per lane before the first use (H = 4096: the whole row)
+      uint4 xv8[8];
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const uint4 wv = gw[e * HC + c];
-        acc[e] += xf[0] * bflo(wv.x) + xf[1] * bfhi(wv.x) + xf[2] * bflo(wv.y) + xf[3] * bfhi(wv.y) + xf[4] * bflo(wv.z) +
-                  xf[5] * bfhi(wv.z) + xf[6] * bflo(wv.w) + xf[7] * bfhi(wv.w);
+      for (int u = 0; u < 8; ++u) xv8[u] = (c0 + 64 * u < HC) ? xr[c0 + 64 * u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 64 * u;
+        if (c >= HC) break;
+        const uint4 xv = xv8[u];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          // v_dot2c_f32_bf16: two bf16 products accumulated in fp32 per instruction, no unpacking (the kernel was VALU-bound on bflo/bfhi + fma)
+          const uint4 wv = gw[e * HC + c];
+          float a_ = acc[e];
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.x), __builtin_bit_cast(bf16x2_t, wv.x), a_, false);
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.y), __builtin_bit_cast(bf16x2_t, wv.y), a_, false);
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.z), __builtin_bit_cast(bf16x2_t, wv.z), a_, false);
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.w), __builtin_bit_cast(bf16x2_t, wv.w), a_, false);
+          acc[e] = a_;
+        }
       }
     }
     float mx = -INFINITY;
@@ -58,60 +72,71 @@ __global__ void __launch_bounds__(256) moe_router_top2_k(const uint16_t* __restr
   }
 }
 
-// ---- index: ONE workgroup; thread i owns a contiguous range of the 2T (token, k) entries -> per-thread expert histogram ->
-//      block-wide exclusive scans -> second walk assigns positions.  Stable: inside an expert the rows are ordered by token, the
-//      order torch.where produces in the reference (:861).
-constexpr int IDX_THREADS = 512;
-__global__ void __launch_bounds__(IDX_THREADS) moe_index_k(const int32_t* __restrict__ experts, int64_t n, int E, int32_t* __restrict__ counts,
-                                                            int32_t* __restrict__ row_token, int32_t* __restrict__ rows) {
-  __shared__ int32_t hist[MOE_MAX_E][IDX_THREADS + 1];
-  __shared__ int32_t base[MOE_MAX_E + 1];
+// ---- index: stable counting sort of the n = 2T (token, k) entries by expert, three launches:
+//      (1) per-chunk expert histograms (4096 entries per workgroup), (2) one small workgroup turns them into chunk bases,
+//      (3) every workgroup ranks its chunk in entry order (ballot + popcount per expert, running bases across the 16 rounds of 256).
+//      Stable: inside an expert the rows are ordered by token, the order torch.where produces in the reference (:861).
+constexpr int IDX_CHUNK = 4096, IDX_T = 256;
+__global__ void __launch_bounds__(IDX_T) moe_hist_k(const int32_t* __restrict__ experts, int64_t n, int E, int32_t* __restrict__ chunk_counts) {
+  __shared__ int32_t h[MOE_MAX_E];
   const int tid = threadIdx.x;
-  const int64_t per = (n + IDX_THREADS - 1) / IDX_THREADS;
-  const int64_t lo = (int64_t)tid * per, hi = lo + per < n ? lo + per : n;
-  int32_t c[MOE_MAX_E];
-#pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e) c[e] = 0;
-  for (int64_t i = lo; i < hi; ++i) {
-    const int e = experts[i];
-#pragma unroll
-    for (int k = 0; k < MOE_MAX_E; ++k) c[k] += (k == e);
-  }
-#pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e)
-    if (e < E) hist[e][tid] = c[e];
+  if (tid < MOE_MAX_E) h[tid] = 0;
   __syncthreads();
-  // exclusive scan over the threads, one wave per expert round-robin (8 waves)
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int e = wave; e < E; e += IDX_THREADS / 64) {
+  const int64_t base = (int64_t)blockIdx.x * IDX_CHUNK;
+  for (int j = tid; j < IDX_CHUNK; j += IDX_T) {
+    const int64_t i = base + j;
+    if (i < n) atomicAdd(&h[experts[i]], 1);
+  }
+  __syncthreads();
+  if (tid < E) chunk_counts[(int64_t)blockIdx.x * E + tid] = h[tid];
+}
+
+// chunk_counts [nchunks, E] -> chunk_base [nchunks, E] (first sorted row of expert e's entries of chunk c), counts [E]
+__global__ void __launch_bounds__(64) moe_scan_k(const int32_t* __restrict__ chunk_counts, int nchunks, int E, int32_t* __restrict__ chunk_base,
+                                                 int32_t* __restrict__ counts) {
+  __shared__ int32_t tot[MOE_MAX_E];
+  const int lane = threadIdx.x;
+  // lane e < E walks expert e's column (nchunks <= a few hundred)
+  if (lane < E) {
     int32_t run = 0;
-    for (int b = 0; b < IDX_THREADS; b += 64) {
-      const int32_t v = hist[e][b + lane];
-      int32_t inc = v;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-      hist[e][b + lane] = run + inc - v;
-      run += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) hist[e][IDX_THREADS] = run;
+    for (int c = 0; c < nchunks; ++c) { const int32_t v = chunk_counts[(int64_t)c * E + lane]; chunk_base[(int64_t)c * E + lane] = run; run += v; }
+    tot[lane] = run; counts[lane] = run;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (lane < E) {
     int32_t off = 0;
-    for (int e = 0; e < E; ++e) { base[e] = off; counts[e] = hist[e][IDX_THREADS]; off += hist[e][IDX_THREADS]; }
-    base[E] = off;
+    for (int e = 0; e < lane; ++e) off += tot[e];
+    for (int c = 0; c < nchunks; ++c) chunk_base[(int64_t)c * E + lane] += off;
   }
+}
+
+__global__ void __launch_bounds__(IDX_T) moe_rank_k(const int32_t* __restrict__ experts, int64_t n, int E, const int32_t* __restrict__ chunk_base,
+                                                    int32_t* __restrict__ row_token, int32_t* __restrict__ rows) {
+  __shared__ int32_t run[MOE_MAX_E];                 // next free sorted row per expert
+  __shared__ int32_t wtot[IDX_T / 64][MOE_MAX_E];    // per wave: entries of expert e in this round
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < E) run[tid] = chunk_base[(int64_t)blockIdx.x * E + tid];
   __syncthreads();
-#pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e) c[e] = e < E ? base[e] + hist[e][tid] : 0;
-  for (int64_t i = lo; i < hi; ++i) {
-    const int e = experts[i];
-    int32_t pos = 0;
-#pragma unroll
-    for (int k = 0; k < MOE_MAX_E; ++k)
-      if (k == e) { pos = c[k]; c[k] += 1; }
-    rows[i] = pos;
-    row_token[pos] = (int32_t)(i >> 1);
+  const int64_t base = (int64_t)blockIdx.x * IDX_CHUNK;
+  for (int r = 0; r < IDX_CHUNK / IDX_T; ++r) {
+    const int64_t i = base + r * IDX_T + tid;
+    const int e = i < n ? experts[i] : -1;
+    int my_rank = 0;
+    for (int k = 0; k < E; ++k) {
+      const uint64_t m = __ballot(e == k);
+      if (e == k) my_rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wtot[wave][k] = __popcll(m);
+    }
+    __syncthreads();
+    if (e >= 0) {
+      int32_t pos = run[e] + my_rank;
+      for (int w = 0; w < wave; ++w) pos += wtot[w][e];
+      rows[i] = pos;
+      row_token[pos] = (int32_t)(i >> 1);
+    }
+    __syncthreads();
+    if (tid < E) run[tid] += wtot[0][tid] + wtot[1][tid] + wtot[2][tid] + wtot[3][tid];
+    __syncthreads();
   }
 }
 
@@ -168,13 +193,32 @@ extern "C" int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* 
   return GRIT_OK;
 }
 
-extern "C" int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t* counts, int32_t* row_token, int32_t* rows, void* stream) {
-  GRIT_REQUIRE(counts, GRIT_E_BADARG, "grit_moe_index: null pointer");
+extern "C" int64_t grit_moe_index_workspace_ints(int64_t T, int E) {
+  const int64_t nch = (2 * T + IDX_CHUNK - 1) / IDX_CHUNK;
+  return 2 * (nch > 0 ? nch : 1) * E;
+}
+
+extern "C" int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t* counts, int32_t* row_token, int32_t* rows, int32_t* workspace,
+                              void* stream) {
+  GRIT_REQUIRE(counts && workspace, GRIT_E_BADARG, "grit_moe_index: null pointer");
   GRIT_REQUIRE(E > 0 && E <= MOE_MAX_E, GRIT_E_UNSUPPORTED, "grit_moe_index: num_experts=%d (max %d)", E, MOE_MAX_E);
   GRIT_REQUIRE(T >= 0 && 2 * T < (1ll << 31), GRIT_E_BADARG, "grit_moe_index: bad T");
   GRIT_REQUIRE(T == 0 || (experts && row_token && rows), GRIT_E_BADARG, "grit_moe_index: null pointer");
-  hipLaunchKernelGGL(moe_index_k, dim3(1), dim3(IDX_THREADS), 0, (hipStream_t)stream, experts, 2 * T, E, counts, row_token, rows);
-  GRIT_CHECK_LAUNCH("grit_moe_index");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = 2 * T;
+  const int nch = (int)((n + IDX_CHUNK - 1) / IDX_CHUNK);
+  int32_t* chunk_counts = workspace;
+  int32_t* chunk_base = workspace + (int64_t)(nch > 0 ? nch : 1) * E;
+  if (nch > 0) {
+    hipLaunchKernelGGL(moe_hist_k, dim3((unsigned)nch), dim3(IDX_T), 0, st, experts, n, E, chunk_counts);
+    GRIT_CHECK_LAUNCH("grit_moe_index: histogram");
+  }
+  hipLaunchKernelGGL(moe_scan_k, dim3(1), dim3(64), 0, st, chunk_counts, nch, E, chunk_base, counts);
+  GRIT_CHECK_LAUNCH("grit_moe_index: scan");
+  if (nch > 0) {
+    hipLaunchKernelGGL(moe_rank_k, dim3((unsigned)nch), dim3(IDX_T), 0, st, experts, n, E, chunk_base, row_token, rows);
+    GRIT_CHECK_LAUNCH("grit_moe_index: rank");
+  }
   return GRIT_OK;
 }
 

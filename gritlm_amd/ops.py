@@ -232,7 +232,8 @@ def moe_route(x: torch.Tensor, gate_w: torch.Tensor):
     rows = torch.empty((T, 2), dtype=I32, device=dev)
     check(_lib.load().grit_moe_router_top2(_chk(x, BF16, "x"), _chk(gate_w, BF16, "gate_w"), experts.data_ptr(), weights.data_ptr(), T, H, E,
                                            _stream()), "grit_moe_router_top2")
-    check(_lib.load().grit_moe_index(experts.data_ptr(), T, E, counts.data_ptr(), row_token.data_ptr(), rows.data_ptr(), _stream()),
+    ws = torch.empty((int(_lib.load().grit_moe_index_workspace_ints(T, E)),), dtype=I32, device=dev)
+    check(_lib.load().grit_moe_index(experts.data_ptr(), T, E, counts.data_ptr(), row_token.data_ptr(), rows.data_ptr(), ws.data_ptr(), _stream()),
           "grit_moe_index")
     return experts, weights, counts, row_token, rows
 

@@ -120,9 +120,11 @@ int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* experts, fl
                          void* stream);
 
 /* Stable counting sort of the 2T (token,k) pairs by expert (replaces torch.where/.tolist() per expert, :859-870):
- * counts [E] int32, row_token [2T] int32 (sorted row -> token), rows [T,2] int32 ((token,k) -> sorted row). */
+ * counts [E] int32, row_token [2T] int32 (sorted row -> token), rows [T,2] int32 ((token,k) -> sorted row);
+ * workspace: grit_moe_index_workspace_ints(T, E) int32 of device memory. */
+int64_t grit_moe_index_workspace_ints(int64_t T, int E);
 int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t* counts, int32_t* row_token, int32_t* rows,
-                   void* stream);
+                   int32_t* workspace, void* stream);
 
 /* out[t] = residual[t] + (weights[t,0]*y[rows[t,0]] + weights[t,1]*y[rows[t,1]]) with the bf16 roundings of :876, :880 and
  * the decoder's residual add (:945).  y [2T,H] bf16, residual (nullable) / out [T,H] bf16 (out may alias residual). */

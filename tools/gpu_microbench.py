@@ -78,7 +78,39 @@ def hbm_cases(T=131072, H=4096, B=256, S=512):
     print(f"embed T={T}  med {med:7.3f} ms  {2 * T * H * 2 / med / 1e6:8.1f} GB/s", flush=True)
 
 
+def new_kernel_cases():
+    """HBM-bound kernels of the round-1 'next' rows: vocabulary CE, MoE router / combine, decode GEMVs."""
+    T, V = 16384, 32000
+    logits = torch.randn((T, V), device=DEV, dtype=torch.float32).to(BF)
+    labels = torch.randint(0, V, (T,), device=DEV)
+    med, _ = timeit(lambda: ops.ce_fwd(logits, labels))
+    print(f"ce_fwd T={T} V={V}  med {med:7.3f} ms  {T * V * 2 / med / 1e6:8.1f} GB/s", flush=True)
+    lse, _ = ops.ce_fwd(logits, labels)
+    med, _ = timeit(lambda: ops.ce_bwd_(logits, labels, lse, 1.0))
+    print(f"ce_bwd T={T} V={V}  med {med:7.3f} ms  {2 * T * V * 2 / med / 1e6:8.1f} GB/s", flush=True)
+    T, H, E = 131072, 4096, 8
+    x = torch.randn((T, H), device=DEV, dtype=torch.float32).to(BF)
+    gw = (torch.randn((E, H), device=DEV) * 0.5).to(BF)
+    med, _ = timeit(lambda: ops.moe_route(x, gw))
+    print(f"moe router+index T={T}  med {med:7.3f} ms  {T * H * 2 / med / 1e6:8.1f} GB/s (x read)", flush=True)
+    _, wts, counts, row_token, rows = ops.moe_route(x, gw)
+    y = torch.randn((2 * T, H), device=DEV, dtype=torch.float32).to(BF)
+    out = torch.empty_like(x)
+    med, _ = timeit(lambda: ops.moe_combine(y, rows, wts, x, out=out))
+    print(f"moe combine T={T}  med {med:7.3f} ms  {4 * T * H * 2 / med / 1e6:8.1f} GB/s", flush=True)
+    for (N, K, epi, tag) in ((6144, 4096, EPI_STORE, "qkv"), (28672, 4096, EPI_SWIGLU, "gate_up"), (4096, 14336, EPI_RESIDUAL, "down"), (32000, 4096, EPI_STORE, "lm_head")):
+        xv = torch.randn((1, K), device=DEV, dtype=torch.float32).to(BF)
+        w = (torch.randn((N, K), device=DEV, dtype=torch.float32) * 0.02).to(BF)
+        res = torch.randn((1, N), device=DEV, dtype=torch.float32).to(BF) if epi == EPI_RESIDUAL else None
+        o = torch.empty((1, N // 2 if epi == EPI_SWIGLU else N), device=DEV, dtype=BF)
+        med, _ = timeit(lambda: ops.gemv(xv, w, out=o, epilogue=epi, residual=res))
+        print(f"gemv {tag:<8s} N={N:<6d} K={K:<6d}  med {med * 1e3:7.1f} us  {N * K * 2 / med / 1e6:8.1f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "new":
+        new_kernel_cases()
+        sys.exit(0)
     M = int(os.environ.get("MB_M", 131072))
     gemm_case(M, 6144, 4096, EPI_STORE, "qkv")
     gemm_case(M, 4096, 4096, EPI_RESIDUAL, "o_proj")
