@@ -36,6 +36,7 @@ _SIGNATURES = {
     "grit_attn_causal_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_pool_norm_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_pool_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "grit_gemm_bf16_nt_rope": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _p, _p, _p, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt_grouped": (_i, [_p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _i, _p]),
     "grit_gemv_bf16": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
     "grit_rmsnorm_gemv_bf16": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p]),

@@ -195,19 +195,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with the scaling
-    // Lazy rescale: the running maximum only has to bound the exponent, it need not be tight.  While no row of the wave exceeds its
-    // running max by more than 2^8, keep it: P <= 256 is exact enough in bf16 (same relative precision) and fp32 sums, and the
-    // 64-register O rescale + one exp per row are skipped for most tiles after the first (wave-uniform branch).
-    const bool keep = __all(mx <= m_run + 8.0f);              // false on the first tile (m_run = -inf) unless the row is fully masked
-    float m_use, alpha = 1.0f;
-    if (keep) {
-      m_use = (m_run == -INFINITY) ? 0.f : m_run;
-    } else {
-      const float m_new = fmaxf(m_run, mx);
-      m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      alpha = __builtin_amdgcn_exp2f(m_run - m_use);          // m_run = -inf -> 0
-      m_run = m_new;
-    }
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+    m_run = m_new;
     float psum = 0.f;
     bf16x8_t pb[2][2];
 #pragma unroll
@@ -225,15 +216,11 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         }
         pb[kb][c] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
       }
-    if (keep) {
-      l_run += psum;
-    } else {
-      l_run = l_run * alpha + psum;
+    l_run = l_run * alpha + psum;
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-    }
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
 
     // ---- O^T += V^T P^T
 #pragma unroll

@@ -51,12 +51,25 @@ struct GemmGroups {
   int n_groups;
 };
 
+// GRIT_EPI_ROPE: STORE with apply_rotary_pos_emb (modeling_mistral_gritlm.py:138-163) fused for the leading rope_cols columns (the q and k
+// heads of the fused QKV projection, head_dim 128).  A wave then owns the column blocks {c, c+16, c+64, c+80} of one head instead of 64
+// consecutive columns, so that the rotation partners (col, col+64) sit in the same lane (fragments j and j+2): the rotation is
+// register-local, exactly the arithmetic of the stand-alone kernel (round the projection to bf16, rotate in fp32, round once).
+struct GemmRope {
+  const float* cos_tab;        // [table rows, 64] fp32
+  const float* sin_tab;
+  const int32_t* positions;    // nullable: position of row m = m % S
+  int S;
+  int rope_cols;
+};
+
 template <int EPI, int ABL = 0>
 __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W_all,
                                                       uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
-                                                      int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups) {
+                                                      int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool ROPE = (EPI == GRIT_EPI_ROPE);
 
   // ---- XCD-aware tile id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group)
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -132,7 +145,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   //      fragment starts at a multiple of 16 rows: (row>>1)&7 == (lane>>1)&7
   const int frow = lane & 15, kq = lane >> 4, swz = (lane >> 1) & 7;
   const int a_off = (wr * 128 + frow) * 128;            // + i*2048
-  const int w_off = A_BYTES + (wc * 64 + frow) * 128;   // + j*2048
+  // first tile row of W fragment j of this wave (= first output column of the fragment inside the tile)
+  auto wrow = [&](int j) { return ROPE ? (wc >> 1) * 128 + (j >> 1) * 64 + (wc & 1) * 32 + (j & 1) * 16 : wc * 64 + j * 16; };
+  const int w_off = A_BYTES + frow * 128;               // + wrow(j)*128
   const int s_off0 = ((kq) ^ swz) << 4, s_off1 = ((4 + kq) ^ swz) << 4;
 
   f32x4_t acc[8][4];
@@ -156,7 +171,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       bf16x8_t wf[4], xf[8];
       if (ABL != 2 || kt == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sb + w_off + j * 2048 + so);
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sb + w_off + wrow(j) * 128 + so);
 #pragma unroll
         for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(sb + a_off + i * 2048 + so);
       } else {
@@ -255,6 +270,31 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   const int ncol = n0 + wc * 64 + kq * 4;
   // RESIDUAL: all 16 residual loads of the lane are issued up front (the fragment registers are dead by now), so the epilogue pays one
   // memory latency instead of one per output row
+  if constexpr (ROPE) {
+    if (n0 + (wc >> 1) * 128 < rope.rope_cols) {        // this wave's head is a q or k head (uniform per wave)
+      const int m0_mod = (int)(m0 % rope.S);              // block-uniform: the only 64-bit division
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t m = mrow + i * 16;
+        const int64_t mc = m < M ? m : M - 1;
+        const int pos = rope.positions ? rope.positions[mc] : (m0_mod + (int)(mc - m0)) % rope.S;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+          const int c1 = (wc & 1) * 32 + p2 * 16 + kq * 4;                       // head-local column of fragment p2, lane's 4 columns
+          const float4 cs = *reinterpret_cast<const float4*>(rope.cos_tab + (int64_t)pos * 64 + c1);
+          const float4 sn = *reinterpret_cast<const float4*>(rope.sin_tab + (int64_t)pos * 64 + c1);
+          const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t xr = pack2bf_hw(acc[i][p2][r], acc[i][p2 + 2][r]);     // q/k = bf16(linear) first (:655-657)
+            const float x1 = bflo(xr), x2 = bfhi(xr);
+            acc[i][p2][r] = x1 * cc[r] - x2 * ss[r];
+            acc[i][p2 + 2][r] = x2 * cc[r] + x1 * ss[r];
+          }
+        }
+      }
+    }
+  }
   uint4 rpre[8][2];
   if constexpr (EPI == GRIT_EPI_RESIDUAL) {
 #pragma unroll
@@ -262,7 +302,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 #pragma unroll
       for (int jq = 0; jq < 2; ++jq) {
         const int64_t m = mrow + i * 16;
-        const int n = n0 + wc * 64 + (2 * jq + (kq & 1)) * 16 + (kq >> 1) * 8;
+        const int n = n0 + wrow(2 * jq + (kq & 1)) + (kq >> 1) * 8;
         rpre[i][jq] = (m < M && n < N) ? *reinterpret_cast<const uint4*>(Rsd + m * ldr + n) : make_uint4(0, 0, 0, 0);
       }
   }
@@ -303,7 +343,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo[r]), __float_as_uint(hi4[r]), false, false);
           lo[r] = __uint_as_float(sw[0]); hi4[r] = __uint_as_float(sw[1]);
         }
-        const int n = n0 + wc * 64 + (jp + (kq & 1)) * 16 + (kq >> 1) * 8;
+        const int n = n0 + wrow(jp + (kq & 1)) + (kq >> 1) * 8;
         if (n >= N) continue;
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
         if constexpr (EPI == GRIT_EPI_RESIDUAL) {
@@ -499,7 +539,8 @@ static int gemm_variant() {
 
 template <int EPI>
 static int launch_gemm(const void* A, const void* W, void* C, const void* R, int64_t M, int N, int K, int64_t lda, int64_t ldw,
-                       int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0}) {
+                       int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0},
+                       GemmRope rope = GemmRope{nullptr, nullptr, nullptr, 0, 0}) {
   const int tiles_m = grp.counts ? (int)(M / BM) + grp.n_groups : (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
   static bool attr_set = false;  // idempotent; benign race
   if (!attr_set) {
@@ -522,7 +563,7 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
   const int remap_mode = rr ? 2 : remap_knob;
 #define GRIT_LAUNCH_ABL(A_)                                                                                                          \
   hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, A_>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, \
-                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob, remap_mode, grp)
+                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob, remap_mode, grp, rope)
   if (abl > 0 && EPI == GRIT_EPI_STORE && gemm_variant() == 1) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
@@ -539,7 +580,7 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
     else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else if (abl == 11) GRIT_LAUNCH_ABL(11); else if (abl == 12) GRIT_LAUNCH_ABL(12); else if (abl == 14) GRIT_LAUNCH_ABL(14); else GRIT_LAUNCH_ABL(13);
-  } else if (gemm_variant() == 8 && grp.counts == nullptr) {
+  } else if (gemm_variant() == 8 && grp.counts == nullptr && EPI != GRIT_EPI_ROPE) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v8_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
     hipLaunchKernelGGL(gemm_bf16_nt_v8_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
                        (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob);
@@ -580,6 +621,25 @@ extern "C" int grit_gemm_bf16_nt_grouped(const void* A, const int32_t* a_rows, c
       GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped: epilogue %d not available (STORE, SWIGLU)", epilogue);
   }
   return GRIT_OK;
+}
+
+extern "C" int grit_gemm_bf16_nt_rope(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
+                                      const float* cos_tab, const float* sin_tab, const int32_t* positions, int S, int table_rows,
+                                      int rope_cols, void* stream) {
+  if (M == 0) return GRIT_OK;
+  GRIT_REQUIRE(A && W && C && cos_tab && sin_tab, GRIT_E_BADARG, "grit_gemm_bf16_nt_rope: null pointer");
+  GRIT_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, GRIT_E_BADARG, "grit_gemm_bf16_nt_rope: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+  GRIT_REQUIRE(N % 128 == 0 && rope_cols % 128 == 0 && rope_cols >= 0 && rope_cols <= N, GRIT_E_UNSUPPORTED,
+               "grit_gemm_bf16_nt_rope: N=%d and rope_cols=%d must be multiples of the head size 128", N, rope_cols);
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N, GRIT_E_BADARG,
+               "grit_gemm_bf16_nt_rope: bad leading dimensions");
+  GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(cos_tab) && aligned16(sin_tab), GRIT_E_BADARG,
+               "grit_gemm_bf16_nt_rope: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((positions != nullptr) ? table_rows > 0 : (S > 0 && table_rows >= S), GRIT_E_BADARG,
+               "grit_gemm_bf16_nt_rope: positions or S (<= table rows) required");
+  GRIT_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_rope: too many tiles");
+  const GemmRope rope{cos_tab, sin_tab, positions, S > 0 ? S : 1, rope_cols};
+  return launch_gemm<GRIT_EPI_ROPE>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, (hipStream_t)stream, GemmGroups{nullptr, nullptr, 0, 0}, rope);
 }
 
 extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,

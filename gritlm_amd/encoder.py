@@ -2,9 +2,9 @@
 
 Replaces ``MistralModel.forward(..., is_causal=False)`` of scripts/modeling_mistral_gritlm.py:936-1096 for
 the embedding path.  Per layer (reference: 3+1+3 nn.Linear GEMMs, ~20 elementwise kernels, repeat_kv,
-a [B,1,S,S] mask) it launches 8 kernels:
+a [B,1,S,S] mask) it launches 7 kernels:
 
-    rmsnorm -> fused QKV GEMM -> RoPE (in place) -> flash attention (GQA, key bitmask)
+    rmsnorm -> fused QKV GEMM with RoPE in its epilogue -> flash attention (GQA, key bitmask)
             -> o_proj GEMM + residual epilogue -> rmsnorm -> gate|up GEMM + SwiGLU epilogue
             -> down GEMM + residual epilogue
 
@@ -254,8 +254,7 @@ class MistralEncoderEngine:
         kv = []
         for L in self.layers:
             ops.rmsnorm(h, L.ln1, eps, out=x)
-            ops.gemm_nt(x, L.wqkv, out=qkv)
-            ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
+            ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)       # q/k/v projections + RoPE in the epilogue
             if return_kv:
                 kvw = qkv.view(B, S, nq + 2 * nkv, d)
                 kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).contiguous(), kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).contiguous()))
@@ -310,8 +309,7 @@ class MistralEncoderEngine:
         ops.embed_gather(self.embed, pids, out=h)
         for L in self.layers:
             ops.rmsnorm(h, L.ln1, eps, out=x)
-            ops.gemm_nt(x, L.wqkv, out=qkv)
-            ops.rope_qk_pos_(qkv, cos, sin, pos, nq, nkv, d)
+            ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, positions=pos, out=qkv)
             ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)

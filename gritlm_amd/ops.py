@@ -198,6 +198,26 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     return out
 
 
+def gemm_nt_rope(a: torch.Tensor, w: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, rope_cols: int, S: int = 0,
+                 positions: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused QKV projection + RoPE on the leading ``rope_cols`` columns (q, k heads; head_dim 128): gemm_nt followed by rope_qk_[pos_],
+    in one launch.  Positions: ``positions`` int32 [M] (packed rows) or row % S."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K, tag=f"N={N},K={K},epi=3") if _timer is not None else None
+    if ev:
+        ev[0].record()
+    check(_lib.load().grit_gemm_bf16_nt_rope(_chk2d(a, BF16, "a"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), M, N, K, a.stride(0), w.stride(0),
+                                             out.stride(0), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"),
+                                             0 if positions is None else _chk(positions, I32, "positions"), int(S), cos.shape[0], int(rope_cols),
+                                             _stream()), "grit_gemm_bf16_nt_rope")
+    if ev:
+        ev[1].record()
+    return out
+
+
 def gemm_nt_grouped(a: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, m_total: int, out: torch.Tensor | None = None,
                     epilogue: int = EPI_STORE, a_rows: torch.Tensor | None = None) -> torch.Tensor:
     """Grouped GEMM over ``w [E,N,K]``: sorted row r (group by group, ``counts`` int32 [E] on the device) is

@@ -38,8 +38,9 @@ enum {
 enum {
   GRIT_EPI_STORE = 0,    /* C = bf16(acc)                                                       */
   GRIT_EPI_RESIDUAL = 1, /* C = bf16(acc + residual)  (residual may alias C)                    */
-  GRIT_EPI_SWIGLU = 2    /* weight rows interleaved gate/up in blocks of grit_swiglu_block() rows;
+  GRIT_EPI_SWIGLU = 2,   /* weight rows interleaved gate/up in blocks of grit_swiglu_block() rows;
                             C[:, N/2] = bf16(silu(bf16(gate)) * bf16(up))                        */
+  GRIT_EPI_ROPE = 3      /* (grit_gemm_bf16_nt_rope) STORE + rotary embedding on the leading columns */
 };
 
 /* pooling modes: gritlm/gritlm.py:188-214 */
@@ -78,6 +79,15 @@ int grit_rope_qk_inplace_pos(void* qkv, const float* cos_tab, const float* sin_t
 int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda,
                       int64_t ldw, int64_t ldc, int epilogue, const void* residual, int64_t ldr,
                       void* stream);
+
+/* The fused QKV projection with apply_rotary_pos_emb (:138-163) in the epilogue: C = A W^T (STORE), and the leading rope_cols
+ * columns (q heads then k heads, head_dim 128; rope_cols = (nq+nkv)*128) are rotated in the lane that produced them -- bit-identical to
+ * grit_gemm_bf16_nt followed by grit_rope_qk_inplace[_pos], without the extra read + write of the activation.
+ * Row m sits at position positions[m] (int32, device) or, when positions is NULL, m % S.  cos/sin: fp32 [table_rows, 64].
+ * N and rope_cols must be multiples of 128. */
+int grit_gemm_bf16_nt_rope(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
+                           const float* cos_tab, const float* sin_tab, const int32_t* positions, int S, int table_rows,
+                           int rope_cols, void* stream);
 
 /* Row-interleave granularity the SWIGLU epilogue expects: packed row r = 2*blk*(r/blk) + r%blk holds gate row r,
  * the next blk rows the matching up rows (blk = 32 for the 32x32x16 kernel generation). */

@@ -105,6 +105,27 @@ def check_gemm(M, N, K, epi=EPI_STORE, seed=7):
     return _res(f"gemm[M={M},N={N},K={K},epi={epi}]", ok, max_err_over_tol=err)
 
 
+def check_gemm_rope(M=300, nq=4, nkv=2, K=256, S=77, packed=False):
+    """Fused QKV GEMM + RoPE epilogue == GEMM followed by the stand-alone RoPE kernel, bit for bit (v heads untouched)."""
+    from gritlm_amd.encoder import rope_tables
+    d = 128
+    N = (nq + 2 * nkv) * d
+    a, w = bf(rnd((M, K), 71)), bf(rnd((N, K), 72, 0.05))
+    cos, sin = rope_tables(max(S, 128), d, 10000.0, True, DEV)
+    if packed:
+        pos = torch.from_numpy((np.arange(M) * 7 % max(S, 128)).astype(np.int32)).to(DEV)
+        ref = ops.rope_qk_pos_(ops.gemm_nt(a, w), cos, sin, pos, nq, nkv, d)
+        got = ops.gemm_nt_rope(a, w, cos, sin, (nq + nkv) * d, positions=pos)
+    else:
+        ref = ops.rope_qk_(ops.gemm_nt(a, w), cos[:S].contiguous(), sin[:S].contiguous(), S, nq, nkv, d)
+        got = ops.gemm_nt_rope(a, w, cos, sin, (nq + nkv) * d, S=S)
+    same = bool(torch.equal(got, ref))
+    plain = ops.gemm_nt(a, w)
+    ok = same and bool(torch.equal(got[:, (nq + nkv) * d:], plain[:, (nq + nkv) * d:])) and not bool(torch.equal(got[:, :d], plain[:, :d]))
+    return _res(f"gemm+rope epilogue [M={M},nq={nq},nkv={nkv},K={K},packed={int(packed)}]", ok,
+                max_abs_diff=float((got.float() - ref.float()).abs().max()))
+
+
 def check_mask_pack():
     rng = np.random.default_rng(9)
     m = (rng.random((5, 200)) < 0.6).astype(np.int64)
@@ -1199,6 +1220,9 @@ ALL_CHECKS = [
     ("gemm_residual", check_gemm, dict(M=520, N=512, K=192, epi=EPI_RESIDUAL)),
     ("gemm_swiglu", check_gemm, dict(M=300, N=1024, K=256, epi=EPI_SWIGLU)),
     ("gemm_swiglu_edge", check_gemm, dict(M=70, N=576, K=64, epi=EPI_SWIGLU)),
+    ("gemm_rope", check_gemm_rope, {}),
+    ("gemm_rope_packed", check_gemm_rope, dict(M=513, nq=2, nkv=1, K=128, packed=True)),
+    ("gemm_rope_7b", check_gemm_rope, dict(M=1024, nq=32, nkv=8, K=512, S=512)),
     ("mask_pack", check_mask_pack, {}),
     ("attn_ragged", check_attention, dict(mask_kind="ragged")),
     ("attn_holes", check_attention, dict(mask_kind="holes", S=257)),
