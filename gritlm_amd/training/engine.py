@@ -226,14 +226,13 @@ class MistralTrainEngine:
             if save or x1 is None:
                 x1, qkv, ctx, x2, gu, act = mk(H), mk((nq + 2 * nkv) * d), mk(nq * d), mk(H), mk(2 * I), mk(I)
             ops.rmsnorm(h, L.ln1.data, eps, out=x1)
-            ops.gemm_nt(x1, L.wqkv, out=qkv)
             if geom.packed:
                 lse = torch.empty((T, nq), dtype=F32, device=dev) if save else None
-                ops.rope_qk_pos_(qkv, cos, sin, geom.pos, nq, nkv, d)
+                ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, positions=geom.pos, out=qkv)      # q/k/v projections + RoPE epilogue
                 ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
             else:
                 lse = torch.empty((B, nq, S), dtype=F32, device=dev) if save else None
-                ops.rope_qk_(qkv, cos, sin, S, nq, nkv, d)
+                ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)
                 ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
             h_mid = mk(H) if save else h
             ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
