@@ -17,8 +17,14 @@ for (N, K, epi) in ((6144, 4096, EPI_STORE), (4096, 4096, EPI_RESIDUAL), (28672,
     w = (torch.randn((N, K), device="cuda", dtype=torch.float32) * 0.02).to(BF)
     out = torch.empty((M, N // 2 if epi == EPI_SWIGLU else N), device="cuda", dtype=BF)
     res = torch.randn((M, N), device="cuda", dtype=torch.float32).to(BF) if epi == EPI_RESIDUAL else None
+    if N == 6144:      # the model's QKV projection runs with the RoPE epilogue (7B: 32 q + 8 k heads rotated, 8 v heads stored)
+        from gritlm_amd.encoder import rope_tables
+        cos, sin = rope_tables(512, 128, 1e4, True, "cuda")
     for _ in range(reps):
-        ops.gemm_nt(a, w, out=out, epilogue=epi, residual=res)
+        if N == 6144:
+            ops.gemm_nt_rope(a, w, cos, sin, 5120, S=512, out=out)
+        else:
+            ops.gemm_nt(a, w, out=out, epilogue=epi, residual=res)
     torch.cuda.synchronize()
     del a, w, out, res
 print("done")

@@ -35,7 +35,7 @@ for f in ("pmc_sq", "pmc_mfma", "pmc_fetch", "pmc_write"):
     for key, c in agg.items():
         out.setdefault(key, {}).update({k: sum(v) / len(v) for k, v in c.items()})
     durs.update({k: sum(v) / len(v) for k, v in dur.items() if v})
-shapes = {"0": "qkv M=131072 N=6144 K=4096 (STORE)", "1": "o_proj N=4096 K=4096 and down N=4096 K=14336 averaged (RESIDUAL)",
+shapes = {"0": "qkv M=131072 N=6144 K=4096 (STORE)", "3": "qkv M=131072 N=6144 K=4096 (STORE + RoPE epilogue)", "1": "o_proj N=4096 K=4096 and down N=4096 K=14336 averaged (RESIDUAL)",
           "2": "gate|up N=28672 K=4096 (SWIGLU)"}
 weights = {}
 for k, v in out.items():
