@@ -44,6 +44,7 @@ _SIGNATURES = {
     "grit_kv_append": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _p]),
     "grit_attn_decode_workspace_floats": (_l, [_i, _i, _i, _i]),
     "grit_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_decode_rope": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_argmax_advance": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _i, _p]),
     "grit_knn_workspace_bytes": (_l, [_i, _l, _i]),
     "grit_knn_topk": (_i, [_p, _p, _i, _l, _i, _l, _l, _i, _p, _p, _p, _p]),

@@ -175,9 +175,14 @@ __global__ void __launch_bounds__(256) kv_append_k(const uint16_t* __restrict__ 
 // ---- decode attention, head_dim 128.  grid (splits of 64 keys, nkv, B), ONE wave per workgroup: at 1-8 sequences the work is tiny, what
 //      matters is that every 64-key slice of the cache is read by its own wave somewhere on the chip (2 k keys x 8 kv heads = 264 waves).
 constexpr int AD_D = 128, AD_CH = 64, AD_G = 8;   // up to 8 query heads per kv head
-__global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__ q, const uint16_t* __restrict__ ck,
-                                                    const uint16_t* __restrict__ cv, const int32_t* __restrict__ lens, float* __restrict__ part,
-                                                    int nq, int nkv, int Lmax, int64_t q_stride, float scale, int max_splits) {
+// ROPE: q arrives un-rotated in the fused qkv row; every workgroup rotates its G query heads itself (position lens[b]) and the one whose
+// slice contains that position also rotates the new k, appends k and v to the cache and then reads them back like any other key --
+// the RoPE + KV-append launch of a decode step disappears.
+template <bool ROPE>
+__global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__ q, uint16_t* __restrict__ ck, uint16_t* __restrict__ cv,
+                                                    const int32_t* __restrict__ lens, float* __restrict__ part, const float* __restrict__ cos_tab,
+                                                    const float* __restrict__ sin_tab, int nq, int nkv, int Lmax, int64_t q_stride, float scale,
+                                                    int max_splits) {
   __shared__ float qs[AD_G][AD_D];           // query heads of this kv head, pre-scaled
   __shared__ float ps[AD_G][64];             // probabilities of the 64 keys
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
@@ -190,9 +195,30 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     for (int i = lane; i < G * (AD_D + 2); i += 64) pbase[i] = (i % (AD_D + 2) == 0) ? -INFINITY : 0.f;
     return;
   }
-  for (int i = lane; i < G * AD_D; i += 64) {
-    const int g = i / AD_D, e = i - g * AD_D;
-    qs[g][e] = bf2f(q[(int64_t)b * q_stride + (int64_t)(hk * G + g) * AD_D + e]) * scale;
+  if constexpr (ROPE) {
+    const int pos = L - 1;
+    const float c = cos_tab[(int64_t)pos * 64 + lane], sn = sin_tab[(int64_t)pos * 64 + lane];     // lane <-> pair (e, e + 64)
+    const uint16_t* row = q + (int64_t)b * q_stride;
+    for (int g = 0; g < G; ++g) {
+      const float x1 = bf2f(row[(int64_t)(hk * G + g) * AD_D + lane]), x2 = bf2f(row[(int64_t)(hk * G + g) * AD_D + 64 + lane]);
+      const uint32_t r = pack2bf(x1 * c - x2 * sn, x2 * c + x1 * sn);                                // one rounding, as rope_k
+      qs[g][lane] = bflo(r) * scale; qs[g][64 + lane] = bfhi(r) * scale;
+    }
+    if (pos >= k0 && pos < k0 + AD_CH) {                  // this workgroup owns the new key: rotate k, append k and v
+      const uint16_t* kr = row + (int64_t)(nq + hk) * AD_D;
+      const uint16_t* vr = row + (int64_t)(nq + nkv + hk) * AD_D;
+      const float x1 = bf2f(kr[lane]), x2 = bf2f(kr[64 + lane]);
+      const uint32_t r = pack2bf(x1 * c - x2 * sn, x2 * c + x1 * sn);
+      uint16_t* kd = ck + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D;
+      kd[lane] = (uint16_t)(r & 0xffff); kd[64 + lane] = (uint16_t)(r >> 16);
+      reinterpret_cast<uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D)[lane] = reinterpret_cast<const uint32_t*>(vr)[lane];
+      __threadfence_block();
+    }
+  } else {
+    for (int i = lane; i < G * AD_D; i += 64) {
+      const int g = i / AD_D, e = i - g * AD_D;
+      qs[g][e] = bf2f(q[(int64_t)b * q_stride + (int64_t)(hk * G + g) * AD_D + e]) * scale;
+    }
   }
   __syncthreads();
   const int key = k0 + lane;
@@ -411,23 +437,44 @@ extern "C" int64_t grit_attn_decode_workspace_floats(int B, int nq, int nkv, int
   return (int64_t)B * nkv * splits * (nq / nkv) * (AD_D + 2);
 }
 
-extern "C" int grit_attn_decode(const void* q, const void* cache_k, const void* cache_v, const int32_t* lens, void* out, float* workspace, int B,
-                                int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale, void* stream) {
+static int attn_decode_launch(const char* name, const void* q, void* cache_k, void* cache_v, const int32_t* lens, void* out, float* workspace,
+                              const float* cos_tab, const float* sin_tab, int B, int nq, int nkv, int d, int Lmax, int64_t q_stride,
+                              int64_t out_stride, float scale, void* stream) {
   if (B == 0) return GRIT_OK;
-  GRIT_REQUIRE(q && cache_k && cache_v && lens && out && workspace, GRIT_E_BADARG, "grit_attn_decode: null pointer");
-  GRIT_REQUIRE(d == AD_D, GRIT_E_UNSUPPORTED, "grit_attn_decode: head_dim=%d (only 128 is built)", d);
-  GRIT_REQUIRE(nq % nkv == 0 && nq / nkv <= AD_G, GRIT_E_UNSUPPORTED, "grit_attn_decode: %d query heads per kv head (max %d)", nq / nkv, AD_G);
-  GRIT_REQUIRE(B > 0 && Lmax > 0 && B <= 65535 && nkv <= 65535, GRIT_E_BADARG, "grit_attn_decode: bad sizes");
-  GRIT_REQUIRE((Lmax + AD_CH - 1) / AD_CH <= 512, GRIT_E_UNSUPPORTED, "grit_attn_decode: Lmax=%d > %d", Lmax, 512 * AD_CH);
+  GRIT_REQUIRE(q && cache_k && cache_v && lens && out && workspace, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(d == AD_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
+  GRIT_REQUIRE(nq % nkv == 0 && nq / nkv <= AD_G, GRIT_E_UNSUPPORTED, "%s: %d query heads per kv head (max %d)", name, nq / nkv, AD_G);
+  GRIT_REQUIRE(B > 0 && Lmax > 0 && B <= 65535 && nkv <= 65535, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE((Lmax + AD_CH - 1) / AD_CH <= 512, GRIT_E_UNSUPPORTED, "%s: Lmax=%d > %d", name, Lmax, 512 * AD_CH);
   const int splits = (Lmax + AD_CH - 1) / AD_CH;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_decode_k, dim3((unsigned)splits, (unsigned)nkv, (unsigned)B), dim3(64), 0, st, (const uint16_t*)q, (const uint16_t*)cache_k,
-                     (const uint16_t*)cache_v, lens, workspace, nq, nkv, Lmax, q_stride, scale, splits);
-  GRIT_CHECK_LAUNCH("grit_attn_decode");
+  const dim3 grid((unsigned)splits, (unsigned)nkv, (unsigned)B);
+  if (cos_tab)
+    hipLaunchKernelGGL(attn_decode_k<true>, grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace, cos_tab,
+                       sin_tab, nq, nkv, Lmax, q_stride, scale, splits);
+  else
+    hipLaunchKernelGGL(attn_decode_k<false>, grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
+                       (const float*)nullptr, (const float*)nullptr, nq, nkv, Lmax, q_stride, scale, splits);
+  GRIT_CHECK_LAUNCH(name);
   hipLaunchKernelGGL(attn_decode_combine_k, dim3((unsigned)nq, (unsigned)B), dim3(AD_D), 0, st, (const float*)workspace, (uint16_t*)out, nq, nkv,
                      splits, out_stride);
-  GRIT_CHECK_LAUNCH("grit_attn_decode: combine");
+  GRIT_CHECK_LAUNCH(name);
   return GRIT_OK;
+}
+
+extern "C" int grit_attn_decode(const void* q, const void* cache_k, const void* cache_v, const int32_t* lens, void* out, float* workspace, int B,
+                                int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_decode_launch("grit_attn_decode", q, (void*)cache_k, (void*)cache_v, lens, out, workspace, nullptr, nullptr, B, nq, nkv, d, Lmax,
+                            q_stride, out_stride, scale, stream);
+}
+
+extern "C" int grit_attn_decode_rope(const void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens,
+                                     void* out, float* workspace, int B, int nq, int nkv, int d, int Lmax, int64_t qkv_stride, int64_t out_stride,
+                                     float scale, void* stream) {
+  GRIT_REQUIRE(cos_tab && sin_tab, GRIT_E_BADARG, "grit_attn_decode_rope: null pointer");
+  GRIT_REQUIRE(qkv_stride >= (int64_t)(nq + 2 * nkv) * d, GRIT_E_BADARG, "grit_attn_decode_rope: qkv_stride too small");
+  return attn_decode_launch("grit_attn_decode_rope", qkv, cache_k, cache_v, lens, out, workspace, cos_tab, sin_tab, B, nq, nkv, d, Lmax, qkv_stride,
+                            out_stride, scale, stream);
 }
 
 extern "C" int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history, int64_t hist_stride,

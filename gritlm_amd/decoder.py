@@ -3,7 +3,7 @@
 Replaces, for the RAG doc-caching flow of the reference (rag/eval.py:237-302: ``model.generate(inputs, past_key_values=kv_cache)`` where
 ``kv_cache`` came from ``encode(..., get_cache=True)``, gritlm/gritlm.py:131-140), the Hugging Face decode loop: every projection of a
 decode step is an HBM-bound GEMV (``grit_gemv_bf16``), attention reads the sequence's KV once (``grit_attn_decode``), the new token's
-K/V are appended in place, sampling is a device-side argmax -- and the whole step (6 launches per layer) is captured in ONE HIP
+K/V are appended in place, sampling is a device-side argmax -- and the whole step (5 launches per layer) is captured in ONE HIP
 graph, so the host only replays it.  Greedy decoding only (``do_sample=False``), batch <= 8, head_dim 128.
 """
 from __future__ import annotations
@@ -43,8 +43,7 @@ class MistralDecoder:
         for li, L in enumerate(e.layers):
             ck, cv = st["cache"][li]
             ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv)                      # input_layernorm + q/k/v projections
-            ops.rope_kv_append(qkv, st["cos"], st["sin"], ck, cv, st["lens"], nq, nkv, d)
-            ops.attn_decode(qkv, ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)
+            ops.attn_decode_rope(qkv, st["cos"], st["sin"], ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)   # RoPE + KV append + attention
             ops.gemv(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm_gemv(h, L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU)   # post_attention_layernorm + gate/up + SwiGLU
             ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)

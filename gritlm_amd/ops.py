@@ -475,6 +475,18 @@ def attn_decode(q: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, l
     return out
 
 
+def attn_decode_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor,
+                     out: torch.Tensor, workspace: torch.Tensor, nq: int, nkv: int, d: int, scale: float | None = None):
+    """rope_kv_append + attn_decode in one launch (qkv: the raw fused projection of the new token; the caches are appended to)."""
+    B, _, Lmax, _ = cache_k.shape
+    assert cos.shape[0] >= Lmax
+    check(_lib.load().grit_attn_decode_rope(_chk2d(qkv, BF16, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"), _chk(cache_k, BF16, "cache_k"),
+                                            _chk(cache_v, BF16, "cache_v"), _chk(lens, I32, "lens"), _chk2d(out, BF16, "out"),
+                                            _chk(workspace, F32, "workspace"), B, nq, nkv, d, Lmax, qkv.stride(0), out.stride(0),
+                                            float(d ** -0.5 if scale is None else scale), _stream()), "grit_attn_decode_rope")
+    return out
+
+
 def argmax_advance(logits: torch.Tensor, next_ids: torch.Tensor, lens: torch.Tensor | None = None, history: torch.Tensor | None = None,
                    step: torch.Tensor | None = None):
     B, V = logits.shape

@@ -260,6 +260,12 @@ int grit_kv_append(const void* qkv, void* cache_k, void* cache_v, const int32_t*
 int64_t grit_attn_decode_workspace_floats(int B, int nq, int nkv, int Lmax);
 int grit_attn_decode(const void* q, const void* cache_k, const void* cache_v, const int32_t* lens, void* out, float* workspace,
                      int B, int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale, void* stream);
+/* The same with the step's RoPE and KV-append folded in: qkv [B, qkv_stride] is the raw fused projection of the new token; q is rotated
+ * on the fly at position lens[b], k is rotated and k, v are appended to the caches by the workgroup whose key slice contains that
+ * position (= grit_rope_kv_append + grit_attn_decode in one launch; the caches are written). */
+int grit_attn_decode_rope(const void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens,
+                          void* out, float* workspace, int B, int nq, int nkv, int d, int Lmax, int64_t qkv_stride, int64_t out_stride,
+                          float scale, void* stream);
 /* Greedy step: next[b] = argmax_v logits[b,v] (bf16 logits, lowest index on ties); optionally history[b, *step] = next[b],
  * *step += 1 and lens[b] += 1 -- all on the device, so a whole decode step is one HIP graph. */
 int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history,

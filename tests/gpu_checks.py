@@ -831,7 +831,17 @@ def check_decode_fused_ops(B=2, H=512, N=768, nq=4, nkv=2, Lmax=256):
     ops.rope_qk_pos_(q2, cos, sin, lens, nq, nkv, d)
     ops.kv_append(q2, ck2, cv2, lens, nq, nkv, d)
     ok &= bool(torch.equal(q1[:, :nq * d], q2[:, :nq * d])) and bool(torch.equal(ck1, ck2)) and bool(torch.equal(cv1, cv2)) and float(ck1.abs().sum()) > 0
-    return _res("decode fused ops (rmsnorm+gemv, rope+kv-append) == unfused kernels", ok)
+    # attention with RoPE + append folded in == rope_kv_append followed by attn_decode, bit for bit (caches included)
+    ck3, cv3 = bf(rnd((B, nkv, Lmax, d), 95)), bf(rnd((B, nkv, Lmax, d), 96))
+    ck4, cv4 = ck3.clone(), cv3.clone()
+    qa, qb = qkv.clone(), qkv.clone()
+    ws = ops.attn_decode_workspace(B, nq, nkv, Lmax, DEV)
+    o3 = torch.empty((B, nq * d), dtype=torch.bfloat16, device=DEV); o4 = torch.empty_like(o3)
+    ops.rope_kv_append(qa, cos, sin, ck3, cv3, lens, nq, nkv, d)
+    ops.attn_decode(qa, ck3, cv3, lens, o3, ws, nq, nkv, d)
+    ops.attn_decode_rope(qb, cos, sin, ck4, cv4, lens, o4, ws, nq, nkv, d)
+    ok &= bool(torch.equal(o3, o4)) and bool(torch.equal(ck3, ck4)) and bool(torch.equal(cv3, cv4))
+    return _res("decode fused ops (rmsnorm+gemv, rope+kv-append, rope+append+attention) == unfused kernels", ok)
 
 
 def check_attn_decode(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
