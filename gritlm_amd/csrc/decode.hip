@@ -333,9 +333,18 @@ __global__ void __launch_bounds__(256) argmax_advance_k(const uint16_t* __restri
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  for (int v = tid; v < V; v += 256) {
-    const float x = bf2f(logits[(int64_t)b * ld + v]);
-    if (x > best) { best = x; idx = v; }
+  const uint16_t* row = logits + (int64_t)b * ld;
+  const int VC = V >> 3;                                      // 16-byte chunks (ld % 8 == 0 keeps the rows aligned)
+  for (int c = tid; c < VC; c += 256) {
+    const uint4 u = reinterpret_cast<const uint4*>(row)[c];
+    const float x[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (x[e] > best) { best = x[e]; idx = c * 8 + e; }      // ascending index inside a thread: first maximum wins
+  }
+  for (int v = (VC << 3) + tid; v < V; v += 256) {
+    const float x = bf2f(row[v]);
+    if (x > best || (x == best && v < idx)) { best = x; idx = v; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -481,7 +490,8 @@ extern "C" int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_
                                    int32_t* step, int B, void* stream) {
   if (B == 0) return GRIT_OK;
   GRIT_REQUIRE(logits && next, GRIT_E_BADARG, "grit_argmax_advance: null pointer");
-  GRIT_REQUIRE(V > 0 && ld >= V && B > 0 && (!history || step), GRIT_E_BADARG, "grit_argmax_advance: bad sizes");
+  GRIT_REQUIRE(V > 0 && ld >= V && ld % 8 == 0 && B > 0 && (!history || step), GRIT_E_BADARG, "grit_argmax_advance: bad sizes");
+  GRIT_REQUIRE(aligned16(logits), GRIT_E_BADARG, "grit_argmax_advance: logits must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(argmax_advance_k, dim3((unsigned)B), dim3(256), 0, st, (const uint16_t*)logits, ld, V, next, lens, history, hist_stride, step);
   GRIT_CHECK_LAUNCH("grit_argmax_advance");
