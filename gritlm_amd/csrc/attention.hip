@@ -5,15 +5,15 @@
 // index arithmetic), no mask tensor (one uint64 per 64 keys), no S x S score matrix.
 //
 // Structure: one 256-thread workgroup = 128 query rows of one (batch, head); each wave owns 32 rows.
-// KV tiles of 64 keys go HBM -> registers -> LDS (K row-major with a 16-B-slot XOR swizzle, V TRANSPOSED
-// to [d][key] with a 136-B row pitch) with the next tile's global loads in flight during the MFMAs.
+// KV tiles of 64 keys go HBM -> registers -> LDS (K row-major with a 16-B-slot XOR swizzle, V row-major with a
+// 320-B pitch and read back TRANSPOSED by ds_read_b64_tr_b16) with the next tile's global loads in flight during the MFMAs.
 //   S^T = K Q^T     v_mfma_f32_32x32x16_bf16(A = K rows, B = Q)  -> lane (q = lane&31) holds 32 keys' scores
 //   O^T = V^T P^T   v_mfma_f32_32x32x16_bf16(A = V^T rows, B = P) -> lane (q = lane&31) holds 64 of its d's
 // Both products are "swapped" so that every softmax statistic (max, sum, rescale) is lane-local: the only
 // cross-lane traffic per tile is one shuffle with lane^32 for the row max.  The P operand needs no
 // permlane/LDS round trip: the MFMA contraction index is permuted identically on the V^T side
-// (key(kb,c,hi,j) = 32kb + 16c + 8(j>>2) + 4hi + (j&3)), which the transposed LDS image makes two
-// 8-byte reads.
+// (key(kb,c,hi,j) = 32kb + 16c + 8(j>>2) + 4hi + (j&3)): two transposing 8-byte LDS reads whose per-lane
+// addresses select exactly those keys.
 #include "common.h"
 
 namespace grit {
@@ -21,9 +21,10 @@ namespace grit {
 constexpr int ATT_D = 128;
 constexpr int ATT_QB = 128;   // query rows per workgroup
 constexpr int ATT_KB = 64;    // keys per tile
-constexpr int VT_PITCH = 136; // bytes per d-row of the transposed V image (64 keys * 2 B + 8 pad)
+constexpr int V_PITCH = 320;  // bytes per key row of the row-major V image: 256 + 64, so that 4 consecutive rows start 16 banks apart
 constexpr int K_LDS_BYTES = ATT_KB * ATT_D * 2;  // 16384
-constexpr int V_LDS_BYTES = ATT_D * VT_PITCH;    // 17408
+constexpr int V_LDS_BYTES = ATT_KB * V_PITCH;    // 20480
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 __device__ __forceinline__ uint32_t lo16(uint32_t w) { return w & 0xffffu; }
 __device__ __forceinline__ uint32_t hi16(uint32_t w) { return w >> 16; }
@@ -84,14 +85,11 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
   // ---- staging roles
   // K: 1024 16-B chunks per tile, 4 per thread: chunk = tid + 256*it -> row = (tid>>4) + 16*it, slot = tid&15
-  // V: 512 (key-pair, 8-d group) items, 2 per thread; inside each 32-lane half: 8 key pairs x 4 d-groups
-  const int lane32 = tid & 31, half = tid >> 5;
   // per-thread staging constants (no arrays / lambdas: keeps the staging registers out of scratch)
   const int k_row = tid >> 4, k_slot = tid & 15;                 // chunk it: row = k_row + 16*it
   const int k_lds_off = k_row * 256 + ((k_slot ^ (k_row & 15)) << 4);  // (row+16it)&15 == row&15
-  const int v_kp0 = (half & 3) * 8 + (lane32 & 7), v_dg0 = (half >> 2) * 4 + (lane32 >> 3);  // it = 0: u = half
-  const int v_kp1 = v_kp0, v_dg1 = v_dg0 + 8;                                                  // it = 1: u = half + 8
-  uint4 kr0, kr1, kr2, kr3, va0, vc0, va1, vc1;
+  const int v_lds_off = k_row * V_PITCH + k_slot * 16;          // V: same (row, 16-byte slot) roles as K, row-major, no swizzle
+  uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
 
 #define ATT_KROW(it) ({ int key_ = key0_ + k_row + 16 * (it); key_ < S ? key_ : S - 1; })
 #define ATT_LOAD_TILE(t)                                                                                       \
@@ -101,21 +99,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     kr1 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(1)) * qkv_stride + k_slot * 8);             \
     kr2 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(2)) * qkv_stride + k_slot * 8);             \
     kr3 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(3)) * qkv_stride + k_slot * 8);             \
-    int ka_ = key0_ + 2 * v_kp0, kc_ = ka_ + 1;                                                                \
-    ka_ = ka_ < S ? ka_ : S - 1; kc_ = kc_ < S ? kc_ : S - 1;                                                  \
-    va0 = *reinterpret_cast<const uint4*>(vbase + (row0 + ka_) * qkv_stride + v_dg0 * 8);                      \
-    vc0 = *reinterpret_cast<const uint4*>(vbase + (row0 + kc_) * qkv_stride + v_dg0 * 8);                      \
-    va1 = *reinterpret_cast<const uint4*>(vbase + (row0 + ka_) * qkv_stride + v_dg1 * 8);                      \
-    vc1 = *reinterpret_cast<const uint4*>(vbase + (row0 + kc_) * qkv_stride + v_dg1 * 8);                      \
-  } while (0)
-#define ATT_VT_STORE(a, c, kp, dg)                                                                             \
-  do {                                                                                                         \
-    uint32_t* dst_ = reinterpret_cast<uint32_t*>(v_lds + ((dg) * 8) * VT_PITCH + (kp) * 4);                    \
-    constexpr int P4 = VT_PITCH / 4;                                                                           \
-    dst_[0 * P4] = lo16((a).x) | (lo16((c).x) << 16); dst_[1 * P4] = hi16((a).x) | (hi16((c).x) << 16);        \
-    dst_[2 * P4] = lo16((a).y) | (lo16((c).y) << 16); dst_[3 * P4] = hi16((a).y) | (hi16((c).y) << 16);        \
-    dst_[4 * P4] = lo16((a).z) | (lo16((c).z) << 16); dst_[5 * P4] = hi16((a).z) | (hi16((c).z) << 16);        \
-    dst_[6 * P4] = lo16((a).w) | (lo16((c).w) << 16); dst_[7 * P4] = hi16((a).w) | (hi16((c).w) << 16);        \
+    vr0 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(0)) * qkv_stride + k_slot * 8);             \
+    vr1 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(1)) * qkv_stride + k_slot * 8);             \
+    vr2 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(2)) * qkv_stride + k_slot * 8);             \
+    vr3 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(3)) * qkv_stride + k_slot * 8);             \
   } while (0)
 #define ATT_STORE_TILE()                                                                                       \
   do {                                                                                                         \
@@ -123,8 +110,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     *reinterpret_cast<uint4*>(k_lds + k_lds_off + 16 * 256) = kr1;                                             \
     *reinterpret_cast<uint4*>(k_lds + k_lds_off + 32 * 256) = kr2;                                             \
     *reinterpret_cast<uint4*>(k_lds + k_lds_off + 48 * 256) = kr3;                                             \
-    ATT_VT_STORE(va0, vc0, v_kp0, v_dg0);                                                                      \
-    ATT_VT_STORE(va1, vc1, v_kp1, v_dg1);                                                                      \
+    *reinterpret_cast<uint4*>(v_lds + v_lds_off) = vr0;                                                        \
+    *reinterpret_cast<uint4*>(v_lds + v_lds_off + 16 * V_PITCH) = vr1;                                         \
+    *reinterpret_cast<uint4*>(v_lds + v_lds_off + 32 * V_PITCH) = vr2;                                         \
+    *reinterpret_cast<uint4*>(v_lds + v_lds_off + 48 * V_PITCH) = vr3;                                         \
   } while (0)
 
   f32x16_t oacc[4];
@@ -136,8 +125,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
   // K fragment address: row = 32kb + (lane&31), d-slot = 2ks + hi, swizzle by row&15 == lane&15
   const int kf_row = ql * 256, kf_x = lane & 15;
-  // V^T fragment address: row d = 32db + (lane&31), keys 32kb + 16c + 4hi (+8)
-  const int vf_row = ql * VT_PITCH + hi * 8;
+  // V fragment (A operand of O^T += V^T P^T) straight from the ROW-MAJOR V image with ds_read_b64_tr_b16: in every 16-lane group lane j
+  // points at V[k0 + j/4][d0 + 4 (j%4)] and lane c receives V[k0 .. k0+3][d0 + c] (the hardware transposes the group's 4 x 16 block);
+  // d0 = 32db + 16 ((lane>>4)&1) makes c <-> the MFMA row lane&31, k0 = 32kb + 16c + 4hi (+8 for the second half of the k-slice)
+  const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
 
   if (ntiles > 0) ATT_LOAD_TILE(0);
   for (int t = 0; t < ntiles; ++t) {
@@ -229,10 +220,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const char* vp = v_lds + db * 32 * VT_PITCH + vf_row + (kb * 32 + c * 16) * 2;
-          const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
-          const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
-          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+          const char* vp = v_lds + vt_lane + (kb * 32 + c * 16) * V_PITCH + db * 64;
+          const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
+          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * V_PITCH));
+          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
         }
     }

@@ -43,12 +43,13 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
   return u >> 16;
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
-// hardware pack (v_cvt_pk_bf16_f32, RNE): one instruction for two conversions -- used in the attention inner loops where the
-// bit-trick version above (8 VALU per pair) showed up next to the MFMAs
+// hardware pack (v_cvt_pk_bf16_f32, RNE): one instruction for two conversions.  Written as a vector conversion, NOT as inline asm: the
+// compiler then knows it is a VALU write and inserts the wait states an MFMA that reads the result as SrcA/B needs -- with an opaque asm
+// statement directly in front of the MFMA, part of the lanes saw stale operands (found with the tr-read attention variant)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_pk_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_pk_t;
 __device__ __forceinline__ uint32_t pack2bf_hw(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_pk_t){lo, hi}, bf16x2_pk_t));
 }
 __device__ __forceinline__ float round_bf(float f) { return __uint_as_float(f2bf(f) << 16); }
 
