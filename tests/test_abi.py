@@ -44,6 +44,30 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
         _lib.check(-2, "x")
 
 
+def test_bad_arguments_of_the_widened_entry_points():
+    """Validation of the round-1 'next' entry points (grouped / RoPE GEMM, MoE, CE, decode, kNN): documented error codes, no launch."""
+    lib = _lib.load()
+    buf = (ctypes.c_char * 8192)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    U, B = _lib.GRIT_E_UNSUPPORTED, _lib.GRIT_E_BADARG
+    assert lib.grit_gemm_bf16_nt_rope(p16, p16, p16, 4, 192, 64, 64, 64, 192, p16, p16, None, 8, 8, 128, None) == U          # N % 128
+    assert b"128" in lib.grit_last_error_string()
+    assert lib.grit_gemm_bf16_nt_rope(p16, p16, p16, 4, 256, 64, 64, 64, 256, p16, p16, None, 0, 8, 128, None) == B          # neither positions nor S
+    assert lib.grit_gemm_bf16_nt_grouped(p16, None, p16, p16, p16, 8, 64, 64, 64, 64, 64, 4096, 64, 1, None) == B            # RESIDUAL not offered
+    assert lib.grit_moe_router_top2(p16, p16, p16, p16, 4, 64, 5, None) == U                                                 # 5 experts
+    assert lib.grit_moe_index(p16, 4, 17, p16, p16, p16, p16, None) == U                                                     # > 16 experts
+    assert lib.grit_ce_fwd(p16, 8, p16, p16, p16, 4, 16, None) == B                                                          # ld < V
+    assert lib.grit_gemv_bf16(p16, p16, p16, 9, 16, 64, 64, 64, 16, 0, None, 0, None) == U                                   # > 8 rows
+    assert b"grit_gemm_bf16_nt" in lib.grit_last_error_string()
+    assert lib.grit_gemv_bf16(p16, p16, p16, 1, 48, 64, 64, 64, 24, 2, None, 0, None) == U                                   # SWIGLU N % 32
+    assert lib.grit_attn_decode(p16, p16, p16, p16, p16, p16, 1, 2, 1, 64, 256, 256, 128, 0.1, None) == U                    # head_dim
+    assert lib.grit_attn_decode(p16, p16, p16, p16, p16, p16, 1, 32, 2, 128, 256, 4096, 4096, 0.1, None) == U                # 16 q heads per kv head
+    assert lib.grit_knn_topk(p16, p16, 2, 100, 64, 64, 1, 2000, p16, p16, p16, None) == U                                    # k > 1024
+    assert lib.grit_knn_topk(p16, p16, 2, 10, 64, 64, 1, 11, p16, p16, p16, None) == U                                       # k > N
+    assert lib.grit_argmax_advance(p16, 12, 16, p16, None, None, 0, None, 1, None) == B                                      # ld < V
+    assert lib.grit_knn_workspace_bytes(4, 10000, 10) > 4 * 10000 * 4
+
+
 def test_ops_refuse_cpu_tensors_loudly():
     import torch
     from gritlm_amd import ops
