@@ -122,3 +122,36 @@ def test_sharded_encode_equals_single_process(tmp_path):
     mp.spawn(_enc_worker, args=(2, _free_port(), d, sents, ret), nprocs=2, join=True)
     for r in range(2):
         np.testing.assert_allclose(ret[r], ref, atol=2e-6)
+
+
+def _unified_worker(rank, world, port, model_dir, data_dir, out_dir, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from gritlm_amd.training import run
+    loss = run.main(["--model_name_or_path", model_dir, "--train_data", data_dir, "--output_dir", out_dir, "--mode", "unified",
+                     "--per_device_train_batch_size", "2", "--gradient_accumulation_steps", "2", "--negatives_cross_device",
+                     "--train_group_size", "4", "--pooling_method", "mean", "--max_steps", "2", "--learning_rate", "1e-3",
+                     "--query_max_len", "16", "--passage_max_len", "24", "--generative_max_len", "32", "--report_to", "none", "--use_cpu"])
+    ret[rank] = dict(loss=float(loss), loss_gen=float(run.main.last_loss_gen))
+    if rank == 0:
+        ret["saved"] = sorted(f for f in os.listdir(out_dir) if f.endswith(".safetensors"))
+
+
+def test_two_rank_unified_cli_keeps_replicas_in_lockstep(tmp_path):
+    """--mode unified under 2 gloo ranks: generative step (its gradients, lm_head included, stay local until the embedding step's
+    averaging), cross-device negatives in the GradCache embedding step; both ranks finish with finite losses and the same embedding loss
+    (it is a function of the gathered global batch)."""
+    import json
+    import synth
+    d = synth.build_mistral_dir(str(tmp_path / "m32"), "tiny", 0, "float32")
+    os.makedirs(tmp_path / "data")
+    W = synth.WORDS
+    rows = [{"query": " ".join(W[i:i + 5]), "pos": [" ".join(W[i + 1:i + 9])], "neg": [" ".join(W[j:j + 7]) for j in range(i + 20, i + 24)]}
+            for i in range(0, 48, 2)]
+    open(tmp_path / "data" / "emb.jsonl", "w").write("\n".join(json.dumps(r) for r in rows))
+    open(tmp_path / "data" / "gen.jsonl", "w").write("\n".join(json.dumps({"text": [" ".join(W[i:i + 4]), " ".join(W[i + 30:i + 40])]}) for i in range(24)))
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_unified_worker, args=(2, _free_port(), d, str(tmp_path / "data"), str(tmp_path / "out"), ret), nprocs=2, join=True)
+    assert all(np.isfinite(ret[r]["loss"]) and np.isfinite(ret[r]["loss_gen"]) for r in range(2))
+    assert abs(ret[0]["loss"] - ret[1]["loss"]) < 1e-5
+    assert ret["saved"]
