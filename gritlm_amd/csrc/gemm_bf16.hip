@@ -7,15 +7,26 @@
 //   * 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave),
 //     BK = 64, v_mfma_f32_16x16x32_bf16, 32 accumulator fragments (128 fp32 regs) per wave;
 //   * both operands are K-contiguous, staged HBM->LDS by direct LDS-DMA (global_load_lds, 16 B/lane,
-//     1 KiB per wave-instruction), two 64 KiB LDS stages, one barrier per K-tile;
+//     1 KiB per wave-instruction) into two 64 KiB stages, each split into four 16 KiB HALF-TILES
+//     (A_h0, A_h1, W_h0, W_h1: the activation rows / weight rows every wave needs for one QUADRANT of
+//     its 128x64 output);
+//   * main loop = 4 phases per K-tile, one output quadrant (16 MFMAs) each; a phase is
+//     {ds_read the quadrant's new fragments, issue ONE half-tile of LDS-DMA, counted vmcnt} | barrier |
+//     {16 MFMAs at raised priority} | barrier.  The two wave groups (wr = 0 / 1; one wave of each on
+//     every SIMD) run ONE BARRIER APART, so on every SIMD one wave feeds the matrix pipe while its
+//     partner issues LDS reads and DMA: the load segments sit beside the other group's MFMAs instead
+//     of in front of its own.  LDS-DMA runs 4-5 phases ahead of its first reader (never vmcnt(0));
 //   * LDS image is lane-linear; the bank-conflict swizzle (16-B slot ^= (row>>1)&7, two 128-B rows =
 //     one 256-B bank row) is applied to the per-lane SOURCE address and to the ds_read_b128 address;
 //   * the W fragment is the MFMA "A" operand and the activation fragment the "B" operand, so each lane
-//     ends up with 4 CONSECUTIVE output columns of one row -> 8-byte packed bf16 stores and a
+//     ends up with 4 CONSECUTIVE output columns of one row -> packed bf16 stores and a
 //     register-local SwiGLU (gate/up weight rows interleaved in blocks of 16);
 //   * XCD-aware block remap (block b runs on XCD b % 8): every XCD walks a contiguous range of tiles,
-//     8 m-tiles x 4 n-tiles in flight per XCD share A/W panels in that XCD's 4 MiB L2.
+//     4 m-tiles x 8 n-tiles in flight per XCD share A/W panels in that XCD's 4 MiB L2.
 #include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
 
 #include "common.h"
 
@@ -23,22 +34,13 @@ namespace grit {
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
+constexpr int HALF_BYTES = 128 * BK * 2;         // 16 KiB: 128 LDS rows x 128 B
 constexpr int A_BYTES = BM * BK * 2;             // 32 KiB
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-
-// Workgroup barrier that also retires this wave's LDS-DMA (global_load_lds) and LDS reads.  hipcc does not model the
-// LDS-DMA builtin as a store to LDS: it may hoist later ds_reads above a plain __syncthreads() and omit the vmcnt
-// wait when the DMA was issued in a previous loop iteration (seen in the ISA of the pipelined kernel) -- so the wait
-// is explicit and both sides are fenced for the compiler with "memory" clobbers.
-__device__ __forceinline__ void lds_dma_barrier() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 
 // Grouped ("MoE") mode: the M rows are the concatenation of n_groups row ranges (counts[g] rows each, read from DEVICE memory so
 // the host never syncs on the routing), group g multiplies against W + g * w_stride.  tiles_m is then an upper bound
@@ -63,7 +65,27 @@ struct GemmRope {
   int rope_cols;
 };
 
-template <int EPI, int ABL = 0>
+// first tile row of W fragment j of the waves in column wc (= first output column of the fragment inside the 256-wide tile)
+template <bool ROPE>
+__device__ __forceinline__ int wrow_of(int wc, int j) {
+  return ROPE ? (wc >> 1) * 128 + (j >> 1) * 64 + (wc & 1) * 32 + (j & 1) * 16 : wc * 64 + j * 16;
+}
+
+// compiler fence between the segments of a phase: hipcc does not model the LDS-DMA builtin as a store to LDS (it would hoist or
+// merge ds_reads across barriers), and it moves register-only MFMAs across asm waits (guide rule 18)
+#define GRIT_SEG_FENCE()                     \
+  do {                                       \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+#define GRIT_BARRIER()                       \
+  do {                                       \
+    GRIT_SEG_FENCE();                        \
+    __builtin_amdgcn_s_barrier();            \
+    GRIT_SEG_FENCE();                        \
+  } while (0)
+
+template <int EPI>
 __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W_all,
                                                       uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
@@ -114,41 +136,41 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
-  // ---- staging addresses: wave `wid` fills chunks wid*4..wid*4+3 (8 rows x 128 B each) of A and of W
+  // ---- LDS-DMA sources.  Half-tile kinds: 0 = A_h0, 1 = A_h1, 2 = W_h0, 3 = W_h1; every half-tile is 128 LDS rows of 128 B and wave
+  //      `wid` fills LDS rows wid*16 .. wid*16+15 of it with two 1-KiB instructions (8 rows each).
+  //      A_h, LDS row p  <->  tile row (p>>6)*128 + h*64 + (p&63)             (64 rows of each M-half of the workgroup)
+  //      W_h, LDS row p  <->  tile row wrow(p>>5, 2h + ((p>>4)&1)) + (p&15)   (fragments 2h, 2h+1 of each of the 4 wave columns)
   const int srow = lane >> 3;                                  // row inside the 8-row chunk
-  const uint16_t* a_src[4];
-  const uint16_t* w_src[4];
+  const uint16_t* src[4][2];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int r = (wid * 4 + c) * 8 + srow;                    // tile row 0..255
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);              // logical 16-B slot held by this physical slot
-    int64_t gm_row = m0 + r; if (gm_row > M - 1) gm_row = M - 1;
-    if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
-    int gn_row = n0 + r; if (gn_row > N - 1) gn_row = N - 1;
-    if (ABL == 14) { gm_row &= 255; gn_row &= 255; }           // timing experiment: L2-resident operands (256 rows x 512 k each)
-    a_src[c] = A + gm_row * lda + slot * 8;
-    w_src[c] = W + (int64_t)gn_row * ldw + slot * 8;
-  }
-
-  auto stage = [&](int buf, int kt) {
-    if (ABL == 14) kt &= 7;
-    char* base = smem + buf * STAGE_BYTES + wid * 4096;
+  for (int c = 0; c < 2; ++c) {
+    const int p = wid * 16 + c * 8 + srow;
+    const int slot = (lane & 7) ^ ((p >> 1) & 7);              // logical 16-B slot held by this physical slot
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[c] + (int64_t)kt * BK), (lptr_t)(base + c * 1024), 16, 0, 0);
-      if (ABL != 10 || kt == 0)
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)kt * BK), (lptr_t)(base + A_BYTES + c * 1024), 16, 0, 0);
+    for (int h = 0; h < 2; ++h) {
+      const int ra = (p >> 6) * 128 + h * 64 + (p & 63);
+      int64_t gm_row = m0 + ra; if (gm_row > M - 1) gm_row = M - 1;
+      if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
+      src[h][c] = A + gm_row * lda + slot * 8;
+      const int rw = wrow_of<ROPE>(p >> 5, 2 * h + ((p >> 4) & 1)) + (p & 15);
+      int gn_row = n0 + rw; if (gn_row > N - 1) gn_row = N - 1;
+      src[2 + h][c] = W + (int64_t)gn_row * ldw + slot * 8;
     }
+  }
+  const int nk = K / BK;
+  auto stage = [&](int kind, int buf, int kt) {               // kt past the end re-stages the last K-tile (nobody reads it): branch-free body
+    const int64_t ko = (int64_t)(kt < nk ? kt : nk - 1) * BK;
+    char* base = smem + buf * STAGE_BYTES + kind * HALF_BYTES + wid * 2048;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][0] + ko), (lptr_t)base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][1] + ko), (lptr_t)(base + 1024), 16, 0, 0);
   };
 
-  // ---- fragment read offsets (bytes inside a stage); swizzle term is lane-constant because every
-  //      fragment starts at a multiple of 16 rows: (row>>1)&7 == (lane>>1)&7
+  // ---- fragment read offsets (bytes inside a stage); the swizzle term is lane-constant because every fragment starts at a
+  //      multiple of 16 LDS rows: (row>>1)&7 == (lane>>1)&7
   const int frow = lane & 15, kq = lane >> 4, swz = (lane >> 1) & 7;
-  const int a_off = (wr * 128 + frow) * 128;            // + i*2048
-  // first tile row of W fragment j of this wave (= first output column of the fragment inside the tile)
-  auto wrow = [&](int j) { return ROPE ? (wc >> 1) * 128 + (j >> 1) * 64 + (wc & 1) * 32 + (j & 1) * 16 : wc * 64 + j * 16; };
-  const int w_off = A_BYTES + frow * 128;               // + wrow(j)*128
-  const int s_off0 = ((kq) ^ swz) << 4, s_off1 = ((4 + kq) ^ swz) << 4;
+  const int s_off[2] = {(kq ^ swz) << 4, ((4 + kq) ^ swz) << 4};
+  const int a_off = (wr * 64 + frow) * 128;                        // A frag i: + (i>>2)*HALF_BYTES + (i&3)*2048
+  const int w_off = 2 * HALF_BYTES + (wc * 32 + frow) * 128;       // W frag j: + (j>>1)*HALF_BYTES + (j&1)*2048
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -156,114 +178,82 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
-  stage(0, 0);
-  lds_dma_barrier();
+  bf16x8_t wf0[2][2], wf1[2][2], xf[4][2];                         // [fragment][k-step]
+#define GRIT_READ_W(WF, H, SB)                                                                        \
+  _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+      WF[jj][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + w_off + (H) * HALF_BYTES + jj * 2048 + s_off[ks])
+#define GRIT_READ_X(H, SB)                                                                            \
+  _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+      xf[ii][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
+#define GRIT_MMA(WF, I0, J0)                                                                          \
+  do {                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+      _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                              \
+          acc[(I0) + ii][(J0) + jj] =                                                                 \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+  } while (0)
+#define GRIT_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (ABL == 0 || ABL == 8 || ABL == 9 || ABL == 12 || ABL == 13 || ABL == 14) stage(cur ^ 1, kt + 1 < nk ? kt + 1 : kt);   // branch-free body (re-stages the last tile once, harmless)
-    else if (kt + 1 < nk && ABL != 1) stage(cur ^ 1, kt + 1);
-    const char* sb = smem + (ABL == 2 ? 0 : cur * STAGE_BYTES);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int so = ks ? s_off1 : s_off0;
-      bf16x8_t wf[4], xf[8];
-      if (ABL != 2 || kt == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sb + w_off + wrow(j) * 128 + so);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(sb + a_off + i * 2048 + so);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(kt, j, ks, lane));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(kt, i, ks, lane));
-      }
-      if (ABL == 3) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(xf[i]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(wf[j]));
-      } else {
-        if (ABL == 5) __builtin_amdgcn_s_setprio(1);
-        if (ABL == 6) __builtin_amdgcn_iglp_opt(0);
-        if (ABL == 7) __builtin_amdgcn_iglp_opt(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        if (ABL == 5) __builtin_amdgcn_s_setprio(0);
-      }
-    }
-    if (ABL == 8) {
-      // explicit issue order for the K-tile body (LLVM sched_group_barrier: 0x10 VMEM, 0x100 DS read, 0x8 MFMA): every pair of
-      // activation fragments is read one 8-MFMA group AHEAD of the group that consumes it, so the lgkmcnt waits are counted
-      // instead of lgkmcnt(0) right behind the read
-      __builtin_amdgcn_sched_group_barrier(0x10, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // w0-3, x0-3 (ks 0)
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G0: x0,x1
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // x4,x5
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G1: x2,x3
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // x6,x7
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G2: x4,x5
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // ks 1: w0-3, x0,x1
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G3: x6,x7
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G4
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G5
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G6
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G7
-    }
-    if (ABL == 12) {  // LDS-DMA spread: one per 8-MFMA group
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 10, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-    }
-    if (ABL == 13) {  // LDS-DMA spread over the first half: one per 4 MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
-    }
-    if (ABL == 0 || ABL == 9 || ABL == 14) {  // default: fragment reads issued two MFMA groups ahead of their consumers
-      __builtin_amdgcn_sched_group_barrier(0x10, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);  // w0-3, x0-5 (ks 0)
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G0
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // x6,x7
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G1
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // ks 1: w0-3, x0,x1
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G2
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G3
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G4
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G5
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G6
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);     // G7
-    }
-    lds_dma_barrier();
+  // One K-tile = 4 phases.  Half-tile stream (issue order) ... A_h0(t) W_h0(t) W_h1(t) A_h1(t) A_h0(t+1) ...; phase p of tile t issues
+  // the half-tile 6 positions ahead of the one phase p reads first, into a slot whose last reader ran >= 2 phases earlier (the other
+  // wave group is half a phase behind, so 2 phases is the minimum that has every reader's lgkmcnt(0) behind a barrier).  A half-tile
+  // read in phase p was waited for -- by EVERY wave, vmcnt(8) = "all but the 4 newest half-tiles have landed" -- before the first
+  // barrier of phase p-1.
+  auto tile = [&](int kt, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* sb = smem + BUF * STAGE_BYTES;
+    // phase 1: quadrant (A_h0, W_h0)
+    GRIT_READ_W(wf0, 0, sb);
+    GRIT_READ_X(0, sb);
+    stage(3, BUF ^ 1, kt + 1);
+    GRIT_VMCNT8();                    // W_h1(kt) landed (read in phase 2)
+    GRIT_BARRIER();
+    GRIT_MMA(wf0, 0, 0);
+    GRIT_BARRIER();
+    // phase 2: quadrant (A_h0, W_h1)
+    GRIT_READ_W(wf1, 1, sb);
+    stage(1, BUF ^ 1, kt + 1);
+    GRIT_VMCNT8();                    // A_h1(kt) landed (read in phase 3)
+    GRIT_BARRIER();
+    GRIT_MMA(wf1, 0, 2);
+    GRIT_BARRIER();
+    // phase 3: quadrant (A_h1, W_h1)
+    GRIT_READ_X(1, sb);
+    stage(0, BUF, kt + 2);
+    GRIT_BARRIER();
+    GRIT_MMA(wf1, 4, 2);
+    GRIT_BARRIER();
+    // phase 4: quadrant (A_h1, W_h0) -- fragments already in registers
+    stage(2, BUF, kt + 2);
+    GRIT_VMCNT8();                    // A_h0(kt+1), W_h0(kt+1) landed (read in phase 1 of the next tile)
+    GRIT_BARRIER();
+    GRIT_MMA(wf0, 4, 0);
+    GRIT_BARRIER();
+  };
+
+  stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(0, 1, 1); stage(2, 1, 1);
+  GRIT_VMCNT8();                      // A_h0(0), W_h0(0)
+  GRIT_BARRIER();
+  if (wr == 1) GRIT_BARRIER();        // the second wave group runs one barrier behind the first
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) tile(kt + 1, std::integral_constant<int, 1>{});
   }
+  if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
+  GRIT_SEG_FENCE();
+#undef GRIT_READ_W
+#undef GRIT_READ_X
+#undef GRIT_MMA
+#undef GRIT_VMCNT8
+  auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
 
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
   const int64_t mrow = m0 + wr * 128 + frow;
@@ -357,184 +347,40 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           }
         }
         const uint4 pk = make_uint4(pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3]), pack2bf_hw(v[4], v[5]), pack2bf_hw(v[6], v[7]));
-        if (ABL == 11) { asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w)); continue; }   // timing experiment: no stores
         *reinterpret_cast<uint4*>(C + m * ldc + n) = pk;
       }
     }
   }
 }
 
-constexpr int KH = 32;                          // k per ring slot (variant 8)
-constexpr int SLOT_BYTES = (BM + BN) * KH * 2;  // 32 KiB
-constexpr int SLOT_A = BM * KH * 2;             // 16 KiB
-
-// ======================================================================================================
-// Variant 8: K-half ring (4 x 32 KiB slots) + tile-level REGISTER double buffering + explicit issue order.
-//   iteration h:  LDS-DMA of K-half h+4 into the slot whose fragments already sit in registers (slot h&3),
-//                 12 ds_read_b128 of K-half h+1 interleaved (sched_group_barrier) with the 32 MFMAs (16x16x32) of K-half h,
-//                 counted vmcnt(8) (K-half h+2 landed; h+3, h+4 stay in flight), ONE barrier.
-// DMA issue -> first use is 3 iterations (~1.5 us of MFMAs), fragment reads never wait behind the barrier, and the
-// body is branch-free (tail indices are clamped: the last K-half is re-staged into slots nobody reads).
-// ======================================================================================================
-template <int EPI>
-__global__ void __launch_bounds__(512) gemm_bf16_nt_v8_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* C,
-                                                         const uint16_t* Rsd, int64_t M, int N, int K, int64_t lda, int64_t ldw,
-                                                         int64_t ldc, int64_t ldr, int tiles_m, int tiles_n, int GM) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int group_sz = GM * tiles_n;
-  const int grp = wg / group_sz, first_m = grp * GM;
-  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-  const int in_grp = wg - grp * group_sz;
-  const int tm = first_m + in_grp % gm, tn = in_grp / gm;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
-
-  // DMA roles: 16-row chunks 2*wid, 2*wid+1 of the A half and of the W half; 64-B rows, slot ^= (-(row>>2))&3
-  const uint16_t* a_src[2];
-  const uint16_t* w_src[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int r = (wid * 2 + c) * 16 + (lane >> 2);
-    const int slot = (lane & 3) ^ ((0 - (r >> 2)) & 3);   // f(row) = (-(row>>2)) & 3: conflict-free for the 16x16x32 lane groups
-    int64_t gm_row = m0 + r; if (gm_row > M - 1) gm_row = M - 1;
-    int gn_row = n0 + r; if (gn_row > N - 1) gn_row = N - 1;
-    a_src[c] = A + gm_row * lda + slot * 8;
-    w_src[c] = W + (int64_t)gn_row * ldw + slot * 8;
-  }
-  const int nh = K / KH;
-  auto stage = [&](int h) {   // h may exceed nh-1 near the tail: clamp the SOURCE, keep the slot
-    const int hs = h < nh ? h : nh - 1;
-    char* base = smem + (h & 3) * SLOT_BYTES + wid * 2048;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[c] + (int64_t)hs * KH), (lptr_t)(base + c * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[c] + (int64_t)hs * KH), (lptr_t)(base + SLOT_A + c * 1024), 16, 0, 0);
-    }
-  };
-  // fragments (16x16x32): row = 16f + (lane&15); the 32-k slice of a row is 4 slots; lane reads slot kq ^ ((row>>2)&3)
-  const int frow = lane & 15, kq = lane >> 4, swz = (0 - (frow >> 2)) & 3;
-  const int x_off = (wr * 128 + frow) * 64 + ((kq ^ swz) << 4);          // + i*1024 (16 rows x 64 B)
-  const int w_off = SLOT_A + (wc * 64 + frow) * 64 + ((kq ^ swz) << 4);  // + j*1024
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  bf16x8_t wa[4], xa[8], wb[4], xb[8];
-#define V8_READ(WF, XF, SLOT)                                                                        \
-  do {                                                                                               \
-    const char* sb_ = smem + (SLOT) * SLOT_BYTES;                                                    \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) WF[j] = *reinterpret_cast<const bf16x8_t*>(sb_ + w_off + j * 1024); \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) XF[i] = *reinterpret_cast<const bf16x8_t*>(sb_ + x_off + i * 1024); \
-  } while (0)
-#define V8_MMA(WF, XF)                                                                               \
-  do {                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                    \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], XF[i], acc[i][j], 0, 0, 0);       \
-  } while (0)
-#define V8_SCHED()                                                                                   \
-  do {                                                                                               \
-    __builtin_amdgcn_sched_group_barrier(0x10, 4, 0);                                                \
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                               \
-    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
-    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
-    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
-    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                               \
-    __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);                                                 \
-  } while (0)
-#define V8_SYNC()                                                                                    \
-  do {                                                                                               \
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                      \
-    __builtin_amdgcn_s_barrier();                                                                    \
-    asm volatile("" ::: "memory");                                                                   \
-  } while (0)
-
-  stage(0); stage(1); stage(2); stage(3);
-  V8_SYNC();                               // K-halves 0 and 1 have landed, 2 and 3 in flight
-  V8_READ(wa, xa, 0);
-  for (int h = 0; h < nh; h += 2) {
-    // even half-step: compute K-half h (registers A), fetch K-half h+1 into registers B, refill slot h&3 with K-half h+4
-    stage(h + 4);
-    V8_READ(wb, xb, (h + 1) & 3);
-    V8_MMA(wa, xa);
-    V8_SCHED();
-    V8_SYNC();
-    // odd half-step
-    stage(h + 5);
-    V8_READ(wa, xa, (h + 2) & 3);
-    V8_MMA(wb, xb);
-    V8_SCHED();
-    V8_SYNC();
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail DMAs before the LDS is released
-#undef V8_READ
-#undef V8_MMA
-#undef V8_SCHED
-#undef V8_SYNC
-
-  const int64_t mrow = m0 + wr * 128 + frow;
-  const int ncol = n0 + wc * 64 + kq * 4;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t m = mrow + i * 16;
-    if (m >= M) continue;
-    if constexpr (EPI == GRIT_EPI_SWIGLU) {
-#pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int nb = n0 + wc * 64 + j * 16;
-        if (nb >= N) continue;
-        const f32x4_t g = acc[i][j], u = acc[i][j + 1];
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = round_bf(silu_f(round_bf(g[r]))) * round_bf(u[r]);
-        *reinterpret_cast<uint2*>(C + m * ldc + (nb >> 1) + kq * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = ncol + j * 16;
-        if (n >= N) continue;
-        f32x4_t v = acc[i][j];
-        if constexpr (EPI == GRIT_EPI_RESIDUAL) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(Rsd + m * ldr + n);
-          v[0] = round_bf(v[0]) + bflo(rv.x); v[1] = round_bf(v[1]) + bfhi(rv.x);
-          v[2] = round_bf(v[2]) + bflo(rv.y); v[3] = round_bf(v[3]) + bfhi(rv.y);
-        }
-        *reinterpret_cast<uint2*>(C + m * ldc + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      }
-    }
-  }
+// Launch knobs for A/B runs (read once, thread-safe static initialisation): GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4:
+// 4 m x 8 n tiles in flight per XCD), GRIT_GEMM_NOREMAP=1 disables the XCD remap, GRIT_GEMM_RR=1 deals tile groups round-robin to the
+// XCDs for dense launches too (default: grouped launches only).
+struct GemmKnobs {
+  int gm, remap, rr_all;
+};
+static const GemmKnobs& gemm_knobs() {
+  static const GemmKnobs k = [] {
+    GemmKnobs v;
+    const char* e = getenv("GRIT_GEMM_GM");
+    v.gm = (e && atoi(e) > 0) ? atoi(e) : 4;
+    v.remap = getenv("GRIT_GEMM_NOREMAP") ? 0 : 1;
+    v.rr_all = getenv("GRIT_GEMM_RR") ? 1 : 0;
+    return v;
+  }();
+  return k;
 }
 
-// kernel generation: 1 = two 64 KiB stages, one barrier per K-tile (default); 8 = K-half ring + register double buffering
-// (GRIT_GEMM_VARIANT=8: ties variant 1).  Removed after measurement (DESIGN.md "GEMM experiments"): 32x32x16 variants,
-// burst-read / ring variants, one-wave-per-SIMD, weights-direct-to-registers.
-// GRIT_GEMM_ABLATE=<n> (variant 1, STORE epilogue; timing experiments, results WRONG for 1,2,3,10):
-//   1 no LDS-DMA in the K loop, 2 no ds_read, 3 no MFMA, 10 weight half of the DMA skipped; 5 setprio, 6/7 iglp_opt(0/1),
-//   8 explicit issue order one group ahead, 0/9 = default (reads two MFMA groups ahead), 11 no epilogue stores,
-//   12/13 LDS-DMA issue spread over the MFMAs (1 per 8 / 1 per 4), 14 operands made L2-resident (rows & 255, k-tiles & 7).
-// GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4: 4 m x 8 n tiles in flight per XCD; measured 2/4/8/16/32 ->
-// 5.41/5.33/5.47/6.03/6.66 ms on the QKV shape, no remap 5.65 ms), GRIT_GEMM_NOREMAP=1 disables the XCD remap (A/B only).
-static int gemm_variant() {
-  static int v = 0;
-  if (v == 0) {
-    const char* e = getenv("GRIT_GEMM_VARIANT");
-    v = (e != nullptr && e[0] == '8') ? 8 : 1;
+// the 128 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
+template <typename KernelT>
+static void ensure_lds_optin(KernelT kernel, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    done.fetch_or(bit, std::memory_order_release);
   }
-  return v;
 }
 
 template <int EPI>
@@ -542,50 +388,16 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
                        int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0},
                        GemmRope rope = GemmRope{nullptr, nullptr, nullptr, 0, 0}) {
   const int tiles_m = grp.counts ? (int)(M / BM) + grp.n_groups : (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
-  static bool attr_set = false;  // idempotent; benign race
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    attr_set = true;
-  }
-  static int abl = -1;
-  if (abl < 0) { const char* e = getenv("GRIT_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
-  static int gm_knob = 0, remap_knob = 1;
-  if (gm_knob == 0) {
-    const char* e = getenv("GRIT_GEMM_GM"); gm_knob = (e && atoi(e) > 0) ? atoi(e) : 4;
-    remap_knob = getenv("GRIT_GEMM_NOREMAP") ? 0 : 1;
-  }
+  static std::atomic<uint64_t> optin{0};
+  ensure_lds_optin(gemm_bf16_nt_k<EPI>, optin);
+  const GemmKnobs& kn = gemm_knobs();
   // grouped launches: round-robin tile groups over the XCDs (remap 2) on a grid rounded up to 8 x whole groups
-  const int total_groups = (tiles_m + gm_knob - 1) / gm_knob;
-  static int rr_all = -1;
-  if (rr_all < 0) rr_all = getenv("GRIT_GEMM_RR") ? 1 : 0;     // experiment: round-robin groups for the dense launches too
-  const bool rr = (grp.counts || rr_all) && remap_knob;
-  const unsigned nblocks = rr ? (unsigned)(8 * ((total_groups + 7) / 8) * gm_knob * tiles_n) : (unsigned)(tiles_m * tiles_n);
-  const int remap_mode = rr ? 2 : remap_knob;
-#define GRIT_LAUNCH_ABL(A_)                                                                                                          \
-  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, A_>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, \
-                     (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob, remap_mode, grp, rope)
-  if (abl > 0 && EPI == GRIT_EPI_STORE && gemm_variant() == 1) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_k<EPI, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (abl == 1) GRIT_LAUNCH_ABL(1); else if (abl == 2) GRIT_LAUNCH_ABL(2); else if (abl == 3) GRIT_LAUNCH_ABL(3);
-    else if (abl == 5) GRIT_LAUNCH_ABL(5); else if (abl == 6) GRIT_LAUNCH_ABL(6); else if (abl == 7) GRIT_LAUNCH_ABL(7); else if (abl == 8) GRIT_LAUNCH_ABL(8); else if (abl == 9) GRIT_LAUNCH_ABL(9); else if (abl == 10) GRIT_LAUNCH_ABL(10); else if (abl == 11) GRIT_LAUNCH_ABL(11); else if (abl == 12) GRIT_LAUNCH_ABL(12); else if (abl == 14) GRIT_LAUNCH_ABL(14); else GRIT_LAUNCH_ABL(13);
-  } else if (gemm_variant() == 8 && grp.counts == nullptr && EPI != GRIT_EPI_ROPE) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v8_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
-    hipLaunchKernelGGL(gemm_bf16_nt_v8_k<EPI>, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 4 * SLOT_BYTES, st, (const uint16_t*)A,
-                       (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, gm_knob);
-  } else
-    GRIT_LAUNCH_ABL(0);
+  const int total_groups = (tiles_m + kn.gm - 1) / kn.gm;
+  const bool rr = (grp.counts || kn.rr_all) && kn.remap;
+  const unsigned nblocks = rr ? (unsigned)(8 * ((total_groups + 7) / 8) * kn.gm * tiles_n) : (unsigned)(tiles_m * tiles_n);
+  const int remap_mode = rr ? 2 : kn.remap;
+  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
+                     (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
   GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt");
   return GRIT_OK;
 }
