@@ -158,7 +158,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     }
   }
   const int nk = K / BK;
+  bool in_loop = false;
   auto stage = [&](int kind, int buf, int kt) {               // kt past the end re-stages the last K-tile (nobody reads it): branch-free body
+#if defined(GRIT_GEMM_VAR) && (GRIT_GEMM_VAR & 64)
+    if (in_loop) return;
+#endif
     const int64_t ko = (int64_t)(kt < nk ? kt : nk - 1) * BK;
     char* base = smem + buf * STAGE_BYTES + kind * HALF_BYTES + wid * 2048;
     __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][0] + ko), (lptr_t)base, 16, 0, 0);
@@ -178,28 +182,44 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  bf16x8_t wf0[2][2], wf1[2][2], xf[4][2];                         // [fragment][k-step]
+#ifndef GRIT_GEMM_VAR
+#define GRIT_GEMM_VAR 3
+#endif
+  constexpr int VAR = GRIT_GEMM_VAR;
+  constexpr bool PFW = VAR & 1;                                    // W_h0 of the NEXT tile read in phase 4 (reads 8/4/8/4 instead of 12/4/8/0)
+  bf16x8_t wf0[2][2][2], wf1[2][2], xf[4][2];                      // [buffer][fragment][k-step]
 #define GRIT_READ_W(WF, H, SB)                                                                        \
   _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-      WF[jj][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + w_off + (H) * HALF_BYTES + jj * 2048 + s_off[ks])
+      if (!(VAR & 128) || !in_loop) WF[jj][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + w_off + (H) * HALF_BYTES + jj * 2048 + s_off[ks])
 #define GRIT_READ_X(H, SB)                                                                            \
   _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-      xf[ii][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
+      if (!(VAR & 128) || !in_loop) xf[ii][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
 #define GRIT_MMA(WF, I0, J0)                                                                          \
   do {                                                                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    __builtin_amdgcn_s_setprio(1);                                                                    \
+    if (!(VAR & 8)) __builtin_amdgcn_s_setprio(1);                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
       _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                \
         _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                              \
-          acc[(I0) + ii][(J0) + jj] =                                                                 \
+          if (VAR & 256) asm volatile("" :: "v"(WF[jj][ks]), "v"(xf[ii][ks]));                        \
+          else acc[(I0) + ii][(J0) + jj] =                                                            \
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                    \
+    if (!(VAR & 8)) __builtin_amdgcn_s_setprio(0);                                                    \
   } while (0)
 #define GRIT_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+  // VAR & 32: ONE barrier per phase -- group 0 synchronises after its compute segment, group 1 after its load segment, so between two
+  // barriers group 0 runs {load p, compute p} while group 1 runs {compute p-1, load p}
+#define GRIT_B1() do { if ((VAR & 32) == 0 || wr == 1) GRIT_BARRIER(); else GRIT_SEG_FENCE(); } while (0)
+#define GRIT_B2() do { if ((VAR & 32) == 0 || wr == 0) GRIT_BARRIER(); else GRIT_SEG_FENCE(); } while (0)
+  // issue order inside a load segment: 2 = LDS reads first, 4 = LDS-DMA first (default: the compiler's)
+#define GRIT_LSEG_ORDER(NREADS)                                                                       \
+  do {                                                                                                \
+    if (VAR & 2) { __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0); __builtin_amdgcn_sched_group_barrier(0x10, 2, 0); } \
+    if (VAR & 4) { __builtin_amdgcn_sched_group_barrier(0x10, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0); } \
+  } while (0)
 
   // One K-tile = 4 phases.  Half-tile stream (issue order) ... A_h0(t) W_h0(t) W_h1(t) A_h1(t) A_h0(t+1) ...; phase p of tile t issues
   // the half-tile 6 positions ahead of the one phase p reads first, into a slot whose last reader ran >= 2 phases earlier (the other
@@ -209,50 +229,64 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   auto tile = [&](int kt, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
     const char* sb = smem + BUF * STAGE_BYTES;
+    const char* sbn = smem + (BUF ^ 1) * STAGE_BYTES;
     // phase 1: quadrant (A_h0, W_h0)
-    GRIT_READ_W(wf0, 0, sb);
+    if (!PFW) GRIT_READ_W(wf0[BUF], 0, sb);
     GRIT_READ_X(0, sb);
     stage(3, BUF ^ 1, kt + 1);
+    GRIT_LSEG_ORDER(PFW ? 8 : 12);
     GRIT_VMCNT8();                    // W_h1(kt) landed (read in phase 2)
-    GRIT_BARRIER();
-    GRIT_MMA(wf0, 0, 0);
-    GRIT_BARRIER();
+    GRIT_B1();
+    GRIT_MMA(wf0[BUF], 0, 0);
+    GRIT_B2();
     // phase 2: quadrant (A_h0, W_h1)
     GRIT_READ_W(wf1, 1, sb);
     stage(1, BUF ^ 1, kt + 1);
+    GRIT_LSEG_ORDER(4);
     GRIT_VMCNT8();                    // A_h1(kt) landed (read in phase 3)
-    GRIT_BARRIER();
+    GRIT_B1();
     GRIT_MMA(wf1, 0, 2);
-    GRIT_BARRIER();
+    GRIT_B2();
     // phase 3: quadrant (A_h1, W_h1)
     GRIT_READ_X(1, sb);
-    stage(0, BUF, kt + 2);
-    GRIT_BARRIER();
+    stage(PFW ? 2 : 0, BUF, kt + 2);
+    GRIT_LSEG_ORDER(8);
+    if (PFW) GRIT_VMCNT8();           // W_h0(kt+1) landed (read in phase 4)
+    GRIT_B1();
     GRIT_MMA(wf1, 4, 2);
-    GRIT_BARRIER();
+    GRIT_B2();
     // phase 4: quadrant (A_h1, W_h0) -- fragments already in registers
-    stage(2, BUF, kt + 2);
-    GRIT_VMCNT8();                    // A_h0(kt+1), W_h0(kt+1) landed (read in phase 1 of the next tile)
-    GRIT_BARRIER();
-    GRIT_MMA(wf0, 4, 0);
-    GRIT_BARRIER();
+    if (PFW) GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
+    stage(PFW ? 0 : 2, BUF, kt + 2);
+    if (PFW) GRIT_LSEG_ORDER(4);
+    GRIT_VMCNT8();                    // A_h0(kt+1) (and W_h0(kt+1)) landed (read in phase 1 of the next tile)
+    GRIT_B1();
+    GRIT_MMA(wf0[BUF], 4, 0);
+    GRIT_B2();
   };
 
-  stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(0, 1, 1); stage(2, 1, 1);
+  if (PFW) { stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(2, 1, 1); stage(0, 1, 1); }
+  else { stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(0, 1, 1); stage(2, 1, 1); }
   GRIT_VMCNT8();                      // A_h0(0), W_h0(0)
   GRIT_BARRIER();
-  if (wr == 1) GRIT_BARRIER();        // the second wave group runs one barrier behind the first
+  if (PFW) GRIT_READ_W(wf0[0], 0, smem);
+  if (VAR & 128) { GRIT_READ_W(wf0[1], 0, smem); GRIT_READ_W(wf1, 1, smem); GRIT_READ_X(0, smem); }
+  in_loop = true;
+  if (wr == 1 && !(VAR & (16 | 32))) GRIT_BARRIER();        // the second wave group runs one barrier behind the first
   for (int kt = 0; kt < nk; kt += 2) {
     tile(kt, std::integral_constant<int, 0>{});
     if (kt + 1 < nk) tile(kt + 1, std::integral_constant<int, 1>{});
   }
-  if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
+  if (wr == 0 && !(VAR & (16 | 32))) GRIT_BARRIER();        // barrier counts of the two groups match again
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
   GRIT_SEG_FENCE();
 #undef GRIT_READ_W
 #undef GRIT_READ_X
 #undef GRIT_MMA
 #undef GRIT_VMCNT8
+#undef GRIT_B1
+#undef GRIT_B2
+#undef GRIT_LSEG_ORDER
   auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
 
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4

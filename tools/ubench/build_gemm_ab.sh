@@ -8,13 +8,7 @@ mkdir -p tools/ubench/_r01/csrc tools/ubench/_r01/include
 git show $REF:gritlm_amd/csrc/gemm_bf16.hip > tools/ubench/_r01/csrc/gemm_bf16.hip
 git show $REF:gritlm_amd/csrc/common.h | sed 's#../../include/gritlm_hip.h#../include/gritlm_hip.h#' > tools/ubench/_r01/csrc/common.h
 git show $REF:include/gritlm_hip.h > tools/ubench/_r01/include/gritlm_hip.h
-cat > tools/ubench/_r01/csrc/stub.hip <<'EOS'
-#include <stdarg.h>
-#include "common.h"
-namespace grit { static char buf[512]; void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); } }
-extern "C" const char* grit_last_error(void) { return grit::buf; }
-EOS
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-variable -o tools/ubench/_r01/libgemm_r01.so \
-    tools/ubench/_r01/csrc/gemm_bf16.hip tools/ubench/_r01/csrc/stub.hip
+    -Itools/ubench/_r01/csrc tools/ubench/_r01/csrc/gemm_bf16.hip tools/ubench/err_stub.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -o tools/ubench/gemm_ab.bin tools/ubench/gemm_ab.cpp -ldl
 echo built
