@@ -13,7 +13,10 @@ no data-path collective, weak scaling); value = docs of all ranks / max-over-ran
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline:     dominant kernel (gemm_bf16_nt, bf16 MFMA bound) measured live with HIP events,
-  cpu_baseline: the numpy oracle ("port") timed on this host's cores on a bounded sample (N = 1 only).
+  cpu_baseline: the reference's CPU encode (stock transformers.MistralModel + bidirectional mask + pooling, bit-equal to the reference
+                on the reference-generated fixtures; oracle/torch_reference.py) timed on this host's cores on a bounded sample (N = 1 only),
+  rocm_torch_baseline: the same Python on this GPU through stock PyTorch-ROCm (bf16, sdpa) at the full config -- what a user gets today,
+  contrastive:  BASELINE configs[2] as stated (256 pairs x (1 + 8) x 512 tokens per GPU, GradCache chunk 32).
 """
 import argparse
 import json
@@ -44,9 +47,16 @@ def measured_traffic():
 DOCS, SEQ = 256, 512
 
 
-def cpu_baseline(sample_docs=2, seq=SEQ, layers=32):
-    """The oracle on host cores: full 32-layer 7B shape on a bounded sample of documents, fp32 numpy/OpenBLAS (weights: one set of
-    layer-shaped arrays shared by all layers -- values do not change the timing, 29 GB of distinct random weights would)."""
+def cpu_baseline():
+    """The reference's CPU path on this host's cores: stock transformers.MistralModel + 4-D bidirectional mask + pooling (bit-equal to
+    the reference's GritLM.encode core on the reference-generated fixtures: oracle/torch_reference.py), fp32, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_reference as TR
+    return TR.time_cpu(layers=2, docs=8, seq=SEQ)
+
+
+def cpu_baseline_numpy(sample_docs=1, seq=SEQ, layers=32):
+    """Second CPU datum: the numpy oracle (oracle/gritlm_oracle.py, fp32 BLAS) through all 32 layers on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -70,19 +80,16 @@ def cpu_baseline(sample_docs=2, seq=SEQ, layers=32):
     t0 = time.perf_counter()
     O.encode_core(w, cfg, ids, mask, "mean", True, acc_dtype=np.float32)
     dt = time.perf_counter() - t0
-    raw = sample_docs / dt
-    cores = len(os.sched_getaffinity(0))
-    return {"value": raw * layers / 32.0, "unit": "docs/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_docs} docs x {seq} tok through {layers} of 32 layers at the 7B layer shape, fp32 numpy/OpenBLAS "
-                      f"oracle (oracle/gritlm_oracle.py), {dt:.2f} s" + ("" if layers == 32 else f"; value = measured {raw:.3f} docs/s x {layers}/32"),
-            "raw_docs_per_s_reduced_model": raw, "seconds": dt}
+    return {"value": sample_docs / dt, "unit": "docs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"numpy oracle (oracle/gritlm_oracle.py, fp32 OpenBLAS), {sample_docs} doc(s) x {seq} tok through all {layers} layers, {dt:.2f} s",
+            "seconds": dt}
 
 
-def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, steps=2, warmup=1, ragged_too=True):
-    """Second headline metric: contrastive pairs/s.  One step = GradCache contrastive step on (q, pos, 7 neg) @ seq512:
-    pass 1 (no grad) -> packed all-gather of the reps (N > 1) -> fused InfoNCE -> pass 2 forward+backward per chunk ->
-    gradient all-reduce (N > 1) -> AdamW.  `pairs` per rank is reduced from BASELINE configs[2]'s 256 to keep the default
-    run short (per-pair work is identical: every pair is 9 sequences x 512 tokens through the same kernels)."""
+def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, steps=1, warmup=1, ragged_pairs=32):
+    """Second headline metric: contrastive pairs/s on BASELINE configs[2] as stated -- per rank 256 queries + 2048 passages
+    (1 positive + 7 negatives each) @ seq512, GradCache chunk 32 (scripts/training/train_gritlm_7b.sh:60-67; gritlm/training/run.py:93-104).
+    One step = pass 1 (no grad) -> chunk-wise all-gather of the reps (N > 1) -> fused InfoNCE (similarity [W*256, W*2048] + CE + rep
+    grads) -> pass 2 forward+backward per chunk -> gradient all-reduce under the last chunk's backward (N > 1) -> AdamW."""
     from gritlm_amd.training.engine import MistralTrainEngine, SyntheticBackbone
     from gritlm_amd.training.gradcache import GradCacheStep
     from gritlm_amd.training.model import DistributedContrastiveLoss, GritLMTrainModel
@@ -100,8 +107,8 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, st
                     "attention_mask": torch.ones((n, SEQ), dtype=torch.int64, device=dev)}
     q, p = mk(pairs), mk(pairs * group)
 
-    def step():
-        loss = gc(q, p)
+    def step(g_=gc, q_=q, p_=p):
+        loss = g_(q_, p_)
         opt.step(); opt.zero_grad(set_to_none=True)
         m.train_engine.weights_updated()
         return loss
@@ -112,6 +119,7 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, st
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.profile = {}
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
@@ -123,40 +131,45 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=16, group=8, chunk=16, st
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    prof = {k: (v / steps if k.endswith("_ms") else v) for k, v in gc.profile_summary().items()}
+    gc.profile = None
+    peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     pairs_per_s = world * pairs * steps / dt
 
-    # ragged training batch (rank-local, outside the timed region above): lengths U{64..512} right-padded to 512 --
+    # ragged training batch (rank-local, outside the timed region above, smaller batch): lengths U{64..512} right-padded to 512 --
     # padded rows through every kernel (what the reference's SDPA path does) vs the packed (un-padded) training path
     ragged = None
-    if ragged_too:
+    if ragged_pairs:
         def rag(n):
             b = mk(n)
             lens = torch.randint(64, SEQ + 1, (n,), generator=gen, device=dev)
             b["attention_mask"] = (torch.arange(SEQ, device=dev).unsqueeze(0) < lens.unsqueeze(1)).to(torch.int64)
             return b, float(lens.float().mean().item())
-        (rq, lq), (rp, lp) = rag(pairs), rag(pairs * group)
+        (rq, lq), (rp, lp) = rag(ragged_pairs), rag(ragged_pairs * group)
         rates, losses = {}, {}
         for packed in (False, True):
             m.native_packed = packed
             loss_r = gc(rq, rp); opt.zero_grad(set_to_none=True)          # warm-up (buffers sized for this layout)
             torch.cuda.synchronize()
             t0r = time.perf_counter()
-            loss_r = gc(rq, rp)
-            opt.step(); opt.zero_grad(set_to_none=True); m.train_engine.weights_updated()
+            loss_r = step(gc, rq, rp)
             torch.cuda.synchronize()
-            rates[packed], losses[packed] = pairs / (time.perf_counter() - t0r), float(loss_r)
+            rates[packed], losses[packed] = ragged_pairs / (time.perf_counter() - t0r), float(loss_r)
         m.native_packed = True
-        ragged = {"lengths": "U{64..512} right-padded to 512", "mean_len": (lq + group * lp) / (1 + group),
+        ragged = {"lengths": "U{64..512} right-padded to 512", "pairs_per_step": ragged_pairs, "mean_len": (lq + group * lp) / (1 + group),
                   "pairs_per_s_per_gpu_padded_path": rates[False], "pairs_per_s_per_gpu_packed_path": rates[True],
                   "loss_padded": losses[False], "loss_packed_after_one_more_update": losses[True]}
     eng_flops = 2.0 * cfg.num_hidden_layers * (cfg.hidden_size * (6144) + 4096 * cfg.hidden_size + 3 * cfg.hidden_size * cfg.intermediate_size) \
         + 4.0 * cfg.num_hidden_layers * SEQ * 4096
     alg_flops_per_pair = 3.0 * eng_flops * SEQ * (1 + group)          # fwd + bwd = 3 x forward; recompute passes are overhead
     return {"metric": "contrastive pairs/sec @ seq512", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": steps,
-            "ms_per_step": dt / steps * 1e3, "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
-            "global_batch": world * pairs, "loss": float(loss),
-            "includes": "GradCache pass 1 + InfoNCE + pass 2 fwd/bwd + grad all-reduce + AdamW",
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
+            "global_batch": world * pairs, "loss": float(loss), "peak_hbm_gib": peak_gb,
+            "includes": "GradCache pass 1 + rep all-gather + InfoNCE + pass 2 fwd/bwd + grad all-reduce + AdamW",
+            "config": f"BASELINE configs[2]: {pairs} (q, pos, 7 neg) per GPU @ seq512, chunk {chunk}, tau 0.02, mean pooling, cross-device negatives"
+                      + ("" if pairs == 256 and chunk == 32 else "  [REDUCED from 256 pairs / chunk 32]"),
             "mfma_roofline_frac": pairs_per_s / world * alg_flops_per_pair / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+            "per_step_ms": prof,
             **({"ragged_batch": ragged} if ragged is not None else {})}
 
 
@@ -169,7 +182,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-contrastive", action="store_true", help="skip the contrastive pairs/s leg")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-batch (padded vs packed) leg")
-    ap.add_argument("--pairs", type=int, default=16, help="contrastive pairs per GPU per step (BASELINE configs[2]: 256)")
+    ap.add_argument("--pairs", type=int, default=256, help="contrastive pairs per GPU per step (BASELINE configs[2]: 256)")
+    ap.add_argument("--chunk", type=int, default=32, help="GradCache chunk size (BASELINE configs[2]: 32)")
+    ap.add_argument("--contrastive-steps", type=int, default=1)
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm encode on this GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -250,12 +266,23 @@ def main():
                   "docs_per_s_padded_path": dps_pad, "docs_per_s_packed_path": dps_pack,
                   "bit_identical": bool(torch.equal(e_pad, e_pack))}
 
+    del eng, emb
+    torch.cuda.empty_cache()
+    torch_baseline = None
+    if world == 1 and not args.no_torch_baseline:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import torch_reference as TR
+            torch_baseline = TR.time_gpu(dev, DOCS, SEQ, args.layers)
+        except Exception as e:  # noqa: BLE001
+            torch_baseline = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
     contrastive = None
     if not args.no_contrastive:
-        del eng, emb
-        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
         try:
-            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, ragged_too=not args.no_ragged)
+            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, chunk=args.chunk, steps=args.contrastive_steps,
+                                          ragged_pairs=0 if args.no_ragged else 32)
         except Exception as e:  # noqa: BLE001  -- never lose the primary metric line to the secondary leg
             contrastive = {"error": repr(e)[:300]}
 
@@ -292,8 +319,16 @@ def main():
             line["contrastive"] = contrastive
         if args.layers != 32:
             line["INVALID"] = "debug run with --layers != 32"
+        if torch_baseline is not None:
+            line["rocm_torch_baseline"] = torch_baseline
+            if "value" in torch_baseline:
+                line["speedup_vs_rocm_torch"] = docs_per_s / torch_baseline["value"]
+        if world > 1:
+            line["collectives"] = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' backend on ROCm)",
+                                   "ranks": dist.get_world_size(), "encode_data_path_collectives": 0}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline_numpy_oracle"] = cpu_baseline_numpy()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

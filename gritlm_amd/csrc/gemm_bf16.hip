@@ -85,52 +85,63 @@ __device__ __forceinline__ int wrow_of(int wc, int j) {
     GRIT_SEG_FENCE();                        \
   } while (0)
 
-template <int EPI>
+template <int EPI, bool PERSIST>
 __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W_all,
                                                       uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                                                       int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool ROPE = (EPI == GRIT_EPI_ROPE);
+  constexpr bool SWIGLU = (EPI == GRIT_EPI_SWIGLU || EPI == GRIT_EPI_SWIGLU_STACKED);
 
-  // ---- XCD-aware tile id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group)
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  // ---- tile of (virtual) block v: XCD-aware id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group).
+  //      PERSIST: the grid is one workgroup per CU (a multiple of 8, so v % 8 -- the XCD -- is the same for every tile of a
+  //      workgroup) and workgroup b walks the tiles v = b, b + grid, b + 2 grid, ...: at any time the 32 CUs of an XCD hold 32
+  //      consecutive tile ids = 4 m-tiles x 8 n-tiles sharing A / W panels in that XCD's L2, exactly as with one block per tile.
+  const int n_virtual = PERSIST ? tiles_m * tiles_n : (int)gridDim.x;
   const int group_sz = GM * tiles_n;
-  int grp, in_grp;
-  if (remap == 2) {
-    // grouped (MoE) launches: tile groups are dealt round-robin to the XCDs (XCD x runs groups x, x+8, ...), so the eight XCDs work
-    // on neighbouring row blocks -- i.e. on the SAME expert -- at any time and that expert's weights stay in the Infinity Cache;
-    // contiguous per-XCD ranges would keep all experts' weights (1.9 GB at the 8x7B shape) live at once
-    const int li = bid >> 3;
-    grp = (li / group_sz) * 8 + xcd;
-    in_grp = li - (li / group_sz) * group_sz;
-  } else {
-    const int wg = remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3) : bid;
-    grp = wg / group_sz;
-    in_grp = wg - grp * group_sz;
-  }
-  const int first_m = grp * GM;
-  if (first_m >= tiles_m) return;                             // (remap == 2: surplus workgroups of the rounded-up grid)
-  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-  if (in_grp >= gm * tiles_n) return;
-  const int tm = first_m + in_grp % gm, tn = in_grp / gm;
-  int64_t m0 = (int64_t)tm * BM, M = M_all;
-  const uint16_t* W = W_all;
-  if (groups.counts != nullptr) {
-    int t = tm, g = 0;
-    int64_t off = 0;
-    for (; g < groups.n_groups; ++g) {
-      const int c = groups.counts[g], nt = (c + BM - 1) / BM;
-      if (t < nt) break;
-      t -= nt; off += c;
+  auto tile_of = [&](int v, int64_t& m0, int64_t& M, const uint16_t*& W, int& n0) -> bool {
+    const int xcd = v & 7, q8 = n_virtual >> 3, r8 = n_virtual & 7;
+    int grp, in_grp;
+    if (!PERSIST && remap == 2) {
+      // grouped (MoE) launches: tile groups are dealt round-robin to the XCDs (XCD x runs groups x, x+8, ...), so the eight XCDs work
+      // on neighbouring row blocks -- i.e. on the SAME expert -- at any time and that expert's weights stay in the Infinity Cache;
+      // contiguous per-XCD ranges would keep all experts' weights (1.9 GB at the 8x7B shape) live at once
+      const int li = v >> 3;
+      grp = (li / group_sz) * 8 + xcd;
+      in_grp = li - (li / group_sz) * group_sz;
+    } else {
+      const int wg = (PERSIST || remap) ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3) : v;
+      grp = wg / group_sz;
+      in_grp = wg - grp * group_sz;
     }
-    if (g == groups.n_groups) return;                             // surplus tile of the upper-bound grid
-    m0 = off + (int64_t)t * BM;
-    M = off + groups.counts[g];                                    // row limit of this group
-    W = W_all + (int64_t)g * groups.w_stride;
-  }
-  const int n0 = tn * BN;
+    const int first_m = grp * GM;
+    if (first_m >= tiles_m) return false;                       // (remap == 2: surplus workgroups of the rounded-up grid)
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    if (in_grp >= gm * tiles_n) return false;
+    const int tm = first_m + in_grp % gm, tn = in_grp / gm;
+    m0 = (int64_t)tm * BM; M = M_all; W = W_all;
+    if (!PERSIST && groups.counts != nullptr) {
+      int t = tm, g = 0;
+      int64_t off = 0;
+      for (; g < groups.n_groups; ++g) {
+        const int c = groups.counts[g], nt = (c + BM - 1) / BM;
+        if (t < nt) break;
+        t -= nt; off += c;
+      }
+      if (g == groups.n_groups) return false;                   // surplus tile of the upper-bound grid
+      m0 = off + (int64_t)t * BM;
+      M = off + groups.counts[g];                                // row limit of this group
+      W = W_all + (int64_t)g * groups.w_stride;
+    }
+    n0 = tn * BN;
+    return true;
+  };
+  int64_t m0, M;
+  const uint16_t* W;
+  int n0;
+  int vtile = blockIdx.x;
+  if (!tile_of(vtile, m0, M, W, n0)) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,33 +151,34 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   //      `wid` fills LDS rows wid*16 .. wid*16+15 of it with two 1-KiB instructions (8 rows each).
   //      A_h, LDS row p  <->  tile row (p>>6)*128 + h*64 + (p&63)             (64 rows of each M-half of the workgroup)
   //      W_h, LDS row p  <->  tile row wrow(p>>5, 2h + ((p>>4)&1)) + (p&15)   (fragments 2h, 2h+1 of each of the 4 wave columns)
-  const int srow = lane >> 3;                                  // row inside the 8-row chunk
   const uint16_t* src[4][2];
+  auto set_src = [&](int h, int64_t tm0, int64_t tM, const uint16_t* tW, int tn0) {     // sources of A_h and W_h of the tile at (tm0, tn0)
+    int ln = lane;
+    if (PERSIST) asm volatile("" : "+v"(ln));                  // recomputed per tile from the lane id: nothing of this is kept in
+                                                               // registers across the K loop (the compiler would hoist and spill)
+    const int srow = ln >> 3;                                  // row inside the 8-row chunk
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int p = wid * 16 + c * 8 + srow;
-    const int slot = (lane & 7) ^ ((p >> 1) & 7);              // logical 16-B slot held by this physical slot
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int c = 0; c < 2; ++c) {
+      const int p = wid * 16 + c * 8 + srow;
+      const int slot = (ln & 7) ^ ((p >> 1) & 7);              // logical 16-B slot held by this physical slot
       const int ra = (p >> 6) * 128 + h * 64 + (p & 63);
-      int64_t gm_row = m0 + ra; if (gm_row > M - 1) gm_row = M - 1;
-      if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
+      int64_t gm_row = tm0 + ra; if (gm_row > tM - 1) gm_row = tM - 1;
+      if (!PERSIST && groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
       src[h][c] = A + gm_row * lda + slot * 8;
       const int rw = wrow_of<ROPE>(p >> 5, 2 * h + ((p >> 4) & 1)) + (p & 15);
-      int gn_row = n0 + rw; if (gn_row > N - 1) gn_row = N - 1;
-      src[2 + h][c] = W + (int64_t)gn_row * ldw + slot * 8;
+      int gn_row = tn0 + rw; if (gn_row > N - 1) gn_row = N - 1;
+      // stacked [gate; up] weights: interleaved row n = 32 q + r is gate row 16 q + r (r < 16) or up row 16 q + r - 16
+      if (EPI == GRIT_EPI_SWIGLU_STACKED) gn_row = ((gn_row >> 5) << 4) + (gn_row & 15) + ((gn_row & 16) ? (N >> 1) : 0);
+      src[2 + h][c] = tW + (int64_t)gn_row * ldw + slot * 8;
     }
-  }
+  };
+  set_src(0, m0, M, W, n0);
+  set_src(1, m0, M, W, n0);
   const int nk = K / BK;
-  bool in_loop = false;
-  auto stage = [&](int kind, int buf, int kt) {               // kt past the end re-stages the last K-tile (nobody reads it): branch-free body
-#if defined(GRIT_GEMM_VAR) && (GRIT_GEMM_VAR & 64)
-    if (in_loop) return;
-#endif
-    const int64_t ko = (int64_t)(kt < nk ? kt : nk - 1) * BK;
+  auto stage = [&](int kind, int buf, int64_t kofs) {          // kofs: k offset (elements) added to the half-tile's source pointers
     char* base = smem + buf * STAGE_BYTES + kind * HALF_BYTES + wid * 2048;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][0] + ko), (lptr_t)base, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][1] + ko), (lptr_t)(base + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][0] + kofs), (lptr_t)base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][1] + kofs), (lptr_t)(base + 1024), 16, 0, 0);
   };
 
   // ---- fragment read offsets (bytes inside a stage); the swizzle term is lane-constant because every fragment starts at a
@@ -177,128 +189,117 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   const int w_off = 2 * HALF_BYTES + (wc * 32 + frow) * 128;       // W frag j: + (j>>1)*HALF_BYTES + (j&1)*2048
 
   f32x4_t acc[8][4];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
 
-#ifndef GRIT_GEMM_VAR
-#define GRIT_GEMM_VAR 3
-#endif
-  constexpr int VAR = GRIT_GEMM_VAR;
-  constexpr bool PFW = VAR & 1;                                    // W_h0 of the NEXT tile read in phase 4 (reads 8/4/8/4 instead of 12/4/8/0)
   bf16x8_t wf0[2][2][2], wf1[2][2], xf[4][2];                      // [buffer][fragment][k-step]
 #define GRIT_READ_W(WF, H, SB)                                                                        \
   _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-      if (!(VAR & 128) || !in_loop) WF[jj][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + w_off + (H) * HALF_BYTES + jj * 2048 + s_off[ks])
+      WF[jj][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + w_off + (H) * HALF_BYTES + jj * 2048 + s_off[ks])
 #define GRIT_READ_X(H, SB)                                                                            \
   _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-      if (!(VAR & 128) || !in_loop) xf[ii][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
+      xf[ii][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
 #define GRIT_MMA(WF, I0, J0)                                                                          \
   do {                                                                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (!(VAR & 8)) __builtin_amdgcn_s_setprio(1);                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
       _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                \
         _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                              \
-          if (VAR & 256) asm volatile("" :: "v"(WF[jj][ks]), "v"(xf[ii][ks]));                        \
-          else acc[(I0) + ii][(J0) + jj] =                                                            \
+          acc[(I0) + ii][(J0) + jj] =                                                                 \
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj], 0, 0, 0); \
-    if (!(VAR & 8)) __builtin_amdgcn_s_setprio(0);                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
   } while (0)
-#define GRIT_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-  // VAR & 32: ONE barrier per phase -- group 0 synchronises after its compute segment, group 1 after its load segment, so between two
-  // barriers group 0 runs {load p, compute p} while group 1 runs {compute p-1, load p}
-#define GRIT_B1() do { if ((VAR & 32) == 0 || wr == 1) GRIT_BARRIER(); else GRIT_SEG_FENCE(); } while (0)
-#define GRIT_B2() do { if ((VAR & 32) == 0 || wr == 0) GRIT_BARRIER(); else GRIT_SEG_FENCE(); } while (0)
-  // issue order inside a load segment: 2 = LDS reads first, 4 = LDS-DMA first (default: the compiler's)
-#define GRIT_LSEG_ORDER(NREADS)                                                                       \
+  // load segment: the LDS reads are issued ahead of the two LDS-DMA instructions, then the counted wait:
+  // vmcnt(8) = "all but the 4 newest half-tiles have landed"
+#define GRIT_LSEG_END(NREADS)                                                                         \
   do {                                                                                                \
-    if (VAR & 2) { __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0); __builtin_amdgcn_sched_group_barrier(0x10, 2, 0); } \
-    if (VAR & 4) { __builtin_amdgcn_sched_group_barrier(0x10, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0); } \
+    __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x10, 2, 0);                                                 \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
   } while (0)
 
-  // One K-tile = 4 phases.  Half-tile stream (issue order) ... A_h0(t) W_h0(t) W_h1(t) A_h1(t) A_h0(t+1) ...; phase p of tile t issues
-  // the half-tile 6 positions ahead of the one phase p reads first, into a slot whose last reader ran >= 2 phases earlier (the other
-  // wave group is half a phase behind, so 2 phases is the minimum that has every reader's lgkmcnt(0) behind a barrier).  A half-tile
-  // read in phase p was waited for -- by EVERY wave, vmcnt(8) = "all but the 4 newest half-tiles have landed" -- before the first
-  // barrier of phase p-1.
-  auto tile = [&](int kt, auto bufc) {
+  // One K-tile = 4 phases, one output quadrant (16 MFMAs) each.  Half-tile stream (issue order):
+  //   ... W_h0(t) A_h0(t) W_h1(t) A_h1(t) W_h0(t+1) ...;  phase p of K-tile t issues the half-tile 6 positions ahead of the newest one it
+  // reads, into a slot whose last reader ran >= 2 phases earlier (the other wave group is half a phase behind, so 2 phases is the
+  // minimum that has every reader's lgkmcnt(0) behind a barrier).  What a phase reads was waited for -- by EVERY wave, vmcnt(8) --
+  // before the first barrier of the previous phase.  Phase 4 has no fragments of its own to read (W_h0 stays in registers), so it
+  // reads the NEXT K-tile's W_h0 instead: LDS reads per phase 8 / 4 / 8 / 4.
+  // k31 / k20: k offsets of the half-tiles staged in phases 1,2 (W_h1, A_h1 of K-tile t+1) and 3,4 (W_h0, A_h0 of K-tile t+2).
+  auto ktile = [&](int64_t k31, int64_t k20, auto bufc, auto lastc) {
     constexpr int BUF = decltype(bufc)::value;
+    constexpr bool LAST = decltype(lastc)::value;       // last K-tile of an output tile (PERSIST): W_h0 of the next tile is read after the epilogue
     const char* sb = smem + BUF * STAGE_BYTES;
     const char* sbn = smem + (BUF ^ 1) * STAGE_BYTES;
     // phase 1: quadrant (A_h0, W_h0)
-    if (!PFW) GRIT_READ_W(wf0[BUF], 0, sb);
     GRIT_READ_X(0, sb);
-    stage(3, BUF ^ 1, kt + 1);
-    GRIT_LSEG_ORDER(PFW ? 8 : 12);
-    GRIT_VMCNT8();                    // W_h1(kt) landed (read in phase 2)
-    GRIT_B1();
+    stage(3, BUF ^ 1, k31);
+    GRIT_LSEG_END(8);                 // W_h1(t) landed (read in phase 2)
+    GRIT_BARRIER();
     GRIT_MMA(wf0[BUF], 0, 0);
-    GRIT_B2();
+    GRIT_BARRIER();
     // phase 2: quadrant (A_h0, W_h1)
     GRIT_READ_W(wf1, 1, sb);
-    stage(1, BUF ^ 1, kt + 1);
-    GRIT_LSEG_ORDER(4);
-    GRIT_VMCNT8();                    // A_h1(kt) landed (read in phase 3)
-    GRIT_B1();
+    stage(1, BUF ^ 1, k31);
+    GRIT_LSEG_END(4);                 // A_h1(t) landed (read in phase 3)
+    GRIT_BARRIER();
     GRIT_MMA(wf1, 0, 2);
-    GRIT_B2();
+    GRIT_BARRIER();
     // phase 3: quadrant (A_h1, W_h1)
     GRIT_READ_X(1, sb);
-    stage(PFW ? 2 : 0, BUF, kt + 2);
-    GRIT_LSEG_ORDER(8);
-    if (PFW) GRIT_VMCNT8();           // W_h0(kt+1) landed (read in phase 4)
-    GRIT_B1();
+    stage(2, BUF, k20);
+    GRIT_LSEG_END(8);                 // W_h0(t+1) landed (read in phase 4)
+    GRIT_BARRIER();
     GRIT_MMA(wf1, 4, 2);
-    GRIT_B2();
-    // phase 4: quadrant (A_h1, W_h0) -- fragments already in registers
-    if (PFW) GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
-    stage(PFW ? 0 : 2, BUF, kt + 2);
-    if (PFW) GRIT_LSEG_ORDER(4);
-    GRIT_VMCNT8();                    // A_h0(kt+1) (and W_h0(kt+1)) landed (read in phase 1 of the next tile)
-    GRIT_B1();
+    GRIT_BARRIER();
+    // phase 4: quadrant (A_h1, W_h0); W_h0 of the next K-tile -> the other buffer's fragment registers
+    if (!LAST) GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
+    stage(0, BUF, k20);
+    GRIT_LSEG_END(LAST ? 0 : 4);                 // A_h0(t+1) landed (read in phase 1 of the next K-tile)
+    GRIT_BARRIER();
     GRIT_MMA(wf0[BUF], 4, 0);
-    GRIT_B2();
+    GRIT_BARRIER();
   };
+  const std::integral_constant<int, 0> B0{};
+  const std::integral_constant<int, 1> B1{};
+  const std::false_type MID{};
+  const std::true_type END{};
+  auto kclamp = [&](int kt) { return (int64_t)(kt < nk ? kt : nk - 1) * BK; };   // past the end: re-stage the last K-tile (nobody reads it)
 
-  if (PFW) { stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(2, 1, 1); stage(0, 1, 1); }
-  else { stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(0, 1, 1); stage(2, 1, 1); }
-  GRIT_VMCNT8();                      // A_h0(0), W_h0(0)
+  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(2, 1, kclamp(1)); stage(0, 1, kclamp(1));
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // W_h0(0), A_h0(0)
   GRIT_BARRIER();
-  if (PFW) GRIT_READ_W(wf0[0], 0, smem);
-  if (VAR & 128) { GRIT_READ_W(wf0[1], 0, smem); GRIT_READ_W(wf1, 1, smem); GRIT_READ_X(0, smem); }
-  in_loop = true;
-  if (wr == 1 && !(VAR & (16 | 32))) GRIT_BARRIER();        // the second wave group runs one barrier behind the first
-  for (int kt = 0; kt < nk; kt += 2) {
-    tile(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 < nk) tile(kt + 1, std::integral_constant<int, 1>{});
-  }
-  if (wr == 0 && !(VAR & (16 | 32))) GRIT_BARRIER();        // barrier counts of the two groups match again
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
-  GRIT_SEG_FENCE();
-#undef GRIT_READ_W
-#undef GRIT_READ_X
-#undef GRIT_MMA
-#undef GRIT_VMCNT8
-#undef GRIT_B1
-#undef GRIT_B2
-#undef GRIT_LSEG_ORDER
-  auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
+  GRIT_READ_W(wf0[0], 0, smem);
+  if (wr == 1) GRIT_BARRIER();        // the second wave group runs one barrier behind the first
 
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
+  auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
+  auto epilogue = [&](int64_t m0, int64_t M, int n0) {
+  int ln_e = lane;
+  if (PERSIST) asm volatile("" : "+v"(ln_e));               // per-lane output coordinates are rebuilt per tile, not carried through the K loop
+  const int frow = ln_e & 15, kq = ln_e >> 4;
   const int64_t mrow = m0 + wr * 128 + frow;
   const int ncol = n0 + wc * 64 + kq * 4;
-  // RESIDUAL: all 16 residual loads of the lane are issued up front (the fragment registers are dead by now), so the epilogue pays one
-  // memory latency instead of one per output row
+  // The 8 row blocks of the lane go out in batches of RB: all table / residual loads of a batch are issued up front, so the epilogue pays
+  // one memory latency per batch.  One workgroup per tile: one batch (the K loop's registers are dead).  PERSIST: the K loop's state
+  // stays live across the epilogue, smaller batches keep it out of scratch memory.
+  constexpr int RB = !PERSIST ? 8 : (ROPE ? 2 : (EPI == GRIT_EPI_RESIDUAL ? 4 : 8));
+#pragma unroll
+  for (int ib = 0; ib < 8; ib += RB) {
+  if (PERSIST) __builtin_amdgcn_sched_barrier(0);
   if constexpr (ROPE) {
     if (n0 + (wc >> 1) * 128 < rope.rope_cols) {        // this wave's head is a q or k head (uniform per wave)
       const int m0_mod = (int)(m0 % rope.S);              // block-uniform: the only 64-bit division
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = ib; i < ib + RB; ++i) {
         const int64_t m = mrow + i * 16;
         const int64_t mc = m < M ? m : M - 1;
         const int pos = rope.positions ? rope.positions[mc] : (m0_mod + (int)(mc - m0)) % rope.S;
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   uint4 rpre[8][2];
   if constexpr (EPI == GRIT_EPI_RESIDUAL) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = ib; i < ib + RB; ++i)
 #pragma unroll
       for (int jq = 0; jq < 2; ++jq) {
         const int64_t m = mrow + i * 16;
@@ -331,10 +332,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = ib; i < ib + RB; ++i) {
     const int64_t m = mrow + i * 16;
     if (m >= M) continue;
-    if constexpr (EPI == GRIT_EPI_SWIGLU) {
+    if constexpr (SWIGLU) {
       // fragments (0,1) and (2,3) are (gate, up) pairs -> two 16-column output blocks; the same permlane16 exchange gives every
       // lane 8 consecutive output columns
       const int nb = n0 + wc * 64;             // multiple of 64
@@ -385,13 +386,57 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       }
     }
   }
+  }
+  };
+
+  if constexpr (!PERSIST) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(kclamp(kt + 1), kclamp(kt + 2), B0, MID);
+      if (kt + 1 < nk) ktile(kclamp(kt + 2), kclamp(kt + 3), B1, MID);
+    }
+    if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
+    GRIT_SEG_FENCE();
+    epilogue(m0, M, n0);
+  } else {
+    // One workgroup per CU walks its tiles with the K-tile stream running THROUGH the tile boundaries: the last two K-tiles of an
+    // output tile stage the first half-tiles of the next one (they would otherwise re-stage dead data), so the LDS-DMA pipeline never
+    // drains and the next tile's first MFMAs wait for nothing but this tile's epilogue.  (nk even and >= 4: the host guarantees it.)
+    for (;;) {
+      for (int kt = 0; kt < nk - 2; kt += 2) {
+        ktile((int64_t)(kt + 1) * BK, (int64_t)(kt + 2) * BK, B0, MID);
+        ktile((int64_t)(kt + 2) * BK, (int64_t)(kt + 3) * BK, B1, MID);
+      }
+      int64_t m0n = m0, Mn = M;
+      const uint16_t* Wn = W;
+      int n0n = n0;
+      const int vnext = vtile + (int)gridDim.x;
+      const bool more = vnext < n_virtual && tile_of(vnext, m0n, Mn, Wn, n0n);     // no next tile: re-stage this one (harmless)
+      set_src(0, m0n, Mn, Wn, n0n);                        // W_h0 / A_h0 of the current tile were last staged two K-tiles ago
+      ktile((int64_t)(nk - 1) * BK, 0, B0, MID);
+      set_src(1, m0n, Mn, Wn, n0n);
+      ktile(0, BK, B1, END);
+      epilogue(m0, M, n0);
+      if (!more) break;
+      zero_acc();
+      GRIT_READ_W(wf0[0], 0, smem);                        // W_h0(0) of the next tile: landed before the last K-tile's phase-3 barrier
+      vtile = vnext; m0 = m0n; M = Mn; W = Wn; n0 = n0n;
+    }
+    if (wr == 0) GRIT_BARRIER();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GRIT_SEG_FENCE();
+  }
+#undef GRIT_READ_W
+#undef GRIT_READ_X
+#undef GRIT_MMA
+#undef GRIT_LSEG_END
 }
 
 // Launch knobs for A/B runs (read once, thread-safe static initialisation): GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4:
 // 4 m x 8 n tiles in flight per XCD), GRIT_GEMM_NOREMAP=1 disables the XCD remap, GRIT_GEMM_RR=1 deals tile groups round-robin to the
-// XCDs for dense launches too (default: grouped launches only).
+// XCDs for dense launches too (default: grouped launches only), GRIT_GEMM_NOPERSIST=1 always launches one workgroup per tile.
 struct GemmKnobs {
-  int gm, remap, rr_all;
+  int gm, remap, rr_all, persist;
 };
 static const GemmKnobs& gemm_knobs() {
   static const GemmKnobs k = [] {
@@ -400,9 +445,23 @@ static const GemmKnobs& gemm_knobs() {
     v.gm = (e && atoi(e) > 0) ? atoi(e) : 4;
     v.remap = getenv("GRIT_GEMM_NOREMAP") ? 0 : 1;
     v.rr_all = getenv("GRIT_GEMM_RR") ? 1 : 0;
+    v.persist = getenv("GRIT_GEMM_NOPERSIST") ? 0 : 1;
     return v;
   }();
   return k;
+}
+
+static int device_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    if (v <= 0) v = 256;
+    cached[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
 }
 
 // the 128 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
@@ -422,16 +481,25 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
                        int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0},
                        GemmRope rope = GemmRope{nullptr, nullptr, nullptr, 0, 0}) {
   const int tiles_m = grp.counts ? (int)(M / BM) + grp.n_groups : (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
-  static std::atomic<uint64_t> optin{0};
-  ensure_lds_optin(gemm_bf16_nt_k<EPI>, optin);
+  static std::atomic<uint64_t> optin{0}, optin_p{0};
   const GemmKnobs& kn = gemm_knobs();
   // grouped launches: round-robin tile groups over the XCDs (remap 2) on a grid rounded up to 8 x whole groups
   const int total_groups = (tiles_m + kn.gm - 1) / kn.gm;
   const bool rr = (grp.counts || kn.rr_all) && kn.remap;
   const unsigned nblocks = rr ? (unsigned)(8 * ((total_groups + 7) / 8) * kn.gm * tiles_n) : (unsigned)(tiles_m * tiles_n);
   const int remap_mode = rr ? 2 : kn.remap;
-  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
-                     (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
+  // persistent form (one workgroup per CU, the K-tile stream runs through the tile boundaries): dense launches with an even number
+  // (>= 4) of K-tiles and more tiles than CUs; everything else takes one workgroup per tile
+  const int n_cu = device_cu_count();
+  if (kn.persist && !rr && grp.counts == nullptr && (K / BK) % 2 == 0 && K / BK >= 4 && (int64_t)tiles_m * tiles_n > n_cu && n_cu % 8 == 0) {
+    ensure_lds_optin(gemm_bf16_nt_k<EPI, true>, optin_p);
+    hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, true>), dim3((unsigned)n_cu), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
+                       (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
+  } else {
+    ensure_lds_optin(gemm_bf16_nt_k<EPI, false>, optin);
+    hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
+                       (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
+  }
   GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt");
   return GRIT_OK;
 }
@@ -512,6 +580,9 @@ extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t 
     case GRIT_EPI_SWIGLU:
       GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
       return launch_gemm<GRIT_EPI_SWIGLU>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    case GRIT_EPI_SWIGLU_STACKED:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU_STACKED>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
     default:
       GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt: unknown epilogue %d", epilogue);
   }

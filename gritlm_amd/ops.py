@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, POOL_MODES, check
+from ._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, EPI_SWIGLU_STACKED, POOL_MODES, check
 
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 
@@ -176,11 +176,11 @@ def pool_norm_varlen_bwd(y: torch.Tensor, dy: torch.Tensor, inv_norm: torch.Tens
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE,
             residual: torch.Tensor | None = None) -> torch.Tensor:
-    """out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue).  SWIGLU: w holds interleaved gate/up rows, out is [M, N/2]."""
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue).  SWIGLU: w holds interleaved gate/up rows (SWIGLU_STACKED: [gate; up]), out is [M, N/2]."""
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K, (a.shape, w.shape)
-    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED) else N
     if out is None:
         out = torch.empty((M, n_out), dtype=BF16, device=a.device)
     assert out.shape == (M, n_out)
@@ -547,3 +547,30 @@ def accum_bf16_from_f32(acc: torch.Tensor, x: torch.Tensor):
     assert acc.numel() == x.numel()
     check(_lib.load().grit_accum_bf16_from_f32(_chk(acc, BF16, "acc"), _chk(x, F32, "x"), acc.numel(), _stream()), "grit_accum_bf16_from_f32")
     return acc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device guard.  A HIP launch goes to the calling thread's CURRENT device and `_stream()` is that device's current stream, while the
+# reference API lets the caller put the model anywhere (GritLM(..., device="cuda:1"), gritlm/gritlm.py:24,57): every public op therefore
+# runs with the device of its first tensor argument made current, so kernels, the stream they are ordered on and torch's own ops on
+# that tensor all agree.  (One `current_device()` read per call when the devices already match.)
+def _on_tensor_device(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        for a in args:
+            if torch.is_tensor(a):
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return guarded
+
+
+for _name, _fn in list(globals().items()):
+    if callable(_fn) and getattr(_fn, "__module__", None) == __name__ and not _name.startswith("_") and not isinstance(_fn, type) \
+            and _name not in ("set_timer", "check", "attn_decode_workspace"):
+        globals()[_name] = _on_tensor_device(_fn)
+del _name, _fn

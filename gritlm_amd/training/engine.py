@@ -8,15 +8,16 @@ Gradients are written by the wgrad GEMMs straight into packed ``.grad`` storage 
 chunks by the GEMM's residual epilogue), exactly what ``param.grad`` accumulation does in the reference.
 
 Replaces, for the embedding tower: torch autograd through scripts/modeling_mistral_gritlm.py + HF gradient
-checkpointing (gritlm/training/run.py:83-84).  Memory is laid out for 288 GB HBM: pass 2 keeps every intermediate of
-the chunk (no recompute => 3x forward FLOPs per chunk instead of the reference's 4x).
+checkpointing (gritlm/training/run.py:83-84).  Memory is laid out for 288 GB HBM: by default pass 2 keeps every intermediate
+of the chunk (no recompute => 3x forward FLOPs per chunk instead of the reference's 4x); ``recompute = True``
+(``--gradient_checkpointing``) keeps only the layer inputs and re-runs each layer's forward inside backward().
 """
 from __future__ import annotations
 
 import torch
 
 from .. import ops
-from .._lib import EPI_RESIDUAL, EPI_STORE
+from .._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU_STACKED
 from ..encoder import EncoderConfig, rope_tables
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -87,6 +88,7 @@ class MistralTrainEngine:
         self._tbuf = {}
         self._wT = {}
         self.cache_transposed_weights = False
+        self.recompute = False          # gradient checkpointing (per-layer recompute in backward)
         c = self.cfg
         if any(p.dtype != BF16 for p in backbone.parameters()):
             raise RuntimeError("MistralTrainEngine: parameters must be bfloat16 (load the model with torch_dtype=bfloat16)")
@@ -195,6 +197,49 @@ class MistralTrainEngine:
             self._wT[key] = (ver, t)
         return t
 
+    # ------------------------------------------------------------------ one decoder layer
+    def _layer_buffers(self, T: int, with_gu: bool):
+        c = self.cfg
+        mk = lambda n: torch.empty((T, n), dtype=BF16, device=self.device)
+        nq, nkv, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        return dict(x1=mk(c.hidden_size), qkv=mk((nq + 2 * nkv) * d), ctx=mk(nq * d), x2=mk(c.hidden_size),
+                    gu=mk(2 * c.intermediate_size) if with_gu else None, act=mk(c.intermediate_size),
+                    h_mid=mk(c.hidden_size) if with_gu else None)
+
+    def _layer_fwd(self, L, h, geom, B, S, cos, sin, buf, need_bwd: bool, h_out=None):
+        """MistralDecoderLayer.forward (scripts/modeling_mistral_gritlm.py:738-790) on the kernels.  ``need_bwd``: also produce what
+        backward() reads (log-sum-exp rows, the pre-activation gate|up, a separate h_mid); otherwise SwiGLU is fused into the gate|up
+        GEMM's epilogue (stacked-weight form) and the residual stream is updated in place."""
+        c = self.cfg
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        T, dev = geom.T, self.device
+        x1, qkv, ctx, x2, act = buf["x1"], buf["qkv"], buf["ctx"], buf["x2"], buf["act"]
+        ops.rmsnorm(h, L.ln1.data, eps, out=x1)
+        if geom.packed:
+            lse = torch.empty((T, nq), dtype=F32, device=dev) if need_bwd else None
+            ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, positions=geom.pos, out=qkv)      # q/k/v projections + RoPE epilogue
+            ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
+        else:
+            lse = torch.empty((B, nq, S), dtype=F32, device=dev) if need_bwd else None
+            ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)
+            ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
+        if need_bwd:
+            h_mid = buf["h_mid"]
+        else:                            # h must survive when it is a saved layer input (recompute policy) -> h_out doubles as h_mid
+            h_mid = h_out if h_out is not None else h
+        ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
+        ops.rmsnorm(h_mid, L.ln2.data, eps, out=x2)
+        gu = buf["gu"]
+        if need_bwd:
+            ops.gemm_nt(x2, L.wgu, out=gu)
+            ops.swiglu(gu, out=act)
+        else:
+            ops.gemm_nt(x2, L.wgu, out=act, epilogue=EPI_SWIGLU_STACKED)
+        if h_out is None:
+            h_out = h_mid
+        ops.gemm_nt(act, L.wdown.data, out=h_out, epilogue=EPI_RESIDUAL, residual=h_mid)
+        return dict(h_in=h, x1=x1, qkv=qkv, ctx=ctx, lse=lse, h_mid=h_mid, x2=x2, gu=gu, act=act, h_out=h_out)
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool, packed: bool = False, causal: bool = False):
         """Returns (last_hidden_state, SavedForward | None).  Padded layout: last_hidden_state is [B,S,H] bf16.
@@ -221,29 +266,20 @@ class MistralTrainEngine:
         h = ops.embed_gather(self.embed.data, ids, out=mk(H))
         saved = SavedForward()
         saved.ids, saved.mask, saved.geom, saved.B, saved.S, saved.layers = ids, mask, geom, B, S, []
-        x1 = qkv = ctx = x2 = gu = act = None
+        # activation policy: save and not recompute -> every intermediate of every layer stays in HBM (3x forward FLOPs per step);
+        # save and recompute -> only each layer's INPUT is kept and backward() re-runs the layer's forward first (the reference's
+        # gradient checkpointing, gritlm/training/run.py:83-84: 4x forward FLOPs, ~1/17 of the activation memory);
+        # not save -> one scratch set, SwiGLU fused into the gate|up GEMM's epilogue
+        keep_all = save and not self.recompute
+        scratch = None
         for L in self.layers:
-            if save or x1 is None:
-                x1, qkv, ctx, x2, gu, act = mk(H), mk((nq + 2 * nkv) * d), mk(nq * d), mk(H), mk(2 * I), mk(I)
-            ops.rmsnorm(h, L.ln1.data, eps, out=x1)
-            if geom.packed:
-                lse = torch.empty((T, nq), dtype=F32, device=dev) if save else None
-                ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, positions=geom.pos, out=qkv)      # q/k/v projections + RoPE epilogue
-                ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
-            else:
-                lse = torch.empty((B, nq, S), dtype=F32, device=dev) if save else None
-                ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)
-                ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
-            h_mid = mk(H) if save else h
-            ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
-            ops.rmsnorm(h_mid, L.ln2.data, eps, out=x2)
-            ops.gemm_nt(x2, L.wgu, out=gu)
-            ops.swiglu(gu, out=act)
-            h_out = mk(H) if save else h_mid
-            ops.gemm_nt(act, L.wdown.data, out=h_out, epilogue=EPI_RESIDUAL, residual=h_mid)
+            if keep_all or scratch is None:
+                scratch = self._layer_buffers(T, with_gu=keep_all)
+            h_out = mk(H) if save else None
+            sv = self._layer_fwd(L, h, geom, B, S, cos, sin, scratch, need_bwd=keep_all, h_out=h_out)
             if save:
-                saved.layers.append(dict(h_in=h, x1=x1, qkv=qkv, ctx=ctx, lse=lse, h_mid=h_mid, x2=x2, gu=gu, act=act))
-            h = h_out
+                saved.layers.append(sv if keep_all else dict(h_in=h))
+            h = sv["h_out"]
         xf = ops.rmsnorm(h, self.norm.data, eps, out=mk(H))
         if save:
             saved.h_final, saved.x_final = h, xf
@@ -329,8 +365,13 @@ class MistralTrainEngine:
         nL = len(self.layers)
         dy = d_last_hidden.reshape(T, H).contiguous()
         dh = ops.rmsnorm_bwd(dy, saved.h_final, self.norm.data, eps, ng[2 * nL])
+        rc_buf = rc_out = None
         for li in range(nL - 1, -1, -1):
             L, sv = self.layers[li], saved.layers[li]
+            if "x1" not in sv:             # recompute policy: only the layer input was kept -> re-run the layer's forward now
+                if rc_buf is None:
+                    rc_buf, rc_out = self._layer_buffers(T, with_gu=True), torch.empty((T, H), dtype=BF16, device=self.device)
+                sv = self._layer_fwd(L, sv["h_in"], geom, B, S, cos, sin, rc_buf, need_bwd=True, h_out=rc_out)
             # ---- MLP: h_out = h_mid + down(silu(gate) * up)
             dact = ops.gemm_nt(dh, self._wt(li, "down", L.wdown))                       # [T,I] = dh @ Wdown
             dhT = self._transposed_act(dh, "dh")

@@ -12,10 +12,19 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List
 
 import torch
 import torch.distributed as dist
+
+
+def dist_active() -> bool:
+    """Data-parallel collectives needed?  True for world_size > 1; GRIT_DIST_WORLD1=1 keeps every collective in the step on a
+    ONE-rank process group too (test hook: the RCCL calls are then issued for real on a single GPU, tests/gpu_checks.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GRIT_DIST_WORLD1") == "1"
 
 
 def split_inputs(model_input: Dict, chunk_size: int) -> List[Dict]:
@@ -43,8 +52,7 @@ class OverlappedGradSync:
 
     def __init__(self, model):
         self.model, self.pending = model, []
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 \
-            and getattr(model, "train_engine", None) is not None
+        self.active = dist_active() and getattr(model, "train_engine", None) is not None
 
     def arm(self):
         if self.active:
@@ -66,7 +74,7 @@ class OverlappedGradSync:
 
 def sync_gradients(model) -> None:
     """Average gradients over ranks (DDP semantics: the effective gradient is (1/W) * grad of the global loss)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not dist_active():
         return
     eng = getattr(model, "train_engine", None)
     bufs = eng.grad_buffers() if eng is not None else [p.grad for p in model.parameters() if p.grad is not None]
@@ -80,35 +88,71 @@ def sync_gradients(model) -> None:
 class ChunkGather:
     """Cross-rank gather of pooled representations, issued chunk by chunk as pass 1 produces them.
 
-    Every chunk's all-gather is asynchronous (RCCL runs it on its own stream over xGMI) and lands directly in the rank-major
-    [W, n_local, H] buffer, so the exchange overlaps the forward of the following chunks -- the query tower's gather
-    overlaps the whole document tower, and only the last passage chunk's gather is exposed.  Replaces the two blocking
-    list-API gathers + torch.cat of ``_dist_gather_tensor`` (gritlm/training/model.py:49-60); result order is identical."""
+    Every chunk is ONE asynchronous ``all_gather_into_tensor`` (RCCL ``ncclAllGather`` straight into a contiguous [W, n_chunk, H]
+    slab: no list API, no staging copies; runs on RCCL's own stream over xGMI), so the exchange overlaps the forward of the
+    following chunks -- the query tower's gather overlaps the whole document tower, and only the last passage chunk's gather is
+    exposed.  ``finish`` stitches the slabs into the rank-major [W * n_local, H] matrix with one copy.  Replaces the two blocking
+    list-API gathers + torch.cat of ``_dist_gather_tensor`` (gritlm/training/model.py:49-60); result order is identical (rank r owns
+    rows [r * n_local, (r + 1) * n_local), the order the targets ``arange(B) * G`` rely on, :45-46)."""
 
     def __init__(self, n_local: int, width: int, dtype, device):
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.buf = torch.empty((self.world, n_local, width), dtype=dtype, device=device)
-        self.handles, self.keep, self.row = [], [], 0
+        self.n_local, self.width, self.dtype, self.device = n_local, width, dtype, device
+        self.items = []            # (slab [W, n, H], work handle, source kept alive until the collective completed)
+        self.calls = 0
 
     def add(self, reps: torch.Tensor):
         reps = reps.detach().contiguous()
         n = reps.shape[0]
-        views = [self.buf[r, self.row:self.row + n] for r in range(self.world)]
-        self.handles.append(dist.all_gather(views, reps, async_op=True))
-        self.keep.append(reps)
-        self.row += n
+        slab = torch.empty((self.world, n, self.width), dtype=self.dtype, device=self.device)
+        work = dist.all_gather_into_tensor(slab.view(self.world * n, self.width), reps, async_op=True)
+        self.items.append((slab, work, reps))
+        self.calls += 1
 
     def finish(self) -> torch.Tensor:
-        for h in self.handles:
-            h.wait()
-        self.keep.clear()
-        return self.buf.view(self.world * self.buf.shape[1], self.buf.shape[2])
+        for _, work, _ in self.items:
+            work.wait()
+        slabs = [s for s, _, _ in self.items]
+        out = slabs[0] if len(slabs) == 1 else torch.cat(slabs, dim=1)
+        assert out.shape[1] == self.n_local, (out.shape, self.n_local)
+        self.items.clear()
+        return out.reshape(self.world * self.n_local, self.width)
+
+
+class _Span:
+    """CUDA-event bracket on the current stream (bench.py's exposed-communication / loss timing); no-op on CPU tensors."""
+
+    def __init__(self, sink: "dict | None", key: str, enabled: bool):
+        self.sink, self.key, self.on = sink, key, bool(enabled and sink is not None)
+
+    def __enter__(self):
+        if self.on:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record()
+            self.sink.setdefault("_events", []).append((self.key, self.a, self.b))
+        return False
 
 
 class GradCacheStep:
     def __init__(self, model, chunk_size: int):
         self.model = model
         self.chunk_size = int(chunk_size)
+        self.profile = None        # set to a dict to collect per-step timings (ms): loss (similarity GEMM + CE + rep grads), the
+                                   # stream time blocked on the rep gather (exposed, non-overlapped part) and on the gradient all-reduce
+
+    def profile_summary(self) -> dict:
+        """Resolve the recorded CUDA events into {key: total ms} (call after torch.cuda.synchronize())."""
+        out = {}
+        if self.profile:
+            for key, a, b in self.profile.pop("_events", []):
+                out[key] = out.get(key, 0.0) + a.elapsed_time(b)
+            self.profile.update(out)
+        return dict(self.profile or {})
 
     @torch.no_grad()
     def _reps_no_grad(self, chunks, gather: "ChunkGather | None" = None):
@@ -143,11 +187,20 @@ class GradCacheStep:
         q_reps, p_reps = torch.cat(q_list, dim=0), torch.cat(p_list, dim=0)
         # loss + representation-gradient cache
         q_leaf, p_leaf = q_reps.detach().requires_grad_(), p_reps.detach().requires_grad_()
+        gpu = q_reps.is_cuda
         if cross:
-            loss = loss_fn.with_gathered(q_leaf, p_leaf, gq.finish(), gp.finish())
+            with _Span(self.profile, "exposed_gather_ms", gpu):
+                q_all, p_all = gq.finish(), gp.finish()
+            if self.profile is not None:
+                self.profile["gather_collectives"] = gq.calls + gp.calls
+                self.profile["gather_bytes_received"] = (q_all.numel() + p_all.numel()) * q_all.element_size() * (gq.world - 1) // gq.world
+            with _Span(self.profile, "loss_fwd_bwd_ms", gpu):
+                loss = loss_fn.with_gathered(q_leaf, p_leaf, q_all, p_all)
+                loss.backward()
         else:
-            loss = loss_fn(q_leaf, p_leaf)
-        loss.backward()
+            with _Span(self.profile, "loss_fwd_bwd_ms", gpu):
+                loss = loss_fn(q_leaf, p_leaf)
+                loss.backward()
         caches = (q_leaf.grad, p_leaf.grad)
         # pass 2 (the gradient all-reduce of the data-parallel ranks rides under the last chunk's backward)
         gsync = OverlappedGradSync(model) if sync else None
@@ -161,5 +214,6 @@ class GradCacheStep:
             reps.backward(gradient=cache[r0:r0 + reps.shape[0]].to(reps.dtype))
             rows[which] = r0 + reps.shape[0]
         if gsync is not None:
-            gsync.finish()
+            with _Span(self.profile, "exposed_grad_allreduce_ms", gpu):
+                gsync.finish()
         return loss.detach()

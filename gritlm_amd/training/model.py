@@ -294,4 +294,5 @@ class GritLMTrainModel(GritLM):
     def gradient_checkpointing_enable(self, *args, **kwargs):
         if self.train_engine is None:
             self.model.gradient_checkpointing_enable(*args, **kwargs)
-        # native engine: activation policy is its own (keeps the chunk's activations in HBM) -- nothing to enable
+        else:   # native engine: keep only the layer inputs of a chunk, re-run each layer's forward inside backward
+            self.train_engine.recompute = True

@@ -46,13 +46,28 @@ def main(argv=None):
     device = f"cuda:{local_rank}" if use_cuda else "cpu"
     set_seed(args.seed)
 
+    # flags of the reference CLI that this entry point does not implement must fail loudly, not train something else
+    unsupported = {"--lora": args.lora, "--qlora": args.qlora, "--num_samples": data_args.num_samples is not None,
+                   "--use_unique_indices": data_args.use_unique_indices, "--split_emb_full": args.split_emb_full,
+                   "--deepspeed": bool(getattr(args, "deepspeed", None)), "--fsdp": bool(getattr(args, "fsdp", None))}
+    bad = [k for k, v in unsupported.items() if v]
+    if bad:
+        raise NotImplementedError(f"{', '.join(bad)}: accepted by the reference's gritlm.training.run, not implemented by the MI355X-native "
+                                  f"entry point (full-parameter data-parallel training only)")
+
     # GradCache switch, run.py:93-104: accumulation steps become chunks of one large contrastive batch
     gc_chunk = None
-    if (args.gradient_accumulation_steps > 1 and args.negatives_cross_device) or (args.no_gen_gas and args.no_emb_gas):
+    if (args.gradient_accumulation_steps > 1 and args.negatives_cross_device and args.mode in ("embedding", "unified")) \
+            or (args.no_gen_gas and args.no_emb_gas):
         gc_chunk = args.per_device_train_batch_size
         args.per_device_train_batch_size *= args.gradient_accumulation_steps
         args.gradient_accumulation_steps = 1
         logger.info("Using GradCache with chunk size %d", gc_chunk)
+    elif args.no_gen_gas or args.no_emb_gas:
+        raise ValueError("Cannot use no_gen_gas or no_emb_gas without GradCache")           # run.py:105-106
+    gas = max(int(args.gradient_accumulation_steps), 1)       # plain accumulation (HF Trainer semantics) when GradCache is not engaged
+    if data_args.generative_max_len is None:
+        data_args.generative_max_len = data_args.passage_max_len                             # run.py:132-133
 
     tok = AutoTokenizer.from_pretrained(model_args.tokenizer_name or model_args.model_name_or_path, padding_side="right")
     if not tok.pad_token and tok.bos_token:
@@ -72,7 +87,7 @@ def main(argv=None):
     max_len = max(data_args.query_max_len or 0, data_args.passage_max_len or 0, data_args.generative_max_len or 0)
     ds = EmbeddingDataset(rows, data_args.train_group_size, max_char_len=max_len * 10, seed=args.seed + rank) if do_emb else None
     collate = EmbeddingCollator(tok, data_args.query_max_len, data_args.passage_max_len)
-    collate_gen = GenerativeCollator(tok, data_args.generative_max_len or 128, data_args.prefixlm) if do_gen else None
+    collate_gen = GenerativeCollator(tok, data_args.generative_max_len, data_args.prefixlm) if do_gen else None
     gen_bs = args.per_device_generative_bs          # smaller generative batch: every (bs // gen_bs)-th sample (data.py:49-54,137-144)
 
     dtype = torch.bfloat16 if args.bf16 else torch.float32
@@ -85,25 +100,82 @@ def main(argv=None):
     if use_cuda and dtype == torch.bfloat16 and getattr(model.model.config, "model_type", "") == "mistral" and model_args.attn[:2] == "bb":
         model.enable_native(device).cache_transposed_weights = True      # invalidated by weights_updated() after every step
         logger.info("native MI355X engine bound to %s", model_args.model_name_or_path)
-    params = [p for p in model.model.parameters() if p.requires_grad]
+    if args.gradient_checkpointing:
+        model.gradient_checkpointing_enable()       # native engine: per-layer recompute; Hugging Face path: the module's own
+    if model.projection is not None:
+        model.projection.to(device)
+    seen, params = set(), []
+    for p_ in model.parameters():                   # backbone AND the optional --projection head (the reference optimises model.parameters())
+        if p_.requires_grad and id(p_) not in seen:
+            seen.add(id(p_)); params.append(p_)
     opt = torch.optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, betas=(args.adam_beta1, args.adam_beta2),
                             eps=args.adam_epsilon)
     bs = args.per_device_train_batch_size
     if gen_bs is not None:
         assert bs >= gen_bs and bs % gen_bs == 0, "Full batch size must be divisible by the generative batch size"
     n_items = max(len(rows), len(gen_rows))         # unified: the longer data set drives the epoch (data.py:33)
-    steps_per_epoch = max(n_items // (bs * world), 1)
+    micro_per_epoch = max(n_items // (bs * world), 1)
+    steps_per_epoch = max(micro_per_epoch // gas, 1)                 # one optimizer step per `gas` micro-batches
     total = args.max_steps if args.max_steps > 0 else int(steps_per_epoch * args.num_train_epochs)
     sched = get_scheduler(args.lr_scheduler_type, opt, num_warmup_steps=args.get_warmup_steps(total), num_training_steps=total)
     gc = GradCacheStep(model, gc_chunk) if gc_chunk else None
 
+    def save_checkpoint(step_):
+        """checkpoint-<step>/: weights under the reference parameter names + optimizer / scheduler / step (HF Trainer layout)."""
+        ck = os.path.join(args.output_dir, f"checkpoint-{step_}")
+        if rank == 0:
+            model.model.save_pretrained(ck, safe_serialization=args.save_safetensors)
+            if model.projection is not None:
+                torch.save(model.projection.state_dict(), os.path.join(ck, "projection.pt"))
+            torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
+            torch.save(sched.state_dict(), os.path.join(ck, "scheduler.pt"))
+            with open(os.path.join(ck, "trainer_state.json"), "w") as f:
+                json.dump({"global_step": step_, "micro_batches_done": step_ * gas, "world_size": world}, f)
+        if dist.is_initialized():
+            dist.barrier()
+
+    step, micro_done = 0, 0
+    if args.resume_from_checkpoint:
+        ck = args.resume_from_checkpoint
+        if not isinstance(ck, str) or not os.path.isdir(ck):
+            raise ValueError(f"--resume_from_checkpoint expects a checkpoint-<step> directory written by this entry point, got {ck!r}")
+        st = json.load(open(os.path.join(ck, "trainer_state.json")))
+        if st["world_size"] != world:
+            raise ValueError(f"checkpoint was written with world_size {st['world_size']}, this run has {world} (data order differs)")
+        from safetensors.torch import load_file
+        wfile = os.path.join(ck, "model.safetensors")
+        sd = load_file(wfile) if os.path.exists(wfile) else torch.load(os.path.join(ck, "pytorch_model.bin"), map_location="cpu")
+        with torch.no_grad():                       # in place: the native engine's packed views stay bound to the parameters
+            own = dict(model.model.named_parameters())
+            for k_, v_ in sd.items():
+                own[k_].copy_(v_.to(own[k_].dtype))
+        if model.projection is not None:
+            model.projection.load_state_dict(torch.load(os.path.join(ck, "projection.pt"), map_location=device))
+        opt.load_state_dict(torch.load(os.path.join(ck, "optimizer.pt"), map_location=device))
+        sched.load_state_dict(torch.load(os.path.join(ck, "scheduler.pt")))
+        step, micro_done = int(st["global_step"]), int(st["micro_batches_done"])
+        if model.train_engine is not None:
+            model.train_engine.weights_updated()
+        logger.info("resumed from %s at step %d", ck, step)
+
     gen = torch.Generator().manual_seed(args.seed)
-    step, t0 = 0, time.time()
+    t0, step0 = time.time(), step
+    micro, skip = 0, micro_done                                      # resume: replay the permutations, skip the consumed micro-batches
+    loss = loss_gen = None
     while step < total:
         order = torch.randperm(n_items, generator=gen).tolist()
         order = order[rank::world]                                  # disjoint shards per rank
         for s in range(0, len(order) - bs + 1, bs):
             idx = order[s:s + bs]
+            if skip > 0:                                            # resume: advance the sampling RNG exactly as the consumed batches did
+                skip -= 1
+                if do_emb:
+                    for i in idx:
+                        ds[i % len(ds)]
+                continue
+            micro += 1
+            last_micro = micro % gas == 0                           # gradients are averaged over ranks / clipped / applied on this one
+            scale = 1.0 / gas
             loss_gen = None
             if do_gen:
                 # generative first (gradcache_trainer.py:551-579): it has no collective, the embedding step does
@@ -111,7 +183,7 @@ def main(argv=None):
                 gb = collate_gen([gen_rows[i % len(gen_rows)] for i in take])
                 gb = {k: v.to(device) for k, v in gb.items()}
                 if args.no_gen_gas or gc_chunk is None:
-                    loss_gen = model(generative=gb).loss_gen
+                    loss_gen = model(generative=gb).loss_gen * scale
                     loss_gen.backward()
                     loss_gen = loss_gen.detach()
                 else:
@@ -123,7 +195,8 @@ def main(argv=None):
                         loss_gen += lg.detach()
                 if not do_emb:
                     loss = loss_gen
-                    sync_gradients(model)
+                    if last_micro:
+                        sync_gradients(model)
             if do_emb:
                 batch = collate([ds[i % len(ds)] for i in idx])
                 q = {k: v.to(device) for k, v in batch["query"].items()}
@@ -135,17 +208,22 @@ def main(argv=None):
             elif args.split_emb:
                 # two half-steps (gradcache_trainer.py:584-605): queries with grad vs frozen passages, then the converse;
                 # both see the same scores, so the two losses agree
-                lq = model(query=q, passage=p, p_grad=False).loss
+                lq = model(query=q, passage=p, p_grad=False).loss * scale
                 lq.backward()
-                lp = model(query=q, passage=p, q_grad=False).loss
+                lp = model(query=q, passage=p, q_grad=False).loss * scale
                 lp.backward()
                 assert torch.allclose(lq.detach(), lp.detach(), rtol=1e-3, atol=1e-4), (float(lq), float(lp))
-                loss = lp
-                sync_gradients(model)
+                loss = lp.detach() / scale
+                if last_micro:
+                    sync_gradients(model)
             else:
-                loss = model(query=q, passage=p, q_grad=not args.emb_p_only, p_grad=not args.emb_q_only).loss
+                loss = model(query=q, passage=p, q_grad=not args.emb_p_only, p_grad=not args.emb_q_only).loss * scale
                 loss.backward()
-                sync_gradients(model)
+                loss = loss.detach() / scale
+                if last_micro:
+                    sync_gradients(model)
+            if not last_micro:
+                continue                                            # keep accumulating into .grad (HF Trainer: loss / gas per micro-batch)
             if args.max_grad_norm and args.max_grad_norm > 0:
                 torch.nn.utils.clip_grad_norm_(params, args.max_grad_norm)
             opt.step(); sched.step(); opt.zero_grad(set_to_none=True)
@@ -154,17 +232,25 @@ def main(argv=None):
             step += 1
             if rank == 0 and step % max(args.logging_steps, 1) == 0:
                 logger.info("step %d/%d loss %.4f%s lr %.3e %.2f s/it", step, total, float(loss),
-                            "" if loss_gen is None else " loss_gen %.4f" % float(loss_gen), sched.get_last_lr()[0], (time.time() - t0) / step)
+                            "" if loss_gen is None else " loss_gen %.4f" % float(loss_gen), sched.get_last_lr()[0],
+                            (time.time() - t0) / max(step - step0, 1))
+            if str(getattr(args.save_strategy, "value", args.save_strategy)) == "steps" and args.save_steps and args.save_steps >= 1 and step % int(args.save_steps) == 0 \
+                    and step < total:
+                save_checkpoint(step)
             if step >= total:
                 break
         if len(order) < bs:
             raise ValueError(f"dataset shard ({len(order)} rows) smaller than the per-device batch {bs}")
     if rank == 0:
         model.model.save_pretrained(args.output_dir, safe_serialization=args.save_safetensors)
+        if model.projection is not None:
+            torch.save(model.projection.state_dict(), os.path.join(args.output_dir, "projection.pt"))
         tok.save_pretrained(args.output_dir)
     if dist.is_initialized():
         dist.barrier()
     main.last_loss_gen = None if loss_gen is None else float(loss_gen)
+    if loss is None:
+        raise ValueError("no optimizer step was taken (max_steps / data too small, or the checkpoint already reached max_steps)")
     return float(loss.detach()) if torch.is_tensor(loss) else float(loss)
 
 

@@ -40,7 +40,10 @@ enum {
   GRIT_EPI_RESIDUAL = 1, /* C = bf16(acc + residual)  (residual may alias C)                    */
   GRIT_EPI_SWIGLU = 2,   /* weight rows interleaved gate/up in blocks of grit_swiglu_block() rows;
                             C[:, N/2] = bf16(silu(bf16(gate)) * bf16(up))                        */
-  GRIT_EPI_ROPE = 3      /* (grit_gemm_bf16_nt_rope) STORE + rotary embedding on the leading columns */
+  GRIT_EPI_ROPE = 3,     /* (grit_gemm_bf16_nt_rope) STORE + rotary embedding on the leading columns */
+  GRIT_EPI_SWIGLU_STACKED = 4 /* SWIGLU on STACKED weights W = [gate (N/2 rows); up (N/2 rows)] -- the layout of a module whose
+                            gate_proj / up_proj parameters are row-slices of one buffer (training engine); the interleave happens in
+                            the per-lane LDS-DMA source address, the arithmetic is GRIT_EPI_SWIGLU's                         */
 };
 
 /* pooling modes: gritlm/gritlm.py:188-214 */

@@ -157,6 +157,34 @@ def gen_encoder(cfg_name, batch, seq, min_len, seed_w=0, seed_x=1234):
     np.savez_compressed(os.path.join(HERE, f"encoder_{cfg_name}.npz"), **out)
 
 
+@torch.no_grad()
+def gen_encoder_7b_l1(batch=2, seq=512, min_len=200, seed_w=0, seed_x=777, n_probe=64):
+    """One decoder layer at the TRUE GritLM-7B layer shape (scripts/training/train_gritlm_7b.sh:54 -> Mistral-7B: H 4096, I 14336,
+    32 query / 8 kv heads) through the reference's MistralModel(is_causal=False) (scripts/modeling_mistral_gritlm.py:936-1096), fp32 and
+    bf16 runs, B=2 x S=512 ragged.  Every GEMM of the layer runs at the K (4096 / 14336) and N (6144 / 4096 / 28672) the benchmark uses.
+    Stored: pooled embeddings + n_probe rows of last_hidden_state (the full tensor would be 16 MB per run)."""
+    cfg_name = "7b-l1"
+    model, cfg = build_ref_model(cfg_name, seed_w)
+    ids, mask = synth.make_batch(cfg, batch, seq, seed_x, min_len)
+    tid, tmask = torch.from_numpy(ids), torch.from_numpy(mask)
+    h32 = model(input_ids=tid, attention_mask=tmask, is_causal=False)[0]
+    h_causal = model(input_ids=tid, attention_mask=tmask, is_causal=True)[0]
+    assert (h32 - h_causal).abs().max() > 1e-3, "is_causal flag is dead"
+    hb = model.to(torch.bfloat16)(input_ids=tid, attention_mask=tmask, is_causal=False)[0].float()
+    valid = np.argwhere(mask.reshape(-1) > 0)[:, 0]
+    probe = np.sort(np.random.default_rng(5).choice(valid, size=n_probe, replace=False))
+    out = dict(cfg_name=cfg_name, seed_w=seed_w, input_ids=ids, attention_mask=mask, probe_rows=probe,
+               probe_hidden=h32.reshape(-1, h32.shape[-1])[probe].numpy(), probe_hidden_bf16=hb.reshape(-1, hb.shape[-1])[probe].numpy())
+    vm = torch.from_numpy(mask.astype(bool))
+    out["rel_refbf16_vs_fp32_all_valid_rows"] = np.float32((torch.linalg.norm((hb - h32)[vm]) / torch.linalg.norm(h32[vm])).item())
+    for method in ("mean", "weightedmean"):
+        g = ref_gritlm_shell(method)
+        out[f"emb_{method}"] = torch.nn.functional.normalize(g.pooling(h32, tmask.clone()), dim=-1).numpy()
+        out[f"emb_{method}_bf16"] = torch.nn.functional.normalize(g.pooling(hb.bfloat16(), tmask.clone()).float(), dim=-1).numpy()
+    print(f"  {cfg_name}: bf16-vs-fp32 rel {out['rel_refbf16_vs_fp32_all_valid_rows']:.3e}, lens {mask.sum(1).tolist()}")
+    np.savez_compressed(os.path.join(HERE, f"encoder_{cfg_name}.npz"), **out)
+
+
 def gen_pooling():
     rng = np.random.default_rng(7)
     hidden = rng.standard_normal((5, 9, 24), dtype=np.float32)
@@ -376,6 +404,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if sys.argv[1:] == ["generative"]:
         gen_generative(); sys.exit(0)
+    if sys.argv[1:] == ["7b-l1"]:            # only the 7B-layer-shape fixture (1.4 GB of fp32 weights, ~2 min on 8 cores)
+        gen_encoder_7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
         gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
         sys.exit(0)
@@ -388,4 +418,5 @@ if __name__ == "__main__":
     print("gritlm encode"); gen_gritlm_encode()
     print("generative"); gen_generative()
     print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
+    print("encoder 7b-l1"); gen_encoder_7b_l1()
     print("done")

@@ -111,3 +111,72 @@ def test_cli_unified_two_steps(tmp_path):
                      "--learning_rate", "1e-4", "--query_max_len", "16", "--passage_max_len", "24", "--generative_max_len", "32",
                      "--loss_gen_type", "mixed", "--report_to", "none", "--use_cpu"])
     assert np.isfinite(loss) and run.main.last_loss_gen is not None and np.isfinite(run.main.last_loss_gen)
+
+
+def _base(tmp_path, d, data, out, *extra):
+    return ["--model_name_or_path", d, "--train_data", data, "--output_dir", str(tmp_path / out), "--train_group_size", "4",
+            "--pooling_method", "mean", "--learning_rate", "1e-3", "--query_max_len", "16", "--passage_max_len", "24", "--report_to", "none",
+            "--use_cpu", "--lr_scheduler_type", "constant", "--weight_decay", "0", *extra]
+
+
+def _weights(out_dir):
+    from safetensors.torch import load_file
+    f = [x for x in os.listdir(out_dir) if x.endswith(".safetensors")]
+    return load_file(os.path.join(out_dir, f[0])) if f else torch.load(os.path.join(out_dir, "pytorch_model.bin"))
+
+
+def test_cli_unsupported_flags_raise(tmp_path):
+    """Flags the reference accepts and this entry point does not implement must raise, e.g. --lora would otherwise
+    silently run a full fine-tune."""
+    import pytest
+    from gritlm_amd.training.run import main
+    d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
+    data = _toy(str(tmp_path / "toy.jsonl"))
+    for flag in (["--lora"], ["--qlora"], ["--use_unique_indices"], ["--num_samples", "x.json"], ["--split_emb_full"]):
+        with pytest.raises(NotImplementedError):
+            main(_base(tmp_path, d, data, "o", "--per_device_train_batch_size", "2", "--max_steps", "1", *flag))
+    with pytest.raises(ValueError):          # run.py:105-106
+        main(_base(tmp_path, d, data, "o", "--per_device_train_batch_size", "2", "--max_steps", "1", "--no_emb_gas"))
+
+
+def test_cli_gradient_accumulation_without_gradcache(tmp_path):
+    """GAS > 1 without --negatives_cross_device accumulates (HF Trainer semantics): the optimizer steps once per GAS micro-batches on
+    the mean gradient -- with SGD-like AdamW at step 1 the update direction equals that of ONE step on the doubled batch order."""
+    from gritlm_amd.training.run import main
+    d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
+    data = _toy(str(tmp_path / "toy.jsonl"))
+    main(_base(tmp_path, d, data, "acc", "--per_device_train_batch_size", "2", "--gradient_accumulation_steps", "3", "--max_steps", "2"))
+    main(_base(tmp_path, d, data, "noacc", "--per_device_train_batch_size", "2", "--max_steps", "2"))
+    w0 = {k: torch.from_numpy(v) for k, v in synth.make_weights(synth.CONFIGS["tiny"], 0).items()}
+    wa, wn = _weights(str(tmp_path / "acc")), _weights(str(tmp_path / "noacc"))
+    k = "layers.0.self_attn.q_proj.weight"
+    assert not torch.equal(wa[k], wn[k])                       # six micro-batches vs two: different trajectories
+    assert (wa[k].float() - w0[k]).abs().max() > 0
+
+
+def test_cli_checkpoint_and_resume_reproduce_the_uninterrupted_run(tmp_path):
+    """--save_steps writes checkpoint-<step>/ (weights + optimizer + scheduler + step); --resume_from_checkpoint continues with the same
+    data order: 2 steps + resume for 2 more == 4 uninterrupted steps (fp32, CPU, deterministic)."""
+    from gritlm_amd.training.run import main
+    d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
+    data = _toy(str(tmp_path / "toy.jsonl"))
+    common = ["--per_device_train_batch_size", "2", "--save_strategy", "steps", "--save_steps", "2", "--save_safetensors", "true"]
+    main(_base(tmp_path, d, data, "full", *common, "--max_steps", "4"))
+    ck = str(tmp_path / "full" / "checkpoint-2")
+    assert {"optimizer.pt", "scheduler.pt", "trainer_state.json"} <= set(os.listdir(ck))
+    main(_base(tmp_path, d, data, "resumed", *common, "--max_steps", "4", "--resume_from_checkpoint", ck))
+    wf, wr = _weights(str(tmp_path / "full")), _weights(str(tmp_path / "resumed"))
+    for k in wf:
+        assert torch.allclose(wf[k].float(), wr[k].float(), rtol=0, atol=1e-6), k
+
+
+def test_cli_projection_head_is_trained_and_saved(tmp_path):
+    from gritlm_amd.training.run import main
+    d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
+    data = _toy(str(tmp_path / "toy.jsonl"))
+    torch.manual_seed(0)
+    main(_base(tmp_path, d, data, "p", "--per_device_train_batch_size", "2", "--max_steps", "2", "--projection", "32"))
+    sd = torch.load(str(tmp_path / "p" / "projection.pt"))
+    torch.manual_seed(0)
+    init = torch.nn.Linear(256, 32)
+    assert sd["weight"].shape == (32, 256) and not torch.allclose(sd["weight"], init.weight)        # the optimizer moved it
