@@ -53,6 +53,20 @@ __device__ __forceinline__ uint32_t pack2bf_hw(float lo, float hi) {
 }
 __device__ __forceinline__ float round_bf(float f) { return __uint_as_float(f2bf(f) << 16); }
 
+// Rotary embedding arithmetic with a FIXED contraction (one rounded product + one fma), so every kernel that rotates -- rope_k, the QKV
+// GEMM's epilogue in both launch forms, the decode kernels -- produces the same bits whatever the surrounding code makes the compiler
+// prefer:  lo = x1*cos - x2*sin,  hi = x2*cos + x1*sin   (modeling_mistral_gritlm.py:138-163, x*cos + rotate_half(x)*sin)
+__device__ __forceinline__ float rope_lo(float x1, float x2, float c, float s) {
+#pragma clang fp contract(off)
+  const float t = x2 * s;
+  return __builtin_fmaf(x1, c, -t);
+}
+__device__ __forceinline__ float rope_hi(float x1, float x2, float c, float s) {
+#pragma clang fp contract(off)
+  const float t = x1 * s;
+  return __builtin_fmaf(x2, c, t);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

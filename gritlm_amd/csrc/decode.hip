@@ -138,8 +138,8 @@ __global__ void __launch_bounds__(256) rope_kv_append_k(uint16_t* __restrict__ q
       for (int e = 0; e < 4; ++e) {
         const float c0 = ct[2 * e], c1 = ct[2 * e + 1], s0 = stb[2 * e], s1 = stb[2 * e + 1];
         const float a0 = bflo(a[e]), a1 = bfhi(a[e]), b0 = bflo(bb[e]), b1 = bfhi(bb[e]);
-        o1[e] = pack2bf(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);      // x*cos + rotate_half(x)*sin, first half: -x2 * sin
-        o2[e] = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);      // second half: +x1 * sin
+        o1[e] = pack2bf(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));      // x*cos + rotate_half(x)*sin, first half: -x2 * sin
+        o2[e] = pack2bf(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));      // second half: +x1 * sin
       }
       const uint4 r1 = make_uint4(o1[0], o1[1], o1[2], o1[3]), r2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
       if (head < nq) {
@@ -201,14 +201,14 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     const uint16_t* row = q + (int64_t)b * q_stride;
     for (int g = 0; g < G; ++g) {
       const float x1 = bf2f(row[(int64_t)(hk * G + g) * AD_D + lane]), x2 = bf2f(row[(int64_t)(hk * G + g) * AD_D + 64 + lane]);
-      const uint32_t r = pack2bf(x1 * c - x2 * sn, x2 * c + x1 * sn);                                // one rounding, as rope_k
+      const uint32_t r = pack2bf(rope_lo(x1, x2, c, sn), rope_hi(x1, x2, c, sn));                     // one rounding, as rope_k
       qs[g][lane] = bflo(r) * scale; qs[g][64 + lane] = bfhi(r) * scale;
     }
     if (pos >= k0 && pos < k0 + AD_CH) {                  // this workgroup owns the new key: rotate k, append k and v
       const uint16_t* kr = row + (int64_t)(nq + hk) * AD_D;
       const uint16_t* vr = row + (int64_t)(nq + nkv + hk) * AD_D;
       const float x1 = bf2f(kr[lane]), x2 = bf2f(kr[64 + lane]);
-      const uint32_t r = pack2bf(x1 * c - x2 * sn, x2 * c + x1 * sn);
+      const uint32_t r = pack2bf(rope_lo(x1, x2, c, sn), rope_hi(x1, x2, c, sn));
       uint16_t* kd = ck + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D;
       kd[lane] = (uint16_t)(r & 0xffff); kd[64 + lane] = (uint16_t)(r >> 16);
       reinterpret_cast<uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D)[lane] = reinterpret_cast<const uint32_t*>(vr)[lane];

@@ -93,8 +93,8 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_generic_k(const uint4* __rest
 __device__ __forceinline__ void rot2(uint32_t a, uint32_t b, float c0, float s0, float c1, float s1, uint32_t& oa,
                                      uint32_t& ob) {
   const float a0 = bflo(a), a1 = bfhi(a), b0 = bflo(b), b1 = bfhi(b);
-  oa = pack2bf(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
-  ob = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+  oa = pack2bf(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+  ob = pack2bf(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
 }
 __global__ void __launch_bounds__(256) rope_k(uint16_t* __restrict__ qkv, const float4* __restrict__ cos_tab,
                                               const float4* __restrict__ sin_tab, const int32_t* __restrict__ positions, int64_t T,

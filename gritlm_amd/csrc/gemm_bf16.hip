@@ -313,8 +313,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           for (int r = 0; r < 4; ++r) {
             const uint32_t xr = pack2bf_hw(acc[i][p2][r], acc[i][p2 + 2][r]);     // q/k = bf16(linear) first (:655-657)
             const float x1 = bflo(xr), x2 = bfhi(xr);
-            acc[i][p2][r] = x1 * cc[r] - x2 * ss[r];
-            acc[i][p2 + 2][r] = x2 * cc[r] + x1 * ss[r];
+            acc[i][p2][r] = rope_lo(x1, x2, cc[r], ss[r]);
+            acc[i][p2 + 2][r] = rope_hi(x1, x2, cc[r], ss[r]);
           }
         }
       }

@@ -113,6 +113,16 @@ static unsigned long long run_case(const Lib& a, const Lib& b, const Case& c, in
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(&total, dcount, 8, hipMemcpyDeviceToHost));
     fprintf(log, "check M=%lld N=%d K=%d epi=%d reps=%d : %llu differing words%s\n", (long long)M, N, K, c.epi, reps, total, total ? "  <-- MISMATCH" : "");
+    if (total) {
+      std::vector<uint16_t> ha(M * outN), hb(M * outN);
+      CK(hipMemcpy(ha.data(), Ca, M * outN * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), Cb, M * outN * 2, hipMemcpyDeviceToHost));
+      int shown = 0; long long rows_bad = 0, last_row = -1;
+      for (int64_t i = 0; i < M * outN; ++i) if (ha[i] != hb[i]) {
+        if (i / outN != last_row) { ++rows_bad; last_row = i / outN; }
+        if (shown < 24) { fprintf(log, "   diff at row %lld col %lld : r01 %04x new %04x\n", (long long)(i / outN), (long long)(i % outN), ha[i], hb[i]); ++shown; }
+      }
+      fprintf(log, "   rows with differences: %lld\n", rows_bad);
+    }
   } else {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double flop = 2.0 * M * N * K;
@@ -144,10 +154,20 @@ static unsigned long long run_case(const Lib& a, const Lib& b, const Case& c, in
 
 int main(int argc, char** argv) {
   const char* mode = argc > 1 ? argv[1] : "all";
-  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  const int reps = (argc > 2 && strcmp(mode, "case")) ? atoi(argv[2]) : 10;
   const char* newlib = getenv("GEMM_NEW") ? getenv("GEMM_NEW") : "gritlm_amd/libgritlm_hip.so";
   const char* oldlib = getenv("GEMM_OLD") ? getenv("GEMM_OLD") : "tools/ubench/_r01/libgemm_r01.so";
   Lib a = load(oldlib), b = load(newlib);
+  if (getenv("GEMM_SELF_AB")) {
+    // library "a" is a COPY of the library under test: latch GRIT_GEMM_NOPERSIST=1 into its launch knobs (read at its first launch),
+    // so the run compares the persistent launch form (b) with the one-workgroup-per-tile form (a) of the SAME kernels bit for bit
+    setenv("GRIT_GEMM_NOPERSIST", "1", 1);
+    uint16_t* t; CK(hipMalloc(&t, 256 * 256 * 2 * 3)); CK(hipMemset(t, 0, 256 * 256 * 2 * 3));
+    a.gemm(t, t + 65536, t + 131072, 256, 256, 64, 64, 64, 256, 0, nullptr, 0, nullptr);
+    CK(hipDeviceSynchronize());
+    unsetenv("GRIT_GEMM_NOPERSIST");
+    (void)hipFree(t);
+  }
   unsigned long long bad = 0;
   if (!strcmp(mode, "check") || !strcmp(mode, "all")) {
     const Case cases[] = {
@@ -155,8 +175,15 @@ int main(int argc, char** argv) {
         {4096, 1024, 512, RESIDUAL}, {777, 528, 576, RESIDUAL}, {4096, 2048, 512, SWIGLU}, {1111, 1088, 192, SWIGLU},
         {2048, 1536, 512, ROPE}, {1500, 768, 320, ROPE}, {5000, 768, 256, GROUPED_STORE}, {5000, 1024, 320, GROUPED_SWIGLU},
         {8192, 4096, 4096, STORE}, {8192, 4096, 14336, RESIDUAL}, {4096, 28672, 4096, SWIGLU}, {8192, 6144, 4096, ROPE},
+        // persistent path (more tiles than CUs, even K-tile count >= 4) with ragged M / N edges and a tile count that is not a multiple of 256
+        {9000, 4352, 512, STORE}, {9000, 4352, 512, RESIDUAL}, {9000, 4352, 512, SWIGLU}, {9000, 4352, 256, ROPE}, {4100, 4352, 256, STORE},
+        {70000, 1280, 384, RESIDUAL},
     };
     for (const Case& c : cases) bad += run_case(a, b, c, c.M * (int64_t)c.N > (1 << 24) ? 3 : reps * 3, false, stdout);
+  }
+  if (!strcmp(mode, "case")) {                  // gemm_ab.bin case M N K epi [reps]
+    const Case c{atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5])};
+    bad += run_case(a, b, c, argc > 6 ? atoi(argv[6]) : 4, true, stdout);
   }
   if (!strcmp(mode, "time") || !strcmp(mode, "all")) {
     const int64_t M = getenv("AB_M") ? atoll(getenv("AB_M")) : 131072;
