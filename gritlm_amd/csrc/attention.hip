@@ -4,9 +4,13 @@
 // scripts/modeling_mistral_gritlm.py (:182-191, :1017-1036, :690-698).  No repeat_kv copy (the kv head is
 // index arithmetic), no mask tensor (one uint64 per 64 keys), no S x S score matrix.
 //
-// Structure: one 256-thread workgroup = 128 query rows of one (batch, head); each wave owns 32 rows.
-// KV tiles of 64 keys go HBM -> registers -> LDS (K row-major with a 16-B-slot XOR swizzle, V row-major with a
-// 320-B pitch and read back TRANSPOSED by ds_read_b64_tr_b16) with the next tile's global loads in flight during the MFMAs.
+// Structure: one 256-thread workgroup = 128 query rows of one (batch, head); each wave owns 32 rows; two workgroups per CU.
+// KV tiles of 64 keys go HBM -> LDS by direct LDS-DMA (global_load_lds, 16 B per lane, 1 KiB = 4 key rows per wave instruction) into
+// a two-stage ring: the DMA of tile t+1 is issued right after the single barrier of tile t and lands under tile t's MFMAs and
+// softmax -- no staging registers, no ds_write pass, one barrier per tile.  Both images are row-major [key][256 B] with the 16-byte
+// units XOR-swizzled through the per-lane SOURCE address (the LDS image of a DMA is lane-linear): K unit ^= key & 15
+// (conflict-free ds_read_b128 of a 32-key fragment), V unit ^= 4 (key & 3) (conflict-free ds_read_b64_tr_b16: the 16 lanes of a
+// transposing read touch 4 keys x 32 B, the XOR puts them -- and the second 16-lane group -- on 16 distinct units of one 256-B bank row).
 //   S^T = K Q^T     v_mfma_f32_32x32x16_bf16(A = K rows, B = Q)  -> lane (q = lane&31) holds 32 keys' scores
 //   O^T = V^T P^T   v_mfma_f32_32x32x16_bf16(A = V^T rows, B = P) -> lane (q = lane&31) holds 64 of its d's
 // Both products are "swapped" so that every softmax statistic (max, sum, rescale) is lane-local: the only
@@ -21,9 +25,12 @@ namespace grit {
 constexpr int ATT_D = 128;
 constexpr int ATT_QB = 128;   // query rows per workgroup
 constexpr int ATT_KB = 64;    // keys per tile
-constexpr int V_PITCH = 320;  // bytes per key row of the row-major V image: 256 + 64, so that 4 consecutive rows start 16 banks apart
+constexpr int V_PITCH = 256;  // bytes per key row of the row-major V image
 constexpr int K_LDS_BYTES = ATT_KB * ATT_D * 2;  // 16384
-constexpr int V_LDS_BYTES = ATT_KB * V_PITCH;    // 20480
+constexpr int V_LDS_BYTES = ATT_KB * V_PITCH;    // 16384
+constexpr int ATT_STAGE_BYTES = K_LDS_BYTES + V_LDS_BYTES;   // 32 KiB per stage, two stages
+typedef const __attribute__((address_space(1))) void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 __device__ __forceinline__ uint32_t lo16(uint32_t w) { return w & 0xffffu; }
@@ -38,9 +45,7 @@ __global__ void __launch_bounds__(256, 2)
 attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                  uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride,
                  int64_t out_stride, float scale_log2) {
-  __shared__ __attribute__((aligned(16))) char smem[K_LDS_BYTES + V_LDS_BYTES];
-  char* k_lds = smem;
-  char* v_lds = smem + K_LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -83,38 +88,24 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
   }
 
-  // ---- staging roles
-  // K: 1024 16-B chunks per tile, 4 per thread: chunk = tid + 256*it -> row = (tid>>4) + 16*it, slot = tid&15
-  // per-thread staging constants (no arrays / lambdas: keeps the staging registers out of scratch)
-  const int k_row = tid >> 4, k_slot = tid & 15;                 // chunk it: row = k_row + 16*it
-  const int k_lds_off = k_row * 256 + ((k_slot ^ (k_row & 15)) << 4);  // (row+16it)&15 == row&15
-  const int v_lds_off = k_row * V_PITCH + k_slot * 16;          // V: same (row, 16-byte slot) roles as K, row-major, no swizzle
-  uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
-
-#define ATT_KROW(it) ({ int key_ = key0_ + k_row + 16 * (it); key_ < S ? key_ : S - 1; })
-#define ATT_LOAD_TILE(t)                                                                                       \
-  do {                                                                                                         \
-    const int key0_ = (t) * ATT_KB;                                                                            \
-    kr0 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(0)) * qkv_stride + k_slot * 8);             \
-    kr1 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(1)) * qkv_stride + k_slot * 8);             \
-    kr2 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(2)) * qkv_stride + k_slot * 8);             \
-    kr3 = *reinterpret_cast<const uint4*>(kbase + (row0 + ATT_KROW(3)) * qkv_stride + k_slot * 8);             \
-    vr0 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(0)) * qkv_stride + k_slot * 8);             \
-    vr1 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(1)) * qkv_stride + k_slot * 8);             \
-    vr2 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(2)) * qkv_stride + k_slot * 8);             \
-    vr3 = *reinterpret_cast<const uint4*>(vbase + (row0 + ATT_KROW(3)) * qkv_stride + k_slot * 8);             \
-  } while (0)
-#define ATT_STORE_TILE()                                                                                       \
-  do {                                                                                                         \
-    *reinterpret_cast<uint4*>(k_lds + k_lds_off) = kr0;                                                        \
-    *reinterpret_cast<uint4*>(k_lds + k_lds_off + 16 * 256) = kr1;                                             \
-    *reinterpret_cast<uint4*>(k_lds + k_lds_off + 32 * 256) = kr2;                                             \
-    *reinterpret_cast<uint4*>(k_lds + k_lds_off + 48 * 256) = kr3;                                             \
-    *reinterpret_cast<uint4*>(v_lds + v_lds_off) = vr0;                                                        \
-    *reinterpret_cast<uint4*>(v_lds + v_lds_off + 16 * V_PITCH) = vr1;                                         \
-    *reinterpret_cast<uint4*>(v_lds + v_lds_off + 32 * V_PITCH) = vr2;                                         \
-    *reinterpret_cast<uint4*>(v_lds + v_lds_off + 48 * V_PITCH) = vr3;                                         \
-  } while (0)
+  // ---- LDS-DMA roles: wave w stages keys 16w .. 16w+15 of a tile, four 1-KiB instructions for K and four for V (4 keys each);
+  //      lane -> key 16w + 4i + (lane>>4), physical 16-byte unit lane&15, which holds the LOGICAL unit (lane&15) ^ swizzle(key)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int st_key = 16 * wv + (lane >> 4);                                     // + 4i
+  const int v_unit = (lane & 15) ^ (4 * ((lane >> 4) & 3));                     // V: unit ^= 4 (key & 3); key & 3 == (lane>>4) & 3
+  auto stage_tile = [&](int t, int buf) {
+    char* kdst = smem + buf * ATT_STAGE_BYTES + wv * 4096;
+    char* vdst = kdst + K_LDS_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = t * ATT_KB + st_key + 4 * i;
+      key = key < S ? key : S - 1;
+      const int k_unit = (lane & 15) ^ ((4 * i + (lane >> 4)) & 15);           // K: unit ^= key & 15
+      const uint16_t* rowp = qkv + (row0 + key) * qkv_stride;
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(rowp + (int64_t)(nq + hk) * ATT_D + k_unit * 8), (att_lptr_t)(kdst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(rowp + (int64_t)(nq + nkv + hk) * ATT_D + v_unit * 8), (att_lptr_t)(vdst + i * 1024), 16, 0, 0);
+    }
+  };
 
   f32x16_t oacc[4];
 #pragma unroll
@@ -128,13 +119,19 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   // V fragment (A operand of O^T += V^T P^T) straight from the ROW-MAJOR V image with ds_read_b64_tr_b16: in every 16-lane group lane j
   // points at V[k0 + j/4][d0 + 4 (j%4)] and lane c receives V[k0 .. k0+3][d0 + c] (the hardware transposes the group's 4 x 16 block);
   // d0 = 32db + 16 ((lane>>4)&1) makes c <-> the MFMA row lane&31, k0 = 32kb + 16c + 4hi (+8 for the second half of the k-slice)
-  const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+  // (key & 3) of every key a lane addresses is (lane>>2)&3, so the V swizzle turns the d-block offset db*64 into (db ^ r)*64, r = (lane>>2)&3:
+  // vt_lane carries r in byte bits 7:6 and the read address of d-block db is vt_lane ^ (db << 6)
+  const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + ((((lane >> 2) & 3) * 4) << 4) + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
 
-  if (ntiles > 0) ATT_LOAD_TILE(0);
+  if (ntiles > 0) stage_tile(0, 0);
   for (int t = 0; t < ntiles; ++t) {
-    ATT_STORE_TILE();
-    __syncthreads();
-    if (t + 1 < ntiles) ATT_LOAD_TILE(t + 1);
+    // tile t has landed (this wave's share: vmcnt; everybody's: the barrier) and every wave is done reading the other stage
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < ntiles) stage_tile(t + 1, (t + 1) & 1);
+    const char* k_lds = smem + (t & 1) * ATT_STAGE_BYTES;
+    const char* v_lds = k_lds + K_LDS_BYTES;
 
     // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
     f32x16_t sacc[2];
@@ -220,14 +217,13 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const char* vp = v_lds + vt_lane + (kb * 32 + c * 16) * V_PITCH + db * 64;
+          const char* vp = v_lds + (vt_lane ^ (db << 6)) + (kb * 32 + c * 16) * V_PITCH;
           const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
           const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * V_PITCH));
           const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
         }
     }
-    __syncthreads();
   }
 
   // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
