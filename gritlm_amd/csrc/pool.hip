@@ -96,7 +96,14 @@ __global__ void __launch_bounds__(POOL_THREADS) pool_norm_fwd_k(const uint16_t* 
   for (int cc = tid; cc < HC; cc += POOL_THREADS) {
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int k = 0;
-    for (; k + 4 <= nz; k += 4) {  // 4 row loads in flight per lane
+    for (; k + 8 <= nz; k += 8) {  // 8 row loads (128 B) in flight per lane: one workgroup per CU has to cover the HBM latency alone
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = hb[(int64_t)cs[k + u] * HC + cc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fma8(a, v[u], cw[k + u]);       // same accumulation order as one row at a time
+    }
+    for (; k + 4 <= nz; k += 4) {
       const uint4 v0 = hb[(int64_t)cs[k] * HC + cc], v1 = hb[(int64_t)cs[k + 1] * HC + cc];
       const uint4 v2 = hb[(int64_t)cs[k + 2] * HC + cc], v3 = hb[(int64_t)cs[k + 3] * HC + cc];
       fma8(a, v0, cw[k]); fma8(a, v1, cw[k + 1]); fma8(a, v2, cw[k + 2]); fma8(a, v3, cw[k + 3]);
@@ -152,6 +159,14 @@ __global__ void __launch_bounds__(POOL_THREADS) pool_norm_varlen_fwd_k(const uin
   for (int cc = tid; cc < HC; cc += POOL_THREADS) {
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int s = s0;
+    for (; s + 8 <= s1; s += 8) {  // 8 row loads in flight per lane (see pool_norm_fwd_k)
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = hb[(int64_t)(s + u) * HC + cc];
+      const float w0 = ramp ? (float)(s - instr + 1) : 1.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fma8(a, v[u], ramp ? w0 + (float)u : 1.f);
+    }
     for (; s + 4 <= s1; s += 4) {
       const uint4 v0 = hb[(int64_t)s * HC + cc], v1 = hb[(int64_t)(s + 1) * HC + cc];
       const uint4 v2 = hb[(int64_t)(s + 2) * HC + cc], v3 = hb[(int64_t)(s + 3) * HC + cc];

@@ -890,6 +890,37 @@ def check_rccl_world1_step():
                 worst_grad_rel=worst, gathers=ret["calls"]["gather"], allreduces=ret["calls"]["allreduce"])
 
 
+def check_wgrad_accumulation_drift(cfg_name="gqa"):
+    """Weight gradients accumulate in bf16 across GradCache chunks (the wgrad GEMM's residual epilogue adds into the packed .grad
+    storage, which is what `param.grad +=` does in the reference's bf16 run).  MEASURE the rounding this costs: the same 8 x 8 batch
+    as ONE chunk (a single accumulation) vs 16 chunks of 4 rows (a 17-term bf16 running sum), relative L2 per parameter."""
+    from gritlm_amd.training.engine import MistralTrainEngine, SyntheticBackbone
+    from gritlm_amd.training.gradcache import GradCacheStep
+    from gritlm_amd.training.model import DistributedContrastiveLoss, GritLMTrainModel
+    cfg = EncoderConfig.from_dict(synth.CONFIGS[cfg_name])
+    idq, mq = synth.make_batch(synth.CONFIGS[cfg_name], 8, 40, seed=15, min_len=9)
+    idp, mp_ = synth.make_batch(synth.CONFIGS[cfg_name], 64, 120, seed=16, min_len=20)
+    q = {"input_ids": torch.from_numpy(idq).to(DEV), "attention_mask": torch.from_numpy(mq).to(DEV)}
+    p = {"input_ids": torch.from_numpy(idp).to(DEV), "attention_mask": torch.from_numpy(mp_).to(DEV)}
+    res = {}
+    for chunk in (64, 4):
+        bb = SyntheticBackbone(cfg, DEV, seed=3)
+        m = GritLMTrainModel.__new__(GritLMTrainModel)
+        torch.nn.Module.__init__(m)
+        m.model, m.projection, m.pooling_method, m.normalized, m.attn, m.embedding_attr = bb, None, "mean", True, "bbcc", None
+        m.emb_loss_fn = DistributedContrastiveLoss(0.02, False)
+        m.train_engine = MistralTrainEngine(bb, cfg, DEV)
+        loss = GradCacheStep(m, chunk)(dict(q), dict(p), sync=False)
+        res[chunk] = (float(loss.item()), {n: f32(t.grad) for n, t in bb.named_parameters()})
+    worst, worst_name = 0.0, ""
+    for n, g1 in res[64][1].items():
+        rel = float(np.linalg.norm(res[4][1][n] - g1) / (np.linalg.norm(g1) + 1e-20))
+        if rel > worst:
+            worst, worst_name = rel, n
+    ok = abs(res[64][0] - res[4][0]) < 1e-4 and worst < 2e-2
+    return _res("bf16 wgrad accumulation: 1 chunk vs 17-term running sum", ok, loss=res[4][0], worst_rel_l2=worst, worst_param=worst_name)
+
+
 def check_ce(T=300, V=1003):
     """Fused vocabulary cross entropy (grit_ce_fwd / grit_ce_bwd) vs fp64 numpy; ignore_index rows, V not a multiple of 8 via ld."""
     rng = np.random.default_rng(81)
@@ -1265,7 +1296,10 @@ def check_full_shape_properties(B=24, S=512):
 
 def check_get_cache():
     """encode(get_cache=True): embeddings + per-layer KV of the bidirectional pass, vs the Hugging Face module on the same GPU
-    (the reference path: gritlm/gritlm.py:131-140 hands back outputs[1])."""
+    (the reference path: gritlm/gritlm.py:131-140 hands back outputs[1]).
+    The comparison target is the stock Hugging Face module run on THIS GPU, not a CPU fixture: stock transformers.MistralModel with a
+    bidirectional mask is bit-equal to the reference on CPU (tests/test_oracle_golden.py::test_torch_reference_equals_reference_fixture),
+    and the cache it returns for use_cache=True is by construction what the reference returns."""
     import tempfile
     from gritlm_amd import GritLM
     g = np.load(os.path.join(GOLDEN, "gritlm_encode.npz"))
@@ -1488,6 +1522,8 @@ ALL_CHECKS = [
     ("attn_decode_gqa4_b1", check_attn_decode, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
     ("native_generate", check_native_generate, {}),
     ("native_generate_gqa", check_native_generate, dict(cfg_name="gqa", P=9, new=6, rows=3)),
+    ("native_generate_7b_layer_shape", check_native_generate, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
+    ("wgrad_accumulation_drift", check_wgrad_accumulation_drift, {}),
     ("knn_topk", check_knn_topk, {}),
     ("knn_topk_transposed_big", check_knn_topk, dict(Q=3, N=300000, H=128, k=100, transposed=True)),
     ("knn_topk_small", check_knn_topk, dict(Q=2, N=37, H=64, k=37)),
