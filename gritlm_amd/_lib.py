@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgritlm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gritlm_hip.h")
 
 GRIT_OK, GRIT_E_BADARG, GRIT_E_UNSUPPORTED, GRIT_E_LAUNCH, GRIT_E_RCCL = 0, -1, -2, -3, -4
-EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ROPE, EPI_SWIGLU_STACKED = 0, 1, 2, 3, 4
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ROPE, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5, 6
 POOL_MODES = {"mean": 0, "weightedmean": 1, "cls": 2, "lasttoken": 3}
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
                                                       int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool ROPE = (EPI == GRIT_EPI_ROPE);
-  constexpr bool SWIGLU = (EPI == GRIT_EPI_SWIGLU || EPI == GRIT_EPI_SWIGLU_STACKED);
+  constexpr bool STACKED = (EPI == GRIT_EPI_SWIGLU_STACKED || EPI == GRIT_EPI_SWIGLU_STACKED_SAVE);
+  constexpr bool SWIGLU = (EPI == GRIT_EPI_SWIGLU || STACKED);
 
   // ---- tile of (virtual) block v: XCD-aware id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group).
   //      PERSIST: the grid is one workgroup per CU (a multiple of 8, so v % 8 -- the XCD -- is the same for every tile of a
@@ -168,14 +169,15 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       const int rw = wrow_of<ROPE>(p >> 5, 2 * h + ((p >> 4) & 1)) + (p & 15);
       int gn_row = tn0 + rw; if (gn_row > N - 1) gn_row = N - 1;
       // stacked [gate; up] weights: interleaved row n = 32 q + r is gate row 16 q + r (r < 16) or up row 16 q + r - 16
-      if (EPI == GRIT_EPI_SWIGLU_STACKED) gn_row = ((gn_row >> 5) << 4) + (gn_row & 15) + ((gn_row & 16) ? (N >> 1) : 0);
+      if (STACKED) gn_row = ((gn_row >> 5) << 4) + (gn_row & 15) + ((gn_row & 16) ? (N >> 1) : 0);
       src[2 + h][c] = tW + (int64_t)gn_row * ldw + slot * 8;
     }
   };
   set_src(0, m0, M, W, n0);
   set_src(1, m0, M, W, n0);
   const int nk = K / BK;
-  auto stage = [&](int kind, int buf, int64_t kofs) {          // kofs: k offset (elements) added to the half-tile's source pointers
+  auto stage = [&](int kind, int buf, int64_t kt_) {           // K-tile kt_ of the half-tile whose row / column pointers are in src[kind]
+    const int64_t kofs = kt_ * BK;
     char* base = smem + buf * STAGE_BYTES + kind * HALF_BYTES + wid * 2048;
     __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][0] + kofs), (lptr_t)base, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][1] + kofs), (lptr_t)(base + 1024), 16, 0, 0);
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // minimum that has every reader's lgkmcnt(0) behind a barrier).  What a phase reads was waited for -- by EVERY wave, vmcnt(8) --
   // before the first barrier of the previous phase.  Phase 4 has no fragments of its own to read (W_h0 stays in registers), so it
   // reads the NEXT K-tile's W_h0 instead: LDS reads per phase 8 / 4 / 8 / 4.
-  // k31 / k20: k offsets of the half-tiles staged in phases 1,2 (W_h1, A_h1 of K-tile t+1) and 3,4 (W_h0, A_h0 of K-tile t+2).
+  // k31 / k20: K-tile index of the half-tiles staged in phases 1,2 (W_h1, A_h1 of K-tile t+1) and 3,4 (W_h0, A_h0 of K-tile t+2).
   auto ktile = [&](int64_t k31, int64_t k20, auto bufc, auto lastc) {
     constexpr int BUF = decltype(bufc)::value;
     constexpr bool LAST = decltype(lastc)::value;       // last K-tile of an output tile (PERSIST): W_h0 of the next tile is read after the epilogue
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   const std::integral_constant<int, 1> B1{};
   const std::false_type MID{};
   const std::true_type END{};
-  auto kclamp = [&](int kt) { return (int64_t)(kt < nk ? kt : nk - 1) * BK; };   // past the end: re-stage the last K-tile (nobody reads it)
+  auto kclamp = [&](int kt) { return (int64_t)(kt < nk ? kt : nk - 1); };        // past the end: re-stage the last K-tile (nobody reads it)
 
   stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(2, 1, kclamp(1)); stage(0, 1, kclamp(1));
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // W_h0(0), A_h0(0)
@@ -355,6 +357,25 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
         if (2 * oc < N)
           *reinterpret_cast<uint4*>(C + m * ldc + oc) = make_uint4(pack2bf_hw(o0[0], o0[1]), pack2bf_hw(o0[2], o0[3]), pack2bf_hw(o1[0], o1[1]),
                                                                   pack2bf_hw(o1[2], o1[3]));
+        if constexpr (EPI == GRIT_EPI_SWIGLU_STACKED_SAVE) {
+          // the bf16 pre-activations the backward pass needs, [gate | up] at the SAME columns as the activation (the exchange that gives
+          // the lane 8 consecutive activation columns gives it the 8 matching gate and up columns)
+          uint32_t gq[2][4], uq[2][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t gu0 = pack2bf_hw(acc[i][0][r], acc[i][1][r]), gu1 = pack2bf_hw(acc[i][2][r], acc[i][3][r]);
+            const auto sg = __builtin_amdgcn_permlane16_swap(gu0 & 0xffffu, gu1 & 0xffffu, false, false);
+            const auto su = __builtin_amdgcn_permlane16_swap(gu0 >> 16, gu1 >> 16, false, false);
+            gq[0][r] = sg[0]; gq[1][r] = sg[1]; uq[0][r] = su[0]; uq[1][r] = su[1];
+          }
+          if (2 * oc < N) {
+            uint16_t* gsave = const_cast<uint16_t*>(Rsd) + m * ldr + oc;
+            *reinterpret_cast<uint4*>(gsave) = make_uint4(gq[0][0] | (gq[0][1] << 16), gq[0][2] | (gq[0][3] << 16), gq[1][0] | (gq[1][1] << 16),
+                                                          gq[1][2] | (gq[1][3] << 16));
+            *reinterpret_cast<uint4*>(gsave + (N >> 1)) = make_uint4(uq[0][0] | (uq[0][1] << 16), uq[0][2] | (uq[0][3] << 16),
+                                                                     uq[1][0] | (uq[1][1] << 16), uq[1][2] | (uq[1][3] << 16));
+          }
+        }
       }
     } else {
       // 16-byte stores: v_permlane16_swap exchanges the 16-lane rows of two adjacent n-fragments so that every lane ends up with
@@ -381,6 +402,23 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
             v[2 * e] = bflo(rr) + bflo(ra[e]); v[2 * e + 1] = bfhi(rr) + bfhi(ra[e]);
           }
         }
+        if constexpr (EPI == GRIT_EPI_SWIGLU_BWD) {
+          // d_act = bf16(acc) (what the un-fused path stores and re-reads), then the arithmetic of grit_swiglu_bwd on the saved [gate | up]
+          const uint4 gv = *reinterpret_cast<const uint4*>(Rsd + m * ldr + n), uv = *reinterpret_cast<const uint4*>(Rsd + m * ldr + N + n);
+          const uint32_t ga[4] = {gv.x, gv.y, gv.z, gv.w}, ua[4] = {uv.x, uv.y, uv.z, uv.w};
+          uint32_t og[4], ou[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t dd = pack2bf_hw(v[2 * e], v[2 * e + 1]);
+            const float d0 = bflo(dd), d1 = bfhi(dd), g0 = bflo(ga[e]), g1 = bfhi(ga[e]), u0 = bflo(ua[e]), u1 = bfhi(ua[e]);
+            const float s0 = 1.0f / (1.0f + __expf(-g0)), s1 = 1.0f / (1.0f + __expf(-g1));
+            og[e] = pack2bf(d0 * u0 * s0 * (1.f + g0 * (1.f - s0)), d1 * u1 * s1 * (1.f + g1 * (1.f - s1)));
+            ou[e] = pack2bf(d0 * g0 * s0, d1 * g1 * s1);
+          }
+          *reinterpret_cast<uint4*>(C + m * ldc + n) = make_uint4(og[0], og[1], og[2], og[3]);
+          *reinterpret_cast<uint4*>(C + m * ldc + N + n) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+          continue;
+        }
         const uint4 pk = make_uint4(pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3]), pack2bf_hw(v[4], v[5]), pack2bf_hw(v[6], v[7]));
         *reinterpret_cast<uint4*>(C + m * ldc + n) = pk;
       }
@@ -404,8 +442,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     // drains and the next tile's first MFMAs wait for nothing but this tile's epilogue.  (nk even and >= 4: the host guarantees it.)
     for (;;) {
       for (int kt = 0; kt < nk - 2; kt += 2) {
-        ktile((int64_t)(kt + 1) * BK, (int64_t)(kt + 2) * BK, B0, MID);
-        ktile((int64_t)(kt + 2) * BK, (int64_t)(kt + 3) * BK, B1, MID);
+        ktile(kt + 1, kt + 2, B0, MID);
+        ktile(kt + 2, kt + 3, B1, MID);
       }
       int64_t m0n = m0, Mn = M;
       const uint16_t* Wn = W;
@@ -413,9 +451,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       const int vnext = vtile + (int)gridDim.x;
       const bool more = vnext < n_virtual && tile_of(vnext, m0n, Mn, Wn, n0n);     // no next tile: re-stage this one (harmless)
       set_src(0, m0n, Mn, Wn, n0n);                        // W_h0 / A_h0 of the current tile were last staged two K-tiles ago
-      ktile((int64_t)(nk - 1) * BK, 0, B0, MID);
+      ktile(nk - 1, 0, B0, MID);
       set_src(1, m0n, Mn, Wn, n0n);
-      ktile(0, BK, B1, END);
+      ktile(0, 1, B1, END);
       epilogue(m0, M, n0);
       if (!more) break;
       zero_acc();
@@ -583,6 +621,15 @@ extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t 
     case GRIT_EPI_SWIGLU_STACKED:
       GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
       return launch_gemm<GRIT_EPI_SWIGLU_STACKED>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    case GRIT_EPI_SWIGLU_STACKED_SAVE:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      GRIT_REQUIRE(residual && ldr % 8 == 0 && ldr >= N && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_bf16_nt: SWIGLU_STACKED_SAVE writes [gate | up] through `residual` (ldr >= N)");
+      return launch_gemm<GRIT_EPI_SWIGLU_STACKED_SAVE>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
+    case GRIT_EPI_SWIGLU_BWD:
+      GRIT_REQUIRE(residual && ldr % 8 == 0 && ldr >= 2 * (int64_t)N && ldc >= 2 * (int64_t)N && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_bf16_nt: SWIGLU_BWD needs the saved [gate | up] in `residual` (ldr >= 2N) and ldc >= 2N");
+      return launch_gemm<GRIT_EPI_SWIGLU_BWD>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
     default:
       GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt: unknown epilogue %d", epilogue);
   }

@@ -5,7 +5,8 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, EPI_SWIGLU_STACKED, POOL_MODES, check
+from ._lib import (EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, POOL_MODES,
+                   check)
 
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 
@@ -176,17 +177,19 @@ def pool_norm_varlen_bwd(y: torch.Tensor, dy: torch.Tensor, inv_norm: torch.Tens
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE,
             residual: torch.Tensor | None = None) -> torch.Tensor:
-    """out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue).  SWIGLU: w holds interleaved gate/up rows (SWIGLU_STACKED: [gate; up]), out is [M, N/2]."""
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue).  SWIGLU: w holds interleaved gate/up rows (SWIGLU_STACKED: [gate; up]), out is [M, N/2].
+    SWIGLU_STACKED_SAVE: additionally writes the bf16 [gate | up] pre-activations into `residual` ([M, N]).
+    SWIGLU_BWD: a @ w^T is d_act [M, N]; `residual` holds the saved [gate | up] ([M, 2N]); out = [d_gate | d_up] ([M, 2N])."""
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K, (a.shape, w.shape)
-    n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED) else N
+    n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE) else (2 * N if epilogue == EPI_SWIGLU_BWD else N)
     if out is None:
         out = torch.empty((M, n_out), dtype=BF16, device=a.device)
     assert out.shape == (M, n_out)
     rp, ldr = 0, 0
-    if epilogue == EPI_RESIDUAL:
-        assert residual is not None and residual.shape == (M, N)
+    if epilogue in (EPI_RESIDUAL, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD):
+        assert residual is not None and residual.shape == (M, 2 * N if epilogue == EPI_SWIGLU_BWD else N)
         rp, ldr = _chk2d(residual, BF16, "residual"), residual.stride(0)
     ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K, tag=f"N={N},K={K},epi={epilogue}") if _timer is not None else None
     if ev:

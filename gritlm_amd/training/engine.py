@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 
 from .. import ops
-from .._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU_STACKED
+from .._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE
 from ..encoder import EncoderConfig, rope_tables
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -180,6 +180,13 @@ class MistralTrainEngine:
         ops.transpose(x, out=view)
         return view
 
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, g: torch.Tensor, tags=("dy", "x")):
+        """g[N_out, K_in] += dy[T, N_out]^T @ x[T, K_in]  (bf16 accumulation in the packed .grad storage through the residual epilogue):
+        two zero-padded transposed copies + the NT GEMM.  (A TN form of the kernel that reads dy and x as they lie -- fragments through
+        ds_read_b64_tr_b16 -- was built and measured in round 2: bit-identical, 25-35 % slower than NT + both transposes, because the
+        transposing reads double the LDS instructions of the load segments; profiles/r02_gemm_tn_wgrad.log.)"""
+        ops.gemm_nt(self._transposed_act(dy, tags[0]), self._transposed_act(x, tags[1]), out=g, epilogue=EPI_RESIDUAL, residual=g)
+
     def _wt(self, li: int, name: str, w: torch.Tensor) -> torch.Tensor:
         """W^T for the dgrad GEMM.  With ``cache_transposed_weights`` it is reused by every GradCache chunk of a step; the cache is
         keyed on the owning Parameters' version counters, so an in-place optimizer update invalidates it even
@@ -230,9 +237,8 @@ class MistralTrainEngine:
         ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
         ops.rmsnorm(h_mid, L.ln2.data, eps, out=x2)
         gu = buf["gu"]
-        if need_bwd:
-            ops.gemm_nt(x2, L.wgu, out=gu)
-            ops.swiglu(gu, out=act)
+        if need_bwd:      # one launch: activation + the saved pre-activations [gate | up]
+            ops.gemm_nt(x2, L.wgu, out=act, epilogue=EPI_SWIGLU_STACKED_SAVE, residual=gu)
         else:
             ops.gemm_nt(x2, L.wgu, out=act, epilogue=EPI_SWIGLU_STACKED)
         if h_out is None:
@@ -344,7 +350,7 @@ class MistralTrainEngine:
             self.lm_head.grad = torch.zeros_like(self.lm_head)
         dx = ops.gemm_nt(dlogits, ops.transpose(self.lm_head.data))                                     # [T,H] = dlogits @ W_lm
         g = self.lm_head.grad
-        ops.gemm_nt(self._transposed_act(dlogits, "dlogits"), self._transposed_act(x, "x"), out=g, epilogue=EPI_RESIDUAL, residual=g)
+        self._wgrad(dlogits, x, g, ("dlogits", "x"))
         self.backward(saved, dx, on_layer_done=on_layer_done)
 
     # ------------------------------------------------------------------ backward
@@ -373,18 +379,15 @@ class MistralTrainEngine:
                     rc_buf, rc_out = self._layer_buffers(T, with_gu=True), torch.empty((T, H), dtype=BF16, device=self.device)
                 sv = self._layer_fwd(L, sv["h_in"], geom, B, S, cos, sin, rc_buf, need_bwd=True, h_out=rc_out)
             # ---- MLP: h_out = h_mid + down(silu(gate) * up)
-            dact = ops.gemm_nt(dh, self._wt(li, "down", L.wdown))                       # [T,I] = dh @ Wdown
-            dhT = self._transposed_act(dh, "dh")
-            ops.gemm_nt(dhT, self._transposed_act(sv["act"], "act"), out=L.gdown, epilogue=EPI_RESIDUAL, residual=L.gdown)
-            dgu = ops.swiglu_bwd(sv["gu"], dact)
+            # d_act = dh @ Wdown with the SwiGLU backward in the epilogue: [T, 2I] = [d_gate | d_up] straight from the accumulators
+            dgu = ops.gemm_nt(dh, self._wt(li, "down", L.wdown), epilogue=EPI_SWIGLU_BWD, residual=sv["gu"])
+            self._wgrad(dh, sv["act"], L.gdown, ("dh", "act"))
             dx2 = ops.gemm_nt(dgu, self._wt(li, "gu", L.wgu))                           # [T,H]
-            ops.gemm_nt(self._transposed_act(dgu, "dgu"), self._transposed_act(sv["x2"], "x"), out=L.ggu, epilogue=EPI_RESIDUAL,
-                        residual=L.ggu)
+            self._wgrad(dgu, sv["x2"], L.ggu, ("dgu", "x"))
             dh_mid = ops.rmsnorm_bwd(dx2, sv["h_mid"], L.ln2.data, eps, ng[2 * li + 1], dres=dh)
             # ---- attention: h_mid = h_in + o_proj(attn(rope(qkv(x1))))
             dctx = ops.gemm_nt(dh_mid, self._wt(li, "o", L.wo))                         # [T,nq*d]
-            ops.gemm_nt(self._transposed_act(dh_mid, "dh"), self._transposed_act(sv["ctx"], "ctx"), out=L.go, epilogue=EPI_RESIDUAL,
-                        residual=L.go)
+            self._wgrad(dh_mid, sv["ctx"], L.go, ("dh", "ctx"))
             if geom.packed:
                 dqkv = ops.attn_bidir_varlen_bwd(sv["qkv"], geom.cu, geom.max_len, sv["ctx"], dctx, sv["lse"], nq, nkv, d, causal=geom.causal)
                 ops.rope_qk_pos_(dqkv, cos, sin, geom.pos, nq, nkv, d, inverse=True)
@@ -392,8 +395,7 @@ class MistralTrainEngine:
                 dqkv = ops.attn_bidir_bwd(sv["qkv"], geom.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d, causal=geom.causal)
                 ops.rope_qk_(dqkv, cos, sin, S, nq, nkv, d, inverse=True)
             dx1 = ops.gemm_nt(dqkv, self._wt(li, "qkv", L.wqkv))                        # [T,H]
-            ops.gemm_nt(self._transposed_act(dqkv, "dqkv"), self._transposed_act(sv["x1"], "x"), out=L.gqkv, epilogue=EPI_RESIDUAL,
-                        residual=L.gqkv)
+            self._wgrad(dqkv, sv["x1"], L.gqkv, ("dqkv", "x"))
             dh = ops.rmsnorm_bwd(dx1, sv["h_in"], L.ln1.data, eps, ng[2 * li], dres=dh_mid)
             if on_layer_done is not None:
                 on_layer_done([L.gqkv, L.go, L.ggu, L.gdown])

@@ -41,9 +41,14 @@ enum {
   GRIT_EPI_SWIGLU = 2,   /* weight rows interleaved gate/up in blocks of grit_swiglu_block() rows;
                             C[:, N/2] = bf16(silu(bf16(gate)) * bf16(up))                        */
   GRIT_EPI_ROPE = 3,     /* (grit_gemm_bf16_nt_rope) STORE + rotary embedding on the leading columns */
-  GRIT_EPI_SWIGLU_STACKED = 4 /* SWIGLU on STACKED weights W = [gate (N/2 rows); up (N/2 rows)] -- the layout of a module whose
+  GRIT_EPI_SWIGLU_STACKED = 4, /* SWIGLU on STACKED weights W = [gate (N/2 rows); up (N/2 rows)] -- the layout of a module whose
                             gate_proj / up_proj parameters are row-slices of one buffer (training engine); the interleave happens in
                             the per-lane LDS-DMA source address, the arithmetic is GRIT_EPI_SWIGLU's                         */
+  GRIT_EPI_SWIGLU_STACKED_SAVE = 5, /* SWIGLU_STACKED that ALSO writes the bf16 pre-activations [gate | up] ([M, N], leading dimension
+                            ldr) through the `residual` pointer (an OUTPUT here): what the backward pass keeps (training forward)   */
+  GRIT_EPI_SWIGLU_BWD = 6 /* backward of SwiGLU fused behind the dgrad GEMM d_act = d_h @ W_down^T (N = intermediate size):
+                            `residual` = saved [gate | up] ([M, 2N], ldr); C = [d_gate | d_up] ([M, 2N], ldc >= 2N):
+                            d_gate = d_act * up * s (1 + gate (1 - s)), d_up = d_act * gate * s, s = sigmoid(gate), d_act = bf16(acc)  */
 };
 
 /* pooling modes: gritlm/gritlm.py:188-214 */
