@@ -85,7 +85,7 @@ __device__ __forceinline__ int wrow_of(int wc, int j) {
     GRIT_SEG_FENCE();                        \
   } while (0)
 
-template <int EPI, bool PERSIST>
+template <int EPI>
 __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W_all,
                                                       uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
@@ -95,16 +95,18 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   constexpr bool STACKED = (EPI == GRIT_EPI_SWIGLU_STACKED || EPI == GRIT_EPI_SWIGLU_STACKED_SAVE);
   constexpr bool SWIGLU = (EPI == GRIT_EPI_SWIGLU || STACKED);
 
-  // ---- tile of (virtual) block v: XCD-aware id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group).
-  //      PERSIST: the grid is one workgroup per CU (a multiple of 8, so v % 8 -- the XCD -- is the same for every tile of a
-  //      workgroup) and workgroup b walks the tiles v = b, b + grid, b + 2 grid, ...: at any time the 32 CUs of an XCD hold 32
-  //      consecutive tile ids = 4 m-tiles x 8 n-tiles sharing A / W panels in that XCD's L2, exactly as with one block per tile.
-  const int n_virtual = PERSIST ? tiles_m * tiles_n : (int)gridDim.x;
+  // ---- tile of block v: XCD-aware id (bijective remap, guide T1) + grouped ordering (GM m-tiles per group): the 32 workgroups an
+  //      XCD runs at a time are 32 consecutive tile ids = 4 m-tiles x 8 n-tiles sharing A / W panels in that XCD's 4 MiB L2.  The
+  //      sharing lives on the tiles of an XCD staying IN STEP (the L2 holds about two K-tiles of the XCD's traffic): one workgroup per
+  //      tile keeps them in step (equal tile times, in-order dispatch); a persistent one-workgroup-per-CU variant with the K-tile stream
+  //      running through the tile boundaries was built in round 2 -- bit-identical, +3 % in isolation, equal in the model (the chip is
+  //      power-limited) at TWICE the L2-miss traffic because its CUs drift apart -- and removed (profiles/r02_gemm_persistent_*.log).
+  const int n_virtual = (int)gridDim.x;
   const int group_sz = GM * tiles_n;
   auto tile_of = [&](int v, int64_t& m0, int64_t& M, const uint16_t*& W, int& n0) -> bool {
     const int xcd = v & 7, q8 = n_virtual >> 3, r8 = n_virtual & 7;
     int grp, in_grp;
-    if (!PERSIST && remap == 2) {
+    if (remap == 2) {
       // grouped (MoE) launches: tile groups are dealt round-robin to the XCDs (XCD x runs groups x, x+8, ...), so the eight XCDs work
       // on neighbouring row blocks -- i.e. on the SAME expert -- at any time and that expert's weights stay in the Infinity Cache;
       // contiguous per-XCD ranges would keep all experts' weights (1.9 GB at the 8x7B shape) live at once
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       grp = (li / group_sz) * 8 + xcd;
       in_grp = li - (li / group_sz) * group_sz;
     } else {
-      const int wg = (PERSIST || remap) ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3) : v;
+      const int wg = remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3) : v;
       grp = wg / group_sz;
       in_grp = wg - grp * group_sz;
     }
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     if (in_grp >= gm * tiles_n) return false;
     const int tm = first_m + in_grp % gm, tn = in_grp / gm;
     m0 = (int64_t)tm * BM; M = M_all; W = W_all;
-    if (!PERSIST && groups.counts != nullptr) {
+    if (groups.counts != nullptr) {
       int t = tm, g = 0;
       int64_t off = 0;
       for (; g < groups.n_groups; ++g) {
@@ -154,9 +156,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   //      W_h, LDS row p  <->  tile row wrow(p>>5, 2h + ((p>>4)&1)) + (p&15)   (fragments 2h, 2h+1 of each of the 4 wave columns)
   const uint16_t* src[4][2];
   auto set_src = [&](int h, int64_t tm0, int64_t tM, const uint16_t* tW, int tn0) {     // sources of A_h and W_h of the tile at (tm0, tn0)
-    int ln = lane;
-    if (PERSIST) asm volatile("" : "+v"(ln));                  // recomputed per tile from the lane id: nothing of this is kept in
-                                                               // registers across the K loop (the compiler would hoist and spill)
+    const int ln = lane;
     const int srow = ln >> 3;                                  // row inside the 8-row chunk
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       const int slot = (ln & 7) ^ ((p >> 1) & 7);              // logical 16-B slot held by this physical slot
       const int ra = (p >> 6) * 128 + h * 64 + (p & 63);
       int64_t gm_row = tm0 + ra; if (gm_row > tM - 1) gm_row = tM - 1;
-      if (!PERSIST && groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
+      if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
       src[h][c] = A + gm_row * lda + slot * 8;
       const int rw = wrow_of<ROPE>(p >> 5, 2 * h + ((p >> 4) & 1)) + (p & 15);
       int gn_row = tn0 + rw; if (gn_row > N - 1) gn_row = N - 1;
@@ -236,9 +236,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // before the first barrier of the previous phase.  Phase 4 has no fragments of its own to read (W_h0 stays in registers), so it
   // reads the NEXT K-tile's W_h0 instead: LDS reads per phase 8 / 4 / 8 / 4.
   // k31 / k20: K-tile index of the half-tiles staged in phases 1,2 (W_h1, A_h1 of K-tile t+1) and 3,4 (W_h0, A_h0 of K-tile t+2).
-  auto ktile = [&](int64_t k31, int64_t k20, auto bufc, auto lastc) {
+  auto ktile = [&](int64_t k31, int64_t k20, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    constexpr bool LAST = decltype(lastc)::value;       // last K-tile of an output tile (PERSIST): W_h0 of the next tile is read after the epilogue
     const char* sb = smem + BUF * STAGE_BYTES;
     const char* sbn = smem + (BUF ^ 1) * STAGE_BYTES;
     // phase 1: quadrant (A_h0, W_h0)
@@ -263,17 +262,15 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     GRIT_MMA(wf1, 4, 2);
     GRIT_BARRIER();
     // phase 4: quadrant (A_h1, W_h0); W_h0 of the next K-tile -> the other buffer's fragment registers
-    if (!LAST) GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
+    GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
     stage(0, BUF, k20);
-    GRIT_LSEG_END(LAST ? 0 : 4);                 // A_h0(t+1) landed (read in phase 1 of the next K-tile)
+    GRIT_LSEG_END(4);                 // A_h0(t+1) landed (read in phase 1 of the next K-tile)
     GRIT_BARRIER();
     GRIT_MMA(wf0[BUF], 4, 0);
     GRIT_BARRIER();
   };
   const std::integral_constant<int, 0> B0{};
   const std::integral_constant<int, 1> B1{};
-  const std::false_type MID{};
-  const std::true_type END{};
   auto kclamp = [&](int kt) { return (int64_t)(kt < nk ? kt : nk - 1); };        // past the end: re-stage the last K-tile (nobody reads it)
 
   stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(2, 1, kclamp(1)); stage(0, 1, kclamp(1));
@@ -285,18 +282,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
   auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
   auto epilogue = [&](int64_t m0, int64_t M, int n0) {
-  int ln_e = lane;
-  if (PERSIST) asm volatile("" : "+v"(ln_e));               // per-lane output coordinates are rebuilt per tile, not carried through the K loop
-  const int frow = ln_e & 15, kq = ln_e >> 4;
   const int64_t mrow = m0 + wr * 128 + frow;
   const int ncol = n0 + wc * 64 + kq * 4;
-  // The 8 row blocks of the lane go out in batches of RB: all table / residual loads of a batch are issued up front, so the epilogue pays
-  // one memory latency per batch.  One workgroup per tile: one batch (the K loop's registers are dead).  PERSIST: the K loop's state
-  // stays live across the epilogue, smaller batches keep it out of scratch memory.
-  constexpr int RB = !PERSIST ? 8 : (ROPE ? 2 : (EPI == GRIT_EPI_RESIDUAL ? 4 : 8));
-#pragma unroll
-  for (int ib = 0; ib < 8; ib += RB) {
-  if (PERSIST) __builtin_amdgcn_sched_barrier(0);
+  // all table / residual loads of the lane's 8 row blocks are issued up front (the K loop's registers are dead by now): the epilogue
+  // pays one memory latency instead of one per row block
+  constexpr int RB = 8, ib = 0;
+  {
   if constexpr (ROPE) {
     if (n0 + (wc >> 1) * 128 < rope.rope_cols) {        // this wave's head is a q or k head (uniform per wave)
       const int m0_mod = (int)(m0 % rope.S);              // block-uniform: the only 64-bit division
@@ -427,43 +418,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   }
   };
 
-  if constexpr (!PERSIST) {
-    for (int kt = 0; kt < nk; kt += 2) {
-      ktile(kclamp(kt + 1), kclamp(kt + 2), B0, MID);
-      if (kt + 1 < nk) ktile(kclamp(kt + 2), kclamp(kt + 3), B1, MID);
-    }
-    if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
-    GRIT_SEG_FENCE();
-    epilogue(m0, M, n0);
-  } else {
-    // One workgroup per CU walks its tiles with the K-tile stream running THROUGH the tile boundaries: the last two K-tiles of an
-    // output tile stage the first half-tiles of the next one (they would otherwise re-stage dead data), so the LDS-DMA pipeline never
-    // drains and the next tile's first MFMAs wait for nothing but this tile's epilogue.  (nk even and >= 4: the host guarantees it.)
-    for (;;) {
-      for (int kt = 0; kt < nk - 2; kt += 2) {
-        ktile(kt + 1, kt + 2, B0, MID);
-        ktile(kt + 2, kt + 3, B1, MID);
-      }
-      int64_t m0n = m0, Mn = M;
-      const uint16_t* Wn = W;
-      int n0n = n0;
-      const int vnext = vtile + (int)gridDim.x;
-      const bool more = vnext < n_virtual && tile_of(vnext, m0n, Mn, Wn, n0n);     // no next tile: re-stage this one (harmless)
-      set_src(0, m0n, Mn, Wn, n0n);                        // W_h0 / A_h0 of the current tile were last staged two K-tiles ago
-      ktile(nk - 1, 0, B0, MID);
-      set_src(1, m0n, Mn, Wn, n0n);
-      ktile(0, 1, B1, END);
-      epilogue(m0, M, n0);
-      if (!more) break;
-      zero_acc();
-      GRIT_READ_W(wf0[0], 0, smem);                        // W_h0(0) of the next tile: landed before the last K-tile's phase-3 barrier
-      vtile = vnext; m0 = m0n; M = Mn; W = Wn; n0 = n0n;
-    }
-    if (wr == 0) GRIT_BARRIER();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GRIT_SEG_FENCE();
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(kclamp(kt + 1), kclamp(kt + 2), B0);
+    if (kt + 1 < nk) ktile(kclamp(kt + 2), kclamp(kt + 3), B1);
   }
+  if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
+  GRIT_SEG_FENCE();
+  epilogue(m0, M, n0);
 #undef GRIT_READ_W
 #undef GRIT_READ_X
 #undef GRIT_MMA
@@ -472,9 +434,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 
 // Launch knobs for A/B runs (read once, thread-safe static initialisation): GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4:
 // 4 m x 8 n tiles in flight per XCD), GRIT_GEMM_NOREMAP=1 disables the XCD remap, GRIT_GEMM_RR=1 deals tile groups round-robin to the
-// XCDs for dense launches too (default: grouped launches only), GRIT_GEMM_NOPERSIST=1 always launches one workgroup per tile.
+// XCDs for dense launches too (default: grouped launches only).
 struct GemmKnobs {
-  int gm, remap, rr_all, persist;
+  int gm, remap, rr_all;
 };
 static const GemmKnobs& gemm_knobs() {
   static const GemmKnobs k = [] {
@@ -483,23 +445,9 @@ static const GemmKnobs& gemm_knobs() {
     v.gm = (e && atoi(e) > 0) ? atoi(e) : 4;
     v.remap = getenv("GRIT_GEMM_NOREMAP") ? 0 : 1;
     v.rr_all = getenv("GRIT_GEMM_RR") ? 1 : 0;
-    v.persist = getenv("GRIT_GEMM_NOPERSIST") ? 0 : 1;
     return v;
   }();
   return k;
-}
-
-static int device_cu_count() {
-  static std::atomic<int> cached[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int v = cached[dev & 63].load(std::memory_order_relaxed);
-  if (v == 0) {
-    (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-    if (v <= 0) v = 256;
-    cached[dev & 63].store(v, std::memory_order_relaxed);
-  }
-  return v;
 }
 
 // the 128 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
@@ -519,25 +467,16 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
                        int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0},
                        GemmRope rope = GemmRope{nullptr, nullptr, nullptr, 0, 0}) {
   const int tiles_m = grp.counts ? (int)(M / BM) + grp.n_groups : (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
-  static std::atomic<uint64_t> optin{0}, optin_p{0};
+  static std::atomic<uint64_t> optin{0};
   const GemmKnobs& kn = gemm_knobs();
   // grouped launches: round-robin tile groups over the XCDs (remap 2) on a grid rounded up to 8 x whole groups
   const int total_groups = (tiles_m + kn.gm - 1) / kn.gm;
   const bool rr = (grp.counts || kn.rr_all) && kn.remap;
   const unsigned nblocks = rr ? (unsigned)(8 * ((total_groups + 7) / 8) * kn.gm * tiles_n) : (unsigned)(tiles_m * tiles_n);
   const int remap_mode = rr ? 2 : kn.remap;
-  // persistent form (one workgroup per CU, the K-tile stream runs through the tile boundaries): dense launches with an even number
-  // (>= 4) of K-tiles and more tiles than CUs; everything else takes one workgroup per tile
-  const int n_cu = device_cu_count();
-  if (kn.persist && !rr && grp.counts == nullptr && (K / BK) % 2 == 0 && K / BK >= 4 && (int64_t)tiles_m * tiles_n > n_cu && n_cu % 8 == 0) {
-    ensure_lds_optin(gemm_bf16_nt_k<EPI, true>, optin_p);
-    hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, true>), dim3((unsigned)n_cu), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
-                       (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
-  } else {
-    ensure_lds_optin(gemm_bf16_nt_k<EPI, false>, optin);
-    hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
-                       (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
-  }
+  ensure_lds_optin(gemm_bf16_nt_k<EPI>, optin);
+  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
+                     (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
   GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt");
   return GRIT_OK;
 }
