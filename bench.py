@@ -85,6 +85,32 @@ def cpu_baseline_numpy(sample_docs=1, seq=SEQ, layers=32):
             "seconds": dt}
 
 
+def vendor_gemm_comparator(dev, M=DOCS * SEQ):
+    """hipBLASLt (`torch.matmul`, plain GEMM without the fused RoPE / residual / SwiGLU epilogues) on the model's four GEMM shapes, same
+    GPU, same run, random bf16 operands: context for `roofline.achieved` (the chip is power-limited on random data)."""
+    out, tot_f, tot_t = {}, 0.0, 0.0
+    for name, (N, K) in {"qkv": (6144, 4096), "o_proj": (4096, 4096), "gate_up": (28672, 4096), "down": (4096, 14336)}.items():
+        a = torch.randn((M, K), device=dev, dtype=torch.float32).to(torch.bfloat16)
+        w = (torch.randn((N, K), device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        wt = w.t()
+        for _ in range(2):
+            c = a @ wt
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            c = a @ wt
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        fl = 2.0 * M * N * K
+        out[name] = fl / (ms * 1e-3) / 1e12
+        tot_f += fl; tot_t += ms * 1e-3
+        del a, w, wt, c
+    torch.cuda.empty_cache()
+    out["flop_weighted"] = tot_f / tot_t / 1e12
+    return out
+
+
 def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, steps=1, warmup=1, ragged_pairs=32):
     """Second headline metric: contrastive pairs/s on BASELINE configs[2] as stated -- per rank 256 queries + 2048 passages
     (1 positive + 7 negatives each) @ seq512, GradCache chunk 32 (scripts/training/train_gritlm_7b.sh:60-67; gritlm/training/run.py:93-104).
@@ -268,6 +294,12 @@ def main():
 
     del eng, emb
     torch.cuda.empty_cache()
+    vendor = None
+    if world == 1 and not args.no_torch_baseline:
+        try:
+            vendor = vendor_gemm_comparator(dev)
+        except Exception as e:  # noqa: BLE001
+            vendor = {"error": repr(e)[:200]}
     torch_baseline = None
     if world == 1 and not args.no_torch_baseline:
         try:
@@ -313,6 +345,8 @@ def main():
             "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                             "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()},
         }
+        if vendor is not None:
+            line["roofline"]["vendor_gemm_tflops_same_shapes_no_epilogue"] = vendor
         if ragged is not None:
             line["ragged_batch"] = ragged
         if contrastive is not None:
