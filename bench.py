@@ -309,15 +309,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             torch_baseline = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
-    contrastive = None
-    if not args.no_contrastive:
-        torch.cuda.reset_peak_memory_stats()
-        try:
-            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, chunk=args.chunk, steps=args.contrastive_steps,
-                                          ragged_pairs=0 if args.no_ragged else 32)
-        except Exception as e:  # noqa: BLE001  -- never lose the primary metric line to the secondary leg
-            contrastive = {"error": repr(e)[:300]}
-
+    line = None
     if rank == 0:
         ks = timer.summary()
         g = ks["gemm_bf16_nt"]
@@ -345,6 +337,34 @@ def main():
             "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
                             "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()},
         }
+    # N > 1: the contrastive leg is the only part with data-path collectives.  If a rank dies or stalls inside it the others would sit in a
+    # collective until the RCCL watchdog aborts the job and the primary line would be lost: a deadline thread on every rank prints the
+    # primary line (with the leg marked as timed out) and exits the process cleanly instead.
+    guard, emitted = None, []
+    if world > 1 and not args.no_contrastive:
+        import threading
+        guard = threading.Event()
+
+        def _deadline(ev=guard, budget=float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "480"))):
+            if not ev.wait(budget):
+                if rank == 0 and not emitted:
+                    if ragged is not None:
+                        line["ragged_batch"] = ragged
+                    line["contrastive"] = {"error": f"contrastive leg exceeded {budget:.0f} s on {world} ranks; primary line emitted by the deadline guard"}
+                    line["collectives"] = {"backend": "nccl", "ranks": world, "encode_data_path_collectives": 0}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        threading.Thread(target=_deadline, daemon=True).start()
+    contrastive = None
+    if not args.no_contrastive:
+        torch.cuda.reset_peak_memory_stats()
+        try:
+            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, chunk=args.chunk, steps=args.contrastive_steps,
+                                          ragged_pairs=0 if args.no_ragged else 32)
+        except Exception as e:  # noqa: BLE001  -- never lose the primary metric line to the secondary leg
+            contrastive = {"error": repr(e)[:300]}
+
+    if rank == 0:
         if vendor is not None:
             line["roofline"]["vendor_gemm_tflops_same_shapes_no_epilogue"] = vendor
         if ragged is not None:
@@ -364,8 +384,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline_numpy_oracle"] = cpu_baseline_numpy()
         print(json.dumps(line), flush=True)
+        emitted.append(True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()          # still under the deadline guard: a rank that never arrives cannot wedge the job
+    if guard is not None:
+        guard.set()
 
 
 if __name__ == "__main__":

@@ -4,7 +4,11 @@
 // scripts/modeling_mistral_gritlm.py (:182-191, :1017-1036, :690-698).  No repeat_kv copy (the kv head is
 // index arithmetic), no mask tensor (one uint64 per 64 keys), no S x S score matrix.
 //
-// Structure: one 256-thread workgroup = 128 query rows of one (batch, head); each wave owns 32 rows; two workgroups per CU.
+// Structure: one 256-thread workgroup walks up to `qpw` consecutive 128-row query blocks of one (batch, head); each wave owns 32 rows of
+// a block; two workgroups per CU.  The K/V tile stream runs THROUGH the block seams (the first tile of the next block is staged, and
+// its Q rows are fetched into the same registers, under the last tile of the current one), so the per-block prologue (Q + first-tile latency) is paid once
+// per workgroup and the output stores of a block drain under the next block's first tile.  Workgroups that share K/V (the GQA
+// group's heads x query-block groups of one (batch, kv head)) are dealt to the SAME XCD back to back (block v runs on XCD v % 8).
 // KV tiles of 64 keys go HBM -> LDS by direct LDS-DMA (global_load_lds, 16 B per lane, 1 KiB = 4 key rows per wave instruction) into
 // a two-stage ring: the DMA of tile t+1 is issued right after the single barrier of tile t and lands under tile t's MFMAs and
 // softmax -- no staging registers, no ds_write pass, one barrier per tile.  Both images are row-major [key][256 B] with the 16-byte
@@ -18,7 +22,25 @@
 // permlane/LDS round trip: the MFMA contraction index is permuted identically on the V^T side
 // (key(kb,c,hi,j) = 32kb + 16c + 8(j>>2) + 4hi + (j&3)): two transposing 8-byte LDS reads whose per-lane
 // addresses select exactly those keys.
+#include <stdlib.h>
+
+#include <atomic>
+
 #include "common.h"
+
+// s_waitcnt vmcnt(0) through the builtin (gfx9 encoding: expcnt 7, lgkmcnt 15 = "don't wait"): unlike an asm statement the waitcnt
+// insertion pass SEES it, so it does not add its own vmcnt(0) in front of the first MFMA that reads the re-fetched Q registers -- that
+// wait would sit behind the freshly issued DMA of the next tile and serialise it
+#define ATT_WAIT_VM0()                      \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_waitcnt(0x0F70);     \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+
+#ifndef ATT_DEFER_MAX
+#define ATT_DEFER_MAX 1
+#endif
 
 namespace grit {
 
@@ -29,6 +51,8 @@ constexpr int V_PITCH = 256;  // bytes per key row of the row-major V image
 constexpr int K_LDS_BYTES = ATT_KB * ATT_D * 2;  // 16384
 constexpr int V_LDS_BYTES = ATT_KB * V_PITCH;    // 16384
 constexpr int ATT_STAGE_BYTES = K_LDS_BYTES + V_LDS_BYTES;   // 32 KiB per stage, two stages
+constexpr int ATT_XPOSE_BYTES = 4096;                         // per wave: 32 rows x 128 B, the Q-in / O-out transposition buffer
+constexpr int ATT_LDS_BYTES = 2 * ATT_STAGE_BYTES + 4 * ATT_XPOSE_BYTES;   // 80 KiB: two workgroups fill the CU's 160 KiB exactly
 typedef const __attribute__((address_space(1))) void* att_gptr_t;
 typedef __attribute__((address_space(3))) void* att_lptr_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -44,55 +68,43 @@ template <bool VARLEN, bool CAUSAL>
 __global__ void __launch_bounds__(256, 2)
 attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                  uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride,
-                 int64_t out_stride, float scale_log2) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE_BYTES];
+                 int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int hk = h / (nq / nkv);
+  // XCD-aware decode: the k-th workgroup of XCD x belongs to K/V set (k / U) * 8 + x, U = (heads per kv head) x (query-block groups)
+  const int gqa = nq / nkv, U = gqa * ngx;
+  const int kx = (int)blockIdx.x >> 3;
+  const int set = (kx / U) * 8 + ((int)blockIdx.x & 7), member = kx % U;
+  if (set >= n_sets) return;
+  const int b = set / nkv, hk = set - b * nkv;
+  const int h = hk * gqa + member % gqa;
+  const int qb_first = (member / gqa) * qpw;
   int S = S_arg;
   int64_t row0 = (int64_t)b * S_arg;
-  int ntiles = 0;
-  const uint64_t* bits = nullptr;
   if constexpr (VARLEN) {
     row0 = cu_seqlens[b];
     S = cu_seqlens[b + 1] - cu_seqlens[b];
-    if (qb * ATT_QB >= S) return;              // uniform per workgroup
-    ntiles = (S + 63) >> 6;
-  } else {
-    const int W = (S + 63) >> 6;
-    bits = key_bits + (int64_t)b * W;
-    // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
-    for (int w = W - 1; w >= 0; --w)
-      if (bits[w] != 0) { ntiles = w + 1; break; }
   }
+  if (qb_first * ATT_QB >= S) return;            // uniform per workgroup
+  const int nqb = (S + ATT_QB - 1) / ATT_QB;
+  const int nblk = (nqb - qb_first) < qpw ? (nqb - qb_first) : qpw;
 
-  if constexpr (CAUSAL) {
-    const int lim = 2 * qb + 2;                 // tiles holding keys <= the last query of this workgroup
-    ntiles = ntiles < lim ? ntiles : lim;
-  }
-
-  const uint16_t* qbase = qkv + (int64_t)h * ATT_D;
-  const uint16_t* kbase = qkv + (int64_t)(nq + hk) * ATT_D;
-  const uint16_t* vbase = qkv + (int64_t)(nq + nkv + hk) * ATT_D;
+  // Global addressing = workgroup-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit per-lane pointers to keep
+  // alive (or spill) around the tile loop.  The launcher guarantees rows * stride * 2 < 2^31.
+  const char* q_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)h * ATT_D);
+  const char* k_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + hk) * ATT_D);
+  const char* v_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + nkv + hk) * ATT_D);
+  char* o_base = reinterpret_cast<char*>(out + row0 * out_stride + (int64_t)h * ATT_D);
+  const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
 
   const int ql = lane & 31, hi = lane >> 5;
-  const int q_row = qb * ATT_QB + wave * 32 + ql;
-  const int q_ld = q_row < S ? q_row : S - 1;
-
-  // ---- Q fragments (B operand): lane holds Q[q][16ks + 8hi .. +8]
-  bf16x8_t qf[8];
-  {
-    const uint16_t* qp = qbase + (row0 + q_ld) * qkv_stride + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-  }
 
   // ---- LDS-DMA roles: wave w stages keys 16w .. 16w+15 of a tile, four 1-KiB instructions for K and four for V (4 keys each);
   //      lane -> key 16w + 4i + (lane>>4), physical 16-byte unit lane&15, which holds the LOGICAL unit (lane&15) ^ swizzle(key)
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int st_key = 16 * wv + (lane >> 4);                                     // + 4i
-  const int v_unit = (lane & 15) ^ (4 * ((lane >> 4) & 3));                     // V: unit ^= 4 (key & 3); key & 3 == (lane>>4) & 3
+  const uint32_t v_unit_b = (uint32_t)(((lane & 15) ^ (4 * ((lane >> 4) & 3))) << 4);   // V: unit ^= 4 (key & 3); key & 3 == (lane>>4) & 3
   auto stage_tile = [&](int t, int buf) {
     char* kdst = smem + buf * ATT_STAGE_BYTES + wv * 4096;
     char* vdst = kdst + K_LDS_BYTES;
@@ -100,19 +112,67 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     for (int i = 0; i < 4; ++i) {
       int key = t * ATT_KB + st_key + 4 * i;
       key = key < S ? key : S - 1;
-      const int k_unit = (lane & 15) ^ ((4 * i + (lane >> 4)) & 15);           // K: unit ^= key & 15
-      const uint16_t* rowp = qkv + (row0 + key) * qkv_stride;
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(rowp + (int64_t)(nq + hk) * ATT_D + k_unit * 8), (att_lptr_t)(kdst + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(rowp + (int64_t)(nq + nkv + hk) * ATT_D + v_unit * 8), (att_lptr_t)(vdst + i * 1024), 16, 0, 0);
+      const uint32_t k_unit_b = (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);   // K: unit ^= key & 15
+      const uint32_t row_b = (uint32_t)key * qkv_stride_b;
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(k_base + (row_b + k_unit_b)), (att_lptr_t)(kdst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (row_b + v_unit_b)), (att_lptr_t)(vdst + i * 1024), 16, 0, 0);
     }
   };
+  // the first tile's DMA goes out before anything else (tile 0 always exists: S > 0)
+  stage_tile(0, 0);
 
-  f32x16_t oacc[4];
+  // ---- Q fragments (B operand): lane holds Q[q][16ks + 8hi .. +8] of query block qb.  A row-per-lane global load touches 32 rows x 32 B
+  //      per instruction (measured: the per-block Q fetch + O store in that shape cost 18 % of the kernel at S = 512), so Q comes
+  //      in through the wave's private 4 KiB transposition buffer instead, one 64-column half (32 rows x 128 B) at a time: LDS-DMA of
+  //      whole 128-byte row segments (4 instructions x 8 rows, 16-byte units swizzled by (row>>1)&7), then ds_read_b128 of the half's
+  //      four k-slices.
+  bf16x8_t qf[8];
+  char* xs = smem + 2 * ATT_STAGE_BYTES + wv * ATT_XPOSE_BYTES;
+  const int q_swz = (ql >> 1) & 7;                                               // swizzle of the lane's own row
+  // (per-block address arithmetic is recomputed from a laundered lane id where it is used: hoisted to kernel entry it would be spilled
+  //  around the tile loop, and a scratch reload's vmcnt wait would sit in front of the hand-placed DMA)
+  auto q_stage_half = [&](int qb, int half) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;                                  // row (+ 8j) and physical unit of a DMA piece
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+    for (int j = 0; j < 4; ++j) {
+      const int r = 8 * j + x_row;
+      int qr = qb * ATT_QB + wave * 32 + r;
+      qr = qr < S ? qr : S - 1;
+      const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);   // logical unit held by physical unit x_unit of row r
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, 0);
+    }
+  };
+  auto q_read_half = [&](int half) {
+    const char* rp = xs + ql * 128;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int ks = 0; ks < 4; ++ks) qf[half * 4 + ks] = *reinterpret_cast<const bf16x8_t*>(rp + (((2 * ks + hi) ^ q_swz) << 4));
+    // the reads must have left the buffer before it is refilled (DMA) or rewritten (O staging)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                           // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+  };
+  // the workgroup's FIRST block takes its Q rows straight from global memory (row-per-lane loads, one round trip that overlaps the
+  // first tile's DMA; two dependent passes through the 4 KiB buffer would put two memory latencies in front of the first product)
+  {
+    const int qr0 = qb_first * ATT_QB + wave * 32 + ql;
+    const char* qp = q_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+  }
+
+  // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
+  int ntiles_all = 0;
+  const uint64_t* bits = nullptr;
+  if constexpr (VARLEN) {
+    ntiles_all = (S + 63) >> 6;
+  } else {
+    const int W = (S + 63) >> 6;
+    bits = key_bits + (int64_t)b * W;
+    for (int w = W - 1; w >= 0; --w)
+      if (bits[w] != 0) { ntiles_all = w + 1; break; }
+  }
 
   // K fragment address: row = 32kb + (lane&31), d-slot = 2ks + hi, swizzle by row&15 == lane&15
   const int kf_row = ql * 256, kf_x = lane & 15;
@@ -123,135 +183,222 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   // vt_lane carries r in byte bits 7:6 and the read address of d-block db is vt_lane ^ (db << 6)
   const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + ((((lane >> 2) & 3) * 4) << 4) + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
 
-  if (ntiles > 0) stage_tile(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
-    // tile t has landed (this wave's share: vmcnt; everybody's: the barrier) and every wave is done reading the other stage
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t + 1 < ntiles) stage_tile(t + 1, (t + 1) & 1);
-    const char* k_lds = smem + (t & 1) * ATT_STAGE_BYTES;
-    const char* v_lds = k_lds + K_LDS_BYTES;
-
-    // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
-    f32x16_t sacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + kb * 32 * 256 + kf_row + (((2 * ks + hi) ^ kf_x) << 4));
-        // the first product takes the constant 0 as its accumulator input (an inline operand: no 16 v_mov per chain)
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
-      }
-    }
-
-    // ---- mask + online softmax (all lane-local except one exchange with lane^32)
-    uint64_t word;
-    if constexpr (VARLEN) {
-      const int rem = S - t * ATT_KB;
-      word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-    } else {
-      word = bits[t];
-    }
-    bool fast = (word == ~0ull);
+  int gt = 0;                                   // tiles consumed so far by this workgroup: tile g lives in stage g & 1
+  ATT_WAIT_VM0();                               // first tile + first Q rows
+  for (int qi = 0; qi < nblk; ++qi) {
+    const int qb = qb_first + qi;
+    const int q_row = qb * ATT_QB + wave * 32 + ql;
+    int ntiles = ntiles_all;
     if constexpr (CAUSAL) {
-      if (t * ATT_KB + ATT_KB - 1 > qb * ATT_QB + wave * 32) {   // tile reaches past this wave's first query: per-lane bound
-        const int n = q_row - t * ATT_KB + 1;                    // keys of this tile the lane's query may see
-        word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
-        fast = false;
-      }
+      const int lim = 2 * qb + 2;               // tiles holding keys <= the last query of this block
+      ntiles = ntiles < lim ? ntiles : lim;
     }
-    float mx = -INFINITY;
-    if (fast) {                   // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-    } else {
-      const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const uint32_t wsel = kb ? whi : wlo;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kbit = (r & 3) + 8 * (r >> 2);  // key within the 32-block, minus 4*hi (already shifted)
-          const float s = ((wsel >> kbit) & 1u) ? sacc[kb][r] : -INFINITY;
-          sacc[kb][r] = s;
-          mx = fmaxf(mx, s);
-        }
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with the scaling
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
-    m_run = m_new;
-    float psum = 0.f;
-    bf16x8_t pb[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        uint32_t pk[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          // exp2(s*scale - m): one fma + one v_exp per score (masked scores are -inf -> 0)
-          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj], scale_log2, -m_use));
-          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj + 1], scale_log2, -m_use));
-          psum += p0 + p1;
-          pk[jj] = pack2bf_hw(p0, p1);
-        }
-        pb[kb][c] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
-      }
-    l_run = l_run * alpha + psum;
+    const bool more = qi + 1 < nblk;
+
+    f32x16_t oacc[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
 
-    // ---- O^T += V^T P^T
+    for (int t = 0; t < ntiles; ++t, ++gt) {
+      // tile t has landed (this wave's share: vmcnt; everybody's: the barrier) and every wave is done reading the other stage.  The
+      // first tile of a block was waited for before the block loop / at the seam (before the previous block stored its output:
+      // vmcnt counts stores, and the stores should drain under this tile, not in front of it).
+      if (t > 0) ATT_WAIT_VM0();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + 1 < ntiles) {
+        stage_tile(t + 1, (gt + 1) & 1);
+      } else if (more) {                        // the stream runs through the block seam: next block's first tile
+        stage_tile(0, (gt + 1) & 1);
+      }
+      // next block's Q, first 64 columns: fetched a whole tile ahead (the buffer is idle), so the wait at the top of the last tile
+      // already covers it
+      if (more && t + 2 == ntiles) q_stage_half(qb + 1, 0);
+      const char* k_lds = smem + (gt & 1) * ATT_STAGE_BYTES;
+      const char* v_lds = k_lds + K_LDS_BYTES;
+
+      // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
+      f32x16_t sacc[2];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
+      for (int kb = 0; kb < 2; ++kb) {
+        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + kb * 32 * 256 + kf_row + (((2 * ks + hi) ^ kf_x) << 4));
+          // the first product takes the constant 0 as its accumulator input (an inline operand: no 16 v_mov per chain)
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
+        }
+      }
+
+      // the next block's Q rows replace this block's as soon as its last QK product has read them: the fetch lands under the
+      // softmax and PV of the last tile, no second register set
+      const bool q_next = more && t + 1 == ntiles;
+      if (q_next) {                 // this block's last QK products have read qf: refill it for the next block
+        if (ntiles == 1) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); }
+        q_read_half(0);
+        q_stage_half(qb + 1, 1);    // the other 64 columns land under the softmax and the PV products
+      }
+
+      // ---- mask + online softmax (all lane-local except one exchange with lane^32)
+      uint64_t word;
+      if constexpr (VARLEN) {
+        const int rem = S - t * ATT_KB;
+        word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+      } else {
+        word = bits[t];
+      }
+      bool fast = (word == ~0ull);
+      if constexpr (CAUSAL) {
+        if (t * ATT_KB + ATT_KB - 1 > qb * ATT_QB + wave * 32) {   // tile reaches past this wave's first query: per-lane bound
+          const int n = q_row - t * ATT_KB + 1;                    // keys of this tile the lane's query may see
+          word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+          fast = false;
+        }
+      }
+      float mx = -INFINITY;
+      if (fast) {                   // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+      } else {
+        const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const uint32_t wsel = kb ? whi : wlo;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kbit = (r & 3) + 8 * (r >> 2);  // key within the 32-block, minus 4*hi (already shifted)
+            const float s = ((wsel >> kbit) & 1u) ? sacc[kb][r] : -INFINITY;
+            sacc[kb][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with the scaling
+      const float m_new = fmaxf(m_run, mx);
+#if ATT_DEFER_MAX
+      // deferred rescale: as long as no row's maximum grows by more than 2^8 the wave keeps its old reference maxima (P <= 256, exact
+      // in the bf16 exponent range; l and O stay consistent with m_run) and skips the 64 accumulator multiplies + exp2 of the rescale
+      const bool grow = !(m_new - m_run <= 8.0f);                 // also true for m_run = -inf (first tile, or all keys masked so far)
+      if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+        const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);  // m_run = -inf -> 0
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
+      const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+#else
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+      m_run = m_new;
+#endif
+      float psum = 0.f;
+      bf16x8_t pb[2][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const char* vp = v_lds + (vt_lane ^ (db << 6)) + (kb * 32 + c * 16) * V_PITCH;
-          const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
-          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * V_PITCH));
-          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
+          uint32_t pk[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            // exp2(s*scale - m): one fma + one v_exp per score (masked scores are -inf -> 0)
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj], scale_log2, -m_use));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj + 1], scale_log2, -m_use));
+            psum += p0 + p1;
+            pk[jj] = pack2bf_hw(p0, p1);
+          }
+          pb[kb][c] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
         }
-    }
-  }
+#if ATT_DEFER_MAX
+      l_run += psum;
+#else
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#endif
 
-  // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  // 16-byte stores: v_permlane32_swap exchanges the two 32-lane halves of the register groups g and g+1, so that a lane ends up with
-  // 8 CONSECUTIVE dims of its row (half 0: group g, half 1: group g+1) -- 8 stores per lane instead of 16 eight-byte ones (guide T21)
-  uint4 ost[4][2];
+
+      // ---- O^T += V^T P^T
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db) {
 #pragma unroll
-    for (int gp = 0; gp < 2; ++gp) {
-      float a[4], bq[4];
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[db][8 * gp + e] * inv_l), __float_as_uint(oacc[db][8 * gp + 4 + e] * inv_l),
-                                                         false, false);
-        a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
+          for (int c = 0; c < 2; ++c) {
+            const char* vp = v_lds + (vt_lane ^ (db << 6)) + (kb * 32 + c * 16) * V_PITCH;
+            const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
+            const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * V_PITCH));
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
+          }
       }
-      ost[db][gp] = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(bq[0], bq[1]), pack2bf(bq[2], bq[3]));
     }
-  if (q_row < S) {
-    uint16_t* op = out + (row0 + q_row) * out_stride + (int64_t)h * ATT_D + 8 * hi;
+
+    // ---- block seam: the next block's first tile and Q rows (issued one tile ago) are waited for BEFORE this block's stores go out
+    ATT_WAIT_VM0();
+    if (more) q_read_half(1);
+
+    // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    // full-line stores through the transposition buffer (a row-per-lane store touches 32 lines x 32 B per instruction): one 64-column
+    // half at a time, every lane writes its 4 pieces of the half (unit ^= (row>>1)&7), then stores 16 B of an 8-row x 128-B piece
+    const int q_wave0 = qb * ATT_QB + wave * 32;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;                                  // row (+ 8j) and physical unit of a store piece
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int half = 0; half < 2; ++half) {
+      char* wp = xs + (ln & 31) * 128;
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4*>(op + db * 32 + gp * 16) = ost[db][gp];
-    if (lse != nullptr && hi == 0) {
+      for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          // v_permlane32_swap exchanges the two 32-lane halves of the register groups g and g+1, so that a lane ends up with 8
+          // CONSECUTIVE dims of its row (half 0: group g, half 1: group g+1): one 16-byte piece
+          const int db = half * 2 + dbl;
+          float a[4], bq[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[db][8 * gp + e] * inv_l),
+                                                             __float_as_uint(oacc[db][8 * gp + 4 + e] * inv_l), false, false);
+            a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
+          }
+          *reinterpret_cast<uint4*>(wp + (((dbl * 4 + gp * 2 + hi) ^ q_swz) << 4)) =
+              make_uint4(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]), pack2bf_hw(bq[0], bq[1]), pack2bf_hw(bq[2], bq[3]));
+        }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                         // lgkmcnt(0): the wave's own writes are in the buffer
+      asm volatile("" ::: "memory");
+      uint4 piece[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) piece[j] = *reinterpret_cast<const uint4*>(xs + j * 1024 + ln * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + x_row;
+        const int qr = q_wave0 + r;
+#ifdef ATT_ABLATE_STORES
+        if (qr < S && scale_log2 < -1e30f)
+#else
+        if (qr < S)
+#endif
+          *reinterpret_cast<uint4*>(o_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4))) = piece[j];
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                         // the pieces are in registers before the buffer is reused
+      asm volatile("" ::: "memory");
+    }
+    if (q_row < S && lse != nullptr && hi == 0) {
       if constexpr (VARLEN) lse[(row0 + q_row) * nq + h] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;  // [T, nq]
       else lse[((int64_t)b * nq + h) * S + q_row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
@@ -262,6 +409,48 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
 using namespace grit;
 
+// Launch geometry: query blocks per workgroup (the K/V stream runs through the block seams, so more blocks per workgroup amortise the
+// prologue) -- as many as 4 while the launch still has >= 4 workgroups per CU-slot pair -- and the XCD-aware 1-D grid.
+// the 80 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
+template <typename KernelT>
+static void attn_lds_optin(KernelT kernel, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
+template <bool VARLEN, bool CAUSAL>
+static void attn_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
+                        int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets) {
+  static std::atomic<uint64_t> optin{0};
+  attn_lds_optin(attn_bidir_fwd_k<VARLEN, CAUSAL>, optin);
+  hipLaunchKernelGGL((attn_bidir_fwd_k<VARLEN, CAUSAL>), grid, dim3(256), ATT_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
+                     out_stride, scale_log2, qpw, ngx, n_sets);
+}
+
+struct AttnGeom {
+  int qpw, ngx, n_sets;
+  unsigned grid;
+};
+static AttnGeom attn_geom(int B, int max_len, int nq, int nkv) {
+  const int nqb = (max_len + ATT_QB - 1) / ATT_QB;
+  static const int forced = getenv("GRIT_ATTN_QPW") ? atoi(getenv("GRIT_ATTN_QPW")) : 0;      // A/B knob
+  int qpw = 1;
+  for (int c = 4; c >= 1; c >>= 1)
+    if ((int64_t)B * nq * ((nqb + c - 1) / c) >= 2048 || c == 1) { qpw = c; break; }
+  if (forced > 0) qpw = forced;
+  if (qpw > nqb) qpw = nqb;
+  AttnGeom g;
+  g.qpw = qpw;
+  g.ngx = (nqb + qpw - 1) / qpw;
+  g.n_sets = B * nkv;
+  g.grid = (unsigned)(8 * ((g.n_sets + 7) / 8) * (nq / nkv) * g.ngx);
+  return g;
+}
+
 static int attn_fwd_padded(const char* name, bool causal, const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
                            int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && key_bits && out, GRIT_E_BADARG, "%s: null pointer", name);
@@ -271,14 +460,17 @@ static int attn_fwd_padded(const char* name, bool causal, const void* qkv, const
   GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "%s: bad strides", name);
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
-  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "%s: grid too large", name);
-  const dim3 grid((unsigned)((S + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
+  GRIT_REQUIRE((int64_t)B * nq * ((S + ATT_QB - 1) / ATT_QB) < (1ll << 30), GRIT_E_UNSUPPORTED, "%s: grid too large", name);
+  GRIT_REQUIRE((int64_t)S * qkv_stride * 2 < (1ll << 31) && (int64_t)S * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
+  const AttnGeom g = attn_geom(B, S, nq, nkv);
+  const dim3 grid(g.grid);
   if (causal)
-    hipLaunchKernelGGL((attn_bidir_fwd_k<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits,
-                       (const int32_t*)nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+    attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
+                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
   else
-    hipLaunchKernelGGL((attn_bidir_fwd_k<false, false>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, key_bits,
-                       (const int32_t*)nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+    attn_launch<false, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
+                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
   GRIT_CHECK_LAUNCH(name);
   return GRIT_OK;
 }
@@ -292,14 +484,17 @@ static int attn_fwd_varlen(const char* name, bool causal, const void* qkv, const
   GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "%s: bad strides", name);
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
-  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "%s: grid too large", name);
-  const dim3 grid((unsigned)((max_len + ATT_QB - 1) / ATT_QB), (unsigned)nq, (unsigned)B);
+  GRIT_REQUIRE((int64_t)B * nq * ((max_len + ATT_QB - 1) / ATT_QB) < (1ll << 30), GRIT_E_UNSUPPORTED, "%s: grid too large", name);
+  GRIT_REQUIRE((int64_t)max_len * qkv_stride * 2 < (1ll << 31) && (int64_t)max_len * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
+  const AttnGeom g = attn_geom(B, max_len, nq, nkv);
+  const dim3 grid(g.grid);
   if (causal)
-    hipLaunchKernelGGL((attn_bidir_fwd_k<true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (const uint64_t*)nullptr,
-                       cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+    attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
+                            out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
   else
-    hipLaunchKernelGGL((attn_bidir_fwd_k<true, false>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (const uint64_t*)nullptr,
-                       cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride, out_stride, scale * 1.4426950408889634f);
+    attn_launch<true, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
+                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
   GRIT_CHECK_LAUNCH(name);
   return GRIT_OK;
 }

@@ -185,6 +185,42 @@ def gen_encoder_7b_l1(batch=2, seq=512, min_len=200, seed_w=0, seed_x=777, n_pro
     np.savez_compressed(os.path.join(HERE, f"encoder_{cfg_name}.npz"), **out)
 
 
+def gen_train_7b_l1():
+    """Contrastive step (direct forward + backward, gritlm/training/model.py:168-222) of the reference at the TRUE 7B layer shape, one
+    layer, fp32 on CPU: 2 queries + 4 passages (group size 2), ragged, tau 0.02, mean pooling.  Stored: loss, reps, per-parameter
+    gradient norms and probe slices of the gradients (the full gradient of this layer is 0.9 GB)."""
+    from gritlm.training.model import GritLMTrainModel, DistributedContrastiveLoss
+    model, cfg = build_ref_model("7b-l1", 0)
+    model.train()
+    m = GritLMTrainModel.__new__(GritLMTrainModel)
+    torch.nn.Module.__init__(m)
+    wrap = torch.nn.Module(); wrap.model = model
+    m.model = wrap; m.embedding_attr = "model"; m.projection = None
+    m.normalized = True; m.pooling_method = "mean"; m.attn = "bbcc"
+    m.emb_loss_fn = DistributedContrastiveLoss(0.02, False)
+    m.gen_loss_fn = None; m.gen_add_kwargs = {}
+    qi, qm = synth.make_batch(cfg, 2, 64, 41, min_len=20)
+    pi, pm = synth.make_batch(cfg, 4, 128, 42, min_len=40)
+    out = m(query={"input_ids": torch.from_numpy(qi), "attention_mask": torch.from_numpy(qm)},
+            passage={"input_ids": torch.from_numpy(pi), "attention_mask": torch.from_numpy(pm)})
+    out.loss.backward()
+    res = dict(q_ids=qi, q_mask=qm, p_ids=pi, p_mask=pm, tau=np.float32(0.02), group=2, loss=np.float32(out.loss.item()),
+               q_reps=out.q_reps.detach().numpy(), p_reps=out.p_reps.detach().numpy())
+    for n, p in model.named_parameters():
+        g = p.grad
+        res["gnorm/" + n] = np.float32(g.norm().item())
+        if n == "embed_tokens.weight":
+            used = np.unique(np.concatenate([qi[qm > 0], pi[pm > 0]]))[:16]
+            res["probe_rows/" + n] = used
+            res["probe/" + n] = g[torch.from_numpy(used)].numpy()
+        elif g.dim() == 2:
+            res["probe/" + n] = g[:8].numpy().copy()            # first 8 rows
+        else:
+            res["probe/" + n] = g.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "train_7b-l1.npz"), **res)
+    print(f"  train 7b-l1: loss {out.loss.item():.6f}")
+
+
 def gen_pooling():
     rng = np.random.default_rng(7)
     hidden = rng.standard_normal((5, 9, 24), dtype=np.float32)
@@ -404,8 +440,10 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if sys.argv[1:] == ["generative"]:
         gen_generative(); sys.exit(0)
-    if sys.argv[1:] == ["7b-l1"]:            # only the 7B-layer-shape fixture (1.4 GB of fp32 weights, ~2 min on 8 cores)
-        gen_encoder_7b_l1(); sys.exit(0)
+    if sys.argv[1:] == ["7b-l1"]:            # only the 7B-layer-shape fixtures (1.4 GB of fp32 weights, ~2 min on 8 cores)
+        gen_encoder_7b_l1(); gen_train_7b_l1(); sys.exit(0)
+    if sys.argv[1:] == ["train-7b-l1"]:
+        gen_train_7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
         gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
         sys.exit(0)
@@ -419,4 +457,5 @@ if __name__ == "__main__":
     print("generative"); gen_generative()
     print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
     print("encoder 7b-l1"); gen_encoder_7b_l1()
+    print("train 7b-l1"); gen_train_7b_l1()
     print("done")

@@ -34,6 +34,24 @@ __global__ void count_diff(const uint32_t* a, const uint32_t* b, int64_t n, unsi
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) c += a[i] != b[i];
   if (c) atomicAdd(out, c);
 }
+__global__ void max_diff_bf16(const uint16_t* a, const uint16_t* b, int64_t n, unsigned int* out) {
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float((uint32_t)a[i] << 16), y = __uint_as_float((uint32_t)b[i] << 16);
+    const float d = fabsf(x - y);
+    m = (d == d) ? fmaxf(m, d) : 1e30f;
+  }
+  atomicMax(out, __float_as_uint(m));          // non-negative floats order like their bit patterns
+}
+__global__ void max_diff_f32(const float* a, const float* b, int64_t n, unsigned int* out) {
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (a[i] == b[i]) continue;                  // covers equal infinities
+    const float d = fabsf(a[i] - b[i]);
+    m = (d == d) ? fmaxf(m, d) : 1e30f;
+  }
+  atomicMax(out, __float_as_uint(m));
+}
 static unsigned long long run(const Lib& a, const Lib& b, int B, int S, int nq, int nkv, bool varlen, bool causal, bool ragged, bool timing) {
   const int d = 128; const int64_t stride = (int64_t)(nq + 2 * nkv) * d, ostride = (int64_t)nq * d;
   std::vector<int> lens(B);
@@ -66,6 +84,19 @@ static unsigned long long run(const Lib& a, const Lib& b, int B, int S, int nq, 
   count_diff<<<1024, 256>>>((const uint32_t*)la, (const uint32_t*)lb, nl, dc);
   CK(hipDeviceSynchronize());
   unsigned long long bad; CK(hipMemcpy(&bad, dc, 8, hipMemcpyDeviceToHost));
+  // ATTN_TOL=<x>: the two libraries may differ in rounding (e.g. deferred softmax rescale): report max |diff| of O (bf16) and LSE
+  // instead of bit equality; a pair counts as a mismatch when the O difference exceeds x
+  float dmax_o = 0.f, dmax_l = 0.f;
+  const char* tol_s = getenv("ATTN_TOL");
+  if (tol_s) {
+    unsigned int* dm; CK(hipMalloc(&dm, 8)); CK(hipMemset(dm, 0, 8));
+    max_diff_bf16<<<1024, 256>>>(oa, ob, T * ostride, dm);
+    max_diff_f32<<<1024, 256>>>(la, lb, nl, dm + 1);
+    unsigned int hm[2]; CK(hipMemcpy(hm, dm, 8, hipMemcpyDeviceToHost));
+    memcpy(&dmax_o, &hm[0], 4); memcpy(&dmax_l, &hm[1], 4);
+    (void)hipFree(dm);
+    bad = (dmax_o > atof(tol_s) || dmax_l > 1e-3f) ? 1 : 0;
+  }
   double ms[2] = {0, 0};
   if (timing) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -78,7 +109,8 @@ static unsigned long long run(const Lib& a, const Lib& b, int B, int S, int nq, 
     ms[0] /= 6; ms[1] /= 6;
   }
   double flop = 0; for (int i = 0; i < B; ++i) flop += 4.0 * nq * (double)lens[i] * lens[i] * d * (causal ? 0.5 : 1.0);
-  printf("%s%s%s B=%d S=%d nq=%d nkv=%d : %llu differing words", varlen ? "varlen " : "padded ", causal ? "causal " : "bidir ", ragged ? "ragged" : "full", B, S, nq, nkv, bad);
+  if (tol_s) printf("%s%s%s B=%d S=%d nq=%d nkv=%d : max|dO| %.3g max|dLSE| %.3g", varlen ? "varlen " : "padded ", causal ? "causal " : "bidir ", ragged ? "ragged" : "full", B, S, nq, nkv, dmax_o, dmax_l);
+  else printf("%s%s%s B=%d S=%d nq=%d nkv=%d : %llu differing words", varlen ? "varlen " : "padded ", causal ? "causal " : "bidir ", ragged ? "ragged" : "full", B, S, nq, nkv, bad);
   if (timing) printf("   old %.3f ms (%.0f TF)  new %.3f ms (%.0f TF)  speed %.3f", ms[0], flop / ms[0] / 1e9, ms[1], flop / ms[1] / 1e9, ms[0] / ms[1]);
   printf("%s\n", bad ? "  <-- MISMATCH" : "");
   (void)hipFree(qkv); (void)hipFree(oa); (void)hipFree(ob); (void)hipFree(la); (void)hipFree(lb); (void)hipFree(dbits); (void)hipFree(dcu); (void)hipFree(dc);
@@ -95,6 +127,8 @@ int main(int argc, char** argv) {
       bad += run(a, b, 3, 333, 4, 2, false, true, true, false);   bad += run(a, b, 4, 1000, 4, 1, true, true, true, false);
       bad += run(a, b, 2, 64, 2, 1, false, false, false, false);  bad += run(a, b, 3, 33, 2, 1, true, false, true, false);
       bad += run(a, b, 2, 4096, 4, 1, false, false, true, false);
+      bad += run(a, b, 9, 700, 8, 2, true, true, true, false);    bad += run(a, b, 70, 640, 32, 8, false, false, true, false);
+      bad += run(a, b, 3, 129, 8, 8, false, false, true, false);  bad += run(a, b, 11, 1536, 32, 8, true, false, true, false);
     }
   }
   if (strcmp(mode, "check")) {
@@ -102,7 +136,10 @@ int main(int argc, char** argv) {
     bad += run(a, b, 64, 2048, 32, 8, false, false, false, true);
     bad += run(a, b, 256, 512, 32, 8, true, false, true, true);
     bad += run(a, b, 64, 2048, 32, 8, false, true, false, true);
+    bad += run(a, b, 4, 8192, 32, 8, false, false, false, true);
+    bad += run(a, b, 8, 512, 32, 8, false, false, false, true);
+    bad += run(a, b, 1, 2048, 32, 8, false, false, false, true);
   }
-  printf(bad ? "RESULT: MISMATCH\n" : "RESULT: bit-identical\n");
+  printf(bad ? "RESULT: MISMATCH\n" : (getenv("ATTN_TOL") ? "RESULT: within tolerance\n" : "RESULT: bit-identical\n"));
   return bad ? 1 : 0;
 }
