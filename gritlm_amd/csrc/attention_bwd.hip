@@ -9,60 +9,118 @@
 //   attn_bwd_dkdv_k : one workgroup per (batch, kv head, 128 keys); each lane OWNS one key, K/V fragments stay in
 //                     registers, loops over the q heads of the GQA group and all query tiles;
 //   attn_bwd_dq_k   : one workgroup per (batch, q head, 128 queries); each lane OWNS one query, loops over KV tiles.
+// Both stream their 64-row tiles HBM -> LDS by direct LDS-DMA into a two-stage ring (the DMA of tile t+1 is issued right after the
+// single barrier of tile t), keep ONE row-major image per operand and read it both as row fragments and, through
+// ds_read_b64_tr_b16, as fragments of the transposed tile; gradients leave through an LDS transposition as full-line stores;
+// workgroups that share their streamed operands sit on the same XCD (block v runs on XCD v % 8).
 // As in the forward every product is arranged so that the owned index is the MFMA "column" (lane&31): the softmax
 // statistics are lane-local (dq kernel) or a broadcast LDS read (dkdv kernel), and P / dS feed the next MFMA from
 // registers with the contraction-index permutation applied on the transposed-LDS-image side.
+#include <atomic>
+
 #include "common.h"
 
 namespace grit {
 
 constexpr int AB_D = 128;
-constexpr int AB_PITCH = 136;                 // transposed image: [128 d][64 rows] bf16, 136-B row pitch
-constexpr int AB_RM = 64 * AB_D * 2;          // 16384: row-major image [64 rows][128 d], 16-B slots XOR (row&15)
-constexpr int AB_TR = AB_D * AB_PITCH;        // 17408
+constexpr int AB_IMG = 64 * 256;              // one staged tile: row-major [64 rows][256 B]
+constexpr int AB_STAGE = 2 * AB_IMG;          // two images per ring stage (Q + dO, or K + V)
+constexpr int AB_RING = 2 * AB_STAGE;         // 64 KiB
+typedef const __attribute__((address_space(1))) void* ab_gptr_t;
+typedef __attribute__((address_space(3))) void* ab_lptr_t;
+typedef __attribute__((ext_vector_type(4))) short ab_s16x4_t;
 
-__device__ __forceinline__ uint32_t lo16b(uint32_t w) { return w & 0xffffu; }
-__device__ __forceinline__ uint32_t hi16b(uint32_t w) { return w >> 16; }
+// s_waitcnt through the builtin (gfx9 encoding) so that the waitcnt insertion pass sees it (cf. attention.hip)
+#define AB_WAIT_VM0()                       \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_waitcnt(0x0F70);     \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+#define AB_SCHED_FENCE()                    \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+#define AB_WAIT_LGKM0()                     \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);     \
+    asm volatile("" ::: "memory");          \
+  } while (0)
 
-// Stage a [64 rows][128] bf16 tile (rows r0.. of `base`, clamped to row < limit) with 256 threads.
-// "pair" mapping (2 rows x 16 B per item, 2 items per thread): can write the row-major image, the transposed image, or both.
-__device__ __forceinline__ void stage_pairs(const uint16_t* __restrict__ base, int64_t stride, int r0, int limit, char* rm, char* tr) {
-  const int tid = threadIdx.x, lane32 = tid & 31, half = tid >> 5;
-  const int kp = (half & 3) * 8 + (lane32 & 7);
-  int ra = r0 + 2 * kp, rb = ra + 1;
-  ra = ra < limit ? ra : limit - 1; rb = rb < limit ? rb : limit - 1;
+// Every staged image is read BOTH as row fragments (ds_read_b128: 16 rows x one 16-byte unit per lane group) and through the
+// transposing ds_read_b64_tr_b16 (4 consecutive rows x 4 units per 32 lanes), so its 16-byte units are XOR-swizzled with
+//   g(row) = ((row & 3) << 2) | ((row >> 2) & 3)
+// -- a bijection of row & 15 (conflict-free row fragments) whose bits 3:2 enumerate 4 consecutive rows (conflict-free transposing
+// reads).  The image of an LDS-DMA is lane-linear, so the swizzle goes into the per-lane SOURCE address.
+//
+// Stage rows r0 .. r0+63 (clamped to < limit) of a [rows][stride] bf16 matrix, 128 columns from `base`: wave w fills rows 16w..16w+15
+// with four 1-KiB instructions (4 rows x 256 B each).
+__device__ __forceinline__ void stage_img(const char* base, uint32_t stride_b, int r0, int limit, char* img, int wv, int lane) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int dg = (half >> 2) * 4 + (lane32 >> 3) + 8 * it;
-    const uint4 a = *reinterpret_cast<const uint4*>(base + (int64_t)ra * stride + dg * 8);
-    const uint4 c = *reinterpret_cast<const uint4*>(base + (int64_t)rb * stride + dg * 8);
-    if (rm != nullptr) {
-      const int row = 2 * kp;
-      *reinterpret_cast<uint4*>(rm + row * 256 + ((dg ^ (row & 15)) << 4)) = a;
-      *reinterpret_cast<uint4*>(rm + (row + 1) * 256 + ((dg ^ ((row + 1) & 15)) << 4)) = c;
-    }
-    if (tr != nullptr) {
-      uint32_t* dst = reinterpret_cast<uint32_t*>(tr + (dg * 8) * AB_PITCH + kp * 4);
-      constexpr int P4 = AB_PITCH / 4;
-      dst[0 * P4] = lo16b(a.x) | (lo16b(c.x) << 16); dst[1 * P4] = hi16b(a.x) | (hi16b(c.x) << 16);
-      dst[2 * P4] = lo16b(a.y) | (lo16b(c.y) << 16); dst[3 * P4] = hi16b(a.y) | (hi16b(c.y) << 16);
-      dst[4 * P4] = lo16b(a.z) | (lo16b(c.z) << 16); dst[5 * P4] = hi16b(a.z) | (hi16b(c.z) << 16);
-      dst[6 * P4] = lo16b(a.w) | (lo16b(c.w) << 16); dst[7 * P4] = hi16b(a.w) | (hi16b(c.w) << 16);
-    }
+  for (int i = 0; i < 4; ++i) {
+    int row = r0 + 16 * wv + 4 * i + (lane >> 4);
+    row = row < limit ? row : limit - 1;
+    const uint32_t unit = (uint32_t)((lane & 15) ^ ((((lane >> 4) & 3) << 2) | i));     // g(16w + 4i + (lane>>4))
+    __builtin_amdgcn_global_load_lds((ab_gptr_t)(base + ((uint32_t)row * stride_b + (unit << 4))), (ab_lptr_t)(img + (16 * wv + 4 * i) * 256), 16, 0, 0);
   }
 }
-
-// A-operand fragment from a row-major image: A[row = rb*32 + (lane&31)][k = 16ks + 8hi + j]
-__device__ __forceinline__ bf16x8_t frag_rm(const char* rm, int rb, int ks, int lane) {
+// A-operand fragment from the row-major image: A[row = rb*32 + (lane&31)][k = 16ks + 8hi + j]
+__device__ __forceinline__ bf16x8_t frag_rm(const char* img, int rb, int ks, int lane) {
   const int row = rb * 32 + (lane & 31);
-  return *reinterpret_cast<const bf16x8_t*>(rm + row * 256 + (((2 * ks + (lane >> 5)) ^ (row & 15)) << 4));
+  const int gl = ((lane & 3) << 2) | ((lane >> 2) & 3);                                   // g(row): row & 15 == lane & 15
+  return *reinterpret_cast<const bf16x8_t*>(img + row * 256 + (((2 * ks + (lane >> 5)) ^ gl) << 4));
 }
-// A-operand fragment from a transposed image: A[row = d = db*32 + (lane&31)][k = (hi,j)] = X[r = rb*32 + 16c + 8(j>>2) + 4hi + (j&3)][d]
-__device__ __forceinline__ bf16x8_t frag_tr(const char* tr, int db, int rb, int c, int lane) {
-  const char* p = tr + (db * 32 + (lane & 31)) * AB_PITCH + (rb * 32 + c * 16 + 4 * (lane >> 5)) * 2;
-  const uint2 v0 = *reinterpret_cast<const uint2*>(p);
-  const uint2 v1 = *reinterpret_cast<const uint2*>(p + 16);
-  return __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+// A-operand fragment of the TRANSPOSED tile straight from the row-major image (ds_read_b64_tr_b16, cf. attention.hip):
+//   A[row = d = db*32 + (lane&31)][k = (hi,j)] = X[r = rb*32 + 16c + 8(j>>2) + 4hi + (j&3)][d]
+// tr0 / tr1: per-lane byte offsets of the two reads (rows +0 / +8) for db = 0, without the tile-row offset
+struct TrLane {
+  int o0, o1;
+};
+__device__ __forceinline__ TrLane tr_lane(int lane) {
+  const int hi = lane >> 5, i = (lane & 15) >> 2, a = (lane >> 4) & 1, b = (lane & 3) >> 1;
+  TrLane t;
+  t.o0 = (4 * hi + i) * 256 + (i << 6) + ((((2 * a + b) ^ hi)) << 4) + 8 * (lane & 1);             // g: bits 3:2 = i, bits 1:0 = (row>>2)&3 = hi
+  t.o1 = (8 + 4 * hi + i) * 256 + (i << 6) + ((((2 * a + b) ^ (2 + hi))) << 4) + 8 * (lane & 1);   //                         ... = 2 + hi
+  return t;
+}
+__device__ __forceinline__ bf16x8_t frag_tr(const char* img, int db, int rb, int c, const TrLane& t) {
+  const char* p = img + (rb * 32 + c * 16) * 256;
+  const ab_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ab_s16x4_t*)(p + (t.o0 ^ (db << 6))));
+  const ab_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ab_s16x4_t*)(p + (t.o1 ^ (db << 6))));
+  return __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
+}
+// Store a wave's [32 rows][128] fp32 accumulator tile (MFMA "transposed" layout: lane (row = lane&31, hi) holds
+// X[row][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of acc[db]) as bf16 with FULL-LINE stores: v_permlane32_swap gives every lane
+// 16-byte pieces, which go through an 8 KiB LDS buffer (unit ^= row & 15) and leave as 4 rows x 256 B per instruction.
+__device__ __forceinline__ void store_tile_rows(const f32x16_t (&acc)[4], float mul, char* xs, char* gbase, uint32_t stride_b, int row_first,
+                                                int limit, int lane) {
+  const int ql = lane & 31, hi = lane >> 5;
+  char* wp = xs + ql * 256;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      float a[4], bq[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[db][8 * gp + e] * mul), __float_as_uint(acc[db][8 * gp + 4 + e] * mul),
+                                                         false, false);
+        a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
+      }
+      *reinterpret_cast<uint4*>(wp + (((db * 4 + gp * 2 + hi) ^ (ql & 15)) << 4)) =
+          make_uint4(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]), pack2bf_hw(bq[0], bq[1]), pack2bf_hw(bq[2], bq[3]));
+    }
+  AB_WAIT_LGKM0();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = 4 * j + (lane >> 4);
+    const uint4 piece = *reinterpret_cast<const uint4*>(xs + j * 1024 + lane * 16);
+    if (row_first + r < limit)
+      *reinterpret_cast<uint4*>(gbase + ((uint32_t)(row_first + r) * stride_b + (uint32_t)(((lane & 15) ^ (r & 15)) << 4))) = piece;
+  }
+  AB_WAIT_LGKM0();
 }
 __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& v, int c) {
   return __builtin_bit_cast(bf16x8_t, make_uint4(pack2bf_hw(v[8 * c + 0], v[8 * c + 1]), pack2bf_hw(v[8 * c + 2], v[8 * c + 3]),
@@ -98,25 +156,29 @@ __global__ void __launch_bounds__(256) attn_delta_k(const uint16_t* __restrict__
 }
 
 // ------------------------------------------------------------------ dK, dV
+// Workgroups of one (batch, kv head) -- its key blocks -- stream the same Q / dO tiles and sit on the same XCD.
 template <bool VARLEN>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                 const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
-                uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal) {
+                uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal,
+                int nkb, int n_sets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* q_rm = smem; char* q_tr = q_rm + AB_RM; char* d_rm = q_tr + AB_TR; char* d_tr = d_rm + AB_RM;
-  float* st = reinterpret_cast<float*>(d_tr + AB_TR);  // [64] lse (log2 domain), [64] delta
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int kblk = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int kx = (int)blockIdx.x >> 3;
+  const int set = (kx / nkb) * 8 + ((int)blockIdx.x & 7), kblk = kx % nkb;
+  if (set >= n_sets) return;
+  const int b = set / nkv, hk = set - b * nkv;
   const int group = nq / nkv;
   int S = S_arg;
   int64_t row0 = (int64_t)b * S_arg;
   if constexpr (VARLEN) {
     row0 = cu_seqlens[b];
     S = cu_seqlens[b + 1] - cu_seqlens[b];
-    if (kblk * 128 >= S) return;
   }
+  if (kblk * 128 >= S) return;
   const int key = kblk * 128 + wave * 32 + (lane & 31);
   bool key_ok = key < S;
   if constexpr (!VARLEN) {
@@ -125,16 +187,38 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
   }
   const int key_ld = key < S ? key : S - 1;
   const float scale_log2 = scale * 1.4426950408889634f;
+  const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
+  const char* seq_qkv = reinterpret_cast<const char*>(qkv + row0 * qkv_stride);      // workgroup-uniform bases, 32-bit per-lane offsets
+  const char* seq_do = reinterpret_cast<const char*>(dout + row0 * out_stride);
+
+  // flat tile list: the query tiles (qt0 .. nqt-1) of each of the group's heads
+  const int nqt = (S + 63) >> 6;
+  const int qt0 = causal ? 2 * kblk : 0;           // causal: query tiles before this key block see none of its keys
+  const int per_head = nqt - qt0;
+  const int ntl = group * per_head;
+  auto tile_of = [&](int n, int& h, int& qt) {
+    const int g = n / per_head;
+    qt = qt0 + (n - g * per_head);
+    h = hk * group + g;
+  };
+  auto stage = [&](int n, int buf) {
+    int h, qt;
+    tile_of(n, h, qt);
+    char* sb = smem + buf * AB_STAGE;
+    stage_img(seq_qkv + (int64_t)h * AB_D * 2, qkv_stride_b, qt * 64, S, sb, wv, lane);
+    stage_img(seq_do + (int64_t)h * AB_D * 2, out_stride_b, qt * 64, S, sb + AB_IMG, wv, lane);
+  };
+  if (ntl > 0) stage(0, 0);
 
   // K, V fragments of the owned key (B operands): X[key][16ks + 8hi .. +8]
   bf16x8_t kf[8], vf[8];
   {
-    const uint16_t* kp = qkv + (row0 + key_ld) * qkv_stride + (int64_t)(nq + hk) * AB_D + hi * 8;
-    const uint16_t* vp = kp + (int64_t)nkv * AB_D;
+    const char* kp = seq_qkv + ((uint32_t)key_ld * qkv_stride_b + (uint32_t)((nq + hk) * AB_D * 2 + hi * 16));
+    const char* vp = kp + nkv * AB_D * 2;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + ks * 16);
-      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + ks * 16);
+      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
+      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vp + ks * 32);
     }
   }
   f32x16_t dk[4], dv[4];
@@ -142,98 +226,137 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+  const TrLane trl = tr_lane(lane);
 
-  const int nqt = (S + 63) >> 6;
-  for (int g = 0; g < group; ++g) {
-    const int h = hk * group + g;
-    const uint16_t* qbase = qkv + row0 * qkv_stride + (int64_t)h * AB_D;
-    const uint16_t* dobase = dout + row0 * out_stride + (int64_t)h * AB_D;
-    // statistics of query q of head h: padded layout [B,nq,S] (stride 1 over q), packed layout [T,nq] (stride nq over q)
-    const float* lrow = VARLEN ? lse + row0 * nq + h : lse + ((int64_t)b * nq + h) * S;
-    const float* drow = VARLEN ? delta + row0 * nq + h : delta + ((int64_t)b * nq + h) * S;
-    const int64_t qs = VARLEN ? nq : 1;
-    for (int qt = causal ? 2 * kblk : 0; qt < nqt; ++qt) {   // causal: query tiles before this key block see none of its keys
-      stage_pairs(qbase, qkv_stride, qt * 64, S, q_rm, q_tr);
-      stage_pairs(dobase, out_stride, qt * 64, S, d_rm, d_tr);
-      if (tid < 64) {
-        const int q = qt * 64 + tid;
-        st[tid] = q < S ? lrow[q * qs] * 1.4426950408889634f : INFINITY;  // +inf -> P = 0 for rows past the sequence
-        st[64 + tid] = q < S ? drow[q * qs] : 0.f;
+  for (int n = 0; n < ntl; ++n) {
+    AB_WAIT_VM0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // statistics of the tile's 64 queries: every wave keeps its own copy, lane l <-> query qt*64 + l (one coalesced load per array,
+    // issued here and first used after the S / dP products; the next tile's DMA is not in flight yet, so the wait for them is
+    // short); a lane fetches the value of "its" query of an accumulator register with ds_bpermute (no LDS memory, no barrier).
+    // Rows past the sequence get lse = +inf -> P = 0.
+    int h_t, qt;
+    tile_of(n, h_t, qt);
+    float raw_l, raw_d, my_l = 0.f, my_d = 0.f;
+    const bool q_in = qt * 64 + lane < S;
+    {
+      const int qc = q_in ? qt * 64 + lane : S - 1;
+      // padded layout [B,nq,S] (stride 1 over q), packed layout [T,nq] (stride nq over q)
+      const float* lrow = VARLEN ? lse + row0 * nq + h_t : lse + ((int64_t)b * nq + h_t) * S;
+      const float* drow = VARLEN ? delta + row0 * nq + h_t : delta + ((int64_t)b * nq + h_t) * S;
+      const int64_t qs = VARLEN ? nq : 1;
+      raw_l = lrow[qc * qs];
+      raw_d = drow[qc * qs];
+    }
+    const char* q_img = smem + (n & 1) * AB_STAGE;
+    const char* d_img = q_img + AB_IMG;
+    // One wave per SIMD: nothing else hides the LDS latency, so the fragment reads of a phase are issued as a block AHEAD of the
+    // products that consume them (sched_barrier pins the blocks; hipcc otherwise sinks every read to its use and waits for each):
+    //   reads A(qb) | products A(qb): S^T, dP^T ; reads B(qb) | softmax(qb) ; reads A(qb+1) | products B(qb): dV, dK | ...
+    bf16x8_t fa[2][8], fb[2][4][2];                 // fa[operand][ks]; fb[c][db][operand]   (operand 0 = Q side, 1 = dO side)
+    auto read_a = [&](int qb) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) { fa[0][ks] = frag_rm(q_img, qb, ks, lane); fa[1][ks] = frag_rm(d_img, qb, ks, lane); }
+    };
+    read_a(0);
+    AB_SCHED_FENCE();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][ks], kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][ks], vf[ks], dp, 0, 0, 0);
       }
-      __syncthreads();
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        f32x16_t s, dp;
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(q_rm, qb, ks, lane), kf[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(d_rm, qb, ks, lane), vf[ks], dp, 0, 0, 0);
-        }
-        // regs 4g..4g+3 <-> q = 32qb + 8g + 4hi + 0..3
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const float4 l4 = *reinterpret_cast<const float4*>(st + qb * 32 + 8 * gq + 4 * hi);
-          const float4 d4 = *reinterpret_cast<const float4*>(st + 64 + qb * 32 + 8 * gq + 4 * hi);
-          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * gq + e;
-            const bool seen = key_ok && (!causal || key <= qt * 64 + qb * 32 + 8 * gq + 4 * hi + e);
-            const float p = seen ? __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[e]) : 0.f;
-            s[r] = p;
-            dp[r] = p * (dp[r] - dl[e]);
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const bf16x8_t pb = pack8(s, c), dsb = pack8(dp, c);
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(d_tr, db, qb, c, lane), pb, dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(q_tr, db, qb, c, lane), dsb, dk[db], 0, 0, 0);
-          }
-        }
+        for (int db = 0; db < 4; ++db) { fb[c][db][0] = frag_tr(q_img, db, qb, c, trl); fb[c][db][1] = frag_tr(d_img, db, qb, c, trl); }
+      AB_SCHED_FENCE();
+      // the next tile's DMA goes out behind the tile's LAST transposing reads: hipcc puts a vmcnt(0) in front of every
+      // ds_read_b64_tr_b16 that follows an LDS-DMA (it treats the two as aliasing), which would wait for the fresh DMA
+      if (qb == 1 && n + 1 < ntl) stage(n + 1, (n + 1) & 1);
+      if (qb == 0) {                                // first use of the statistics loaded at the tile top
+        my_l = q_in ? raw_l * 1.4426950408889634f : INFINITY;
+        my_d = q_in ? raw_d : 0.f;
       }
-      __syncthreads();
+      // regs 4g..4g+3 <-> q = 32qb + 8g + 4hi + 0..3
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = qb * 32 + 8 * (r >> 2) + (r & 3);                 // + 4 hi
+        const int src = (ql + 4 * hi) << 2;
+        const float lv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_l)));
+        const float dl = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_d)));
+        const bool seen = key_ok && (!causal || key <= qt * 64 + ql + 4 * hi);
+        const float p = seen ? __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv) : 0.f;
+        s[r] = p;
+        dp[r] = p * (dp[r] - dl);
+      }
+      bf16x8_t pb[2], dsb[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { pb[c] = pack8(s, c); dsb[c] = pack8(dp, c); }
+      if (qb == 0) read_a(1);
+      AB_SCHED_FENCE();
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][db][1], pb[c], dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][db][0], dsb[c], dk[db], 0, 0, 0);
+        }
     }
   }
-  if (key < S) {
-    uint16_t* kp = dqkv + (row0 + key) * qkv_stride + (int64_t)(nq + hk) * AB_D + 4 * hi;
-    uint16_t* vp = kp + (int64_t)nkv * AB_D;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        *reinterpret_cast<uint2*>(kp + db * 32 + gq * 8) = make_uint2(pack2bf(dk[db][4 * gq] * scale, dk[db][4 * gq + 1] * scale),
-                                                                     pack2bf(dk[db][4 * gq + 2] * scale, dk[db][4 * gq + 3] * scale));
-        *reinterpret_cast<uint2*>(vp + db * 32 + gq * 8) = make_uint2(pack2bf(dv[db][4 * gq], dv[db][4 * gq + 1]),
-                                                                     pack2bf(dv[db][4 * gq + 2], dv[db][4 * gq + 3]));
-      }
-  }
+  // every wave is done with the ring: it becomes the transposition buffer of the full-line gradient stores
+  AB_WAIT_VM0();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  char* xs = smem + wv * 8192;
+  char* seq_dqkv = reinterpret_cast<char*>(dqkv + row0 * qkv_stride);
+  store_tile_rows(dk, scale, xs, seq_dqkv + (int64_t)(nq + hk) * AB_D * 2, qkv_stride_b, kblk * 128 + wave * 32, S, lane);
+  store_tile_rows(dv, 1.0f, xs, seq_dqkv + (int64_t)(nq + nkv + hk) * AB_D * 2, qkv_stride_b, kblk * 128 + wave * 32, S, lane);
 }
 
 // ------------------------------------------------------------------ dQ
+// Workgroups of one (batch, kv head) -- the group's heads x query blocks -- stream the same K / V tiles and sit on the same XCD.
 template <bool VARLEN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
               const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
-              uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* k_rm = smem; char* k_tr = k_rm + AB_RM; char* v_rm = k_tr + AB_TR;
+              uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal,
+              int nqb, int n_sets) {
+  __shared__ __attribute__((aligned(16))) char smem[AB_RING];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int hk = h / (nq / nkv);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int gqa = nq / nkv, U = gqa * nqb;
+  const int kx = (int)blockIdx.x >> 3;
+  const int set = (kx / U) * 8 + ((int)blockIdx.x & 7), member = kx % U;
+  if (set >= n_sets) return;
+  const int b = set / nkv, hk = set - b * nkv;
+  const int h = hk * gqa + member % gqa, qblk = member / gqa;
   int S = S_arg;
   int64_t row0 = (int64_t)b * S_arg;
-  const uint64_t* bits = nullptr;
-  int ntiles = 0;
   if constexpr (VARLEN) {
     row0 = cu_seqlens[b];
     S = cu_seqlens[b + 1] - cu_seqlens[b];
-    if (qblk * 128 >= S) return;
+  }
+  if (qblk * 128 >= S) return;
+  const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
+  const char* seq_qkv = reinterpret_cast<const char*>(qkv + row0 * qkv_stride);
+  const char* k_base = seq_qkv + (int64_t)(nq + hk) * AB_D * 2;
+  const char* v_base = k_base + (int64_t)nkv * AB_D * 2;
+  auto stage = [&](int t, int buf) {
+    stage_img(k_base, qkv_stride_b, t * 64, S, smem + buf * AB_STAGE, wv, lane);
+    stage_img(v_base, qkv_stride_b, t * 64, S, smem + buf * AB_STAGE + AB_IMG, wv, lane);
+  };
+  stage(0, 0);                                      // tile 0 always exists (S > 0)
+
+  const uint64_t* bits = nullptr;
+  int ntiles = 0;
+  if constexpr (VARLEN) {
     ntiles = (S + 63) >> 6;
   } else {
     const int W = (S + 63) >> 6;
@@ -251,12 +374,12 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
 
   bf16x8_t qf[8], dof[8];
   {
-    const uint16_t* qp = qkv + (row0 + q_ld) * qkv_stride + (int64_t)h * AB_D + hi * 8;
-    const uint16_t* dp = dout + (row0 + q_ld) * out_stride + (int64_t)h * AB_D + hi * 8;
+    const char* qp = seq_qkv + ((uint32_t)q_ld * qkv_stride_b + (uint32_t)(h * AB_D * 2 + hi * 16));
+    const char* dp = reinterpret_cast<const char*>(dout + row0 * out_stride) + ((uint32_t)q_ld * out_stride_b + (uint32_t)(h * AB_D * 2 + hi * 16));
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dp + ks * 16);
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dp + ks * 32);
     }
   }
   f32x16_t dq[4];
@@ -264,13 +387,14 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+  const TrLane trl = tr_lane(lane);
 
-  const uint16_t* kbase = qkv + row0 * qkv_stride + (int64_t)(nq + hk) * AB_D;
-  const uint16_t* vbase = kbase + (int64_t)nkv * AB_D;
   for (int t = 0; t < ntiles; ++t) {
-    stage_pairs(kbase, qkv_stride, t * 64, S, k_rm, k_tr);
-    stage_pairs(vbase, qkv_stride, t * 64, S, v_rm, nullptr);
-    __syncthreads();
+    AB_WAIT_VM0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* k_img = smem + (t & 1) * AB_STAGE;
+    const char* v_img = k_img + AB_IMG;
     uint64_t word;
     if constexpr (VARLEN) {
       const int rem = S - t * 64;
@@ -283,16 +407,51 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
       word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
     }
     const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
+    // hipcc sinks every fragment read to its use and waits for each (one read in flight); the reads are therefore issued in pinned
+    // groups a group ahead of the products that consume them (two waves per SIMD leave ~30 registers for that: 2 k-slices x {K, V}
+    // per group, double-buffered), and the transposed-K fragments of the dQ products go out ahead of the softmax arithmetic
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16_t s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      bf16x8_t fa[2][4];
+      auto read_a = [&](int g, int buf) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(k_rm, kb, ks, lane), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(v_rm, kb, ks, lane), dof[ks], dp, 0, 0, 0);
-      }
+        for (int j = 0; j < 2; ++j) {
+          fa[buf][2 * j] = frag_rm(k_img, kb, 2 * g + j, lane);
+          fa[buf][2 * j + 1] = frag_rm(v_img, kb, 2 * g + j, lane);
+        }
+      };
+      auto mma_a = [&](int g, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][2 * j], qf[2 * g + j], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][2 * j + 1], dof[2 * g + j], dp, 0, 0, 0);
+        }
+      };
+      read_a(0, 0);
+      AB_SCHED_FENCE();
+      read_a(1, 1);
+      AB_SCHED_FENCE();
+      mma_a(0, 0);
+      read_a(2, 0);
+      AB_SCHED_FENCE();
+      mma_a(1, 1);
+      read_a(3, 1);
+      AB_SCHED_FENCE();
+      mma_a(2, 0);
+      AB_SCHED_FENCE();
+      mma_a(3, 1);
+      bf16x8_t fb[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) fb[c][db] = frag_tr(k_img, db, kb, c, trl);
+      AB_SCHED_FENCE();
+      // the next tile's DMA goes out behind the tile's LAST transposing reads (hipcc waits vmcnt(0) in front of every
+      // ds_read_b64_tr_b16 that follows an LDS-DMA)
+      if (kb == 1 && t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
       const uint32_t wsel = kb ? whi : wlo;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -300,25 +459,21 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
         const float p = ((wsel >> kbit) & 1u) ? __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse2) : 0.f;
         dp[r] = p * (dp[r] - dlt);
       }
+      bf16x8_t dsb[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const bf16x8_t dsb = pack8(dp, c);
+      for (int c = 0; c < 2; ++c) dsb[c] = pack8(dp, c);
+      AB_SCHED_FENCE();
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(k_tr, db, kb, c, lane), dsb, dq[db], 0, 0, 0);
-      }
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][db], dsb[c], dq[db], 0, 0, 0);
     }
-    __syncthreads();
   }
-  if (q < S) {
-    uint16_t* op = dqkv + (row0 + q) * qkv_stride + (int64_t)h * AB_D + 4 * hi;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        *reinterpret_cast<uint2*>(op + db * 32 + gq * 8) = make_uint2(pack2bf(dq[db][4 * gq] * scale, dq[db][4 * gq + 1] * scale),
-                                                                     pack2bf(dq[db][4 * gq + 2] * scale, dq[db][4 * gq + 3] * scale));
-  }
+  AB_WAIT_VM0();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  store_tile_rows(dq, scale, smem + wv * 8192, reinterpret_cast<char*>(dqkv + row0 * qkv_stride) + (int64_t)h * AB_D * 2, qkv_stride_b,
+                  qblk * 128 + wave * 32, S, lane);
 }
 
 }  // namespace grit
@@ -332,29 +487,34 @@ static int attn_bwd_launch(bool varlen, int causal, const void* qkv, const uint6
   hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((items * 16 + 255) / 256)), dim3(256), 0, st, (const uint16_t*)out,
                      (const uint16_t*)dout, delta, T, varlen ? 0 : S_or_maxlen, nq, out_stride);
   GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: delta");
-  static bool attr_set = false;
-  const int lds_kv = 2 * AB_RM + 2 * AB_TR + 512, lds_q = 2 * AB_RM + AB_TR;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    attr_set = true;
+  const int lds_kv = AB_RING;
+  static std::atomic<uint64_t> optin{0};                       // per-device function attribute
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(optin.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+      optin.fetch_or(bit, std::memory_order_release);
+    }
   }
-  const unsigned nblk = (unsigned)((S_or_maxlen + 127) / 128);
+  const int nblk = (S_or_maxlen + 127) / 128;
+  const int n_sets = B * nkv, sets8 = 8 * ((n_sets + 7) / 8);
+  const dim3 grid_kv((unsigned)(sets8 * nblk)), grid_q((unsigned)(sets8 * (nq / nkv) * nblk));
   if (varlen) {
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<true>, dim3(nblk, (unsigned)nkv, (unsigned)B), dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<true>, grid_kv, dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dkdv");
-    hipLaunchKernelGGL(attn_bwd_dq_k<true>, dim3(nblk, (unsigned)nq, (unsigned)B), dim3(256), lds_q, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
+    hipLaunchKernelGGL(attn_bwd_dq_k<true>, grid_q, dim3(256), 0, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dq");
   } else {
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<false>, dim3(nblk, (unsigned)nkv, (unsigned)B), dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<false>, grid_kv, dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dkdv");
-    hipLaunchKernelGGL(attn_bwd_dq_k<false>, dim3(nblk, (unsigned)nq, (unsigned)B), dim3(256), lds_q, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal);
+    hipLaunchKernelGGL(attn_bwd_dq_k<false>, grid_q, dim3(256), 0, st, (const uint16_t*)qkv, key_bits, cu,
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dq");
   }
   return GRIT_OK;
@@ -371,7 +531,9 @@ static int attn_bwd_padded(int causal, const void* qkv, const uint64_t* key_bits
                GRIT_E_BADARG, "grit_attn_bidir_bwd: bad strides");
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
                "grit_attn_bidir_bwd: pointers must be 16-byte aligned");
-  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: grid too large");
+  GRIT_REQUIRE((int64_t)B * nq * ((S + 127) / 128) < (1ll << 30), GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: grid too large");
+  GRIT_REQUIRE((int64_t)S * qkv_stride * 2 < (1ll << 31) && (int64_t)S * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "grit_attn_bidir_bwd: one sequence spans more than 2 GiB (32-bit row offsets)");
   return attn_bwd_launch(false, causal, qkv, key_bits, nullptr, out, dout, lse, delta, dqkv, B, S, (int64_t)B * S, nq, nkv, qkv_stride,
                          out_stride, scale, (hipStream_t)stream);
 }
@@ -397,7 +559,9 @@ static int attn_bwd_varlen(int causal, const void* qkv, const int32_t* cu_seqlen
                GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: bad strides");
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
                "grit_attn_bidir_varlen_bwd: pointers must be 16-byte aligned");
-  GRIT_REQUIRE(nq <= 65535 && B <= 65535, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: grid too large");
+  GRIT_REQUIRE((int64_t)B * nq * ((max_len + 127) / 128) < (1ll << 30), GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: grid too large");
+  GRIT_REQUIRE((int64_t)max_len * qkv_stride * 2 < (1ll << 31) && (int64_t)max_len * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "grit_attn_bidir_varlen_bwd: one sequence spans more than 2 GiB (32-bit row offsets)");
   return attn_bwd_launch(true, causal, qkv, nullptr, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, qkv_stride, out_stride,
                          scale, (hipStream_t)stream);
 }
