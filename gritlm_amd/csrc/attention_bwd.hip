@@ -264,12 +264,11 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16_t s, dp;
+      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][ks], kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][ks], vf[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < 8; ++ks) {              // the first product of a chain takes the inline constant 0 as accumulator
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][ks], kf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][ks], vf[ks], ks == 0 ? zero16 : dp, 0, 0, 0);
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -284,16 +283,23 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
         my_d = q_in ? raw_d : 0.f;
       }
       // regs 4g..4g+3 <-> q = 32qb + 8g + 4hi + 0..3
+      // the statistics of the half's 32 queries, fetched as a block (hipcc would otherwise fetch, wait and use them one by one)
+      float lv[16], dl[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int src = (qb * 32 + 8 * (r >> 2) + (r & 3) + 4 * hi) << 2;
+        lv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_l)));
+        dl[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_d)));
+      }
+      AB_SCHED_FENCE();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = qb * 32 + 8 * (r >> 2) + (r & 3);                 // + 4 hi
-        const int src = (ql + 4 * hi) << 2;
-        const float lv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_l)));
-        const float dl = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_d)));
-        const bool seen = key_ok && (!causal || key <= qt * 64 + ql + 4 * hi);
-        const float p = seen ? __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv) : 0.f;
+        const bool seen = key_ok & ((causal == 0) | (key <= qt * 64 + ql + 4 * hi));      // bitwise: no short-circuit branches
+        const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[r]);                 // unconditional: a select, not a branch
+        const float p = seen ? e : 0.f;
         s[r] = p;
-        dp[r] = p * (dp[r] - dl);
+        dp[r] = p * (dp[r] - dl[r]);
       }
       bf16x8_t pb[2], dsb[2];
 #pragma unroll
@@ -456,7 +462,8 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kbit = (r & 3) + 8 * (r >> 2);
-        const float p = ((wsel >> kbit) & 1u) ? __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse2) : 0.f;
+        const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse2);   // unconditional: a select, not a branch per element
+        const float p = ((wsel >> kbit) & 1u) ? e : 0.f;
         dp[r] = p * (dp[r] - dlt);
       }
       bf16x8_t dsb[2];

@@ -86,8 +86,9 @@ __global__ void __launch_bounds__(256) gemm_f32_strided_k(const float* __restric
     }
 }
 
-// one workgroup per query row: logsumexp, loss contribution, then d loss / d raw-scores in place
-__global__ void __launch_bounds__(256) infonce_ce_k(float* __restrict__ scores, float* __restrict__ loss, int Nq, int Np, int group,
+// one workgroup per query row: logsumexp, the row's loss term (loss_rows[i]; summed in a fixed order by infonce_loss_k -- no float
+// atomics: the loss is bit-reproducible from run to run), then d loss / d raw-scores in place
+__global__ void __launch_bounds__(256) infonce_ce_k(float* __restrict__ scores, float* __restrict__ loss_rows, int Nq, int Np, int group,
                                                     float inv_temperature, int want_grad) {
   __shared__ float red[8];
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(256) infonce_ce_k(float* __restrict__ scores, 
   const float e_t = expf(s_t - mx);
   const float tot = sum_others + e_t;
   const float li = (s_t == mx) ? log1pf(sum_others) : (mx - s_t) + logf(tot);
-  if (tid == 0) atomicAdd(loss, li / (float)Nq);
+  if (tid == 0) loss_rows[i] = li;
   if (!want_grad) return;
   __syncthreads();  // row[tgt] read above before anyone overwrites it
   const float sc = inv_temperature / (float)Nq, inv_tot = 1.0f / tot;
@@ -121,6 +122,19 @@ __global__ void __launch_bounds__(256) infonce_ce_k(float* __restrict__ scores, 
     const float pj = (j == tgt) ? -sum_others * inv_tot : expf(row[j] - mx) * inv_tot;
     row[j] = pj * sc;
   }
+}
+
+// loss[0] = mean(loss[1 .. Nq]): one workgroup, fixed summation tree (thread t adds rows t, t+256, ... in order; then a fixed
+// wave / cross-wave reduction)
+__global__ void __launch_bounds__(256) infonce_loss_k(float* __restrict__ loss, int Nq) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (int i = tid; i < Nq; i += 256) acc += loss[1 + i];
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)Nq;
 }
 
 static int launch_f32_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk,
@@ -149,16 +163,14 @@ extern "C" int grit_infonce_fwd_bwd(const float* q, const float* p, float inv_te
   GRIT_REQUIRE((dq == nullptr) || (q_off >= 0 && nq_loc > 0 && q_off + nq_loc <= Nq), GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad q range");
   GRIT_REQUIRE((dp == nullptr) || (p_off >= 0 && np_loc > 0 && p_off + np_loc <= Np), GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad p range");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) {
-    set_error("grit_infonce_fwd_bwd: hipMemsetAsync failed");
-    return GRIT_E_LAUNCH;
-  }
   // scores[i,j] = inv_t * sum_h q[i,h] p[j,h]
   int rc = launch_f32_gemm(q, p, scores, Nq, Np, H, H, 1, 1, H, Np, inv_temperature, st);
   if (rc) return rc;
   const int want_grad = (dq != nullptr) || (dp != nullptr);
-  hipLaunchKernelGGL(infonce_ce_k, dim3(Nq), dim3(256), 0, st, scores, loss, Nq, Np, Np / Nq, inv_temperature, want_grad);
+  hipLaunchKernelGGL(infonce_ce_k, dim3(Nq), dim3(256), 0, st, scores, loss + 1, Nq, Np, Np / Nq, inv_temperature, want_grad);
   GRIT_CHECK_LAUNCH("grit_infonce_fwd_bwd: ce");
+  hipLaunchKernelGGL(infonce_loss_k, dim3(1), dim3(256), 0, st, loss, Nq);
+  GRIT_CHECK_LAUNCH("grit_infonce_fwd_bwd: loss");
   if (dq) {  // dq[m,h] = sum_j dS[q_off+m, j] p[j,h]
     rc = launch_f32_gemm(scores + (int64_t)q_off * Np, p, dq, nq_loc, H, Np, Np, 1, H, 1, H, 1.0f, st);
     if (rc) return rc;

@@ -185,7 +185,8 @@ int grit_pool_norm_varlen_bwd(const float* y, const float* dy, const float* inv_
 
 /* scores = q p^T / tau (fp32 MFMA, exact f32), target[i] = i * (Np / Nq), CrossEntropyLoss(mean).
  * q [Nq,H] fp32, p [Np,H] fp32 (already gathered across ranks, rank order).
- * scores: workspace fp32 [Nq,Np] (holds d loss / d scores afterwards); loss: 1 fp32.
+ * scores: workspace fp32 [Nq,Np] (holds d loss / d scores afterwards); loss: fp32 [1 + Nq] -- loss[0] = the mean loss,
+ * loss[1 + i] = the loss term of query row i (summed in a fixed order: the result is bit-reproducible, no float atomics).
  * Gradients are produced only for the caller's local rows, exactly the rows that carry grad in the
  * reference after `_dist_gather_tensor` (:49-60): dq [nq_loc,H] for q rows [q_off, q_off+nq_loc),
  * dp [np_loc,H] for p rows [p_off, p_off+np_loc).  dq/dp may be NULL (forward only). */

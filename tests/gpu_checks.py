@@ -242,6 +242,24 @@ def check_infonce_local_rows():
     return _res("infonce local rows vs 2-rank gloo reference", ok, worst_abs=worst)
 
 
+def check_infonce_reproducible(nq=333, group=4, H=256, tau=0.02, reps=8):
+    """The loss is reduced in a fixed order (per-row terms + one fixed summation tree, no float atomics): the same inputs must give
+    the same BITS every time (check_train_packed_vs_padded compares two steps' losses for equality)."""
+    rng = np.random.default_rng(22)
+    q = torch.from_numpy(O.l2_normalize(rng.standard_normal((nq, H), dtype=np.float32))).to(DEV)
+    p = torch.from_numpy(O.l2_normalize(rng.standard_normal((nq * group, H), dtype=np.float32))).to(DEV)
+    first = None
+    same = True
+    for _ in range(reps):
+        loss, dq, dp = ops.infonce(q, p, tau)
+        cur = (loss.clone(), dq.clone(), dp.clone())
+        if first is None:
+            first = cur
+        else:
+            same &= all(bool(torch.equal(a, b)) for a, b in zip(first, cur))
+    return _res("infonce loss and gradients bit-reproducible", same, loss=float(first[0].item()))
+
+
 def check_infonce_big(nq=256, group=8, H=512, tau=0.02):
     rng = np.random.default_rng(21)
     q = O.l2_normalize(rng.standard_normal((nq, H), dtype=np.float32))
@@ -1536,6 +1554,7 @@ ALL_CHECKS = [
     ("infonce_c", check_infonce, dict(tag="c")),
     ("infonce_local", check_infonce_local_rows, {}),
     ("infonce_big", check_infonce_big, {}),
+    ("infonce_reproducible", check_infonce_reproducible, {}),
     ("transpose", check_transpose, {}),
     ("rmsnorm_bwd", check_rmsnorm_bwd, {}),
     ("rmsnorm_bwd_4096", check_rmsnorm_bwd, dict(T=21, H=4096, with_res=False)),
