@@ -281,13 +281,15 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with the scaling
       const float m_new = fmaxf(m_run, mx);
 #if ATT_DEFER_MAX
-      // deferred rescale: as long as no row's maximum grows by more than 2^8 the wave keeps its old reference maxima (P <= 256, exact
-      // in the bf16 exponent range; l and O stay consistent with m_run) and skips the 64 accumulator multiplies + exp2 of the rescale
+      // deferred rescale: a row keeps its old reference maximum as long as its maximum grows by less than 2^8 (P <= 256, exact in
+      // the bf16 exponent range; l and O stay consistent with m_run); when NO row of the wave has to move, the 64 accumulator
+      // multiplies + exp2 of the rescale are skipped.  The decision is per row (rows that stay multiply by exactly 1), so a row's
+      // result never depends on which other rows share its wave -- the packed and the padded layout stay bit-identical.
       const bool grow = !(m_new - m_run <= 8.0f);                 // also true for m_run = -inf (first tile, or all keys masked so far)
       if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
         const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);  // m_run = -inf -> 0
-        m_run = m_new;
+        const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_ref) : 1.0f;  // m_run = -inf -> 0
+        m_run = grow ? m_new : m_run;
         l_run *= alpha;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
