@@ -138,29 +138,46 @@ __global__ void __launch_bounds__(256) mask_pack_k(const int64_t* __restrict__ m
 }
 
 // ---------------------------------------------------------------- bf16 transpose [R,C] -> [C,R]
+// 64 x 256 tile per workgroup: eight 16-byte loads in flight per lane, row-major LDS image (544-byte pitch: 4 consecutive rows sit 8
+// banks apart), read back TRANSPOSED by the hardware (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block, lane c
+// receives column c's 4 rows) -- two reads give a lane 8 consecutive source rows of one column = 16 bytes of one output row; the four
+// lane groups of a wave hold four neighbouring pieces of the same 16 output rows (64 contiguous bytes per row and store).
+// (Round 1 read the image back with sixteen 2-byte LDS reads per lane from a 64 x 64 tile: 2.4 TB/s.)
+constexpr int TR_ROWS = 64, TR_COLS = 256, TR_PITCH = 544;
+typedef __attribute__((ext_vector_type(4))) short tr_s16x4_t;
 __global__ void __launch_bounds__(256) transpose_k(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t R,
                                                    int64_t C, int64_t ld_in, int64_t ld_out) {
-  __shared__ uint16_t tile[64][72];
-  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) char tile[TR_ROWS * TR_PITCH];
+  const int64_t r0 = (int64_t)blockIdx.y * TR_ROWS, c0 = (int64_t)blockIdx.x * TR_COLS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint4 v[8];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int idx = tid + it * 256;  // 512 chunks of 8
-    const int r = idx >> 3, cc = (idx & 7) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + r < R && c0 + cc < C) v = *reinterpret_cast<const uint4*>(in + (r0 + r) * ld_in + c0 + cc);
-    *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + it * 256;                   // 2048 chunks of 8 elements: 32 per row
+    const int r = idx >> 5, cc = (idx & 31) * 8;
+    v[it] = make_uint4(0, 0, 0, 0);
+    if (r0 + r < R && c0 + cc < C) v[it] = *reinterpret_cast<const uint4*>(in + (r0 + r) * ld_in + c0 + cc);
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + it * 256;
+    *reinterpret_cast<uint4*>(tile + (idx >> 5) * TR_PITCH + (idx & 31) * 16) = v[it];
   }
   __syncthreads();
+  const int g = lane >> 4, j = lane & 15;
+  const int rd = (j >> 2) * TR_PITCH + (j & 3) * 8;   // lane j of a group points at block row j/4, block columns 4 (j%4) .. +3
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int idx = tid + it * 256;
-    const int c = idx >> 3, rr = (idx & 7) * 8;  // output row = input column c, 8 consecutive input rows
-    if (c0 + c < C && r0 + rr < R) {
-      uint32_t w[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[rr + 2 * k][c] | ((uint32_t)tile[rr + 2 * k + 1][c] << 16);
-      *reinterpret_cast<uint4*>(out + (c0 + c) * ld_out + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+  for (int it = 0; it < 8; ++it) {
+    const int u = wave * 8 + it;                      // 32 units per workgroup: 16 column blocks x 2 row halves
+    const int d0 = (u >> 1) * 16, k0 = (u & 1) * 32 + g * 8;
+    const char* p = tile + k0 * TR_PITCH + d0 * 2 + rd;
+    const tr_s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_s16x4_t*)(p));
+    const tr_s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_s16x4_t*)(p + 4 * TR_PITCH));
+    const int64_t c = c0 + d0 + j;                    // output row = source column; 8 consecutive source rows from k0
+    if (c < C && r0 + k0 < R) {
+      const uint4 w = make_uint4((uint16_t)a[0] | ((uint32_t)(uint16_t)a[1] << 16), (uint16_t)a[2] | ((uint32_t)(uint16_t)a[3] << 16),
+                                 (uint16_t)b[0] | ((uint32_t)(uint16_t)b[1] << 16), (uint16_t)b[2] | ((uint32_t)(uint16_t)b[3] << 16));
+      *reinterpret_cast<uint4*>(out + c * ld_out + r0 + k0) = w;
     }
   }
 }
@@ -270,7 +287,7 @@ int grit_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t
   GRIT_REQUIRE(ld_in >= C && ld_out >= (R + 7) / 8 * 8 && ld_in % 8 == 0 && ld_out % 8 == 0, GRIT_E_BADARG,
                "grit_transpose_bf16: bad leading dimensions (ld_out must cover R rounded up to 8)");
   GRIT_REQUIRE(aligned16(in) && aligned16(out), GRIT_E_BADARG, "grit_transpose_bf16: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(transpose_k, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(transpose_k, dim3((unsigned)((C + TR_COLS - 1) / TR_COLS), (unsigned)((R + TR_ROWS - 1) / TR_ROWS)), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)in, (uint16_t*)out, R, C, ld_in, ld_out);
   GRIT_CHECK_LAUNCH("grit_transpose_bf16");
   return GRIT_OK;

@@ -280,7 +280,25 @@ def check_transpose(R=136, Cc=200):
     ok &= np.array_equal(f32(wide)[:, :R], x.T) and float(wide[:, R:].abs().max()) == 0.0
     y = rnd((20, 64), 24)                                                     # rows not a multiple of 8
     ok &= np.array_equal(f32(ops.transpose(bf(y))), y.T)
-    return _res("transpose", ok)
+    for (r, c) in ((1, 8), (64, 256), (65, 264), (300, 520), (1000, 1032)):     # tile edges of the 64 x 256 workgroup tile
+        z = rnd((r, c), 25 + r)
+        ok &= np.array_equal(f32(ops.transpose(bf(z))), z.T)
+    big = bf(rnd((200, 400), 26))
+    view = big[:, 16:336]                                                      # row stride 400, 320 columns
+    ok &= bool(torch.equal(ops.transpose(view), view.t()))
+    # rate at a weight-gradient operand of the training step (16384 tokens x 4096): read + write
+    a = torch.randn((16384, 4096), device=DEV).to(torch.bfloat16)
+    o = torch.empty((4096, 16384), dtype=torch.bfloat16, device=DEV)
+    for _ in range(3):
+        ops.transpose(a, out=o)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.transpose(a, out=o)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100.0
+    ok &= bool(torch.equal(o, a.t()))
+    return _res("transpose", ok, us_16384x4096=us, TB_per_s=2 * a.numel() * 2 / (us * 1e-6) / 1e12)
 
 
 def check_rmsnorm_bwd(T=50, H=256, with_res=True):
