@@ -312,7 +312,22 @@ def check_rmsnorm_bwd(T=50, H=256, with_res=True):
     dx = f32(ops.rmsnorm_bwd(bf(dy), bf(x), bf(w), 1e-5, dw, None if dres is None else bf(dres)))
     e1 = float(np.max(np.abs(dx - dx_ref) / (1.2e-2 * np.abs(dx_ref) + 1e-2 * np.sqrt(np.mean(dx_ref ** 2)))))
     e2 = float(np.max(np.abs(f32(dw) - 0.5 - dw_ref))) / float(np.abs(dw_ref).max())
-    return _res(f"rmsnorm_bwd[T={T},H={H},res={int(with_res)}]", e1 < 1.0 and e2 < 1e-3, dx_err_over_tol=e1, dw_rel=e2)
+    extra = {}
+    if with_res and H == 256:     # rate at a training chunk (16384 tokens x 4096): dy, x, dres read + dx written
+        Tb, Hb = 16384, 4096
+        a, b_, c_ = (torch.randn((Tb, Hb), device=DEV).to(torch.bfloat16) for _ in range(3))
+        wb = torch.ones((Hb,), device=DEV, dtype=torch.bfloat16)
+        dwb = torch.zeros((Hb,), dtype=torch.float32, device=DEV)
+        for _ in range(3):
+            ops.rmsnorm_bwd(a, b_, wb, 1e-5, dwb, c_)
+        e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.rmsnorm_bwd(a, b_, wb, 1e-5, dwb, c_)
+        e1_.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1_) * 100.0
+        extra = dict(us_16384x4096=us, TB_per_s=4 * Tb * Hb * 2 / (us * 1e-6) / 1e12)
+    return _res(f"rmsnorm_bwd[T={T},H={H},res={int(with_res)}]", e1 < 1.0 and e2 < 1e-3, dx_err_over_tol=e1, dw_rel=e2, **extra)
 
 
 def check_swiglu(T=37, I=512):
