@@ -514,6 +514,48 @@ extern "C" int grit_gemm_bf16_nt_grouped(const void* A, const int32_t* a_rows, c
   return GRIT_OK;
 }
 
+// Grouped launch with the training epilogues (Mixtral's expert MLP, forward with saved pre-activations and backward):
+// STORE, SWIGLU (interleaved weights), SWIGLU_STACKED, SWIGLU_STACKED_SAVE ([gate | up] of every sorted row through `residual`),
+// SWIGLU_BWD (saved [gate | up] of the sorted rows in `residual`).  Same semantics per group as grit_gemm_bf16_nt.
+extern "C" int grit_gemm_bf16_nt_grouped_epi(const void* A, const int32_t* a_rows, const void* W, void* C, const void* residual,
+                                             const int32_t* group_counts, int num_groups, int64_t M_total, int N, int K, int64_t lda,
+                                             int64_t ldw, int64_t w_group_stride, int64_t ldc, int64_t ldr, int epilogue, void* stream) {
+  if (M_total == 0) return GRIT_OK;
+  GRIT_REQUIRE(A && W && C && group_counts, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped_epi: null pointer");
+  GRIT_REQUIRE(M_total >= 0 && N > 0 && K > 0 && num_groups > 0 && num_groups <= 1024, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped_epi: bad sizes");
+  GRIT_REQUIRE(K % 64 == 0 && N % 16 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_grouped_epi: K=%d must be a multiple of 64, N=%d of 16", K, N);
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && w_group_stride % 8 == 0 && lda >= K && ldw >= K, GRIT_E_BADARG,
+               "grit_gemm_bf16_nt_grouped_epi: bad leading dimensions");
+  GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C), GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped_epi: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((int64_t)(M_total / BM + num_groups) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "grit_gemm_bf16_nt_grouped_epi: too many tiles");
+  const GemmGroups grp{group_counts, a_rows, w_group_stride, num_groups};
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case GRIT_EPI_STORE:
+      GRIT_REQUIRE(ldc >= N, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped_epi: ldc < N");
+      return launch_gemm<GRIT_EPI_STORE>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    case GRIT_EPI_SWIGLU:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_grouped_epi: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    case GRIT_EPI_SWIGLU_STACKED:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_grouped_epi: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU_STACKED>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    case GRIT_EPI_SWIGLU_STACKED_SAVE:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_grouped_epi: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      GRIT_REQUIRE(residual && ldr % 8 == 0 && ldr >= N && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_bf16_nt_grouped_epi: SWIGLU_STACKED_SAVE writes [gate | up] through `residual` (ldr >= N)");
+      return launch_gemm<GRIT_EPI_SWIGLU_STACKED_SAVE>(A, W, C, residual, M_total, N, K, lda, ldw, ldc, ldr, st, grp);
+    case GRIT_EPI_SWIGLU_BWD:
+      GRIT_REQUIRE(residual && ldr % 8 == 0 && ldr >= 2 * (int64_t)N && ldc >= 2 * (int64_t)N && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_bf16_nt_grouped_epi: SWIGLU_BWD needs the saved [gate | up] in `residual` (ldr >= 2N) and ldc >= 2N");
+      return launch_gemm<GRIT_EPI_SWIGLU_BWD>(A, W, C, residual, M_total, N, K, lda, ldw, ldc, ldr, st, grp);
+    default:
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt_grouped_epi: epilogue %d not available", epilogue);
+  }
+  return GRIT_OK;
+}
+
 extern "C" int grit_gemm_bf16_nt_rope(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
                                       const float* cos_tab, const float* sin_tab, const int32_t* positions, int S, int table_rows,
                                       int rope_cols, void* stream) {

@@ -165,9 +165,55 @@ __global__ void __launch_bounds__(256) moe_combine_k(const uint16_t* __restrict_
   reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- backward of combine (autograd of final_hidden_states += expert_out * routing_weight, modeling_mixtral_gritlm.py:861-880):
+//      one wave per routed row r:  dy[r] = bf16(w(r) * dout[token(r)]),  dw[token(r), slot(r)] = <y[r], dout[token(r)]>  (fp32)
+__global__ void __launch_bounds__(256) moe_combine_bwd_k(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
+                                                         const int32_t* __restrict__ row_token, const int32_t* __restrict__ rows,
+                                                         const float* __restrict__ weights, uint16_t* __restrict__ dy, float* __restrict__ dw,
+                                                         int64_t R, int H) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int HC = H >> 3;
+  const int t = row_token[r];
+  const int slot = (rows[2 * (int64_t)t] == (int32_t)r) ? 0 : 1;
+  const float w = weights[2 * (int64_t)t + slot];
+  const uint4* gp = reinterpret_cast<const uint4*>(dout) + (int64_t)t * HC;
+  const uint4* yp = reinterpret_cast<const uint4*>(y) + r * HC;
+  uint4* op = reinterpret_cast<uint4*>(dy) + r * HC;
+  float dot = 0.f;
+  for (int c = lane; c < HC; c += 64) {
+    const uint4 g = gp[c], yv = yp[c];
+    const uint32_t ga[4] = {g.x, g.y, g.z, g.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g0 = bflo(ga[k]), g1 = bfhi(ga[k]);
+      dot += g0 * bflo(ya[k]) + g1 * bfhi(ya[k]);
+      o[k] = pack2bf_hw(w * g0, w * g1);
+    }
+    op[c] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) dw[2 * (int64_t)t + slot] = dot;
+}
+
 }  // namespace grit
 
 using namespace grit;
+
+extern "C" int grit_moe_combine_bwd(const void* dout, const void* y, const int32_t* row_token, const int32_t* rows, const float* weights,
+                                    void* dy, float* dw, int64_t T, int H, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(dout && y && row_token && rows && weights && dy && dw, GRIT_E_BADARG, "grit_moe_combine_bwd: null pointer");
+  GRIT_REQUIRE(T > 0 && H > 0 && H % 8 == 0, GRIT_E_BADARG, "grit_moe_combine_bwd: bad sizes T=%lld H=%d", (long long)T, H);
+  GRIT_REQUIRE(aligned16(dout) && aligned16(y) && aligned16(dy), GRIT_E_BADARG, "grit_moe_combine_bwd: pointers must be 16-byte aligned");
+  const int64_t R = 2 * T;
+  hipLaunchKernelGGL(moe_combine_bwd_k, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout,
+                     (const uint16_t*)y, row_token, rows, weights, (uint16_t*)dy, dw, R, H);
+  GRIT_CHECK_LAUNCH("grit_moe_combine_bwd");
+  return GRIT_OK;
+}
 
 extern "C" int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* experts, float* weights, int64_t T, int H, int E,
                                     void* stream) {

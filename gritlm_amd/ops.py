@@ -243,6 +243,49 @@ def gemm_nt_grouped(a: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, m_to
     return out
 
 
+def gemm_nt_grouped_epi(a: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, m_total: int, epilogue: int, out: torch.Tensor | None = None,
+                        residual: torch.Tensor | None = None, a_rows: torch.Tensor | None = None) -> torch.Tensor:
+    """Grouped GEMM over ``w [E,N,K]`` with the training epilogues (see grit_gemm_bf16_nt_grouped_epi): STORE / SWIGLU* give
+    ``out [m_total, N or N/2]``; SWIGLU_STACKED_SAVE also fills ``residual [m_total, N]`` with [gate | up]; SWIGLU_BWD reads the saved
+    ``residual [m_total, 2N]`` and gives ``out [m_total, 2N]`` = [d_gate | d_up]."""
+    E, N, K = w.shape
+    assert a.shape[1] == K
+    if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE):
+        n_out = N // 2
+    elif epilogue == EPI_SWIGLU_BWD:
+        n_out = 2 * N
+    else:
+        n_out = N
+    if out is None:
+        out = torch.empty((m_total, n_out), dtype=BF16, device=a.device)
+    assert out.shape == (m_total, n_out)
+    if epilogue in (EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD):
+        need = N if epilogue == EPI_SWIGLU_STACKED_SAVE else 2 * N
+        assert residual is not None and tuple(residual.shape) == (m_total, need), "residual: [m_total, N] (SAVE) / [m_total, 2N] (BWD)"
+    ev = _timer.span("gemm_bf16_nt_grouped", 2.0 * m_total * N * K) if _timer is not None else None
+    if ev:
+        ev[0].record()
+    check(_lib.load().grit_gemm_bf16_nt_grouped_epi(_chk2d(a, BF16, "a"), 0 if a_rows is None else _chk(a_rows, I32, "a_rows"),
+                                                    _chk3d(w, BF16, "w"), _chk2d(out, BF16, "out"),
+                                                    0 if residual is None else _chk2d(residual, BF16, "residual"), _chk(counts, I32, "counts"),
+                                                    E, m_total, N, K, a.stride(0), w.stride(1), w.stride(0), out.stride(0),
+                                                    0 if residual is None else residual.stride(0), epilogue, _stream()),
+          "grit_gemm_bf16_nt_grouped_epi")
+    if ev:
+        ev[1].record()
+    return out
+
+
+def moe_combine_bwd(dout: torch.Tensor, y: torch.Tensor, row_token: torch.Tensor, rows: torch.Tensor, weights: torch.Tensor):
+    """Backward of moe_combine: (dy [2T,H] bf16 = w * dout[token], dw [T,2] fp32 = <y, dout[token]>)."""
+    T, H = dout.shape
+    dy = torch.empty((2 * T, H), dtype=BF16, device=dout.device)
+    dw = torch.empty((T, 2), dtype=F32, device=dout.device)
+    check(_lib.load().grit_moe_combine_bwd(_chk(dout, BF16, "dout"), _chk(y, BF16, "y"), _chk(row_token, I32, "row_token"), _chk(rows, I32, "rows"),
+                                           _chk(weights, F32, "weights"), dy.data_ptr(), dw.data_ptr(), T, H, _stream()), "grit_moe_combine_bwd")
+    return dy, dw
+
+
 def moe_route(x: torch.Tensor, gate_w: torch.Tensor):
     """Top-2 routing of x [T,H] -> (experts [T,2] i32, weights [T,2] f32, counts [E] i32, row_token [2T] i32, rows [T,2] i32)."""
     T, H = x.shape

@@ -28,7 +28,7 @@ def _pad64(n: int) -> int:
 
 
 class _LayerParams:
-    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "gqkv", "go", "ggu", "gdown", "mods")
+    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "gqkv", "go", "ggu", "gdown", "mods", "wgate")
 
 
 class SavedForward:
@@ -99,16 +99,53 @@ class MistralTrainEngine:
             L = _LayerParams()
             at, mlp = layer.self_attn, layer.mlp
             L.wqkv = self._pack([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight])
-            L.wgu = self._pack([mlp.gate_proj.weight, mlp.up_proj.weight])
-            L.wo, L.wdown = at.o_proj.weight, mlp.down_proj.weight
+            L.wo = at.o_proj.weight
             L.ln1, L.ln2 = layer.input_layernorm.weight, layer.post_attention_layernorm.weight
             L.mods = (at, mlp, layer)
             L.gqkv = L.ggu = L.go = L.gdown = None
+            self._bind_mlp(L, mlp)
             self.layers.append(L)
         self._g_embed = None
         self._g_norm = None
         self._f32_norm_grads = None
         self._f32_embed_grad = None
+
+    # ------------------------------------------------------------------ MLP hooks (dense SwiGLU here; MixtralTrainEngine overrides)
+    def _bind_mlp(self, L, mlp):
+        L.wgu = self._pack([mlp.gate_proj.weight, mlp.up_proj.weight])
+        L.wdown = mlp.down_proj.weight
+        L.wgate = None
+
+    def _prepare_mlp_grads(self, L):
+        _, mlp, _ = L.mods
+        L.ggu = self._packed_grad([mlp.gate_proj.weight, mlp.up_proj.weight], L.ggu)
+        L.gdown = self._packed_grad([mlp.down_proj.weight], L.gdown)
+
+    def _mlp_owners(self, li: int, name: str):
+        _, mlp, _ = self.layers[li].mods
+        return {"gu": (mlp.gate_proj.weight, mlp.up_proj.weight), "down": (mlp.down_proj.weight,)}[name]
+
+    def _layer_grads(self, L) -> list[torch.Tensor]:
+        return [L.gqkv, L.go, L.ggu, L.gdown]
+
+    def _mlp_fwd(self, L, h_mid, x2, buf, need_bwd: bool, h_out):
+        """h_out = h_mid + down(silu(gate(x2)) * up(x2)); returns what _mlp_bwd reads."""
+        gu, act = buf["gu"], buf["act"]
+        if need_bwd:      # one launch: activation + the saved pre-activations [gate | up]
+            ops.gemm_nt(x2, L.wgu, out=act, epilogue=EPI_SWIGLU_STACKED_SAVE, residual=gu)
+        else:
+            ops.gemm_nt(x2, L.wgu, out=act, epilogue=EPI_SWIGLU_STACKED)
+        ops.gemm_nt(act, L.wdown.data, out=h_out, epilogue=EPI_RESIDUAL, residual=h_mid)
+        return dict(gu=gu, act=act)
+
+    def _mlp_bwd(self, li: int, L, sv, dh):
+        """Accumulates the MLP's weight gradients; returns d loss / d x2 ([T,H], the input of the MLP = post-attention norm output)."""
+        # d_act = dh @ Wdown with the SwiGLU backward in the epilogue: [T, 2I] = [d_gate | d_up] straight from the accumulators
+        dgu = ops.gemm_nt(dh, self._wt(li, "down", L.wdown), epilogue=EPI_SWIGLU_BWD, residual=sv["gu"])
+        self._wgrad(dh, sv["act"], L.gdown, ("dh", "act"))
+        dx2 = ops.gemm_nt(dgu, self._wt(li, "gu", L.wgu))                           # [T,H]
+        self._wgrad(dgu, sv["x2"], L.ggu, ("dgu", "x"))
+        return dx2
 
     # ------------------------------------------------------------------ parameter packing
     def _pack(self, params):
@@ -143,9 +180,8 @@ class MistralTrainEngine:
         for L in self.layers:
             at, mlp, layer = L.mods
             L.gqkv = self._packed_grad([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], L.gqkv)
-            L.ggu = self._packed_grad([mlp.gate_proj.weight, mlp.up_proj.weight], L.ggu)
             L.go = self._packed_grad([at.o_proj.weight], L.go)
-            L.gdown = self._packed_grad([mlp.down_proj.weight], L.gdown)
+            self._prepare_mlp_grads(L)
         # 1-D parameters and the embedding: plain .grad tensors
         for p in [self.embed, self.norm] + [x for L in self.layers for x in (L.ln1, L.ln2)]:
             if p.grad is None:
@@ -192,14 +228,21 @@ class MistralTrainEngine:
         keyed on the owning Parameters' version counters, so an in-place optimizer update invalidates it even
         if ``weights_updated()`` is never called."""
         key = (li, name)
-        at, mlp, _ = self.layers[li].mods
-        owners = {"qkv": (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), "o": (at.o_proj.weight,),
-                  "gu": (mlp.gate_proj.weight, mlp.up_proj.weight), "down": (mlp.down_proj.weight,)}[name]
+        at, _, _ = self.layers[li].mods
+        if name == "qkv":
+            owners = (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight)
+        elif name == "o":
+            owners = (at.o_proj.weight,)
+        else:
+            owners = self._mlp_owners(li, name)
         ver = tuple(p._version for p in owners)       # the Parameters' counters (the packed base tensor's own counter does not see them)
         hit = self._wT.get(key) if self.cache_transposed_weights else None
         if hit is not None and hit[0] == ver:
             return hit[1]
-        t = ops.transpose(w.data)
+        if w.dim() == 3:                              # stacked expert weights [E,N,K] -> [E,K,N]
+            t = torch.stack([ops.transpose(w.data[e]) for e in range(w.shape[0])])
+        else:
+            t = ops.transpose(w.data)
         if self.cache_transposed_weights:
             self._wT[key] = (ver, t)
         return t
@@ -220,7 +263,7 @@ class MistralTrainEngine:
         c = self.cfg
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         T, dev = geom.T, self.device
-        x1, qkv, ctx, x2, act = buf["x1"], buf["qkv"], buf["ctx"], buf["x2"], buf["act"]
+        x1, qkv, ctx, x2 = buf["x1"], buf["qkv"], buf["ctx"], buf["x2"]
         ops.rmsnorm(h, L.ln1.data, eps, out=x1)
         if geom.packed:
             lse = torch.empty((T, nq), dtype=F32, device=dev) if need_bwd else None
@@ -236,15 +279,11 @@ class MistralTrainEngine:
             h_mid = h_out if h_out is not None else h
         ops.gemm_nt(ctx, L.wo.data, out=h_mid, epilogue=EPI_RESIDUAL, residual=h)
         ops.rmsnorm(h_mid, L.ln2.data, eps, out=x2)
-        gu = buf["gu"]
-        if need_bwd:      # one launch: activation + the saved pre-activations [gate | up]
-            ops.gemm_nt(x2, L.wgu, out=act, epilogue=EPI_SWIGLU_STACKED_SAVE, residual=gu)
-        else:
-            ops.gemm_nt(x2, L.wgu, out=act, epilogue=EPI_SWIGLU_STACKED)
         if h_out is None:
             h_out = h_mid
-        ops.gemm_nt(act, L.wdown.data, out=h_out, epilogue=EPI_RESIDUAL, residual=h_mid)
-        return dict(h_in=h, x1=x1, qkv=qkv, ctx=ctx, lse=lse, h_mid=h_mid, x2=x2, gu=gu, act=act, h_out=h_out)
+        sv = dict(h_in=h, x1=x1, qkv=qkv, ctx=ctx, lse=lse, h_mid=h_mid, x2=x2, h_out=h_out)
+        sv.update(self._mlp_fwd(L, h_mid, x2, buf, need_bwd, h_out))
+        return sv
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, save: bool, packed: bool = False, causal: bool = False):
@@ -378,12 +417,8 @@ class MistralTrainEngine:
                 if rc_buf is None:
                     rc_buf, rc_out = self._layer_buffers(T, with_gu=True), torch.empty((T, H), dtype=BF16, device=self.device)
                 sv = self._layer_fwd(L, sv["h_in"], geom, B, S, cos, sin, rc_buf, need_bwd=True, h_out=rc_out)
-            # ---- MLP: h_out = h_mid + down(silu(gate) * up)
-            # d_act = dh @ Wdown with the SwiGLU backward in the epilogue: [T, 2I] = [d_gate | d_up] straight from the accumulators
-            dgu = ops.gemm_nt(dh, self._wt(li, "down", L.wdown), epilogue=EPI_SWIGLU_BWD, residual=sv["gu"])
-            self._wgrad(dh, sv["act"], L.gdown, ("dh", "act"))
-            dx2 = ops.gemm_nt(dgu, self._wt(li, "gu", L.wgu))                           # [T,H]
-            self._wgrad(dgu, sv["x2"], L.ggu, ("dgu", "x"))
+            # ---- MLP: h_out = h_mid + mlp(x2)
+            dx2 = self._mlp_bwd(li, L, sv, dh)
             dh_mid = ops.rmsnorm_bwd(dx2, sv["h_mid"], L.ln2.data, eps, ng[2 * li + 1], dres=dh)
             # ---- attention: h_mid = h_in + o_proj(attn(rope(qkv(x1))))
             dctx = ops.gemm_nt(dh_mid, self._wt(li, "o", L.wo))                         # [T,nq*d]
@@ -398,7 +433,7 @@ class MistralTrainEngine:
             self._wgrad(dqkv, sv["x1"], L.gqkv, ("dqkv", "x"))
             dh = ops.rmsnorm_bwd(dx1, sv["h_in"], L.ln1.data, eps, ng[2 * li], dres=dh_mid)
             if on_layer_done is not None:
-                on_layer_done([L.gqkv, L.go, L.ggu, L.gdown])
+                on_layer_done(self._layer_grads(L))
         # ---- embedding + fold the fp32 side accumulators into the bf16 .grad tensors
         if self._f32_embed_grad is None:
             self._f32_embed_grad = torch.zeros(tuple(self.embed.shape), dtype=F32, device=self.device)
@@ -417,10 +452,100 @@ class MistralTrainEngine:
         self.prepare_grads()
         out = []
         for L in self.layers:
-            out += ([] if small_only else [L.gqkv, L.go, L.ggu, L.gdown]) + [L.ln1.grad, L.ln2.grad]
+            out += ([] if small_only else self._layer_grads(L)) + [L.ln1.grad, L.ln2.grad]
         if self.lm_head is not None and self.lm_head.grad is not None:
             out.append(self.lm_head.grad)
         return out + [self.embed.grad, self.norm.grad]
+
+
+class MixtralTrainEngine(MistralTrainEngine):
+    """The same engine on a Hugging Face ``MixtralModel`` (transformers >= 5 layout: ``mlp.gate.weight [E,H]``,
+    ``mlp.experts.gate_up_proj [E,2I,H]`` = [gate rows | up rows] per expert, ``mlp.experts.down_proj [E,H,I]``): attention, norms and
+    the residual stream are the base class's; the MLP is the sparse-MoE block of scripts/modeling_mixtral_gritlm.py:815-882
+    (softmax -> top-2 -> renormalise routing, per-expert SwiGLU MLP, weighted sum) with its autograd:
+
+      forward   route (kernel) -> grouped gate|up GEMM on the token-sorted rows (SwiGLU + saved pre-activations in the epilogue,
+                straight on the fused ``gate_up_proj`` parameter) -> grouped down GEMM -> weighted combine + residual
+      backward  combine backward (dy = w * dh[token], dw = <y, dh[token]>) -> grouped dgrad with the SwiGLU backward in the epilogue
+                -> grouped dgrad to the sorted inputs -> sum of a token's two rows; per-expert weight gradients with the dense NT
+                GEMM on the expert's row segment (ONE host sync per layer for the 8 row counts -- the training GEMMs are
+                milliseconds long; the inference path stays sync-free); the router's softmax / top-2 / renormalise backward and
+                its two skinny GEMMs ([T,E] x [E,H]) run as torch fp32 ops on the [T,E] logits.
+
+    The router auxiliary loss (load_balancing_loss_func, :80-153) is not part of this path: the reference adds it only inside
+    MixtralForCausalLM.forward when ``output_router_logits`` is set (default off), never for the embedding tower."""
+
+    def _bind_mlp(self, L, mlp):
+        ex = mlp.experts
+        L.wgu, L.wdown, L.wgate = ex.gate_up_proj, ex.down_proj, mlp.gate.weight
+        c = self.cfg
+        E, H, I = c.num_local_experts, c.hidden_size, c.intermediate_size
+        if tuple(L.wgu.shape) != (E, 2 * I, H) or tuple(L.wdown.shape) != (E, H, I) or tuple(L.wgate.shape) != (E, H):
+            raise RuntimeError(f"MixtralTrainEngine: unexpected expert parameter shapes {tuple(L.wgu.shape)}, {tuple(L.wdown.shape)}, "
+                               f"{tuple(L.wgate.shape)} (fused gate_up_proj / down_proj layout of transformers >= 5 expected)")
+
+    def _prepare_mlp_grads(self, L):
+        for p in (L.wgu, L.wdown, L.wgate):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        L.ggu, L.gdown = L.wgu.grad, L.wdown.grad
+
+    def _mlp_owners(self, li: int, name: str):
+        L = self.layers[li]
+        return {"gu": (L.wgu,), "down": (L.wdown,)}[name]
+
+    def _layer_grads(self, L) -> list[torch.Tensor]:
+        return [L.gqkv, L.go, L.ggu, L.gdown, L.wgate.grad]
+
+    def _layer_buffers(self, T: int, with_gu: bool):
+        c = self.cfg
+        buf = super()._layer_buffers(T, with_gu=False)
+        mk = lambda n: torch.empty((2 * T, n), dtype=BF16, device=self.device)      # every token visits two experts
+        buf["act"], buf["y"] = mk(c.intermediate_size), mk(c.hidden_size)
+        buf["gu"] = mk(2 * c.intermediate_size) if with_gu else None
+        if with_gu:
+            buf["h_mid"] = torch.empty((T, c.hidden_size), dtype=BF16, device=self.device)
+        return buf
+
+    def _mlp_fwd(self, L, h_mid, x2, buf, need_bwd: bool, h_out):
+        T = x2.shape[0]
+        experts, weights, counts, row_token, rows = ops.moe_route(x2, L.wgate.data)
+        gu, act, y = buf["gu"], buf["act"], buf["y"]
+        if need_bwd:
+            ops.gemm_nt_grouped_epi(x2, L.wgu.data, counts, 2 * T, EPI_SWIGLU_STACKED_SAVE, out=act, residual=gu, a_rows=row_token)
+        else:
+            ops.gemm_nt_grouped_epi(x2, L.wgu.data, counts, 2 * T, EPI_SWIGLU_STACKED, out=act, a_rows=row_token)
+        ops.gemm_nt_grouped_epi(act, L.wdown.data, counts, 2 * T, EPI_STORE, out=y)
+        ops.moe_combine(y, rows, weights, h_mid, out=h_out)
+        return dict(gu=gu, act=act, y=y, experts=experts, weights=weights, counts=counts, row_token=row_token, rows=rows)
+
+    def _mlp_bwd(self, li: int, L, sv, dh):
+        T, H = dh.shape
+        counts, row_token, rows = sv["counts"], sv["row_token"], sv["rows"]
+        dy, dw = ops.moe_combine_bwd(dh, sv["y"], row_token, rows, sv["weights"])                       # [2T,H] bf16, [T,2] fp32
+        dgu = ops.gemm_nt_grouped_epi(dy, self._wt(li, "down", L.wdown), counts, 2 * T, EPI_SWIGLU_BWD, residual=sv["gu"])   # [2T,2I]
+        dxs = ops.gemm_nt_grouped_epi(dgu, self._wt(li, "gu", L.wgu), counts, 2 * T, EPI_STORE)                            # [2T,H]
+        ones = torch.ones((T, 2), dtype=F32, device=self.device)
+        dx2 = ops.moe_combine(dxs, rows, ones, None)                                                    # a token's two routed rows
+        # ---- per-expert weight gradients on the expert's row segment
+        x_sorted = sv["x2"].index_select(0, row_token.to(torch.int64))
+        off = 0
+        for e, n in enumerate(counts.tolist()):
+            if n:
+                seg = slice(off, off + n)
+                self._wgrad(dy[seg], sv["act"][seg], L.gdown[e], ("dy_e", "act_e"))
+                self._wgrad(dgu[seg], x_sorted[seg], L.ggu[e], ("dgu_e", "x_e"))
+                off += n
+        # ---- router: w = renormalised top-2 of softmax(x2 Wg^T); d w arrives from the combine backward
+        with torch.enable_grad():
+            xf = sv["x2"].detach().to(F32).requires_grad_(True)
+            wg = L.wgate.detach().to(F32).requires_grad_(True)
+            p = torch.softmax(xf @ wg.t(), dim=-1)
+            sel = torch.gather(p, 1, sv["experts"].to(torch.int64))
+            w = sel / sel.sum(dim=-1, keepdim=True)
+            (w * dw).sum().backward()
+        L.wgate.grad.add_(wg.grad.to(BF16))
+        return (dx2.to(F32) + xf.grad).to(BF16)
 
 
 class SyntheticBackbone(torch.nn.Module):

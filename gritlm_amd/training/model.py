@@ -212,16 +212,17 @@ class GritLMTrainModel(GritLM):
     # ------------------------------------------------------------------ native engine
     def enable_native(self, device=None):
         """Bind the HIP training engine to the backbone (after the model sits on its device in bf16)."""
-        from .engine import MistralTrainEngine
+        from .engine import MistralTrainEngine, MixtralTrainEngine
         dev = torch.device(device if device is not None else self.device)
         cfg = self.model.config
-        if not (dev.type == "cuda" and getattr(cfg, "model_type", "") == "mistral" and self.attn[:2] == "bb"
-                and self.model.dtype == torch.bfloat16):
-            raise RuntimeError(f"native training engine needs a bf16 Mistral on a HIP device with 'bb' attention "
+        mtype = getattr(cfg, "model_type", "")
+        if not (dev.type == "cuda" and mtype in ("mistral", "mixtral") and self.attn[:2] == "bb" and self.model.dtype == torch.bfloat16):
+            raise RuntimeError(f"native training engine needs a bf16 Mistral / Mixtral on a HIP device with 'bb' attention "
                                f"(got device={dev}, model_type={getattr(cfg, 'model_type', None)}, attn={self.attn}, dtype={self.model.dtype})")
         self.model.to(dev)
         # a causal-LM wrapper (mode unified / generative) also hands its lm_head to the engine: generative branch on HIP kernels
-        self.train_engine = MistralTrainEngine(self._backbone(), cfg, dev, lm_head=getattr(self.model, "lm_head", None))
+        engine_cls = MixtralTrainEngine if mtype == "mixtral" else MistralTrainEngine
+        self.train_engine = engine_cls(self._backbone(), cfg, dev, lm_head=getattr(self.model, "lm_head", None))
         return self.train_engine
 
     def encode(self, features):

@@ -149,6 +149,20 @@ int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t* counts, in
 int grit_moe_combine(const void* y, const int32_t* rows, const float* weights, const void* residual, void* out, int64_t T,
                      int H, void* stream);
 
+/* Backward of grit_moe_combine (autograd of `final_hidden_states += expert_out * routing_weight`, scripts/modeling_mixtral_gritlm.py
+ * :861-880): for every routed row r (2T of them): dy[r] = bf16(w(r) * dout[token(r)]); dw[token(r), slot(r)] = <y[r], dout[token(r)]>
+ * in fp32.  dout [T,H] bf16, y [2T,H] bf16 (the expert outputs of the forward, sorted row order), dy [2T,H] bf16, dw [T,2] fp32. */
+int grit_moe_combine_bwd(const void* dout, const void* y, const int32_t* row_token, const int32_t* rows, const float* weights,
+                         void* dy, float* dw, int64_t T, int H, void* stream);
+
+/* grit_gemm_bf16_nt_grouped with the training epilogues of the expert MLP (forward with saved pre-activations, backward):
+ * STORE, SWIGLU, SWIGLU_STACKED (w = [gate rows; up rows] per expert, the layout of `experts.gate_up_proj`), SWIGLU_STACKED_SAVE
+ * (additionally writes bf16 [gate | up] of every sorted row through `residual`, ldr >= N), SWIGLU_BWD (C = [d_gate | d_up] from the
+ * saved [gate | up] in `residual`, ldr >= 2N, ldc >= 2N).  Per group the semantics of grit_gemm_bf16_nt. */
+int grit_gemm_bf16_nt_grouped_epi(const void* A, const int32_t* a_rows, const void* W, void* C, const void* residual,
+                                  const int32_t* group_counts, int num_groups, int64_t M_total, int N, int K, int64_t lda,
+                                  int64_t ldw, int64_t w_group_stride, int64_t ldc, int64_t ldr, int epilogue, void* stream);
+
 /* Causal variants (key <= query in addition to the key-padding mask): the generative branch of unified training
  * (MistralSdpaAttention with is_causal=True; causal mask :1005-1031).  Same layouts as the bidirectional entry points. */
 int grit_attn_causal_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,

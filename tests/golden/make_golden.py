@@ -221,6 +221,62 @@ def gen_train_7b_l1():
     print(f"  train 7b-l1: loss {out.loss.item():.6f}")
 
 
+def gen_train_mixtral(cfg_name="moe-tiny", seed_w=0):
+    """Contrastive step of the reference on the bidirectional Mixtral (scripts/modeling_mixtral_gritlm.py: sparse-MoE MLP :815-882,
+    autograd through the routing weights) -- GritLMTrainModel.forward + backward, fp32 and bf16 on CPU: loss, reps, every gradient
+    (reference parameter names), and the routing both runs took."""
+    from gritlm.training.model import GritLMTrainModel, DistributedContrastiveLoss
+    mod = load_ref_mixtral()
+    cfg = synth.CONFIGS[cfg_name]
+    qi, qm = synth.make_batch(cfg, 4, 40, 51, min_len=9)
+    pi, pm = synth.make_batch(cfg, 8, 64, 52, min_len=16)
+    res = dict(cfg_name=cfg_name, seed_w=seed_w, q_ids=qi, q_mask=qm, p_ids=pi, p_mask=pm, tau=np.float32(0.02), group=2)
+    grads = {}
+    for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        hc = synth.hf_config(cfg)
+        hc.use_cache = False
+        hc._attn_implementation = "sdpa"
+        model = mod.MixtralModel(hc)
+        w = synth.make_weights(cfg, seed_w)
+        missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+        assert not unexpected and all("rotary" in m_ or "inv_freq" in m_ for m_ in missing), (missing, unexpected)
+        model = model.to(dtype).train()
+        m = GritLMTrainModel.__new__(GritLMTrainModel)
+        torch.nn.Module.__init__(m)
+        wrap = torch.nn.Module(); wrap.model = model
+        m.model = wrap; m.embedding_attr = "model"; m.projection = None
+        m.normalized = True; m.pooling_method = "mean"; m.attn = "bbcc"
+        m.emb_loss_fn = DistributedContrastiveLoss(0.02, False)
+        m.gen_loss_fn = None; m.gen_add_kwargs = {}
+        sel = []
+        hooks = [layer.block_sparse_moe.register_forward_hook(
+            lambda _m, _i, o: sel.append(torch.topk(torch.softmax(o[1].float(), dim=1), 2, dim=-1)[1])) for layer in model.layers]
+        out = m(query={"input_ids": torch.from_numpy(qi), "attention_mask": torch.from_numpy(qm)},
+                passage={"input_ids": torch.from_numpy(pi), "attention_mask": torch.from_numpy(pm)})
+        for hk in hooks:
+            hk.remove()
+        out.loss.backward()
+        res[f"loss_{tag}"] = np.float32(out.loss.item())
+        res[f"q_reps_{tag}"] = out.q_reps.detach().float().numpy()
+        res[f"p_reps_{tag}"] = out.p_reps.detach().float().numpy()
+        grads[tag] = {n: p.grad.float().numpy() for n, p in model.named_parameters()}
+        # hook order: query tower (layer 0, 1, ...) then passage tower
+        nl = len(model.layers)
+        res[f"routing_q_{tag}"] = torch.stack(sel[:nl]).numpy()
+        res[f"routing_p_{tag}"] = torch.stack(sel[nl:]).numpy()
+        print(f"  train {cfg_name} [{tag}]: loss {out.loss.item():.5f}")
+    worst = max(float(np.linalg.norm(grads["bf16"][k] - grads["f32"][k]) / (np.linalg.norm(grads["f32"][k]) + 1e-20)) for k in grads["f32"])
+    print(f"  reference bf16-vs-fp32 gradients: worst relative l2 {worst:.3e}")
+    res["ref_bf16_vs_f32_worst_rel_l2"] = np.float32(worst)
+    # the fixture keeps every gradient norm (both runs) and the fp32 gradients of everything except experts 1-4, 6, 7 (25 MB otherwise)
+    for n, g in grads["f32"].items():
+        res["gnorm_f32/" + n] = np.float32(np.linalg.norm(g))
+        res["gnorm_bf16/" + n] = np.float32(np.linalg.norm(grads["bf16"][n]))
+        if ".experts." not in n or ".experts.0." in n or ".experts.5." in n:
+            res["grad_f32/" + n] = g
+    np.savez_compressed(os.path.join(HERE, f"train_{cfg_name}.npz"), **res)
+
+
 def gen_pooling():
     rng = np.random.default_rng(7)
     hidden = rng.standard_normal((5, 9, 24), dtype=np.float32)
@@ -442,6 +498,8 @@ if __name__ == "__main__":
         gen_generative(); sys.exit(0)
     if sys.argv[1:] == ["7b-l1"]:            # only the 7B-layer-shape fixtures (1.4 GB of fp32 weights, ~2 min on 8 cores)
         gen_encoder_7b_l1(); gen_train_7b_l1(); sys.exit(0)
+    if sys.argv[1:] == ["train-mixtral"]:
+        gen_train_mixtral(); sys.exit(0)
     if sys.argv[1:] == ["train-7b-l1"]:
         gen_train_7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
@@ -458,4 +516,5 @@ if __name__ == "__main__":
     print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
     print("encoder 7b-l1"); gen_encoder_7b_l1()
     print("train 7b-l1"); gen_train_7b_l1()
+    print("train mixtral"); gen_train_mixtral()
     print("done")

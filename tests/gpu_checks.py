@@ -852,6 +852,77 @@ def check_train_step_7b_layer():
     return _res("native train step [7b-l1: direct / gradcache / recompute] vs reference loss+grads", bool(ok), **out)
 
 
+def check_train_step_mixtral(mode="direct"):
+    """Native contrastive step on the bidirectional MIXTRAL (sparse-MoE MLP forward with saved pre-activations, MoE backward: combine
+    backward, grouped dgrads with the SwiGLU backward in the epilogue, per-expert weight gradients, router backward) vs the
+    REFERENCE's loss, representations and parameter gradients (tests/golden/train_moe-tiny.npz: GritLMTrainModel.forward + backward
+    around scripts/modeling_mixtral_gritlm.py, fp32 and bf16 on CPU).  Gradients: relative l2 vs the fp32 run below 6e-2 (the
+    reference's own bf16 run is 2.8e-2 away); every parameter's gradient norm within 5e-2."""
+    import tempfile
+    from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+    g = np.load(os.path.join(GOLDEN, "train_moe-tiny.npz"))
+    I = synth.CONFIGS["moe-tiny"]["intermediate_size"]
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mixtral_dir(os.path.join(td, "m16"), "moe-tiny", 0, "bfloat16")
+        m = GritLMTrainModel(model_name_or_path=d16, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=float(g["tau"]), negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16)
+        m.enable_native()
+        from gritlm_amd.training.engine import MixtralTrainEngine
+        ok &= isinstance(m.train_engine, MixtralTrainEngine)
+        q = {"input_ids": torch.from_numpy(g["q_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["q_mask"]).to(DEV)}
+        p = {"input_ids": torch.from_numpy(g["p_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["p_mask"]).to(DEV)}
+        if mode == "direct":
+            o = m(query=q, passage=p)
+            loss = o.loss
+            loss.backward()
+            for nm, r in (("q", o.q_reps), ("p", o.p_reps)):
+                c = float(np.max(1 - np.sum(f32(r) * g[nm + "_reps_f32"], axis=1)))
+                out[f"{nm}_reps_1-cos"] = c
+                ok &= c < 2e-4          # bf16 routing flips a few near-tied tokens (the reference's own bf16 run: see the fixture)
+            out["ref_bf16_q_1-cos"] = float(np.max(1 - np.sum(g["q_reps_bf16"] * g["q_reps_f32"], axis=1)))
+        else:
+            if mode == "recompute":
+                m.gradient_checkpointing_enable()
+            loss = GradCacheStep(m, chunk_size=2)(q, p)
+        lv = float(loss.item())
+        out["loss"], out["loss_ref_f32"], out["loss_ref_bf16"] = lv, float(g["loss_f32"]), float(g["loss_bf16"])
+        ok &= abs(lv - float(g["loss_f32"])) < 2e-3 * max(1.0, abs(float(g["loss_f32"])))
+        sd = dict(m._backbone().named_parameters())
+
+        def ours(ref_name):
+            """gradient of the reference-named parameter out of the fused transformers >= 5 parameters"""
+            if "block_sparse_moe" not in ref_name:
+                return f32(sd[ref_name].grad)
+            pre, rest = ref_name.split(".block_sparse_moe.")
+            if rest == "gate.weight":
+                return f32(sd[pre + ".mlp.gate.weight"].grad)
+            _, e, w, _ = rest.split(".")            # experts.E.w1.weight
+            e = int(e)
+            if w == "w2":
+                return f32(sd[pre + ".mlp.experts.down_proj"].grad[e])
+            gu = sd[pre + ".mlp.experts.gate_up_proj"].grad[e]
+            return f32(gu[:I] if w == "w1" else gu[I:])
+
+        worst, worst_name, worst_norm = 0.0, "", 0.0
+        for k in g.files:
+            if k.startswith("grad_f32/"):
+                n = k[len("grad_f32/"):]
+                ref = g[k]
+                rel = float(np.linalg.norm(ours(n) - ref) / (np.linalg.norm(ref) + 1e-20))
+                if rel > worst:
+                    worst, worst_name = rel, n
+            elif k.startswith("gnorm_f32/"):
+                n = k[len("gnorm_f32/"):]
+                rn = float(g[k])
+                if rn > 1e-6:
+                    worst_norm = max(worst_norm, abs(float(np.linalg.norm(ours(n))) - rn) / rn)
+        out["worst_grad_rel_l2"], out["worst_grad"], out["worst_norm_rel"] = worst, worst_name.replace("block_sparse_moe", "moe"), worst_norm
+        out["ref_bf16_vs_f32"] = float(g["ref_bf16_vs_f32_worst_rel_l2"])
+        ok &= worst < 6e-2 and worst_norm < 5e-2
+    return _res(f"native Mixtral train step [{mode}] vs reference loss+grads", bool(ok), **out)
+
+
 def check_train_packed_vs_padded(cfg_name="gqa"):
     """One contrastive step with the packed (un-padded) training path vs the padded one: identical reps and loss, parameter
     gradients equal up to the bf16 accumulation order of the wgrad GEMMs (K = tokens, padded rows contribute exact zeros)."""
@@ -1633,6 +1704,9 @@ ALL_CHECKS = [
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
     ("train_7b_layer", check_train_step_7b_layer, {}),
+    ("train_mixtral_direct", check_train_step_mixtral, dict(mode="direct")),
+    ("train_mixtral_gradcache", check_train_step_mixtral, dict(mode="gradcache")),
+    ("train_mixtral_recompute", check_train_step_mixtral, dict(mode="recompute")),
     ("train_packed_vs_padded", check_train_packed_vs_padded, {}),
     ("train_recompute", check_train_recompute, {}),
     ("swiglu_stacked", check_swiglu_stacked, {}),
