@@ -476,6 +476,9 @@ class MixtralTrainEngine(MistralTrainEngine):
     MixtralForCausalLM.forward when ``output_router_logits`` is set (default off), never for the embedding tower."""
 
     def _bind_mlp(self, L, mlp):
+        if getattr(getattr(self.backbone, "config", None), "output_router_logits", False):
+            # reference: MixtralForCausalLM.forward adds router_aux_loss_coef * load_balancing_loss_func(...) (:80-153, :1390-1400)
+            raise NotImplementedError("MixtralTrainEngine: config.output_router_logits=True (router auxiliary loss) is not built")
         ex = mlp.experts
         L.wgu, L.wdown, L.wgate = ex.gate_up_proj, ex.down_proj, mlp.gate.weight
         c = self.cfg

@@ -852,6 +852,56 @@ def check_train_step_7b_layer():
     return _res("native train step [7b-l1: direct / gradcache / recompute] vs reference loss+grads", bool(ok), **out)
 
 
+def check_grouped_training_epilogues(E=4, H=256, I=512, counts=(300, 0, 129, 71)):
+    """grit_gemm_bf16_nt_grouped_epi (the expert MLP of Mixtral training) against the dense kernel group by group, bit for bit:
+    SWIGLU_STACKED_SAVE with the token gather (a_rows), STORE, SWIGLU_BWD; an empty group in the middle; + moe_combine_bwd vs torch."""
+    from gritlm_amd._lib import EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE
+    M = int(sum(counts))
+    T = M // 2
+    rng = np.random.default_rng(77)
+    x = bf(rnd((T, H), 1))
+    a_rows = torch.from_numpy(rng.integers(0, T, M).astype(np.int32)).to(DEV)
+    wgu, wdn = bf(rnd((E, 2 * I, H), 2, 0.05)), bf(rnd((E, H, I), 3, 0.05))
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    gu = torch.zeros((M, 2 * I), dtype=torch.bfloat16, device=DEV)
+    act = ops.gemm_nt_grouped_epi(x, wgu, cnt, M, EPI_SWIGLU_STACKED_SAVE, residual=gu, a_rows=a_rows)
+    act2 = ops.gemm_nt_grouped_epi(x, wgu, cnt, M, EPI_SWIGLU_STACKED, a_rows=a_rows)
+    y = ops.gemm_nt_grouped_epi(act, wdn, cnt, M, EPI_STORE)
+    dy = bf(rnd((M, H), 4))
+    wdnT = torch.stack([ops.transpose(wdn[e]) for e in range(E)])               # [E, I, H]
+    dgu = ops.gemm_nt_grouped_epi(dy, wdnT, cnt, M, EPI_SWIGLU_BWD, residual=gu)
+    ok, off = bool(torch.equal(act, act2)), 0
+    xg = x.index_select(0, a_rows.to(torch.int64))
+    for e, n in enumerate(counts):
+        if n == 0:
+            continue
+        seg = slice(off, off + n)
+        gu_e = torch.zeros((n, 2 * I), dtype=torch.bfloat16, device=DEV)
+        act_e = ops.gemm_nt(xg[seg].contiguous(), wgu[e], epilogue=EPI_SWIGLU_STACKED_SAVE, residual=gu_e)
+        ok &= bool(torch.equal(act_e, act[seg])) and bool(torch.equal(gu_e, gu[seg]))
+        ok &= bool(torch.equal(ops.gemm_nt(act[seg].contiguous(), wdn[e]), y[seg]))
+        ok &= bool(torch.equal(ops.gemm_nt(dy[seg].contiguous(), wdnT[e], epilogue=EPI_SWIGLU_BWD, residual=gu[seg].contiguous()), dgu[seg]))
+        off += n
+    # combine backward vs torch: routed rows of token t are rows[t,0], rows[t,1]
+    Tt = 37
+    perm = torch.from_numpy(rng.permutation(2 * Tt).astype(np.int32)).to(DEV)
+    rows = perm.view(Tt, 2).contiguous()
+    row_token = torch.empty((2 * Tt,), dtype=torch.int32, device=DEV)
+    row_token[rows.view(-1).to(torch.int64)] = torch.arange(Tt, device=DEV, dtype=torch.int32).repeat_interleave(2)
+    wts = torch.from_numpy(rng.random((Tt, 2), dtype=np.float32)).to(DEV)
+    dout, yy = bf(rnd((Tt, H), 5)), bf(rnd((2 * Tt, H), 6))
+    dyy, dw = ops.moe_combine_bwd(dout, yy, row_token, rows, wts)
+    w_sorted = torch.empty((2 * Tt,), dtype=torch.float32, device=DEV)
+    w_sorted[rows.view(-1).to(torch.int64)] = wts.view(-1)
+    dg = dout.index_select(0, row_token.to(torch.int64)).float()
+    dy_ref = (dg * w_sorted[:, None]).to(torch.bfloat16)
+    dw_ref = (dg * yy.float()).sum(-1)[rows.view(-1).to(torch.int64)].view(Tt, 2)
+    ok &= bool(torch.equal(dyy, dy_ref))
+    e_dw = float((dw - dw_ref).abs().max() / (dw_ref.abs().max() + 1e-9))
+    ok &= e_dw < 1e-5
+    return _res("grouped training epilogues == dense per group; combine backward vs torch", ok, dw_rel=e_dw)
+
+
 def check_train_step_mixtral(mode="direct"):
     """Native contrastive step on the bidirectional MIXTRAL (sparse-MoE MLP forward with saved pre-activations, MoE backward: combine
     backward, grouped dgrads with the SwiGLU backward in the epilogue, per-expert weight gradients, router backward) vs the
@@ -1336,14 +1386,17 @@ def check_knn_topk(Q=5, N=10000, H=256, k=10, transposed=False):
     return _res(f"knn_topk[Q={Q},N={N},H={H},k={k},transposed={transposed}]", bool(ok), max_score_err=float(np.max(np.abs(sc - ref_sc))))
 
 
-def check_cli_native():
-    """python -m gritlm.training.run on the GPU: bf16 tiny Mistral, (instruction, text) rows, GradCache switch, native engine."""
+def check_cli_native(arch="mistral"):
+    """python -m gritlm.training.run on the GPU: bf16 tiny Mistral (or Mixtral), (instruction, text) rows, GradCache switch, native engine."""
     import json
     import tempfile
     from gritlm.training.run import main
     W = synth.WORDS
     with tempfile.TemporaryDirectory() as td:
-        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        if arch == "mixtral":
+            d16 = synth.build_mixtral_dir(os.path.join(td, "m16"), "moe-tiny", 0, "bfloat16")
+        else:
+            d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
         rows = []
         for i in range(0, 64, 2):
             negs = [["w3", " ".join(W[j:j + 7])] for j in range(i + 20, i + 27)]
@@ -1358,10 +1411,10 @@ def check_cli_native():
         l8 = main(common + ["--max_steps", "8"])
         files = os.listdir(out)
     ok = np.isfinite(l1) and np.isfinite(l8) and l8 < l1 and "config.json" in files
-    return _res("CLI gritlm.training.run native (loss decreases over 8 steps)", ok, loss_step1=float(l1), loss_step8=float(l8))
+    return _res(f"CLI gritlm.training.run native [{arch}] (loss decreases over 8 steps)", ok, loss_step1=float(l1), loss_step8=float(l8))
 
 
-def check_cli_unified_native():
+def check_cli_unified_native(arch="mistral"):
     """python -m gritlm.training.run --mode unified on the GPU: generative branch (causal kernels + lm_head + CE) and the GradCache
     embedding step both on the native engine; both losses fall over 8 steps."""
     import json
@@ -1369,7 +1422,10 @@ def check_cli_unified_native():
     from gritlm.training import run
     W = synth.WORDS
     with tempfile.TemporaryDirectory() as td:
-        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        if arch == "mixtral":
+            d16 = synth.build_mixtral_dir(os.path.join(td, "m16"), "moe-tiny", 0, "bfloat16")
+        else:
+            d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
         os.makedirs(os.path.join(td, "data"))
         rows = []
         for i in range(0, 64, 2):
@@ -1386,7 +1442,7 @@ def check_cli_unified_native():
         l1 = run.main(common + ["--max_steps", "1"]); g1 = run.main.last_loss_gen
         l8 = run.main(common + ["--max_steps", "8"]); g8 = run.main.last_loss_gen
     ok = all(np.isfinite(v) for v in (l1, l8, g1, g8)) and l8 < l1 and g8 < g1
-    return _res("CLI --mode unified native (emb + gen losses decrease over 8 steps)", bool(ok), loss_emb_1=float(l1), loss_emb_8=float(l8),
+    return _res(f"[{arch}] CLI --mode unified native (emb + gen losses decrease over 8 steps)", bool(ok), loss_emb_1=float(l1), loss_emb_8=float(l8),
                 loss_gen_1=float(g1), loss_gen_8=float(g8))
 
 
@@ -1704,6 +1760,7 @@ ALL_CHECKS = [
     ("train_direct", check_train_step, dict(mode="direct")),
     ("train_gradcache", check_train_step, dict(mode="gradcache")),
     ("train_7b_layer", check_train_step_7b_layer, {}),
+    ("grouped_training_epilogues", check_grouped_training_epilogues, {}),
     ("train_mixtral_direct", check_train_step_mixtral, dict(mode="direct")),
     ("train_mixtral_gradcache", check_train_step_mixtral, dict(mode="gradcache")),
     ("train_mixtral_recompute", check_train_step_mixtral, dict(mode="recompute")),
@@ -1735,6 +1792,8 @@ ALL_CHECKS = [
     ("knn_topk_transposed_big", check_knn_topk, dict(Q=3, N=300000, H=128, k=100, transposed=True)),
     ("knn_topk_small", check_knn_topk, dict(Q=2, N=37, H=64, k=37)),
     ("cli_native", check_cli_native, {}),
+    ("cli_native_mixtral", check_cli_native, dict(arch="mixtral")),
     ("cli_unified_native", check_cli_unified_native, {}),
+    ("cli_unified_native_mixtral", check_cli_unified_native, dict(arch="mixtral")),
     ("overlapped_grad_sync", check_overlapped_grad_sync, {}),
 ]

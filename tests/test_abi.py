@@ -54,6 +54,12 @@ def test_bad_arguments_of_the_widened_entry_points():
     assert b"128" in lib.grit_last_error_string()
     assert lib.grit_gemm_bf16_nt_rope(p16, p16, p16, 4, 256, 64, 64, 64, 256, p16, p16, None, 0, 8, 128, None) == B          # neither positions nor S
     assert lib.grit_gemm_bf16_nt_grouped(p16, None, p16, p16, p16, 8, 64, 64, 64, 64, 64, 4096, 64, 1, None) == B            # RESIDUAL not offered
+    # the training form of the grouped GEMM: RESIDUAL not offered, SAVE without its [gate | up] buffer, BWD with a short ldr
+    assert lib.grit_gemm_bf16_nt_grouped_epi(p16, None, p16, p16, None, p16, 8, 64, 64, 64, 64, 64, 4096, 64, 0, 1, None) == B
+    assert lib.grit_gemm_bf16_nt_grouped_epi(p16, None, p16, p16, None, p16, 8, 64, 64, 64, 64, 64, 4096, 32, 0, 5, None) == B
+    assert b"SWIGLU_STACKED_SAVE" in lib.grit_last_error_string()
+    assert lib.grit_gemm_bf16_nt_grouped_epi(p16, None, p16, p16, p16, p16, 8, 64, 64, 64, 64, 64, 4096, 128, 64, 6, None) == B
+    assert lib.grit_moe_combine_bwd(p16, p16, p16, p16, p16, p16, p16, 4, 60, None) == B                                     # H % 8
     assert lib.grit_moe_router_top2(p16, p16, p16, p16, 4, 64, 5, None) == U                                                 # 5 experts
     assert lib.grit_moe_index(p16, 4, 17, p16, p16, p16, p16, None) == U                                                     # > 16 experts
     assert lib.grit_ce_fwd(p16, 8, p16, p16, p16, 4, 16, None) == B                                                          # ld < V
