@@ -33,7 +33,7 @@ class _LayerParams:
 
 class SavedForward:
     """Everything pass 2 keeps from the forward of one chunk."""
-    __slots__ = ("ids", "mask", "geom", "B", "S", "layers", "h_final", "x_final")
+    __slots__ = ("ids", "mask", "geom", "B", "S", "layers", "h_final", "x_final", "router")
 
 
 class _Geometry:
@@ -89,6 +89,8 @@ class MistralTrainEngine:
         self._wT = {}
         self.cache_transposed_weights = False
         self.recompute = False          # gradient checkpointing (per-layer recompute in backward)
+        self._router_log = None         # Mixtral: list collecting (logits fp32 [T,E], experts [T,2]) per layer while it is a list
+        self._aux_dlogits = None        # Mixtral: d aux_loss / d router logits per layer during backward_lm
         c = self.cfg
         if any(p.dtype != BF16 for p in backbone.parameters()):
             raise RuntimeError("MistralTrainEngine: parameters must be bfloat16 (load the model with torch_dtype=bfloat16)")
@@ -317,6 +319,7 @@ class MistralTrainEngine:
         # not save -> one scratch set, SwiGLU fused into the gate|up GEMM's epilogue
         keep_all = save and not self.recompute
         scratch = None
+        saved.router = self._router_log
         for L in self.layers:
             if keep_all or scratch is None:
                 scratch = self._layer_buffers(T, with_gu=keep_all)
@@ -352,7 +355,7 @@ class MistralTrainEngine:
 
     # ------------------------------------------------------------------ generative branch
     def forward_lm(self, input_ids, attention_mask, labels, loss_gen_type: str = "mixed", loss_gen_factor: float = 1.0, save: bool = True,
-                   packed: bool = True):
+                   packed: bool = True, router_aux_coef: float = 0.0):
         """NextTokenLoss(labels, lm_head(model(ids, causal))) -- gritlm/training/model.py:66-107,185-194 -- as a device scalar,
         plus the state backward_lm needs.  'mixed': mean over the non-ignored shifted tokens of this call; 'token': sum / batch."""
         if self.lm_head is None:
@@ -360,7 +363,11 @@ class MistralTrainEngine:
         if loss_gen_type not in ("mixed", "token"):
             raise ValueError(f"Invalid loss_gen_type: {loss_gen_type}")
         B, S = input_ids.shape
-        hidden, saved = self.forward(input_ids, attention_mask, save=save, packed=packed, causal=True)
+        self._router_log = [] if router_aux_coef else None
+        try:
+            hidden, saved = self.forward(input_ids, attention_mask, save=save, packed=packed, causal=True)
+        finally:
+            self._router_log = None
         geom = saved.geom
         x = hidden if geom.packed else hidden.view(B * S, -1)
         # "tokens < n predict n" (:94-96): row (b, s) is scored against labels[b, s+1]; the last position of a row has no target
@@ -376,13 +383,23 @@ class MistralTrainEngine:
         else:
             inv = torch.full((), 1.0 / B, dtype=F32, device=self.device)            # reduction="sum" / labels.size(0)
         loss = loss_row.sum() * inv * loss_gen_factor
-        state = (saved, x, logits, shifted, lse, inv.reshape(1).contiguous(), float(loss_gen_factor)) if save else None
+        aux_dl = None
+        if router_aux_coef:
+            aux, aux_dl = self._router_aux_loss(saved, want_grad=save)
+            loss = loss + router_aux_coef * aux
+        state = (saved, x, logits, shifted, lse, inv.reshape(1).contiguous(), float(loss_gen_factor), aux_dl, float(router_aux_coef)) if save else None
         return loss, state
+
+    def _router_aux_loss(self, saved, want_grad: bool):
+        raise NotImplementedError("router auxiliary loss: only on MixtralTrainEngine")
 
     def backward_lm(self, state, d_loss: torch.Tensor | float = 1.0, on_layer_done=None):
         """Accumulate the parameter gradients (backbone + lm_head) of d_loss * loss."""
-        saved, x, logits, shifted, lse, inv, factor = state
+        saved, x, logits, shifted, lse, inv, factor, aux_dl, aux_coef = state
         dev_scale = inv * d_loss if torch.is_tensor(d_loss) else inv * float(d_loss)
+        if aux_dl is not None:          # d (coef * aux) / d router logits of every layer, scaled by the incoming d_loss
+            sc = (d_loss.to(F32) if torch.is_tensor(d_loss) else float(d_loss)) * aux_coef
+            self._aux_dlogits = [g * sc for g in aux_dl]
         dlogits = ops.ce_bwd_(logits, shifted, lse, factor, dev_scale.to(F32).reshape(1).contiguous())
         self.prepare_grads()
         if self.lm_head.grad is None:
@@ -390,7 +407,10 @@ class MistralTrainEngine:
         dx = ops.gemm_nt(dlogits, ops.transpose(self.lm_head.data))                                     # [T,H] = dlogits @ W_lm
         g = self.lm_head.grad
         self._wgrad(dlogits, x, g, ("dlogits", "x"))
-        self.backward(saved, dx, on_layer_done=on_layer_done)
+        try:
+            self.backward(saved, dx, on_layer_done=on_layer_done)
+        finally:
+            self._aux_dlogits = None
 
     # ------------------------------------------------------------------ backward
     def backward(self, saved: SavedForward, d_last_hidden: torch.Tensor, on_layer_done=None):
@@ -472,13 +492,11 @@ class MixtralTrainEngine(MistralTrainEngine):
                 milliseconds long; the inference path stays sync-free); the router's softmax / top-2 / renormalise backward and
                 its two skinny GEMMs ([T,E] x [E,H]) run as torch fp32 ops on the [T,E] logits.
 
-    The router auxiliary loss (load_balancing_loss_func, :80-153) is not part of this path: the reference adds it only inside
-    MixtralForCausalLM.forward when ``output_router_logits`` is set (default off), never for the embedding tower."""
+    The router auxiliary loss (load_balancing_loss_func, :80-153) belongs to the generative branch only (the reference adds it inside
+    MixtralForCausalLM.forward, which GritLMTrainModel calls with output_router_logits=True for a Mixtral; never for the embedding
+    tower): forward_lm(router_aux_coef=...) records the router logits, _router_aux_loss evaluates it, _mlp_bwd feeds its gradient in."""
 
     def _bind_mlp(self, L, mlp):
-        if getattr(getattr(self.backbone, "config", None), "output_router_logits", False):
-            # reference: MixtralForCausalLM.forward adds router_aux_loss_coef * load_balancing_loss_func(...) (:80-153, :1390-1400)
-            raise NotImplementedError("MixtralTrainEngine: config.output_router_logits=True (router auxiliary loss) is not built")
         ex = mlp.experts
         L.wgu, L.wdown, L.wgate = ex.gate_up_proj, ex.down_proj, mlp.gate.weight
         c = self.cfg
@@ -513,6 +531,8 @@ class MixtralTrainEngine(MistralTrainEngine):
     def _mlp_fwd(self, L, h_mid, x2, buf, need_bwd: bool, h_out):
         T = x2.shape[0]
         experts, weights, counts, row_token, rows = ops.moe_route(x2, L.wgate.data)
+        if self._router_log is not None and len(self._router_log) < len(self.layers):     # (not again for a recomputed layer)
+            self._router_log.append((x2.to(F32) @ L.wgate.data.to(F32).t(), experts))
         gu, act, y = buf["gu"], buf["act"], buf["y"]
         if need_bwd:
             ops.gemm_nt_grouped_epi(x2, L.wgu.data, counts, 2 * T, EPI_SWIGLU_STACKED_SAVE, out=act, residual=gu, a_rows=row_token)
@@ -543,12 +563,43 @@ class MixtralTrainEngine(MistralTrainEngine):
         with torch.enable_grad():
             xf = sv["x2"].detach().to(F32).requires_grad_(True)
             wg = L.wgate.detach().to(F32).requires_grad_(True)
-            p = torch.softmax(xf @ wg.t(), dim=-1)
+            logits = xf @ wg.t()
+            p = torch.softmax(logits, dim=-1)
             sel = torch.gather(p, 1, sv["experts"].to(torch.int64))
             w = sel / sel.sum(dim=-1, keepdim=True)
-            (w * dw).sum().backward()
+            obj = (w * dw).sum()
+            if self._aux_dlogits is not None:      # + the auxiliary load-balancing loss's pull on this layer's logits
+                obj = obj + (logits * self._aux_dlogits[li]).sum()
+            obj.backward()
         L.wgate.grad.add_(wg.grad.to(BF16))
         return (dx2.to(F32) + xf.grad).to(BF16)
+
+    def _router_aux_loss(self, saved, want_grad: bool):
+        """load_balancing_loss_func (scripts/modeling_mixtral_gritlm.py:80-153) over the router logits of every layer of one forward:
+        E * sum_{slot,e} f[slot,e] * P[e], f = fraction of the (real) tokens whose top-`slot` expert is e, P = mean router probability
+        of e -- the reference masks padding positions with the attention mask; here the rows of a packed chunk ARE the real
+        tokens, and a padded chunk uses the mask.  Returns (aux, [d aux / d logits per layer] | None); only P is differentiable."""
+        E = self.cfg.num_local_experts
+        log = saved.router
+        if not log or len(log) != len(self.layers):
+            raise RuntimeError("router auxiliary loss: the forward did not record the router logits")
+        keep = None if saved.geom.packed else (saved.mask.reshape(-1) != 0)
+        leaves = [lg.detach().requires_grad_(want_grad) for lg, _ in log]
+        with torch.enable_grad():
+            logits = torch.cat(leaves, dim=0)
+            sel = torch.cat([ex for _, ex in log], dim=0).to(torch.int64)                       # [L*T, 2]
+            probs = torch.softmax(logits, dim=-1)
+            onehot = torch.nn.functional.one_hot(sel, E).to(F32)                                 # [L*T, 2, E]
+            if keep is None:
+                f, P = onehot.mean(dim=0), probs.mean(dim=0)
+            else:
+                m = keep.repeat(len(log)).to(F32)
+                f = (onehot * m[:, None, None]).sum(dim=0) / m.sum()
+                P = (probs * m[:, None]).sum(dim=0) / m.sum()
+            aux = (f * P.unsqueeze(0)).sum() * E
+            if want_grad:
+                aux.backward()
+        return aux.detach(), ([lf.grad for lf in leaves] if want_grad else None)
 
 
 class SyntheticBackbone(torch.nn.Module):

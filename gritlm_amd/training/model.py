@@ -174,8 +174,14 @@ class _NativeGenFn(torch.autograd.Function):
         eng = model.train_engine
         grad = bool(ctx.needs_input_grad[0])
         fn = model.gen_loss_fn
-        loss, state = eng.forward_lm(input_ids, attention_mask, labels, fn.loss_gen_type, fn.loss_gen_factor, save=grad,
-                                     packed=getattr(model, "native_packed", True))
+        if fn is not None:
+            kind, factor, aux = fn.loss_gen_type, fn.loss_gen_factor, 0.0
+        else:       # a Mixtral: the reference takes the model's own loss (training/model.py:123-127,185-194) = token-sum cross entropy
+            #         / batch * loss_gen_factor + router_aux_loss_coef * load_balancing_loss (modeling_mixtral_gritlm.py:1406-1430)
+            factor = model.gen_add_kwargs.get("loss_gen_factor")
+            kind, factor, aux = "token", (1.0 if factor is None else factor), float(getattr(model.model.config, "router_aux_loss_coef", 0.0))
+        loss, state = eng.forward_lm(input_ids, attention_mask, labels, kind, factor, save=grad,
+                                     packed=getattr(model, "native_packed", True), router_aux_coef=aux)
         if grad:
             ctx.model, ctx.state = model, state
         return loss
@@ -269,8 +275,8 @@ class GritLMTrainModel(GritLM):
         """query [b, n]; passage [b*s, m] (s = group size); generative [b, m]."""
         loss_gen = None
         if generative is not None:      # generative first, as in the reference (:185-194)
-            if (self.train_engine is not None and self.train_engine.lm_head is not None and self.gen_loss_fn is not None
-                    and self.attn[2:4] == "cc"):
+            native_gen = self.train_engine is not None and self.train_engine.lm_head is not None and self.attn[2:4] == "cc"
+            if native_gen and (self.gen_loss_fn is not None or getattr(self.model.config, "model_type", "") == "mixtral"):
                 labels = generative.pop("labels")
                 loss_gen = _NativeGenFn.apply(self.train_engine.embed, self, generative["input_ids"], generative["attention_mask"], labels)
             elif self.gen_loss_fn is not None:

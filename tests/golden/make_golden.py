@@ -277,6 +277,64 @@ def gen_train_mixtral(cfg_name="moe-tiny", seed_w=0):
     np.savez_compressed(os.path.join(HERE, f"train_{cfg_name}.npz"), **res)
 
 
+def gen_generative_mixtral(cfg_name="moe-tiny"):
+    """Generative branch of unified training on the reference's MIXTRAL (gritlm/training/model.py:123-127,185-194: for a Mixtral the
+    model's own loss is used): MixtralForCausalLM.forward(labels, loss_gen_factor, output_router_logits=True) = token-sum cross
+    entropy / batch * factor + router_aux_loss_coef * load_balancing_loss_func(...) (modeling_mixtral_gritlm.py:80-153, :1406-1430).
+    Stored: loss, aux_loss, gradients of the router weights (the only parameters the auxiliary loss reaches directly), of expert 0 / 5,
+    of the attention / norm / embedding / lm_head parameters; every gradient norm."""
+    mod = load_ref_mixtral()
+    cfg = synth.CONFIGS[cfg_name]
+    hc = synth.hf_config(cfg)
+    hc.use_cache = False
+    hc._attn_implementation = "sdpa"
+    hc.router_aux_loss_coef = 0.5      # large on purpose (Mixtral-8x7B ships 0.02): the router gradients must SEE the auxiliary term
+    lm = mod.MixtralForCausalLM(hc)
+    w = synth.make_weights(cfg, 0)
+    sd = {"model." + k: torch.from_numpy(v) for k, v in w.items()}
+    rng = np.random.default_rng(99)
+    sd["lm_head.weight"] = torch.from_numpy(synth._bf16_round(rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"]), dtype=np.float32) * 0.02))
+    missing, unexpected = lm.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    lm.train()
+    B, S = 5, 56
+    # batch seed 93 of 33..132: the one whose closest routing decision is the least close (second vs third expert >= 9.8 % apart
+    # wherever the second expert's weight is not negligible).  A token-SUM loss under causal attention makes a single flipped
+    # near-tie (bf16 vs fp32 logits) change the gradients of its whole sequence -- with seed 33 one token at 0.2435 vs 0.2425 moved
+    # the layer-0 attention gradients by 20-40 % while every kernel agreed to 0.5 % (tools/dbg/mixtral_gen_probe.py)
+    ids, mask = synth.make_batch(cfg, B, S, 93, min_len=12)
+    labels = ids.copy()
+    labels[mask == 0] = -100
+    for b, n_instr in enumerate([7, 0, 11, 3, 20]):
+        labels[b, :min(n_instr, int(mask[b].sum()) - 2)] = -100
+    factor = 0.25
+    call = lambda: lm(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), labels=torch.from_numpy(labels), return_dict=True,
+                      loss_gen_factor=factor, output_router_logits=True)
+    # the same step WITHOUT the auxiliary term (coefficient 0): a few gradients, to tell an error of the auxiliary path from any other
+    lm.router_aux_loss_coef = 0.0
+    out0 = call()
+    out0.loss.backward()
+    res = dict(loss_noaux=np.float32(out0.loss.item()))
+    for n, p in lm.named_parameters():
+        if n in ("model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.block_sparse_moe.gate.weight",
+                 "model.layers.1.block_sparse_moe.gate.weight", "model.layers.1.block_sparse_moe.experts.0.w1.weight", "lm_head.weight"):
+            res["grad_noaux/" + n] = p.grad.numpy().copy()
+    lm.zero_grad()
+    lm.router_aux_loss_coef = hc.router_aux_loss_coef
+    out = call()
+    out.loss.backward()
+    res["routing"] = torch.stack([torch.topk(torch.softmax(lg.float(), dim=-1), 2, dim=-1)[1] for lg in out.router_logits]).numpy()   # [L, B*S, 2]
+    res.update(cfg_name=cfg_name, input_ids=ids, attention_mask=mask, labels=labels, factor=np.float32(factor),
+               router_aux_loss_coef=np.float32(lm.router_aux_loss_coef), loss=np.float32(out.loss.item()), aux_loss=np.float32(out.aux_loss.item()))
+    for n, p in lm.named_parameters():
+        g = p.grad
+        res["gnorm/" + n] = np.float32(g.norm().item())
+        if ".experts." not in n or ".experts.0." in n or ".experts.5." in n:
+            res["grad/" + n] = g.numpy().copy()
+    print(f"  generative mixtral: loss {out.loss.item():.6f} (aux {out.aux_loss.item():.6f} x {lm.router_aux_loss_coef})")
+    np.savez_compressed(os.path.join(HERE, f"generative_{cfg_name}.npz"), **res)
+
+
 def gen_pooling():
     rng = np.random.default_rng(7)
     hidden = rng.standard_normal((5, 9, 24), dtype=np.float32)
@@ -499,7 +557,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["7b-l1"]:            # only the 7B-layer-shape fixtures (1.4 GB of fp32 weights, ~2 min on 8 cores)
         gen_encoder_7b_l1(); gen_train_7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["train-mixtral"]:
-        gen_train_mixtral(); sys.exit(0)
+        gen_train_mixtral(); gen_generative_mixtral(); sys.exit(0)
+    if sys.argv[1:] == ["generative-mixtral"]:
+        gen_generative_mixtral(); sys.exit(0)
     if sys.argv[1:] == ["train-7b-l1"]:
         gen_train_7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
@@ -516,5 +576,5 @@ if __name__ == "__main__":
     print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
     print("encoder 7b-l1"); gen_encoder_7b_l1()
     print("train 7b-l1"); gen_train_7b_l1()
-    print("train mixtral"); gen_train_mixtral()
+    print("train mixtral"); gen_train_mixtral(); gen_generative_mixtral()
     print("done")

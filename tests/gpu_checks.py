@@ -973,6 +973,94 @@ def check_train_step_mixtral(mode="direct"):
     return _res(f"native Mixtral train step [{mode}] vs reference loss+grads", bool(ok), **out)
 
 
+def check_generative_mixtral():
+    """Generative branch on a Mixtral (the reference takes the model's own loss there: token-sum cross entropy / batch * factor +
+    router_aux_loss_coef * load_balancing_loss_func) vs the reference's MixtralForCausalLM.forward + backward
+    (tests/golden/generative_moe-tiny.npz, fp32 on CPU, aux coefficient 0.5 so that the router gradients are dominated by the
+    auxiliary term): loss, and every stored gradient incl. the routers' and lm_head's."""
+    import tempfile
+    from gritlm_amd.training import GritLMTrainModel
+    g = np.load(os.path.join(GOLDEN, "generative_moe-tiny.npz"))
+    I = synth.CONFIGS["moe-tiny"]["intermediate_size"]
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mixtral_dir(os.path.join(td, "mixtral-tiny"), "moe-tiny", 0, "bfloat16")     # "mixtral" in the path: model's own loss
+        m = GritLMTrainModel(model_name_or_path=d16, mode="unified", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=0.02, negatives_cross_device=False, loss_gen_type="token", loss_gen_factor=float(g["factor"]),
+                             device="cuda", torch_dtype=torch.bfloat16)
+        ok &= m.gen_loss_fn is None
+        m.enable_native()
+        mk_gen = lambda: {"input_ids": torch.from_numpy(g["input_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["attention_mask"]).to(DEV),
+                          "labels": torch.from_numpy(g["labels"]).to(DEV)}
+        # (1) without the auxiliary term
+        m.model.config.router_aux_loss_coef = 0.0
+        o0 = m(generative=mk_gen())
+        o0.loss.backward()
+        sd0 = dict(m.model.named_parameters())
+        worst0 = 0.0
+        for k in g.files:
+            if k.startswith("grad_noaux/"):
+                n = k[len("grad_noaux/"):]
+                nn = n.replace("block_sparse_moe.gate.weight", "mlp.gate.weight")
+                got = f32(sd0[nn].grad) if "experts" not in n else f32(sd0[n.split(".block_sparse_moe.")[0] + ".mlp.experts.gate_up_proj"].grad[0][:I])
+                rel = float(np.linalg.norm(got - g[k]) / (np.linalg.norm(g[k]) + 1e-20))
+                if os.environ.get("GRIT_CHECK_VERBOSE"):
+                    print(f"   [no aux] {n:60s} rel {rel:.3e}")
+                worst0 = max(worst0, rel)
+        out["loss_noaux"], out["loss_noaux_ref"], out["worst_grad_noaux"] = float(o0.loss_gen.item()), float(g["loss_noaux"]), worst0
+        ok &= worst0 < 6e-2
+        m.model.zero_grad(set_to_none=True)
+        # (2) with it
+        m.model.config.router_aux_loss_coef = float(g["router_aux_loss_coef"])
+        if "routing" in g.files:          # routing agreement with the reference's fp32 run (real tokens, either order of the two experts)
+            eng = m.train_engine
+            eng._router_log = []
+            with torch.no_grad():
+                eng.forward(mk_gen()["input_ids"], mk_gen()["attention_mask"], save=False, packed=True, causal=True)
+            log, eng._router_log = eng._router_log, None
+            keep = g["attention_mask"].reshape(-1) != 0
+            agree = []
+            for li, (_, ex) in enumerate(log):
+                ref = np.sort(g["routing"][li][keep], axis=-1)
+                agree.append(float((np.sort(ex.cpu().numpy(), axis=-1) == ref).all(-1).mean()))
+            out["routing_agreement_per_layer"] = str([round(a, 4) for a in agree])
+        o = m(generative=mk_gen())
+        o.loss.backward()
+        lv = float(o.loss_gen.item())
+        out["loss"], out["loss_ref"], out["aux_ref"] = lv, float(g["loss"]), float(g["aux_loss"])
+        ok &= abs(lv - float(g["loss"])) < 2e-3 * abs(float(g["loss"]))
+        sd = dict(m.model.named_parameters())
+
+        def ours(ref_name):
+            if "block_sparse_moe" not in ref_name:
+                return f32(sd[ref_name].grad)
+            pre, rest = ref_name.split(".block_sparse_moe.")
+            if rest == "gate.weight":
+                return f32(sd[pre + ".mlp.gate.weight"].grad)
+            _, e, w, _ = rest.split(".")
+            e = int(e)
+            if w == "w2":
+                return f32(sd[pre + ".mlp.experts.down_proj"].grad[e])
+            gu = sd[pre + ".mlp.experts.gate_up_proj"].grad[e]
+            return f32(gu[:I] if w == "w1" else gu[I:])
+
+        worst, worst_name, worst_gate = 0.0, "", 0.0
+        for k in g.files:
+            if k.startswith("grad/"):
+                n = k[len("grad/"):]
+                ref = g[k]
+                rel = float(np.linalg.norm(ours(n) - ref) / (np.linalg.norm(ref) + 1e-20))
+                if "gate.weight" in n:
+                    worst_gate = max(worst_gate, rel)
+                if os.environ.get("GRIT_CHECK_VERBOSE"):
+                    print(f"   {n:60s} rel {rel:.3e}  |ref| {np.linalg.norm(ref):.3e} |ours| {np.linalg.norm(ours(n)):.3e}")
+                if rel > worst:
+                    worst, worst_name = rel, n
+        out["worst_grad_rel_l2"], out["worst_grad"], out["worst_router_grad_rel_l2"] = worst, worst_name.replace("block_sparse_moe", "moe"), worst_gate
+        ok &= worst < 6e-2
+    return _res("native Mixtral generative loss (CE + router auxiliary loss) vs reference loss+grads", bool(ok), **out)
+
+
 def check_train_packed_vs_padded(cfg_name="gqa"):
     """One contrastive step with the packed (un-padded) training path vs the padded one: identical reps and loss, parameter
     gradients equal up to the bf16 accumulation order of the wgrad GEMMs (K = tokens, padded rows contribute exact zeros)."""
@@ -1764,6 +1852,7 @@ ALL_CHECKS = [
     ("train_mixtral_direct", check_train_step_mixtral, dict(mode="direct")),
     ("train_mixtral_gradcache", check_train_step_mixtral, dict(mode="gradcache")),
     ("train_mixtral_recompute", check_train_step_mixtral, dict(mode="recompute")),
+    ("generative_mixtral_aux", check_generative_mixtral, {}),
     ("train_packed_vs_padded", check_train_packed_vs_padded, {}),
     ("train_recompute", check_train_recompute, {}),
     ("swiglu_stacked", check_swiglu_stacked, {}),
