@@ -199,6 +199,23 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
             **({"ragged_batch": ragged} if ragged is not None else {})}
 
 
+def deadline_guard(budget_s: float, late_line):
+    """Arms a daemon thread: unless the returned Event is set within ``budget_s`` seconds the thread prints ``late_line()`` (if it
+    returns a string) and ends the PROCESS with exit code 0 (``os._exit``: the main thread may be parked inside a collective that will
+    never complete).  tests/test_bench_guard.py exercises it in a subprocess."""
+    import threading
+    done = threading.Event()
+
+    def _watch():
+        if not done.wait(budget_s):
+            out = late_line()
+            if out is not None:
+                print(out, flush=True)
+            os._exit(0)
+    threading.Thread(target=_watch, daemon=True).start()
+    return done
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,19 +359,15 @@ def main():
     # primary line (with the leg marked as timed out) and exits the process cleanly instead.
     guard, emitted = None, []
     if world > 1 and not args.no_contrastive:
-        import threading
-        guard = threading.Event()
-
-        def _deadline(ev=guard, budget=float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "480"))):
-            if not ev.wait(budget):
-                if rank == 0 and not emitted:
-                    if ragged is not None:
-                        line["ragged_batch"] = ragged
-                    line["contrastive"] = {"error": f"contrastive leg exceeded {budget:.0f} s on {world} ranks; primary line emitted by the deadline guard"}
-                    line["collectives"] = {"backend": "nccl", "ranks": world, "encode_data_path_collectives": 0}
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
-        threading.Thread(target=_deadline, daemon=True).start()
+        def _late_line():
+            if rank != 0 or emitted:
+                return None
+            if ragged is not None:
+                line["ragged_batch"] = ragged
+            line["contrastive"] = {"error": f"contrastive leg exceeded its deadline on {world} ranks; primary line emitted by the deadline guard"}
+            line["collectives"] = {"backend": "nccl", "ranks": world, "encode_data_path_collectives": 0}
+            return json.dumps(line)
+        guard = deadline_guard(float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "480")), _late_line)
     contrastive = None
     if not args.no_contrastive:
         torch.cuda.reset_peak_memory_stats()
