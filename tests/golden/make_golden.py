@@ -268,11 +268,12 @@ def gen_train_mixtral(cfg_name="moe-tiny", seed_w=0):
     worst = max(float(np.linalg.norm(grads["bf16"][k] - grads["f32"][k]) / (np.linalg.norm(grads["f32"][k]) + 1e-20)) for k in grads["f32"])
     print(f"  reference bf16-vs-fp32 gradients: worst relative l2 {worst:.3e}")
     res["ref_bf16_vs_f32_worst_rel_l2"] = np.float32(worst)
-    # the fixture keeps every gradient norm (both runs) and the fp32 gradients of everything except experts 1-4, 6, 7 (25 MB otherwise)
+    # the fixture keeps every gradient norm (both runs) and the fp32 gradients of everything but most experts (25 MB otherwise):
+    # expert 0 of both layers and expert 5 of the last one
     for n, g in grads["f32"].items():
         res["gnorm_f32/" + n] = np.float32(np.linalg.norm(g))
         res["gnorm_bf16/" + n] = np.float32(np.linalg.norm(grads["bf16"][n]))
-        if ".experts." not in n or ".experts.0." in n or ".experts.5." in n:
+        if ".experts." not in n or ".experts.0." in n or ".layers.1.block_sparse_moe.experts.5." in n:
             res["grad_f32/" + n] = g
     np.savez_compressed(os.path.join(HERE, f"train_{cfg_name}.npz"), **res)
 
@@ -317,7 +318,7 @@ def gen_generative_mixtral(cfg_name="moe-tiny"):
     res = dict(loss_noaux=np.float32(out0.loss.item()))
     for n, p in lm.named_parameters():
         if n in ("model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.block_sparse_moe.gate.weight",
-                 "model.layers.1.block_sparse_moe.gate.weight", "model.layers.1.block_sparse_moe.experts.0.w1.weight", "lm_head.weight"):
+                 "model.layers.1.block_sparse_moe.gate.weight", "model.layers.1.block_sparse_moe.experts.0.w1.weight"):
             res["grad_noaux/" + n] = p.grad.numpy().copy()
     lm.zero_grad()
     lm.router_aux_loss_coef = hc.router_aux_loss_coef
@@ -329,7 +330,7 @@ def gen_generative_mixtral(cfg_name="moe-tiny"):
     for n, p in lm.named_parameters():
         g = p.grad
         res["gnorm/" + n] = np.float32(g.norm().item())
-        if ".experts." not in n or ".experts.0." in n or ".experts.5." in n:
+        if ".experts." not in n or ".layers.0.block_sparse_moe.experts.0." in n or ".layers.1.block_sparse_moe.experts.5." in n:
             res["grad/" + n] = g.numpy().copy()
     print(f"  generative mixtral: loss {out.loss.item():.6f} (aux {out.aux_loss.item():.6f} x {lm.router_aux_loss_coef})")
     np.savez_compressed(os.path.join(HERE, f"generative_{cfg_name}.npz"), **res)
