@@ -359,6 +359,29 @@ def encode_core(weights, cfg, input_ids, attention_mask, pooling_method="mean", 
 
 
 # ----------------------------------------------------------------------------
+# Mixtral router auxiliary loss  (scripts/modeling_mixtral_gritlm.py)
+# ----------------------------------------------------------------------------
+def router_aux_loss(gate_logits: np.ndarray, attention_mask: np.ndarray, top_k: int = 2) -> float:
+    """load_balancing_loss_func, scripts/modeling_mixtral_gritlm.py:80-153, with an attention mask (the training call, :1423-1428).
+
+    gate_logits [L, B*S, E] (one [B*S, E] block per layer, concatenated by the reference :109-111), attention_mask [B, S].
+    routing_weights = softmax; selected = top-k; f[slot, e] = share of the REAL tokens (all layers) whose slot-th choice is e (:131-133);
+    P[e] = mean routing weight of e over the real tokens (:144-146); loss = E * sum_{slot, e} f[slot, e] * P[e] (:148-149)."""
+    L, N, E = gate_logits.shape
+    z = gate_logits.astype(F64).reshape(L * N, E)
+    z = z - z.max(axis=1, keepdims=True)
+    w = np.exp(z)
+    w /= w.sum(axis=1, keepdims=True)
+    order = np.argsort(-w, axis=1, kind="stable")[:, :top_k]                       # torch.topk: descending, first index on ties
+    onehot = np.zeros((L * N, top_k, E), F64)
+    np.put_along_axis(onehot, order[:, :, None], 1.0, axis=2)
+    m = np.tile(attention_mask.reshape(-1).astype(F64), L)
+    f = (onehot * m[:, None, None]).sum(axis=0) / m.sum()
+    P = (w * m[:, None]).sum(axis=0) / m.sum()
+    return float((f * P[None, :]).sum() * E)
+
+
+# ----------------------------------------------------------------------------
 # Contrastive loss  (gritlm/training/model.py)
 # ----------------------------------------------------------------------------
 def infonce(q: np.ndarray, p: np.ndarray, temperature: float):

@@ -325,6 +325,7 @@ def gen_generative_mixtral(cfg_name="moe-tiny"):
     out = call()
     out.loss.backward()
     res["routing"] = torch.stack([torch.topk(torch.softmax(lg.float(), dim=-1), 2, dim=-1)[1] for lg in out.router_logits]).numpy()   # [L, B*S, 2]
+    res["router_logits"] = torch.stack([lg.detach().float() for lg in out.router_logits]).numpy()                                       # [L, B*S, E]
     res.update(cfg_name=cfg_name, input_ids=ids, attention_mask=mask, labels=labels, factor=np.float32(factor),
                router_aux_loss_coef=np.float32(lm.router_aux_loss_coef), loss=np.float32(out.loss.item()), aux_loss=np.float32(out.aux_loss.item()))
     for n, p in lm.named_parameters():

@@ -46,6 +46,27 @@ def test_infonce_matches_reference(golden_dir, tag):
     np.testing.assert_allclose(dp, g[f"{tag}_dp"], rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("fixture,suffix", [("train_7b-l1.npz", ""), ("train_moe-tiny.npz", "_f32")])
+def test_training_fixtures_loss_is_the_infonce_of_their_reps(golden_dir, fixture, suffix):
+    """The training-step fixtures (reference GritLMTrainModel.forward at the 7B layer shape / around its Mixtral) carry reps and loss:
+    the oracle's InfoNCE on those reps must give that loss -- two more reference-generated vectors for the loss, and a consistency
+    check of the fixtures the GPU training checks read."""
+    g = _load(golden_dir, fixture)
+    loss, _, _, _ = O.infonce(g["q_reps" + suffix], g["p_reps" + suffix], float(g["tau"]))
+    ref = float(g["loss" + suffix])
+    assert abs(loss - ref) < 2e-4 * max(1.0, abs(ref)), (loss, ref)
+    assert np.allclose(np.linalg.norm(g["q_reps" + suffix], axis=1), 1.0, atol=1e-5)
+
+
+def test_router_aux_loss_matches_reference(golden_dir):
+    """oracle.router_aux_loss (Mixtral's load_balancing_loss_func) on the reference's own router logits == the reference's aux_loss."""
+    g = _load(golden_dir, "generative_moe-tiny.npz")
+    aux = O.router_aux_loss(g["router_logits"], g["attention_mask"])
+    assert abs(aux - float(g["aux_loss"])) < 1e-5 * float(g["aux_loss"]), (aux, float(g["aux_loss"]))
+    # and the loss decomposes as the reference says: loss = loss_noaux + coef * aux
+    assert abs(float(g["loss"]) - (float(g["loss_noaux"]) + float(g["router_aux_loss_coef"]) * float(g["aux_loss"]))) < 1e-4 * float(g["loss"])
+
+
 def test_distributed_infonce_matches_reference_gloo_run(golden_dir):
     g = _load(golden_dir, "infonce_dist2.npz")
     world = int(g["world"]); q, p, tau = g["q"], g["p"], float(g["tau"])
