@@ -70,11 +70,11 @@ static unsigned long long run_case(const Lib& a, const Lib& b, const Case& c, in
   const int64_t M = c.M; const int N = c.N, K = c.K;
   const bool grouped = c.epi >= 10;
   const int epi = grouped ? c.epi - 10 : c.epi;
-  const int outN = epi == SWIGLU ? N / 2 : N;
+  const int outN = epi == SWIGLU ? N / 2 : (epi == 6 ? 2 * N : N);        // 6 = SWIGLU_BWD: C = [d_gate | d_up], residual = saved [gate | up]
   const int ngroups = 5;
   uint16_t* A = dev_bf16(M * K, 11, 1.0f);
   uint16_t* W = dev_bf16((int64_t)N * K * (grouped ? ngroups : 1), 23, 0.05f);
-  uint16_t* R = epi == RESIDUAL ? dev_bf16(M * N, 37, 1.0f) : nullptr;
+  uint16_t* R = epi == RESIDUAL ? dev_bf16(M * N, 37, 1.0f) : (epi == 6 ? dev_bf16(M * 2 * N, 37, 1.0f) : nullptr);
   uint16_t *Ca, *Cb;
   CK(hipMalloc(&Ca, M * outN * 2 + 64)); CK(hipMalloc(&Cb, M * outN * 2 + 64));
   float *cosT = nullptr, *sinT = nullptr;
@@ -98,7 +98,7 @@ static unsigned long long run_case(const Lib& a, const Lib& b, const Case& c, in
     int rc;
     if (grouped) rc = l.grouped(A, rows, W, C, counts, ngroups, M, N, K, K, K, (int64_t)N * K, outN, epi, nullptr);
     else if (epi == ROPE) rc = l.rope(A, W, C, M, N, K, K, K, N, cosT, sinT, nullptr, 512, 512, (N / 128) * 128 - (N >= 256 ? 128 : 0), nullptr);
-    else rc = l.gemm(A, W, C, M, N, K, K, K, outN, epi, R, N, nullptr);
+    else rc = l.gemm(A, W, C, M, N, K, K, K, outN, epi, R, epi == 6 ? 2 * N : N, nullptr);
     if (rc != 0) { fprintf(stderr, "launch rc=%d (%s)\n", rc, l.err ? l.err() : "?"); exit(3); }
   };
   unsigned long long total = 0;
