@@ -221,16 +221,20 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       const char* v_lds = k_lds + K_LDS_BYTES;
 
       // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
+      // the two 32-key halves are two INDEPENDENT accumulation chains, issued alternately: a v_mfma_f32_32x32x16_bf16 occupies the pipe
+      // for 32 cycles but its result is ready after 64, so back-to-back products on ONE accumulator run at half rate (PMC: 80
+      // SQ_VALU_MFMA_BUSY_CYCLES per MFMA with the chains issued one after the other)
       f32x16_t sacc[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      {
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + kb * 32 * 256 + kf_row + (((2 * ks + hi) ^ kf_x) << 4));
-          // the first product takes the constant 0 as its accumulator input (an inline operand: no 16 v_mov per chain)
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
-        }
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + kb * 32 * 256 + kf_row + (((2 * ks + hi) ^ kf_x) << 4));
+            // the first product takes the constant 0 as its accumulator input (an inline operand: no 16 v_mov per chain)
+            sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
+          }
       }
 
       // the next block's Q rows replace this block's as soon as its last QK product has read them: the fetch lands under the
@@ -330,20 +334,19 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 #endif
 
 
-      // ---- O^T += V^T P^T
+      // ---- O^T += V^T P^T   (the four d-blocks are four independent accumulators: round-robin, never the same one twice in a row)
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
+          for (int db = 0; db < 4; ++db) {
             const char* vp = v_lds + (vt_lane ^ (db << 6)) + (kb * 32 + c * 16) * V_PITCH;
             const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
             const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * V_PITCH));
             const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
             oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
           }
-      }
     }
 
     // ---- block seam: the next block's first tile and Q rows (issued one tile ago) are waited for BEFORE this block's stores go out
