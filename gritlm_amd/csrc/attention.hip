@@ -222,8 +222,8 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
       // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
       // the two 32-key halves are two INDEPENDENT accumulation chains, issued alternately: a v_mfma_f32_32x32x16_bf16 occupies the pipe
-      // for 32 cycles but its result is ready after 64, so back-to-back products on ONE accumulator run at half rate (PMC: 80
-      // SQ_VALU_MFMA_BUSY_CYCLES per MFMA with the chains issued one after the other)
+      // for 32 cycles but its result is ready after 64, so a product that accumulates onto the one issued just before it has to
+      // wait (hipcc keeps MFMA source order; A/B against "8 products on one half, then 8 on the other": +2.5-4.5 %, bit-identical)
       f32x16_t sacc[2];
       {
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
