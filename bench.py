@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the GritLM embedding-encode hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -13,6 +13,7 @@ no data-path collective, weak scaling); value = docs of all ranks / max-over-ran
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline:     dominant kernel (gemm_bf16_nt, bf16 MFMA bound) measured live with HIP events,
+  parity_full_depth: HIP engine vs the fp32 numpy oracle through all 32 layers on identical weights (and stock HF bf16 as yardstick),
   cpu_baseline: the reference's CPU encode (stock transformers.MistralModel + bidirectional mask + pooling, bit-equal to the reference
                 on the reference-generated fixtures; oracle/torch_reference.py) timed on this host's cores on a bounded sample (N = 1 only),
   rocm_torch_baseline: the same Python on this GPU through stock PyTorch-ROCm (bf16, sdpa) at the full config -- what a user gets today,
@@ -35,15 +36,21 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 def measured_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE, each collected in its own --pmc run: profiles/rNN_gemm_pmc.json).  bench.py cannot run PMC
-    collection itself; None if no profile of this kernel generation is committed."""
+    collection itself, so the figure is only as fresh as that profile: the profile stores the sha256 of the kernel
+    source it was collected on and a mismatch with the shipped gritlm_amd/csrc/gemm_bf16.hip is flagged ``traffic_stale``.
+    Returns (bytes or None, {provenance fields})."""
     import glob
+    import hashlib
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc.json")))
     if not files:
-        return None
+        return None, {}
     try:
-        return json.load(open(files[-1]))["avg_traffic_bytes_per_gemm_launch_in_forward"]
+        d = json.load(open(files[-1]))
+        sha = hashlib.sha256(open(os.path.join(ROOT, "gritlm_amd", "csrc", "gemm_bf16.hip"), "rb").read()).hexdigest()[:16]
+        note = {"traffic_source": os.path.relpath(files[-1], ROOT), "traffic_stale": d.get("gemm_bf16_hip_sha16") != sha}
+        return d["avg_traffic_bytes_per_gemm_launch_in_forward"], note
     except Exception:  # noqa: BLE001
-        return None
+        return None, {}
 DOCS, SEQ = 256, 512
 
 
@@ -53,36 +60,6 @@ def cpu_baseline():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch_reference as TR
     return TR.time_cpu(layers=2, docs=8, seq=SEQ)
-
-
-def cpu_baseline_numpy(sample_docs=1, seq=SEQ, layers=32):
-    """Second CPU datum: the numpy oracle (oracle/gritlm_oracle.py, fp32 BLAS) through all 32 layers on a bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import gritlm_oracle as O
-    import synth
-    cfg = dict(synth.CONFIGS["7b"]); cfg["num_hidden_layers"] = layers; cfg["vocab_size"] = 2048
-    rng = np.random.default_rng(0)
-    H, I = cfg["hidden_size"], cfg["intermediate_size"]
-    d = H // cfg["num_attention_heads"]; nkv = cfg["num_key_value_heads"]
-    lin = lambda o, i: (rng.random((o, i), dtype=np.float32) - 0.5) * 0.07
-    w = {"embed_tokens.weight": lin(cfg["vocab_size"], H), "norm.weight": np.ones(H, np.float32)}
-    base = {"self_attn.q_proj.weight": lin(H, H), "self_attn.k_proj.weight": lin(nkv * d, H),
-            "self_attn.v_proj.weight": lin(nkv * d, H), "self_attn.o_proj.weight": lin(H, H),
-            "mlp.gate_proj.weight": lin(I, H), "mlp.up_proj.weight": lin(I, H), "mlp.down_proj.weight": lin(H, I),
-            "input_layernorm.weight": np.ones(H, np.float32), "post_attention_layernorm.weight": np.ones(H, np.float32)}
-    for li in range(layers):           # same arrays for every layer: timing only
-        for k, v in base.items():
-            w[f"layers.{li}.{k}"] = v
-    ids, mask = synth.make_batch(cfg, sample_docs, seq, seed=1234)
-    O.encode_core(w, cfg, ids[:1, :64], mask[:1, :64], "mean", True, acc_dtype=np.float32)   # warm BLAS threads
-    t0 = time.perf_counter()
-    O.encode_core(w, cfg, ids, mask, "mean", True, acc_dtype=np.float32)
-    dt = time.perf_counter() - t0
-    return {"value": sample_docs / dt, "unit": "docs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
-            "sample": f"numpy oracle (oracle/gritlm_oracle.py, fp32 OpenBLAS), {sample_docs} doc(s) x {seq} tok through all {layers} layers, {dt:.2f} s",
-            "seconds": dt}
 
 
 def vendor_gemm_comparator(dev, M=DOCS * SEQ):
@@ -199,6 +176,82 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
             **({"ragged_batch": ragged} if ragged is not None else {})}
 
 
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment: start the N ranks ourselves, exactly as the driver's
+    documented command does (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same flags>``), pass their output through (rank 0 prints the one JSON line) and return their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n} without a launcher environment -> starting {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+class DryEncoder:
+    """--dry-cpu ONLY (no GPU in the build container): a tiny stock ``transformers.MistralModel`` on the host stands in for the HIP
+    engine so that everything AROUND the kernels -- self-launch, process group, barriers, max-over-ranks timing, the cross-rank
+    GradCache step, the deadline guard, the one JSON line -- can be executed with 2 gloo ranks by tests/test_bench_cli.py.  The line
+    it produces carries "INVALID"; no number in it is a measurement."""
+
+    def __init__(self, layers: int, seed: int = 0):
+        from transformers import MistralConfig, MistralModel
+        hc = MistralConfig(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=layers, num_attention_heads=2,
+                           num_key_value_heads=1, head_dim=32, max_position_embeddings=512, sliding_window=None, pad_token_id=0,
+                           bos_token_id=1, eos_token_id=2, tie_word_embeddings=False)
+        hc.use_cache = False
+        hc._attn_implementation = "sdpa"
+        torch.manual_seed(seed)
+        self.model = MistralModel(hc).eval()
+        self.config = hc
+
+    @torch.no_grad()
+    def encode(self, ids, mask):
+        h = self.model(input_ids=ids, attention_mask=mask, is_causal=False)[0]
+        m = mask.unsqueeze(-1).float()
+        return torch.nn.functional.normalize((h.float() * m).sum(1) / m.sum(1), dim=-1)
+
+
+def dry_contrastive_leg(enc: "DryEncoder", world, rank, dist, pairs, group, chunk, seq):
+    """--dry-cpu: the cross-rank GradCache step (chunk-wise rep gathers, loss on the gathered batch with local-shard-only gradients,
+    gradient averaging) on the Hugging Face CPU path of GritLMTrainModel, gloo collectives."""
+    from gritlm_amd.training.gradcache import GradCacheStep
+    from gritlm_amd.training.model import DistributedContrastiveLoss, GritLMTrainModel
+    m = GritLMTrainModel.__new__(GritLMTrainModel)
+    torch.nn.Module.__init__(m)
+    m.model, m.embedding_attr, m.projection, m.normalized, m.pooling_method, m.attn = enc.model.train(), None, None, True, "mean", "bbcc"
+    m.emb_loss_fn = DistributedContrastiveLoss(0.02, dist is not None)
+    m.train_engine = None
+    gc = GradCacheStep(m, chunk)
+    gc.profile = {}
+    gen = torch.Generator().manual_seed(4321 + rank)
+    mk = lambda n: {"input_ids": torch.randint(3, enc.config.vocab_size, (n, seq), generator=gen),
+                    "attention_mask": torch.ones((n, seq), dtype=torch.int64)}
+    q, p = mk(pairs), mk(pairs * group)
+    t0 = time.perf_counter()
+    loss = gc(q, p)
+    if dist is not None:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    gnorm = torch.stack([x.grad.float().norm() for x in enc.model.parameters() if x.grad is not None]).norm().reshape(1).double()
+    spread = gnorm.clone()
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lo, hi = gnorm.clone(), gnorm.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = hi - lo
+    prof = gc.profile_summary()
+    return {"metric": "contrastive pairs/sec (DRY RUN)", "value": world * pairs / float(t.item()), "unit": "pairs/s", "n_gpus": world,
+            "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk, "global_batch": world * pairs,
+            "loss": float(loss), "grad_norm_after_averaging": float(gnorm.item()),
+            "grad_norm_spread_over_ranks": float(spread.item()) if dist is not None else 0.0,
+            "per_step_ms": {k: v for k, v in prof.items() if not k.startswith("_")}}
+
+
 def deadline_guard(budget_s: float, late_line):
     """Arms a daemon thread: unless the returned Event is set within ``budget_s`` seconds the thread prints ``late_line()`` (if it
     returns a string) and ends the PROCESS with exit code 0 (``os._exit``: the main thread may be parked inside a collective that will
@@ -216,7 +269,76 @@ def deadline_guard(budget_s: float, late_line):
     return done
 
 
+def full_depth_parity(dev):
+    """32-layer parity datum: the HIP engine on the SAME weights and token ids the ``cpu_baseline_numpy_oracle`` leg
+    pushes through all 32 fp32 layers (1 doc x 512 tokens, 7B layer shape), and -- as the yardstick -- the stock Hugging Face module in
+    bf16 on this GPU on the same weights: how far does ANY bf16 implementation of scripts/modeling_mistral_gritlm.py:936-1096 land from
+    the fp32 result after 32 layers."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch_reference as TR
+    from gritlm_amd import ops
+    from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine
+    cfg, w, ids, mask = oracle_full_depth_case()
+    t0 = time.perf_counter()
+    ref = oracle_full_depth_run(cfg, w, ids, mask)                                  # fp32 numpy oracle, all 32 layers
+    dt = time.perf_counter() - t0
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    eng = MistralEncoderEngine.from_state_dict(EncoderConfig.from_dict(cfg), sd, dev)
+    tid, tm = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    e_hip = ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy()
+    del eng
+    torch.cuda.empty_cache()
+    hf = TR.build_model(cfg, torch.bfloat16, dev, state_dict=sd)
+    e_hf = TR.encode(hf, tid, tm).float().cpu().numpy()
+    del hf
+    torch.cuda.empty_cache()
+    cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
+    hip, stock = cosd(e_hip, ref), cosd(e_hf, ref)
+    return {"what": "1 doc x 512 tokens through all 32 layers at the 7B layer shape, identical bf16-representable weights on every side",
+            "one_minus_cos_vs_fp32_oracle": hip, "stock_hf_bf16_one_minus_cos_vs_fp32_oracle": stock,
+            "one_minus_cos_vs_stock_hf_bf16": cosd(e_hip, e_hf),
+            "bound": "north_star: < 1e-4, or no further from fp32 than the reference's own bf16 run (stock HF bf16 on this GPU)",
+            "within_bound": bool(hip < 1e-4 or hip <= 1.25 * stock)}, {
+            "value": ids.shape[0] / dt, "unit": "docs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"numpy oracle (oracle/gritlm_oracle.py, fp32 OpenBLAS), {ids.shape[0]} doc(s) x {ids.shape[1]} tok through all "
+                      f"{cfg['num_hidden_layers']} layers, {dt:.2f} s", "seconds": dt}
+
+
+def oracle_full_depth_case(sample_docs=1, seq=512, layers=32):
+    """Weights / ids of the full-depth oracle leg: 7B layer shape, small vocabulary, the SAME bf16-representable arrays for every layer
+    (host memory stays at one layer; timing and error accumulation do not care)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import synth
+    cfg = dict(synth.CONFIGS["7b"]); cfg["num_hidden_layers"] = layers; cfg["vocab_size"] = 2048
+    rng = np.random.default_rng(0)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    d = H // cfg["num_attention_heads"]; nkv = cfg["num_key_value_heads"]
+    lin = lambda o, i: synth._bf16_round((rng.random((o, i), dtype=np.float32) - 0.5) * 0.07)
+    nrm = lambda: synth._bf16_round(1.0 + 0.1 * rng.standard_normal(H, dtype=np.float32))
+    w = {"embed_tokens.weight": lin(cfg["vocab_size"], H), "norm.weight": nrm()}
+    base = {"self_attn.q_proj.weight": lin(H, H), "self_attn.k_proj.weight": lin(nkv * d, H),
+            "self_attn.v_proj.weight": lin(nkv * d, H), "self_attn.o_proj.weight": lin(H, H),
+            "mlp.gate_proj.weight": lin(I, H), "mlp.up_proj.weight": lin(I, H), "mlp.down_proj.weight": lin(H, I),
+            "input_layernorm.weight": nrm(), "post_attention_layernorm.weight": nrm()}
+    for li in range(layers):
+        for k, v in base.items():
+            w[f"layers.{li}.{k}"] = v
+    ids, mask = synth.make_batch(cfg, sample_docs, seq, seed=1234)
+    return cfg, w, ids, mask
+
+
+def oracle_full_depth_run(cfg, w, ids, mask):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import gritlm_oracle as O
+    O.encode_core(w, cfg, ids[:1, :64], mask[:1, :64], "mean", True, acc_dtype=np.float32)   # warm BLAS threads
+    return O.encode_core(w, cfg, ids, mask, "mean", True, acc_dtype=np.float32)
+
+
 def main():
+    global DOCS, SEQ
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -229,63 +351,88 @@ def main():
     ap.add_argument("--chunk", type=int, default=32, help="GradCache chunk size (BASELINE configs[2]: 32)")
     ap.add_argument("--contrastive-steps", type=int, default=1)
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm encode on this GPU")
+    ap.add_argument("--dry-cpu", action="store_true",
+                    help="plumbing check without a GPU: gloo ranks, a tiny Hugging Face model on the host instead of the HIP engine; "
+                         "the line is marked INVALID (tests/test_bench_cli.py)")
     args = ap.parse_args()
+    dry = args.dry_cpu
 
+    forced = bool(os.environ.get("GRIT_BENCH_FORCE_DIST"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not forced:
+        if not dry and torch.cuda.device_count() < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != max(args.gpus, 1) and not forced:
+        print(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; reporting n_gpus = {world}", file=sys.stderr)
+    if dry:
+        dev = torch.device("cpu")
+        DOCS, SEQ = 8, 16
+        torch.set_num_threads(2)
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     # GRIT_BENCH_FORCE_DIST=1 (single process): run the N > 1 code path -- RCCL process group, barriers, max-over-ranks reduction,
     # cross-device loss, chunk-wise gathers, overlapped gradient all-reduce, deadline guard -- on a ONE-rank group, the only form of it
     # a one-GPU box can execute
-    multi = world > 1 or bool(os.environ.get("GRIT_BENCH_FORCE_DIST"))
+    multi = world > 1 or forced
+    backend = "gloo" if dry else "nccl"                                      # "nccl" == RCCL on ROCm
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29571")
         import datetime
-        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10),          # "nccl" == RCCL on ROCm
-                                rank=rank, world_size=world)
+        kw = {} if dry else {"device_id": dev}
+        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=10), rank=rank, world_size=world, **kw)
 
-    from gritlm_amd import ops
-    from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine
-
-    cfg = EncoderConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
-                        num_key_value_heads=8, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=10000.0)
-    eng = MistralEncoderEngine.random_init(cfg, dev, seed=0)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    if dry:
+        eng = DryEncoder(args.layers)
+        ops = timer = None
+        cfg = eng.config
+    else:
+        from gritlm_amd import ops
+        from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine
+        cfg = EncoderConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
+                            num_key_value_heads=8, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=10000.0)
+        eng = MistralEncoderEngine.random_init(cfg, dev, seed=0)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     ids = torch.randint(3, cfg.vocab_size, (DOCS, SEQ), generator=gen, device=dev, dtype=torch.int64)
     mask = torch.ones((DOCS, SEQ), dtype=torch.int64, device=dev)
 
     def step():
+        if dry:
+            return eng.encode(ids, mask)
         h = eng.forward(ids, mask, borrow=True)
         return ops.pool_norm(h, mask, "mean", True)
 
     for _ in range(args.warmup):
         emb = step()
-    timer = ops.KernelTimer()
-    torch.cuda.synchronize()
+    if not dry:
+        timer = ops.KernelTimer()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    ops.set_timer(timer)
+    sync()
+    if not dry:
+        ops.set_timer(timer)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         emb = step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    ops.set_timer(None)
+    if not dry:
+        ops.set_timer(None)
     assert torch.isfinite(emb).all(), "non-finite embeddings"
-    flops_per_token = eng.flops_per_token(SEQ)
+    flops_per_token = 0.0 if dry else eng.flops_per_token(SEQ)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -294,7 +441,7 @@ def main():
 
     # ---- ragged batch (SURVEY §8d "C2 padded variant"): lengths ~ U{64..512}, right-padded; padded vs packed (un-padded) path
     ragged = None
-    if not args.no_ragged:
+    if not args.no_ragged and not dry:
         g2 = torch.Generator(device=dev).manual_seed(99 + rank)
         lens = torch.randint(64, SEQ + 1, (DOCS,), generator=g2, device=dev)
         lens[0] = SEQ
@@ -316,32 +463,41 @@ def main():
                   "docs_per_s_padded_path": dps_pad, "docs_per_s_packed_path": dps_pack,
                   "bit_identical": bool(torch.equal(e_pad, e_pack))}
 
-    del eng, emb
-    torch.cuda.empty_cache()
+    baselines = not multi and not dry and not args.no_torch_baseline
+    hf_sd = eng.to_hf_state_dict() if baselines else None           # views of the engine's weights: the stock module is loaded from them
+    emb_engine = emb.float().clone()
+    if not dry:
+        eng._ws.clear()
+    del emb
+    if not baselines and not dry:
+        del eng
+    if not dry:
+        torch.cuda.empty_cache()
     vendor = None
-    if not multi and not args.no_torch_baseline:
+    if baselines:
         try:
             vendor = vendor_gemm_comparator(dev)
         except Exception as e:  # noqa: BLE001
             vendor = {"error": repr(e)[:200]}
     torch_baseline = None
-    if not multi and not args.no_torch_baseline:
+    if baselines:
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import torch_reference as TR
-            torch_baseline = TR.time_gpu(dev, DOCS, SEQ, args.layers)
+            torch_baseline = TR.time_gpu(dev, DOCS, SEQ, args.layers, state_dict=hf_sd, ids=ids, mask=mask)
+            e_hf = torch_baseline.pop("embeddings")
+            cos = torch.nn.functional.cosine_similarity(e_hf.float(), emb_engine, dim=1)
+            torch_baseline["engine_vs_stock_hf_same_weights_bf16"] = {
+                "what": f"the {DOCS} embeddings of the timed batch: HIP engine vs the stock Hugging Face module loaded from the engine's own "
+                        f"weights, bf16 on both sides, {args.layers} layers", "max_one_minus_cos": float((1 - cos).max().item()),
+                "mean_one_minus_cos": float((1 - cos).mean().item())}
+            del e_hf
         except Exception as e:  # noqa: BLE001
             torch_baseline = {"error": repr(e)[:300]}
+        del hf_sd, eng
         torch.cuda.empty_cache()
     line = None
     if rank == 0:
-        ks = timer.summary()
-        g = ks["gemm_bf16_nt"]
-        achieved = g["work"] / (g["total_ms"] * 1e-3) / 1e12           # TFLOP/s over all launches == avg flops / avg duration
-        shapes = {t: {"launches": v["launches"], "avg_ms": v["total_ms"] / v["launches"], "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12}
-                  for t, v in g.get("by_tag", {}).items()}
-        att = [v for t, v in g.get("by_tag", {}).items() if t.startswith("N=6144,K=4096") or t.startswith("N=4096,K=4096")]
-        att_tf = sum(v["work"] for v in att) / (sum(v["total_ms"] for v in att) * 1e-3) / 1e12 if att else None
         docs_per_s = world * DOCS * args.steps / dt_max
         flops_per_doc = flops_per_token * SEQ
         line = {
@@ -351,16 +507,25 @@ def main():
             "config": {"workload": "GritLM-7B (Mistral-7B shape, 32L, random-init) bf16 bidirectional encode, batch 256 x seq512, "
                                    "mean pooling + L2 normalise, per GPU", "docs_per_step_per_gpu": DOCS, "seq_len": SEQ,
                        "layers": args.layers, "parallelism": f"replicas x{world} (no data-path collective)"},
-            "model_flops_utilisation": docs_per_s / world * flops_per_doc / (MFMA_BF16_PEAK_TFLOPS * 1e12),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_k", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(),
-                         "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
-                         "avg_flops_per_launch": g["work"] / g["launches"], "by_shape": shapes,
-                         "attention_gemms_qkv_oproj": None if att_tf is None else
-                         {"achieved": att_tf, "frac": att_tf / MFMA_BF16_PEAK_TFLOPS}},
-            "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
-                            "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()},
         }
+        if not dry:
+            ks = timer.summary()
+            g = ks["gemm_bf16_nt"]
+            achieved = g["work"] / (g["total_ms"] * 1e-3) / 1e12           # TFLOP/s over all launches == avg flops / avg duration
+            shapes = {t: {"launches": v["launches"], "avg_ms": v["total_ms"] / v["launches"], "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12}
+                      for t, v in g.get("by_tag", {}).items()}
+            att = [v for t, v in g.get("by_tag", {}).items() if t.startswith("N=6144,K=4096") or t.startswith("N=4096,K=4096")]
+            att_tf = sum(v["work"] for v in att) / (sum(v["total_ms"] for v in att) * 1e-3) / 1e12 if att else None
+            traffic, traffic_note = measured_traffic()
+            line["model_flops_utilisation"] = docs_per_s / world * flops_per_doc / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_nt_k", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, **traffic_note,
+                                "launches": g["launches"], "avg_launch_ms": g["avg_ms"],
+                                "avg_flops_per_launch": g["work"] / g["launches"], "by_shape": shapes,
+                                "attention_gemms_qkv_oproj": None if att_tf is None else
+                                {"achieved": att_tf, "frac": att_tf / MFMA_BF16_PEAK_TFLOPS}}
+            line["kernels"] = {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3),
+                                   "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in ks.items()}
     # N > 1: the contrastive leg is the only part with data-path collectives.  If a rank dies or stalls inside it the others would sit in a
     # collective until the RCCL watchdog aborts the job and the primary line would be lost: a deadline thread on every rank prints the
     # primary line (with the leg marked as timed out) and exits the process cleanly instead.
@@ -372,15 +537,18 @@ def main():
             if ragged is not None:
                 line["ragged_batch"] = ragged
             line["contrastive"] = {"error": f"contrastive leg exceeded its deadline on {world} ranks; primary line emitted by the deadline guard"}
-            line["collectives"] = {"backend": "nccl", "ranks": world, "encode_data_path_collectives": 0}
+            line["collectives"] = {"backend": backend, "ranks": world, "encode_data_path_collectives": 0}
             return json.dumps(line)
         guard = deadline_guard(float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "480")), _late_line)
     contrastive = None
     if not args.no_contrastive:
-        torch.cuda.reset_peak_memory_stats()
         try:
-            contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, chunk=args.chunk, steps=args.contrastive_steps,
-                                          ragged_pairs=0 if args.no_ragged else 32)
+            if dry:
+                contrastive = dry_contrastive_leg(eng, world, rank, dist, pairs=args.pairs, group=2, chunk=args.chunk, seq=SEQ)
+            else:
+                torch.cuda.reset_peak_memory_stats()
+                contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, chunk=args.chunk, steps=args.contrastive_steps,
+                                              ragged_pairs=0 if args.no_ragged else 32)
         except Exception as e:  # noqa: BLE001  -- never lose the primary metric line to the secondary leg
             contrastive = {"error": repr(e)[:300]}
 
@@ -391,18 +559,24 @@ def main():
             line["ragged_batch"] = ragged
         if contrastive is not None:
             line["contrastive"] = contrastive
-        if args.layers != 32:
+        if dry:
+            line["INVALID"] = "--dry-cpu: plumbing check on the host (tiny Hugging Face model, gloo); no number here is a measurement"
+        elif args.layers != 32:
             line["INVALID"] = "debug run with --layers != 32"
         if torch_baseline is not None:
             line["rocm_torch_baseline"] = torch_baseline
             if "value" in torch_baseline:
                 line["speedup_vs_rocm_torch"] = docs_per_s / torch_baseline["value"]
         if multi:
-            line["collectives"] = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' backend on ROCm)",
+            line["collectives"] = {"backend": dist.get_backend(), "library": "gloo (dry run)" if dry else
+                                   "RCCL (torch.distributed 'nccl' backend on ROCm)",
                                    "ranks": dist.get_world_size(), "encode_data_path_collectives": 0}
-        if not multi and not args.no_cpu_baseline:
+        if not multi and not dry and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-            line["cpu_baseline_numpy_oracle"] = cpu_baseline_numpy()
+            try:
+                line["parity_full_depth"], line["cpu_baseline_numpy_oracle"] = full_depth_parity(dev)
+            except Exception as e:  # noqa: BLE001
+                line["parity_full_depth"] = {"error": repr(e)[:300]}
         print(json.dumps(line), flush=True)
         emitted.append(True)
     if dist is not None:

@@ -184,6 +184,31 @@ class MistralEncoderEngine:
         eng.norm = nrm()
         return eng
 
+    def to_hf_state_dict(self) -> dict:
+        """The engine's (repacked) weights under the Hugging Face ``MistralModel`` names (inverse of ``from_state_dict``: the fused QKV
+        matrix split back, the gate / up rows de-interleaved); dense MLP only.  bench.py / the tests load the STOCK module from it to
+        compare the two implementations on identical parameters."""
+        c = self.cfg
+        if c.num_local_experts:
+            raise NotImplementedError("to_hf_state_dict: dense (Mistral) engines only")
+        from . import _lib
+        blk = _lib.load().grit_swiglu_block()
+        nq, nkv, d, I, H = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.intermediate_size, c.hidden_size
+        sd = {"embed_tokens.weight": self.embed, "norm.weight": self.norm}
+        for i, L in enumerate(self.layers):
+            p = f"layers.{i}."
+            sd[p + "self_attn.q_proj.weight"] = L.wqkv[:nq * d]
+            sd[p + "self_attn.k_proj.weight"] = L.wqkv[nq * d:(nq + nkv) * d]
+            sd[p + "self_attn.v_proj.weight"] = L.wqkv[(nq + nkv) * d:]
+            sd[p + "self_attn.o_proj.weight"] = L.wo
+            gu = L.wgu.view(I // blk, 2, blk, H)
+            sd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(I, H)
+            sd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(I, H)
+            sd[p + "mlp.down_proj.weight"] = L.wdown
+            sd[p + "input_layernorm.weight"] = L.ln1
+            sd[p + "post_attention_layernorm.weight"] = L.ln2
+        return sd
+
     # ------------------------------------------------------------------ buffers
     def _workspace(self, T: int):
         """Activation buffers for T token rows: one allocation sized for the largest T seen, handed out as row-slices

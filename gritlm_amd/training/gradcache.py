@@ -45,10 +45,27 @@ def _rows(chunk: Dict) -> int:
     return v.shape[0] if isinstance(v, torch.Tensor) else len(v)
 
 
+def _all_reduce_mean(buf: torch.Tensor):
+    """Asynchronous all-reduce that leaves the MEAN over ranks in ``buf``.  RCCL averages inside the collective
+    (``ReduceOp.AVG``: no second pass over the 14.5 GB of gradients after the exchange); gloo has no AVG, so the CPU test
+    path sums and divides.  Returns (work handle, divisor to apply after ``wait()`` or None)."""
+    if dist.get_backend() == "nccl":
+        return dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True), None
+    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), dist.get_world_size()
+
+
+def _finish_mean(pending) -> None:
+    for buf, (work, div) in pending:
+        work.wait()
+        if div is not None:
+            buf.div_(div)
+
+
 class OverlappedGradSync:
     """Data-parallel gradient averaging overlapped with the backward of the LAST GradCache chunk (what DDP does when ``no_sync`` is
     lifted on the last chunk, grad_cache.py:230-236): the native engine reports each layer's packed gradient buffers as soon as
-    they are final and their all-reduce (RCCL, own stream) runs under the remaining layers' backward kernels."""
+    they are final and their averaging all-reduce (RCCL ``ncclAvg``, own stream) runs under the remaining layers' backward kernels;
+    nothing but the waits is left on the critical path after the last chunk."""
 
     def __init__(self, model):
         self.model, self.pending = model, []
@@ -56,19 +73,16 @@ class OverlappedGradSync:
 
     def arm(self):
         if self.active:
-            self.model._on_layer_done = lambda bufs: self.pending.extend((b, dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True)) for b in bufs)
+            self.model._on_layer_done = lambda bufs: self.pending.extend((b, _all_reduce_mean(b)) for b in bufs)
 
     def finish(self):
         if not self.active:
             sync_gradients(self.model)
             return
         self.model._on_layer_done = None
-        w = dist.get_world_size()
         small = self.model.train_engine.grad_buffers(small_only=True)
-        self.pending.extend((b, dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True)) for b in small)
-        for b, h in self.pending:
-            h.wait()
-            b.div_(w)
+        self.pending.extend((b, _all_reduce_mean(b)) for b in small)
+        _finish_mean(self.pending)
         self.pending.clear()
 
 
@@ -78,11 +92,7 @@ def sync_gradients(model) -> None:
         return
     eng = getattr(model, "train_engine", None)
     bufs = eng.grad_buffers() if eng is not None else [p.grad for p in model.parameters() if p.grad is not None]
-    w = dist.get_world_size()
-    handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in bufs]
-    for h, b in zip(handles, bufs):
-        h.wait()
-        b.div_(w)
+    _finish_mean([(b, _all_reduce_mean(b)) for b in bufs])
 
 
 class ChunkGather:

@@ -1,0 +1,59 @@
+"""bench.py's launch plumbing, executed without a GPU (VERDICT r02 "next" #1).
+
+``python bench.py --gpus N`` with N > 1 and NO launcher environment must start its own N ranks (the round-2 file exited with rc 2
+there) and rank 0 must print exactly one JSON line with ``n_gpus == N`` and ``collectives.ranks == N``.  ``--dry-cpu`` swaps the HIP
+engine for a tiny Hugging Face model on the host and RCCL for gloo, so the whole control flow around the kernels -- self-launch through
+``torch.distributed.run``, process group, barriers, max-over-ranks timing, the cross-rank GradCache step (chunk-wise gathers, loss on
+the gathered batch, gradient averaging), the deadline guard, process-group teardown -- runs here with 2 ranks."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "GRIT_BENCH_FORCE_DIST", "GRIT_DIST_WORLD1")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-cpu", "--layers", "1", "--steps", "2", "--warmup", "1",
+                        "--pairs", "4", "--chunk", "2", *flags], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), r
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks_and_prints_one_line():
+    line, r = _run("--gpus", "2")
+    assert "starting 2 ranks" in r.stderr
+    assert line["n_gpus"] == 2 and line["collectives"]["ranks"] == 2 and line["collectives"]["backend"] == "gloo"
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["value"] > 0
+    assert "INVALID" in line                                   # a dry run must never pass for a measurement
+    c = line["contrastive"]
+    assert "error" not in c, c
+    assert c["global_batch"] == 8 and c["n_gpus"] == 2
+    assert c["per_step_ms"]["gather_collectives"] == 2 + 4      # one gather per GradCache chunk: 4 q rows / 2 + 8 p rows / 2
+    assert c["grad_norm_spread_over_ranks"] < 1e-6 * max(1.0, c["grad_norm_after_averaging"])     # replicas hold the same averaged gradient
+    assert c["loss"] == c["loss"] and c["loss"] > 0
+
+
+def test_single_process_dry_run_has_no_collectives():
+    line, r = _run("--gpus", "1")
+    assert "starting" not in r.stderr
+    assert line["n_gpus"] == 1 and "collectives" not in line and "INVALID" in line
+    assert "error" not in line["contrastive"]
+
+
+def test_under_a_launcher_environment_bench_does_not_relaunch():
+    """The driver's form: ``python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2``."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-cpu", "--layers", "1", "--steps",
+                        "1", "--warmup", "0", "--no-contrastive"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "starting 2 ranks" not in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["collectives"]["ranks"] == 2
