@@ -6,7 +6,7 @@ import json
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = f"gpurun_out/prof_{tag}"
 shutil.copy(f"{src}/bench_stats/bench_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy(f"{src}/bench_stats.json", f"profiles/{tag}_bench_under_rocprof.json")
@@ -48,7 +48,9 @@ for k, v in out.items():
     v["mfma_busy_frac_of_simd_cycles"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (g * 1024)
     v["hbm_side_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024   # guide: FETCH_SIZE x2 on gfx950, KB units
 avg = sum(out[k]["hbm_side_bytes_per_launch"] * weights[k] for k in out) / sum(weights.values())
-res = {"note": "rocprofv3 --pmc passes (SQ / MFMA+GRBM / FETCH_SIZE / WRITE_SIZE each in its own run, --kernel-trace only) on tools/gemm_probe.py, "
+import hashlib
+res = {"gemm_bf16_hip_sha16": hashlib.sha256(open("gritlm_amd/csrc/gemm_bf16.hip", "rb").read()).hexdigest()[:16],   # bench.py: traffic_stale check
+       "note": "rocprofv3 --pmc passes (SQ / MFMA+GRBM / FETCH_SIZE / WRITE_SIZE each in its own run, --kernel-trace only) on tools/gemm_probe.py, "
                "M=131072, 3 launches per shape; GRBM_GUI_ACTIVE is summed over the 8 XCDs; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (chip cycles x 1024 SIMDs)",
        "kernels": out, "avg_traffic_bytes_per_gemm_launch_in_forward": avg}
 json.dump(res, open(f"profiles/{tag}_gemm_pmc.json", "w"), indent=1)
