@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgritlm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gritlm_hip.h")
 
+ABI_VERSION = 2
 GRIT_OK, GRIT_E_BADARG, GRIT_E_UNSUPPORTED, GRIT_E_LAUNCH, GRIT_E_RCCL = 0, -1, -2, -3, -4
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ROPE, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5, 6
 POOL_MODES = {"mean": 0, "weightedmean": 1, "cls": 2, "lasttoken": 3}
@@ -57,7 +58,7 @@ _SIGNATURES = {
     "grit_moe_combine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p]),
     "grit_gemm_bf16_nt_grouped_epi": (_i, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _l, _i, _p]),
     "grit_pool_norm_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "grit_infonce_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "grit_infonce_rows_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "grit_transpose_bf16": (_i, [_p, _p, _l, _l, _l, _l, _p]),
     "grit_rmsnorm_bwd_workspace_rows": (_l, [_l]),
     "grit_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _p]),
@@ -98,8 +99,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is absent -> loud
         fn.restype = res
         fn.argtypes = args
-    if lib.grit_version() != 1:
-        raise GritHipError(f"ABI version mismatch: library {lib.grit_version()} != binding 1")
+    if lib.grit_version() != ABI_VERSION:
+        raise GritHipError(f"ABI version mismatch: library {lib.grit_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
 

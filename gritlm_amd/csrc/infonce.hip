@@ -6,7 +6,7 @@
 // bitwise an fmaf chain): at tau = 0.02 a cosine error of 2e-5 already moves a logit by 1e-3, so a
 // bf16-input MFMA would miss the 1e-3 loss tolerance (SURVEY.md §7 hard part 3).
 //
-//   1. scores = (1/tau) q p^T                       strided f32 MFMA GEMM
+//   1. scores = (1/tau) q p^T                       strided f32 MFMA GEMM (gemm_f32.hip)
 //   2. per row: lse, loss += (lse - s[i, i*G])/Nq;  scores <- (softmax - onehot) / (Nq tau)   (in place)
 //   3. dq = dS[q_off.., :] p ,  dp = dS[:, p_off..]^T q   for the caller's own rows only -- the rows
 //      that carry grad after `_dist_gather_tensor` re-inserts the local shard (:49-60).
@@ -14,77 +14,9 @@
 
 namespace grit {
 
-constexpr int FB = 128;   // tile M = N
-constexpr int FK = 16;    // tile K
-constexpr int FP = FB + 4;
-
-// C[M,N] = alpha * sum_k A(m,k) B(k,n);  A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
-__global__ void __launch_bounds__(256) gemm_f32_strided_k(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
-                                                          int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
-                                                          int64_t ldc, float alpha) {
-  __shared__ float As[FK][FP];
-  __shared__ float Bs[FK][FP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * FB, n0 = blockIdx.x * FB;
-  const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  for (int k0 = 0; k0 < K; k0 += FK) {
-#pragma unroll
-    for (int it = 0; it < (FB * FK) / 256; ++it) {
-      const int idx = tid + 256 * it;
-      {
-        const int k = a_kfast ? (idx & (FK - 1)) : (idx / FB);
-        const int m = a_kfast ? (idx / FK) : (idx & (FB - 1));
-        float v = 0.f;
-        if (m0 + m < M && k0 + k < K) v = A[(int64_t)(m0 + m) * sam + (int64_t)(k0 + k) * sak];
-        As[k][m] = v;
-      }
-      {
-        const int k = b_kfast ? (idx & (FK - 1)) : (idx / FB);
-        const int n = b_kfast ? (idx / FK) : (idx & (FB - 1));
-        float v = 0.f;
-        if (n0 + n < N && k0 + k < K) v = Bm[(int64_t)(k0 + k) * sbk + (int64_t)(n0 + n) * sbn];
-        Bs[k][n] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < FK / 2; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      float a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[kk][wm * 64 + i * 32 + (lane & 31)];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[kk][wn * 64 + j * 32 + (lane & 31)];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // D[row i][col j]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < N) C[(int64_t)m * ldc + n] = alpha * acc[i][j][r];
-      }
-    }
-}
+// exact-f32 MFMA GEMM with arbitrary operand strides: gemm_f32.hip
+int launch_f32_gemm_strided(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+                            int64_t ldc, float alpha, hipStream_t st);
 
 // one workgroup per query row: logsumexp, the row's loss term (loss_rows[i]; summed in a fixed order by infonce_loss_k -- no float
 // atomics: the loss is bit-reproducible from run to run), then d loss / d raw-scores in place
@@ -124,13 +56,13 @@ __global__ void __launch_bounds__(256) infonce_ce_k(float* __restrict__ scores, 
   }
 }
 
-// loss[0] = mean(loss[1 .. Nq]): one workgroup, fixed summation tree (thread t adds rows t, t+256, ... in order; then a fixed
+// loss[0] = mean(loss_rows[0 .. Nq)): one workgroup, fixed summation tree (thread t adds rows t, t+256, ... in order; then a fixed
 // wave / cross-wave reduction)
-__global__ void __launch_bounds__(256) infonce_loss_k(float* __restrict__ loss, int Nq) {
+__global__ void __launch_bounds__(256) infonce_loss_k(float* __restrict__ loss, const float* __restrict__ loss_rows, int Nq) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
   float acc = 0.f;
-  for (int i = tid; i < Nq; i += 256) acc += loss[1 + i];
+  for (int i = tid; i < Nq; i += 256) acc += loss_rows[i];
   acc = wave_sum(acc);
   if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
@@ -139,38 +71,32 @@ __global__ void __launch_bounds__(256) infonce_loss_k(float* __restrict__ loss, 
 
 static int launch_f32_gemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk,
                            int64_t sbn, int64_t ldc, float alpha, hipStream_t st) {
-  dim3 grid((unsigned)((N + FB - 1) / FB), (unsigned)((M + FB - 1) / FB));
-  hipLaunchKernelGGL(gemm_f32_strided_k, grid, dim3(256), 0, st, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha);
-  GRIT_CHECK_LAUNCH("grit_infonce: f32 gemm");
-  return GRIT_OK;
-}
-
-// shared with knn.hip (brute-force index search = the same similarity GEMM)
-int launch_f32_gemm_strided(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
-                            int64_t ldc, float alpha, hipStream_t st) {
-  return launch_f32_gemm(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, st);
+  return launch_f32_gemm_strided(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, st);
 }
 
 }  // namespace grit
 
 using namespace grit;
 
-extern "C" int grit_infonce_fwd_bwd(const float* q, const float* p, float inv_temperature, float* scores, float* loss, float* dq,
-                                    float* dp, int Nq, int Np, int H, int q_off, int nq_loc, int p_off, int np_loc, void* stream) {
-  GRIT_REQUIRE(q && p && scores && loss, GRIT_E_BADARG, "grit_infonce_fwd_bwd: null pointer");
-  GRIT_REQUIRE(Nq > 0 && Np > 0 && H > 0, GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad sizes");
-  GRIT_REQUIRE(Np % Nq == 0, GRIT_E_BADARG, "grit_infonce_fwd_bwd: Np=%d is not a multiple of Nq=%d (target = i * Np/Nq)", Np, Nq);
-  GRIT_REQUIRE((dq == nullptr) || (q_off >= 0 && nq_loc > 0 && q_off + nq_loc <= Nq), GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad q range");
-  GRIT_REQUIRE((dp == nullptr) || (p_off >= 0 && np_loc > 0 && p_off + np_loc <= Np), GRIT_E_BADARG, "grit_infonce_fwd_bwd: bad p range");
+// (ABI 2: the round-2 entry point `grit_infonce_fwd_bwd` took ONE loss pointer that silently grew from 1 to 1 + Nq floats; the per-row
+// terms now have their own argument and the symbol a new name, so a caller built against the old header fails at load time.)
+extern "C" int grit_infonce_rows_fwd_bwd(const float* q, const float* p, float inv_temperature, float* scores, float* loss, float* loss_rows,
+                                         float* dq, float* dp, int Nq, int Np, int H, int q_off, int nq_loc, int p_off, int np_loc,
+                                         void* stream) {
+  GRIT_REQUIRE(q && p && scores && loss && loss_rows, GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: null pointer");
+  GRIT_REQUIRE(Nq > 0 && Np > 0 && H > 0, GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad sizes");
+  GRIT_REQUIRE(Np % Nq == 0, GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: Np=%d is not a multiple of Nq=%d (target = i * Np/Nq)", Np, Nq);
+  GRIT_REQUIRE((dq == nullptr) || (q_off >= 0 && nq_loc > 0 && q_off + nq_loc <= Nq), GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad q range");
+  GRIT_REQUIRE((dp == nullptr) || (p_off >= 0 && np_loc > 0 && p_off + np_loc <= Np), GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad p range");
   hipStream_t st = (hipStream_t)stream;
   // scores[i,j] = inv_t * sum_h q[i,h] p[j,h]
   int rc = launch_f32_gemm(q, p, scores, Nq, Np, H, H, 1, 1, H, Np, inv_temperature, st);
   if (rc) return rc;
   const int want_grad = (dq != nullptr) || (dp != nullptr);
-  hipLaunchKernelGGL(infonce_ce_k, dim3(Nq), dim3(256), 0, st, scores, loss + 1, Nq, Np, Np / Nq, inv_temperature, want_grad);
-  GRIT_CHECK_LAUNCH("grit_infonce_fwd_bwd: ce");
-  hipLaunchKernelGGL(infonce_loss_k, dim3(1), dim3(256), 0, st, loss, Nq);
-  GRIT_CHECK_LAUNCH("grit_infonce_fwd_bwd: loss");
+  hipLaunchKernelGGL(infonce_ce_k, dim3(Nq), dim3(256), 0, st, scores, loss_rows, Nq, Np, Np / Nq, inv_temperature, want_grad);
+  GRIT_CHECK_LAUNCH("grit_infonce_rows_fwd_bwd: ce");
+  hipLaunchKernelGGL(infonce_loss_k, dim3(1), dim3(256), 0, st, loss, loss_rows, Nq);
+  GRIT_CHECK_LAUNCH("grit_infonce_rows_fwd_bwd: loss");
   if (dq) {  // dq[m,h] = sum_j dS[q_off+m, j] p[j,h]
     rc = launch_f32_gemm(scores + (int64_t)q_off * Np, p, dq, nq_loc, H, Np, Np, 1, H, 1, H, 1.0f, st);
     if (rc) return rc;

@@ -376,12 +376,13 @@ def infonce(q: torch.Tensor, p: torch.Tensor, temperature: float, q_off: int = 0
     np_loc = Np if np_loc is None else np_loc
     scores = torch.empty((Nq, Np), dtype=F32, device=q.device)
     loss_buf = torch.empty((1 + Nq,), dtype=F32, device=q.device)        # [0] mean loss, [1 + i] the term of row i
-    loss = loss_buf[:1]
+    loss, loss_rows = loss_buf[:1], loss_buf[1:]
     dq = torch.empty((nq_loc, H), dtype=F32, device=q.device) if want_grad else None
     dp = torch.empty((np_loc, H), dtype=F32, device=q.device) if want_grad else None
-    check(_lib.load().grit_infonce_fwd_bwd(_chk(q, F32, "q"), _chk(p, F32, "p"), 1.0 / float(temperature), _chk(scores, F32, "scores"),
-                                           _chk(loss_buf, F32, "loss"), 0 if dq is None else dq.data_ptr(), 0 if dp is None else dp.data_ptr(),
-                                           Nq, Np, H, q_off, nq_loc, p_off, np_loc, _stream()), "grit_infonce_fwd_bwd")
+    check(_lib.load().grit_infonce_rows_fwd_bwd(_chk(q, F32, "q"), _chk(p, F32, "p"), 1.0 / float(temperature), _chk(scores, F32, "scores"),
+                                                _chk(loss, F32, "loss"), _chk(loss_rows, F32, "loss_rows"),
+                                                0 if dq is None else dq.data_ptr(), 0 if dp is None else dp.data_ptr(),
+                                                Nq, Np, H, q_off, nq_loc, p_off, np_loc, _stream()), "grit_infonce_rows_fwd_bwd")
     return loss, dq, dp
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 1
+#define GRIT_ABI_VERSION 2
 
 enum {
   GRIT_OK = 0,
@@ -199,14 +199,15 @@ int grit_pool_norm_varlen_bwd(const float* y, const float* dy, const float* inv_
 
 /* scores = q p^T / tau (fp32 MFMA, exact f32), target[i] = i * (Np / Nq), CrossEntropyLoss(mean).
  * q [Nq,H] fp32, p [Np,H] fp32 (already gathered across ranks, rank order).
- * scores: workspace fp32 [Nq,Np] (holds d loss / d scores afterwards); loss: fp32 [1 + Nq] -- loss[0] = the mean loss,
- * loss[1 + i] = the loss term of query row i (summed in a fixed order: the result is bit-reproducible, no float atomics).
+ * scores: workspace fp32 [Nq,Np] (holds d loss / d scores afterwards); loss: fp32 [1] = the mean loss; loss_rows: fp32 [Nq],
+ * loss_rows[i] = the loss term of query row i (summed in a fixed order: the result is bit-reproducible, no float atomics).
+ * (ABI 2 renamed this entry point from grit_infonce_fwd_bwd, whose single `loss` pointer had grown to 1 + Nq floats.)
  * Gradients are produced only for the caller's local rows, exactly the rows that carry grad in the
  * reference after `_dist_gather_tensor` (:49-60): dq [nq_loc,H] for q rows [q_off, q_off+nq_loc),
  * dp [np_loc,H] for p rows [p_off, p_off+np_loc).  dq/dp may be NULL (forward only). */
-int grit_infonce_fwd_bwd(const float* q, const float* p, float inv_temperature, float* scores, float* loss,
-                         float* dq, float* dp, int Nq, int Np, int H, int q_off, int nq_loc, int p_off,
-                         int np_loc, void* stream);
+int grit_infonce_rows_fwd_bwd(const float* q, const float* p, float inv_temperature, float* scores, float* loss,
+                              float* loss_rows, float* dq, float* dp, int Nq, int Np, int H, int q_off, int nq_loc,
+                              int p_off, int np_loc, void* stream);
 
 /* ---- helpers -------------------------------------------------------------------------------- */
 

@@ -349,6 +349,26 @@ def check_infonce_big(nq=256, group=8, H=512, tau=0.02):
     return _res(f"infonce[Nq={nq},G={group},H={H}] vs oracle", lerr < 1e-3 and e1 < 2e-3 and e2 < 2e-3, loss_abs=lerr, dq_rel=e1, dp_rel=e2)
 
 
+def check_infonce_shapes(nq, group, H, q_off=0, nq_loc=None, p_off=0, np_loc=None, tau=0.05, seed=61):
+    """The three products of the step (scores, dq, dp) through every path of the round-3 f32 GEMM (csrc/gemm_f32.hip): 128x128 / 64x64
+    / 32x128 tiles, k-contiguous and row-contiguous LDS images, 16-byte and guarded scalar operand loads (H or offsets not a multiple
+    of 4), ragged M / N / K edges, local-row ranges -- vs the fp64 oracle."""
+    rng = np.random.default_rng(seed)
+    q = O.l2_normalize(rng.standard_normal((nq, H), dtype=np.float32))
+    p = O.l2_normalize(rng.standard_normal((nq * group, H), dtype=np.float32))
+    nq_loc = nq - q_off if nq_loc is None else nq_loc
+    np_loc = nq * group - p_off if np_loc is None else np_loc
+    loss_ref, dq_ref, dp_ref, _ = O.infonce(q, p, tau)
+    dq_ref, dp_ref = dq_ref[q_off:q_off + nq_loc], dp_ref[p_off:p_off + np_loc]
+    loss, dq, dp = ops.infonce(torch.from_numpy(q).to(DEV), torch.from_numpy(p).to(DEV), tau, q_off, nq_loc, p_off, np_loc)
+    lerr = abs(float(loss.item()) - loss_ref)
+    e1 = float(np.max(np.abs(f32(dq) - dq_ref))) / float(np.abs(dq_ref).max())
+    e2 = float(np.max(np.abs(f32(dp) - dp_ref))) / float(np.abs(dp_ref).max())
+    ok = lerr < 1e-3 and e1 < 2e-3 and e2 < 2e-3 and dq.shape == dq_ref.shape and dp.shape == dp_ref.shape
+    return _res(f"infonce shapes [Nq={nq},G={group},H={H},q[{q_off}:+{nq_loc}],p[{p_off}:+{np_loc}]] vs oracle", ok, loss_abs=lerr, dq_rel=e1,
+                dp_rel=e2)
+
+
 def check_transpose(R=136, Cc=200):
     x = rnd((R, Cc), 23)
     ok = np.array_equal(f32(ops.transpose(bf(x))), x.T)
@@ -1918,6 +1938,12 @@ ALL_CHECKS = [
     ("infonce_local", check_infonce_local_rows, {}),
     ("infonce_big", check_infonce_big, {}),
     ("infonce_reproducible", check_infonce_reproducible, {}),
+    ("infonce_tiles128", check_infonce_shapes, dict(nq=1024, group=4, H=96)),                       # 8 x 32 = 256 tiles of 128 x 128
+    ("infonce_tiles128_local", check_infonce_shapes, dict(nq=1024, group=4, H=64, q_off=384, nq_loc=128, p_off=1536, np_loc=512)),
+    ("infonce_scalar_loads", check_infonce_shapes, dict(nq=75, group=3, H=50)),                     # H % 4 != 0, Np % 4 != 0
+    ("infonce_odd_offsets", check_infonce_shapes, dict(nq=130, group=2, H=132, q_off=7, nq_loc=33, p_off=13, np_loc=71)),
+    ("infonce_few_rows", check_infonce_shapes, dict(nq=8, group=8, H=260)),                          # M <= 32: the 32 x 128 tile
+    ("infonce_ragged_k", check_infonce_shapes, dict(nq=96, group=5, H=1028)),                        # K = 1028 / 480 / 96: partial K-steps
     ("transpose", check_transpose, {}),
     ("rmsnorm_bwd", check_rmsnorm_bwd, {}),
     ("rmsnorm_bwd_4096", check_rmsnorm_bwd, dict(T=21, H=4096, with_res=False)),
@@ -1996,6 +2022,8 @@ ALL_CHECKS = [
     ("knn_topk", check_knn_topk, {}),
     ("knn_topk_transposed_big", check_knn_topk, dict(Q=3, N=300000, H=128, k=100, transposed=True)),
     ("knn_topk_small", check_knn_topk, dict(Q=2, N=37, H=64, k=37)),
+    ("knn_topk_transposed_odd", check_knn_topk, dict(Q=33, N=4099, H=68, k=5, transposed=True)),    # [H,N] index, N % 4 != 0, 64 x 64 tiles
+    ("knn_topk_q32", check_knn_topk, dict(Q=32, N=70000, H=128, k=10)),                              # the 32 x 128 tile on a long index
     ("cli_native", check_cli_native, {}),
     ("cli_native_mixtral", check_cli_native, dict(arch="mixtral")),
     ("cli_unified_native", check_cli_unified_native, {}),

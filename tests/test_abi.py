@@ -15,7 +15,7 @@ def test_library_loads_and_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/gritlm_hip.h but not exported"
     assert set(syms) == set(_lib._SIGNATURES), "ctypes signature table out of sync with the header"
-    assert lib.grit_version() == 1
+    assert lib.grit_version() == _lib.ABI_VERSION
 
 
 def test_header_cites_reference_for_each_entry_point():
@@ -39,7 +39,7 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert lib.grit_gemm_bf16_nt(p16, p16, p16, 4, 16, 64, 64, 64, 16, 7, None, 0, None) == _lib.GRIT_E_BADARG        # epilogue
     assert lib.grit_attn_bidir_fwd(p16, p16, p16, None, 1, 8, 2, 1, 64, 256, 128, 0.1, None) == _lib.GRIT_E_UNSUPPORTED  # head_dim
     assert lib.grit_pool_norm_fwd(p16, p16, None, p16, None, 1, 8, 64, 9, 1, None) == _lib.GRIT_E_BADARG             # pooling mode
-    assert lib.grit_infonce_fwd_bwd(p16, p16, 50.0, p16, p16, None, None, 3, 7, 8, 0, 3, 0, 7, None) == _lib.GRIT_E_BADARG  # Np % Nq
+    assert lib.grit_infonce_rows_fwd_bwd(p16, p16, 50.0, p16, p16, p16, None, None, 3, 7, 8, 0, 3, 0, 7, None) == _lib.GRIT_E_BADARG  # Np % Nq
     with pytest.raises(_lib.GritHipError):
         _lib.check(-2, "x")
 

@@ -24,7 +24,7 @@ def test_native_library_is_loaded():
     from gritlm_amd import _lib
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     lib = _lib.load()
-    assert lib.grit_version() == 1
+    assert lib.grit_version() == _lib.ABI_VERSION
     import ctypes, os
     maps = open(f"/proc/{os.getpid()}/maps").read()
     assert "libgritlm_hip.so" in maps, "native library not mapped into the process"
