@@ -68,7 +68,7 @@ _SIGNATURES = {
     "grit_attn_causal_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_attn_bidir_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _i, _l, _l, _f, _p]),
     "grit_attn_causal_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _i, _l, _l, _f, _p]),
-    "grit_embed_scatter_add": (_i, [_p, _p, _p, _l, _i, _l, _p]),
+    "grit_embed_scatter_add_sorted": (_i, [_p, _p, _p, _p, _l, _i, _l, _p]),
     "grit_accum_bf16_from_f32": (_i, [_p, _p, _l, _p]),
 }
 

@@ -190,18 +190,32 @@ __global__ void __launch_bounds__(256) swiglu_bwd_k(const uint16_t* __restrict__
   }
 }
 
-// ---------------------------------------------------------------- embedding backward: dtable[ids[t]] += dh[t]  (fp32 atomics)
-__global__ void __launch_bounds__(256) embed_scatter_add_k(const uint4* __restrict__ dh, const int64_t* __restrict__ ids,
-                                                           float* __restrict__ dtable, int64_t T, int HC, int64_t V) {
-  const int64_t total = T * HC;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t t = i / HC; const int c = (int)(i - t * HC);
-    int64_t id = ids[t];
-    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    const uint4 v = dh[i];
-    float* dst = dtable + (id * HC + c) * 8;
-    atomicAdd(dst + 0, bflo(v.x)); atomicAdd(dst + 1, bfhi(v.x)); atomicAdd(dst + 2, bflo(v.y)); atomicAdd(dst + 3, bfhi(v.y));
-    atomicAdd(dst + 4, bflo(v.z)); atomicAdd(dst + 5, bfhi(v.z)); atomicAdd(dst + 6, bflo(v.w)); atomicAdd(dst + 7, bfhi(v.w));
+// ---------------------------------------------------------------- embedding backward, deterministic (no atomics)
+// The token rows are visited in the order of a STABLE sort of their ids (`order`; `sorted_ids[i] = ids[order[i]]`): workgroup i owns the run
+// of equal ids that STARTS at sorted position i (every other workgroup exits), sums the run's rows of dh in that fixed order in fp32 and
+// folds the sum into the bf16 gradient row:  grad[id] = bf16(grad[id] + sum_{t in run} dh[t]).  Only touched rows are read or written
+// (the round-2 kernel scattered with fp32 atomics into a dense fp32 [V,H] table -- 524 MB at the 7B shape -- that was then folded and
+// cleared in full for every GradCache chunk, and whose sums depended on the arrival order of the atomics).
+__global__ void __launch_bounds__(256) embed_scatter_sorted_k(const uint4* __restrict__ dh, const int64_t* __restrict__ sorted_ids,
+                                                              const int64_t* __restrict__ order, uint4* __restrict__ grad, int64_t T, int HC,
+                                                              int64_t V) {
+  const int64_t i = blockIdx.x;
+  const int64_t id = sorted_ids[i];
+  if (i > 0 && sorted_ids[i - 1] == id) return;
+  int64_t end = i + 1;
+  while (end < T && sorted_ids[end] == id) ++end;
+  const int64_t row = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  for (int c = threadIdx.x; c < HC; c += 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t j = i; j < end; ++j) {
+      const uint4 v = dh[order[j] * HC + c];
+      acc[0] += bflo(v.x); acc[1] += bfhi(v.x); acc[2] += bflo(v.y); acc[3] += bfhi(v.y);
+      acc[4] += bflo(v.z); acc[5] += bfhi(v.z); acc[6] += bflo(v.w); acc[7] += bfhi(v.w);
+    }
+    uint4 g = grad[row * HC + c];
+    g.x = pack2bf(bflo(g.x) + acc[0], bfhi(g.x) + acc[1]); g.y = pack2bf(bflo(g.y) + acc[2], bfhi(g.y) + acc[3]);
+    g.z = pack2bf(bflo(g.z) + acc[4], bfhi(g.z) + acc[5]); g.w = pack2bf(bflo(g.w) + acc[6], bfhi(g.w) + acc[7]);
+    grad[row * HC + c] = g;
   }
 }
 
@@ -275,13 +289,14 @@ int grit_swiglu_bwd(const void* gu, const void* dact, void* dgu, int64_t T, int 
   return GRIT_OK;
 }
 
-int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream) {
-  GRIT_REQUIRE(dh && ids && dtable, GRIT_E_BADARG, "grit_embed_scatter_add: null pointer");
-  GRIT_REQUIRE(T > 0 && H > 0 && V > 0 && H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_embed_scatter_add: bad sizes");
-  GRIT_REQUIRE(aligned16(dh), GRIT_E_BADARG, "grit_embed_scatter_add: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(embed_scatter_add_k, dim3(grid_for(T * (H / 8))), dim3(256), 0, (hipStream_t)stream, (const uint4*)dh, ids, dtable, T,
-                     H / 8, V);
-  GRIT_CHECK_LAUNCH("grit_embed_scatter_add");
+int grit_embed_scatter_add_sorted(const void* dh, const int64_t* sorted_ids, const int64_t* order, void* grad, int64_t T, int H, int64_t V,
+                                 void* stream) {
+  GRIT_REQUIRE(dh && sorted_ids && order && grad, GRIT_E_BADARG, "grit_embed_scatter_add_sorted: null pointer");
+  GRIT_REQUIRE(T > 0 && T < (1ll << 31) && H > 0 && V > 0 && H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_embed_scatter_add_sorted: bad sizes");
+  GRIT_REQUIRE(aligned16(dh) && aligned16(grad), GRIT_E_BADARG, "grit_embed_scatter_add_sorted: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(embed_scatter_sorted_k, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const uint4*)dh, sorted_ids, order,
+                     (uint4*)grad, T, H / 8, V);
+  GRIT_CHECK_LAUNCH("grit_embed_scatter_add_sorted");
   return GRIT_OK;
 }
 

@@ -583,12 +583,15 @@ def ce_bwd_(logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, scale
     return logits
 
 
-def embed_scatter_add(dh: torch.Tensor, ids: torch.Tensor, dtable: torch.Tensor):
-    V, H = dtable.shape
+def embed_scatter_add(dh: torch.Tensor, ids: torch.Tensor, grad: torch.Tensor):
+    """Embedding weight gradient: grad[ids[t]] += dh[t] (bf16 table, fp32 sums in token order; deterministic, no atomics).  The stable
+    sort of the ids is index plumbing and stays in torch."""
+    V, H = grad.shape
     T = ids.numel()
-    check(_lib.load().grit_embed_scatter_add(_chk(dh, BF16, "dh"), _chk(ids, I64, "ids"), _chk(dtable, F32, "dtable"), T, H, V, _stream()),
-          "grit_embed_scatter_add")
-    return dtable
+    sorted_ids, order = torch.sort(ids.reshape(-1).clamp(0, V - 1), stable=True)
+    check(_lib.load().grit_embed_scatter_add_sorted(_chk(dh, BF16, "dh"), _chk(sorted_ids, I64, "sorted_ids"), _chk(order, I64, "order"),
+                                                    _chk(grad, BF16, "grad"), T, H, V, _stream()), "grit_embed_scatter_add_sorted")
+    return grad
 
 
 def accum_bf16_from_f32(acc: torch.Tensor, x: torch.Tensor):
@@ -607,7 +610,7 @@ def _on_tensor_device(fn):
 
     @functools.wraps(fn)
     def guarded(*args, **kwargs):
-        for a in args:
+        for a in (*args, *kwargs.values()):          # first tensor, positional or keyword
             if torch.is_tensor(a):
                 if a.is_cuda and a.device.index != torch.cuda.current_device():
                     with torch.cuda.device(a.device):
@@ -617,8 +620,12 @@ def _on_tensor_device(fn):
     return guarded
 
 
+# Every public function of this module that launches kernels is wrapped; host-only helpers are listed, so a new op is guarded by default
+# and tests/test_abi.py::test_every_public_op_is_device_guarded fails if a launcher slips through.
+_HOST_ONLY = ("set_timer", "check", "attn_decode_workspace")
 for _name, _fn in list(globals().items()):
     if callable(_fn) and getattr(_fn, "__module__", None) == __name__ and not _name.startswith("_") and not isinstance(_fn, type) \
-            and _name not in ("set_timer", "check", "attn_decode_workspace"):
+            and _name not in _HOST_ONLY:
         globals()[_name] = _on_tensor_device(_fn)
+        globals()[_name]._device_guarded = True
 del _name, _fn

@@ -99,6 +99,11 @@ class MistralTrainEngine:
         self.layers: list[_LayerParams] = []
         for layer in backbone.layers:
             L = _LayerParams()
+            if not hasattr(layer, "mlp"):       # e.g. the reference file's own Mixtral class: block_sparse_moe.experts[i].w1/w2/w3
+                raise RuntimeError(f"{type(self).__name__}: decoder layers of {type(backbone).__name__} have no `.mlp` (found: "
+                                   f"{[n for n, _ in layer.named_children()]}); the training engine binds the layout of the installed "
+                                   "transformers (Mistral: mlp.gate_proj/up_proj/down_proj; Mixtral >= 5: mlp.gate + fused "
+                                   "mlp.experts.gate_up_proj/down_proj).  Load the checkpoint with AutoModel of the installed transformers.")
             at, mlp = layer.self_attn, layer.mlp
             L.wqkv = self._pack([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight])
             L.wo = at.o_proj.weight
@@ -110,7 +115,6 @@ class MistralTrainEngine:
         self._g_embed = None
         self._g_norm = None
         self._f32_norm_grads = None
-        self._f32_embed_grad = None
 
     # ------------------------------------------------------------------ MLP hooks (dense SwiGLU here; MixtralTrainEngine overrides)
     def _bind_mlp(self, L, mlp):
@@ -455,11 +459,7 @@ class MistralTrainEngine:
             if on_layer_done is not None:
                 on_layer_done(self._layer_grads(L))
         # ---- embedding + fold the fp32 side accumulators into the bf16 .grad tensors
-        if self._f32_embed_grad is None:
-            self._f32_embed_grad = torch.zeros(tuple(self.embed.shape), dtype=F32, device=self.device)
-        ops.embed_scatter_add(dh, saved.ids, self._f32_embed_grad)
-        ops.accum_bf16_from_f32(self.embed.grad, self._f32_embed_grad)
-        self._f32_embed_grad.zero_()
+        ops.embed_scatter_add(dh, saved.ids, self.embed.grad)          # fixed summation order: the whole step is bit-reproducible
         for li, L in enumerate(self.layers):
             ops.accum_bf16_from_f32(L.ln1.grad, ng[2 * li])
             ops.accum_bf16_from_f32(L.ln2.grad, ng[2 * li + 1])
@@ -497,7 +497,10 @@ class MixtralTrainEngine(MistralTrainEngine):
     tower): forward_lm(router_aux_coef=...) records the router logits, _router_aux_loss evaluates it, _mlp_bwd feeds its gradient in."""
 
     def _bind_mlp(self, L, mlp):
-        ex = mlp.experts
+        ex = getattr(mlp, "experts", None)
+        if ex is None or not hasattr(ex, "gate_up_proj") or not hasattr(ex, "down_proj") or not hasattr(mlp, "gate"):
+            raise RuntimeError("MixtralTrainEngine: the sparse-MoE block must expose `gate.weight` and the fused `experts.gate_up_proj` / "
+                               "`experts.down_proj` parameters (transformers >= 5); a per-expert w1/w3/w2 module list is not bound")
         L.wgu, L.wdown, L.wgate = ex.gate_up_proj, ex.down_proj, mlp.gate.weight
         c = self.cfg
         E, H, I = c.num_local_experts, c.hidden_size, c.intermediate_size

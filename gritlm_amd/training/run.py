@@ -129,6 +129,8 @@ def main(argv=None):
                 torch.save(model.projection.state_dict(), os.path.join(ck, "projection.pt"))
             torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
             torch.save(sched.state_dict(), os.path.join(ck, "scheduler.pt"))
+            torch.save({"cpu": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else []},
+                       os.path.join(ck, "rng_state.pth"))
             with open(os.path.join(ck, "trainer_state.json"), "w") as f:
                 json.dump({"global_step": step_, "micro_batches_done": step_ * gas, "world_size": world}, f)
         if dist.is_initialized():
@@ -139,7 +141,12 @@ def main(argv=None):
         ck = args.resume_from_checkpoint
         if not isinstance(ck, str) or not os.path.isdir(ck):
             raise ValueError(f"--resume_from_checkpoint expects a checkpoint-<step> directory written by this entry point, got {ck!r}")
-        st = json.load(open(os.path.join(ck, "trainer_state.json")))
+        st_path = os.path.join(ck, "trainer_state.json")
+        st = json.load(open(st_path)) if os.path.exists(st_path) else {}
+        lacking = [k_ for k_ in ("global_step", "micro_batches_done", "world_size") if k_ not in st]
+        if lacking:       # e.g. a checkpoint written by the Hugging Face Trainer / the reference: its trainer_state.json has another schema
+            raise ValueError(f"{st_path} lacks {lacking}: --resume_from_checkpoint resumes checkpoints written by THIS entry point "
+                             "(weights of any Hugging Face checkpoint can be loaded with --model_name_or_path instead)")
         if st["world_size"] != world:
             raise ValueError(f"checkpoint was written with world_size {st['world_size']}, this run has {world} (data order differs)")
         from safetensors.torch import load_file
@@ -147,13 +154,27 @@ def main(argv=None):
         sd = load_file(wfile) if os.path.exists(wfile) else torch.load(os.path.join(ck, "pytorch_model.bin"), map_location="cpu")
         with torch.no_grad():                       # in place: the native engine's packed views stay bound to the parameters
             own = dict(model.model.named_parameters())
+            own.update(dict(model.model.named_buffers()))
+            unknown = [k_ for k_ in sd if k_ not in own]
+            if unknown:
+                logger.warning("checkpoint keys without a counterpart in the model (skipped): %s", unknown[:8])
+            missing = [k_ for k_ in dict(model.model.named_parameters()) if k_ not in sd]
+            if missing:
+                raise ValueError(f"checkpoint {ck} lacks parameters of this model: {missing[:8]}")
             for k_, v_ in sd.items():
-                own[k_].copy_(v_.to(own[k_].dtype))
+                if k_ in own:
+                    own[k_].copy_(v_.to(own[k_].dtype))
         if model.projection is not None:
             model.projection.load_state_dict(torch.load(os.path.join(ck, "projection.pt"), map_location=device))
         opt.load_state_dict(torch.load(os.path.join(ck, "optimizer.pt"), map_location=device))
         sched.load_state_dict(torch.load(os.path.join(ck, "scheduler.pt")))
         step, micro_done = int(st["global_step"]), int(st["micro_batches_done"])
+        rng_path = os.path.join(ck, "rng_state.pth")
+        if os.path.exists(rng_path):
+            rng = torch.load(rng_path, map_location="cpu")
+            torch.set_rng_state(rng["cpu"])
+            if rng["cuda"] and torch.cuda.is_available() and len(rng["cuda"]) == torch.cuda.device_count():
+                torch.cuda.set_rng_state_all(rng["cuda"])
         if model.train_engine is not None:
             model.train_engine.weights_updated()
         logger.info("resumed from %s at step %d", ck, step)
@@ -183,9 +204,9 @@ def main(argv=None):
                 gb = collate_gen([gen_rows[i % len(gen_rows)] for i in take])
                 gb = {k: v.to(device) for k, v in gb.items()}
                 if args.no_gen_gas or gc_chunk is None:
-                    loss_gen = model(generative=gb).loss_gen * scale
-                    loss_gen.backward()
-                    loss_gen = loss_gen.detach()
+                    loss_gen = model(generative=gb).loss_gen
+                    (loss_gen * scale).backward()                   # 1/gas goes into the gradient only: the LOGGED loss is un-scaled, like
+                    loss_gen = loss_gen.detach()                    # the embedding loss beside it
                 else:
                     chunks = split_inputs(gb, gc_chunk)
                     loss_gen = torch.zeros((), device=device)

@@ -305,8 +305,12 @@ int64_t grit_knn_workspace_bytes(int Q, int64_t N, int k);
 int grit_knn_topk(const float* queries, const float* embeddings, int Q, int64_t N, int H, int64_t emb_stride_n, int64_t emb_stride_h,
                   int k, void* workspace, float* out_scores, int64_t* out_index, void* stream);
 
-/* embedding backward: dtable[ids[t], :] += dh[t, :]  (dtable fp32 [V,H], fp32 atomics) */
-int grit_embed_scatter_add(const void* dh, const int64_t* ids, float* dtable, int64_t T, int H, int64_t V, void* stream);
+/* embedding backward (nn.Embedding's weight gradient, scripts/modeling_mistral_gritlm.py:918,994), deterministic: no atomics.
+ * order [T] int64 = a STABLE argsort of the token ids, sorted_ids[i] = ids[order[i]]; dh [T,H] bf16; grad [V,H] bf16 (in/out):
+ * grad[id, :] = bf16(grad[id, :] + sum of dh[t, :] over the tokens t with ids[t] == id, added in token order in fp32).
+ * Rows of ids that do not occur are neither read nor written. */
+int grit_embed_scatter_add_sorted(const void* dh, const int64_t* sorted_ids, const int64_t* order, void* grad, int64_t T, int H,
+                                  int64_t V, void* stream);
 
 /* acc (bf16, n values) += x (fp32): folds an fp32 gradient into a bf16 .grad buffer */
 int grit_accum_bf16_from_f32(void* acc, const float* x, int64_t n, void* stream);

@@ -217,8 +217,32 @@ def gen_train_7b_l1():
             res["probe/" + n] = g[:8].numpy().copy()            # first 8 rows
         else:
             res["probe/" + n] = g.numpy().copy()
+    # the reference's OWN bf16 run of the same step (model.to(bfloat16), CPU): the yardstick for a bf16 implementation
+    f32_probe = {k: v for k, v in res.items() if k.startswith("probe/")}
+    model.zero_grad(set_to_none=True)
+    model.to(torch.bfloat16)
+    out16 = m(query={"input_ids": torch.from_numpy(qi), "attention_mask": torch.from_numpy(qm)},
+              passage={"input_ids": torch.from_numpy(pi), "attention_mask": torch.from_numpy(pm)})
+    out16.loss.backward()
+    res["loss_bf16"] = np.float32(out16.loss.item())
+    res["q_reps_bf16"] = out16.q_reps.detach().float().numpy()
+    res["p_reps_bf16"] = out16.p_reps.detach().float().numpy()
+    worst = 0.0
+    for n, p in model.named_parameters():
+        g = p.grad.float()
+        res["gnorm_bf16/" + n] = np.float32(g.norm().item())
+        if n == "embed_tokens.weight":
+            pr = g[torch.from_numpy(res["probe_rows/" + n])].numpy()
+        elif g.dim() == 2:
+            pr = g[:8].numpy().copy()
+        else:
+            pr = g.numpy().copy()
+        res["probe_bf16/" + n] = pr
+        ref = f32_probe["probe/" + n]
+        worst = max(worst, float(np.linalg.norm(pr - ref) / (np.linalg.norm(ref) + 1e-20)))
+    res["ref_bf16_vs_f32_worst_probe_rel_l2"] = np.float32(worst)
     np.savez_compressed(os.path.join(HERE, "train_7b-l1.npz"), **res)
-    print(f"  train 7b-l1: loss {out.loss.item():.6f}")
+    print(f"  train 7b-l1: loss {out.loss.item():.6f}  (reference bf16 run: {out16.loss.item():.6f}, worst probe rel l2 {worst:.3e})")
 
 
 def gen_train_mixtral(cfg_name="moe-tiny", seed_w=0):
@@ -445,8 +469,26 @@ def gen_gradcache():
     res["loss_gradcache"] = np.float32(loss.item())
     for n in names:
         res["grad_gradcache/" + n] = sdp[n].grad.numpy().copy()
+    # the reference's OWN bf16 run of both schedules
+    model.zero_grad(set_to_none=True)
+    model.to(torch.bfloat16)
+    out16 = m(query=qd, passage=pd)
+    out16.loss.backward()
+    res["loss_direct_bf16"] = np.float32(out16.loss.item())
+    res["q_reps_bf16"] = out16.q_reps.detach().float().numpy()
+    res["p_reps_bf16"] = out16.p_reps.detach().float().numpy()
+    sdp = dict(model.named_parameters())
+    for n in names:
+        res["grad_direct_bf16/" + n] = sdp[n].grad.float().numpy().copy()
+    model.zero_grad(set_to_none=True)
+    gc16 = GradCache(models=[m, m], chunk_sizes=2, loss_fn=m.emb_loss_fn, get_rep_fn=lambda x: x["q_reps"])
+    gc16.model_call = (lambda self, mod, x: mod(x)).__get__(gc16)
+    loss16 = gc16(qd, pd, no_sync_except_last=False)
+    res["loss_gradcache_bf16"] = np.float32(loss16.item())
+    for n in names:
+        res["grad_gradcache_bf16/" + n] = sdp[n].grad.float().numpy().copy()
     np.savez_compressed(os.path.join(HERE, "gradcache_tiny.npz"), **res)
-    print(f"  gradcache: loss direct {out.loss.item():.6f} vs gc {loss.item():.6f}")
+    print(f"  gradcache: loss direct {out.loss.item():.6f} vs gc {loss.item():.6f}  (reference bf16: {out16.loss.item():.6f} / {loss16.item():.6f})")
 
 
 def gen_generative():
@@ -564,6 +606,8 @@ if __name__ == "__main__":
         gen_generative_mixtral(); sys.exit(0)
     if sys.argv[1:] == ["train-7b-l1"]:
         gen_train_7b_l1(); sys.exit(0)
+    if sys.argv[1:] == ["gradcache"]:
+        gen_gradcache(); sys.exit(0)
     if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
         gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
         sys.exit(0)

@@ -544,17 +544,31 @@ def check_pool_bwd_varlen(method="mean", normalize=True, lens=(40, 25, 33, 1), H
 
 
 def check_embed_scatter():
-    ids = np.array([[3, 5, 3, 7], [7, 7, 0, 3]], dtype=np.int64)
-    dh = rnd((8, 64), 43)
-    ref = np.zeros((9, 64), dtype=np.float64)
-    for t, i in enumerate(ids.reshape(-1)):
-        ref[i] += dh[t]
-    tab = torch.zeros((9, 64), dtype=torch.float32, device=DEV)
-    ops.embed_scatter_add(bf(dh), torch.from_numpy(ids).to(DEV).view(-1), tab)
-    acc = bf(rnd((9, 64), 44))
-    want = O.bf16_round(f32(acc) + f32(tab))
-    ops.accum_bf16_from_f32(acc, tab)
-    return _res("embed_scatter_add + accum_bf16", float(np.max(np.abs(f32(tab) - ref))) < 1e-5 and np.array_equal(f32(acc), want))
+    """Embedding weight gradient: bf16 table += fp32 sums of the token rows, summed in token order per id (deterministic): equal to
+    the sequential reference BIT FOR BIT, repeatable, untouched rows untouched; plus the fp32 -> bf16 fold used for the norm weights."""
+    rng = np.random.default_rng(45)
+    V, H, T = 50, 264, 700                                              # ~14 tokens per id: long runs, 33 column groups (not 256 | HC)
+    ids = rng.integers(0, V - 3, size=T).astype(np.int64)               # ids V-3 .. V-1 never occur
+    dh = rnd((T, H), 43)
+    base = rnd((V, H), 44)
+    want = base.copy()
+    sums = np.zeros((V, H), dtype=np.float32)
+    for t in range(T):                                                  # fp32 running sums in token order, like the kernel
+        sums[ids[t]] = sums[ids[t]] + dh[t]
+    touched = np.unique(ids)
+    want[touched] = O.bf16_round(base[touched] + sums[touched])
+    tid = torch.from_numpy(ids).to(DEV)
+    outs = []
+    for _ in range(3):
+        tab = bf(base)
+        ops.embed_scatter_add(bf(dh), tid, tab)
+        outs.append(f32(tab))
+    ok = all(np.array_equal(o, want) for o in outs)
+    acc = bf(rnd((9, 64), 44)); x = torch.from_numpy(rnd((9, 64), 46) * 3).to(DEV)
+    want2 = O.bf16_round(f32(acc) + f32(x))
+    ops.accum_bf16_from_f32(acc, x)
+    ok &= np.array_equal(f32(acc), want2)
+    return _res("embed_scatter_add (sorted, deterministic) + accum_bf16", ok, max_abs=float(np.max(np.abs(outs[0] - want))))
 
 
 def build_engine(cfg_name, seed=0):
@@ -870,6 +884,12 @@ def check_gritlm_native_mixtral():
     return _res("GritLM.encode native on a Mixtral directory vs oracle", bool(ok), **out)
 
 
+# Training pins.  The fixtures carry the reference's fp32 run AND its own bf16 run (model.to(bfloat16), CPU).  A bf16
+# implementation is held to "no further from fp32 than 1.25x the reference's own bf16 run" per parameter (+ GRAD_FLOOR for parameters
+# whose reference error is ~0), and to LOSS_VS_BF16_REF of the bf16-reference loss.
+GRAD_FLOOR = 2e-3
+LOSS_VS_BF16_REF = 1e-3
+
 _NAMES = ["layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight", "norm.weight", "layers.0.input_layernorm.weight",
           "layers.1.self_attn.v_proj.weight", "embed_tokens.weight"]
 
@@ -897,20 +917,25 @@ def check_train_step(mode="direct"):
             ok &= out["q_reps_1-cos"] < 1e-4
         else:
             loss = GradCacheStep(m, chunk_size=2)(q, p)
-        ref_loss = float(g["loss_direct" if mode == "direct" else "loss_gradcache"])
-        out["loss"] = float(loss.item()); out["loss_ref"] = ref_loss
-        # bf16 encoder vs the reference's fp32 run: measured 15.18 vs 15.17 (7e-4 relative); the InfoNCE kernel itself holds 1e-3 ABSOLUTE on
-        # identical fp32 reps (check_infonce)
-        ok &= abs(out["loss"] - ref_loss) < 2e-3 * max(1.0, abs(ref_loss))
+        key = "direct" if mode == "direct" else "gradcache"
+        ref_loss, ref_loss16 = float(g[f"loss_{key}"]), float(g[f"loss_{key}_bf16"])
+        out["loss"] = float(loss.item()); out["loss_ref"] = ref_loss; out["loss_ref_bf16"] = ref_loss16
+        # the InfoNCE kernel itself holds 1e-3 ABSOLUTE on identical fp32 reps (check_infonce); around a bf16 encoder the yardstick is the
+        # reference's own bf16 run of the step (15.1819 vs 15.1736 in fp32)
+        ok &= abs(out["loss"] - ref_loss) <= 1.25 * abs(ref_loss16 - ref_loss) + 1e-3
+        ok &= abs(out["loss"] - ref_loss16) < LOSS_VS_BF16_REF
         sd = dict(m._backbone().named_parameters())
-        worst = 0.0
+        worst = worst_ratio = 0.0
         for n in _NAMES:
-            ref = g[("grad_direct/" if mode == "direct" else "grad_gradcache/") + n]
+            ref, ref16 = g[f"grad_{key}/" + n], g[f"grad_{key}_bf16/" + n]
             got = f32(sd[n].grad)
             rel = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-20))
+            rel16 = float(np.linalg.norm(ref16 - ref) / (np.linalg.norm(ref) + 1e-20))
             out[n.replace("layers.", "L").replace(".weight", "")] = rel
             worst = max(worst, rel)
-        ok &= worst < 6e-2
+            worst_ratio = max(worst_ratio, rel / (1.25 * rel16 + GRAD_FLOOR))
+        out["grad_err_over_bound"] = worst_ratio                 # bound per parameter: 1.25 x the reference's own bf16 error + floor
+        ok &= worst_ratio <= 1.0
         if mode == "gradcache":
             # transposed-weight cache follows in-place parameter updates without an explicit weights_updated()
             eng = m.train_engine
@@ -929,16 +954,17 @@ def check_train_step(mode="direct"):
 def check_train_step_7b_layer():
     """One contrastive step at the TRUE 7B layer shape (H 4096, 32/8 heads, I 14336, one layer; every dgrad/wgrad GEMM at the bench's
     N and K) vs the reference's direct forward + backward in fp32 (tests/golden/train_7b-l1.npz, from GritLMTrainModel.forward).
-    Three native schedules against the same reference: direct, GradCache (chunk 2), GradCache with layer recompute.  Loss within
-    2e-3 relative (stated tolerance 1e-3 absolute holds for the InfoNCE kernel on identical reps; the bf16 encoder adds the rest),
-    reps 1-cos < 1e-4, gradient probes and norms within 6e-2 relative l2 (bf16 weights/activations vs fp32)."""
+    Three native schedules against the same reference: direct, GradCache (chunk 2), GradCache with layer recompute.  The fixture also
+    holds the reference's OWN bf16 run of the step: loss no further from fp32 than 1.25x that run (+ 1e-3) and within LOSS_VS_BF16_REF of
+    the bf16-reference loss; reps 1-cos < 1e-4; every parameter's gradient probe and gradient norm no further from fp32 than 1.25x the
+    reference's bf16 run of that parameter (+ GRAD_FLOOR)."""
     import tempfile
     from gritlm_amd.training import GradCacheStep, GritLMTrainModel
     g = np.load(os.path.join(GOLDEN, "train_7b-l1.npz"))
     out, ok = {}, True
     q = {"input_ids": torch.from_numpy(g["q_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["q_mask"]).to(DEV)}
     p = {"input_ids": torch.from_numpy(g["p_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["p_mask"]).to(DEV)}
-    ref_loss = float(g["loss"])
+    ref_loss, ref_loss16 = float(g["loss"]), float(g["loss_bf16"])
     with tempfile.TemporaryDirectory() as td:
         d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "7b-l1", 0, "bfloat16")
         for sched in ("direct", "gradcache", "gradcache+recompute"):
@@ -959,27 +985,40 @@ def check_train_step_7b_layer():
                 loss = GradCacheStep(m, chunk_size=2)(dict(q), dict(p))
             lv = float(loss.item())
             out[f"loss[{sched}]"] = lv
-            ok &= abs(lv - ref_loss) < 2e-3 * max(1.0, abs(ref_loss))
-            worst_probe, worst_norm = 0.0, 0.0
+            # yardstick = the reference's OWN bf16 run of this step (fixture keys *_bf16): no further from the fp32 loss than 1.25x that
+            # run (+ the north-star's 1e-3), and within LOSS_VS_BF16_REF of the bf16-reference loss itself
+            ok &= abs(lv - ref_loss) <= 1.25 * abs(ref_loss16 - ref_loss) + 1e-3
+            out[f"loss_minus_bf16ref[{sched}]"] = lv - ref_loss16
+            ok &= abs(lv - ref_loss16) < LOSS_VS_BF16_REF
+            worst_probe, worst_norm, worst_ratio, worst_nratio = 0.0, 0.0, 0.0, 0.0
             for n, t in m._backbone().named_parameters():
                 got = t.grad
-                ref_n = float(g["gnorm/" + n])
-                worst_norm = max(worst_norm, abs(float(got.float().norm().item()) - ref_n) / (ref_n + 1e-20))
-                ref = g["probe/" + n]
+                ref_n, ref_n16 = float(g["gnorm/" + n]), float(g["gnorm_bf16/" + n])
+                en = abs(float(got.float().norm().item()) - ref_n) / (ref_n + 1e-20)
+                worst_norm = max(worst_norm, en)
+                worst_nratio = max(worst_nratio, en / (1.25 * abs(ref_n16 - ref_n) / (ref_n + 1e-20) + GRAD_FLOOR))
+                ref, ref16 = g["probe/" + n], g["probe_bf16/" + n]
                 if n == "embed_tokens.weight":
                     gp = f32(got[torch.from_numpy(g["probe_rows/" + n]).to(DEV)])
                 elif got.dim() == 2:
                     gp = f32(got[:8])
                 else:
                     gp = f32(got)
-                worst_probe = max(worst_probe, float(np.linalg.norm(gp - ref) / (np.linalg.norm(ref) + 1e-20)))
+                e = float(np.linalg.norm(gp - ref) / (np.linalg.norm(ref) + 1e-20))
+                e16 = float(np.linalg.norm(ref16 - ref) / (np.linalg.norm(ref) + 1e-20))
+                worst_probe = max(worst_probe, e)
+                worst_ratio = max(worst_ratio, e / (1.25 * e16 + GRAD_FLOOR))
             out[f"grad_probe_rel[{sched}]"] = worst_probe
             out[f"grad_norm_rel[{sched}]"] = worst_norm
-            ok &= worst_probe < 6e-2 and worst_norm < 3e-2
+            out[f"probe_err_over_bound[{sched}]"] = worst_ratio          # bound per parameter: 1.25 x the reference's own bf16 error + floor
+            out[f"norm_err_over_bound[{sched}]"] = worst_nratio
+            ok &= worst_ratio <= 1.0 and worst_nratio <= 1.0
             del m
             torch.cuda.empty_cache()
     out["loss_ref"] = ref_loss
-    return _res("native train step [7b-l1: direct / gradcache / recompute] vs reference loss+grads", bool(ok), **out)
+    out["loss_ref_bf16"] = ref_loss16
+    out["ref_bf16_worst_probe_rel"] = float(g["ref_bf16_vs_f32_worst_probe_rel_l2"])
+    return _res("native train step [7b-l1: direct / gradcache / recompute] vs reference loss+grads (fp32 and its own bf16 run)", bool(ok), **out)
 
 
 def check_grouped_training_epilogues(E=4, H=256, I=512, counts=(300, 0, 129, 71)):
@@ -1224,6 +1263,11 @@ def check_train_packed_vs_padded(cfg_name="gqa"):
         worst = max(worst, rel)
     out["worst_grad_rel_l2"] = worst
     ok &= worst < 1e-2
+    # the embedding gradient has no token-count contraction (row sums in token order, no atomics since round 3): padded rows add exact
+    # zeros, so both layouts must give the SAME BITS -- and so must a repetition of the step
+    emb_same = bool(np.array_equal(res[True][3]["embed_tokens.weight"], res[False][3]["embed_tokens.weight"]))
+    out["embedding_grad_identical"] = emb_same
+    ok &= emb_same
     ok &= res[True][4]._tbuf and all(k[1] > 0 for k in res[True][4]._tbuf)
     return _res(f"packed training step == padded training step [{cfg_name}]", bool(ok), **out)
 

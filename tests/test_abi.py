@@ -98,3 +98,14 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "gritlm_oracle" not in src and "oracle." not in src, f"{f} references the oracle"
+
+
+def test_every_public_op_is_device_guarded():
+    """ops.* launch on the CURRENT device's stream: every public launcher must run under the device of its first tensor argument,
+    positional or keyword."""
+    import inspect
+    from gritlm_amd import ops
+    for name, fn in vars(ops).items():
+        if name.startswith("_") or not inspect.isfunction(fn) or getattr(fn, "__module__", None) != ops.__name__ or name in ops._HOST_ONLY:
+            continue
+        assert getattr(fn, "_device_guarded", False), f"ops.{name} is not wrapped by the device guard"
