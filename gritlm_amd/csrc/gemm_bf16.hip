@@ -22,7 +22,14 @@
 //     ends up with 4 CONSECUTIVE output columns of one row -> packed bf16 stores and a
 //     register-local SwiGLU (gate/up weight rows interleaved in blocks of 16);
 //   * XCD-aware block remap (block b runs on XCD b % 8): every XCD walks a contiguous range of tiles,
-//     4 m-tiles x 8 n-tiles in flight per XCD share A/W panels in that XCD's 4 MiB L2.
+//     4 m-tiles x 8 n-tiles in flight per XCD share A/W panels in that XCD's 4 MiB L2;
+//   * big dense launches are PERSISTENT (round 3): one workgroup per CU pulls tiles from its XCD's queue (one device counter per
+//     XCD: the next tile goes to whichever CU is ready first, exactly the order the hardware dispatcher would produce, so the tiles
+//     an XCD runs at one time stay neighbours and keep sharing panels -- the round-2 persistent form walked a STATIC tile list
+//     per CU, its CUs drifted apart and its L2-miss traffic doubled) and the K-tile stream runs THROUGH the tile boundaries: the
+//     last two K-tiles of a tile stage the first half-tiles of the next one, the epilogue's stores drain under the next tile's first
+//     K-tile.  Per tile this removes the workgroup launch, the cold 96 KiB prologue burst every CU issues at the same moment and
+//     the exposed store drain: ~10 us of a 101 us tile at K = 4096 (tools/gemm_sustained_ab.py, profiles/r03_gemm_*).
 #include <stdlib.h>
 
 #include <atomic>
@@ -36,6 +43,7 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 64 KiB
 constexpr int HALF_BYTES = 128 * BK * 2;         // 16 KiB: 128 LDS rows x 128 B
 constexpr int A_BYTES = BM * BK * 2;             // 32 KiB
+constexpr int PERSIST_LDS_BYTES = 2 * STAGE_BYTES + 64 + 4 * 512 * 8;   // ring + tile mailbox + per-thread source-offset table (144.06 KiB)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -85,11 +93,17 @@ __device__ __forceinline__ int wrow_of(int wc, int j) {
     GRIT_SEG_FENCE();                        \
   } while (0)
 
-template <int EPI>
+#ifdef GRIT_GEMM_STAMP
+// debug build only (tools/ubench/gemm_stamp.cpp): shader-clock stamps of two waves (one per wave group) of a few workgroups at the
+// seams of the persistent tile loop
+__device__ unsigned long long g_stamps[8 * 2 * 64 * 8];      // [workgroup slot][wave group][tile][point]
+#endif
+template <int EPI, bool PERSIST>
 __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W_all,
                                                       uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
-                                                      int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope) {
+                                                      int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope,
+                                                      unsigned int* tile_ctr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool ROPE = (EPI == GRIT_EPI_ROPE);
   constexpr bool STACKED = (EPI == GRIT_EPI_SWIGLU_STACKED || EPI == GRIT_EPI_SWIGLU_STACKED_SAVE);
@@ -101,12 +115,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   //      tile keeps them in step (equal tile times, in-order dispatch); a persistent one-workgroup-per-CU variant with the K-tile stream
   //      running through the tile boundaries was built in round 2 -- bit-identical, +3 % in isolation, equal in the model (the chip is
   //      power-limited) at TWICE the L2-miss traffic because its CUs drift apart -- and removed (profiles/r02_gemm_persistent_*.log).
-  const int n_virtual = (int)gridDim.x;
+  //      PERSIST: v = 8 * (index in the XCD's queue) + XCD, the same numbering one workgroup per tile would have.
+  const int n_virtual = PERSIST ? tiles_m * tiles_n : (int)gridDim.x;
   const int group_sz = GM * tiles_n;
   auto tile_of = [&](int v, int64_t& m0, int64_t& M, const uint16_t*& W, int& n0) -> bool {
     const int xcd = v & 7, q8 = n_virtual >> 3, r8 = n_virtual & 7;
     int grp, in_grp;
-    if (remap == 2) {
+    if (!PERSIST && remap == 2) {
       // grouped (MoE) launches: tile groups are dealt round-robin to the XCDs (XCD x runs groups x, x+8, ...), so the eight XCDs work
       // on neighbouring row blocks -- i.e. on the SAME expert -- at any time and that expert's weights stay in the Infinity Cache;
       // contiguous per-XCD ranges would keep all experts' weights (1.9 GB at the 8x7B shape) live at once
@@ -114,7 +129,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       grp = (li / group_sz) * 8 + xcd;
       in_grp = li - (li / group_sz) * group_sz;
     } else {
-      const int wg = remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3) : v;
+      const int wg = (PERSIST || remap) ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3) : v;
       grp = wg / group_sz;
       in_grp = wg - grp * group_sz;
     }
@@ -124,7 +139,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     if (in_grp >= gm * tiles_n) return false;
     const int tm = first_m + in_grp % gm, tn = in_grp / gm;
     m0 = (int64_t)tm * BM; M = M_all; W = W_all;
-    if (groups.counts != nullptr) {
+    if (!PERSIST && groups.counts != nullptr) {
       int t = tm, g = 0;
       int64_t off = 0;
       for (; g < groups.n_groups; ++g) {
@@ -140,55 +155,129 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     n0 = tn * BN;
     return true;
   };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  // PERSIST: the XCD's tile queue.  Thread 0 draws queue positions with one returning atomic each and publishes them through two
+  // mailbox words BEHIND the staging ring (the same dynamic LDS array: a second __shared__ object would make hipcc drain the LDS-DMA
+  // queue in front of every fragment read); a position is drawn a whole tile before it is needed (in the previous tile's epilogue,
+  // where the DMA queue is drained anyway), so neither the atomic's latency nor the compiler's wait for its result touches the K loop.
+  volatile int* mailbox = reinterpret_cast<volatile int*>(smem + 2 * STAGE_BYTES);
+  const int my_xcd = (int)(blockIdx.x & 7);
+  auto draw = [&](int slot) {                      // thread 0 only
+    const unsigned pos = __hip_atomic_fetch_add(tile_ctr + my_xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mailbox[slot] = (int)(pos > 0x0fffffffu ? 0x0fffffffu : pos);
+  };
+  auto vtile_of_pos = [&](int pos) { return pos >= ((n_virtual >> 3) + (my_xcd < (n_virtual & 7) ? 1 : 0)) ? -1 : pos * 8 + my_xcd; };
+
   int64_t m0, M;
   const uint16_t* W;
   int n0;
   int vtile = blockIdx.x;
+  int tile_no = 0;                                 // PERSIST: tiles done by this workgroup (mailbox slot parity)
+  if constexpr (PERSIST) {
+    if (tid == 0) { draw(0); draw(1); }
+    __syncthreads();
+    vtile = vtile_of_pos(__builtin_amdgcn_readfirstlane(mailbox[0]));
+    if (vtile < 0) return;                         // more workgroups than tiles in this XCD's queue
+  }
   if (!tile_of(vtile, m0, M, W, n0)) return;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
 
   // ---- LDS-DMA sources.  Half-tile kinds: 0 = A_h0, 1 = A_h1, 2 = W_h0, 3 = W_h1; every half-tile is 128 LDS rows of 128 B and wave
   //      `wid` fills LDS rows wid*16 .. wid*16+15 of it with two 1-KiB instructions (8 rows each).
   //      A_h, LDS row p  <->  tile row (p>>6)*128 + h*64 + (p&63)             (64 rows of each M-half of the workgroup)
   //      W_h, LDS row p  <->  tile row wrow(p>>5, 2h + ((p>>4)&1)) + (p&15)   (fragments 2h, 2h+1 of each of the 4 wave columns)
+  // Non-persistent launches keep one 64-bit pointer per (half-tile kind, chunk) and lane in registers (16 VGPRs).  PERSIST cannot
+  // afford them: the kernel sits at 242 of 256 VGPRs, its epilogue runs INSIDE the tile loop, and every register hipcc spills there
+  // comes back as a scratch load in the middle of the LDS-DMA stream -- which it waits for with vmcnt(0), draining the DMA queue
+  // (the first build of this loop did that ten times per tile and gained nothing).  So PERSIST keeps a 32-bit BYTE OFFSET per (kind,
+  // chunk) and lane in LDS, behind the staging ring next to the mailbox (A rows against the first row of their tile, W rows against W:
+  // the host routes operands whose offsets would not fit 32 bits to the per-tile launch), and every load segment fetches the two
+  // offsets of the half-tile it stages with one 8-byte LDS read (lgkmcnt, not vmcnt).  Every thread reads only what it wrote itself:
+  // program order is all the synchronisation the table needs.
   const uint16_t* src[4][2];
+  const uint16_t* abase[2];                                    // PERSIST: first row of the tile the A_h0 / A_h1 offsets refer to
   auto set_src = [&](int h, int64_t tm0, int64_t tM, const uint16_t* tW, int tn0) {     // sources of A_h and W_h of the tile at (tm0, tn0)
-    const int ln = lane;
+    int ln = lane;
+    if (PERSIST) asm volatile("" : "+v"(ln));                  // recomputed per tile from the lane id: nothing of this is kept in
+                                                               // registers across the K loop (the compiler would hoist and spill)
     const int srow = ln >> 3;                                  // row inside the 8-row chunk
+    if constexpr (PERSIST) abase[h] = A + tm0 * lda;
+    const int row_lim = (int)((tM - 1 - tm0) < 255 ? (tM - 1 - tm0) : 255);              // last valid row of the tile, tile-relative
+    uint32_t oa[2], ow[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int p = wid * 16 + c * 8 + srow;
       const int slot = (ln & 7) ^ ((p >> 1) & 7);              // logical 16-B slot held by this physical slot
       const int ra = (p >> 6) * 128 + h * 64 + (p & 63);
-      int64_t gm_row = tm0 + ra; if (gm_row > tM - 1) gm_row = tM - 1;
-      if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
-      src[h][c] = A + gm_row * lda + slot * 8;
       const int rw = wrow_of<ROPE>(p >> 5, 2 * h + ((p >> 4) & 1)) + (p & 15);
       int gn_row = tn0 + rw; if (gn_row > N - 1) gn_row = N - 1;
       // stacked [gate; up] weights: interleaved row n = 32 q + r is gate row 16 q + r (r < 16) or up row 16 q + r - 16
       if (STACKED) gn_row = ((gn_row >> 5) << 4) + (gn_row & 15) + ((gn_row & 16) ? (N >> 1) : 0);
-      src[2 + h][c] = tW + (int64_t)gn_row * ldw + slot * 8;
+      if constexpr (PERSIST) {
+        const int rr = ra < row_lim ? ra : row_lim;
+        oa[c] = (uint32_t)rr * (uint32_t)(lda * 2) + (uint32_t)(slot * 16);
+        ow[c] = (uint32_t)gn_row * (uint32_t)(ldw * 2) + (uint32_t)(slot * 16);
+      } else {
+        int64_t gm_row = tm0 + ra; if (gm_row > tM - 1) gm_row = tM - 1;
+        if (groups.a_rows != nullptr) gm_row = groups.a_rows[gm_row];
+        src[h][c] = A + gm_row * lda + slot * 8;
+        src[2 + h][c] = tW + (int64_t)gn_row * ldw + slot * 8;
+      }
+    }
+    if constexpr (PERSIST) {        // (inline asm stores: invisible to hipcc's wait-count pass, which would order them behind the pending LDS-DMA)
+      const uint32_t ta = (uint32_t)(2 * STAGE_BYTES + 64 + (h * 512 + wid * 64 + ln) * 8);
+      const uint64_t va = (uint64_t)oa[0] | ((uint64_t)oa[1] << 32), vw = (uint64_t)ow[0] | ((uint64_t)ow[1] << 32);
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8192" : : "v"(ta), "v"(va), "v"(vw) : "memory");
     }
   };
   set_src(0, m0, M, W, n0);
   set_src(1, m0, M, W, n0);
   const int nk = K / BK;
+  // PERSIST: the two offsets a stage() call needs are fetched ONE PHASE AHEAD by an inline-asm ds_read_b64 (`prefetch_off`), so the
+  // LDS latency sits under the 16 MFMAs in between and hipcc's wait-count pass never sees the read (a C++ LDS load placed here gets an
+  // s_waitcnt vmcnt(0) in front of it -- the pass orders every LDS load it knows about behind all pending LDS-DMA -- and the DMA queue
+  // would drain once per phase).  The read is covered by the lgkmcnt(0) that opens the next MFMA segment; `cur_off` is made opaque right
+  // before its use so that nothing computed from it can be scheduled above that wait.
+  uint32_t soff_addr;                                                    // this thread's slot of kind 0 (kind k: + 4096 k)
+  uint64_t cur_off = 0;                                                  // {chunk 0, chunk 1} offsets of the next stage() call
+#define GRIT_PREFETCH_OFF(KIND)                                                                                                     \
+  do {                                                                                                                              \
+    if constexpr (PERSIST) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(cur_off) : "v"(soff_addr), "i"((KIND) * 4096) : "memory"); \
+  } while (0)
   auto stage = [&](int kind, int buf, int64_t kt_) {           // K-tile kt_ of the half-tile whose row / column pointers are in src[kind]
     const int64_t kofs = kt_ * BK;
     char* base = smem + buf * STAGE_BYTES + kind * HALF_BYTES + wid * 2048;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][0] + kofs), (lptr_t)base, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][1] + kofs), (lptr_t)(base + 1024), 16, 0, 0);
+    if constexpr (PERSIST) {
+      asm volatile("" : "+v"(cur_off));
+      const uint64_t ubu = reinterpret_cast<uint64_t>((kind < 2 ? abase[kind] : W_all) + kofs);    // wave-uniform: force scalar registers
+      const char* ub = reinterpret_cast<const char*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ubu >> 32)) << 32) |
+                                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ubu));
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (uint32_t)cur_off), (lptr_t)base, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ub + (uint32_t)(cur_off >> 32)), (lptr_t)(base + 1024), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][0] + kofs), (lptr_t)base, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[kind][1] + kofs), (lptr_t)(base + 1024), 16, 0, 0);
+    }
   };
-
   // ---- fragment read offsets (bytes inside a stage); the swizzle term is lane-constant because every fragment starts at a
   //      multiple of 16 LDS rows: (row>>1)&7 == (lane>>1)&7
-  const int frow = lane & 15, kq = lane >> 4, swz = (lane >> 1) & 7;
-  const int s_off[2] = {(kq ^ swz) << 4, ((4 + kq) ^ swz) << 4};
-  const int a_off = (wr * 64 + frow) * 128;                        // A frag i: + (i>>2)*HALF_BYTES + (i&3)*2048
-  const int w_off = 2 * HALF_BYTES + (wc * 32 + frow) * 128;       // W frag j: + (j>>1)*HALF_BYTES + (j&1)*2048
+  //      PERSIST: all of these lane constants are REBUILT from a laundered lane id at the top of every tile, so that none of them is
+  //      live across the epilogue (hipcc otherwise spills a handful of them in the prologue and reloads them inside the first K-tiles
+  //      of every tile -- scratch loads in the LDS-DMA stream)
+  int frow, kq, s_off[2], a_off, w_off;
+  auto lane_consts = [&]() {
+    int ln = lane;
+    if (PERSIST) asm volatile("" : "+v"(ln));
+    frow = ln & 15; kq = ln >> 4;
+    const int swz = (ln >> 1) & 7;
+    s_off[0] = (kq ^ swz) << 4; s_off[1] = ((4 + kq) ^ swz) << 4;
+    a_off = (wr * 64 + frow) * 128;                        // A frag i: + (i>>2)*HALF_BYTES + (i&3)*2048
+    w_off = 2 * HALF_BYTES + (wc * 32 + frow) * 128;       // W frag j: + (j>>1)*HALF_BYTES + (j&1)*2048
+    soff_addr = (uint32_t)(2 * STAGE_BYTES + 64 + (wid * 64 + ln) * 8);
+  };
+  lane_consts();
 
   f32x4_t acc[8][4];
   auto zero_acc = [&]() {
@@ -222,11 +311,16 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   } while (0)
   // load segment: the LDS reads are issued ahead of the two LDS-DMA instructions, then the counted wait:
   // vmcnt(8) = "all but the 4 newest half-tiles have landed"
-#define GRIT_LSEG_END(NREADS)                                                                         \
+  // WAIT: 1 = the counted wait; 2 = drain; 3 = the counted wait unless `skip_waits` (a wave-uniform run-time flag: ONE copy of the
+  // first K-tile's code serves the first tile of a workgroup and the tiles that follow an epilogue -- two copies made hipcc spill a
+  // fragment at their join, and a spill reload inside the K loop is a vmcnt(0))
+#define GRIT_LSEG_END(NREADS, WAIT)                                                                   \
   do {                                                                                                \
     __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);                                           \
     __builtin_amdgcn_sched_group_barrier(0x10, 2, 0);                                                 \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
+    if constexpr ((WAIT) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                       \
+    if constexpr ((WAIT) == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+    if constexpr ((WAIT) == 3) { if (!skip_waits) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }  \
   } while (0)
 
   // One K-tile = 4 phases, one output quadrant (16 MFMAs) each.  Half-tile stream (issue order):
@@ -236,44 +330,68 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // before the first barrier of the previous phase.  Phase 4 has no fragments of its own to read (W_h0 stays in registers), so it
   // reads the NEXT K-tile's W_h0 instead: LDS reads per phase 8 / 4 / 8 / 4.
   // k31 / k20: K-tile index of the half-tiles staged in phases 1,2 (W_h1, A_h1 of K-tile t+1) and 3,4 (W_h0, A_h0 of K-tile t+2).
-  auto ktile = [&](int64_t k31, int64_t k20, auto bufc) {
+  // PERSIST, `pos`: 0 = inside a tile; 1 = FIRST K-tile of a tile that follows another one in this workgroup: everything its four phases
+  // read landed before the previous tile's epilogue, and the epilogue's stores are still draining (they share the vmcnt counter with
+  // the LDS-DMA and are OLDER than anything issued since), so its phases do not wait at all -- the first counted wait, one K-tile
+  // later, needs exactly what it always needs (the half-tile staged 4 phases earlier) and finds the stores retired under ~1.6 us of
+  // matrix work; 2 = LAST K-tile of a tile: W_h0 of the next tile is read after the epilogue, and everything staged so far (the next
+  // tile's first K-tile and a half) must have landed before the stores go out.
+  bool skip_waits = false;
+  auto ktile = [&](int64_t k31, int64_t k20, auto bufc, auto posc) {
     constexpr int BUF = decltype(bufc)::value;
+    constexpr int POS = decltype(posc)::value;
+    constexpr int WAIT = POS == 1 ? 3 : 1;
     const char* sb = smem + BUF * STAGE_BYTES;
     const char* sbn = smem + (BUF ^ 1) * STAGE_BYTES;
     // phase 1: quadrant (A_h0, W_h0)
     GRIT_READ_X(0, sb);
     stage(3, BUF ^ 1, k31);
-    GRIT_LSEG_END(8);                 // W_h1(t) landed (read in phase 2)
+    GRIT_PREFETCH_OFF(1);
+    GRIT_LSEG_END(8, WAIT);           // W_h1(t) landed (read in phase 2)
     GRIT_BARRIER();
     GRIT_MMA(wf0[BUF], 0, 0);
     GRIT_BARRIER();
     // phase 2: quadrant (A_h0, W_h1)
     GRIT_READ_W(wf1, 1, sb);
     stage(1, BUF ^ 1, k31);
-    GRIT_LSEG_END(4);                 // A_h1(t) landed (read in phase 3)
+    GRIT_PREFETCH_OFF(2);
+    GRIT_LSEG_END(4, WAIT);           // A_h1(t) landed (read in phase 3)
     GRIT_BARRIER();
     GRIT_MMA(wf1, 0, 2);
     GRIT_BARRIER();
     // phase 3: quadrant (A_h1, W_h1)
     GRIT_READ_X(1, sb);
     stage(2, BUF, k20);
-    GRIT_LSEG_END(8);                 // W_h0(t+1) landed (read in phase 4)
+    GRIT_PREFETCH_OFF(0);
+    GRIT_LSEG_END(8, WAIT);           // W_h0(t+1) landed (read in phase 4)
     GRIT_BARRIER();
     GRIT_MMA(wf1, 4, 2);
     GRIT_BARRIER();
     // phase 4: quadrant (A_h1, W_h0); W_h0 of the next K-tile -> the other buffer's fragment registers
-    GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
+    if constexpr (POS != 2) GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
     stage(0, BUF, k20);
-    GRIT_LSEG_END(4);                 // A_h0(t+1) landed (read in phase 1 of the next K-tile)
+    GRIT_PREFETCH_OFF(3);
+    GRIT_LSEG_END(POS == 2 ? 0 : 4, POS == 2 ? 2 : WAIT);      // A_h0(t+1) landed (read in phase 1 of the next K-tile)
     GRIT_BARRIER();
     GRIT_MMA(wf0[BUF], 4, 0);
     GRIT_BARRIER();
   };
   const std::integral_constant<int, 0> B0{};
   const std::integral_constant<int, 1> B1{};
+  const std::integral_constant<int, 0> MID{};
+  const std::integral_constant<int, 1> FIRST{};
+  const std::integral_constant<int, 2> LAST{};
   auto kclamp = [&](int kt) { return (int64_t)(kt < nk ? kt : nk - 1); };        // past the end: re-stage the last K-tile (nobody reads it)
 
-  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(2, 1, kclamp(1)); stage(0, 1, kclamp(1));
+  // prologue (PERSIST: every offset pair is fetched and waited for in place; set_src's table writes are this thread's own)
+#define GRIT_OFF_NOW(KIND)                                                                \
+  do {                                                                                    \
+    GRIT_PREFETCH_OFF(KIND);                                                              \
+    if constexpr (PERSIST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+  } while (0)
+  GRIT_OFF_NOW(2); stage(2, 0, 0); GRIT_OFF_NOW(0); stage(0, 0, 0); GRIT_OFF_NOW(3); stage(3, 0, 0); GRIT_OFF_NOW(1); stage(1, 0, 0);
+  GRIT_OFF_NOW(2); stage(2, 1, kclamp(1)); GRIT_OFF_NOW(0); stage(0, 1, kclamp(1));
+  GRIT_PREFETCH_OFF(3);                   // for phase 1 of the first K-tile (covered by the lgkmcnt(0) of the W_h0 fragment read below)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // W_h0(0), A_h0(0)
   GRIT_BARRIER();
   GRIT_READ_W(wf0[0], 0, smem);
@@ -282,12 +400,18 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
   auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
   auto epilogue = [&](int64_t m0, int64_t M, int n0) {
+  int ln_e = lane;
+  if (PERSIST) asm volatile("" : "+v"(ln_e));               // per-lane output coordinates are rebuilt per tile, not carried through the K loop
+  const int frow = ln_e & 15, kq = ln_e >> 4;
   const int64_t mrow = m0 + wr * 128 + frow;
   const int ncol = n0 + wc * 64 + kq * 4;
-  // all table / residual loads of the lane's 8 row blocks are issued up front (the K loop's registers are dead by now): the epilogue
-  // pays one memory latency instead of one per row block
-  constexpr int RB = 8, ib = 0;
-  {
+  // The 8 row blocks of the lane go out in batches of RB: all table / residual loads of a batch are issued up front, so the epilogue pays
+  // one memory latency per batch.  One workgroup per tile: one batch (the K loop's registers are dead).  PERSIST: the K loop's state
+  // stays live across the epilogue, smaller batches keep it out of scratch memory.
+  constexpr int RB = !PERSIST ? 8 : (ROPE ? 2 : 8);
+#pragma unroll
+  for (int ib = 0; ib < 8; ib += RB) {
+  if (PERSIST) __builtin_amdgcn_sched_barrier(0);
   if constexpr (ROPE) {
     if (n0 + (wc >> 1) * 128 < rope.rope_cols) {        // this wave's head is a q or k head (uniform per wave)
       const int m0_mod = (int)(m0 % rope.S);              // block-uniform: the only 64-bit division
@@ -418,15 +542,78 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   }
   };
 
-  for (int kt = 0; kt < nk; kt += 2) {
-    ktile(kclamp(kt + 1), kclamp(kt + 2), B0);
-    if (kt + 1 < nk) ktile(kclamp(kt + 2), kclamp(kt + 3), B1);
+  if constexpr (!PERSIST) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(kclamp(kt + 1), kclamp(kt + 2), B0, MID);
+      if (kt + 1 < nk) ktile(kclamp(kt + 2), kclamp(kt + 3), B1, MID);
+    }
+    if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
+    GRIT_SEG_FENCE();
+    epilogue(m0, M, n0);
+  } else {
+#ifdef GRIT_GEMM_STAMP
+#define GRIT_STAMP(ID)                                                                                                              \
+  do {                                                                                                                              \
+    if ((tid & 255) == 0 && (blockIdx.x % 37) == 0 && blockIdx.x / 37 < 8 && tile_no < 64)                                          \
+      g_stamps[(((blockIdx.x / 37) * 2 + (tid >> 8)) * 64 + tile_no) * 8 + (ID)] = __builtin_readcyclecounter();                    \
+  } while (0)
+#else
+#define GRIT_STAMP(ID) do { } while (0)
+#endif
+    // One workgroup per CU walks the tiles it draws from its XCD's queue with the K-tile stream running THROUGH the tile boundaries.
+    // (nk even and >= 4: the host guarantees it.)
+    for (;;) {
+      GRIT_STAMP(0);
+      ktile(1, 2, B0, FIRST);                              // (skip_waits: false for the workgroup's first tile)
+      GRIT_STAMP(1);
+      ktile(2, 3, B1, MID);
+      GRIT_STAMP(2);
+      for (int kt = 2; kt < nk - 2; kt += 2) {
+        ktile(kt + 1, kt + 2, B0, MID);
+        ktile(kt + 2, kt + 3, B1, MID);
+      }
+      GRIT_STAMP(3);
+      // next tile (drawn one tile ago); no next tile: re-stage this one (harmless, nobody reads it)
+      int64_t m0n = m0, Mn = M;
+      const uint16_t* Wn = W;
+      int n0n = n0;
+      // (inline asm: a C++ LDS load here would get hipcc's vmcnt(0) in front of it and drain the DMA queue once per tile)
+      int pos_next;
+      {
+        const uint32_t mb_addr = (uint32_t)(2 * STAGE_BYTES + 4 * ((tile_no + 1) & 1));
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos_next) : "v"(mb_addr) : "memory");
+      }
+      const int vnext = vtile_of_pos(__builtin_amdgcn_readfirstlane(pos_next));
+      const bool more = vnext >= 0 && tile_of(vnext, m0n, Mn, Wn, n0n);
+      set_src(0, m0n, Mn, Wn, n0n);                        // W_h0 / A_h0 of the current tile were last staged two K-tiles ago
+      ktile(nk - 1, 0, B0, MID);
+      GRIT_STAMP(4);
+      set_src(1, m0n, Mn, Wn, n0n);
+      GRIT_OFF_NOW(3);                                     // the pair fetched in the previous phase 4 predates set_src(1)
+      ktile(0, 1, B1, LAST);
+      GRIT_STAMP(5);
+      // The two wave groups run one barrier apart inside a tile; at the seam they are brought IN STEP (the leading group waits half a
+      // phase for the other one's last MFMAs) so that both run their epilogues at the same time -- left staggered, each group sat at
+      // its next barrier for the whole length of the other group's epilogue (stamped: 2 x 4.3 k cycles per tile with the plain-store
+      // epilogue, 2 x 13 k with the residual one) -- and the stagger is re-established in front of the next tile.
+      if (wr == 0) GRIT_BARRIER();
+      if (tid == 0 && more) draw(tile_no & 1);             // queue position of the tile after the next one (this tile's slot is free)
+      epilogue(m0, M, n0);
+      GRIT_STAMP(6);
+      if (!more) break;
+      lane_consts();
+      zero_acc();
+      GRIT_READ_W(wf0[0], 0, smem);                        // W_h0(0) of the next tile: landed before the last K-tile's final wait
+      if (wr == 1) GRIT_BARRIER();                         // one barrier behind again
+      vtile = vnext; m0 = m0n; M = Mn; W = Wn; n0 = n0n; ++tile_no; skip_waits = true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GRIT_SEG_FENCE();
   }
-  if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
-  GRIT_SEG_FENCE();
-  epilogue(m0, M, n0);
 #undef GRIT_READ_W
+#undef GRIT_PREFETCH_OFF
+#undef GRIT_OFF_NOW
 #undef GRIT_READ_X
 #undef GRIT_MMA
 #undef GRIT_LSEG_END
@@ -434,9 +621,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 
 // Launch knobs for A/B runs (read once, thread-safe static initialisation): GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4:
 // 4 m x 8 n tiles in flight per XCD), GRIT_GEMM_NOREMAP=1 disables the XCD remap, GRIT_GEMM_RR=1 deals tile groups round-robin to the
-// XCDs for dense launches too (default: grouped launches only).
+// XCDs for dense launches too (default: grouped launches only), GRIT_GEMM_NOPERSIST=1 always launches one workgroup per tile.
 struct GemmKnobs {
-  int gm, remap, rr_all;
+  int gm, remap, rr_all, persist;
 };
 static const GemmKnobs& gemm_knobs() {
   static const GemmKnobs k = [] {
@@ -445,19 +632,56 @@ static const GemmKnobs& gemm_knobs() {
     v.gm = (e && atoi(e) > 0) ? atoi(e) : 4;
     v.remap = getenv("GRIT_GEMM_NOREMAP") ? 0 : 1;
     v.rr_all = getenv("GRIT_GEMM_RR") ? 1 : 0;
+    v.persist = getenv("GRIT_GEMM_NOPERSIST") ? 0 : 1;
     return v;
   }();
   return k;
 }
 
+static int device_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    if (v <= 0) v = 256;
+    cached[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+// Tile-queue counters of the persistent launches: a ring of CTR_SETS sets of 8 counters (one per XCD) in a module-scope device array
+// (the library never allocates).  A launch takes the next set of the ring, clears it with a 32-byte memset node on ITS stream and
+// hands it to the kernel: launches on one stream are ordered behind each other, launches on different streams use different sets
+// (the ring is 4096 launches long).
+constexpr int CTR_SETS = 4096;
+__device__ unsigned int g_tile_ctr[CTR_SETS * 8];
+static unsigned int* next_counter_set(hipStream_t st) {
+  static std::atomic<uint32_t> ring{0};
+  static std::atomic<unsigned int*> base[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  unsigned int* b = base[dev & 63].load(std::memory_order_acquire);
+  if (b == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_ctr)) != hipSuccess || p == nullptr) return nullptr;
+    b = (unsigned int*)p;
+    base[dev & 63].store(b, std::memory_order_release);
+  }
+  unsigned int* set = b + (size_t)(ring.fetch_add(1, std::memory_order_relaxed) % CTR_SETS) * 8;
+  if (hipMemsetAsync(set, 0, 8 * sizeof(unsigned int), st) != hipSuccess) return nullptr;
+  return set;
+}
+
 // the 128 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
 template <typename KernelT>
-static void ensure_lds_optin(KernelT kernel, std::atomic<uint64_t>& done) {
+static void ensure_lds_optin(KernelT kernel, std::atomic<uint64_t>& done, int bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done.fetch_or(bit, std::memory_order_release);
   }
 }
@@ -467,16 +691,35 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
                        int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0},
                        GemmRope rope = GemmRope{nullptr, nullptr, nullptr, 0, 0}) {
   const int tiles_m = grp.counts ? (int)(M / BM) + grp.n_groups : (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
-  static std::atomic<uint64_t> optin{0};
+  static std::atomic<uint64_t> optin{0}, optin_p{0};
   const GemmKnobs& kn = gemm_knobs();
   // grouped launches: round-robin tile groups over the XCDs (remap 2) on a grid rounded up to 8 x whole groups
   const int total_groups = (tiles_m + kn.gm - 1) / kn.gm;
   const bool rr = (grp.counts || kn.rr_all) && kn.remap;
   const unsigned nblocks = rr ? (unsigned)(8 * ((total_groups + 7) / 8) * kn.gm * tiles_n) : (unsigned)(tiles_m * tiles_n);
   const int remap_mode = rr ? 2 : kn.remap;
-  ensure_lds_optin(gemm_bf16_nt_k<EPI>, optin);
-  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
-                     (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope);
+  // persistent form: dense launches with an even number (4 .. 128) of K-tiles and at least two tiles per CU; everything else takes
+  // one workgroup per tile (at K = 14336 the seam is 3 % of a tile and the persistent loop's extra work per phase -- the offset fetch,
+  // 64-bit source address adds -- costs as much: measured 0.99x, profiles/r03_gemm_ab_persistent.log)
+  const int n_cu = device_cu_count();
+  const bool off32 = 256 * lda * 2 + 128 < (1ll << 32) && (int64_t)N * ldw * 2 + 128 < (1ll << 32);     // PERSIST's 32-bit source offsets
+  if (kn.persist && !rr && grp.counts == nullptr && (K / BK) % 2 == 0 && K / BK >= 4 && K / BK <= 128 && (int64_t)tiles_m * tiles_n >= 2 * (int64_t)n_cu &&
+      n_cu % 8 == 0 && off32) {
+    unsigned int* ctr = next_counter_set(st);
+    if (ctr != nullptr) {
+      ensure_lds_optin(gemm_bf16_nt_k<EPI, true>, optin_p, PERSIST_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, true>), dim3((unsigned)n_cu), dim3(512), PERSIST_LDS_BYTES, st, (const uint16_t*)A,
+                         (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm,
+                         remap_mode, grp, rope, ctr);
+      GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt (persistent)");
+      return GRIT_OK;
+    }
+    (void)hipGetLastError();          // no counter set (symbol lookup / memset refused, e.g. inside a stream capture): per-tile launch
+  }
+  ensure_lds_optin(gemm_bf16_nt_k<EPI, false>, optin, 2 * STAGE_BYTES);
+  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
+                     (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope,
+                     (unsigned int*)nullptr);
   GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt");
   return GRIT_OK;
 }
@@ -485,6 +728,11 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
 
 using namespace grit;
 
+#ifdef GRIT_GEMM_STAMP
+extern "C" int grit_debug_gemm_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(grit::g_stamps), sizeof(grit::g_stamps));
+}
+#endif
 extern "C" int grit_swiglu_block(void) { return 16; }
 
 extern "C" int grit_gemm_bf16_nt_grouped(const void* A, const int32_t* a_rows, const void* W, void* C, const int32_t* group_counts,
