@@ -70,7 +70,14 @@ _SIGNATURES = {
     "grit_attn_causal_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _i, _l, _l, _f, _p]),
     "grit_embed_scatter_add_sorted": (_i, [_p, _p, _p, _p, _l, _i, _l, _p]),
     "grit_accum_bf16_from_f32": (_i, [_p, _p, _l, _p]),
+    "grit_comm_unique_id": (_i, [_p]),
+    "grit_comm_init": (_i, [_p, _i, _i, C.POINTER(C.c_void_p)]),
+    "grit_comm_allgather_packed": (_i, [_p, _p, _l, _p, _l, _i, _p, _p, _p]),
+    "grit_comm_destroy": (_i, [_p]),
+    "grit_stream_create_cu_mask": (_i, [_i, C.POINTER(C.c_void_p)]),
+    "grit_stream_destroy": (_i, [_p]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -110,14 +110,25 @@ class ChunkGather:
         self.n_local, self.width, self.dtype, self.device = n_local, width, dtype, device
         self.items = []            # (slab [W, n, H], work handle, source kept alive until the collective completed)
         self.calls = 0
+        # GRIT_NATIVE_COMM=1: the same gathers on RCCL directly through the C ABI (grit_comm_allgather_packed, gritlm_amd/comm.py) on a
+        # side stream ordered with events, instead of torch.distributed
+        self.native = None
+        if torch.device(device).type == "cuda" and dtype == torch.float32:
+            from .. import comm as _comm
+            if _comm.enabled():
+                self.native = _comm.NativeComm.get(device)
 
     def add(self, reps: torch.Tensor):
         reps = reps.detach().contiguous()
         n = reps.shape[0]
+        self.calls += 1
+        if self.native is not None:
+            h = self.native.allgather_packed(reps, None)
+            self.items.append((h.q_all.view(self.world, n, self.width), h, reps))
+            return
         slab = torch.empty((self.world, n, self.width), dtype=self.dtype, device=self.device)
         work = dist.all_gather_into_tensor(slab.view(self.world * n, self.width), reps, async_op=True)
         self.items.append((slab, work, reps))
-        self.calls += 1
 
     def finish(self) -> torch.Tensor:
         for _, work, _ in self.items:

@@ -36,6 +36,10 @@ def packed_all_gather(q: Tensor, p: Tensor, world_size: int):
     """One collective for both towers: every rank contributes [Bq + Bp, H]; returns (q_all [W*Bq,H], p_all [W*Bp,H])
     in rank order (= the ``torch.cat`` order of the reference, :57-58, which the targets ``arange(B) * G`` rely on)."""
     bq, bp = q.shape[0], p.shape[0]
+    if q.is_cuda and q.dtype == torch.float32 and p.dtype == torch.float32:
+        from .. import comm as _comm
+        if _comm.enabled():       # RCCL through the C ABI: one grouped gather straight into the rank-major matrices, no packing copy
+            return _comm.NativeComm.get(q.device).allgather_packed(q, p).wait()
     packed = torch.cat([q, p], dim=0).contiguous()
     flat = torch.empty((world_size * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(flat, packed)           # concatenated layout: works on RCCL and gloo alike

@@ -31,7 +31,7 @@ enum {
   GRIT_E_BADARG = -1,      /* null pointer / non-positive size / misaligned pointer            */
   GRIT_E_UNSUPPORTED = -2, /* shape outside what the gfx950 kernels are built for              */
   GRIT_E_LAUNCH = -3,      /* hipLaunchKernel / runtime error                                   */
-  GRIT_E_RCCL = -4
+  GRIT_E_RCCL = -4         /* RCCL unavailable (librccl.so not loadable) or an ncclResult_t error (grit_comm_*) */
 };
 
 /* GEMM epilogues (grit_gemm_bf16_nt) */
@@ -208,6 +208,26 @@ int grit_pool_norm_varlen_bwd(const float* y, const float* dy, const float* inv_
 int grit_infonce_rows_fwd_bwd(const float* q, const float* p, float inv_temperature, float* scores, float* loss,
                               float* loss_rows, float* dq, float* dp, int Nq, int Np, int H, int q_off, int nq_loc,
                               int p_off, int np_loc, void* stream);
+
+/* ---- cross-rank exchange on RCCL: DistributedContrastiveLoss._dist_gather_tensor, gritlm/training/model.py:49-60 ------------------ */
+
+#define GRIT_COMM_ID_BYTES 128
+/* Rank 0 draws a unique id (ncclGetUniqueId) into id_out[GRIT_COMM_ID_BYTES] (HOST memory); the host program hands the bytes to every
+ * rank over its own channel (torch.distributed store / broadcast, MPI, a file). */
+int grit_comm_unique_id(void* id_out);
+/* ncclCommInitRank on the calling thread's current HIP device; collective over all `world` ranks.  *comm_out is an opaque handle. */
+int grit_comm_init(const void* id, int world, int rank, void** comm_out);
+/* ONE grouped all-gather of both towers (ncclGroupStart / 2 x ncclAllGather / ncclGroupEnd) on `stream`:
+ * q_local [nq_rows, H], p_local [np_rows, H] fp32 -> q_all [world * nq_rows, H], p_all [world * np_rows, H], rank-major (rank r's rows
+ * at [r * n, (r + 1) * n): the torch.cat order of :57-58 that the targets arange(B) * G rely on).  No staging copies; the caller owns
+ * every buffer and orders `stream` against its compute stream (events).  Either tower may be empty (n rows = 0).  The backward of the
+ * gather is not a collective (each rank differentiates its own rows only). */
+int grit_comm_allgather_packed(void* comm, const float* q_local, int64_t nq_rows, const float* p_local, int64_t np_rows, int H,
+                               float* q_all, float* p_all, void* stream);
+int grit_comm_destroy(void* comm);
+/* side stream restricted to the first n_cus compute units (hipExtStreamCreateWithCUMask) for the collective's kernels */
+int grit_stream_create_cu_mask(int n_cus, void** stream_out);
+int grit_stream_destroy(void* stream);
 
 /* ---- helpers -------------------------------------------------------------------------------- */
 

@@ -1403,6 +1403,71 @@ def check_rccl_world1_step():
                 worst_grad_rel=worst, gathers=ret["calls"]["gather"], allreduces=ret["calls"]["allreduce"])
 
 
+def _native_comm_worker(rank, port, model_dir, ret):
+    """ONE rank; the rep gathers go through the C ABI (grit_comm_*: ncclCommInitRank + grouped ncclAllGather on a side stream)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["GRIT_DIST_WORLD1"] = "1"
+    os.environ["GRIT_NATIVE_COMM"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from gritlm_amd import comm
+        from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+        from gritlm_amd.training.model import packed_all_gather
+        g = np.load(os.path.join(GOLDEN, "gradcache_tiny.npz"))
+        nc = comm.NativeComm.get("cuda:0")
+        calls = {"n": 0}
+        orig = nc.allgather_packed
+        def counted(q, p):
+            calls["n"] += 1
+            return orig(q, p)
+        nc.allgather_packed = counted
+        tg = torch.Generator(device="cuda").manual_seed(3)
+        a, b = torch.randn((5, 256), generator=tg, device="cuda"), torch.randn((40, 256), generator=tg, device="cuda")
+        qa, pa = packed_all_gather(a, b, 1)
+        ret["identity"] = bool(torch.equal(qa, a) and torch.equal(pa, b))
+        masked = comm.NativeComm("cuda:0", cu_mask=32)                      # a second communicator on a CU-masked side stream
+        h = masked.allgather_packed(a, None)
+        ret["masked_identity"] = bool(torch.equal(h.wait()[0], a) and h.p_all is None)
+        masked.close()
+        m = GritLMTrainModel(model_name_or_path=model_dir, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=0.02, negatives_cross_device=True, device="cuda", torch_dtype=torch.bfloat16)
+        m.enable_native()
+        q = {"input_ids": torch.from_numpy(g["q_ids"]).cuda(), "attention_mask": torch.from_numpy(g["q_mask"]).cuda()}
+        p = {"input_ids": torch.from_numpy(g["p_ids"]).cuda(), "attention_mask": torch.from_numpy(g["p_mask"]).cuda()}
+        loss = GradCacheStep(m, chunk_size=2)(q, p, sync=True)
+        torch.cuda.synchronize()
+        sd = dict(m._backbone().named_parameters())
+        ret["loss"] = float(loss.item()); ret["gathers"] = calls["n"]
+        ret["grads"] = {n: sd[n].grad.float().cpu().numpy() for n in ("layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight")}
+        nc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def check_native_comm():
+    """grit_comm_* (gritlm/training/model.py:49-60 on RCCL below torch.distributed) on a one-rank communicator: the packed
+    gather returns its inputs (also on a CU-masked side stream), and the cross-device GradCache step with every rep gather routed
+    through it reproduces the reference's step (tests/golden/gradcache_tiny.npz)."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    g = np.load(os.path.join(GOLDEN, "gradcache_tiny.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        mgr = mp.Manager(); ret = mgr.dict()
+        mp.spawn(_native_comm_worker, args=(port, d16, ret), nprocs=1, join=True)
+    ref_loss, ref_loss16 = float(g["loss_gradcache"]), float(g["loss_gradcache_bf16"])
+    worst = max(float(np.linalg.norm(ret["grads"][n] - g["grad_gradcache/" + n]) / np.linalg.norm(g["grad_gradcache/" + n])) for n in ret["grads"])
+    ok = ret["identity"] and ret["masked_identity"] and abs(ret["loss"] - ref_loss) <= 1.25 * abs(ref_loss16 - ref_loss) + LOSS_VS_F32_REF \
+        and worst < 3e-2 and ret["gathers"] >= 1 + 2 + 8
+    return _res("grit_comm_* on a 1-rank RCCL communicator (packed gather, CU-masked stream, GradCache step)", ok, loss=ret["loss"],
+                loss_ref=ref_loss, worst_grad_rel=worst, native_gathers=ret["gathers"])
+
+
 def check_wgrad_accumulation_drift(cfg_name="gqa"):
     """Weight gradients accumulate in bf16 across GradCache chunks (the wgrad GEMM's residual epilogue adds into the packed .grad
     storage, which is what `param.grad +=` does in the reference's bf16 run).  MEASURE the rounding this costs: the same 8 x 8 batch
@@ -2049,6 +2114,7 @@ ALL_CHECKS = [
     ("swiglu_train_epilogues_big", check_swiglu_fused_train_epilogues, dict(M=4100, I=14336, K=4096)),
     ("swiglu_stacked_7b", check_swiglu_stacked, dict(M=512, I=14336, K=4096)),
     ("rccl_world1_step", check_rccl_world1_step, {}),
+    ("native_comm_world1", check_native_comm, {}),
     ("ce", check_ce, {}),
     ("ce_vocab32000", check_ce, dict(T=40, V=32000)),
     ("generative_mixed", check_generative_step, dict(kind="mixed")),

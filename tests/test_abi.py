@@ -109,3 +109,18 @@ def test_every_public_op_is_device_guarded():
         if name.startswith("_") or not inspect.isfunction(fn) or getattr(fn, "__module__", None) != ops.__name__ or name in ops._HOST_ONLY:
             continue
         assert getattr(fn, "_device_guarded", False), f"ops.{name} is not wrapped by the device guard"
+
+
+def test_comm_entry_points_validate_without_a_gpu():
+    """grit_comm_* (cross-rank gather on RCCL): argument validation needs neither a GPU nor a communicator."""
+    lib = _lib.load()
+    B = _lib.GRIT_E_BADARG
+    h = ctypes.c_void_p()
+    assert lib.grit_comm_unique_id(None) == B
+    assert lib.grit_comm_init(None, 2, 0, ctypes.byref(h)) == B
+    buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+    assert lib.grit_comm_init(buf, 2, 2, ctypes.byref(h)) == B                       # rank outside the world
+    assert lib.grit_comm_allgather_packed(None, None, 1, None, 1, 8, None, None, None) == B
+    assert b"null communicator" in lib.grit_last_error_string()
+    assert lib.grit_comm_destroy(None) == 0 and lib.grit_stream_destroy(None) == 0
+    assert lib.grit_stream_create_cu_mask(0, ctypes.byref(h)) == B

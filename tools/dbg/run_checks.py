@@ -1,8 +1,13 @@
-import sys, os
-sys.path[:0] = ["/root/repo", "/root/repo/tests", "/root/repo/oracle"]
-os.chdir("/root/repo")
+#!/usr/bin/env python3
+"""Run a chosen subset of tests/gpu_checks.py and print one RESULT line per check: python tools/dbg/run_checks.py name [name ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+os.chdir(ROOT)
 import gpu_checks as G
-for name, fn, kw in G.ALL_CHECKS:
-    if name in ("train_direct", "train_gradcache", "train_7b_layer", "train_packed_vs_padded", "embed_scatter", "full_depth_parity_32_layers"):
-        r = fn(**kw)
-        print("RESULT", name, r["ok"], r["detail"], flush=True)
+want = set(sys.argv[1:])
+if __name__ == "__main__":
+    for name, fn, kw in G.ALL_CHECKS:
+        if name in want:
+            r = fn(**kw)
+            print("RESULT", name, r["ok"], r["detail"], flush=True)
