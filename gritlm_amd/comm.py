@@ -87,9 +87,9 @@ class NativeComm:
                                                       H, ptr(q_all), ptr(p_all), self.stream.cuda_stream), "grit_comm_allgather_packed")
         ev = torch.cuda.Event()
         ev.record(self.stream)
-        for t in (q, p, q_all, p_all):
-            if t is not None:
-                t.record_stream(self.stream)
+        # no record_stream(): the handle keeps the inputs alive until wait() has ordered the compute stream behind the collective, after
+        # which the allocator may reuse them in compute-stream order (and a CU-masked stream can then be destroyed without the caching
+        # allocator still holding it)
         return GatherHandle(q_all, p_all, ev, (q, p))
 
     def close(self):
@@ -100,4 +100,6 @@ class NativeComm:
         if getattr(self, "_raw_stream", None) is not None:
             self.lib.grit_stream_destroy(self._raw_stream)
             self._raw_stream = None
-        self._instances.pop((self.device.index, os.getpid()), None)
+        key = (self.device.index, os.getpid())
+        if self._instances.get(key) is self:
+            self._instances.pop(key)

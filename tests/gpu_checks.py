@@ -1437,10 +1437,17 @@ def _native_comm_worker(rank, port, model_dir, ret):
         m.enable_native()
         q = {"input_ids": torch.from_numpy(g["q_ids"]).cuda(), "attention_mask": torch.from_numpy(g["q_mask"]).cuda()}
         p = {"input_ids": torch.from_numpy(g["p_ids"]).cuda(), "attention_mask": torch.from_numpy(g["p_mask"]).cuda()}
+        from gritlm_amd.training import gradcache as gcm
+        seen = []
+        orig_init = gcm.ChunkGather.__init__
+        def spy(self, n_local, width, dtype, device):
+            orig_init(self, n_local, width, dtype, device)
+            seen.append((str(dtype), str(device), self.native is not None))
+        gcm.ChunkGather.__init__ = spy
         loss = GradCacheStep(m, chunk_size=2)(q, p, sync=True)
         torch.cuda.synchronize()
         sd = dict(m._backbone().named_parameters())
-        ret["loss"] = float(loss.item()); ret["gathers"] = calls["n"]
+        ret["loss"] = float(loss.item()); ret["gathers"] = calls["n"]; ret["chunk_gathers"] = list(seen)
         ret["grads"] = {n: sd[n].grad.float().cpu().numpy() for n in ("layers.0.self_attn.q_proj.weight", "layers.1.mlp.down_proj.weight")}
         nc.close()
     finally:
@@ -1465,7 +1472,8 @@ def check_native_comm():
     ok = ret["identity"] and ret["masked_identity"] and abs(ret["loss"] - ref_loss) <= 1.25 * abs(ref_loss16 - ref_loss) + LOSS_VS_F32_REF \
         and worst < 3e-2 and ret["gathers"] >= 1 + 2 + 8
     return _res("grit_comm_* on a 1-rank RCCL communicator (packed gather, CU-masked stream, GradCache step)", ok, loss=ret["loss"],
-                loss_ref=ref_loss, worst_grad_rel=worst, native_gathers=ret["gathers"])
+                loss_ref=ref_loss, worst_grad_rel=worst, native_gathers=ret["gathers"], identity=ret["identity"],
+                masked_identity=ret["masked_identity"], chunk_gathers=str(ret["chunk_gathers"]))
 
 
 def check_wgrad_accumulation_drift(cfg_name="gqa"):
