@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgritlm_hip.so")
+LIB_PATH = os.environ.get("GRIT_HIP_LIB") or os.path.join(_HERE, "libgritlm_hip.so")      # GRIT_HIP_LIB: A/B builds (tools/ubench)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gritlm_hip.h")
 
 ABI_VERSION = 2

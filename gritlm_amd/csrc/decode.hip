@@ -46,6 +46,21 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     for (int i = 0; i < GV_ROWS; ++i) rows[i] = r0 + i < N ? r0 + i : N - 1;
   }
   const int KC = K >> 3;
+  // The weights are streamed ONCE per token and shared with nobody: non-temporal loads (no L2 / Infinity Cache allocation that would only
+  // evict the activations and the KV cache; measured on this chip as the `nt-weights` row of the decode price list: issue -> landed
+  // -18 %; here 3.59 -> 3.47 ms per token, profiles/r03_decode_ab.log).  The first weight pieces of the lane go out BEFORE the RMSNorm statistics are reduced: the HBM latency of the stream's
+  // head overlaps the (L2-resident, serial) sum of squares instead of following it -- the 50 MB q|k|v GEMV is one workgroup wave deep.
+  auto wload = [&](int i, int c) -> uint4 {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W + (int64_t)rows[i] * ldw) + c);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  const int c0 = wave * 64 + lane;
+  uint4 wv[GV_ROWS];
+  if (c0 < KC) {
+#pragma unroll
+    for (int i = 0; i < GV_ROWS; ++i) wv[i] = wload(i, c0);
+  }
   float inv[NB];
   if (PRENORM) {
 #pragma unroll
@@ -65,10 +80,13 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
   for (int i = 0; i < GV_ROWS; ++i)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
-  for (int c = wave * 64 + lane; c < KC; c += 256) {
-    uint4 wv[GV_ROWS];
+  for (int c = c0; c < KC; c += 256) {
+    // (a one-step software pipeline of the weight loads -- next iteration's pieces requested before this iteration's arithmetic -- was
+    //  measured 8 % SLOWER at the 7B shape: 16 more registers per lane, fewer workgroups in flight; profiles/r03_decode_ab.log)
+    if (c != c0) {
 #pragma unroll
-    for (int i = 0; i < GV_ROWS; ++i) wv[i] = reinterpret_cast<const uint4*>(W + (int64_t)rows[i] * ldw)[c];
+      for (int i = 0; i < GV_ROWS; ++i) wv[i] = wload(i, c);
+    }
     uint4 lw = make_uint4(0, 0, 0, 0);
     if (PRENORM) lw = reinterpret_cast<const uint4*>(ln_w)[c];
 #pragma unroll
