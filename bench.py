@@ -136,6 +136,13 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
     dt = float(t.item())
     prof = {k: (v / steps if k.endswith("_ms") else v) for k, v in gc.profile_summary().items()}
     gc.profile = None
+    if dist is not None and prof.get("gather_bytes_received") is not None:
+        # the exchange step against xGMI (7 links x ~153 GB/s per GPU, /opt/skills/guides): bytes a rank receives per step and the time its
+        # compute stream was BLOCKED on them (the rest of the transfer ran under the document tower); a lower bound of the achieved rate
+        prof["xgmi_peak_gbps_per_gpu"] = 7 * 153
+        ex = prof.get("exposed_gather_ms", 0.0)
+        prof["exposed_gather_us"] = ex * 1e3
+        prof["gather_gbps_over_exposed_time"] = (prof["gather_bytes_received"] / (ex * 1e-3) / 1e9) if ex > 0 else None
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     pairs_per_s = world * pairs * steps / dt
 

@@ -35,13 +35,15 @@ for f in ("pmc_sq", "pmc_mfma", "pmc_fetch", "pmc_write"):
     for key, c in agg.items():
         out.setdefault(key, {}).update({k: sum(v) / len(v) for k, v in c.items()})
     durs.update({k: sum(v) / len(v) for k, v in dur.items() if v})
-shapes = {"0": "qkv M=131072 N=6144 K=4096 (STORE)", "3": "qkv M=131072 N=6144 K=4096 (STORE + RoPE epilogue)", "1": "o_proj N=4096 K=4096 and down N=4096 K=14336 averaged (RESIDUAL)",
-          "2": "gate|up N=28672 K=4096 (SWIGLU)"}
+shapes = {("0", "true"): "qkv M=131072 N=6144 K=4096 (STORE, persistent)", ("3", "true"): "qkv M=131072 N=6144 K=4096 (STORE + RoPE epilogue, persistent)",
+          ("1", "true"): "o_proj N=4096 K=4096 (RESIDUAL, persistent)", ("1", "false"): "down N=4096 K=14336 (RESIDUAL, one workgroup per tile)",
+          ("2", "true"): "gate|up N=28672 K=4096 (SWIGLU, persistent)"}
 weights = {}
 for k, v in out.items():
-    epi = k.split("<")[1].split(",")[0].strip(">")
-    v["shape"] = shapes.get(epi, "?")
-    weights[k] = 2 if epi == "1" else 1
+    targs = [t.strip() for t in k.split("<")[1].strip(">").split(",")]
+    epi, persist = targs[0], (targs[1] if len(targs) > 1 else "false")
+    v["shape"] = shapes.get((epi, persist), f"epilogue {epi}, persistent {persist}")
+    weights[k] = 1
     g = v["GRBM_GUI_ACTIVE"] / 8            # the counter is summed over the 8 XCDs
     v["avg_duration_s_under_pmc"] = durs[k]
     v["effective_clock_ghz"] = g / durs[k] / 1e9
