@@ -542,6 +542,125 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   }
   };
 
+  // ---- epilogue through LDS (round 3; used by STORE / RESIDUAL, written for RoPE and SwiGLU too).  In the MFMA layout consecutive lanes hold
+  //      consecutive ROWS (lane & 15 = row, lane >> 4 = which 16-byte piece), so one 16-byte store (or residual load) instruction
+  //      touches 16 rows x 64 B: every lane of a 16-lane pass hits a different cache line -- the epilogue was issue-bound in the texture
+  //      path (stamps: 5.6-8.5 k cycles per tile for the stores alone, 17-19 k with the residual loads).  Each wave now turns its row
+  //      block (16 rows x 128 B) through a private 4 KiB piece of the staging ring (dead at this point: the A_h1 / W_h1 slots of stage 1)
+  //      and goes to memory with lanes 8 r .. 8 r + 7 on the 8 pieces of ONE row: 8 full 128-byte lines per instruction (RoPE: two 64-byte
+  //      segments per row; SwiGLU: 4 lanes per 64-byte output row).  The arithmetic is untouched -- the residual is added after the
+  //      turn, to the same bf16-rounded value -- so the results are bit-identical to the direct epilogue (tools/ubench/gemm_ab.cpp).
+  auto epilogue_lds = [&](int64_t m0, int64_t M, int n0) {
+    int ln_e = lane;
+    if (PERSIST) asm volatile("" : "+v"(ln_e));
+    const int frow = ln_e & 15, kq = ln_e >> 4;
+    char* xp = smem + STAGE_BYTES + (wid < 4 ? HALF_BYTES : 3 * HALF_BYTES) + (wid & 3) * 4096;
+    const int64_t mbase = m0 + wr * 128;
+    const int tr = ln_e >> 3, tu = ln_e & 7;                                   // transposed side: row (+ 8) and 16-byte unit of the row
+    const int ncol_t = n0 + wrow(tu >> 1) + (tu & 1) * 8;
+    uint4 rpre[8][2];
+    if constexpr (EPI == GRIT_EPI_RESIDUAL) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int64_t m = mbase + i * 16 + hh * 8 + tr;
+          rpre[i][hh] = (m < M && ncol_t < N) ? *reinterpret_cast<const uint4*>(Rsd + m * ldr + ncol_t) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    bool rotate = false;
+    int m0_mod = 0;
+    if constexpr (ROPE) {
+      rotate = n0 + (wc >> 1) * 128 < rope.rope_cols;                           // this wave's head is a q or k head (uniform per wave)
+      m0_mod = (int)(m0 % rope.S);                                              // block-uniform: the only 64-bit division
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (PERSIST && (i & 1) == 0) __builtin_amdgcn_sched_barrier(0);           // bound the live range of the per-row-block temporaries
+      if constexpr (ROPE) {
+        if (rotate) {
+          const int64_t m = mbase + frow + i * 16;
+          const int64_t mc = m < M ? m : M - 1;
+          const int pos = rope.positions ? rope.positions[mc] : (m0_mod + (int)(mc - m0)) % rope.S;
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            const int c1 = (wc & 1) * 32 + p2 * 16 + kq * 4;                     // head-local column of fragment p2, lane's 4 columns
+            const float4 cs = *reinterpret_cast<const float4*>(rope.cos_tab + (int64_t)pos * 64 + c1);
+            const float4 sn = *reinterpret_cast<const float4*>(rope.sin_tab + (int64_t)pos * 64 + c1);
+            const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t xr = pack2bf_hw(acc[i][p2][r], acc[i][p2 + 2][r]);   // q/k = bf16(linear) first (:655-657)
+              const float x1 = bflo(xr), x2 = bfhi(xr);
+              acc[i][p2][r] = rope_lo(x1, x2, cc[r], ss[r]);
+              acc[i][p2 + 2][r] = rope_hi(x1, x2, cc[r], ss[r]);
+            }
+          }
+        }
+      }
+      char* xb = xp + (i & 1) * 2048;
+      if constexpr (SWIGLU) {
+        float o0[4], o1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t gu0 = pack2bf_hw(acc[i][0][r], acc[i][1][r]), gu1 = pack2bf_hw(acc[i][2][r], acc[i][3][r]);
+          const uint32_t ss = pack2bf_hw(silu_f(bflo(gu0)), silu_f(bflo(gu1)));
+          o0[r] = bflo(ss) * bfhi(gu0);
+          o1[r] = bfhi(ss) * bfhi(gu1);
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o0[r]), __float_as_uint(o1[r]), false, false);
+          o0[r] = __uint_as_float(sw[0]); o1[r] = __uint_as_float(sw[1]);
+        }
+        // 16 rows x 64 B (32 output columns of the wave): unit q of the row, swizzled by (row >> 1) & 3
+        const int q = (kq & 1) * 2 + (kq >> 1);
+        *reinterpret_cast<uint4*>(xb + frow * 64 + ((q ^ ((frow >> 1) & 3)) << 4)) =
+            make_uint4(pack2bf_hw(o0[0], o0[1]), pack2bf_hw(o0[2], o0[3]), pack2bf_hw(o1[0], o1[1]), pack2bf_hw(o1[2], o1[3]));
+      } else {
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          f32x4_t lo = acc[i][jp], hi4 = acc[i][jp + 1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo[r]), __float_as_uint(hi4[r]), false, false);
+            lo[r] = __uint_as_float(sw[0]); hi4[r] = __uint_as_float(sw[1]);
+          }
+          const int pidx = (jp + (kq & 1)) * 2 + (kq >> 1);                      // 16-byte unit of the row: fragment jp + (kq & 1), half kq >> 1
+          *reinterpret_cast<uint4*>(xb + frow * 128 + ((pidx ^ (frow & 7)) << 4)) =
+              make_uint4(pack2bf_hw(lo[0], lo[1]), pack2bf_hw(lo[2], lo[3]), pack2bf_hw(hi4[0], hi4[1]), pack2bf_hw(hi4[2], hi4[3]));
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): the wave's own pieces are in the buffer
+      asm volatile("" ::: "memory");
+      if constexpr (SWIGLU) {
+        const int row = ln_e >> 2, unit = ln_e & 3;
+        const uint4 piece = *reinterpret_cast<const uint4*>(xb + row * 64 + ((unit ^ ((row >> 1) & 3)) << 4));
+        const int64_t m = mbase + i * 16 + row;
+        const int oc = ((n0 + wc * 64) >> 1) + unit * 8;
+        if (m < M && 2 * oc < N) *reinterpret_cast<uint4*>(C + m * ldc + oc) = piece;
+      } else {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int row = hh * 8 + tr;
+          uint4 piece = *reinterpret_cast<const uint4*>(xb + row * 128 + ((tu ^ (row & 7)) << 4));
+          const int64_t m = mbase + i * 16 + row;
+          if constexpr (EPI == GRIT_EPI_RESIDUAL) {
+            // the reference rounds the Linear output to bf16 before the residual add (:769,:775): `piece` holds the rounded values
+            const uint4 rv = rpre[i][hh];
+            piece = make_uint4(pack2bf_hw(bflo(piece.x) + bflo(rv.x), bfhi(piece.x) + bfhi(rv.x)), pack2bf_hw(bflo(piece.y) + bflo(rv.y), bfhi(piece.y) + bfhi(rv.y)),
+                               pack2bf_hw(bflo(piece.z) + bflo(rv.z), bfhi(piece.z) + bfhi(rv.z)), pack2bf_hw(bflo(piece.w) + bflo(rv.w), bfhi(piece.w) + bfhi(rv.w)));
+          }
+          if (m < M && ncol_t < N) *reinterpret_cast<uint4*>(C + m * ldc + ncol_t) = piece;
+        }
+      }
+    }
+  };
+  // Measured against the direct epilogue on the same box (ratios to the round-2 kernel, M = 131072; profiles/r03_gemm_ab_lds_epilogue.log):
+  // RESIDUAL K = 4096 1.019 -> 1.049, K = 14336 1.003 -> 1.011, STORE 1.029 -> 1.039, RoPE 1.026 -> 1.025, SwiGLU 1.027 -> 1.017 (its output
+  // rows are 64 bytes: nothing to merge, one more LDS round trip).  So: the turn for the full-width epilogues, the direct form for the rest.
+  // What the stamps say is left of the residual epilogue (14.5 k cycles per tile): 128 KiB read + 128 KiB written per CU by all 256 CUs
+  // at the same moment = 64 MB at ~7 TB/s -- the seam of a lock-stepped launch is an HBM burst, not an issue problem.
+  constexpr bool LDS_EPI = (EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_RESIDUAL);
+
   if constexpr (!PERSIST) {
     for (int kt = 0; kt < nk; kt += 2) {
       ktile(kclamp(kt + 1), kclamp(kt + 2), B0, MID);
@@ -550,7 +669,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
     GRIT_SEG_FENCE();
-    epilogue(m0, M, n0);
+    if constexpr (LDS_EPI) {
+      GRIT_BARRIER();                   // ... everybody's, before the ring is reused as the epilogue's transposition space
+      epilogue_lds(m0, M, n0);
+    } else {
+      epilogue(m0, M, n0);
+    }
   } else {
 #ifdef GRIT_GEMM_STAMP
 #define GRIT_STAMP(ID)                                                                                                              \
@@ -599,7 +723,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       // epilogue, 2 x 13 k with the residual one) -- and the stagger is re-established in front of the next tile.
       if (wr == 0) GRIT_BARRIER();
       if (tid == 0 && more) draw(tile_no & 1);             // queue position of the tile after the next one (this tile's slot is free)
-      epilogue(m0, M, n0);
+      if constexpr (LDS_EPI) {
+        // (the groups are in step: every wave has passed the last barrier of the last K-tile, so every read of the A_h1 / W_h1 slots of
+        //  stage 1 -- the transposition space -- is done)
+        epilogue_lds(m0, M, n0);
+        GRIT_BARRIER();                                    // nobody stages the next tile's W_h1 / A_h1 into them before everybody is out
+      } else {
+        epilogue(m0, M, n0);
+      }
       GRIT_STAMP(6);
       if (!more) break;
       lane_consts();
