@@ -259,7 +259,21 @@ def dry_contrastive_leg(enc: "DryEncoder", world, rank, dist, pairs, group, chun
             "per_step_ms": {k: v for k, v in prof.items() if not k.startswith("_")}}
 
 
-def deadline_guard(budget_s: float, late_line):
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints a five-line version banner through C stdio when
+    its first communicator comes up, and it reaches the pipe at exit, i.e. AFTER the JSON line (the round-2 forced-distributed run shows
+    it: profiles/r02_bench_forced_one_rank_rccl.json) -- so the process's fd 1 is pointed at stderr for everybody else and the line is
+    written to the saved descriptor.  Returns emit(str)."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(text: str):
+        os.write(real, (text + "\n").encode())
+    return emit
+
+
+def deadline_guard(budget_s: float, late_line, emit=None):
     """Arms a daemon thread: unless the returned Event is set within ``budget_s`` seconds the thread prints ``late_line()`` (if it
     returns a string) and ends the PROCESS with exit code 0 (``os._exit``: the main thread may be parked inside a collective that will
     never complete).  tests/test_bench_guard.py exercises it in a subprocess."""
@@ -270,7 +284,7 @@ def deadline_guard(budget_s: float, late_line):
         if not done.wait(budget_s):
             out = late_line()
             if out is not None:
-                print(out, flush=True)
+                (emit or (lambda t: print(t, flush=True)))(out)
             os._exit(0)
     threading.Thread(target=_watch, daemon=True).start()
     return done
@@ -370,6 +384,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
             sys.exit(2)
         sys.exit(self_launch(args.gpus))
+    emit = claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -546,7 +561,7 @@ def main():
             line["contrastive"] = {"error": f"contrastive leg exceeded its deadline on {world} ranks; primary line emitted by the deadline guard"}
             line["collectives"] = {"backend": backend, "ranks": world, "encode_data_path_collectives": 0}
             return json.dumps(line)
-        guard = deadline_guard(float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "480")), _late_line)
+        guard = deadline_guard(float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "480")), _late_line, emit)
     contrastive = None
     if not args.no_contrastive:
         try:
@@ -584,7 +599,7 @@ def main():
                 line["parity_full_depth"], line["cpu_baseline_numpy_oracle"] = full_depth_parity(dev)
             except Exception as e:  # noqa: BLE001
                 line["parity_full_depth"] = {"error": repr(e)[:300]}
-        print(json.dumps(line), flush=True)
+        emit(json.dumps(line))
         emitted.append(True)
     if dist is not None:
         dist.destroy_process_group()          # still under the deadline guard: a rank that never arrives cannot wedge the job

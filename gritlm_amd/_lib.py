@@ -101,6 +101,10 @@ def load():
         raise GritHipError(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the native path.")
+    # PyTorch ships its own libamdhip64; the library must bind to THAT runtime instance when both live in one process (streams and device
+    # pointers cross the boundary).  Loaded first, it would resolve /opt/rocm's copy, torch would bring a second one, and the first launch
+    # would fail with "no ROCm-capable device is detected" (found with build() followed by smoke() in one process): torch goes first.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is absent -> loud

@@ -19,8 +19,8 @@ def _run(*flags):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-cpu", "--layers", "1", "--steps", "2", "--warmup", "1",
                         "--pairs", "4", "--chunk", "2", *flags], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # ONE line on stdout: library chatter (gloo, RCCL) goes to stderr
     return json.loads(lines[0]), r
 
 
