@@ -152,9 +152,12 @@ class _NativeEncodeFn(torch.autograd.Function):
     directly into the packed ``.grad`` storage (like fused wgrad accumulation) and returns no tensor gradients."""
 
     @staticmethod
-    def forward(ctx, anchor, model, input_ids, attention_mask, instr_len):
+    def forward(ctx, anchor, model, input_ids, attention_mask, instr_len, want_grad):
+        # `want_grad` is decided by the CALLER (torch.is_grad_enabled() there): inside a Function's forward grad mode is always off and
+        # ctx.needs_input_grad only mirrors anchor.requires_grad -- it is True under torch.no_grad() too.  Round 3 found GradCache's
+        # no-grad pass 1 saving every activation (and running the SAVE epilogue) because of that.
         eng = model.train_engine
-        grad = bool(ctx.needs_input_grad[0])      # grad mode + anchor.requires_grad at apply() time
+        grad = bool(want_grad)
         reps, state = eng.forward_pooled(input_ids, attention_mask, model.pooling_method, bool(model.normalized), instr_len, save=grad,
                                          packed=getattr(model, "native_packed", True))
         if grad:
@@ -166,7 +169,7 @@ class _NativeEncodeFn(torch.autograd.Function):
         model = ctx.model
         model.train_engine.backward_pooled(ctx.state, d_reps, on_layer_done=getattr(model, "_on_layer_done", None))
         ctx.state = None
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class _NativeGenFn(torch.autograd.Function):
@@ -174,9 +177,9 @@ class _NativeGenFn(torch.autograd.Function):
     entropy); backward accumulates backbone + lm_head gradients into ``.grad`` and returns no tensor gradients."""
 
     @staticmethod
-    def forward(ctx, anchor, model, input_ids, attention_mask, labels):
+    def forward(ctx, anchor, model, input_ids, attention_mask, labels, want_grad):
         eng = model.train_engine
-        grad = bool(ctx.needs_input_grad[0])
+        grad = bool(want_grad)                    # decided by the caller, see _NativeEncodeFn
         fn = model.gen_loss_fn
         if fn is not None:
             kind, factor, aux = fn.loss_gen_type, fn.loss_gen_factor, 0.0
@@ -194,7 +197,7 @@ class _NativeGenFn(torch.autograd.Function):
     def backward(ctx, d_loss):
         ctx.model.train_engine.backward_lm(ctx.state, d_loss, on_layer_done=getattr(ctx.model, "_on_layer_done", None))
         ctx.state = None
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class GritLMTrainModel(GritLM):
@@ -245,7 +248,8 @@ class GritLMTrainModel(GritLM):
                 il = torch.as_tensor(il, dtype=torch.int32, device=self.train_engine.device).contiguous()
                 if "mean" not in self.pooling_method:
                     raise NotImplementedError("instruction_lens with non-mean pooling is not on the native path")
-            return _NativeEncodeFn.apply(self.train_engine.embed, self, ids, mask, il)
+            anchor = self.train_engine.embed
+            return _NativeEncodeFn.apply(anchor, self, ids, mask, il, torch.is_grad_enabled() and anchor.requires_grad)
         # ---- Hugging Face path (CPU / other architectures): the reference's steps (:134-165)
         attention_mask = features["attention_mask"].clone() if "attention_mask" in features else None
         instruction_lens = features.get("instruction_lens")
@@ -282,7 +286,9 @@ class GritLMTrainModel(GritLM):
             native_gen = self.train_engine is not None and self.train_engine.lm_head is not None and self.attn[2:4] == "cc"
             if native_gen and (self.gen_loss_fn is not None or getattr(self.model.config, "model_type", "") == "mixtral"):
                 labels = generative.pop("labels")
-                loss_gen = _NativeGenFn.apply(self.train_engine.embed, self, generative["input_ids"], generative["attention_mask"], labels)
+                anchor = self.train_engine.embed
+                loss_gen = _NativeGenFn.apply(anchor, self, generative["input_ids"], generative["attention_mask"], labels,
+                                              torch.is_grad_enabled() and anchor.requires_grad)
             elif self.gen_loss_fn is not None:
                 loss_gen = self.gen_loss_fn(generative.pop("labels"), self.model(**generative, **self.gen_add_kwargs).logits)
             else:

@@ -918,7 +918,19 @@ def check_train_step(mode="direct"):
             out["q_reps_1-cos"] = float(np.max(1 - np.sum(qr * g["q_reps"], axis=1)))
             ok &= out["q_reps_1-cos"] < 1e-4
         else:
+            # GradCache's pass 1 is a no-grad forward: it must not keep activations (round 3 found it saving all of them: inside an
+            # autograd.Function grad mode is always off and ctx.needs_input_grad is True under no_grad too)
+            saves = []
+            orig_fp = m.train_engine.forward_pooled
+            def spy(*a, **k):
+                saves.append(bool(k.get("save", False)))
+                return orig_fp(*a, **k)
+            m.train_engine.forward_pooled = spy
             loss = GradCacheStep(m, chunk_size=2)(q, p)
+            m.train_engine.forward_pooled = orig_fp
+            n_chunks = (g["q_ids"].shape[0] + 1) // 2 + (g["p_ids"].shape[0] + 1) // 2
+            out["pass1_saves"] = sum(saves[:n_chunks]); out["pass2_saves"] = sum(saves[n_chunks:])
+            ok &= len(saves) == 2 * n_chunks and out["pass1_saves"] == 0 and out["pass2_saves"] == n_chunks
         key = "direct" if mode == "direct" else "gradcache"
         ref_loss, ref_loss16 = float(g[f"loss_{key}"]), float(g[f"loss_{key}_bf16"])
         out["loss"] = float(loss.item()); out["loss_ref"] = ref_loss; out["loss_ref_bf16"] = ref_loss16
