@@ -31,6 +31,7 @@ _SIGNATURES = {
     "grit_attn_causal_varlen_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_pool_norm_varlen_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
+    "grit_gemm_bf16_nt_pair": (_i, [_p, _p, _p, _p, _l, _i, _l, _l, _l, _l, _p, _p, _p, _p, _l, _i, _l, _l, _l, _l, _i, _i, _p]),
     "grit_swiglu_block": (_i, []),
     "grit_mask_pack": (_i, [_p, _p, _i, _i, _p]),
     "grit_attn_bidir_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),

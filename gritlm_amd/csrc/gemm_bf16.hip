@@ -73,6 +73,18 @@ struct GemmRope {
   int rope_cols;
 };
 
+// A SECOND problem riding in the same launch (grit_gemm_bf16_nt_pair: same K, same epilogue): tiles [0, first_tiles) of the XCD-remapped
+// order belong to the launch's own operands, the rest to these.  Two weight-gradient GEMMs whose tile counts are no multiples of the CU
+// count (q|k|v: 384 tiles = 1.5 waves of 256 CUs, down: 896 = 3.5) fill whole waves together (1280 = 5).
+struct GemmSecond {
+  const uint16_t* A;
+  const uint16_t* W;
+  uint16_t* C;
+  const uint16_t* R;
+  int64_t M, lda, ldw, ldc, ldr;
+  int N, tiles_m, tiles_n, first_tiles;
+};
+
 // first tile row of W fragment j of the waves in column wc (= first output column of the fragment inside the 256-wide tile)
 template <bool ROPE>
 __device__ __forceinline__ int wrow_of(int wc, int j) {
@@ -103,8 +115,23 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
                                                       uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                                                       int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope,
-                                                      unsigned int* tile_ctr) {
+                                                      unsigned int* tile_ctr, GemmSecond second) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // pair launch (non-persistent, dense): pick the problem of this workgroup from its position in the XCD-remapped order of the WHOLE
+  // grid, then continue with that problem's operands and a problem-local tile id (remap = 3: "already remapped")
+  int pair_wg = 0;
+  if constexpr (!PERSIST) {
+    if (second.first_tiles > 0) {
+      const int v = (int)blockIdx.x, nv = (int)gridDim.x, xcd = v & 7, q8 = nv >> 3, r8 = nv & 7;
+      pair_wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+      if (pair_wg >= second.first_tiles) {
+        pair_wg -= second.first_tiles;
+        A = second.A; W_all = second.W; C = second.C; Rsd = second.R; M_all = second.M; N = second.N;
+        lda = second.lda; ldw = second.ldw; ldc = second.ldc; ldr = second.ldr; tiles_m = second.tiles_m; tiles_n = second.tiles_n;
+      }
+      remap = 3;
+    }
+  }
   constexpr bool ROPE = (EPI == GRIT_EPI_ROPE);
   constexpr bool STACKED = (EPI == GRIT_EPI_SWIGLU_STACKED || EPI == GRIT_EPI_SWIGLU_STACKED_SAVE);
   constexpr bool SWIGLU = (EPI == GRIT_EPI_SWIGLU || STACKED);
@@ -129,7 +156,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       grp = (li / group_sz) * 8 + xcd;
       in_grp = li - (li / group_sz) * group_sz;
     } else {
-      const int wg = (PERSIST || remap) ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3) : v;
+      const int wg = (!PERSIST && remap == 3) ? pair_wg
+                     : ((PERSIST || remap) ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3) : v);
       grp = wg / group_sz;
       in_grp = wg - grp * group_sz;
     }
@@ -841,7 +869,7 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
       ensure_lds_optin(gemm_bf16_nt_k<EPI, true>, optin_p, PERSIST_LDS_BYTES);
       hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, true>), dim3((unsigned)n_cu), dim3(512), PERSIST_LDS_BYTES, st, (const uint16_t*)A,
                          (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm,
-                         remap_mode, grp, rope, ctr);
+                         remap_mode, grp, rope, ctr, GemmSecond{});
       GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt (persistent)");
       return GRIT_OK;
     }
@@ -850,8 +878,24 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
   ensure_lds_optin(gemm_bf16_nt_k<EPI, false>, optin, 2 * STAGE_BYTES);
   hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
                      (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope,
-                     (unsigned int*)nullptr);
+                     (unsigned int*)nullptr, GemmSecond{});
   GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt");
+  return GRIT_OK;
+}
+
+template <int EPI>
+static int launch_gemm_pair(const void* A1, const void* W1, void* C1, const void* R1, int64_t M1, int N1, int64_t lda1, int64_t ldw1,
+                            int64_t ldc1, int64_t ldr1, const void* A2, const void* W2, void* C2, const void* R2, int64_t M2, int N2,
+                            int64_t lda2, int64_t ldw2, int64_t ldc2, int64_t ldr2, int K, hipStream_t st) {
+  const int tm1 = (int)((M1 + BM - 1) / BM), tn1 = (N1 + BN - 1) / BN, tm2 = (int)((M2 + BM - 1) / BM), tn2 = (N2 + BN - 1) / BN;
+  static std::atomic<uint64_t> optin{0};
+  const GemmKnobs& kn = gemm_knobs();
+  const GemmSecond sec{(const uint16_t*)A2, (const uint16_t*)W2, (uint16_t*)C2, (const uint16_t*)R2, M2, lda2, ldw2, ldc2, ldr2, N2, tm2, tn2, tm1 * tn1};
+  ensure_lds_optin(gemm_bf16_nt_k<EPI, false>, optin, 2 * STAGE_BYTES);
+  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false>), dim3((unsigned)(tm1 * tn1 + tm2 * tn2)), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A1,
+                     (const uint16_t*)W1, (uint16_t*)C1, (const uint16_t*)R1, M1, N1, K, lda1, ldw1, ldc1, ldr1, tm1, tn1, kn.gm, 1,
+                     GemmGroups{nullptr, nullptr, 0, 0}, GemmRope{nullptr, nullptr, nullptr, 0, 0}, (unsigned int*)nullptr, sec);
+  GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt_pair");
   return GRIT_OK;
 }
 
@@ -952,6 +996,35 @@ extern "C" int grit_gemm_bf16_nt_rope(const void* A, const void* W, void* C, int
   GRIT_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_rope: too many tiles");
   const GemmRope rope{cos_tab, sin_tab, positions, S > 0 ? S : 1, rope_cols};
   return launch_gemm<GRIT_EPI_ROPE>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, (hipStream_t)stream, GemmGroups{nullptr, nullptr, 0, 0}, rope);
+}
+
+// Two dense GEMMs with the same K and epilogue (STORE or RESIDUAL) in ONE launch: the weight-gradient GEMMs of a layer whose tile counts
+// leave half a wave of CUs idle when launched alone.  Per problem the semantics (and the bits) are those of grit_gemm_bf16_nt.
+extern "C" int grit_gemm_bf16_nt_pair(const void* A1, const void* W1, void* C1, const void* R1, int64_t M1, int N1, int64_t lda1, int64_t ldw1,
+                                      int64_t ldc1, int64_t ldr1, const void* A2, const void* W2, void* C2, const void* R2, int64_t M2, int N2,
+                                      int64_t lda2, int64_t ldw2, int64_t ldc2, int64_t ldr2, int K, int epilogue, void* stream) {
+  GRIT_REQUIRE(A1 && W1 && C1 && A2 && W2 && C2, GRIT_E_BADARG, "grit_gemm_bf16_nt_pair: null pointer");
+  GRIT_REQUIRE(M1 > 0 && N1 > 0 && M2 > 0 && N2 > 0 && K > 0, GRIT_E_BADARG, "grit_gemm_bf16_nt_pair: bad sizes");
+  GRIT_REQUIRE(K % 64 == 0 && N1 % 16 == 0 && N2 % 16 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_pair: K must be a multiple of 64, N of 16");
+  GRIT_REQUIRE(lda1 % 8 == 0 && ldw1 % 8 == 0 && ldc1 % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0 && ldc2 % 8 == 0 && lda1 >= K && ldw1 >= K &&
+                   lda2 >= K && ldw2 >= K && ldc1 >= N1 && ldc2 >= N2,
+               GRIT_E_BADARG, "grit_gemm_bf16_nt_pair: bad leading dimensions");
+  GRIT_REQUIRE(aligned16(A1) && aligned16(W1) && aligned16(C1) && aligned16(A2) && aligned16(W2) && aligned16(C2), GRIT_E_BADARG,
+               "grit_gemm_bf16_nt_pair: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((int64_t)((M1 + BM - 1) / BM) * ((N1 + BN - 1) / BN) + (int64_t)((M2 + BM - 1) / BM) * ((N2 + BN - 1) / BN) < (1ll << 31),
+               GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt_pair: too many tiles");
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case GRIT_EPI_STORE:
+      return launch_gemm_pair<GRIT_EPI_STORE>(A1, W1, C1, nullptr, M1, N1, lda1, ldw1, ldc1, 0, A2, W2, C2, nullptr, M2, N2, lda2, ldw2, ldc2, 0, K, st);
+    case GRIT_EPI_RESIDUAL:
+      GRIT_REQUIRE(R1 && R2 && ldr1 % 8 == 0 && ldr2 % 8 == 0 && ldr1 >= N1 && ldr2 >= N2 && aligned16(R1) && aligned16(R2), GRIT_E_BADARG,
+                   "grit_gemm_bf16_nt_pair: RESIDUAL epilogue needs both residuals (ldr >= N)");
+      return launch_gemm_pair<GRIT_EPI_RESIDUAL>(A1, W1, C1, R1, M1, N1, lda1, ldw1, ldc1, ldr1, A2, W2, C2, R2, M2, N2, lda2, ldw2, ldc2, ldr2, K, st);
+    default:
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt_pair: epilogue %d not available (STORE, RESIDUAL)", epilogue);
+  }
+  return GRIT_OK;
 }
 
 extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,

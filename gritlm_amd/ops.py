@@ -201,6 +201,27 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     return out
 
 
+def gemm_nt_pair(a1: torch.Tensor, w1: torch.Tensor, out1: torch.Tensor, a2: torch.Tensor, w2: torch.Tensor, out2: torch.Tensor,
+                 accumulate: bool = True) -> None:
+    """Two dense GEMMs with the same K in ONE launch: out_i (+)= a_i[M_i,K] @ w_i[N_i,K]^T, bit-identical to two gemm_nt calls.  Used for
+    weight-gradient pairs whose tile counts do not fill whole waves of CUs on their own (``accumulate``: RESIDUAL epilogue onto out_i)."""
+    (M1, K), (M2, K2) = a1.shape, a2.shape
+    N1, N2 = w1.shape[0], w2.shape[0]
+    assert K == K2 == w1.shape[1] == w2.shape[1] and out1.shape == (M1, N1) and out2.shape == (M2, N2)
+    epi = EPI_RESIDUAL if accumulate else EPI_STORE
+    ev = _timer.span("gemm_bf16_nt", 2.0 * (M1 * N1 + M2 * N2) * K, tag=f"pair N={N1}+{N2},K={K},epi={epi}") if _timer is not None else None
+    if ev:
+        ev[0].record()
+    o1, o2 = _chk2d(out1, BF16, "out1"), _chk2d(out2, BF16, "out2")
+    check(_lib.load().grit_gemm_bf16_nt_pair(_chk2d(a1, BF16, "a1"), _chk2d(w1, BF16, "w1"), o1, o1 if accumulate else 0, M1, N1, a1.stride(0),
+                                             w1.stride(0), out1.stride(0), out1.stride(0) if accumulate else 0,
+                                             _chk2d(a2, BF16, "a2"), _chk2d(w2, BF16, "w2"), o2, o2 if accumulate else 0, M2, N2, a2.stride(0),
+                                             w2.stride(0), out2.stride(0), out2.stride(0) if accumulate else 0, K, epi, _stream()),
+          "grit_gemm_bf16_nt_pair")
+    if ev:
+        ev[1].record()
+
+
 def gemm_nt_rope(a: torch.Tensor, w: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, rope_cols: int, S: int = 0,
                  positions: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """Fused QKV projection + RoPE on the leading ``rope_cols`` columns (q, k heads; head_dim 128): gemm_nt followed by rope_qk_[pos_],

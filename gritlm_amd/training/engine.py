@@ -14,6 +14,8 @@ of the chunk (no recompute => 3x forward FLOPs per chunk instead of the referenc
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import ops
@@ -88,6 +90,8 @@ class MistralTrainEngine:
         self._tbuf = {}
         self._wT = {}
         self.cache_transposed_weights = False
+        self.pair_wgrads = os.environ.get("GRIT_NO_WGRAD_PAIR") != "1"     # down_proj + q|k|v_proj weight gradients in one launch
+        self._deferred_wgrad = None
         self.recompute = False          # gradient checkpointing (per-layer recompute in backward)
         self._router_log = None         # Mixtral: list collecting (logits fp32 [T,E], experts [T,2]) per layer while it is a list
         self._aux_dlogits = None        # Mixtral: d aux_loss / d router logits per layer during backward_lm
@@ -148,7 +152,10 @@ class MistralTrainEngine:
         """Accumulates the MLP's weight gradients; returns d loss / d x2 ([T,H], the input of the MLP = post-attention norm output)."""
         # d_act = dh @ Wdown with the SwiGLU backward in the epilogue: [T, 2I] = [d_gate | d_up] straight from the accumulators
         dgu = ops.gemm_nt(dh, self._wt(li, "down", L.wdown), epilogue=EPI_SWIGLU_BWD, residual=sv["gu"])
-        self._wgrad(dh, sv["act"], L.gdown, ("dh", "act"))
+        if self.pair_wgrads:      # transposed now (dh is consumed by the next norm backward), multiplied together with the q|k|v wgrad
+            self._deferred_wgrad = (self._transposed_act(dh, "dh_down"), self._transposed_act(sv["act"], "act"), L.gdown)
+        else:
+            self._wgrad(dh, sv["act"], L.gdown, ("dh", "act"))
         dx2 = ops.gemm_nt(dgu, self._wt(li, "gu", L.wgu))                           # [T,H]
         self._wgrad(dgu, sv["x2"], L.ggu, ("dgu", "x"))
         return dx2
@@ -454,7 +461,14 @@ class MistralTrainEngine:
                 dqkv = ops.attn_bidir_bwd(sv["qkv"], geom.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d, causal=geom.causal)
                 ops.rope_qk_(dqkv, cos, sin, S, nq, nkv, d, inverse=True)
             dx1 = ops.gemm_nt(dqkv, self._wt(li, "qkv", L.wqkv))                        # [T,H]
-            self._wgrad(dqkv, sv["x1"], L.gqkv, ("dqkv", "x"))
+            if self._deferred_wgrad is not None:
+                # down_proj's and q|k|v_proj's weight gradients in one launch: 896 + 384 tiles of 256 x 256 = 5 whole waves of 256 CUs
+                # (alone: 3.5 and 1.5 waves, i.e. one wave of K = T tiles per layer idle on half the chip); same bits as two launches
+                aT, xT, g = self._deferred_wgrad
+                self._deferred_wgrad = None
+                ops.gemm_nt_pair(aT, xT, g, self._transposed_act(dqkv, "dqkv"), self._transposed_act(sv["x1"], "x"), L.gqkv)
+            else:
+                self._wgrad(dqkv, sv["x1"], L.gqkv, ("dqkv", "x"))
             dh = ops.rmsnorm_bwd(dx1, sv["h_in"], L.ln1.data, eps, ng[2 * li], dres=dh_mid)
             if on_layer_done is not None:
                 on_layer_done(self._layer_grads(L))

@@ -195,6 +195,13 @@ int grit_pool_norm_varlen_bwd(const float* y, const float* dy, const float* inv_
                               const int32_t* instr_len, void* dhidden, int B, int H, int mode, int normalize,
                               void* stream);
 
+/* Two dense GEMMs with the same K and epilogue (STORE or RESIDUAL) in one launch -- autograd's weight-gradient GEMMs of nn.Linear
+ * (q/k/v_proj + down_proj of a layer: 384 + 896 tiles of 256 x 256 fill 5 whole waves of 256 CUs instead of 2 + 4 partial ones).
+ * Per problem exactly grit_gemm_bf16_nt (same bits). */
+int grit_gemm_bf16_nt_pair(const void* A1, const void* W1, void* C1, const void* residual1, int64_t M1, int N1, int64_t lda1, int64_t ldw1,
+                           int64_t ldc1, int64_t ldr1, const void* A2, const void* W2, void* C2, const void* residual2, int64_t M2, int N2,
+                           int64_t lda2, int64_t ldw2, int64_t ldc2, int64_t ldr2, int K, int epilogue, void* stream);
+
 /* ---- contrastive loss: gritlm/training/model.py:36-47,62-64 --------------------------------- */
 
 /* scores = q p^T / tau (fp32 MFMA, exact f32), target[i] = i * (Np / Nq), CrossEntropyLoss(mean).

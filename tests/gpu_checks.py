@@ -105,6 +105,25 @@ def check_gemm(M, N, K, epi=EPI_STORE, seed=7):
     return _res(f"gemm[M={M},N={N},K={K},epi={epi}]", ok, max_err_over_tol=err)
 
 
+def check_gemm_pair(M1=300, N1=272, M2=520, N2=720, K=192, accumulate=True, seed=17):
+    """grit_gemm_bf16_nt_pair: two problems in one launch must give the bits of two grit_gemm_bf16_nt launches (strided operands too)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    a1, w1, a2, w2 = mk(M1, K + 64)[:, :K], mk(N1, K), mk(M2, K), mk(N2, K + 128)[:, :K]
+    o1, o2 = mk(M1, N1), mk(M2, N2 + 8)[:, :N2]
+    r1, r2 = o1.clone(), o2.clone()
+    if accumulate:
+        ops.gemm_nt(a1, w1, out=r1, epilogue=EPI_RESIDUAL, residual=r1)
+        ops.gemm_nt(a2, w2, out=r2, epilogue=EPI_RESIDUAL, residual=r2)
+    else:
+        ops.gemm_nt(a1, w1, out=r1)
+        ops.gemm_nt(a2, w2, out=r2)
+    ops.gemm_nt_pair(a1, w1, o1, a2, w2, o2, accumulate=accumulate)
+    same = bool(torch.equal(o1, r1)) and bool(torch.equal(o2, r2))
+    return _res(f"gemm_pair[{M1}x{N1}+{M2}x{N2},K={K},acc={accumulate}]", same,
+                diff1=float((o1.float() - r1.float()).abs().max()), diff2=float((o2.float() - r2.float()).abs().max()))
+
+
 def check_gemm_rope(M=300, nq=4, nkv=2, K=256, S=77, packed=False):
     """Fused QKV GEMM + RoPE epilogue == GEMM followed by the stand-alone RoPE kernel, bit for bit (v heads untouched)."""
     from gritlm_amd.encoder import rope_tables
@@ -2037,6 +2056,9 @@ ALL_CHECKS = [
     ("gemm_residual", check_gemm, dict(M=520, N=512, K=192, epi=EPI_RESIDUAL)),
     ("gemm_swiglu", check_gemm, dict(M=300, N=1024, K=256, epi=EPI_SWIGLU)),
     ("gemm_swiglu_edge", check_gemm, dict(M=70, N=576, K=64, epi=EPI_SWIGLU)),
+    ("gemm_pair", check_gemm_pair, {}),
+    ("gemm_pair_store", check_gemm_pair, dict(M1=17, N1=1536, M2=1024, N2=256, K=256, accumulate=False)),
+    ("gemm_pair_wgrad_shape", check_gemm_pair, dict(M1=4096, N1=14336, M2=6144, N2=4096, K=2048)),
     ("gemm_rope", check_gemm_rope, {}),
     ("gemm_rope_packed", check_gemm_rope, dict(M=513, nq=2, nkv=1, K=128, packed=True)),
     ("gemm_rope_7b", check_gemm_rope, dict(M=1024, nq=32, nkv=8, K=512, S=512)),

@@ -37,6 +37,11 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert lib.grit_gemm_bf16_nt(p16, p16, p16, 4, 24, 64, 64, 64, 24, 0, None, 0, None) == _lib.GRIT_E_UNSUPPORTED   # N % 16
     assert lib.grit_gemm_bf16_nt(p16 + 2, p16, p16, 4, 16, 64, 64, 64, 16, 0, None, 0, None) == _lib.GRIT_E_BADARG    # alignment
     assert lib.grit_gemm_bf16_nt(p16, p16, p16, 4, 16, 64, 64, 64, 16, 7, None, 0, None) == _lib.GRIT_E_BADARG        # epilogue
+    pair = lambda K=64, epi=0, r=None, n2=16: lib.grit_gemm_bf16_nt_pair(p16, p16, p16, r, 4, 16, K, K, 16, 16, p16, p16, p16, r, 4, n2, K, K, n2, n2,
+                                                                       K, epi, None)
+    assert pair(K=48) == _lib.GRIT_E_UNSUPPORTED and pair(n2=24) == _lib.GRIT_E_UNSUPPORTED                          # K % 64, N % 16
+    assert pair(epi=1) == _lib.GRIT_E_BADARG and b"residual" in lib.grit_last_error_string()                          # RESIDUAL without R
+    assert pair(epi=2) == _lib.GRIT_E_BADARG and b"not available" in lib.grit_last_error_string()                     # SWIGLU pairs: no
     assert lib.grit_attn_bidir_fwd(p16, p16, p16, None, 1, 8, 2, 1, 64, 256, 128, 0.1, None) == _lib.GRIT_E_UNSUPPORTED  # head_dim
     assert lib.grit_pool_norm_fwd(p16, p16, None, p16, None, 1, 8, 64, 9, 1, None) == _lib.GRIT_E_BADARG             # pooling mode
     assert lib.grit_infonce_rows_fwd_bwd(p16, p16, 50.0, p16, p16, p16, None, None, 3, 7, 8, 0, 3, 0, 7, None) == _lib.GRIT_E_BADARG  # Np % Nq
