@@ -36,6 +36,10 @@ _SIGNATURES = {
     "grit_mask_pack": (_i, [_p, _p, _i, _i, _p]),
     "grit_attn_bidir_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_attn_causal_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_causal_window_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
+    "grit_attn_causal_window_varlen_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
+    "grit_attn_causal_window_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
+    "grit_attn_causal_window_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _i, _l, _l, _f, _i, _p]),
     "grit_pool_norm_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_pool_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt_rope": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _p, _p, _p, _i, _i, _i, _p]),

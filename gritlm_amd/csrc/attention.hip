@@ -64,11 +64,14 @@ __device__ __forceinline__ uint32_t hi16(uint32_t w) { return w >> 16; }
 // every key of a sequence is valid, so the key bitmask is synthesised from the length.
 // CAUSAL: additionally key <= query (the generative branch of unified training, MistralSdpaAttention with is_causal=True,
 // modeling_mistral_gritlm.py:690-698 / :1017-1036); tiles past the workgroup's last query are skipped.
+// CAUSAL with window > 0 (Mistral's sliding window, modeling_mistral_gritlm.py:381-385 / the sliding-window causal mask of
+// _prepare_4d_causal_attention_mask, :1005-1036): a query sees the `window` keys q - window + 1 .. q; tiles that lie wholly in front
+// of a query block's first visible key are skipped as well.
 template <bool VARLEN, bool CAUSAL>
 __global__ void __launch_bounds__(256, 2)
 attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                  uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride,
-                 int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets) {
+                 int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets, int window) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -118,8 +121,9 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (row_b + v_unit_b)), (att_lptr_t)(vdst + i * 1024), 16, 0, 0);
     }
   };
-  // the first tile's DMA goes out before anything else (tile 0 always exists: S > 0)
-  stage_tile(0, 0);
+  // the first tile's DMA goes out before anything else (tile 0 always exists: S > 0); with a window the first tile of the first block
+  // is known only after the key bitmask has been scanned (below)
+  if (!(CAUSAL && window > 0)) stage_tile(0, 0);
 
   // ---- Q fragments (B operand): lane holds Q[q][16ks + 8hi .. +8] of query block qb.  A row-per-lane global load touches 32 rows x 32 B
   //      per instruction (measured: the per-block Q fetch + O store in that shape cost 18 % of the kernel at S = 512), so Q comes
@@ -183,17 +187,35 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   // vt_lane carries r in byte bits 7:6 and the read address of d-block db is vt_lane ^ (db << 6)
   const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + ((((lane >> 2) & 3) * 4) << 4) + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
 
+  // KV tiles [t0, t1) of query block qb
+  auto tile_range = [&](int qb, int& t0, int& t1) {
+    t0 = 0;
+    t1 = ntiles_all;
+    if constexpr (CAUSAL) {
+      const int lim = 2 * qb + 2;               // tiles holding keys <= the last query of this block
+      t1 = t1 < lim ? t1 : lim;
+      if (window > 0) {
+        const int lo = qb * ATT_QB - window + 1;                // first key the block's FIRST query sees
+        t0 = lo > 0 ? lo >> 6 : 0;
+        t0 = t0 < t1 ? t0 : (t1 > 0 ? t1 - 1 : 0);             // never an empty range while the sequence has keys (the K/V stream
+      }                                                        // through the block seams counts on one tile per block); its keys are
+    }                                                          // then masked for every row
+  };
+  if (CAUSAL && window > 0) {
+    int f0, f1;
+    tile_range(qb_first, f0, f1);
+    stage_tile(f0, 0);
+  }
+
   int gt = 0;                                   // tiles consumed so far by this workgroup: tile g lives in stage g & 1
   ATT_WAIT_VM0();                               // first tile + first Q rows
   for (int qi = 0; qi < nblk; ++qi) {
     const int qb = qb_first + qi;
     const int q_row = qb * ATT_QB + wave * 32 + ql;
-    int ntiles = ntiles_all;
-    if constexpr (CAUSAL) {
-      const int lim = 2 * qb + 2;               // tiles holding keys <= the last query of this block
-      ntiles = ntiles < lim ? ntiles : lim;
-    }
+    int t_first, ntiles, next_first = 0, next_end;
+    tile_range(qb, t_first, ntiles);
     const bool more = qi + 1 < nblk;
+    if (more) tile_range(qb + 1, next_first, next_end);
 
     f32x16_t oacc[4];
 #pragma unroll
@@ -202,17 +224,17 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int t = 0; t < ntiles; ++t, ++gt) {
+    for (int t = t_first; t < ntiles; ++t, ++gt) {
       // tile t has landed (this wave's share: vmcnt; everybody's: the barrier) and every wave is done reading the other stage.  The
       // first tile of a block was waited for before the block loop / at the seam (before the previous block stored its output:
       // vmcnt counts stores, and the stores should drain under this tile, not in front of it).
-      if (t > 0) ATT_WAIT_VM0();
+      if (t > t_first) ATT_WAIT_VM0();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (t + 1 < ntiles) {
         stage_tile(t + 1, (gt + 1) & 1);
       } else if (more) {                        // the stream runs through the block seam: next block's first tile
-        stage_tile(0, (gt + 1) & 1);
+        stage_tile(next_first, (gt + 1) & 1);
       }
       // next block's Q, first 64 columns: fetched a whole tile ahead (the buffer is idle), so the wait at the top of the last tile
       // already covers it
@@ -241,7 +263,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       // softmax and PV of the last tile, no second register set
       const bool q_next = more && t + 1 == ntiles;
       if (q_next) {                 // this block's last QK products have read qf: refill it for the next block
-        if (ntiles == 1) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); }
+        if (ntiles - t_first == 1) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); }
         q_read_half(0);
         q_stage_half(qb + 1, 1);    // the other 64 columns land under the softmax and the PV products
       }
@@ -256,9 +278,15 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       }
       bool fast = (word == ~0ull);
       if constexpr (CAUSAL) {
-        if (t * ATT_KB + ATT_KB - 1 > qb * ATT_QB + wave * 32) {   // tile reaches past this wave's first query: per-lane bound
+        const int qw0 = qb * ATT_QB + wave * 32;                   // this wave's first query
+        // tile reaches past the wave's first query, or starts in front of the first key the wave's LAST query sees: per-lane bounds
+        if (t * ATT_KB + ATT_KB - 1 > qw0 || (window > 0 && t * ATT_KB < qw0 + 32 - window)) {
           const int n = q_row - t * ATT_KB + 1;                    // keys of this tile the lane's query may see
           word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+          if (window > 0) {
+            const int lo = n - window;                             // keys of this tile in front of the lane's window
+            word &= lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+          }
           fast = false;
         }
       }
@@ -429,11 +457,12 @@ static void attn_lds_optin(KernelT kernel, std::atomic<uint64_t>& done) {
 }
 template <bool VARLEN, bool CAUSAL>
 static void attn_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
-                        int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets) {
+                        int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets,
+                        int window) {
   static std::atomic<uint64_t> optin{0};
   attn_lds_optin(attn_bidir_fwd_k<VARLEN, CAUSAL>, optin);
   hipLaunchKernelGGL((attn_bidir_fwd_k<VARLEN, CAUSAL>), grid, dim3(256), ATT_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
-                     out_stride, scale_log2, qpw, ngx, n_sets);
+                     out_stride, scale_log2, qpw, ngx, n_sets, window);
 }
 
 struct AttnGeom {
@@ -456,12 +485,13 @@ static AttnGeom attn_geom(int B, int max_len, int nq, int nkv) {
   return g;
 }
 
-static int attn_fwd_padded(const char* name, bool causal, const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
+static int attn_fwd_padded(const char* name, bool causal, int window, const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
                            int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && key_bits && out, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "%s: bad sizes", name);
   GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
+  GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "%s: window=%d (>= 1 keys per query, causal attention only)", name, window);
   GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "%s: bad strides", name);
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
@@ -472,20 +502,21 @@ static int attn_fwd_padded(const char* name, bool causal, const void* qkv, const
   const dim3 grid(g.grid);
   if (causal)
     attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
-                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
+                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   else
     attn_launch<false, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
-                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
+                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   GRIT_CHECK_LAUNCH(name);
   return GRIT_OK;
 }
 
-static int attn_fwd_varlen(const char* name, bool causal, const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len,
+static int attn_fwd_varlen(const char* name, bool causal, int window, const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len,
                            int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && cu_seqlens && out, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(B > 0 && max_len > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "%s: bad sizes", name);
   GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
+  GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "%s: window=%d (>= 1 keys per query, causal attention only)", name, window);
   GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "%s: bad strides", name);
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
@@ -496,29 +527,44 @@ static int attn_fwd_varlen(const char* name, bool causal, const void* qkv, const
   const dim3 grid(g.grid);
   if (causal)
     attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
-                            out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
+                            out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   else
     attn_launch<true, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
-                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
+                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   GRIT_CHECK_LAUNCH(name);
   return GRIT_OK;
 }
 
 extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  return attn_fwd_padded("grit_attn_bidir_fwd", false, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+  return attn_fwd_padded("grit_attn_bidir_fwd", false, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }
 extern "C" int grit_attn_causal_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
                                     int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  return attn_fwd_padded("grit_attn_causal_fwd", true, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+  return attn_fwd_padded("grit_attn_causal_fwd", true, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }
 extern "C" int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
                                           int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  return attn_fwd_varlen("grit_attn_bidir_varlen_fwd", false, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
+  return attn_fwd_varlen("grit_attn_bidir_varlen_fwd", false, 0, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
                          stream);
 }
 extern "C" int grit_attn_causal_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
                                            int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  return attn_fwd_varlen("grit_attn_causal_varlen_fwd", true, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
+  return attn_fwd_varlen("grit_attn_causal_varlen_fwd", true, 0, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
                          stream);
+}
+
+// Sliding-window causal attention: query q sees keys q - window + 1 .. q (window >= 1; window >= S is plain causal attention).
+extern "C" int grit_attn_causal_window_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                           int d, int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream) {
+  GRIT_REQUIRE(window >= 1, GRIT_E_BADARG, "grit_attn_causal_window_fwd: window=%d must be >= 1", window);
+  return attn_fwd_padded("grit_attn_causal_window_fwd", true, window, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream);
+}
+extern "C" int grit_attn_causal_window_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                                  int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, int window,
+                                                  void* stream) {
+  GRIT_REQUIRE(window >= 1, GRIT_E_BADARG, "grit_attn_causal_window_varlen_fwd: window=%d must be >= 1", window);
+  return attn_fwd_varlen("grit_attn_causal_window_varlen_fwd", true, window, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride,
+                         out_stride, scale, stream);
 }

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256)
 attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                 const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
                 uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal,
-                int nkb, int n_sets) {
+                int nkb, int n_sets, int window) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
@@ -192,8 +192,12 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
   const char* seq_do = reinterpret_cast<const char*>(dout + row0 * out_stride);
 
   // flat tile list: the query tiles (qt0 .. nqt-1) of each of the group's heads
-  const int nqt = (S + 63) >> 6;
+  int nqt = (S + 63) >> 6;
   const int qt0 = causal ? 2 * kblk : 0;           // causal: query tiles before this key block see none of its keys
+  if (window > 0) {                                // sliding window: nor do the tiles behind query (last key of the block) + window - 1
+    const int qt_end = ((kblk * 128 + 126 + window) >> 6) + 1;
+    nqt = nqt < qt_end ? nqt : qt_end;
+  }
   const int per_head = nqt - qt0;
   const int ntl = group * per_head;
   auto tile_of = [&](int n, int& h, int& qt) {
@@ -295,7 +299,8 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = qb * 32 + 8 * (r >> 2) + (r & 3);                 // + 4 hi
-        const bool seen = key_ok & ((causal == 0) | (key <= qt * 64 + ql + 4 * hi));      // bitwise: no short-circuit branches
+        const int qd = qt * 64 + ql + 4 * hi - key;                                        // query - key
+        const bool seen = key_ok & ((causal == 0) | (qd >= 0)) & ((window == 0) | (qd < window));   // bitwise: no short-circuit branches
         const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[r]);                 // unconditional: a select, not a branch
         const float p = seen ? e : 0.f;
         s[r] = p;
@@ -332,7 +337,7 @@ __global__ void __launch_bounds__(256, 2)
 attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
               const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
               uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal,
-              int nqb, int n_sets) {
+              int nqb, int n_sets, int window) {
   __shared__ __attribute__((aligned(16))) char smem[AB_RING];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
@@ -358,7 +363,9 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
     stage_img(k_base, qkv_stride_b, t * 64, S, smem + buf * AB_STAGE, wv, lane);
     stage_img(v_base, qkv_stride_b, t * 64, S, smem + buf * AB_STAGE + AB_IMG, wv, lane);
   };
-  stage(0, 0);                                      // tile 0 always exists (S > 0)
+  // first K/V tile: 0 (always exists: S > 0), or the one holding the first key of the block's first query's window
+  const int t_first = window > 0 && qblk * 128 - window + 1 > 0 ? (qblk * 128 - window + 1) >> 6 : 0;
+  stage(t_first, t_first & 1);
 
   const uint64_t* bits = nullptr;
   int ntiles = 0;
@@ -395,7 +402,7 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
   const TrLane trl = tr_lane(lane);
 
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_first; t < ntiles; ++t) {
     AB_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -411,6 +418,10 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
     if (causal) {
       const int n = q - t * 64 + 1;
       word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+      if (window > 0) {
+        const int lo = n - window;                  // keys of this tile in front of the query's window
+        word &= lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+      }
     }
     const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
     // hipcc sinks every fragment read to its use and waits for each (one read in flight); the reads are therefore issued in pinned
@@ -487,7 +498,7 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
 
 using namespace grit;
 
-static int attn_bwd_launch(bool varlen, int causal, const void* qkv, const uint64_t* key_bits, const int32_t* cu, const void* out, const void* dout,
+static int attn_bwd_launch(bool varlen, int causal, int window, const void* qkv, const uint64_t* key_bits, const int32_t* cu, const void* out, const void* dout,
                            const float* lse, float* delta, void* dqkv, int B, int S_or_maxlen, int64_t T, int nq, int nkv,
                            int64_t qkv_stride, int64_t out_stride, float scale, hipStream_t st) {
   const int64_t items = T * nq;
@@ -511,29 +522,30 @@ static int attn_bwd_launch(bool varlen, int causal, const void* qkv, const uint6
   const dim3 grid_kv((unsigned)(sets8 * nblk)), grid_q((unsigned)(sets8 * (nq / nkv) * nblk));
   if (varlen) {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<true>, grid_kv, dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets, window);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dkdv");
     hipLaunchKernelGGL(attn_bwd_dq_k<true>, grid_q, dim3(256), 0, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets, window);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_varlen_bwd: dq");
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<false>, grid_kv, dim3(256), lds_kv, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets, window);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dkdv");
     hipLaunchKernelGGL(attn_bwd_dq_k<false>, grid_q, dim3(256), 0, st, (const uint16_t*)qkv, key_bits, cu,
-                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets);
+                       (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, S_or_maxlen, nq, nkv, qkv_stride, out_stride, scale, causal, nblk, n_sets, window);
     GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: dq");
   }
   return GRIT_OK;
 }
 
-static int attn_bwd_padded(int causal, const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+static int attn_bwd_padded(int causal, int window, const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
                            float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
                            int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && key_bits && out && dout && lse && delta && dqkv, GRIT_E_BADARG, "grit_attn_bidir_bwd: null pointer");
   GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_bwd: bad sizes");
   GRIT_REQUIRE(d == AB_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: head_dim=%d (only 128 is built)", d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_bwd: nq not a multiple of nkv");
+  GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "grit_attn_bidir_bwd: window=%d (causal attention only)", window);
   GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "grit_attn_bidir_bwd: bad strides");
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
@@ -541,27 +553,28 @@ static int attn_bwd_padded(int causal, const void* qkv, const uint64_t* key_bits
   GRIT_REQUIRE((int64_t)B * nq * ((S + 127) / 128) < (1ll << 30), GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: grid too large");
   GRIT_REQUIRE((int64_t)S * qkv_stride * 2 < (1ll << 31) && (int64_t)S * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
                "grit_attn_bidir_bwd: one sequence spans more than 2 GiB (32-bit row offsets)");
-  return attn_bwd_launch(false, causal, qkv, key_bits, nullptr, out, dout, lse, delta, dqkv, B, S, (int64_t)B * S, nq, nkv, qkv_stride,
+  return attn_bwd_launch(false, causal, window, qkv, key_bits, nullptr, out, dout, lse, delta, dqkv, B, S, (int64_t)B * S, nq, nkv, qkv_stride,
                          out_stride, scale, (hipStream_t)stream);
 }
 extern "C" int grit_attn_bidir_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
                                    float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
                                    int64_t out_stride, float scale, void* stream) {
-  return attn_bwd_padded(0, qkv, key_bits, out, dout, lse, delta, dqkv, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+  return attn_bwd_padded(0, 0, qkv, key_bits, out, dout, lse, delta, dqkv, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }
 extern "C" int grit_attn_causal_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
                                     float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
                                     int64_t out_stride, float scale, void* stream) {
-  return attn_bwd_padded(1, qkv, key_bits, out, dout, lse, delta, dqkv, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+  return attn_bwd_padded(1, 0, qkv, key_bits, out, dout, lse, delta, dqkv, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }
 
-static int attn_bwd_varlen(int causal, const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+static int attn_bwd_varlen(int causal, int window, const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
                            float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
                            int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && cu_seqlens && out && dout && lse && delta && dqkv, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: null pointer");
   GRIT_REQUIRE(B > 0 && max_len > 0 && T > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: bad sizes");
   GRIT_REQUIRE(d == AB_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: head_dim=%d (only 128 is built)", d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: nq not a multiple of nkv");
+  GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: window=%d (causal attention only)", window);
   GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
                GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: bad strides");
   GRIT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), GRIT_E_BADARG,
@@ -569,16 +582,30 @@ static int attn_bwd_varlen(int causal, const void* qkv, const int32_t* cu_seqlen
   GRIT_REQUIRE((int64_t)B * nq * ((max_len + 127) / 128) < (1ll << 30), GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: grid too large");
   GRIT_REQUIRE((int64_t)max_len * qkv_stride * 2 < (1ll << 31) && (int64_t)max_len * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
                "grit_attn_bidir_varlen_bwd: one sequence spans more than 2 GiB (32-bit row offsets)");
-  return attn_bwd_launch(true, causal, qkv, nullptr, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, qkv_stride, out_stride,
+  return attn_bwd_launch(true, causal, window, qkv, nullptr, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, qkv_stride, out_stride,
                          scale, (hipStream_t)stream);
 }
 extern "C" int grit_attn_bidir_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
                                           float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
                                           int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  return attn_bwd_varlen(0, qkv, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+  return attn_bwd_varlen(0, 0, qkv, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }
 extern "C" int grit_attn_causal_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
                                            float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
                                            int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
-  return attn_bwd_varlen(1, qkv, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+  return attn_bwd_varlen(1, 0, qkv, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+// backward of grit_attn_causal_window_fwd / _varlen_fwd (same window: keys q - window + 1 .. q)
+extern "C" int grit_attn_causal_window_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+                                           float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
+                                           int64_t out_stride, float scale, int window, void* stream) {
+  GRIT_REQUIRE(window >= 1, GRIT_E_BADARG, "grit_attn_causal_window_bwd: window=%d must be >= 1", window);
+  return attn_bwd_padded(1, window, qkv, key_bits, out, dout, lse, delta, dqkv, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+extern "C" int grit_attn_causal_window_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout,
+                                                  const float* lse, float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv,
+                                                  int d, int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream) {
+  GRIT_REQUIRE(window >= 1, GRIT_E_BADARG, "grit_attn_causal_window_varlen_bwd: window=%d must be >= 1", window);
+  return attn_bwd_varlen(1, window, qkv, cu_seqlens, out, dout, lse, delta, dqkv, B, max_len, T, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream);
 }

@@ -98,6 +98,11 @@ class MistralDecoder:
         nq, nkv, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
         past = _layers_of(past_key_values) if past_key_values is not None else None
         S0 = past[0][0].shape[2] if past is not None else 0
+        if 0 < self.eng.window_keys < S0 + P + max_new_tokens:
+            # the reference's sdpa path (window_keys = 0) attends to the whole cache; its eager / flash paths window the cache (and the
+            # flash path slices it, modeling_mistral_gritlm.py:394-415) -- the decode kernels attend to the whole cache only
+            raise NotImplementedError(f"native decode past the sliding window ({self.eng.window_keys} keys) is built for the sdpa semantics "
+                                      "only (window_keys = 0: full causal attention over the cache)")
         Lmax = (S0 + P + max_new_tokens + 255) // 256 * 256
         st = self._state(B, Lmax)
         st["history"] = torch.zeros((B, max_new_tokens), dtype=I64, device=dev)

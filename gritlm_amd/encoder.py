@@ -99,6 +99,29 @@ class _Layer:
     __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "wgate", "w13", "w2")
 
 
+def sliding_window_keys(sliding_window, attn_implementation: str | None = "sdpa") -> int:
+    """How many keys (its own included) a CAUSAL query sees under ``config.sliding_window``, per attention path of the reference; 0 = no
+    window.  The reference's three paths do not agree (scripts/modeling_mistral_gritlm.py):
+
+    * ``sdpa`` (its default): :1011-1016 hands NO sliding_window to `_prepare_4d_causal_attention_mask_for_sdpa` -- plain causal
+      attention at every length;
+    * ``eager``: :1022-1031 passes `sliding_window=config.sliding_window`; the mask of its pinned transformers 4.37.2 keeps
+      ``sliding_window`` keys (later transformers releases keep one more -- set the engine's ``window_keys`` to override);
+    * ``flash_attention_2``: `window_size=(W, W)` (:548, :570) once the sequence is longer than W -- ``sliding_window + 1`` keys.
+
+    The bidirectional embedding path never applies the window (in no path of the reference)."""
+    if not sliding_window:
+        return 0
+    impl = attn_implementation or "sdpa"
+    if impl == "sdpa":
+        return 0
+    if impl == "eager":
+        return int(sliding_window)
+    if impl == "flash_attention_2":
+        return int(sliding_window) + 1
+    raise ValueError(f"unknown attn_implementation {attn_implementation!r}")
+
+
 class MistralEncoderEngine:
     """Forward-only native engine (inference / GradCache pass 1)."""
 
@@ -114,7 +137,8 @@ class MistralEncoderEngine:
         self.rope_bf16 = True
         self.record_routing = None      # tests: set to a list to collect every MoE layer's selected experts [T,2]
         self.causal = False             # True: causal attention ('cc' embedding attention of the reference's attn string)
-        self.sliding_window = None      # causal + S > window is not built (bidirectional attention ignores the window, as the reference)
+        self.window_keys = 0            # causal attention: keys a query sees (sliding_window_keys(); 0 = no window).  The bidirectional
+                                        # path ignores it, as the reference
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -241,9 +265,9 @@ class MistralEncoderEngine:
         ops.gemm_nt_grouped(ws["act2"], L.w2, counts, 2 * T, out=ws["y2"])
         ops.moe_combine(ws["y2"], rows, weights, h, out=h)
 
-    def _check_window(self, S: int):
-        if self.causal and self.sliding_window is not None and S > self.sliding_window:
-            raise NotImplementedError(f"causal attention with sliding_window={self.sliding_window} < sequence length {S} is not built")
+    def _window(self, S: int) -> int:
+        """``window`` argument of the attention kernels for sequences of up to S tokens (0: every earlier key is inside the window)."""
+        return int(self.window_keys) if self.causal and 0 < self.window_keys < S else 0
 
     def _rope_tables(self, S: int):
         t = self._rope.get(S)
@@ -265,7 +289,7 @@ class MistralEncoderEngine:
         c = self.cfg
         B, S = input_ids.shape
         T = B * S
-        self._check_window(S)
+        window = self._window(S)
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
         if attention_mask is None:
             attention_mask = torch.ones((B, S), dtype=torch.int64, device=self.device)
@@ -283,7 +307,7 @@ class MistralEncoderEngine:
             if return_kv:
                 kvw = qkv.view(B, S, nq + 2 * nkv, d)
                 kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).contiguous(), kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).contiguous()))
-            ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, causal=self.causal)
+            ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, causal=self.causal, window=window)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)
@@ -311,7 +335,7 @@ class MistralEncoderEngine:
         computes every padded row.  Results are bit-identical to the padded path."""
         c = self.cfg
         B, S = input_ids.shape
-        self._check_window(S)
+        window = self._window(S)
         mask = attention_mask.to(device=self.device, dtype=torch.int64)
         ids = input_ids.to(device=self.device, dtype=torch.int64)
         if packed is None:
@@ -335,7 +359,7 @@ class MistralEncoderEngine:
         for L in self.layers:
             ops.rmsnorm(h, L.ln1, eps, out=x)
             ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, positions=pos, out=qkv)
-            ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal)
+            ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal, window=window)
             ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)

@@ -133,7 +133,8 @@ class GritLM(torch.nn.Module):
         ecfg.check_supported()
         self.engine = MistralEncoderEngine.from_state_dict(ecfg, self._backbone().state_dict(), dev)
         self.engine.causal = self.attn[:2] == "cc"       # 'cc..': causal embedding attention (e.g. lasttoken / weightedmean models)
-        self.engine.sliding_window = getattr(cfg, "sliding_window", None)
+        from .encoder import sliding_window_keys
+        self.engine.window_keys = sliding_window_keys(getattr(cfg, "sliding_window", None), getattr(cfg, "_attn_implementation", None))
 
     def native_decoder(self):
         """Greedy decoder on the HIP kernels (gritlm_amd.decoder.MistralDecoder) sharing the engine's weights; use it where the reference

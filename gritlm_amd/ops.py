@@ -126,10 +126,21 @@ def rope_qk_pos_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, positi
     return qkv
 
 
+def _attn_entry(kind: str, causal: bool, window: int):
+    """(entry point, extra arguments) of an attention call: bidirectional, causal, or causal with a sliding window of ``window`` keys."""
+    lib = _lib.load()
+    if window and window > 0:
+        if not causal:
+            raise ValueError("a sliding window applies to causal attention only (the bidirectional embedding path ignores it, as the reference)")
+        return getattr(lib, "grit_attn_causal_window_" + kind), (int(window),)
+    return getattr(lib, ("grit_attn_causal_" if causal else "grit_attn_bidir_") + kind), ()
+
+
 def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, nq: int, nkv: int, d: int,
                       out: torch.Tensor | None = None, scale: float | None = None, lse: torch.Tensor | None = None,
-                      causal: bool = False) -> torch.Tensor:
-    """lse (optional, fp32 [T, nq]) receives the log-sum-exp rows for grit_attn_bidir_varlen_bwd."""
+                      causal: bool = False, window: int = 0) -> torch.Tensor:
+    """lse (optional, fp32 [T, nq]) receives the log-sum-exp rows for grit_attn_bidir_varlen_bwd.  ``window`` > 0 (causal only): sliding
+    window, a query sees keys q - window + 1 .. q."""
     T, stride = qkv.shape
     B = cu_seqlens.numel() - 1
     if out is None:
@@ -139,10 +150,9 @@ def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
     ev = _timer.span("attn_bidir_fwd", 0.0) if _timer is not None else None
     if ev:
         ev[0].record()
-    fn = _lib.load().grit_attn_causal_varlen_fwd if causal else _lib.load().grit_attn_bidir_varlen_fwd
+    fn, wa = _attn_entry("varlen_fwd", causal, window)
     check(fn(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"),
-                                                 0 if lse is None else _chk(lse, F32, "lse"), B,
-                                                 int(max_len), nq, nkv, d, stride, out.stride(0), float(scale), _stream()),
+             0 if lse is None else _chk(lse, F32, "lse"), B, int(max_len), nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()),
           "grit_attn_bidir_varlen_fwd")
     if ev:
         ev[1].record()
@@ -345,7 +355,7 @@ def mask_pack(mask: torch.Tensor) -> torch.Tensor:
 
 def attn_bidir(qkv: torch.Tensor, key_bits: torch.Tensor, B: int, S: int, nq: int, nkv: int, d: int,
                out: torch.Tensor | None = None, lse: torch.Tensor | None = None, scale: float | None = None,
-               causal: bool = False) -> torch.Tensor:
+               causal: bool = False, window: int = 0) -> torch.Tensor:
     T, stride = qkv.shape
     assert T == B * S
     if out is None:
@@ -355,10 +365,9 @@ def attn_bidir(qkv: torch.Tensor, key_bits: torch.Tensor, B: int, S: int, nq: in
     ev = _timer.span("attn_bidir_fwd", 4.0 * B * nq * S * S * d) if _timer is not None else None
     if ev:
         ev[0].record()
-    fn = _lib.load().grit_attn_causal_fwd if causal else _lib.load().grit_attn_bidir_fwd
+    fn, wa = _attn_entry("fwd", causal, window)
     check(fn(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"),
-                                          0 if lse is None else _chk(lse, F32, "lse"), B, S, nq, nkv, d, stride, out.stride(0),
-                                          float(scale), _stream()), "grit_attn_bidir_fwd")
+             0 if lse is None else _chk(lse, F32, "lse"), B, S, nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()), "grit_attn_bidir_fwd")
     if ev:
         ev[1].record()
     return out
@@ -457,23 +466,23 @@ def swiglu_bwd(gu: torch.Tensor, dact: torch.Tensor, out: torch.Tensor | None = 
 
 def attn_bidir_bwd(qkv: torch.Tensor, key_bits: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, S: int,
                    nq: int, nkv: int, d: int, dqkv: torch.Tensor | None = None, scale: float | None = None,
-                   causal: bool = False) -> torch.Tensor:
+                   causal: bool = False, window: int = 0) -> torch.Tensor:
     T, stride = qkv.shape
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     if scale is None:
         scale = d ** -0.5
     delta = torch.empty((B, nq, S), dtype=F32, device=qkv.device)
-    fn = _lib.load().grit_attn_causal_bwd if causal else _lib.load().grit_attn_bidir_bwd
-    check(fn(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"),
-                                          _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"), delta.data_ptr(), _chk(dqkv, BF16, "dqkv"),
-                                          B, S, nq, nkv, d, stride, out.stride(0), float(scale), _stream()), "grit_attn_bidir_bwd")
+    fn, wa = _attn_entry("bwd", causal, window)
+    check(fn(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
+             delta.data_ptr(), _chk(dqkv, BF16, "dqkv"), B, S, nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()),
+          "grit_attn_bidir_bwd")
     return dqkv
 
 
 def attn_bidir_varlen_bwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, out: torch.Tensor, dout: torch.Tensor,
                           lse: torch.Tensor, nq: int, nkv: int, d: int, dqkv: torch.Tensor | None = None,
-                          scale: float | None = None, causal: bool = False) -> torch.Tensor:
+                          scale: float | None = None, causal: bool = False, window: int = 0) -> torch.Tensor:
     T, stride = qkv.shape
     B = cu_seqlens.numel() - 1
     if dqkv is None:
@@ -481,11 +490,10 @@ def attn_bidir_varlen_bwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: 
     if scale is None:
         scale = d ** -0.5
     delta = torch.empty((T, nq), dtype=F32, device=qkv.device)
-    fn = _lib.load().grit_attn_causal_varlen_bwd if causal else _lib.load().grit_attn_bidir_varlen_bwd
-    check(fn(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"),
-                                                 _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"), delta.data_ptr(),
-                                                 _chk(dqkv, BF16, "dqkv"), B, int(max_len), T, nq, nkv, d, stride, out.stride(0),
-                                                 float(scale), _stream()), "grit_attn_bidir_varlen_bwd")
+    fn, wa = _attn_entry("varlen_bwd", causal, window)
+    check(fn(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
+             delta.data_ptr(), _chk(dqkv, BF16, "dqkv"), B, int(max_len), T, nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()),
+          "grit_attn_bidir_varlen_bwd")
     return dqkv
 
 

@@ -20,7 +20,7 @@ import torch
 
 from .. import ops
 from .._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE
-from ..encoder import EncoderConfig, rope_tables
+from ..encoder import EncoderConfig, rope_tables, sliding_window_keys
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -42,12 +42,12 @@ class _Geometry:
     """Row layout of one chunk.  Padded: T = B*S rows, key-padding bitmask.  Packed: only the real tokens of a right-padded
     batch (rows of sequence b at [cu[b], cu[b+1])), per-row RoPE positions -- GEMMs, norms and attention never see padding
     (the reference computes every padded position)."""
-    __slots__ = ("packed", "B", "S", "T", "bits", "cu", "pos", "max_len", "keep", "causal")
+    __slots__ = ("packed", "B", "S", "T", "bits", "cu", "pos", "max_len", "keep", "causal", "window")
 
     @staticmethod
     def padded(mask: torch.Tensor):
         g = _Geometry()
-        g.packed, (g.B, g.S), g.causal = False, mask.shape, False
+        g.packed, (g.B, g.S), g.causal, g.window = False, mask.shape, False, 0
         g.T = g.B * g.S
         g.bits = ops.mask_pack(mask)
         g.cu = g.pos = g.keep = None
@@ -67,7 +67,7 @@ class _Geometry:
         if not ok:
             return None
         g = _Geometry()
-        g.packed, g.B, g.S, g.T, g.max_len, g.keep, g.bits, g.causal = True, B, S, int(T), int(max_len), keep, None, False
+        g.packed, g.B, g.S, g.T, g.max_len, g.keep, g.bits, g.causal, g.window = True, B, S, int(T), int(max_len), keep, None, False, 0
         g.cu = torch.zeros((B + 1,), dtype=torch.int32, device=mask.device)
         g.cu[1:] = torch.cumsum(lens, dim=0)
         g.pos = ar.to(torch.int32).unsqueeze(0).expand(B, S)[keep].contiguous()
@@ -80,7 +80,8 @@ class MistralTrainEngine:
         self.lm_head = lm_head.weight if lm_head is not None else None
         if self.lm_head is not None and self.lm_head.dtype != BF16:
             raise RuntimeError("MistralTrainEngine: lm_head must be bfloat16")
-        self.sliding_window = getattr(hf_config, "sliding_window", None)
+        # causal (generative) attention: keys a query sees under config.sliding_window -- depends on the attention path, as in the reference
+        self.window_keys = sliding_window_keys(getattr(hf_config, "sliding_window", None), getattr(hf_config, "_attn_implementation", None))
         self.cfg = hf_config if isinstance(hf_config, EncoderConfig) else EncoderConfig.from_hf(hf_config)
         self.cfg.check_supported()
         self.device = torch.device(device)
@@ -281,11 +282,11 @@ class MistralTrainEngine:
         if geom.packed:
             lse = torch.empty((T, nq), dtype=F32, device=dev) if need_bwd else None
             ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, positions=geom.pos, out=qkv)      # q/k/v projections + RoPE epilogue
-            ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
+            ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal, window=geom.window)
         else:
             lse = torch.empty((B, nq, S), dtype=F32, device=dev) if need_bwd else None
             ops.gemm_nt_rope(x1, L.wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)
-            ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal)
+            ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, lse=lse, causal=geom.causal, window=geom.window)
         if need_bwd:
             h_mid = buf["h_mid"]
         else:                            # h must survive when it is a saved layer input (recompute policy) -> h_out doubles as h_mid
@@ -312,8 +313,7 @@ class MistralTrainEngine:
         if geom is None:
             geom = _Geometry.padded(mask)
         geom.causal = bool(causal)
-        if causal and self.sliding_window is not None and S > self.sliding_window:
-            raise NotImplementedError(f"causal attention with sliding_window={self.sliding_window} < sequence length {S}")
+        geom.window = int(self.window_keys) if causal and 0 < self.window_keys < S else 0
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         ids = ids[geom.keep].contiguous() if geom.packed else ids.view(-1)
         T = geom.T
@@ -455,10 +455,10 @@ class MistralTrainEngine:
             dctx = ops.gemm_nt(dh_mid, self._wt(li, "o", L.wo))                         # [T,nq*d]
             self._wgrad(dh_mid, sv["ctx"], L.go, ("dh", "ctx"))
             if geom.packed:
-                dqkv = ops.attn_bidir_varlen_bwd(sv["qkv"], geom.cu, geom.max_len, sv["ctx"], dctx, sv["lse"], nq, nkv, d, causal=geom.causal)
+                dqkv = ops.attn_bidir_varlen_bwd(sv["qkv"], geom.cu, geom.max_len, sv["ctx"], dctx, sv["lse"], nq, nkv, d, causal=geom.causal, window=geom.window)
                 ops.rope_qk_pos_(dqkv, cos, sin, geom.pos, nq, nkv, d, inverse=True)
             else:
-                dqkv = ops.attn_bidir_bwd(sv["qkv"], geom.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d, causal=geom.causal)
+                dqkv = ops.attn_bidir_bwd(sv["qkv"], geom.bits, sv["ctx"], dctx, sv["lse"], B, S, nq, nkv, d, causal=geom.causal, window=geom.window)
                 ops.rope_qk_(dqkv, cos, sin, S, nq, nkv, d, inverse=True)
             dx1 = ops.gemm_nt(dqkv, self._wt(li, "qkv", L.wqkv))                        # [T,H]
             if self._deferred_wgrad is not None:

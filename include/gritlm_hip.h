@@ -170,6 +170,15 @@ int grit_attn_causal_fwd(const void* qkv, const uint64_t* key_bits, void* out, f
 int grit_attn_causal_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
                                 int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
 
+/* Sliding-window causal attention (Mistral's `sliding_window`: modeling_mistral_gritlm.py:381-385 and the sliding-window causal mask of
+ * :1005-1036): query q sees the `window` keys q - window + 1 .. q that the key mask allows (window >= 1; window >= S is plain causal
+ * attention).  `window` counts keys INCLUDING the query's own: config.sliding_window for the mask the reference's eager / sdpa paths
+ * build under its pinned transformers 4.37.2, config.sliding_window + 1 for its flash-attention path (window_size = (W, W)). */
+int grit_attn_causal_window_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv, int d,
+                                int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream);
+int grit_attn_causal_window_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                       int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream);
+
 /* ---- pooling + normalise: gritlm/gritlm.py:178-218,156-158; training/model.py:151-165 --------- */
 
 /* hidden [B,S,H] bf16; mask [B,S] int64 (attention mask); instr_len (nullable) [B] int32: the first
@@ -276,6 +285,13 @@ int grit_attn_causal_bwd(const void* qkv, const uint64_t* key_bits, const void* 
 int grit_attn_causal_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
                                 float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
                                 int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+/* backward of the sliding-window variants (autograd through MistralSdpaAttention with the sliding-window mask) */
+int grit_attn_causal_window_bwd(const void* qkv, const uint64_t* key_bits, const void* out, const void* dout, const float* lse,
+                                float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
+                                int64_t out_stride, float scale, int window, void* stream);
+int grit_attn_causal_window_varlen_bwd(const void* qkv, const int32_t* cu_seqlens, const void* out, const void* dout, const float* lse,
+                                       float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
+                                       int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream);
 
 /* ---- generative branch: NextTokenLoss, gritlm/training/model.py:66-107 -------------------------- */
 

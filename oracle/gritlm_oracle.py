@@ -96,9 +96,46 @@ def apply_rope(x: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
     return x * cos[None, None] + rotate_half(x) * sin[None, None]
 
 
-def attention_bidirectional(q, k, v, key_mask, acc_dtype=F64, causal=False):
+def causal_window_mask(S: int, window: int = 0) -> np.ndarray:
+    """[S, S] bool, True where query i sees key j: j <= i, and with ``window`` > 0 additionally i - j < window (``window`` = number of
+    keys a query sees, its own included).
+
+    The sliding-window causal mask is built by a dependency that is not vendored in the reference: transformers (pinned ==4.37.2 in the
+    reference's requirements), `modeling_attn_mask_utils.AttentionMaskConverter._make_causal_mask`, called from
+    `_prepare_4d_causal_attention_mask(..., sliding_window=config.sliding_window)` at scripts/modeling_mistral_gritlm.py:1005-1031.
+    Its published algorithm: lower-triangular mask, then fill finfo.min wherever `1 - triu(ones, diagonal=-sliding_window + 1)` is set,
+    i.e. j < i - sliding_window + 1 -> window = sliding_window keys.  Later transformers releases (the one installed in the build
+    container generated tests/golden/sliding_window_gqa.npz) mask `tril(ones, diagonal=-sliding_window - 1)`, i.e. j <= i - W - 1
+    -> window = sliding_window + 1 keys, which is also what the reference's flash-attention path keeps (window_size=(W, W), :548 / :570).
+    The fixture records which of the two its generating run used."""
+    i = np.arange(S)[:, None]
+    j = np.arange(S)[None, :]
+    m = j <= i
+    if window and window > 0:
+        m &= (i - j) < window
+    return m
+
+
+def masked_softmax(scores, key_mask, causal=False, window=0):
+    """softmax over the keys a query is allowed to see (scores [B, H, S, S]).  A query row with NO allowed key -- a padding row behind a
+    sliding window -- gets p = 0 (the reference's finfo.min mask gives such rows a uniform distribution; they are padding either way,
+    and a zero row keeps NaN out of the padded keys of the next layer)."""
+    S = scores.shape[-1]
+    allowed = np.ones((1, 1, S, S), dtype=bool)
+    if key_mask is not None:
+        allowed = allowed & key_mask.astype(bool)[:, None, None, :]
+    if causal:
+        allowed = allowed & causal_window_mask(S, window)[None, None]
+    scores = np.where(allowed, scores, -np.inf)
+    m = scores.max(axis=-1, keepdims=True)
+    p = np.exp(scores - np.where(np.isfinite(m), m, 0.0))
+    den = p.sum(axis=-1, keepdims=True)
+    return p / np.where(den > 0, den, 1.0)
+
+
+def attention_bidirectional(q, k, v, key_mask, acc_dtype=F64, causal=False, window=0):
     """Attention core with is_causal=False and a key-padding mask (``causal=True``: additionally key <= query, the mask of
-    `_prepare_4d_causal_attention_mask(_for_sdpa)`, :1005-1016 / :1021-1031 -- the generative branch).
+    `_prepare_4d_causal_attention_mask(_for_sdpa)`, :1005-1016 / :1021-1031 -- the generative branch; ``window``: causal_window_mask).
 
     MistralSdpaAttention.forward scripts/modeling_mistral_gritlm.py:627-705
     (repeat_kv :182-191, SDPA :690-698) with the additive mask of
@@ -114,14 +151,7 @@ def attention_bidirectional(q, k, v, key_mask, acc_dtype=F64, causal=False):
     k = np.repeat(k, rep, axis=1).astype(acc_dtype)
     v = np.repeat(v, rep, axis=1).astype(acc_dtype)
     scores = np.matmul(q.astype(acc_dtype), k.transpose(0, 1, 3, 2)) / np.sqrt(d).astype(acc_dtype)
-    if key_mask is not None:
-        neg = np.where(key_mask.astype(bool), 0.0, -np.inf).astype(acc_dtype)[:, None, None, :]
-        scores = scores + neg
-    if causal:
-        scores = scores + np.where(np.tril(np.ones((S, S), dtype=bool)), 0.0, -np.inf).astype(acc_dtype)[None, None]
-    scores = scores - scores.max(axis=-1, keepdims=True)
-    p = np.exp(scores)
-    p = p / p.sum(axis=-1, keepdims=True)
+    p = masked_softmax(scores, key_mask, causal, window)
     out = np.matmul(p, v)
     return out.transpose(0, 2, 1, 3).reshape(B, S, Hq * d).astype(F32)
 
@@ -138,7 +168,7 @@ def mlp(x, w_gate, w_up, w_down):
 
 
 def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_mask: np.ndarray | None,
-                   emulate_bf16: bool = False, return_layers: bool = False, acc_dtype=F64, causal: bool = False):
+                   emulate_bf16: bool = False, return_layers: bool = False, acc_dtype=F64, causal: bool = False, window: int = 0):
     """MistralModel.forward with is_causal=False, scripts/modeling_mistral_gritlm.py:936-1096.
 
     ``weights`` uses the HF state_dict names of MistralModel (``embed_tokens.weight``,
@@ -174,7 +204,7 @@ def mistral_encode(weights: dict, cfg: dict, input_ids: np.ndarray, attention_ma
         v = v.reshape(B, S, nkv, d).transpose(0, 2, 1, 3)
         q = rnd(apply_rope(q, cos, sin)); k = rnd(apply_rope(k, cos, sin))             # :666-668
         kv_layers.append((k.copy(), v.copy()))                                         # what use_cache=True hands back (:671-673)
-        a = rnd(attention_bidirectional(q, k, v, attention_mask, acc_dtype, causal))              # :690-698
+        a = rnd(attention_bidirectional(q, k, v, attention_mask, acc_dtype, causal, window))      # :690-698
         a = rnd(a @ weights[p + "self_attn.o_proj.weight"].T)                          # :703
         h = rnd(res + a)                                                               # :769
         res = h
@@ -470,7 +500,7 @@ def swiglu_backward(g, u, dact):
     return (d * u * s * (1.0 + g * (1.0 - s))).astype(F32), (d * g * s).astype(F32)
 
 
-def attention_bidirectional_backward(q, k, v, key_mask, dout, causal=False):
+def attention_bidirectional_backward(q, k, v, key_mask, dout, causal=False, window=0):
     """Backward of attention_bidirectional.  q [B,Hq,S,d], k,v [B,Hkv,S,d], dout [B,S,Hq*d]
     -> dq [B,Hq,S,d], dk, dv [B,Hkv,S,d] (GQA: kv gradients summed over the group)."""
     B, Hq, S, d = q.shape
@@ -479,13 +509,7 @@ def attention_bidirectional_backward(q, k, v, key_mask, dout, causal=False):
     q64 = q.astype(F64)
     kk = np.repeat(k, rep, axis=1).astype(F64); vv = np.repeat(v, rep, axis=1).astype(F64)
     scale = 1.0 / np.sqrt(d)
-    sc = np.matmul(q64, kk.transpose(0, 1, 3, 2)) * scale
-    if key_mask is not None:
-        sc = sc + np.where(key_mask.astype(bool), 0.0, -np.inf)[:, None, None, :]
-    if causal:
-        sc = sc + np.where(np.tril(np.ones((S, S), dtype=bool)), 0.0, -np.inf)[None, None]
-    sc = sc - sc.max(-1, keepdims=True)
-    p = np.exp(sc); p /= p.sum(-1, keepdims=True)
+    p = masked_softmax(np.matmul(q64, kk.transpose(0, 1, 3, 2)) * scale, key_mask, causal, window)
     do = dout.astype(F64).reshape(B, S, Hq, d).transpose(0, 2, 1, 3)
     dv_full = np.matmul(p.transpose(0, 1, 3, 2), do)
     dp = np.matmul(do, vv.transpose(0, 1, 3, 2))

@@ -560,6 +560,46 @@ def gen_generative():
     np.savez_compressed(os.path.join(HERE, "generative_tiny.npz"), **res)
 
 
+@torch.no_grad()
+def gen_sliding_window(cfg_name="gqa", window=16, batch=3, seq=200, min_len=90, seed_w=0, seed_x=2468):
+    """Causal attention with Mistral's sliding window on the reference: MistralModel(is_causal=True) with config.sliding_window = 16 on
+    sequences far longer than the window, through the reference's EAGER attention path (the one that hands `sliding_window` to
+    `_prepare_4d_causal_attention_mask`, scripts/modeling_mistral_gritlm.py:1022-1031; under the transformers installed here its sdpa
+    branch, :1011-1016, passes no window at all).  The mask itself comes from the installed transformers, so the fixture records HOW MANY
+    keys a query saw (`window_keys`: sliding_window under the pinned 4.37.2, sliding_window + 1 under later releases) -- found by
+    matching the hidden states against both candidates -- together with the transformers version of the generating run."""
+    import transformers
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gritlm_oracle as O
+    cfg = dict(synth.CONFIGS[cfg_name])
+    hc = synth.hf_config(cfg)
+    hc.use_cache = False
+    hc.sliding_window = window
+    hc._attn_implementation = "eager"
+    model = REFMOD.MistralModel(hc).eval()
+    w = synth.make_weights(cfg, seed_w)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    ids, mask = synth.make_batch(cfg, batch, seq, seed_x, min_len)
+    tid, tmask = torch.from_numpy(ids), torch.from_numpy(mask)
+    h = model(input_ids=tid, attention_mask=tmask, is_causal=True)[0]
+    hc.sliding_window = None
+    h_full = model(input_ids=tid, attention_mask=tmask, is_causal=True)[0]
+    assert (h - h_full).abs().max() > 1e-3, "sliding_window is dead in the reference's eager path"
+    keep = mask.astype(bool)
+    errs = {}
+    for keys in (window, window + 1):
+        ho = O.mistral_encode(w, cfg, ids, mask, causal=True, window=keys)
+        errs[keys] = float(np.abs(ho - h.numpy())[keep].max())
+    keys = min(errs, key=errs.get)
+    print(f"  sliding window {window}: max |oracle - reference| with {window} keys {errs[window]:.2e}, with {window + 1} keys {errs[window + 1]:.2e}"
+          f" -> the reference under transformers {transformers.__version__} keeps {keys}")
+    assert errs[keys] < 1e-4 and errs[2 * window + 1 - keys] > 1e-3, errs
+    np.savez_compressed(os.path.join(HERE, f"sliding_window_{cfg_name}.npz"), cfg_name=cfg_name, seed_w=seed_w, input_ids=ids,
+                        attention_mask=mask, sliding_window=window, window_keys=keys, transformers_version=transformers.__version__,
+                        last_hidden_state=h.numpy())
+
+
 def gen_gritlm_encode():
     """The reference's own GritLM(...).encode() end to end on CPU (tokenise -> forward -> pool -> normalise):
     (a) BASELINE.json configs[0] plumbing case: GPT-Neo, weightedmean, attn=None, 32 docs @ max_length 128;
@@ -597,6 +637,8 @@ def gen_gritlm_encode():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["sliding-window"]:
+        gen_sliding_window(); sys.exit(0)
     if sys.argv[1:] == ["generative"]:
         gen_generative(); sys.exit(0)
     if sys.argv[1:] == ["7b-l1"]:            # only the 7B-layer-shape fixtures (1.4 GB of fp32 weights, ~2 min on 8 cores)
@@ -620,6 +662,7 @@ if __name__ == "__main__":
     print("gradcache"); gen_gradcache()
     print("gritlm encode"); gen_gritlm_encode()
     print("generative"); gen_generative()
+    print("sliding window"); gen_sliding_window()
     print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
     print("encoder 7b-l1"); gen_encoder_7b_l1()
     print("train 7b-l1"); gen_train_7b_l1()

@@ -158,7 +158,7 @@ def check_mask_pack():
     return _res("mask_pack", ok)
 
 
-def check_attention(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=11, causal=False):
+def check_attention(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=11, causal=False, window=0):
     d = 128
     width = (nq + 2 * nkv) * d
     qkv = rnd((B * S, width), seed)
@@ -179,24 +179,27 @@ def check_attention(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=11, causal
             mask[1, 37:] = 0
     x = qkv.reshape(B, S, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
     q, k, v = x[:, :nq], x[:, nq:nq + nkv], x[:, nq + nkv:]
-    ref = O.attention_bidirectional(q, k, v, mask, causal=causal)
+    ref = O.attention_bidirectional(q, k, v, mask, causal=causal, window=window)
     lse_t = torch.empty((B, nq, S), dtype=torch.float32, device=DEV)
     bits = ops.mask_pack(torch.from_numpy(mask).to(DEV))
-    out = f32(ops.attn_bidir(bf(qkv), bits, B, S, nq, nkv, d, lse=lse_t, causal=causal)).reshape(B, S, nq * d)
+    out = f32(ops.attn_bidir(bf(qkv), bits, B, S, nq, nkv, d, lse=lse_t, causal=causal, window=window)).reshape(B, S, nq * d)
     # reference lse
     kk = np.repeat(k, nq // nkv, axis=1)
     sc = np.einsum("bhqd,bhkd->bhqk", q.astype(np.float64), kk.astype(np.float64)) / np.sqrt(d)
-    sc = sc + np.where(mask.astype(bool), 0.0, -np.inf)[:, None, None, :]
+    allowed = np.broadcast_to(mask.astype(bool)[:, None, None, :], sc.shape)
     if causal:
-        sc = sc + np.where(np.tril(np.ones((S, S), dtype=bool)), 0.0, -np.inf)[None, None]
-    mx = sc.max(-1, keepdims=True)
-    lse_ref = (mx[..., 0] + np.log(np.exp(sc - mx).sum(-1)))
+        allowed = allowed & O.causal_window_mask(S, window)[None, None]
+    sc = np.where(allowed, sc, -np.inf)
+    sees = allowed.any(-1)                      # a padding query behind a sliding window sees no key at all: output 0, lse -inf
+    mx = np.where(sees, sc.max(-1), 0.0)[..., None]
+    with np.errstate(divide="ignore"):
+        lse_ref = (mx[..., 0] + np.log(np.exp(sc - mx).sum(-1)))
     err = float(np.max(np.abs(out - ref)))
-    lerr = float(np.max(np.abs(f32(lse_t) - lse_ref)))
-    ok = err < 2e-2 and lerr < 2e-3 and not np.isnan(out).any()
+    lerr = float(np.max(np.abs(f32(lse_t) - lse_ref)[sees]))
+    ok = err < 2e-2 and lerr < 2e-3 and not np.isnan(out).any() and bool(np.all(np.isneginf(f32(lse_t)[~sees])))
     if not ok:
         _dump(f"attn_{mask_kind}_{S}", qkv=qkv, mask=mask, out=out, ref=ref, lse=f32(lse_t), lse_ref=lse_ref.astype(np.float32))
-    return _res(f"attention[B={B},S={S},nq={nq},nkv={nkv},{mask_kind},causal={int(causal)}]", ok, max_abs=err, lse_abs=lerr)
+    return _res(f"attention[B={B},S={S},nq={nq},nkv={nkv},{mask_kind},causal={int(causal)},window={window}]", ok, max_abs=err, lse_abs=lerr)
 
 
 # ---------------------------------------------------------------------------------------------  the forward's multi-block ("seam") path
@@ -459,7 +462,7 @@ def check_swiglu(T=37, I=512):
     return _res("swiglu fwd/bwd (concat layout)", e < 1.0, err_over_tol=e)
 
 
-def check_attention_bwd(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=41, causal=False):
+def check_attention_bwd(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=41, causal=False, window=0):
     d = 128
     width = (nq + 2 * nkv) * d
     qkv = rnd((B * S, width), seed, 0.7)
@@ -473,12 +476,12 @@ def check_attention_bwd(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=41, ca
         mask = (rng.random((B, S)) < 0.7).astype(np.int64); mask[:, 0] = 1
     x = qkv.reshape(B, S, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
     q, k, v = x[:, :nq], x[:, nq:nq + nkv], x[:, nq + nkv:]
-    dq, dk, dv = O.attention_bidirectional_backward(q, k, v, mask, dout.reshape(B, S, nq * d), causal=causal)
+    dq, dk, dv = O.attention_bidirectional_backward(q, k, v, mask, dout.reshape(B, S, nq * d), causal=causal, window=window)
     ref = np.concatenate([dq, dk, dv], axis=1).transpose(0, 2, 1, 3).reshape(B * S, width)
     tq, bits = bf(qkv), ops.mask_pack(torch.from_numpy(mask).to(DEV))
     lse = torch.empty((B, nq, S), dtype=torch.float32, device=DEV)
-    out = ops.attn_bidir(tq, bits, B, S, nq, nkv, d, lse=lse, causal=causal)
-    got = f32(ops.attn_bidir_bwd(tq, bits, out, bf(dout), lse, B, S, nq, nkv, d, causal=causal))
+    out = ops.attn_bidir(tq, bits, B, S, nq, nkv, d, lse=lse, causal=causal, window=window)
+    got = f32(ops.attn_bidir_bwd(tq, bits, out, bf(dout), lse, B, S, nq, nkv, d, causal=causal, window=window))
     errs = {}
     ok = not np.isnan(got).any()
     for name, sl in (("dq", slice(0, nq * d)), ("dk", slice(nq * d, (nq + nkv) * d)), ("dv", slice((nq + nkv) * d, width))):
@@ -491,10 +494,10 @@ def check_attention_bwd(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=41, ca
         ok &= e < 1.0 and rowrel < 1e-2
     if not ok:
         _dump(f"attn_bwd_{mask_kind}_{S}", qkv=qkv, mask=mask, dout=dout, got=got, ref=ref)
-    return _res(f"attention_bwd[B={B},S={S},nq={nq},nkv={nkv},{mask_kind},causal={int(causal)}]", ok, **errs)
+    return _res(f"attention_bwd[B={B},S={S},nq={nq},nkv={nkv},{mask_kind},causal={int(causal)},window={window}]", ok, **errs)
 
 
-def check_attention_bwd_varlen(lens=(200, 71, 128, 1, 300), nq=4, nkv=2, seed=47, causal=False):
+def check_attention_bwd_varlen(lens=(200, 71, 128, 1, 300), nq=4, nkv=2, seed=47, causal=False, window=0):
     """Packed attention backward vs (1) the oracle per sequence and (2) the padded kernel on the same rows (bit-identical:
     padded query rows / masked keys only ever add exact zeros)."""
     d = 128
@@ -506,8 +509,8 @@ def check_attention_bwd_varlen(lens=(200, 71, 128, 1, 300), nq=4, nkv=2, seed=47
     tcu = torch.from_numpy(cu).to(DEV)
     tq, tdo = bf(qkv), bf(dout)
     lse = torch.empty((T, nq), dtype=torch.float32, device=DEV)
-    out = ops.attn_bidir_varlen(tq, tcu, S, nq, nkv, d, lse=lse, causal=causal)
-    got = f32(ops.attn_bidir_varlen_bwd(tq, tcu, S, out, tdo, lse, nq, nkv, d, causal=causal))
+    out = ops.attn_bidir_varlen(tq, tcu, S, nq, nkv, d, lse=lse, causal=causal, window=window)
+    got = f32(ops.attn_bidir_varlen_bwd(tq, tcu, S, out, tdo, lse, nq, nkv, d, causal=causal, window=window))
     # padded twin
     mask = np.zeros((B, S), dtype=np.int64)
     pq = np.zeros((B, S, width), dtype=np.float32); pdo = np.zeros((B, S, nq * d), dtype=np.float32)
@@ -516,8 +519,9 @@ def check_attention_bwd_varlen(lens=(200, 71, 128, 1, 300), nq=4, nkv=2, seed=47
         pq[b, :L] = f32(tq)[cu[b]:cu[b + 1]]; pdo[b, :L] = f32(tdo)[cu[b]:cu[b + 1]]
     tpq, bits = bf(pq.reshape(B * S, width)), ops.mask_pack(torch.from_numpy(mask).to(DEV))
     plse = torch.empty((B, nq, S), dtype=torch.float32, device=DEV)
-    pout = ops.attn_bidir(tpq, bits, B, S, nq, nkv, d, lse=plse, causal=causal)
-    pgot = f32(ops.attn_bidir_bwd(tpq, bits, pout, bf(pdo.reshape(B * S, nq * d)), plse, B, S, nq, nkv, d, causal=causal)).reshape(B, S, width)
+    pout = ops.attn_bidir(tpq, bits, B, S, nq, nkv, d, lse=plse, causal=causal, window=window)
+    pgot = f32(ops.attn_bidir_bwd(tpq, bits, pout, bf(pdo.reshape(B * S, nq * d)), plse, B, S, nq, nkv, d, causal=causal,
+                                  window=window)).reshape(B, S, width)
     ok = not np.isnan(got).any()
     same = all(np.array_equal(got[cu[b]:cu[b + 1]], pgot[b, :L]) for b, L in enumerate(lens))
     same_fwd = all(np.array_equal(f32(out)[cu[b]:cu[b + 1]], f32(pout).reshape(B, S, -1)[b, :L]) for b, L in enumerate(lens))
@@ -525,12 +529,12 @@ def check_attention_bwd_varlen(lens=(200, 71, 128, 1, 300), nq=4, nkv=2, seed=47
     for b, L in enumerate(lens):
         x = f32(tq)[cu[b]:cu[b + 1]].reshape(1, L, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
         dq, dk, dv = O.attention_bidirectional_backward(x[:, :nq], x[:, nq:nq + nkv], x[:, nq + nkv:], np.ones((1, L), dtype=np.int64),
-                                                        f32(tdo)[cu[b]:cu[b + 1]].reshape(1, L, nq * d), causal=causal)
+                                                        f32(tdo)[cu[b]:cu[b + 1]].reshape(1, L, nq * d), causal=causal, window=window)
         ref = np.concatenate([dq, dk, dv], axis=1).transpose(0, 2, 1, 3).reshape(L, width)
         rms = float(np.sqrt(np.mean(ref ** 2)))
         worst = max(worst, float(np.max(np.abs(got[cu[b]:cu[b + 1]] - ref) / (2.0 ** -7 * np.abs(ref) + 6e-2 * rms + 1e-12))))
     ok &= same and same_fwd and worst < 1.0
-    return _res(f"attention_bwd varlen [lens={list(lens)},causal={int(causal)}]", ok, identical_to_padded=bool(same), fwd_identical=bool(same_fwd),
+    return _res(f"attention_bwd varlen [lens={list(lens)},causal={int(causal)},window={window}]", ok, identical_to_padded=bool(same), fwd_identical=bool(same_fwd),
                 maxerr_over_tol_vs_oracle=worst)
 
 
@@ -1859,6 +1863,66 @@ def check_causal_encode(cfg_name="gqa", B=4, S=150):
     return _res(f"causal ('cc') embedding encode [{cfg_name}] vs oracle", bool(ok), **out)
 
 
+def check_sliding_window_encode():
+    """Causal attention with Mistral's sliding window, engine vs the REFERENCE's eager path (tests/golden/sliding_window_gqa.npz: window 16
+    on sequences of up to 200 tokens; the fixture records how many keys a query saw in the generating run) -- padded and packed."""
+    g = np.load(os.path.join(GOLDEN, "sliding_window_gqa.npz"))
+    eng, cfg, w = build_engine(str(g["cfg_name"]), int(g["seed_w"]))
+    eng.causal, eng.window_keys = True, int(g["window_keys"])
+    ids, mask = g["input_ids"], g["attention_mask"]
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    valid = mask.astype(bool)
+    ref = g["last_hidden_state"]
+    rel = lambda a: float(np.linalg.norm((a - ref)[valid]) / np.linalg.norm(ref[valid]))
+    h_pad = f32(eng.forward(tid, tm))
+    eng.window_keys = 0
+    h_full = f32(eng.forward(tid, tm))
+    eng.window_keys = int(g["window_keys"])
+    a = f32(eng.encode_pooled(tid, tm, "mean", True, packed=False))
+    b = f32(eng.encode_pooled(tid, tm, "mean", True, packed=True))
+    emb_ref = O.l2_normalize(O.pooling(ref, mask, "mean"))
+    cos = float(np.max(1 - np.sum(b * emb_ref, axis=1)))
+    out = dict(rel_l2_vs_reference=rel(h_pad), rel_l2_without_window=rel(h_full), pooled_1_minus_cos=cos, window_keys=int(g["window_keys"]))
+    ok = rel(h_pad) < 2e-2 and rel(h_full) > 10 * rel(h_pad) and np.array_equal(a, b) and cos < 1e-4
+    return _res("sliding-window causal encode vs reference (eager path)", bool(ok), **out)
+
+
+def check_generative_window(window=9):
+    """The generative branch under a sliding window (train engine: causal attention fwd + bwd with ``window_keys``): loss vs the oracle
+    with the same window, packed == padded, and it differs from the loss without a window."""
+    import tempfile
+    from gritlm_amd.training import GritLMTrainModel
+    g = np.load(os.path.join(GOLDEN, "generative_tiny.npz"))
+    cfg = synth.CONFIGS["tiny"]
+    w = synth.make_weights(cfg, 0)
+    h = O.mistral_encode(w, cfg, g["input_ids"], g["attention_mask"], causal=True, window=window)
+    ref_loss = O.next_token_loss(h @ g["lm_head"].T, g["labels"], "mixed", float(g["factor_mixed"]))
+    out, ok, grads = dict(loss_oracle=ref_loss, loss_no_window_reference=float(g["loss_gen_mixed"])), True, {}
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        m = GritLMTrainModel(model_name_or_path=d16, mode="unified", pooling_method="mean", normalized=True, attn="bbcc", temperature=0.02,
+                             negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16, loss_gen_type="mixed",
+                             loss_gen_factor=float(g["factor_mixed"]))
+        m.enable_native()
+        m.train_engine.window_keys = window
+        for packed in (True, False):
+            m.native_packed = packed
+            m.model.zero_grad(set_to_none=True)
+            gen = {"input_ids": torch.from_numpy(g["input_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["attention_mask"]).to(DEV),
+                   "labels": torch.from_numpy(g["labels"]).to(DEV)}
+            o = m(generative=gen)
+            o.loss_gen.backward()
+            tag = "packed" if packed else "padded"
+            out[f"loss_{tag}"] = float(o.loss_gen.item())
+            ok &= abs(out[f"loss_{tag}"] - ref_loss) < 1e-2 * max(1.0, abs(ref_loss))
+            grads[tag] = {n: p.grad.detach().float().clone() for n, p in m.model.named_parameters() if p.grad is not None}
+        worst = max(float((grads["packed"][n] - grads["padded"][n]).norm() / (grads["padded"][n].norm() + 1e-20)) for n in grads["padded"])
+        out["worst_grad_rel_packed_vs_padded"] = worst
+        ok &= worst < 1e-2 and abs(ref_loss - float(g["loss_gen_mixed"])) > 1e-3
+        ok &= all(bool(torch.isfinite(t).all()) for t in grads["packed"].values())
+    return _res(f"generative step under a sliding window of {window} keys", bool(ok), **out)
+
+
 def check_edge_cases():
     """Empty / minimal / degenerate inputs the host can hand over (reference behaviour noted per case)."""
     ok, notes = True, {}
@@ -2109,6 +2173,19 @@ ALL_CHECKS = [
     ("attn_bwd_causal_full", check_attention_bwd, dict(mask_kind="none", S=256, B=1, nq=8, nkv=2, causal=True)),
     ("attn_bwd_causal_330", check_attention_bwd, dict(mask_kind="ragged", S=330, B=2, nq=2, nkv=1, causal=True)),
     ("attn_bwd_varlen_causal", check_attention_bwd_varlen, dict(causal=True)),
+    ("attn_window_16", check_attention, dict(mask_kind="ragged", causal=True, window=16)),
+    ("attn_window_1", check_attention, dict(B=1, S=130, nq=2, nkv=1, mask_kind="none", causal=True, window=1)),
+    ("attn_window_64_513", check_attention, dict(B=3, S=513, nq=4, nkv=2, mask_kind="ragged", seed=26, causal=True, window=64)),
+    ("attn_window_100_holes", check_attention, dict(B=2, S=330, nq=2, nkv=1, mask_kind="holes", seed=22, causal=True, window=100)),
+    ("attn_window_129_1024", check_attention, dict(B=1, S=1024, nq=2, nkv=1, mask_kind="none", seed=25, causal=True, window=129)),
+    ("attn_window_300_short_rows", check_attention, dict(B=2, S=512, nq=8, nkv=2, mask_kind="short_rows", seed=27, causal=True, window=300)),
+    ("attn_window_ge_S", check_attention, dict(mask_kind="ragged", causal=True, window=200)),
+    ("attn_bwd_window_16", check_attention_bwd, dict(causal=True, window=16)),
+    ("attn_bwd_window_2", check_attention_bwd, dict(mask_kind="none", S=130, B=1, nq=2, nkv=1, causal=True, window=2)),   # (window 1: p = 1, dq = dk = 0 exactly)
+    ("attn_bwd_window_100_330", check_attention_bwd, dict(mask_kind="ragged", S=330, B=2, nq=2, nkv=1, causal=True, window=100)),
+    ("attn_bwd_window_129_holes", check_attention_bwd, dict(mask_kind="holes", S=400, B=2, nq=2, nkv=1, causal=True, window=129)),
+    ("attn_bwd_varlen_window_64", check_attention_bwd_varlen, dict(lens=(385, 33, 512, 7), nq=4, nkv=2, causal=True, window=64)),
+    ("attn_bwd_varlen_window_200", check_attention_bwd_varlen, dict(lens=(200, 71, 128, 1, 300, 513, 64, 40), nq=4, nkv=2, causal=True, window=200)),
     ("attn_bwd_varlen", check_attention_bwd_varlen, {}),
     ("attn_bwd_varlen_gqa4", check_attention_bwd_varlen, dict(lens=(129, 64, 257), nq=8, nkv=2)),
     ("pool_bwd_varlen_mean", check_pool_bwd_varlen, dict(method="mean")),
@@ -2133,6 +2210,8 @@ ALL_CHECKS = [
     ("mixtral_tiny", check_mixtral_golden, dict(cfg_name="moe-tiny")),
     ("mixtral_gqa", check_mixtral_golden, dict(cfg_name="moe-gqa")),
     ("causal_encode", check_causal_encode, {}),
+    ("sliding_window_encode", check_sliding_window_encode, {}),
+    ("generative_window", check_generative_window, {}),
     ("edge_cases", check_edge_cases, {}),
     ("long_sequence_4096", check_long_sequence, {}),
     ("full_shape_properties", check_full_shape_properties, {}),

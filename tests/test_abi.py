@@ -43,6 +43,9 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert pair(epi=1) == _lib.GRIT_E_BADARG and b"residual" in lib.grit_last_error_string()                          # RESIDUAL without R
     assert pair(epi=2) == _lib.GRIT_E_BADARG and b"not available" in lib.grit_last_error_string()                     # SWIGLU pairs: no
     assert lib.grit_attn_bidir_fwd(p16, p16, p16, None, 1, 8, 2, 1, 64, 256, 128, 0.1, None) == _lib.GRIT_E_UNSUPPORTED  # head_dim
+    assert lib.grit_attn_causal_window_fwd(p16, p16, p16, None, 1, 8, 2, 1, 128, 512, 256, 0.1, 0, None) == _lib.GRIT_E_BADARG   # window < 1
+    assert b"window" in lib.grit_last_error_string()
+    assert lib.grit_attn_causal_window_varlen_bwd(p16, p16, p16, p16, p16, p16, p16, 1, 8, 8, 2, 1, 128, 512, 256, 0.1, -3, None) == _lib.GRIT_E_BADARG
     assert lib.grit_pool_norm_fwd(p16, p16, None, p16, None, 1, 8, 64, 9, 1, None) == _lib.GRIT_E_BADARG             # pooling mode
     assert lib.grit_infonce_rows_fwd_bwd(p16, p16, 50.0, p16, p16, p16, None, None, 3, 7, 8, 0, 3, 0, 7, None) == _lib.GRIT_E_BADARG  # Np % Nq
     with pytest.raises(_lib.GritHipError):

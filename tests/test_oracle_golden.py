@@ -191,6 +191,35 @@ def test_generative_branch_matches_reference(golden_dir):
         assert abs(got - float(g[f"loss_gen_{kind}"])) < 2e-4 * max(1.0, abs(got)), (kind, got, float(g[f"loss_gen_{kind}"]))
 
 
+def test_sliding_window_causal_encode_matches_reference(golden_dir):
+    """Causal attention under Mistral's sliding window: the oracle's window mask vs the reference's eager path (window 16, sequences of up
+    to 200 tokens).  The fixture records how many keys a query saw in the generating run (the mask comes from transformers, and its
+    releases differ by one key: oracle/gritlm_oracle.py::causal_window_mask)."""
+    g = _load(golden_dir, "sliding_window_gqa.npz")
+    cfg = synth.CONFIGS[str(g["cfg_name"])]
+    w = synth.make_weights(cfg, int(g["seed_w"]))
+    W, keys = int(g["sliding_window"]), int(g["window_keys"])
+    assert keys in (W, W + 1)
+    valid = g["attention_mask"].astype(bool)
+    h = O.mistral_encode(w, cfg, g["input_ids"], g["attention_mask"], causal=True, window=keys)
+    assert np.abs(h - g["last_hidden_state"])[valid].max() < 1e-4
+    other = O.mistral_encode(w, cfg, g["input_ids"], g["attention_mask"], causal=True, window=2 * W + 1 - keys)
+    assert np.abs(other - g["last_hidden_state"])[valid].max() > 1e-2          # one key more or less is far outside the tolerance
+    m = O.causal_window_mask(6, 3)
+    assert m.sum(axis=1).tolist() == [1, 2, 3, 3, 3, 3] and bool(m[5, 3]) and not bool(m[5, 2]) and not bool(m[2, 3])
+    assert np.array_equal(O.causal_window_mask(5, 0), np.tril(np.ones((5, 5), dtype=bool)))
+
+
+def test_sliding_window_keys_per_attention_path():
+    """Which window the engines use, per attention path of the reference (gritlm_amd/encoder.py::sliding_window_keys)."""
+    from gritlm_amd.encoder import sliding_window_keys
+    assert sliding_window_keys(None, "eager") == 0 and sliding_window_keys(4096, None) == 0
+    assert sliding_window_keys(4096, "sdpa") == 0                 # the reference's sdpa branch passes no window: full causal attention
+    assert sliding_window_keys(4096, "eager") == 4096 and sliding_window_keys(4096, "flash_attention_2") == 4097
+    with pytest.raises(ValueError):
+        sliding_window_keys(4096, "flex")
+
+
 def test_prefix_continuation_consistent_with_pinned_causal_encode(golden_dir):
     """mistral_continue (generation on top of cached K/V) == the causal encode pinned by generative_tiny.npz when the prefix K/V
     come from a causal pass; a bidirectional (document) prefix gives different logits."""
