@@ -174,6 +174,7 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
     alg_flops_per_pair = 3.0 * eng_flops * SEQ * (1 + group)          # fwd + bwd = 3 x forward; recompute passes are overhead
     return {"metric": "contrastive pairs/sec @ seq512", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
+            "gradcache_pass1_rows_per_call": gc.pass1_chunk_size,      # pass 1 keeps nothing: several chunks per call, same bits
             "global_batch": world * pairs, "loss": float(loss), "peak_hbm_gib": peak_gb,
             "includes": "GradCache pass 1 + rep all-gather + InfoNCE + pass 2 fwd/bwd + grad all-reduce + AdamW",
             "config": f"BASELINE configs[2]: {pairs} (q, pos, 7 neg) per GPU @ seq512, chunk {chunk}, tau 0.02, mean pooling, cross-device negatives"

@@ -159,10 +159,28 @@ class _Span:
         return False
 
 
+def pass1_chunk_rows(model, chunk_size: int) -> int:
+    """Rows per model call in PASS 1.  The reference uses ``chunk_size`` for both passes because the chunk is a memory knob of
+    the activation-keeping pass 2.  Pass 1 keeps nothing, and on the native engine a row's representation does not depend on
+    which rows share its launch (every kernel is batch-invariant: ``packed_encode*`` / ``train_packed_vs_padded`` compare
+    bit for bit), so pass 1 may run ``GRIT_GRADCACHE_PASS1_MULT`` (default 4) chunks per call: the same bits from 4x fewer,
+    4x larger launches (GEMMs at M = 65536 instead of 16384 for 32 x 512-token chunks, 18 instead of 72 gathers at
+    BASELINE configs[2]).  The Hugging Face path keeps the reference's behaviour (CPU BLAS is not batch-invariant)."""
+    eng = getattr(model, "train_engine", None)
+    if eng is None or getattr(model, "projection", None) is not None:
+        return int(chunk_size)
+    try:
+        mult = int(os.environ.get("GRIT_GRADCACHE_PASS1_MULT", "4"))
+    except ValueError:
+        mult = 4
+    return int(chunk_size) * max(1, mult)
+
+
 class GradCacheStep:
-    def __init__(self, model, chunk_size: int):
+    def __init__(self, model, chunk_size: int, pass1_chunk_size: "int | None" = None):
         self.model = model
         self.chunk_size = int(chunk_size)
+        self.pass1_chunk_size = int(pass1_chunk_size) if pass1_chunk_size else pass1_chunk_rows(model, self.chunk_size)
         self.profile = None        # set to a dict to collect per-step timings (ms): loss (similarity GEMM + CE + rep grads), the
                                    # stream time blocked on the rep gather (exposed, non-overlapped part) and on the gradient all-reduce
 
@@ -175,27 +193,21 @@ class GradCacheStep:
             self.profile.update(out)
         return dict(self.profile or {})
 
-    @torch.no_grad()
-    def _reps_no_grad(self, chunks, gather: "ChunkGather | None" = None):
-        out = []
-        for c in chunks:
-            r = self.model.encode(c)
-            if gather is not None:
-                gather.add(r)
-            out.append(r)
-        return torch.cat(out, dim=0)
-
     def __call__(self, query: Dict, passage: Dict, sync: bool = True) -> torch.Tensor:
         model = self.model
         q_chunks, p_chunks = split_inputs(query, self.chunk_size), split_inputs(passage, self.chunk_size)
         loss_fn = model.emb_loss_fn
         cross = bool(getattr(loss_fn, "negatives_cross_device", False))
         nq = sum(_rows(c) for c in q_chunks); npas = sum(_rows(c) for c in p_chunks)
-        # pass 1 (the cross-rank exchange rides along, chunk by chunk)
+        # pass 1 (the cross-rank exchange rides along, chunk by chunk); its calls may span several pass-2 chunks (pass1_chunk_rows)
+        if self.pass1_chunk_size != self.chunk_size:
+            q1_chunks, p1_chunks = split_inputs(query, self.pass1_chunk_size), split_inputs(passage, self.pass1_chunk_size)
+        else:
+            q1_chunks, p1_chunks = q_chunks, p_chunks
         gq = gp = None
         q_list, p_list = [], []
         with torch.no_grad():
-            for chunks, lst, which in ((q_chunks, q_list, "q"), (p_chunks, p_list, "p")):
+            for chunks, lst, which in ((q1_chunks, q_list, "q"), (p1_chunks, p_list, "p")):
                 for c in chunks:
                     r = model.encode(c)
                     if cross:

@@ -952,8 +952,13 @@ def check_train_step(mode="direct"):
             loss = GradCacheStep(m, chunk_size=2)(q, p)
             m.train_engine.forward_pooled = orig_fp
             n_chunks = (g["q_ids"].shape[0] + 1) // 2 + (g["p_ids"].shape[0] + 1) // 2
-            out["pass1_saves"] = sum(saves[:n_chunks]); out["pass2_saves"] = sum(saves[n_chunks:])
-            ok &= len(saves) == 2 * n_chunks and out["pass1_saves"] == 0 and out["pass2_saves"] == n_chunks
+            # pass 1 runs several chunks per call (gradcache.pass1_chunk_rows: default 4 x the chunk)
+            from gritlm_amd.training.gradcache import pass1_chunk_rows
+            p1 = pass1_chunk_rows(m, 2)
+            n_calls1 = -(-g["q_ids"].shape[0] // p1) + -(-g["p_ids"].shape[0] // p1)
+            out["pass1_calls"] = n_calls1
+            out["pass1_saves"] = sum(saves[:n_calls1]); out["pass2_saves"] = sum(saves[n_calls1:])
+            ok &= len(saves) == n_calls1 + n_chunks and out["pass1_saves"] == 0 and out["pass2_saves"] == n_chunks
         key = "direct" if mode == "direct" else "gradcache"
         ref_loss, ref_loss16 = float(g[f"loss_{key}"]), float(g[f"loss_{key}_bf16"])
         out["loss"] = float(loss.item()); out["loss_ref"] = ref_loss; out["loss_ref_bf16"] = ref_loss16
@@ -1308,6 +1313,45 @@ def check_train_packed_vs_padded(cfg_name="gqa"):
     ok &= emb_same
     ok &= res[True][4]._tbuf and all(k[1] > 0 for k in res[True][4]._tbuf)
     return _res(f"packed training step == padded training step [{cfg_name}]", bool(ok), **out)
+
+
+def check_gradcache_pass1_superchunks(cfg_name="gqa"):
+    """GradCache pass 1 in calls of 4 chunks (gradcache.pass1_chunk_rows) against pass 1 chunk by chunk: the kernels are
+    batch-invariant, so the loss and EVERY parameter gradient must come out with the same bits."""
+    from gritlm_amd.training import GradCacheStep
+    from gritlm_amd.training.engine import MistralTrainEngine, SyntheticBackbone
+    from gritlm_amd.training.model import DistributedContrastiveLoss, GritLMTrainModel
+    cfg = EncoderConfig.from_dict(synth.CONFIGS[cfg_name])
+    idq, mq = synth.make_batch(synth.CONFIGS[cfg_name], 6, 48, seed=15, min_len=9)
+    idp, mp_ = synth.make_batch(synth.CONFIGS[cfg_name], 18, 150, seed=16, min_len=20)
+    q = {"input_ids": torch.from_numpy(idq).to(DEV), "attention_mask": torch.from_numpy(mq).to(DEV), "instruction_lens": [3, 0, 5, 2, 1, 0]}
+    p = {"input_ids": torch.from_numpy(idp).to(DEV), "attention_mask": torch.from_numpy(mp_).to(DEV)}
+    res, calls = {}, {}
+    for p1 in (2, 8, 5):                      # chunk by chunk / 4 chunks per call / a size that cuts across the pass-2 chunks
+        bb = SyntheticBackbone(cfg, DEV, seed=3)
+        m = GritLMTrainModel.__new__(GritLMTrainModel)
+        torch.nn.Module.__init__(m)
+        m.model, m.projection, m.pooling_method, m.normalized, m.attn, m.embedding_attr = bb, None, "mean", True, "bbcc", None
+        m.emb_loss_fn = DistributedContrastiveLoss(0.02, False)
+        m.train_engine = MistralTrainEngine(bb, cfg, DEV)
+        n = []
+        orig = m.train_engine.forward_pooled
+        def spy(*a, _o=orig, _n=n, **k):
+            _n.append(int(a[0].shape[0]))
+            return _o(*a, **k)
+        m.train_engine.forward_pooled = spy
+        gc = GradCacheStep(m, chunk_size=2, pass1_chunk_size=p1)
+        loss = gc(dict(q), dict(p), sync=False)
+        res[p1] = (float(loss.item()), {k_: f32(t.grad) for k_, t in bb.named_parameters()})
+        calls[p1] = n
+    ok = True
+    for p1 in (8, 5):
+        ok &= res[p1][0] == res[2][0] and all(np.array_equal(res[p1][1][k_], v) for k_, v in res[2][1].items())
+    ok &= len(calls[2]) == 2 * 12 and len(calls[8]) == 1 + 3 + 12 and max(calls[8][:4]) == 8 and max(calls[8][4:]) == 2
+    default_rows = GradCacheStep(m, chunk_size=2).pass1_chunk_size
+    ok &= default_rows == 8
+    return _res(f"GradCache pass 1 in super-chunks == chunk by chunk, bit for bit [{cfg_name}]", bool(ok), loss=res[2][0],
+                pass1_calls={k_: len(v) - 12 for k_, v in calls.items()})
 
 
 def check_swiglu_stacked(M=300, I=512, K=256):
@@ -2229,6 +2273,7 @@ ALL_CHECKS = [
     ("train_mixtral_recompute", check_train_step_mixtral, dict(mode="recompute")),
     ("generative_mixtral_aux", check_generative_mixtral, {}),
     ("train_packed_vs_padded", check_train_packed_vs_padded, {}),
+    ("gradcache_pass1_superchunks", check_gradcache_pass1_superchunks, {}),
     ("train_recompute", check_train_recompute, {}),
     ("swiglu_stacked", check_swiglu_stacked, {}),
     ("swiglu_train_epilogues", check_swiglu_fused_train_epilogues, {}),
