@@ -64,54 +64,72 @@ __global__ void __launch_bounds__(256) rmsnorm_bwd_k(const uint4* __restrict__ d
 // Fast path for H = NCH * 512 (every lane owns the same 8*NCH columns in every row): the row stays in registers between the two
 // sweeps and the weight gradient accumulates in registers; one LDS reduction per workgroup at the end instead of LDS atomics per row.
 template <int NCH>
-__global__ void __launch_bounds__(256) rmsnorm_bwd_reg_k(const uint4* __restrict__ dy, const uint4* __restrict__ x, const uint4* __restrict__ w,
+__global__ void __launch_bounds__(256, NCH >= 8 ? 2 : 1) rmsnorm_bwd_reg_k(const uint4* __restrict__ dy, const uint4* __restrict__ x, const uint4* __restrict__ w,
                                                          const uint4* dres, uint4* dx, float* __restrict__ dw_partial, int64_t T, int H,
                                                          float eps) {
   __shared__ float red[3][NCH * 512];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the weight row lives in LDS (8 KiB at H = 4096), not in 4 * NCH registers per lane: with x, dy, dres (all three requested up front,
+  // ONE memory round trip per row) and the 8 * NCH weight-gradient accumulators the H = 4096 instantiation then fits 256 registers =
+  // two waves per SIMD; the round-2 form (weights in registers, dres fetched after the row statistics) needed 339 = one wave per SIMD
+  // with two round trips per row and ran at 3.6 TB/s
+  __shared__ uint4 wsh[NCH * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform row pointers: scalar base + one per-lane offset register
   const int HC = H >> 3;
   float dwa[NCH][8];
-  uint4 wv[NCH];
+  for (int i = tid; i < NCH * 64; i += 256) wsh[i] = w[i];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    wv[c] = w[c * 64 + lane];
+  for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) dwa[c][e] = 0.f;
-  }
+  __syncthreads();
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T; row += (int64_t)gridDim.x * 4) {
-    uint4 xv[NCH], gv[NCH];
+    uint4 xv[NCH], gv[NCH], rv[NCH];
+    const uint4* xrow = x + row * HC;
+    const uint4* grow = dy + row * HC;
+    const uint4* rrow = dres != nullptr ? dres + row * HC : nullptr;
+    uint4* orow = dx + row * HC;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) { xv[c] = x[row * HC + c * 64 + lane]; gv[c] = dy[row * HC + c * 64 + lane]; }
+    for (int c = 0; c < NCH; ++c) { xv[c] = xrow[c * 64 + lane]; gv[c] = grow[c * 64 + lane]; }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) rv[c] = rrow != nullptr ? rrow[c * 64 + lane] : make_uint4(0, 0, 0, 0);
     float ss = 0.f, dot = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+      const uint4 wv = wsh[c * 64 + lane];
       const uint32_t xa[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w}, ga[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w},
-                     wa[4] = {wv[c].x, wv[c].y, wv[c].z, wv[c].w};
+                     wa[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float x0 = bflo(xa[e]), x1 = bfhi(xa[e]);
         ss += x0 * x0 + x1 * x1;
         dot += bflo(ga[e]) * bflo(wa[e]) * x0 + bfhi(ga[e]) * bfhi(wa[e]) * x1;
       }
+      if (NCH >= 8) __builtin_amdgcn_sched_barrier(0);          // one column block at a time: bounds the live fp32 temporaries
     }
     ss = wave_sum(ss); dot = wave_sum(dot);
     const float rs = rsqrtf(ss / (float)H + eps);
     const float k2 = rs * rs * rs * dot / (float)H;
+    // the packed rows are made opaque here: otherwise the fp32 unpackings of the first sweep (64 + 64 registers at H = 4096) are kept
+    // alive across the reduction for the second sweep and the kernel spills
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      asm volatile("" : "+v"(xv[c].x), "+v"(xv[c].y), "+v"(xv[c].z), "+v"(xv[c].w), "+v"(gv[c].x), "+v"(gv[c].y), "+v"(gv[c].z), "+v"(gv[c].w));
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      uint4 rv = make_uint4(0, 0, 0, 0);
-      if (dres != nullptr) rv = dres[row * HC + c * 64 + lane];
+      const uint4 wv = wsh[c * 64 + lane];
       const uint32_t xa[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w}, ga[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w},
-                     wa[4] = {wv[c].x, wv[c].y, wv[c].z, wv[c].w}, ra[4] = {rv.x, rv.y, rv.z, rv.w};
+                     wa[4] = {wv.x, wv.y, wv.z, wv.w}, ra[4] = {rv[c].x, rv[c].y, rv[c].z, rv[c].w};
       uint32_t o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float x0 = bflo(xa[e]), x1 = bfhi(xa[e]), g0 = bflo(ga[e]), g1 = bfhi(ga[e]);
-        o[e] = pack2bf(rs * g0 * bflo(wa[e]) - x0 * k2 + bflo(ra[e]), rs * g1 * bfhi(wa[e]) - x1 * k2 + bfhi(ra[e]));
+        o[e] = pack2bf_hw(rs * g0 * bflo(wa[e]) - x0 * k2 + bflo(ra[e]), rs * g1 * bfhi(wa[e]) - x1 * k2 + bfhi(ra[e]));
         dwa[c][2 * e] += g0 * x0 * rs;
         dwa[c][2 * e + 1] += g1 * x1 * rs;
       }
-      dx[row * HC + c * 64 + lane] = make_uint4(o[0], o[1], o[2], o[3]);
+      orow[c * 64 + lane] = make_uint4(o[0], o[1], o[2], o[3]);
+      if (NCH >= 8) __builtin_amdgcn_sched_barrier(0);
     }
   }
   // waves 1..3 park their partial sums in LDS, wave 0 adds them up and writes the workgroup's row of dw_partial
@@ -180,10 +198,11 @@ __global__ void __launch_bounds__(256) swiglu_bwd_k(const uint16_t* __restrict__
     uint32_t og[4], ou[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float g0 = bflo(ga[e]), g1 = bfhi(ga[e]), u0 = bflo(ua[e]), u1 = bfhi(ua[e]), d0 = bflo(da[e]), d1 = bfhi(da[e]);
-      const float s0 = sigmoid_f(g0), s1 = sigmoid_f(g1);
-      og[e] = pack2bf(d0 * u0 * s0 * (1.f + g0 * (1.f - s0)), d1 * u1 * s1 * (1.f + g1 * (1.f - s1)));
-      ou[e] = pack2bf(d0 * g0 * s0, d1 * g1 * s1);
+      float dg0, du0, dg1, du1;
+      swiglu_bwd_elem(bflo(da[e]), bflo(ga[e]), bflo(ua[e]), dg0, du0);
+      swiglu_bwd_elem(bfhi(da[e]), bfhi(ga[e]), bfhi(ua[e]), dg1, du1);
+      og[e] = pack2bf_hw(dg0, dg1);
+      ou[e] = pack2bf_hw(du0, du1);
     }
     *reinterpret_cast<uint4*>(dgu + t * 2 * I + c * 8) = make_uint4(og[0], og[1], og[2], og[3]);
     *reinterpret_cast<uint4*>(dgu + t * 2 * I + I + c * 8) = make_uint4(ou[0], ou[1], ou[2], ou[3]);

@@ -67,6 +67,23 @@ __device__ __forceinline__ float rope_hi(float x1, float x2, float c, float s) {
   return __builtin_fmaf(x2, c, t);
 }
 
+// SwiGLU backward of one element on bf16-rounded operands: d_gate = d * u * s * (1 + g (1 - s)), d_up = d * g * s, s = sigmoid(g).
+// ONE definition with a fixed contraction for the stand-alone kernel (backward.hip) and both GEMM epilogues (gemm_bf16.hip), which the
+// checks compare bit for bit.  The sigmoid's reciprocal is v_rcp_f32 (1 ulp) instead of the correctly rounded division (~10 VALU
+// instructions per element in an epilogue that handles 128 elements per lane and tile): 1 bf16 output in 1.7 million moves by one ulp,
+// the d_act GEMM gains 4-6 % (profiles/r03_gemm_ab_swiglu_bwd_epilogue.log; -DGRIT_SWIGLU_BWD_DIV restores the division for A/B builds).
+__device__ __forceinline__ void swiglu_bwd_elem(float d, float g, float u, float& d_gate, float& d_up) {
+#pragma clang fp contract(off)
+#ifdef GRIT_SWIGLU_BWD_DIV
+  const float s = 1.0f / (1.0f + __expf(-g));
+#else
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+#endif
+  const float t = g * (1.f - s);
+  d_gate = d * u * s * (1.f + t);
+  d_up = d * g * s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -105,6 +105,12 @@ __device__ __forceinline__ int wrow_of(int wc, int j) {
     GRIT_SEG_FENCE();                        \
   } while (0)
 
+// A/B builds only (tools/ubench): -DGRIT_SWIGLU_BWD_DIRECT keeps the direct (row-per-lane) epilogue for SWIGLU_BWD
+#ifdef GRIT_SWIGLU_BWD_DIRECT
+#define GRIT_SWB_DIRECT(EPI) ((EPI) == GRIT_EPI_SWIGLU_BWD)
+#else
+#define GRIT_SWB_DIRECT(EPI) false
+#endif
 #ifdef GRIT_GEMM_STAMP
 // debug build only (tools/ubench/gemm_stamp.cpp): shader-clock stamps of two waves (one per wave group) of a few workgroups at the
 // seams of the persistent tile loop
@@ -553,10 +559,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const uint32_t dd = pack2bf_hw(v[2 * e], v[2 * e + 1]);
-            const float d0 = bflo(dd), d1 = bfhi(dd), g0 = bflo(ga[e]), g1 = bfhi(ga[e]), u0 = bflo(ua[e]), u1 = bfhi(ua[e]);
-            const float s0 = 1.0f / (1.0f + __expf(-g0)), s1 = 1.0f / (1.0f + __expf(-g1));
-            og[e] = pack2bf(d0 * u0 * s0 * (1.f + g0 * (1.f - s0)), d1 * u1 * s1 * (1.f + g1 * (1.f - s1)));
-            ou[e] = pack2bf(d0 * g0 * s0, d1 * g1 * s1);
+            float dg0, du0, dg1, du1;
+            swiglu_bwd_elem(bflo(dd), bflo(ga[e]), bflo(ua[e]), dg0, du0);
+            swiglu_bwd_elem(bfhi(dd), bfhi(ga[e]), bfhi(ua[e]), dg1, du1);
+            og[e] = pack2bf_hw(dg0, dg1);
+            ou[e] = pack2bf_hw(du0, du1);
           }
           *reinterpret_cast<uint4*>(C + m * ldc + n) = make_uint4(og[0], og[1], og[2], og[3]);
           *reinterpret_cast<uint4*>(C + m * ldc + N + n) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
@@ -595,6 +602,23 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           const int64_t m = mbase + i * 16 + hh * 8 + tr;
           rpre[i][hh] = (m < M && ncol_t < N) ? *reinterpret_cast<const uint4*>(Rsd + m * ldr + ncol_t) : make_uint4(0, 0, 0, 0);
         }
+    }
+    // SWIGLU_BWD: the saved [gate | up] rows of a row block are fetched FOUR row blocks ahead into a ring of 4 x 2 x 2 16-byte registers
+    // (all 32 at once would be 128 VGPRs next to the 128 accumulators); after the turn a lane owns 8 consecutive columns of one row, so
+    // each of these loads -- and each of the two stores -- is a full 128-byte line per 8 lanes instead of 16 rows x 64 B per instruction
+    uint4 gpre[4][2], upre[4][2];
+    auto swb_fetch = [&](int i) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int64_t m = mbase + i * 16 + hh * 8 + tr;
+        const bool in = m < M && ncol_t < N;
+        gpre[i & 3][hh] = in ? *reinterpret_cast<const uint4*>(Rsd + m * ldr + ncol_t) : make_uint4(0, 0, 0, 0);
+        upre[i & 3][hh] = in ? *reinterpret_cast<const uint4*>(Rsd + m * ldr + N + ncol_t) : make_uint4(0, 0, 0, 0);
+      }
+    };
+    if constexpr (EPI == GRIT_EPI_SWIGLU_BWD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) swb_fetch(i);
     }
     bool rotate = false;
     int m0_mod = 0;
@@ -677,7 +701,29 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
             piece = make_uint4(pack2bf_hw(bflo(piece.x) + bflo(rv.x), bfhi(piece.x) + bfhi(rv.x)), pack2bf_hw(bflo(piece.y) + bflo(rv.y), bfhi(piece.y) + bfhi(rv.y)),
                                pack2bf_hw(bflo(piece.z) + bflo(rv.z), bfhi(piece.z) + bfhi(rv.z)), pack2bf_hw(bflo(piece.w) + bflo(rv.w), bfhi(piece.w) + bfhi(rv.w)));
           }
+          if constexpr (EPI == GRIT_EPI_SWIGLU_BWD) {
+            // `piece` = d_act rounded to bf16 (what the un-fused path stores and re-reads), then the arithmetic of grit_swiglu_bwd
+            const uint4 gv = gpre[i & 3][hh], uv = upre[i & 3][hh];
+            const uint32_t da[4] = {piece.x, piece.y, piece.z, piece.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w}, ua[4] = {uv.x, uv.y, uv.z, uv.w};
+            uint32_t og[4], ou[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float dg0, du0, dg1, du1;
+              swiglu_bwd_elem(bflo(da[e]), bflo(ga[e]), bflo(ua[e]), dg0, du0);
+              swiglu_bwd_elem(bfhi(da[e]), bfhi(ga[e]), bfhi(ua[e]), dg1, du1);
+              og[e] = pack2bf_hw(dg0, dg1);
+              ou[e] = pack2bf_hw(du0, du1);
+            }
+            if (m < M && ncol_t < N) {
+              *reinterpret_cast<uint4*>(C + m * ldc + ncol_t) = make_uint4(og[0], og[1], og[2], og[3]);
+              *reinterpret_cast<uint4*>(C + m * ldc + N + ncol_t) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+            }
+            continue;
+          }
           if (m < M && ncol_t < N) *reinterpret_cast<uint4*>(C + m * ldc + ncol_t) = piece;
+        }
+        if constexpr (EPI == GRIT_EPI_SWIGLU_BWD) {
+          if (i + 4 < 8) swb_fetch(i + 4);            // the slot just consumed takes the rows of the block four ahead
         }
       }
     }
@@ -687,7 +733,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // rows are 64 bytes: nothing to merge, one more LDS round trip).  So: the turn for the full-width epilogues, the direct form for the rest.
   // What the stamps say is left of the residual epilogue (14.5 k cycles per tile): 128 KiB read + 128 KiB written per CU by all 256 CUs
   // at the same moment = 64 MB at ~7 TB/s -- the seam of a lock-stepped launch is an HBM burst, not an issue problem.
-  constexpr bool LDS_EPI = (EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_RESIDUAL);
+  // SWIGLU_BWD (round 3, second half): two 16-byte loads + two 16-byte stores per 8 outputs made the direct form the slowest epilogue of the
+  // training step (1135 TF on the d_act GEMM against 1400-1470 for the other dense launches of a chunk); through the turn they are full lines.
+  constexpr bool LDS_EPI = (EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_RESIDUAL || EPI == GRIT_EPI_SWIGLU_BWD) && !GRIT_SWB_DIRECT(EPI);
 
   if constexpr (!PERSIST) {
     for (int kt = 0; kt < nk; kt += 2) {

@@ -178,6 +178,8 @@ int main(int argc, char** argv) {
         // persistent path (more tiles than CUs, even K-tile count >= 4) with ragged M / N edges and a tile count that is not a multiple of 256
         {9000, 4352, 512, STORE}, {9000, 4352, 512, RESIDUAL}, {9000, 4352, 512, SWIGLU}, {9000, 4352, 256, ROPE}, {4100, 4352, 256, STORE},
         {70000, 1280, 384, RESIDUAL},
+        // SWIGLU_BWD (epi 6: C = [d_gate | d_up], residual = saved [gate | up]): per-tile and persistent launches, ragged M / N edges
+        {300, 272, 320, 6}, {777, 528, 576, 6}, {4096, 2048, 512, 6}, {9000, 4352, 512, 6}, {70000, 1280, 384, 6}, {4100, 14336, 4096, 6},
     };
     for (const Case& c : cases) bad += run_case(a, b, c, c.M * (int64_t)c.N > (1 << 24) ? 3 : reps * 3, false, stdout);
   }
