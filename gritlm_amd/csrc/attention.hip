@@ -41,6 +41,39 @@
 #ifndef ATT_DEFER_MAX
 #define ATT_DEFER_MAX 1
 #endif
+// Round 3, second half: the LDS fragment reads of both products are inline asm with counted lgkmcnt (defaults 1; 0 = the compiler-
+// scheduled builtin / C++ loads of the round-2 kernel, kept for tools/ubench/attn_ab.bin).  Bit-identical; +4 % at B 256 x S 512 and at
+// S 2048, +10 % on ragged packed batches (profiles/r03_attn_fwd_ab_asm_reads.log).
+#ifndef ATT_ASM_TR
+#define ATT_ASM_TR 1
+#endif
+#ifndef ATT_ASM_K
+#define ATT_ASM_K 1
+#endif
+#ifndef ATT_K_AHEAD
+#define ATT_K_AHEAD 2
+#endif
+#ifndef ATT_DMA_SPREAD
+#define ATT_DMA_SPREAD 1
+#endif
+#ifndef ATT_SETPRIO
+#define ATT_SETPRIO 1
+#endif
+#ifndef ATT_PIECE_CONST
+#define ATT_PIECE_CONST 0
+#endif
+#ifndef ATT_K_XOR
+#define ATT_K_XOR 1
+#endif
+#ifndef ATT_TR_EARLY
+#define ATT_TR_EARLY 1
+#endif
+#ifndef ATT_NT_Q
+#define ATT_NT_Q 0
+#endif
+#ifndef ATT_NT_O
+#define ATT_NT_O 0
+#endif
 
 namespace grit {
 
@@ -121,6 +154,41 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (row_b + v_unit_b)), (att_lptr_t)(vdst + i * 1024), 16, 0, 0);
     }
   };
+  // one 1-KiB piece of a tile (ATT_DMA_SPREAD: the eight pieces of the next tile are issued BETWEEN the QK products of the current one --
+  // an LDS-DMA instruction costs 60-185 issue cycles (guide, 'LDS-DMA piece issue cost'), eight of them in front of the first K read
+  // held the whole tile back; between MFMAs the cost sits under the matrix pipe)
+#if ATT_PIECE_CONST
+  // per-lane byte offsets of the lane's pieces inside a tile (row part + swizzled unit), so that a piece of a COMPLETE tile costs one
+  // VGPR + SGPR add instead of add / min / 32-bit multiply / add per piece (8 multiplies per tile at quarter rate)
+  uint32_t pc_k[4], pc_v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    pc_k[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
+  pc_v = (uint32_t)st_key * qkv_stride_b + v_unit_b;
+#endif
+  auto stage_piece = [&](int t, int buf, int i, int is_v) {
+    char* dst = smem + buf * ATT_STAGE_BYTES + wv * 4096 + (is_v ? K_LDS_BYTES : 0) + i * 1024;
+#if ATT_PIECE_CONST
+    if ((t + 1) * ATT_KB <= S) {                                       // wave-uniform: every key of the tile exists, nothing to clamp
+      const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
+      if (is_v) {
+        __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (pc_v + (tile_b + (uint32_t)(4 * i) * qkv_stride_b))), (att_lptr_t)dst, 16, 0, 0);
+      } else {
+        __builtin_amdgcn_global_load_lds((att_gptr_t)(k_base + (pc_k[i] + tile_b)), (att_lptr_t)dst, 16, 0, 0);
+      }
+      return;
+    }
+#endif
+    int key = t * ATT_KB + st_key + 4 * i;
+    key = key < S ? key : S - 1;
+    const uint32_t row_b = (uint32_t)key * qkv_stride_b;
+    if (is_v) {
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (row_b + v_unit_b)), (att_lptr_t)dst, 16, 0, 0);
+    } else {
+      const uint32_t k_unit_b = (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(k_base + (row_b + k_unit_b)), (att_lptr_t)dst, 16, 0, 0);
+    }
+  };
   // the first tile's DMA goes out before anything else (tile 0 always exists: S > 0); with a window the first tile of the first block
   // is known only after the key bitmask has been scanned (below)
   if (!(CAUSAL && window > 0)) stage_tile(0, 0);
@@ -145,7 +213,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       int qr = qb * ATT_QB + wave * 32 + r;
       qr = qr < S ? qr : S - 1;
       const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);   // logical unit held by physical unit x_unit of row r
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, ATT_NT_Q ? 2 : 0);
     }
   };
   auto q_read_half = [&](int half) {
@@ -163,7 +231,13 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     const int qr0 = qb_first * ATT_QB + wave * 32 + ql;
     const char* qp = q_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+    for (int ks = 0; ks < 8; ++ks) {
+#if ATT_NT_Q
+      qf[ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(qp + ks * 32));
+#else
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+#endif
+    }
   }
 
   // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
@@ -231,11 +305,16 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       if (t > t_first) ATT_WAIT_VM0();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#if ATT_ASM_K && ATT_DMA_SPREAD
+      const bool st_do = (t + 1 < ntiles) || more;
+      const int st_t = (t + 1 < ntiles) ? t + 1 : next_first, st_buf = (gt + 1) & 1;
+#else
       if (t + 1 < ntiles) {
         stage_tile(t + 1, (gt + 1) & 1);
       } else if (more) {                        // the stream runs through the block seam: next block's first tile
         stage_tile(next_first, (gt + 1) & 1);
       }
+#endif
       // next block's Q, first 64 columns: fetched a whole tile ahead (the buffer is idle), so the wait at the top of the last tile
       // already covers it
       if (more && t + 2 == ntiles) q_stage_half(qb + 1, 0);
@@ -247,6 +326,65 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       // for 32 cycles but its result is ready after 64, so a product that accumulates onto the one issued just before it has to
       // wait (hipcc keeps MFMA source order; A/B against "8 products on one half, then 8 on the other": +2.5-4.5 %, bit-identical)
       f32x16_t sacc[2];
+#if ATT_ASM_K
+      // K fragments as inline-asm ds_read_b128 with counted lgkmcnt, requested ATT_K_AHEAD k-slices (2 reads each) ahead of the products
+      // that consume them (hipcc issues them in small batches and waits lgkmcnt(0) seven times per tile)
+      {
+        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if ATT_K_XOR
+        // (2 ks + hi) ^ kf_x == (2 ks) ^ (hi ^ kf_x): one per-tile base with the lane's constant in address bits 7:4, one v_xor per k-slice
+        const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)k_lds) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
+#else
+        const uint32_t kbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)k_lds) + (uint32_t)kf_row;
+#endif
+        bf16x8_t kr[8][2];
+#if ATT_DMA_SPREAD
+#define ATT_SPREAD_PIECE(KS) do { if (st_do) stage_piece(st_t, st_buf, (KS) >> 1, (KS) & 1); asm volatile("" ::: "memory"); } while (0)
+#else
+#define ATT_SPREAD_PIECE(KS) do { } while (0)
+#endif
+#define ATT_K_READ(KS)                                                                                                              \
+  do {                                                                                                                              \
+    const uint32_t ka = ATT_K_XOR ? (kbase ^ (uint32_t)((KS) << 5)) : kbase + (uint32_t)((((2 * (KS) + hi) ^ kf_x)) << 4);            \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(kr[KS][0]) : "v"(ka));                                                                \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(kr[KS][1]) : "v"(ka));                                                    \
+  } while (0)
+#define ATT_K_MMA(KS, N)                                                                                                            \
+  do {                                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[KS][0]), "+v"(kr[KS][1]) : : "memory");                                      \
+    sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][0], qf[KS], (KS) == 0 ? zero16 : sacc[0], 0, 0, 0);                    \
+    sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][1], qf[KS], (KS) == 0 ? zero16 : sacc[1], 0, 0, 0);                    \
+    ATT_SPREAD_PIECE(KS);                                                                                                           \
+  } while (0)
+#if ATT_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#if ATT_K_AHEAD == 3
+        ATT_K_READ(0); ATT_K_READ(1); ATT_K_READ(2);
+        ATT_K_READ(3); ATT_K_MMA(0, 6);
+        ATT_K_READ(4); ATT_K_MMA(1, 6);
+        ATT_K_READ(5); ATT_K_MMA(2, 6);
+        ATT_K_READ(6); ATT_K_MMA(3, 6);
+        ATT_K_READ(7); ATT_K_MMA(4, 6);
+        ATT_K_MMA(5, 4); ATT_K_MMA(6, 2); ATT_K_MMA(7, 0);
+#else
+        ATT_K_READ(0); ATT_K_READ(1);
+        ATT_K_READ(2); ATT_K_MMA(0, 4);
+        ATT_K_READ(3); ATT_K_MMA(1, 4);
+        ATT_K_READ(4); ATT_K_MMA(2, 4);
+        ATT_K_READ(5); ATT_K_MMA(3, 4);
+        ATT_K_READ(6); ATT_K_MMA(4, 4);
+        ATT_K_READ(7); ATT_K_MMA(5, 4);
+        ATT_K_MMA(6, 2); ATT_K_MMA(7, 0);
+#endif
+#if ATT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#undef ATT_K_READ
+#undef ATT_K_MMA
+#undef ATT_SPREAD_PIECE
+      }
+#else
       {
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -258,6 +396,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
             sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
           }
       }
+#endif
 
       // the next block's Q rows replace this block's as soon as its last QK product has read them: the fetch lands under the
       // softmax and PV of the last tile, no second register set
@@ -267,6 +406,28 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         q_read_half(0);
         q_stage_half(qb + 1, 1);    // the other 64 columns land under the softmax and the PV products
       }
+
+#if ATT_ASM_TR
+      // The transposing V reads as inline asm with COUNTED lgkmcnt: hipcc's wait-count pass treats a ds_read_b64_tr_b16 builtin as aliasing the
+      // pending LDS-DMA and puts an s_waitcnt vmcnt(0) in front of the first one -- the NEXT tile's DMA then had to land before this
+      // tile's PV products could start.  Four groups (kb, c) of 8 reads feed 4 MFMAs each; group g + 1 is requested before group g is
+      // waited for (lgkmcnt(8): LDS returns in order), two register sets of 16.  ATT_TR_EARLY: the first two groups are requested HERE,
+      // in front of the softmax (the V tile has been in LDS since the barrier at the top of the tile; the K fragments' registers are free).
+      const uint32_t vbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)v_lds);
+      uint32_t va[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) va[db] = vbase + (uint32_t)(vt_lane ^ (db << 6));
+      s16x4_t vr[2][4][2];
+#define ATT_TR_GROUP(G, BUF)                                                                                                          \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][0]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH));                \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][1]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH + 8 * V_PITCH)); \
+  }
+#if ATT_TR_EARLY
+      ATT_TR_GROUP(0, 0)
+      ATT_TR_GROUP(1, 1)
+#endif
+#endif
 
       // ---- mask + online softmax (all lane-local except one exchange with lane^32)
       uint64_t word;
@@ -363,6 +524,43 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
 
       // ---- O^T += V^T P^T   (the four d-blocks are four independent accumulators: round-robin, never the same one twice in a row)
+#if ATT_ASM_TR
+      {
+#define ATT_TR_WAIT(N, BUF)                                                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                            \
+               : "+v"(vr[BUF][0][0]), "+v"(vr[BUF][0][1]), "+v"(vr[BUF][1][0]), "+v"(vr[BUF][1][1]), "+v"(vr[BUF][2][0]),              \
+                 "+v"(vr[BUF][2][1]), "+v"(vr[BUF][3][0]), "+v"(vr[BUF][3][1]))
+#define ATT_TR_MMA(G, BUF)                                                                                                            \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    const s16x4_t v0 = vr[BUF][db][0], v1 = vr[BUF][db][1];                                                                           \
+    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
+    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[(G) >> 1][(G) & 1], oacc[db], 0, 0, 0);                                 \
+  }
+#if ATT_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#if !ATT_TR_EARLY
+        ATT_TR_GROUP(0, 0)
+        ATT_TR_GROUP(1, 1)
+#endif
+        ATT_TR_WAIT(8, 0);
+        ATT_TR_MMA(0, 0)
+        ATT_TR_GROUP(2, 0)
+        ATT_TR_WAIT(8, 1);
+        ATT_TR_MMA(1, 1)
+        ATT_TR_GROUP(3, 1)
+        ATT_TR_WAIT(8, 0);
+        ATT_TR_MMA(2, 0)
+        ATT_TR_WAIT(0, 1);
+        ATT_TR_MMA(3, 1)
+#if ATT_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#undef ATT_TR_GROUP
+#undef ATT_TR_WAIT
+#undef ATT_TR_MMA
+      }
+#else
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -375,6 +573,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
             const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
             oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
           }
+#endif
     }
 
     // ---- block seam: the next block's first tile and Q rows (issued one tile ago) are waited for BEFORE this block's stores go out
@@ -425,7 +624,16 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 #else
         if (qr < S)
 #endif
-          *reinterpret_cast<uint4*>(o_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4))) = piece[j];
+        {
+          typedef __attribute__((ext_vector_type(4))) unsigned int att_u32x4_t;
+          att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(o_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4)));
+          const att_u32x4_t pv = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+#if ATT_NT_O
+          __builtin_nontemporal_store(pv, op);
+#else
+          *op = pv;
+#endif
+        }
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);                                         // the pieces are in registers before the buffer is reused
@@ -469,11 +677,13 @@ struct AttnGeom {
   int qpw, ngx, n_sets;
   unsigned grid;
 };
-static AttnGeom attn_geom(int B, int max_len, int nq, int nkv) {
+static AttnGeom attn_geom(int B, int max_len, int nq, int nkv, bool causal) {
   const int nqb = (max_len + ATT_QB - 1) / ATT_QB;
   static const int forced = getenv("GRIT_ATTN_QPW") ? atoi(getenv("GRIT_ATTN_QPW")) : 0;      // A/B knob
   int qpw = 1;
-  for (int c = 4; c >= 1; c >>= 1)
+  // causal: consecutive query blocks see 2, 4, 6, ... KV tiles, so a workgroup walking 4 of them is up to 4x longer than its neighbour;
+  // 2 blocks per workgroup balance better (B 64 x S 2048: 869 -> 893 TF, profiles/r03_attn_fwd_ab_asm_reads.log)
+  for (int c = causal ? 2 : 4; c >= 1; c >>= 1)
     if ((int64_t)B * nq * ((nqb + c - 1) / c) >= 2048 || c == 1) { qpw = c; break; }
   if (forced > 0) qpw = forced;
   if (qpw > nqb) qpw = nqb;
@@ -498,7 +708,7 @@ static int attn_fwd_padded(const char* name, bool causal, int window, const void
   GRIT_REQUIRE((int64_t)B * nq * ((S + ATT_QB - 1) / ATT_QB) < (1ll << 30), GRIT_E_UNSUPPORTED, "%s: grid too large", name);
   GRIT_REQUIRE((int64_t)S * qkv_stride * 2 < (1ll << 31) && (int64_t)S * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
                "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
-  const AttnGeom g = attn_geom(B, S, nq, nkv);
+  const AttnGeom g = attn_geom(B, S, nq, nkv, causal);
   const dim3 grid(g.grid);
   if (causal)
     attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
@@ -523,7 +733,7 @@ static int attn_fwd_varlen(const char* name, bool causal, int window, const void
   GRIT_REQUIRE((int64_t)B * nq * ((max_len + ATT_QB - 1) / ATT_QB) < (1ll << 30), GRIT_E_UNSUPPORTED, "%s: grid too large", name);
   GRIT_REQUIRE((int64_t)max_len * qkv_stride * 2 < (1ll << 31) && (int64_t)max_len * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
                "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
-  const AttnGeom g = attn_geom(B, max_len, nq, nkv);
+  const AttnGeom g = attn_geom(B, max_len, nq, nkv, causal);
   const dim3 grid(g.grid);
   if (causal)
     attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,

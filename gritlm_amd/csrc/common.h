@@ -67,6 +67,19 @@ __device__ __forceinline__ float rope_hi(float x1, float x2, float c, float s) {
   return __builtin_fmaf(x2, c, t);
 }
 
+// silu(x) = x * sigmoid(x) for every kernel that evaluates the MLP activation (GEMM epilogues, the stand-alone SwiGLU kernel, the decode
+// GEMV): ONE definition, so the fused and un-fused paths the checks compare stay bit-identical.  Correctly rounded division: the
+// v_rcp_f32 form (-DGRIT_SILU_RCP) moved 2 of 1.9 G activations by one bf16 ulp and measured 0.98x on the gate|up GEMM (within the
+// run-to-run noise of that launch, profiles/r03_gemm_ab_opaque_zero.log), so the forward arithmetic stays what round 1 pinned.
+__device__ __forceinline__ float silu_f(float x) {
+#pragma clang fp contract(off)
+#ifdef GRIT_SILU_RCP
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+#else
+  return x / (1.0f + __expf(-x));
+#endif
+}
+
 // SwiGLU backward of one element on bf16-rounded operands: d_gate = d * u * s * (1 + g (1 - s)), d_up = d * g * s, s = sigmoid(g).
 // ONE definition with a fixed contraction for the stand-alone kernel (backward.hip) and both GEMM epilogues (gemm_bf16.hip), which the
 // checks compare bit for bit.  The sigmoid's reciprocal is v_rcp_f32 (1 ulp) instead of the correctly rounded division (~10 VALU

@@ -11,7 +11,6 @@
 
 namespace grit {
 
-__device__ __forceinline__ float silu_d(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
   return bflo(a.x) * bflo(b.x) + bfhi(a.x) * bfhi(b.x) + bflo(a.y) * bflo(b.y) + bfhi(a.y) * bfhi(b.y) + bflo(a.z) * bflo(b.z) +
@@ -119,7 +118,7 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
       if (p < N / 2 && b < B) {
         const float g = red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b];
         const float u = red[0][2 * i + 1][b] + red[1][2 * i + 1][b] + red[2][2 * i + 1][b] + red[3][2 * i + 1][b];
-        out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_d(round_bf(g))) * round_bf(u));
+        out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_f(round_bf(g))) * round_bf(u));
       }
     }
   } else if (t < GV_ROWS * NB) {

@@ -48,7 +48,6 @@ constexpr int PERSIST_LDS_BYTES = 2 * STAGE_BYTES + 64 + 4 * 512 * 8;   // ring 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // Grouped ("MoE") mode: the M rows are the concatenation of n_groups row ranges (counts[g] rows each, read from DEVICE memory so
 // the host never syncs on the routing), group g multiplies against W + g * w_stride.  tiles_m is then an upper bound
@@ -318,7 +317,17 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // PERSIST: the zeros are made opaque, i.e. 128 v_mov per tile instead of a constant-0 accumulator operand on the first K-tile's
+        // MFMAs.  With the folded form the accumulators were not live at the top of the first K-tile, hipcc packed other values into
+        // their registers and then SPILLED one 16-byte accumulator fragment in phase 1 -- its scratch reload (vmcnt(0): a full drain of
+        // the LDS-DMA queue) sat in the middle of phase 2's MFMAs, once per tile, in every variant but RoPE / RESIDUAL.  Opaque: 0 spills,
+        // 0 scratch in all seven persistent instantiations (tools/kernel_resources.py).  -DGRIT_GEMM_FOLDED_ZERO: the old form (A/B).
+#ifndef GRIT_GEMM_FOLDED_ZERO
+        if (PERSIST) asm volatile("" : "+v"(acc[i][j]));
+#endif
+      }
   };
   zero_acc();
 
@@ -828,9 +837,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
 
 // Launch knobs for A/B runs (read once, thread-safe static initialisation): GRIT_GEMM_GM=<n> m-tiles per scheduling group (default 4:
 // 4 m x 8 n tiles in flight per XCD), GRIT_GEMM_NOREMAP=1 disables the XCD remap, GRIT_GEMM_RR=1 deals tile groups round-robin to the
-// XCDs for dense launches too (default: grouped launches only), GRIT_GEMM_NOPERSIST=1 always launches one workgroup per tile.
+// XCDs for dense launches too (default: grouped launches only), GRIT_GEMM_NOPERSIST=1 always launches one workgroup per tile,
+// GRIT_GEMM_PERSIST_MAXKT=<n> lifts the K-tile bound of the persistent form (default 128).
 struct GemmKnobs {
-  int gm, remap, rr_all, persist;
+  int gm, remap, rr_all, persist, persist_max_kt;
 };
 static const GemmKnobs& gemm_knobs() {
   static const GemmKnobs k = [] {
@@ -840,6 +850,8 @@ static const GemmKnobs& gemm_knobs() {
     v.remap = getenv("GRIT_GEMM_NOREMAP") ? 0 : 1;
     v.rr_all = getenv("GRIT_GEMM_RR") ? 1 : 0;
     v.persist = getenv("GRIT_GEMM_NOPERSIST") ? 0 : 1;
+    e = getenv("GRIT_GEMM_PERSIST_MAXKT");                       // A/B knob: largest K-tile count that still takes the persistent form
+    v.persist_max_kt = (e && atoi(e) > 0) ? atoi(e) : 1024;
     return v;
   }();
   return k;
@@ -905,12 +917,14 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
   const bool rr = (grp.counts || kn.rr_all) && kn.remap;
   const unsigned nblocks = rr ? (unsigned)(8 * ((total_groups + 7) / 8) * kn.gm * tiles_n) : (unsigned)(tiles_m * tiles_n);
   const int remap_mode = rr ? 2 : kn.remap;
-  // persistent form: dense launches with an even number (4 .. 128) of K-tiles and at least two tiles per CU; everything else takes
-  // one workgroup per tile (at K = 14336 the seam is 3 % of a tile and the persistent loop's extra work per phase -- the offset fetch,
-  // 64-bit source address adds -- costs as much: measured 0.99x, profiles/r03_gemm_ab_persistent.log)
+  // persistent form: dense launches with an even number (>= 4) of K-tiles and at least two tiles per CU; everything else takes one
+  // workgroup per tile.  (Until the accumulator spill of the first K-tile was removed -- zero_acc above -- the form measured 0.99x at
+  // K = 14336, where the seam is only 3 % of a tile, and was bounded to <= 128 K-tiles; without the per-tile queue drain it wins there
+  // too: down_proj 1.013x at M = 131072, 1.042x at a training chunk, the gate|up weight gradient (K = 16384 tokens) 1.031x, bit-identical;
+  // profiles/r03_gemm_ab_opaque_zero.log.  GRIT_GEMM_PERSIST_MAXKT restores a bound for A/B runs.)
   const int n_cu = device_cu_count();
   const bool off32 = 256 * lda * 2 + 128 < (1ll << 32) && (int64_t)N * ldw * 2 + 128 < (1ll << 32);     // PERSIST's 32-bit source offsets
-  if (kn.persist && !rr && grp.counts == nullptr && (K / BK) % 2 == 0 && K / BK >= 4 && K / BK <= 128 && (int64_t)tiles_m * tiles_n >= 2 * (int64_t)n_cu &&
+  if (kn.persist && !rr && grp.counts == nullptr && (K / BK) % 2 == 0 && K / BK >= 4 && K / BK <= kn.persist_max_kt && (int64_t)tiles_m * tiles_n >= 2 * (int64_t)n_cu &&
       n_cu % 8 == 0 && off32) {
     unsigned int* ctr = next_counter_set(st);
     if (ctr != nullptr) {

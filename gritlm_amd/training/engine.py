@@ -25,8 +25,10 @@ from ..encoder import EncoderConfig, rope_tables, sliding_window_keys
 BF16, F32 = torch.bfloat16, torch.float32
 
 
-def _pad64(n: int) -> int:
-    return (n + 63) // 64 * 64
+def _pad_k(n: int) -> int:
+    """Token count -> K extent of the weight-gradient GEMMs: a multiple of 128, i.e. an EVEN number of 64-wide K-tiles, which the
+    persistent launch form of the GEMM needs (zero columns contribute exact zeros)."""
+    return (n + 127) // 128 * 128
 
 
 class _LayerParams:
@@ -216,9 +218,9 @@ class MistralTrainEngine:
         return t
 
     def _transposed_act(self, x: torch.Tensor, tag: str) -> torch.Tensor:
-        """x [T,N] -> x^T in a zero-padded [N, pad64(T)] buffer (K operand of the wgrad GEMM)."""
+        """x [T,N] -> x^T in a zero-padded [N, T rounded up to 128] buffer (K operand of the wgrad GEMM)."""
         T, N = x.shape
-        Tp = _pad64(T)
+        Tp = _pad_k(T)
         key = (tag, N)
         buf = self._tbuf.get(key)
         if buf is None or buf.shape[1] < Tp:               # grow-only: packed chunks have a different T every time

@@ -2212,6 +2212,8 @@ ALL_CHECKS = [
     ("transpose", check_transpose, {}),
     ("rmsnorm_bwd", check_rmsnorm_bwd, {}),
     ("rmsnorm_bwd_4096", check_rmsnorm_bwd, dict(T=21, H=4096, with_res=False)),
+    ("rmsnorm_bwd_4096_res", check_rmsnorm_bwd, dict(T=2077, H=4096, with_res=True)),     # > 4 x 512 rows: every workgroup loops
+    ("rmsnorm_bwd_2048_res", check_rmsnorm_bwd, dict(T=300, H=2048, with_res=True)),
     ("swiglu", check_swiglu, {}),
     ("attn_bwd_ragged", check_attention_bwd, {}),
     ("attn_bwd_holes", check_attention_bwd, dict(mask_kind="holes", S=130, B=2, nq=2, nkv=1)),
