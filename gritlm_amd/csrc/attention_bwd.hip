@@ -30,6 +30,10 @@ typedef const __attribute__((address_space(1))) void* ab_gptr_t;
 typedef __attribute__((address_space(3))) void* ab_lptr_t;
 typedef __attribute__((ext_vector_type(4))) short ab_s16x4_t;
 
+// AB_ASM_DKDV = 1 (default): the dK / dV loop with inline-asm LDS reads (below); 0 = the round-2 loop, kept for tools/ubench/attn_bwd_ab.bin
+#ifndef AB_ASM_DKDV
+#define AB_ASM_DKDV 1
+#endif
 // s_waitcnt through the builtin (gfx9 encoding) so that the waitcnt insertion pass sees it (cf. attention.hip)
 #define AB_WAIT_VM0()                       \
   do {                                      \
@@ -232,29 +236,173 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
   const TrLane trl = tr_lane(lane);
 
+  // statistics of a tile's 64 queries: every wave keeps its own copy, lane l <-> query qt*64 + l (one coalesced load per array); a lane
+  // fetches the value of "its" query of an accumulator register with ds_bpermute (no LDS memory, no barrier).  Rows past the sequence
+  // get lse = +inf -> P = 0.
+  auto load_stats = [&](int n_, float& l_, float& d_) {
+    int h_s, qt_s;
+    tile_of(n_, h_s, qt_s);
+    const int qc = qt_s * 64 + lane < S ? qt_s * 64 + lane : S - 1;
+    // padded layout [B,nq,S] (stride 1 over q), packed layout [T,nq] (stride nq over q)
+    const float* lrow = VARLEN ? lse + row0 * nq + h_s : lse + ((int64_t)b * nq + h_s) * S;
+    const float* drow = VARLEN ? delta + row0 * nq + h_s : delta + ((int64_t)b * nq + h_s) * S;
+    const int64_t qs = VARLEN ? nq : 1;
+    l_ = lrow[qc * qs];
+    d_ = drow[qc * qs];
+  };
+#if AB_ASM_DKDV
+  // (asm path: the statistics of tile n + 1 are requested during tile n, BEHIND its LDS-DMA, and are covered by the vmcnt(0) at the
+  //  top of tile n + 1 -- requested at the top of their own tile, hipcc's wait for them (vmcnt(0): the DMA sits in a conditional
+  //  branch, so it cannot count) would pull the whole DMA of the next tile in front of the first softmax)
+  float next_l = 0.f, next_d = 0.f;
+  if (ntl > 0) load_stats(0, next_l, next_d);
+#endif
   for (int n = 0; n < ntl; ++n) {
     AB_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // statistics of the tile's 64 queries: every wave keeps its own copy, lane l <-> query qt*64 + l (one coalesced load per array,
-    // issued here and first used after the S / dP products; the next tile's DMA is not in flight yet, so the wait for them is
-    // short); a lane fetches the value of "its" query of an accumulator register with ds_bpermute (no LDS memory, no barrier).
-    // Rows past the sequence get lse = +inf -> P = 0.
     int h_t, qt;
     tile_of(n, h_t, qt);
     float raw_l, raw_d, my_l = 0.f, my_d = 0.f;
     const bool q_in = qt * 64 + lane < S;
-    {
-      const int qc = q_in ? qt * 64 + lane : S - 1;
-      // padded layout [B,nq,S] (stride 1 over q), packed layout [T,nq] (stride nq over q)
-      const float* lrow = VARLEN ? lse + row0 * nq + h_t : lse + ((int64_t)b * nq + h_t) * S;
-      const float* drow = VARLEN ? delta + row0 * nq + h_t : delta + ((int64_t)b * nq + h_t) * S;
-      const int64_t qs = VARLEN ? nq : 1;
-      raw_l = lrow[qc * qs];
-      raw_d = drow[qc * qs];
-    }
+#if AB_ASM_DKDV
+    raw_l = next_l; raw_d = next_d;
+#else
+    // (issued here and first used after the S / dP products; the next tile's DMA is not in flight yet, so the wait for them is short)
+    load_stats(n, raw_l, raw_d);
+#endif
     const char* q_img = smem + (n & 1) * AB_STAGE;
     const char* d_img = q_img + AB_IMG;
+#if AB_ASM_DKDV
+    // Round 3, second half: every LDS fragment read of the tile is inline asm with counted lgkmcnt (cf. attention.hip).  What it buys here:
+    //  * the row fragments stream through THREE register sets two k-slices ahead of their products (24 registers instead of the 64 of a
+    //    whole half requested up front), the transposed fragments come in two groups of 8 (the second one in flight under the first one's
+    //    products): 96 registers of fragments in flight instead of 128, every read waited for exactly when its product needs it;
+    //  * no ds_read_b64_tr_b16 builtin follows an LDS-DMA any more (hipcc puts a vmcnt(0) in front of each), so the next tile's DMA goes
+    //    out at the TOP of the tile instead of behind its last transposing read: a whole tile of flight instead of a quarter.
+    if (n + 1 < ntl) {
+      stage(n + 1, (n + 1) & 1);
+      load_stats(n + 1, next_l, next_d);
+    }
+    {
+      const uint32_t img_b = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)q_img);
+      // row fragments: (2 ks + hi) ^ g == (2 ks) ^ (hi ^ g) -> the lane's constant sits in address bits 7:4, a k-slice is one v_xor
+      const uint32_t a_base = (img_b + (uint32_t)((lane & 31) * 256)) | (uint32_t)((hi ^ (((lane & 3) << 2) | ((lane >> 2) & 3))) << 4);
+      uint32_t t0[4], t1[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) { t0[db] = img_b + (uint32_t)(trl.o0 ^ (db << 6)); t1[db] = img_b + (uint32_t)(trl.o1 ^ (db << 6)); }
+      bf16x8_t fa0[3], fa1[3];
+      ab_s16x4_t fbr[2][4][2][2];                                // [group c][db][operand][half]
+      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16_t s, dp;
+#define DK_A_READ(QB, KS)                                                                                                         \
+  do {                                                                                                                            \
+    const uint32_t ka = a_base ^ (uint32_t)((KS) << 5);                                                                           \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa0[(KS) % 3]) : "v"(ka), "i"((QB) * 8192));                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa1[(KS) % 3]) : "v"(ka), "i"((QB) * 8192 + AB_IMG));                     \
+  } while (0)
+  // (The products as inline asm with the register FILE of every accumulator fixed -- S / dP "+v", dK / dV "+a" -- remove ALL ~540
+  //  v_accvgpr moves per tile that hipcc generates around its one-form-for-all MFMA selection; built, bit-identical, and measured EQUAL
+  //  to this form (+1.9 % at S 512, -1.5 % at S 2048: profiles/r03_attn_bwd_ab_asm_reads.log): the moves ride in issue slots the
+  //  matrix pipe leaves free.  Not kept.)
+#define DK_MFMA_V0(D, A, B) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, zero16, 0, 0, 0)
+#define DK_MFMA_V(D, A, B) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, D, 0, 0, 0)
+#define DK_MFMA_A(D, A, B) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, D, 0, 0, 0)
+#define DK_A_MMA(KS, N)                                                                                                           \
+  do {                                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fa0[(KS) % 3]), "+v"(fa1[(KS) % 3]) : : "memory");                            \
+    if ((KS) == 0) { DK_MFMA_V0(s, fa0[(KS) % 3], kf[KS]); DK_MFMA_V0(dp, fa1[(KS) % 3], vf[KS]); }                               \
+    else { DK_MFMA_V(s, fa0[(KS) % 3], kf[KS]); DK_MFMA_V(dp, fa1[(KS) % 3], vf[KS]); }                                           \
+  } while (0)
+#define DK_B_READ1(QB, C, DB, OP)                                                                                                 \
+  do {                                                                                                                            \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fbr[C][DB][OP][0]) : "v"(t0[DB]), "i"(((QB) * 32 + (C) * 16) * 256 + (OP) * AB_IMG)); \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fbr[C][DB][OP][1]) : "v"(t1[DB]), "i"(((QB) * 32 + (C) * 16) * 256 + (OP) * AB_IMG)); \
+  } while (0)
+#define DK_B_READ(QB, C)                                                                                                          \
+  do {                                                                                                                            \
+    DK_B_READ1(QB, C, 0, 0); DK_B_READ1(QB, C, 0, 1); DK_B_READ1(QB, C, 1, 0); DK_B_READ1(QB, C, 1, 1);                           \
+    DK_B_READ1(QB, C, 2, 0); DK_B_READ1(QB, C, 2, 1); DK_B_READ1(QB, C, 3, 0); DK_B_READ1(QB, C, 3, 1);                           \
+  } while (0)
+#define DK_B_WAIT(C, N)                                                                                                           \
+  do {                                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                      \
+                 : "+v"(fbr[C][0][0][0]), "+v"(fbr[C][0][0][1]), "+v"(fbr[C][0][1][0]), "+v"(fbr[C][0][1][1]), "+v"(fbr[C][1][0][0]), \
+                   "+v"(fbr[C][1][0][1]), "+v"(fbr[C][1][1][0]), "+v"(fbr[C][1][1][1]) : : "memory");                             \
+    asm volatile(""                                                                                                               \
+                 : "+v"(fbr[C][2][0][0]), "+v"(fbr[C][2][0][1]), "+v"(fbr[C][2][1][0]), "+v"(fbr[C][2][1][1]), "+v"(fbr[C][3][0][0]), \
+                   "+v"(fbr[C][3][0][1]), "+v"(fbr[C][3][1][0]), "+v"(fbr[C][3][1][1]));                                          \
+  } while (0)
+#define DK_FRAG(C, DB, OP)                                                                                                        \
+  __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){fbr[C][DB][OP][0][0], fbr[C][DB][OP][0][1], fbr[C][DB][OP][0][2], \
+                                                                           fbr[C][DB][OP][0][3], fbr[C][DB][OP][1][0], fbr[C][DB][OP][1][1], \
+                                                                           fbr[C][DB][OP][1][2], fbr[C][DB][OP][1][3]})
+#define DK_B_MMA(C)                                                                                                               \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                              \
+    const bf16x8_t f1_ = DK_FRAG(C, db, 1), f0_ = DK_FRAG(C, db, 0);                                                              \
+    DK_MFMA_A(dv[db], f1_, pb[C]);                                                                                                \
+    DK_MFMA_A(dk[db], f0_, dsb[C]);                                                                                               \
+  }
+#define DK_SOFTMAX(QB)                                                                                                            \
+  do {                                                                                                                            \
+    if ((QB) == 0) {                                                                                                              \
+      my_l = q_in ? raw_l * 1.4426950408889634f : INFINITY;                                                                       \
+      my_d = q_in ? raw_d : 0.f;                                                                                                  \
+    }                                                                                                                             \
+    float lv[16], dl[16];                                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                              \
+      const int src = ((QB) * 32 + 8 * (r >> 2) + (r & 3) + 4 * hi) << 2;                                                         \
+      lv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_l)));                                            \
+      dl[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_d)));                                            \
+    }                                                                                                                             \
+    AB_SCHED_FENCE();                                                                                                             \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                              \
+      const int ql = (QB) * 32 + 8 * (r >> 2) + (r & 3);                                                                          \
+      const int qd = qt * 64 + ql + 4 * hi - key;                                                                                 \
+      const bool seen = key_ok & ((causal == 0) | (qd >= 0)) & ((window == 0) | (qd < window));                                   \
+      const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[r]);                                                          \
+      const float p = seen ? e : 0.f;                                                                                             \
+      s[r] = p;                                                                                                                   \
+      dp[r] = p * (dp[r] - dl[r]);                                                                                                \
+    }                                                                                                                             \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) { pb[c] = pack8(s, c); dsb[c] = pack8(dp, c); }                                 \
+  } while (0)
+#define DK_HALF(QB)                                                                                                               \
+  do {                                                                                                                            \
+    DK_A_READ(QB, 2); DK_A_MMA(0, 4);                                                                                             \
+    DK_A_READ(QB, 3); DK_A_MMA(1, 4);                                                                                             \
+    DK_A_READ(QB, 4); DK_A_MMA(2, 4);                                                                                             \
+    DK_A_READ(QB, 5); DK_A_MMA(3, 4);                                                                                             \
+    DK_A_READ(QB, 6); DK_A_MMA(4, 4);                                                                                             \
+    DK_A_READ(QB, 7); DK_A_MMA(5, 4);                                                                                             \
+    DK_A_MMA(6, 2); DK_A_MMA(7, 0);                                                                                               \
+    DK_B_READ(QB, 0);                      /* 16 transposing reads in flight under the softmax */                                 \
+    bf16x8_t pb[2], dsb[2];                                                                                                       \
+    DK_SOFTMAX(QB);                                                                                                               \
+    DK_B_WAIT(0, 0);                                                                                                              \
+    DK_B_READ(QB, 1);                      /* ... the second group under the first group's products */                           \
+    DK_B_MMA(0)                                                                                                                   \
+    if ((QB) == 0) { DK_A_READ(1, 0); DK_A_READ(1, 1); DK_B_WAIT(1, 4); } else { DK_B_WAIT(1, 0); }                               \
+    DK_B_MMA(1)                                                                                                                   \
+  } while (0)
+      DK_A_READ(0, 0); DK_A_READ(0, 1);
+      DK_HALF(0);
+      DK_HALF(1);
+#undef DK_A_READ
+#undef DK_A_MMA
+#undef DK_MFMA_V0
+#undef DK_MFMA_V
+#undef DK_MFMA_A
+#undef DK_B_READ1
+#undef DK_B_READ
+#undef DK_B_WAIT
+#undef DK_FRAG
+#undef DK_B_MMA
+#undef DK_SOFTMAX
+#undef DK_HALF
+    }
+    continue;
+#endif
     // One wave per SIMD: nothing else hides the LDS latency, so the fragment reads of a phase are issued as a block AHEAD of the
     // products that consume them (sched_barrier pins the blocks; hipcc otherwise sinks every read to its use and waits for each):
     //   reads A(qb) | products A(qb): S^T, dP^T ; reads B(qb) | softmax(qb) ; reads A(qb+1) | products B(qb): dV, dK | ...
