@@ -167,7 +167,7 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
                 const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
                 uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal,
                 int nkb, int n_sets, int window) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(256))) char smem[];          // 256: the asm read addresses OR / XOR lane constants into bits 7:4
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -486,7 +486,7 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
               const uint16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
               uint16_t* __restrict__ dqkv, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale, int causal,
               int nqb, int n_sets, int window) {
-  __shared__ __attribute__((aligned(16))) char smem[AB_RING];
+  __shared__ __attribute__((aligned(256))) char smem[AB_RING];   // 256: the asm read addresses OR the lane constant into bits 7:4
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -572,6 +572,10 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
       }
     }
     const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
+    // (The same inline-asm read scheme as attn_bwd_dkdv_k -- row fragments two k-slices ahead, the transposing reads in one counted group,
+    //  the next tile's DMA at the tile top -- was built for this loop too: bit-identical, 1.017 / 1.000 / 0.996 / 0.994 of this form on
+    //  the four harness shapes (profiles/r03_attn_bwd_ab_asm_reads.log).  With two waves per SIMD the partner wave covers what the
+    //  pinned groups below leave open; not kept.)
     // hipcc sinks every fragment read to its use and waits for each (one read in flight); the reads are therefore issued in pinned
     // groups a group ahead of the products that consume them (two waves per SIMD leave ~30 registers for that: 2 k-slices x {K, V}
     // per group, double-buffered), and the transposed-K fragments of the dQ products go out ahead of the softmax arithmetic
