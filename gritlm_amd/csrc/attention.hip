@@ -50,17 +50,14 @@
 #ifndef ATT_ASM_K
 #define ATT_ASM_K 1
 #endif
-#ifndef ATT_K_AHEAD
-#define ATT_K_AHEAD 2
-#endif
 #ifndef ATT_DMA_SPREAD
 #define ATT_DMA_SPREAD 1
 #endif
 #ifndef ATT_SETPRIO
 #define ATT_SETPRIO 1
 #endif
-#ifndef ATT_PIECE_CONST
-#define ATT_PIECE_CONST 0
+#ifndef ATT_BUF_DMA
+#define ATT_BUF_DMA 1
 #endif
 #ifndef ATT_K_XOR
 #define ATT_K_XOR 1
@@ -157,9 +154,12 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   // one 1-KiB piece of a tile (ATT_DMA_SPREAD: the eight pieces of the next tile are issued BETWEEN the QK products of the current one --
   // an LDS-DMA instruction costs 60-185 issue cycles (guide, 'LDS-DMA piece issue cost'), eight of them in front of the first K read
   // held the whole tile back; between MFMAs the cost sits under the matrix pipe)
-#if ATT_PIECE_CONST
-  // per-lane byte offsets of the lane's pieces inside a tile (row part + swizzled unit), so that a piece of a COMPLETE tile costs one
-  // VGPR + SGPR add instead of add / min / 32-bit multiply / add per piece (8 multiplies per tile at quarter rate)
+#if ATT_BUF_DMA
+  // Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): the descriptor's range check zero-fills rows past the sequence (their
+  // keys are masked anyway: finite K -> score -> -inf, P = 0 x finite V), so a piece needs no per-lane clamp / 32-bit multiply: the
+  // lane's offset inside a tile (row + swizzled unit) is a constant VGPR, the tile's row offset goes into the scalar offset operand.
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u), 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(v_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u), 0x00020000);
   uint32_t pc_k[4], pc_v;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -168,17 +168,11 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 #endif
   auto stage_piece = [&](int t, int buf, int i, int is_v) {
     char* dst = smem + buf * ATT_STAGE_BYTES + wv * 4096 + (is_v ? K_LDS_BYTES : 0) + i * 1024;
-#if ATT_PIECE_CONST
-    if ((t + 1) * ATT_KB <= S) {                                       // wave-uniform: every key of the tile exists, nothing to clamp
-      const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
-      if (is_v) {
-        __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (pc_v + (tile_b + (uint32_t)(4 * i) * qkv_stride_b))), (att_lptr_t)dst, 16, 0, 0);
-      } else {
-        __builtin_amdgcn_global_load_lds((att_gptr_t)(k_base + (pc_k[i] + tile_b)), (att_lptr_t)dst, 16, 0, 0);
-      }
-      return;
-    }
-#endif
+#if ATT_BUF_DMA
+    const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
+    if (is_v) __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (att_lptr_t)dst, 16, (int)pc_v, (int)(tile_b + (uint32_t)(4 * i) * qkv_stride_b), 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (att_lptr_t)dst, 16, (int)pc_k[i], (int)tile_b, 0, 0);
+#else
     int key = t * ATT_KB + st_key + 4 * i;
     key = key < S ? key : S - 1;
     const uint32_t row_b = (uint32_t)key * qkv_stride_b;
@@ -188,6 +182,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       const uint32_t k_unit_b = (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
       __builtin_amdgcn_global_load_lds((att_gptr_t)(k_base + (row_b + k_unit_b)), (att_lptr_t)dst, 16, 0, 0);
     }
+#endif
   };
   // the first tile's DMA goes out before anything else (tile 0 always exists: S > 0); with a window the first tile of the first block
   // is known only after the key bitmask has been scanned (below)
@@ -320,6 +315,30 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       if (more && t + 2 == ntiles) q_stage_half(qb + 1, 0);
       const char* k_lds = smem + (gt & 1) * ATT_STAGE_BYTES;
       const char* v_lds = k_lds + K_LDS_BYTES;
+      // the tile's key-mask word is fetched HERE (a scalar load; its latency sits under the QK products) and turned into `fast` before
+      // the asm LDS reads of the PV products are requested: fetched where it is used, hipcc's lgkmcnt(0) for the scalar load waited for
+      // the load's own round trip AND for the sixteen V reads just issued -- once per tile
+      uint64_t word;
+      if constexpr (VARLEN) {
+        const int rem = S - t * ATT_KB;
+        word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+      } else {
+        word = bits[t];
+      }
+      bool fast = (word == ~0ull);
+      if constexpr (CAUSAL) {
+        const int qw0 = qb * ATT_QB + wave * 32;                   // this wave's first query
+        // tile reaches past the wave's first query, or starts in front of the first key the wave's LAST query sees: per-lane bounds
+        if (t * ATT_KB + ATT_KB - 1 > qw0 || (window > 0 && t * ATT_KB < qw0 + 32 - window)) {
+          const int n = q_row - t * ATT_KB + 1;                    // keys of this tile the lane's query may see
+          word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+          if (window > 0) {
+            const int lo = n - window;                             // keys of this tile in front of the lane's window
+            word &= lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+          }
+          fast = false;
+        }
+      }
 
       // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
       // the two 32-key halves are two INDEPENDENT accumulation chains, issued alternately: a v_mfma_f32_32x32x16_bf16 occupies the pipe
@@ -327,8 +346,8 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       // wait (hipcc keeps MFMA source order; A/B against "8 products on one half, then 8 on the other": +2.5-4.5 %, bit-identical)
       f32x16_t sacc[2];
 #if ATT_ASM_K
-      // K fragments as inline-asm ds_read_b128 with counted lgkmcnt, requested ATT_K_AHEAD k-slices (2 reads each) ahead of the products
-      // that consume them (hipcc issues them in small batches and waits lgkmcnt(0) seven times per tile)
+      // K fragments as inline-asm ds_read_b128 with counted lgkmcnt, requested two k-slices (2 reads each) ahead of the products that
+      // consume them (hipcc issues them in small batches and waits lgkmcnt(0) seven times per tile)
       {
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if ATT_K_XOR
@@ -338,11 +357,6 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         const uint32_t kbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)k_lds) + (uint32_t)kf_row;
 #endif
         bf16x8_t kr[8][2];
-#if ATT_DMA_SPREAD
-#define ATT_SPREAD_PIECE(KS) do { if (st_do) stage_piece(st_t, st_buf, (KS) >> 1, (KS) & 1); asm volatile("" ::: "memory"); } while (0)
-#else
-#define ATT_SPREAD_PIECE(KS) do { } while (0)
-#endif
 #define ATT_K_READ(KS)                                                                                                              \
   do {                                                                                                                              \
     const uint32_t ka = ATT_K_XOR ? (kbase ^ (uint32_t)((KS) << 5)) : kbase + (uint32_t)((((2 * (KS) + hi) ^ kf_x)) << 4);            \
@@ -354,20 +368,13 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[KS][0]), "+v"(kr[KS][1]) : : "memory");                                      \
     sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][0], qf[KS], (KS) == 0 ? zero16 : sacc[0], 0, 0, 0);                    \
     sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][1], qf[KS], (KS) == 0 ? zero16 : sacc[1], 0, 0, 0);                    \
-    ATT_SPREAD_PIECE(KS);                                                                                                           \
+    if (ATT_DMA_SPREAD) { if (st_do) stage_piece(st_t, st_buf, (KS) >> 1, (KS) & 1); asm volatile("" ::: "memory"); }               \
   } while (0)
+        // K fragments two k-slices ahead of their products (three ahead: no gain); one LDS-DMA piece of the next tile behind every
+        // product pair (one copy of the block with eight uniform branches: a copy per case of `st_do` measured 2 % slower at S 2048)
 #if ATT_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
-#if ATT_K_AHEAD == 3
-        ATT_K_READ(0); ATT_K_READ(1); ATT_K_READ(2);
-        ATT_K_READ(3); ATT_K_MMA(0, 6);
-        ATT_K_READ(4); ATT_K_MMA(1, 6);
-        ATT_K_READ(5); ATT_K_MMA(2, 6);
-        ATT_K_READ(6); ATT_K_MMA(3, 6);
-        ATT_K_READ(7); ATT_K_MMA(4, 6);
-        ATT_K_MMA(5, 4); ATT_K_MMA(6, 2); ATT_K_MMA(7, 0);
-#else
         ATT_K_READ(0); ATT_K_READ(1);
         ATT_K_READ(2); ATT_K_MMA(0, 4);
         ATT_K_READ(3); ATT_K_MMA(1, 4);
@@ -376,13 +383,11 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         ATT_K_READ(6); ATT_K_MMA(4, 4);
         ATT_K_READ(7); ATT_K_MMA(5, 4);
         ATT_K_MMA(6, 2); ATT_K_MMA(7, 0);
-#endif
 #if ATT_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
 #undef ATT_K_READ
 #undef ATT_K_MMA
-#undef ATT_SPREAD_PIECE
       }
 #else
       {
@@ -424,33 +429,17 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][1]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH + 8 * V_PITCH)); \
   }
 #if ATT_TR_EARLY
+      {
+        int fast_i = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);   // wave-uniform; made opaque HERE so that the compare -- and with it hipcc's wait for the
+        asm volatile("" : "+s"(fast_i));            // mask word's scalar load -- sits in front of the V reads, not behind them
+        fast = fast_i != 0;
+      }
       ATT_TR_GROUP(0, 0)
       ATT_TR_GROUP(1, 1)
 #endif
 #endif
 
       // ---- mask + online softmax (all lane-local except one exchange with lane^32)
-      uint64_t word;
-      if constexpr (VARLEN) {
-        const int rem = S - t * ATT_KB;
-        word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-      } else {
-        word = bits[t];
-      }
-      bool fast = (word == ~0ull);
-      if constexpr (CAUSAL) {
-        const int qw0 = qb * ATT_QB + wave * 32;                   // this wave's first query
-        // tile reaches past the wave's first query, or starts in front of the first key the wave's LAST query sees: per-lane bounds
-        if (t * ATT_KB + ATT_KB - 1 > qw0 || (window > 0 && t * ATT_KB < qw0 + 32 - window)) {
-          const int n = q_row - t * ATT_KB + 1;                    // keys of this tile the lane's query may see
-          word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
-          if (window > 0) {
-            const int lo = n - window;                             // keys of this tile in front of the lane's window
-            word &= lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
-          }
-          fast = false;
-        }
-      }
       float mx = -INFINITY;
       if (fast) {                   // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
 #pragma unroll
@@ -471,7 +460,12 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
           }
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with the scaling
+      {
+        // max over the two 32-lane halves through v_permlane32_swap (a VALU instruction): __shfl_xor is a ds_bpermute, an LDS-queue
+        // instruction whose lgkmcnt(0) also waits for the V reads requested in front of the softmax
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2;      // scale > 0: max commutes with the scaling
+      }
       const float m_new = fmaxf(m_run, mx);
 #if ATT_DEFER_MAX
       // deferred rescale: a row keeps its old reference maximum as long as its maximum grows by less than 2^8 (P <= 256, exact in
@@ -581,7 +575,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     if (more) q_read_half(1);
 
     // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);     // (once per block; through v_permlane32_swap like the tile maximum: measured 2 % slower at S >= 2048)
     const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     // full-line stores through the transposition buffer (a row-per-lane store touches 32 lines x 32 B per instruction): one 64-column
     // half at a time, every lane writes its 4 pieces of the half (unit ^= (row>>1)&7), then stores 16 B of an 8-row x 128-B piece
