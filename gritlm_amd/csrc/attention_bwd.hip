@@ -550,6 +550,12 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
   const TrLane trl = tr_lane(lane);
 
+  // padded layout: the mask word of tile t + 1 is fetched at the end of tile t (a scalar load issued at the top of its own tile is
+  // waited for right there -- hipcc needs it for the causal bounds -- with its whole round trip exposed behind the barrier)
+  uint64_t word_next = 0;
+  if constexpr (!VARLEN) {
+    if (t_first < ntiles) word_next = bits[t_first];
+  }
   for (int t = t_first; t < ntiles; ++t) {
     AB_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
@@ -561,7 +567,7 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
       const int rem = S - t * 64;
       word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     } else {
-      word = bits[t];
+      word = word_next;
     }
     if (causal) {
       const int n = q - t * 64 + 1;
@@ -638,6 +644,9 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
 #pragma unroll
         for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][db], dsb[c], dq[db], 0, 0, 0);
     }
+    // (requested at the END of the tile: while a scalar load is outstanding hipcc turns every counted LDS wait into lgkmcnt(0), so it
+    //  must not sit inside the pinned read groups; here its round trip overlaps the wait for the next tile's DMA and the barrier)
+    if constexpr (!VARLEN) word_next = bits[t + 1 < ntiles ? t + 1 : t];
   }
   AB_WAIT_VM0();
   __builtin_amdgcn_s_barrier();
