@@ -59,6 +59,9 @@
 #ifndef ATT_BUF_DMA
 #define ATT_BUF_DMA 1
 #endif
+#ifndef ATT_ALWAYS_STAGE
+#define ATT_ALWAYS_STAGE 1
+#endif
 #ifndef ATT_K_XOR
 #define ATT_K_XOR 1
 #endif
@@ -157,21 +160,23 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 #if ATT_BUF_DMA
   // Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): the descriptor's range check zero-fills rows past the sequence (their
   // keys are masked anyway: finite K -> score -> -inf, P = 0 x finite V), so a piece needs no per-lane clamp / 32-bit multiply: the
-  // lane's offset inside a tile (row + swizzled unit) is a constant VGPR, the tile's row offset goes into the scalar offset operand.
-  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u), 0x00020000);
-  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(v_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u), 0x00020000);
-  uint32_t pc_k[4], pc_v;
+  // lane's offset inside a tile (row + swizzled unit; V: + the distance of the V heads from the K heads) is a constant VGPR per piece,
+  // the tile's row offset ONE scalar operand for all eight pieces, and ONE descriptor serves K and V (a V row of the last valid key
+  // ends exactly at num_records; the next row of either operand starts (nq + nkv) x 256 - 256 >= 0 bytes behind it).
+  const uint32_t v_delta_b = (uint32_t)nkv * ATT_D * 2u;
+  const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u + v_delta_b), 0x00020000);
+  uint32_t pc_k[4], pc_v[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
     pc_k[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
-  pc_v = (uint32_t)st_key * qkv_stride_b + v_unit_b;
+    pc_v[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + v_unit_b + v_delta_b;
+  }
 #endif
   auto stage_piece = [&](int t, int buf, int i, int is_v) {
     char* dst = smem + buf * ATT_STAGE_BYTES + wv * 4096 + (is_v ? K_LDS_BYTES : 0) + i * 1024;
 #if ATT_BUF_DMA
     const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
-    if (is_v) __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (att_lptr_t)dst, 16, (int)pc_v, (int)(tile_b + (uint32_t)(4 * i) * qkv_stride_b), 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (att_lptr_t)dst, 16, (int)pc_k[i], (int)tile_b, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(is_v ? pc_v[i] : pc_k[i]), (int)tile_b, 0, 0);
 #else
     int key = t * ATT_KB + st_key + 4 * i;
     key = key < S ? key : S - 1;
@@ -301,8 +306,15 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 #if ATT_ASM_K && ATT_DMA_SPREAD
+#if ATT_ALWAYS_STAGE
+      // the eight pieces are issued unconditionally: behind the workgroup's very last tile they re-stage that tile into the idle stage
+      // (nobody reads it; the wait in front of the block's output stores covers it) instead of costing a uniform branch per piece
+      constexpr bool st_do = true;
+      const int st_t = (t + 1 < ntiles) ? t + 1 : (more ? next_first : t), st_buf = (gt + 1) & 1;
+#else
       const bool st_do = (t + 1 < ntiles) || more;
       const int st_t = (t + 1 < ntiles) ? t + 1 : next_first, st_buf = (gt + 1) & 1;
+#endif
 #else
       if (t + 1 < ntiles) {
         stage_tile(t + 1, (gt + 1) & 1);
@@ -442,10 +454,16 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       // ---- mask + online softmax (all lane-local except one exchange with lane^32)
       float mx = -INFINITY;
       if (fast) {                   // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
+        // four independent chains (max is exact: any order gives the same bits); one chain of 16 dependent v_max3 is a latency chain
+        float m4[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const int kb = c4 >> 1, r0 = (c4 & 1) * 8;
+          m4[c4] = fmaxf(fmaxf(sacc[kb][r0], sacc[kb][r0 + 1]), sacc[kb][r0 + 2]);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+          for (int r = 3; r < 8; ++r) m4[c4] = fmaxf(m4[c4], sacc[kb][r0 + r]);
+        }
+        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       } else {
         const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
 #pragma unroll
