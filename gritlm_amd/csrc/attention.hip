@@ -9,16 +9,19 @@
 // its Q rows are fetched into the same registers, under the last tile of the current one), so the per-block prologue (Q + first-tile latency) is paid once
 // per workgroup and the output stores of a block drain under the next block's first tile.  Workgroups that share K/V (the GQA
 // group's heads x query-block groups of one (batch, kv head)) are dealt to the SAME XCD back to back (block v runs on XCD v % 8).
-// KV tiles of 64 keys go HBM -> LDS by direct LDS-DMA (global_load_lds, 16 B per lane, 1 KiB = 4 key rows per wave instruction) into
-// a two-stage ring: the DMA of tile t+1 is issued right after the single barrier of tile t and lands under tile t's MFMAs and
-// softmax -- no staging registers, no ds_write pass, one barrier per tile.  Both images are row-major [key][256 B] with the 16-byte
+// KV tiles of 64 keys go HBM -> LDS by direct LDS-DMA (buffer_load ... lds, 16 B per lane, 1 KiB = 4 key rows per wave instruction;
+// the descriptor's range check zero-fills rows past the sequence) into a two-stage ring: the eight pieces of tile t+1 are issued
+// BETWEEN the QK products of tile t and land under its softmax and PV products -- no staging registers, no ds_write pass, one barrier
+// per tile.  Every LDS fragment read of the tile loop is inline asm with counted lgkmcnt (round 3): K fragments two k-slices ahead of
+// their products, V fragments in four groups of 8 with the first two requested in front of the softmax; nothing in the loop makes hipcc
+// wait for more than it needs (its own lgkmcnt(0) / vmcnt(0) in front of builtin LDS reads, scalar loads and ds_bpermute cost 12 %).  Both images are row-major [key][256 B] with the 16-byte
 // units XOR-swizzled through the per-lane SOURCE address (the LDS image of a DMA is lane-linear): K unit ^= key & 15
 // (conflict-free ds_read_b128 of a 32-key fragment), V unit ^= 4 (key & 3) (conflict-free ds_read_b64_tr_b16: the 16 lanes of a
 // transposing read touch 4 keys x 32 B, the XOR puts them -- and the second 16-lane group -- on 16 distinct units of one 256-B bank row).
 //   S^T = K Q^T     v_mfma_f32_32x32x16_bf16(A = K rows, B = Q)  -> lane (q = lane&31) holds 32 keys' scores
 //   O^T = V^T P^T   v_mfma_f32_32x32x16_bf16(A = V^T rows, B = P) -> lane (q = lane&31) holds 64 of its d's
 // Both products are "swapped" so that every softmax statistic (max, sum, rescale) is lane-local: the only
-// cross-lane traffic per tile is one shuffle with lane^32 for the row max.  The P operand needs no
+// cross-lane traffic per tile is one v_permlane32_swap for the row max.  The P operand needs no
 // permlane/LDS round trip: the MFMA contraction index is permuted identically on the V^T side
 // (key(kb,c,hi,j) = 32kb + 16c + 8(j>>2) + 4hi + (j&3)): two transposing 8-byte LDS reads whose per-lane
 // addresses select exactly those keys.
@@ -41,39 +44,11 @@
 #ifndef ATT_DEFER_MAX
 #define ATT_DEFER_MAX 1
 #endif
-// Round 3, second half: the LDS fragment reads of both products are inline asm with counted lgkmcnt (defaults 1; 0 = the compiler-
-// scheduled builtin / C++ loads of the round-2 kernel, kept for tools/ubench/attn_ab.bin).  Bit-identical; +4 % at B 256 x S 512 and at
-// S 2048, +10 % on ragged packed batches (profiles/r03_attn_fwd_ab_asm_reads.log).
-#ifndef ATT_ASM_TR
-#define ATT_ASM_TR 1
-#endif
-#ifndef ATT_ASM_K
-#define ATT_ASM_K 1
-#endif
-#ifndef ATT_DMA_SPREAD
-#define ATT_DMA_SPREAD 1
-#endif
-#ifndef ATT_SETPRIO
-#define ATT_SETPRIO 1
-#endif
-#ifndef ATT_BUF_DMA
-#define ATT_BUF_DMA 1
-#endif
-#ifndef ATT_ALWAYS_STAGE
-#define ATT_ALWAYS_STAGE 1
-#endif
-#ifndef ATT_K_XOR
-#define ATT_K_XOR 1
-#endif
-#ifndef ATT_TR_EARLY
-#define ATT_TR_EARLY 1
-#endif
-#ifndef ATT_NT_Q
-#define ATT_NT_Q 0
-#endif
-#ifndef ATT_NT_O
-#define ATT_NT_O 0
-#endif
+// (ATT_DEFER_MAX and ATT_ABLATE_STORES are the A/B knobs of tools/ubench/attn_ab.cpp.  The levers of round 3 -- asm reads, spread /
+//  buffer-addressed / unconditional DMA pieces, early V reads, s_setprio over QK, xor K addresses, hoisted mask word, permlane row
+//  maximum -- were each A/B'd as a compile-time variant against the kernel of the previous commit, bit-identical every time
+//  (profiles/r03_attn_fwd_ab_asm_reads.log, 773 -> 870 TF at B 256 x S 512); the variants are resolved in this file, the round-2
+//  kernel is rebuilt from git history by tools/ubench/build_attn_ab.sh.)
 
 namespace grit {
 
@@ -154,10 +129,9 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (row_b + v_unit_b)), (att_lptr_t)(vdst + i * 1024), 16, 0, 0);
     }
   };
-  // one 1-KiB piece of a tile (ATT_DMA_SPREAD: the eight pieces of the next tile are issued BETWEEN the QK products of the current one --
+  // one 1-KiB piece of a tile (the eight pieces of the next tile are issued BETWEEN the QK products of the current one --
   // an LDS-DMA instruction costs 60-185 issue cycles (guide, 'LDS-DMA piece issue cost'), eight of them in front of the first K read
   // held the whole tile back; between MFMAs the cost sits under the matrix pipe)
-#if ATT_BUF_DMA
   // Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): the descriptor's range check zero-fills rows past the sequence (their
   // keys are masked anyway: finite K -> score -> -inf, P = 0 x finite V), so a piece needs no per-lane clamp / 32-bit multiply: the
   // lane's offset inside a tile (row + swizzled unit; V: + the distance of the V heads from the K heads) is a constant VGPR per piece,
@@ -171,23 +145,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     pc_k[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
     pc_v[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + v_unit_b + v_delta_b;
   }
-#endif
   auto stage_piece = [&](int t, int buf, int i, int is_v) {
     char* dst = smem + buf * ATT_STAGE_BYTES + wv * 4096 + (is_v ? K_LDS_BYTES : 0) + i * 1024;
-#if ATT_BUF_DMA
     const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(is_v ? pc_v[i] : pc_k[i]), (int)tile_b, 0, 0);
-#else
-    int key = t * ATT_KB + st_key + 4 * i;
-    key = key < S ? key : S - 1;
-    const uint32_t row_b = (uint32_t)key * qkv_stride_b;
-    if (is_v) {
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (row_b + v_unit_b)), (att_lptr_t)dst, 16, 0, 0);
-    } else {
-      const uint32_t k_unit_b = (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(k_base + (row_b + k_unit_b)), (att_lptr_t)dst, 16, 0, 0);
-    }
-#endif
   };
   // the first tile's DMA goes out before anything else (tile 0 always exists: S > 0); with a window the first tile of the first block
   // is known only after the key bitmask has been scanned (below)
@@ -213,7 +174,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       int qr = qb * ATT_QB + wave * 32 + r;
       qr = qr < S ? qr : S - 1;
       const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);   // logical unit held by physical unit x_unit of row r
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, ATT_NT_Q ? 2 : 0);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, 0);
     }
   };
   auto q_read_half = [&](int half) {
@@ -232,11 +193,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     const char* qp = q_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-#if ATT_NT_Q
-      qf[ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(qp + ks * 32));
-#else
       qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
-#endif
     }
   }
 
@@ -305,23 +262,9 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       if (t > t_first) ATT_WAIT_VM0();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-#if ATT_ASM_K && ATT_DMA_SPREAD
-#if ATT_ALWAYS_STAGE
       // the eight pieces are issued unconditionally: behind the workgroup's very last tile they re-stage that tile into the idle stage
       // (nobody reads it; the wait in front of the block's output stores covers it) instead of costing a uniform branch per piece
-      constexpr bool st_do = true;
       const int st_t = (t + 1 < ntiles) ? t + 1 : (more ? next_first : t), st_buf = (gt + 1) & 1;
-#else
-      const bool st_do = (t + 1 < ntiles) || more;
-      const int st_t = (t + 1 < ntiles) ? t + 1 : next_first, st_buf = (gt + 1) & 1;
-#endif
-#else
-      if (t + 1 < ntiles) {
-        stage_tile(t + 1, (gt + 1) & 1);
-      } else if (more) {                        // the stream runs through the block seam: next block's first tile
-        stage_tile(next_first, (gt + 1) & 1);
-      }
-#endif
       // next block's Q, first 64 columns: fetched a whole tile ahead (the buffer is idle), so the wait at the top of the last tile
       // already covers it
       if (more && t + 2 == ntiles) q_stage_half(qb + 1, 0);
@@ -357,21 +300,16 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       // for 32 cycles but its result is ready after 64, so a product that accumulates onto the one issued just before it has to
       // wait (hipcc keeps MFMA source order; A/B against "8 products on one half, then 8 on the other": +2.5-4.5 %, bit-identical)
       f32x16_t sacc[2];
-#if ATT_ASM_K
       // K fragments as inline-asm ds_read_b128 with counted lgkmcnt, requested two k-slices (2 reads each) ahead of the products that
       // consume them (hipcc issues them in small batches and waits lgkmcnt(0) seven times per tile)
       {
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if ATT_K_XOR
         // (2 ks + hi) ^ kf_x == (2 ks) ^ (hi ^ kf_x): one per-tile base with the lane's constant in address bits 7:4, one v_xor per k-slice
         const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)k_lds) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
-#else
-        const uint32_t kbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)k_lds) + (uint32_t)kf_row;
-#endif
         bf16x8_t kr[8][2];
 #define ATT_K_READ(KS)                                                                                                              \
   do {                                                                                                                              \
-    const uint32_t ka = ATT_K_XOR ? (kbase ^ (uint32_t)((KS) << 5)) : kbase + (uint32_t)((((2 * (KS) + hi) ^ kf_x)) << 4);            \
+    const uint32_t ka = kbase ^ (uint32_t)((KS) << 5);                                                                              \
     asm volatile("ds_read_b128 %0, %1" : "=v"(kr[KS][0]) : "v"(ka));                                                                \
     asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(kr[KS][1]) : "v"(ka));                                                    \
   } while (0)
@@ -380,13 +318,12 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[KS][0]), "+v"(kr[KS][1]) : : "memory");                                      \
     sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][0], qf[KS], (KS) == 0 ? zero16 : sacc[0], 0, 0, 0);                    \
     sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][1], qf[KS], (KS) == 0 ? zero16 : sacc[1], 0, 0, 0);                    \
-    if (ATT_DMA_SPREAD) { if (st_do) stage_piece(st_t, st_buf, (KS) >> 1, (KS) & 1); asm volatile("" ::: "memory"); }               \
+    stage_piece(st_t, st_buf, (KS) >> 1, (KS) & 1);                                                                                 \
+    asm volatile("" ::: "memory");                                                                                                  \
   } while (0)
         // K fragments two k-slices ahead of their products (three ahead: no gain); one LDS-DMA piece of the next tile behind every
-        // product pair (one copy of the block with eight uniform branches: a copy per case of `st_do` measured 2 % slower at S 2048)
-#if ATT_SETPRIO
+        // product pair; s_setprio 1 over the section: 0 .. +2 % (over the PV section as well: -1.5 %)
         __builtin_amdgcn_s_setprio(1);
-#endif
         ATT_K_READ(0); ATT_K_READ(1);
         ATT_K_READ(2); ATT_K_MMA(0, 4);
         ATT_K_READ(3); ATT_K_MMA(1, 4);
@@ -395,25 +332,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         ATT_K_READ(6); ATT_K_MMA(4, 4);
         ATT_K_READ(7); ATT_K_MMA(5, 4);
         ATT_K_MMA(6, 2); ATT_K_MMA(7, 0);
-#if ATT_SETPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
 #undef ATT_K_READ
 #undef ATT_K_MMA
       }
-#else
-      {
-        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + kb * 32 * 256 + kf_row + (((2 * ks + hi) ^ kf_x) << 4));
-            // the first product takes the constant 0 as its accumulator input (an inline operand: no 16 v_mov per chain)
-            sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sacc[kb], 0, 0, 0);
-          }
-      }
-#endif
 
       // the next block's Q rows replace this block's as soon as its last QK product has read them: the fetch lands under the
       // softmax and PV of the last tile, no second register set
@@ -424,11 +346,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         q_stage_half(qb + 1, 1);    // the other 64 columns land under the softmax and the PV products
       }
 
-#if ATT_ASM_TR
       // The transposing V reads as inline asm with COUNTED lgkmcnt: hipcc's wait-count pass treats a ds_read_b64_tr_b16 builtin as aliasing the
       // pending LDS-DMA and puts an s_waitcnt vmcnt(0) in front of the first one -- the NEXT tile's DMA then had to land before this
       // tile's PV products could start.  Four groups (kb, c) of 8 reads feed 4 MFMAs each; group g + 1 is requested before group g is
-      // waited for (lgkmcnt(8): LDS returns in order), two register sets of 16.  ATT_TR_EARLY: the first two groups are requested HERE,
+      // waited for (lgkmcnt(8): LDS returns in order), two register sets of 16.  The first two groups are requested HERE,
       // in front of the softmax (the V tile has been in LDS since the barrier at the top of the tile; the K fragments' registers are free).
       const uint32_t vbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)v_lds);
       uint32_t va[4];
@@ -440,7 +361,6 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][0]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH));                \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][1]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH + 8 * V_PITCH)); \
   }
-#if ATT_TR_EARLY
       {
         int fast_i = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);   // wave-uniform; made opaque HERE so that the compare -- and with it hipcc's wait for the
         asm volatile("" : "+s"(fast_i));            // mask word's scalar load -- sits in front of the V reads, not behind them
@@ -448,8 +368,6 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       }
       ATT_TR_GROUP(0, 0)
       ATT_TR_GROUP(1, 1)
-#endif
-#endif
 
       // ---- mask + online softmax (all lane-local except one exchange with lane^32)
       float mx = -INFINITY;
@@ -536,7 +454,6 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
 
       // ---- O^T += V^T P^T   (the four d-blocks are four independent accumulators: round-robin, never the same one twice in a row)
-#if ATT_ASM_TR
       {
 #define ATT_TR_WAIT(N, BUF)                                                                                                           \
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                            \
@@ -548,13 +465,6 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[(G) >> 1][(G) & 1], oacc[db], 0, 0, 0);                                 \
   }
-#if ATT_SETPRIO == 2
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#if !ATT_TR_EARLY
-        ATT_TR_GROUP(0, 0)
-        ATT_TR_GROUP(1, 1)
-#endif
         ATT_TR_WAIT(8, 0);
         ATT_TR_MMA(0, 0)
         ATT_TR_GROUP(2, 0)
@@ -565,27 +475,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         ATT_TR_MMA(2, 0)
         ATT_TR_WAIT(0, 1);
         ATT_TR_MMA(3, 1)
-#if ATT_SETPRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
 #undef ATT_TR_GROUP
 #undef ATT_TR_WAIT
 #undef ATT_TR_MMA
       }
-#else
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const char* vp = v_lds + (vt_lane ^ (db << 6)) + (kb * 32 + c * 16) * V_PITCH;
-            const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
-            const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * V_PITCH));
-            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]});
-            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][c], oacc[db], 0, 0, 0);
-          }
-#endif
     }
 
     // ---- block seam: the next block's first tile and Q rows (issued one tile ago) are waited for BEFORE this block's stores go out
@@ -640,11 +533,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
           typedef __attribute__((ext_vector_type(4))) unsigned int att_u32x4_t;
           att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(o_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4)));
           const att_u32x4_t pv = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
-#if ATT_NT_O
-          __builtin_nontemporal_store(pv, op);
-#else
           *op = pv;
-#endif
         }
       }
       asm volatile("" ::: "memory");

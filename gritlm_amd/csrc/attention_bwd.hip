@@ -30,10 +30,6 @@ typedef const __attribute__((address_space(1))) void* ab_gptr_t;
 typedef __attribute__((address_space(3))) void* ab_lptr_t;
 typedef __attribute__((ext_vector_type(4))) short ab_s16x4_t;
 
-// AB_ASM_DKDV = 1 (default): the dK / dV loop with inline-asm LDS reads (below); 0 = the round-2 loop, kept for tools/ubench/attn_bwd_ab.bin
-#ifndef AB_ASM_DKDV
-#define AB_ASM_DKDV 1
-#endif
 // s_waitcnt through the builtin (gfx9 encoding) so that the waitcnt insertion pass sees it (cf. attention.hip)
 #define AB_WAIT_VM0()                       \
   do {                                      \
@@ -250,13 +246,11 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     l_ = lrow[qc * qs];
     d_ = drow[qc * qs];
   };
-#if AB_ASM_DKDV
-  // (asm path: the statistics of tile n + 1 are requested during tile n, BEHIND its LDS-DMA, and are covered by the vmcnt(0) at the
-  //  top of tile n + 1 -- requested at the top of their own tile, hipcc's wait for them (vmcnt(0): the DMA sits in a conditional
-  //  branch, so it cannot count) would pull the whole DMA of the next tile in front of the first softmax)
+  // the statistics of tile n + 1 are requested during tile n, BEHIND its LDS-DMA, and are covered by the vmcnt(0) at the top of tile
+  // n + 1 -- requested at the top of their own tile, hipcc's wait for them (vmcnt(0): the DMA sits in a conditional branch, so it
+  // cannot count) would pull the whole DMA of the next tile in front of the first softmax
   float next_l = 0.f, next_d = 0.f;
   if (ntl > 0) load_stats(0, next_l, next_d);
-#endif
   for (int n = 0; n < ntl; ++n) {
     AB_WAIT_VM0();
     __builtin_amdgcn_s_barrier();
@@ -265,15 +259,9 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     tile_of(n, h_t, qt);
     float raw_l, raw_d, my_l = 0.f, my_d = 0.f;
     const bool q_in = qt * 64 + lane < S;
-#if AB_ASM_DKDV
     raw_l = next_l; raw_d = next_d;
-#else
-    // (issued here and first used after the S / dP products; the next tile's DMA is not in flight yet, so the wait for them is short)
-    load_stats(n, raw_l, raw_d);
-#endif
     const char* q_img = smem + (n & 1) * AB_STAGE;
     const char* d_img = q_img + AB_IMG;
-#if AB_ASM_DKDV
     // Round 3, second half: every LDS fragment read of the tile is inline asm with counted lgkmcnt (cf. attention.hip).  What it buys here:
     //  * the row fragments stream through THREE register sets two k-slices ahead of their products (24 registers instead of the 64 of a
     //    whole half requested up front), the transposed fragments come in two groups of 8 (the second one in flight under the first one's
@@ -400,72 +388,6 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
 #undef DK_B_MMA
 #undef DK_SOFTMAX
 #undef DK_HALF
-    }
-    continue;
-#endif
-    // One wave per SIMD: nothing else hides the LDS latency, so the fragment reads of a phase are issued as a block AHEAD of the
-    // products that consume them (sched_barrier pins the blocks; hipcc otherwise sinks every read to its use and waits for each):
-    //   reads A(qb) | products A(qb): S^T, dP^T ; reads B(qb) | softmax(qb) ; reads A(qb+1) | products B(qb): dV, dK | ...
-    bf16x8_t fa[2][8], fb[2][4][2];                 // fa[operand][ks]; fb[c][db][operand]   (operand 0 = Q side, 1 = dO side)
-    auto read_a = [&](int qb) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { fa[0][ks] = frag_rm(q_img, qb, ks, lane); fa[1][ks] = frag_rm(d_img, qb, ks, lane); }
-    };
-    read_a(0);
-    AB_SCHED_FENCE();
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      f32x16_t s, dp;
-      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {              // the first product of a chain takes the inline constant 0 as accumulator
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][ks], kf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][ks], vf[ks], ks == 0 ? zero16 : dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int db = 0; db < 4; ++db) { fb[c][db][0] = frag_tr(q_img, db, qb, c, trl); fb[c][db][1] = frag_tr(d_img, db, qb, c, trl); }
-      AB_SCHED_FENCE();
-      // the next tile's DMA goes out behind the tile's LAST transposing reads: hipcc puts a vmcnt(0) in front of every
-      // ds_read_b64_tr_b16 that follows an LDS-DMA (it treats the two as aliasing), which would wait for the fresh DMA
-      if (qb == 1 && n + 1 < ntl) stage(n + 1, (n + 1) & 1);
-      if (qb == 0) {                                // first use of the statistics loaded at the tile top
-        my_l = q_in ? raw_l * 1.4426950408889634f : INFINITY;
-        my_d = q_in ? raw_d : 0.f;
-      }
-      // regs 4g..4g+3 <-> q = 32qb + 8g + 4hi + 0..3
-      // the statistics of the half's 32 queries, fetched as a block (hipcc would otherwise fetch, wait and use them one by one)
-      float lv[16], dl[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int src = (qb * 32 + 8 * (r >> 2) + (r & 3) + 4 * hi) << 2;
-        lv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_l)));
-        dl[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_d)));
-      }
-      AB_SCHED_FENCE();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = qb * 32 + 8 * (r >> 2) + (r & 3);                 // + 4 hi
-        const int qd = qt * 64 + ql + 4 * hi - key;                                        // query - key
-        const bool seen = key_ok & ((causal == 0) | (qd >= 0)) & ((window == 0) | (qd < window));   // bitwise: no short-circuit branches
-        const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[r]);                 // unconditional: a select, not a branch
-        const float p = seen ? e : 0.f;
-        s[r] = p;
-        dp[r] = p * (dp[r] - dl[r]);
-      }
-      bf16x8_t pb[2], dsb[2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) { pb[c] = pack8(s, c); dsb[c] = pack8(dp, c); }
-      if (qb == 0) read_a(1);
-      AB_SCHED_FENCE();
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][db][1], pb[c], dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][db][0], dsb[c], dk[db], 0, 0, 0);
-        }
     }
   }
   // every wave is done with the ring: it becomes the transposition buffer of the full-line gradient stores

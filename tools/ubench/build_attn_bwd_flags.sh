@@ -1,5 +1,6 @@
 #!/bin/bash
-# Private attention-backward libraries for tools/ubench/attn_bwd_ab.bin from the CURRENT attention_bwd.hip with extra compiler flags:
+# Private attention-backward libraries for tools/ubench/attn_bwd_ab.bin from the CURRENT attention_bwd.hip with extra compiler flags
+# (the reference kernel of a comparison comes from git history: build_attn_bwd_ab.sh <commit>):
 #   build_attn_bwd_flags.sh name1 "-DFLAG_A" name2 "-DFLAG_B" ...   ->  tools/ubench/_var/libattn_bwd_<name>.so
 set -e
 cd "$(dirname "$0")/../.."

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Private attention-forward libraries for tools/ubench/attn_ab.bin from the CURRENT attention.hip with extra compiler flags:
+# Private attention-forward libraries for tools/ubench/attn_ab.bin from the CURRENT attention.hip with extra compiler flags (how the
+# round-3 levers were A/B'd one by one; the knobs they used are resolved in the source now -- the reference kernel of a comparison comes
+# from git history: build_attn_ab.sh <commit>):
 #   build_attn_flags.sh name1 "-DFLAG_A" name2 "-DFLAG_B -DFLAG_C" ...   ->  tools/ubench/_var/libattn_<name>.so
 set -e
 cd "$(dirname "$0")/../.."
