@@ -184,6 +184,23 @@ class GradCacheStep:
         self.profile = None        # set to a dict to collect per-step timings (ms): loss (similarity GEMM + CE + rep grads), the
                                    # stream time blocked on the rep gather (exposed, non-overlapped part) and on the gradient all-reduce
 
+    def _pass1_rows(self, model_input: Dict) -> int:
+        """Rows per pass-1 call for this tower: ``pass1_chunk_size``, capped so that one call stays at or below
+        ``GRIT_GRADCACHE_PASS1_TOKENS`` padded tokens (default 65536 = 128 rows x 512) -- the no-grad forward's scratch activations grow
+        with the call (4.3 GB at 65536 tokens of the 7B shape), and a long-sequence tower (2048-token passages) must not turn the
+        reference's memory knob into a 4x larger allocation -- in whole multiples of the pass-2 chunk and never below it."""
+        ids = model_input.get("input_ids") if isinstance(model_input, dict) else None
+        seq = int(ids.shape[1]) if isinstance(ids, torch.Tensor) and ids.dim() == 2 else 0
+        rows = self.pass1_chunk_size
+        if seq > 0:
+            try:
+                cap_tokens = int(os.environ.get("GRIT_GRADCACHE_PASS1_TOKENS", "65536"))
+            except ValueError:
+                cap_tokens = 65536
+            cap_rows = (cap_tokens // seq) // self.chunk_size * self.chunk_size
+            rows = min(rows, max(self.chunk_size, cap_rows))
+        return max(self.chunk_size, rows)
+
     def profile_summary(self) -> dict:
         """Resolve the recorded CUDA events into {key: total ms} (call after torch.cuda.synchronize())."""
         out = {}
@@ -201,7 +218,8 @@ class GradCacheStep:
         nq = sum(_rows(c) for c in q_chunks); npas = sum(_rows(c) for c in p_chunks)
         # pass 1 (the cross-rank exchange rides along, chunk by chunk); its calls may span several pass-2 chunks (pass1_chunk_rows)
         if self.pass1_chunk_size != self.chunk_size:
-            q1_chunks, p1_chunks = split_inputs(query, self.pass1_chunk_size), split_inputs(passage, self.pass1_chunk_size)
+            q1_chunks = split_inputs(query, self._pass1_rows(query))
+            p1_chunks = split_inputs(passage, self._pass1_rows(passage))
         else:
             q1_chunks, p1_chunks = q_chunks, p_chunks
         gq = gp = None
