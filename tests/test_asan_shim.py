@@ -1,0 +1,17 @@
+"""The C-ABI host shim under AddressSanitizer + UBSan (tools/asan_host_shim.sh): every rejected-argument call of tests/test_abi.py runs
+against a host-instrumented build of the library (device code untouched).  No GPU needed."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"), reason="no shared ASAN runtime in this image")
+def test_abi_tests_pass_on_the_sanitizer_build():
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan_host_shim.sh")], capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0, tail
+    assert "passed" in r.stdout and "AddressSanitizer" not in tail and "runtime error" not in tail, tail
