@@ -105,11 +105,17 @@ class ChunkGather:
     list-API gathers + torch.cat of ``_dist_gather_tensor`` (gritlm/training/model.py:49-60); result order is identical (rank r owns
     rows [r * n_local, (r + 1) * n_local), the order the targets ``arange(B) * G`` rely on, :45-46)."""
 
-    def __init__(self, n_local: int, width: int, dtype, device):
+    def __init__(self, n_local: int, width: int, dtype, device, group_rows: "int | None" = None):
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.n_local, self.width, self.dtype, self.device = n_local, width, dtype, device
         self.items = []            # (slab [W, n, H], work handle, source kept alive until the collective completed)
         self.calls = 0
+        # The collective schedule must be the SAME on every rank, whatever each rank's model calls looked like: a rank whose batch was
+        # padded to a longer sequence may run pass 1 in smaller calls (GradCacheStep._pass1_rows caps a call by tokens).  With
+        # ``group_rows`` set, rows are gathered in groups of exactly that many (a configuration constant) plus one remainder group at
+        # ``flush`` -- a function of n_local alone, which all ranks share (all_gather needs equal shapes anyway).
+        self.group_rows = int(group_rows) if group_rows else 0
+        self.pending, self.pending_rows = [], 0
         # GRIT_NATIVE_COMM=1: the same gathers on RCCL directly through the C ABI (grit_comm_allgather_packed, gritlm_amd/comm.py) on a
         # side stream ordered with events, instead of torch.distributed
         self.native = None
@@ -119,7 +125,29 @@ class ChunkGather:
                 self.native = _comm.NativeComm.get(device)
 
     def add(self, reps: torch.Tensor):
-        reps = reps.detach().contiguous()
+        reps = reps.detach()
+        if not self.group_rows:
+            return self._gather(reps.contiguous())
+        if not self.pending and reps.shape[0] == self.group_rows:        # the usual case: one call = one group, no copy
+            return self._gather(reps.contiguous())
+        self.pending.append(reps)
+        self.pending_rows += reps.shape[0]
+        while self.pending_rows >= self.group_rows:
+            self._gather(self._take(self.group_rows))
+
+    def flush(self):
+        """The remainder group (fewer than ``group_rows`` rows), once the tower's last call has been added."""
+        if self.pending_rows:
+            self._gather(self._take(self.pending_rows))
+
+    def _take(self, n: int) -> torch.Tensor:
+        buf = self.pending[0] if len(self.pending) == 1 else torch.cat(self.pending, dim=0)
+        head, tail = buf[:n].contiguous(), buf[n:]
+        self.pending = [tail] if tail.shape[0] else []
+        self.pending_rows = int(tail.shape[0])
+        return head
+
+    def _gather(self, reps: torch.Tensor):
         n = reps.shape[0]
         self.calls += 1
         if self.native is not None:
@@ -131,6 +159,7 @@ class ChunkGather:
         self.items.append((slab, work, reps))
 
     def finish(self) -> torch.Tensor:
+        self.flush()
         for _, work, _ in self.items:
             work.wait()
         slabs = [s for s, _, _ in self.items]
@@ -229,12 +258,16 @@ class GradCacheStep:
                 for c in chunks:
                     r = model.encode(c)
                     if cross:
+                        # groups of pass1_chunk_size rows: the same collectives on every rank even when _pass1_rows differs between
+                        # ranks (batches padded to different lengths)
                         if which == "q" and gq is None:
-                            gq = ChunkGather(nq, r.shape[1], r.dtype, r.device)
+                            gq = ChunkGather(nq, r.shape[1], r.dtype, r.device, self.pass1_chunk_size)
                         if which == "p" and gp is None:
-                            gp = ChunkGather(npas, r.shape[1], r.dtype, r.device)
+                            gp = ChunkGather(npas, r.shape[1], r.dtype, r.device, self.pass1_chunk_size)
                         (gq if which == "q" else gp).add(r)
                     lst.append(r)
+                if cross and (gq if which == "q" else gp) is not None:
+                    (gq if which == "q" else gp).flush()         # the tower's remainder goes out before the next tower starts
         q_reps, p_reps = torch.cat(q_list, dim=0), torch.cat(p_list, dim=0)
         # loss + representation-gradient cache
         q_leaf, p_leaf = q_reps.detach().requires_grad_(), p_reps.detach().requires_grad_()

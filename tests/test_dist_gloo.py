@@ -96,6 +96,59 @@ def test_two_rank_gradcache_step_equals_reference_global_batch(tmp_path):
         np.testing.assert_array_equal(ret[0]["grads"][n], ret[1]["grads"][n])      # replicas stay in lock-step
 
 
+def _gc_uneven_worker(rank, world, port, model_dir, ret):
+    """Rank 1's passages are padded 8 columns further than rank 0's (a collator pads every rank's batch to ITS longest text), and the
+    pass-1 token cap sits between the two lengths: rank 0 runs pass 1 in calls of 4 rows, rank 1 in calls of 2."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+        import gritlm_amd.training.gradcache as gcmod
+        g = np.load(os.path.join(GOLDEN, "gradcache_tiny.npz"))
+        m = GritLMTrainModel(model_name_or_path=model_dir, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=0.02, negatives_cross_device=True, device="cpu")
+        m.model.train()
+        B, G = g["q_ids"].shape[0], int(g["group"])
+        bq = B // world
+        sl_q, sl_p = slice(rank * bq, (rank + 1) * bq), slice(rank * bq * G, (rank + 1) * bq * G)
+        q = {"input_ids": torch.from_numpy(g["q_ids"][sl_q]), "attention_mask": torch.from_numpy(g["q_mask"][sl_q])}
+        p_ids, p_mask = torch.from_numpy(g["p_ids"][sl_p]), torch.from_numpy(g["p_mask"][sl_p])
+        seq = p_ids.shape[1]
+        os.environ["GRIT_GRADCACHE_PASS1_TOKENS"] = str(4 * seq)
+        if rank == 1:
+            p_ids = torch.cat([p_ids, torch.zeros((p_ids.shape[0], 8), dtype=p_ids.dtype)], dim=1)
+            p_mask = torch.cat([p_mask, torch.zeros((p_mask.shape[0], 8), dtype=p_mask.dtype)], dim=1)
+        p = {"input_ids": p_ids, "attention_mask": p_mask}
+        step = GradCacheStep(m, chunk_size=2, pass1_chunk_size=4)
+        rows = step._pass1_rows(p)
+        sizes = []
+        orig = gcmod.ChunkGather._gather
+        def spy(self, reps):
+            sizes.append(int(reps.shape[0]))
+            return orig(self, reps)
+        gcmod.ChunkGather._gather = spy
+        loss = step(q, p)
+        ret[rank] = dict(loss=loss.item(), pass1_rows=rows, gather_sizes=sizes)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_schedule_does_not_depend_on_a_ranks_padding(tmp_path):
+    """The cross-rank gathers are a function of the configuration and the per-rank batch size only: ranks whose pass-1 calls differ in
+    size (different padded lengths under the token cap) still issue the same collectives, and the loss is the reference's."""
+    import synth
+    d = synth.build_mistral_dir(str(tmp_path / "m32"), "tiny", 0, "float32")
+    g = np.load(os.path.join(GOLDEN, "gradcache_tiny.npz"))
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_gc_uneven_worker, args=(world, _free_port(), d, ret), nprocs=world, join=True)
+    assert ret[0]["pass1_rows"] == 4 and ret[1]["pass1_rows"] == 2          # the premise: the ranks' model calls differ
+    assert ret[0]["gather_sizes"] == ret[1]["gather_sizes"], (ret[0]["gather_sizes"], ret[1]["gather_sizes"])
+    for r in range(world):
+        assert abs(ret[r]["loss"] - float(g["loss_gradcache"])) < 2e-4
+
+
 def _enc_worker(rank, world, port, model_dir, sents, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
