@@ -233,7 +233,9 @@ class GritLM(torch.nn.Module):
             chunks.append(emb)
 
         if convert_to_tensor:
-            result = torch.cat(chunks, dim=0)
+            result = torch.cat(chunks, dim=0)             # no sentences: torch.cat([]) raises, as in the reference (:163)
+        elif not chunks:
+            raise ValueError("need at least one array to concatenate")      # what the reference's np.concatenate([]) raises (:163)
         else:
             # ONE device->host copy for the whole call (the reference syncs per batch, :164)
             result = torch.cat(chunks, dim=0).to(torch.float32).cpu().numpy()

@@ -52,6 +52,15 @@ def test_mistral_cpu_matches_reference_including_instruction_masking(gold, dirs)
     np.testing.assert_allclose(corp, m.encode(["w1 w2 w3", "w4"], max_length=16), atol=1e-7)
 
 
+def test_no_sentences_raises_like_the_reference(dirs):
+    """gritlm.py:162-164: np.concatenate([]) -> ValueError; torch.cat([]) raises too (ValueError or RuntimeError by torch version)."""
+    m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu")
+    with pytest.raises(ValueError, match="at least one array"):
+        m.encode([], max_length=8)
+    with pytest.raises((ValueError, RuntimeError)):
+        m.encode([], max_length=8, convert_to_tensor=True)
+
+
 def test_constructor_contract(dirs):
     with pytest.raises(ValueError, match="Mixed attention"):
         GritLM(dirs["m32"], attn="bbcb", device="cpu")
