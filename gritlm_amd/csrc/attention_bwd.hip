@@ -625,7 +625,7 @@ static int attn_bwd_padded(int causal, int window, const void* qkv, const uint64
                            float* delta, void* dqkv, int B, int S, int nq, int nkv, int d, int64_t qkv_stride,
                            int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && key_bits && out && dout && lse && delta && dqkv, GRIT_E_BADARG, "grit_attn_bidir_bwd: null pointer");
-  GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_bwd: bad sizes");
+  GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0 && S <= (1 << 30) && nq <= 65535 && nkv <= 65535, GRIT_E_BADARG, "grit_attn_bidir_bwd: bad sizes");
   GRIT_REQUIRE(d == AB_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_bwd: head_dim=%d (only 128 is built)", d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_bwd: nq not a multiple of nkv");
   GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "grit_attn_bidir_bwd: window=%d (causal attention only)", window);
@@ -654,7 +654,8 @@ static int attn_bwd_varlen(int causal, int window, const void* qkv, const int32_
                            float* delta, void* dqkv, int B, int max_len, int64_t T, int nq, int nkv, int d,
                            int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   GRIT_REQUIRE(qkv && cu_seqlens && out && dout && lse && delta && dqkv, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: null pointer");
-  GRIT_REQUIRE(B > 0 && max_len > 0 && T > 0 && nq > 0 && nkv > 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: bad sizes");
+  GRIT_REQUIRE(B > 0 && max_len > 0 && T > 0 && nq > 0 && nkv > 0 && max_len <= (1 << 30) && nq <= 65535 && nkv <= 65535, GRIT_E_BADARG,
+               "grit_attn_bidir_varlen_bwd: bad sizes");
   GRIT_REQUIRE(d == AB_D, GRIT_E_UNSUPPORTED, "grit_attn_bidir_varlen_bwd: head_dim=%d (only 128 is built)", d);
   GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: nq not a multiple of nkv");
   GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "grit_attn_bidir_varlen_bwd: window=%d (causal attention only)", window);

@@ -459,7 +459,9 @@ extern "C" int grit_kv_append(const void* qkv, void* cache_k, void* cache_v, con
 }
 
 extern "C" int64_t grit_attn_decode_workspace_floats(int B, int nq, int nkv, int Lmax) {
-  const int splits = (Lmax + AD_CH - 1) / AD_CH;
+  // a size query has no error channel: 0 for sizes the compute call rejects
+  if (B <= 0 || nq <= 0 || nkv <= 0 || Lmax <= 0 || B > 65535 || nkv > 65535 || nq > 65535 || Lmax > 512 * AD_CH) return 0;
+  const int64_t splits = ((int64_t)Lmax + AD_CH - 1) / AD_CH;
   return (int64_t)B * nkv * splits * (nq / nkv) * (AD_D + 2);
 }
 
@@ -469,9 +471,9 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
   if (B == 0) return GRIT_OK;
   GRIT_REQUIRE(q && cache_k && cache_v && lens && out && workspace, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(d == AD_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
+  GRIT_REQUIRE(B > 0 && Lmax > 0 && nq > 0 && nkv > 0 && B <= 65535 && nkv <= 65535 && nq <= 65535, GRIT_E_BADARG, "%s: bad sizes", name);
   GRIT_REQUIRE(nq % nkv == 0 && nq / nkv <= AD_G, GRIT_E_UNSUPPORTED, "%s: %d query heads per kv head (max %d)", name, nq / nkv, AD_G);
-  GRIT_REQUIRE(B > 0 && Lmax > 0 && B <= 65535 && nkv <= 65535, GRIT_E_BADARG, "%s: bad sizes", name);
-  GRIT_REQUIRE((Lmax + AD_CH - 1) / AD_CH <= 512, GRIT_E_UNSUPPORTED, "%s: Lmax=%d > %d", name, Lmax, 512 * AD_CH);
+  GRIT_REQUIRE(Lmax <= 512 * AD_CH, GRIT_E_UNSUPPORTED, "%s: Lmax=%d > %d", name, Lmax, 512 * AD_CH);
   const int splits = (Lmax + AD_CH - 1) / AD_CH;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)splits, (unsigned)nkv, (unsigned)B);
@@ -498,7 +500,8 @@ extern "C" int grit_attn_decode_rope(const void* qkv, const float* cos_tab, cons
                                      void* out, float* workspace, int B, int nq, int nkv, int d, int Lmax, int64_t qkv_stride, int64_t out_stride,
                                      float scale, void* stream) {
   GRIT_REQUIRE(cos_tab && sin_tab, GRIT_E_BADARG, "grit_attn_decode_rope: null pointer");
-  GRIT_REQUIRE(qkv_stride >= (int64_t)(nq + 2 * nkv) * d, GRIT_E_BADARG, "grit_attn_decode_rope: qkv_stride too small");
+  GRIT_REQUIRE(nq > 0 && nkv > 0 && nq <= 65535 && nkv <= 65535 && d > 0 && d <= 65535, GRIT_E_BADARG, "grit_attn_decode_rope: bad sizes");
+  GRIT_REQUIRE(qkv_stride >= ((int64_t)nq + 2 * (int64_t)nkv) * d, GRIT_E_BADARG, "grit_attn_decode_rope: qkv_stride too small");
   return attn_decode_launch("grit_attn_decode_rope", qkv, cache_k, cache_v, lens, out, workspace, cos_tab, sin_tab, B, nq, nkv, d, Lmax, qkv_stride,
                             out_stride, scale, stream);
 }

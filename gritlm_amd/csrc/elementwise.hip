@@ -259,7 +259,8 @@ static int rope_launch(void* qkv, const float* cos_tab, const float* sin_tab, co
   GRIT_REQUIRE(qkv && cos_tab && sin_tab, GRIT_E_BADARG, "grit_rope_qk_inplace: null pointer");
   GRIT_REQUIRE(T >= 0 && S > 0 && nq > 0 && nkv >= 0 && d > 0, GRIT_E_BADARG, "grit_rope_qk_inplace: bad sizes");
   GRIT_REQUIRE(d % 16 == 0, GRIT_E_UNSUPPORTED, "grit_rope_qk_inplace: head_dim=%d must be a multiple of 16", d);
-  GRIT_REQUIRE(row_stride % 8 == 0 && row_stride >= (int64_t)(nq + nkv) * d, GRIT_E_BADARG, "grit_rope_qk_inplace: bad row_stride");
+  GRIT_REQUIRE(row_stride % 8 == 0 && row_stride >= ((int64_t)nq + nkv) * d, GRIT_E_BADARG, "grit_rope_qk_inplace: bad row_stride");
+  GRIT_REQUIRE((int64_t)nq + nkv <= INT32_MAX, GRIT_E_BADARG, "grit_rope_qk_inplace: bad sizes");
   GRIT_REQUIRE(aligned16(qkv) && aligned16(cos_tab) && aligned16(sin_tab), GRIT_E_BADARG, "grit_rope_qk_inplace: pointers must be 16-byte aligned");
   if (T == 0) return GRIT_OK;
   const int nheads = nq + nkv;
@@ -272,7 +273,7 @@ static int rope_launch(void* qkv, const float* cos_tab, const float* sin_tab, co
 
 int grit_mask_pack(const int64_t* mask, uint64_t* bits, int B, int S, void* stream) {
   GRIT_REQUIRE(mask && bits, GRIT_E_BADARG, "grit_mask_pack: null pointer");
-  GRIT_REQUIRE(B > 0 && S > 0, GRIT_E_BADARG, "grit_mask_pack: bad sizes");
+  GRIT_REQUIRE(B > 0 && S > 0 && S <= (1 << 30), GRIT_E_BADARG, "grit_mask_pack: bad sizes");
   const int W = (S + 63) / 64;
   const int64_t words = (int64_t)B * W;
   hipLaunchKernelGGL(mask_pack_k, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mask, bits, B, S, W);

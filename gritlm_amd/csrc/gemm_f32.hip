@@ -177,6 +177,8 @@ static int launch_shape(const float* A, const float* B, float* C, int M, int N, 
 int launch_f32_gemm_strided(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
                             int64_t ldc, float alpha, hipStream_t st) {
   if (M <= 0 || N <= 0) return GRIT_OK;
+  GRIT_REQUIRE(K > 0 && M <= (1 << 30) && N <= (1 << 30) && K <= (1 << 30), GRIT_E_BADARG, "f32 gemm: bad sizes M=%d N=%d K=%d", M, N, K);
+  GRIT_REQUIRE((int64_t)((M + 31) / 32) * ((N + 63) / 64) < (1ll << 31), GRIT_E_UNSUPPORTED, "f32 gemm: grid too large (M=%d N=%d)", M, N);
   // LDS image by the contiguous index; an operand with no unit stride is staged k-major through the scalar path
   const bool ak = (sak == 1) || (sam != 1), bk = (sbk == 1) || (sbn != 1);
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };

@@ -86,8 +86,8 @@ extern "C" int grit_infonce_rows_fwd_bwd(const float* q, const float* p, float i
   GRIT_REQUIRE(q && p && scores && loss && loss_rows, GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: null pointer");
   GRIT_REQUIRE(Nq > 0 && Np > 0 && H > 0, GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad sizes");
   GRIT_REQUIRE(Np % Nq == 0, GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: Np=%d is not a multiple of Nq=%d (target = i * Np/Nq)", Np, Nq);
-  GRIT_REQUIRE((dq == nullptr) || (q_off >= 0 && nq_loc > 0 && q_off + nq_loc <= Nq), GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad q range");
-  GRIT_REQUIRE((dp == nullptr) || (p_off >= 0 && np_loc > 0 && p_off + np_loc <= Np), GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad p range");
+  GRIT_REQUIRE((dq == nullptr) || (q_off >= 0 && nq_loc > 0 && (int64_t)q_off + nq_loc <= Nq), GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad q range");
+  GRIT_REQUIRE((dp == nullptr) || (p_off >= 0 && np_loc > 0 && (int64_t)p_off + np_loc <= Np), GRIT_E_BADARG, "grit_infonce_rows_fwd_bwd: bad p range");
   hipStream_t st = (hipStream_t)stream;
   // scores[i,j] = inv_t * sum_h q[i,h] p[j,h]
   int rc = launch_f32_gemm(q, p, scores, Nq, Np, H, H, 1, 1, H, Np, inv_temperature, st);

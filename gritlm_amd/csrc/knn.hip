@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(TK_T) topk_chunk_k(const float* __restrict__ v
 using namespace grit;
 
 extern "C" int64_t grit_knn_workspace_bytes(int Q, int64_t N, int k) {
-  if (Q <= 0 || N <= 0 || k <= 0) return 0;
+  if (Q <= 0 || N <= 0 || k <= 0 || Q > 65535 || N >= (1ll << 31) || k > TK_C / 2) return 0;   // 0 for sizes grit_knn_topk rejects
   const int64_t c1 = (N + TK_C - 1) / TK_C;
   // scores [Q,N] fp32 + two candidate buffers (values fp32 + ids int64) of the first level's size
   return (int64_t)Q * N * 4 + 2 * (int64_t)Q * c1 * k * 12 + 256;

@@ -240,6 +240,7 @@ extern "C" int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* 
 }
 
 extern "C" int64_t grit_moe_index_workspace_ints(int64_t T, int E) {
+  if (T < 0 || E <= 0 || T > (1ll << 40)) return 0;         // 0 for sizes grit_moe_index rejects
   const int64_t nch = (2 * T + IDX_CHUNK - 1) / IDX_CHUNK;
   return 2 * (nch > 0 ? nch : 1) * E;
 }
@@ -248,7 +249,7 @@ extern "C" int grit_moe_index(const int32_t* experts, int64_t T, int E, int32_t*
                               void* stream) {
   GRIT_REQUIRE(counts && workspace, GRIT_E_BADARG, "grit_moe_index: null pointer");
   GRIT_REQUIRE(E > 0 && E <= MOE_MAX_E, GRIT_E_UNSUPPORTED, "grit_moe_index: num_experts=%d (max %d)", E, MOE_MAX_E);
-  GRIT_REQUIRE(T >= 0 && 2 * T < (1ll << 31), GRIT_E_BADARG, "grit_moe_index: bad T");
+  GRIT_REQUIRE(T >= 0 && T < (1ll << 30), GRIT_E_BADARG, "grit_moe_index: bad T");
   GRIT_REQUIRE(T == 0 || (experts && row_token && rows), GRIT_E_BADARG, "grit_moe_index: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = 2 * T;

@@ -11,6 +11,8 @@
  *   - `stream` is a hipStream_t passed as void*; NOTHING synchronises the device or allocates;
  *   - bf16 tensors are passed as `const void*` to 16-bit storage, row-major, innermost contiguous;
  *   - return 0 on success, negative GRIT_E_* on failure (then grit_last_error_string() explains);
+ *   - the *_workspace_* size queries have no error channel: they return 0 for sizes their compute entry point rejects
+ *     (which then reports the error); sizes are range-checked BEFORE any arithmetic on them (tools/fuzz_abi.py);
  *   - re-entrant and thread-safe for distinct streams (forward from the Python main thread,
  *     backward from autograd worker threads).
  */
