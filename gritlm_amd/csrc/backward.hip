@@ -1,6 +1,8 @@
 // HBM-bound backward pieces of the contrastive training step (autograd of the ops in elementwise.hip /
 // the MLP activation): RMSNorm backward (+ fused residual-gradient add), SwiGLU forward/backward on the
 // concatenated [gate | up] layout used by the training engine, embedding scatter-add, small helpers.
+#include <atomic>
+
 #include "common.h"
 
 namespace grit {
@@ -263,6 +265,19 @@ static inline int grid_for(int64_t items) {
 
 using namespace grit;
 
+// A dynamic-LDS opt-in is a PER-DEVICE function attribute: set once per (kernel, device), from whichever thread gets there first
+// (autograd worker threads call into the backward entry points concurrently).
+template <typename KernelT>
+static void lds_optin_once(KernelT kernel, std::atomic<uint64_t>& done, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
+
 extern "C" {
 
 int64_t grit_rmsnorm_bwd_workspace_rows(int64_t T) {
@@ -279,11 +294,8 @@ int grit_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* d
   GRIT_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w) && aligned16(dx) && (dres == nullptr || aligned16(dres)), GRIT_E_BADARG,
                "grit_rmsnorm_bwd: pointers must be 16-byte aligned");
   const int nblk = (int)grit_rmsnorm_bwd_workspace_rows(T);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)rmsnorm_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> optin{0};
+  lds_optin_once(rmsnorm_bwd_k, optin, 128 * 1024);
   hipStream_t st = (hipStream_t)stream;
 #define GRIT_RMSBWD_REG(NCH_)                                                                                                   \
   hipLaunchKernelGGL(rmsnorm_bwd_reg_k<NCH_>, dim3(nblk), dim3(256), 0, st, (const uint4*)dy, (const uint4*)x, (const uint4*)w,      \

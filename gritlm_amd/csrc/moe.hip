@@ -5,6 +5,8 @@
 //   combine : out = residual + (w_a * y_a  (+)  w_b * y_b) with the reference's bf16 rounding points (:876, :880, decoder :945)
 // The expert MLPs themselves are two launches of grit_gemm_bf16_nt_grouped (gathered A rows, SwiGLU epilogue; then w2).
 // All three kernels are HBM/latency-bound byte work; no MFMA.
+#include <atomic>
+
 #include "common.h"
 
 namespace grit {
@@ -202,6 +204,19 @@ __global__ void __launch_bounds__(256) moe_combine_bwd_k(const uint16_t* __restr
 
 using namespace grit;
 
+// A dynamic-LDS opt-in is a PER-DEVICE function attribute: set once per (kernel, device), from whichever thread gets there first
+// (autograd worker threads call into the backward entry points concurrently).
+template <typename KernelT>
+static void lds_optin_once(KernelT kernel, std::atomic<uint64_t>& done, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
+
 extern "C" int grit_moe_combine_bwd(const void* dout, const void* y, const int32_t* row_token, const int32_t* rows, const float* weights,
                                     void* dy, float* dw, int64_t T, int H, void* stream) {
   if (T == 0) return GRIT_OK;
@@ -229,8 +244,8 @@ extern "C" int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* 
   hipStream_t st = (hipStream_t)stream;
 #define GRIT_ROUTER(E_)                                                                                                       \
   do {                                                                                                                        \
-    static bool set_ = false;                                                                                                 \
-    if (!set_) { (void)hipFuncSetAttribute((const void*)moe_router_top2_k<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
+    static std::atomic<uint64_t> optin_{0};                                                                                   \
+    lds_optin_once(moe_router_top2_k<E_>, optin_, 160 * 1024);                                                                \
     hipLaunchKernelGGL(moe_router_top2_k<E_>, dim3((unsigned)nb), dim3(256), lds, st, (const uint16_t*)x, (const uint16_t*)gate_w, T, H,  \
                        experts, weights);                                                                                     \
   } while (0)

@@ -6,6 +6,8 @@
 // 1 KiB per wave-instruction), skips rows whose pooling weight is zero (padding / instruction tokens are
 // never read), accumulates in fp32 registers and normalises in the same launch.  HBM-bound:
 // algorithmic bytes = B*S*H*2 read + B*H*4 written.
+#include <atomic>
+
 #include "common.h"
 
 namespace grit {
@@ -305,6 +307,19 @@ __global__ void __launch_bounds__(POOL_THREADS) pool_norm_varlen_bwd_k(const flo
 
 using namespace grit;
 
+// A dynamic-LDS opt-in is a PER-DEVICE function attribute: set once per (kernel, device), from whichever thread gets there first
+// (autograd worker threads call into the backward entry points concurrently).
+template <typename KernelT>
+static void lds_optin_once(KernelT kernel, std::atomic<uint64_t>& done, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
+
 extern "C" {
 
 int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* instr_len, float* out, float* inv_norm, int B, int S,
@@ -318,11 +333,8 @@ int grit_pool_norm_fwd(const void* hidden, const int64_t* mask, const int32_t* i
   GRIT_REQUIRE(aligned16(hidden) && aligned16(out), GRIT_E_BADARG, "grit_pool_norm_fwd: pointers must be 16-byte aligned");
   if (B == 0) return GRIT_OK;
   const size_t lds = 8 * (size_t)S + 64;
-  static bool attr_set_f = false;
-  if (!attr_set_f) {
-    (void)hipFuncSetAttribute((const void*)pool_norm_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set_f = true;
-  }
+  static std::atomic<uint64_t> optin_f{0};
+  lds_optin_once(pool_norm_fwd_k, optin_f, 160 * 1024);
   hipLaunchKernelGGL(pool_norm_fwd_k, dim3(B), dim3(POOL_THREADS), lds, (hipStream_t)stream, (const uint16_t*)hidden, mask, instr_len,
                      out, inv_norm, S, H, mode, normalize);
   GRIT_CHECK_LAUNCH("grit_pool_norm_fwd");
@@ -355,11 +367,8 @@ int grit_pool_norm_bwd(const float* y, const float* dy, const float* inv_norm, c
   GRIT_REQUIRE(lds <= 160 * 1024, GRIT_E_UNSUPPORTED, "grit_pool_norm_bwd: H=%d S=%d exceed LDS", H, S);
   GRIT_REQUIRE(aligned16(dhidden), GRIT_E_BADARG, "grit_pool_norm_bwd: pointers must be 16-byte aligned");
   if (B == 0) return GRIT_OK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pool_norm_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> optin_b{0};
+  lds_optin_once(pool_norm_bwd_k, optin_b, 160 * 1024);
   hipLaunchKernelGGL(pool_norm_bwd_k, dim3(B), dim3(POOL_THREADS), lds, (hipStream_t)stream, y, dy, inv_norm, mask, instr_len,
                      (uint16_t*)dhidden, S, H, mode, normalize);
   GRIT_CHECK_LAUNCH("grit_pool_norm_bwd");
@@ -376,11 +385,8 @@ int grit_pool_norm_varlen_bwd(const float* y, const float* dy, const float* inv_
   GRIT_REQUIRE(H % 8 == 0 && H <= 32768, GRIT_E_UNSUPPORTED, "grit_pool_norm_varlen_bwd: H=%d must be a multiple of 8, <= 32768", H);
   GRIT_REQUIRE(aligned16(dhidden), GRIT_E_BADARG, "grit_pool_norm_varlen_bwd: pointers must be 16-byte aligned");
   const size_t lds = 4 * (size_t)H + 64;
-  static bool attr_set_vb = false;
-  if (!attr_set_vb) {
-    (void)hipFuncSetAttribute((const void*)pool_norm_varlen_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set_vb = true;
-  }
+  static std::atomic<uint64_t> optin_vb{0};
+  lds_optin_once(pool_norm_varlen_bwd_k, optin_vb, 160 * 1024);
   hipLaunchKernelGGL(pool_norm_varlen_bwd_k, dim3(B), dim3(POOL_THREADS), lds, (hipStream_t)stream, y, dy, inv_norm, cu_seqlens, instr_len,
                      (uint16_t*)dhidden, H, mode, normalize);
   GRIT_CHECK_LAUNCH("grit_pool_norm_varlen_bwd");
