@@ -1519,8 +1519,8 @@ def _native_comm_worker(rank, port, model_dir, ret):
         from gritlm_amd.training import gradcache as gcm
         seen = []
         orig_init = gcm.ChunkGather.__init__
-        def spy(self, n_local, width, dtype, device):
-            orig_init(self, n_local, width, dtype, device)
+        def spy(self, n_local, width, dtype, device, *a, **k):
+            orig_init(self, n_local, width, dtype, device, *a, **k)
             seen.append((str(dtype), str(device), self.native is not None))
         gcm.ChunkGather.__init__ = spy
         gcs = GradCacheStep(m, chunk_size=2)
