@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gritlm_hip.h")
 
 ABI_VERSION = 2
 GRIT_OK, GRIT_E_BADARG, GRIT_E_UNSUPPORTED, GRIT_E_LAUNCH, GRIT_E_RCCL = 0, -1, -2, -3, -4
-EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ROPE, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5, 6
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ROPE, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD, EPI_RESIDUAL_F32 = 0, 1, 2, 3, 4, 5, 6, 7
 POOL_MODES = {"mean": 0, "weightedmean": 1, "cls": 2, "lasttoken": 3}
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -25,6 +25,8 @@ _SIGNATURES = {
     "grit_last_error_string": (C.c_char_p, []),
     "grit_embed_gather": (_i, [_p, _p, _p, _l, _i, _l, _p]),
     "grit_rmsnorm_fwd": (_i, [_p, _p, _p, _l, _i, _f, _p]),
+    "grit_embed_gather_f32": (_i, [_p, _p, _p, _l, _i, _l, _p]),
+    "grit_rmsnorm_fwd_f32in": (_i, [_p, _p, _p, _l, _i, _f, _p]),
     "grit_rope_qk_inplace": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _l, _i, _p]),
     "grit_rope_qk_inplace_pos": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _l, _i, _p]),
     "grit_attn_bidir_varlen_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),

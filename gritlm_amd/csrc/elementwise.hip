@@ -30,6 +30,21 @@ __global__ void __launch_bounds__(256) embed_gather_k(const uint4* __restrict__ 
   }
 }
 
+// fp32 residual stream (opt-in, DESIGN "precision policy"): the same gather, rows widened to fp32 (exact)
+__global__ void __launch_bounds__(256) embed_gather_f32_k(const uint4* __restrict__ table, const int64_t* __restrict__ ids,
+                                                          float4* __restrict__ out, int64_t T, int HC, int64_t V) {
+  const int64_t total = T * HC;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / HC;
+    const int c = (int)(i - t * HC);
+    int64_t id = ids[t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const uint4 v = table[id * HC + c];
+    out[2 * i] = make_float4(bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y));
+    out[2 * i + 1] = make_float4(bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w));
+  }
+}
+
 // ---------------------------------------------------------------- RMSNorm forward
 // scripts/modeling_mistral_gritlm.py:84-89.  One wave per row, row held in registers when H = NCH*512.
 __device__ __forceinline__ float sumsq8(const uint4& v) {
@@ -86,6 +101,52 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_generic_k(const uint4* __rest
   const float rs = rsqrtf(ss / (float)H + eps);
   uint4* yr = y + row * HC;
   for (int c = lane; c < HC; c += 64) yr[c] = norm8(xr[c], w[c], rs);
+}
+
+// RMSNorm of an fp32 residual stream: x [T,H] fp32 -> y bf16 = bf16(w * (x * rsqrt(mean(x^2) + eps))), ONE rounding (what the reference
+// computes when it runs in fp32, :84-89, rounded once to the bf16 operand the next GEMM takes).  One wave per row; a lane owns the
+// float4 at index c*64 + lane of every 256-element chunk c, so every load instruction covers 1 KiB contiguous and every store 512 B.
+template <int NCH>   // H = NCH * 256
+__global__ void __launch_bounds__(256) rmsnorm_fwd_f32in_reg_k(const float4* __restrict__ x, const uint2* __restrict__ w,
+                                                               uint2* __restrict__ y, int64_t T, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const int HQ = H >> 2;
+  const float4* xr = x + row * HQ;
+  float4 v[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) v[c] = xr[c * 64 + lane];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)H + eps);
+  uint2* yr = y + row * HQ;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const uint2 ww = w[c * 64 + lane];
+    yr[c * 64 + lane] = make_uint2(pack2bf_hw(bflo(ww.x) * (v[c].x * rs), bfhi(ww.x) * (v[c].y * rs)),
+                                   pack2bf_hw(bflo(ww.y) * (v[c].z * rs), bfhi(ww.y) * (v[c].w * rs)));
+  }
+}
+__global__ void __launch_bounds__(256) rmsnorm_fwd_f32in_generic_k(const float4* __restrict__ x, const uint2* __restrict__ w,
+                                                                   uint2* __restrict__ y, int64_t T, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const int HQ = H >> 2;
+  const float4* xr = x + row * HQ;
+  float ss = 0.f;
+  for (int c = lane; c < HQ; c += 64) { const float4 a = xr[c]; ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)H + eps);
+  uint2* yr = y + row * HQ;
+  for (int c = lane; c < HQ; c += 64) {
+    const float4 a = xr[c];
+    const uint2 ww = w[c];
+    yr[c] = make_uint2(pack2bf_hw(bflo(ww.x) * (a.x * rs), bfhi(ww.x) * (a.y * rs)), pack2bf_hw(bflo(ww.y) * (a.z * rs), bfhi(ww.y) * (a.w * rs)));
+  }
 }
 
 // ---------------------------------------------------------------- RoPE (in place on q,k of the fused qkv rows)
@@ -236,6 +297,42 @@ int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, fl
     hipLaunchKernelGGL(rmsnorm_fwd_generic_k, grid, block, 0, st, xp, wp, yp, T, H, eps);
   }
   GRIT_CHECK_LAUNCH("grit_rmsnorm_fwd");
+  return GRIT_OK;
+}
+
+int grit_embed_gather_f32(const void* table, const int64_t* ids, float* out, int64_t T, int H, int64_t V, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(table && ids && out, GRIT_E_BADARG, "grit_embed_gather_f32: null pointer");
+  GRIT_REQUIRE(T >= 0 && H > 0 && V > 0, GRIT_E_BADARG, "grit_embed_gather_f32: bad sizes T=%lld H=%d V=%lld", (long long)T, H, (long long)V);
+  GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_embed_gather_f32: H=%d must be a multiple of 8", H);
+  GRIT_REQUIRE(aligned16(table) && aligned16(out), GRIT_E_BADARG, "grit_embed_gather_f32: pointers must be 16-byte aligned");
+  const int HC = H / 8;
+  hipLaunchKernelGGL(embed_gather_f32_k, dim3(grid_for(T * HC, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)table, ids,
+                     (float4*)out, T, HC, V);
+  GRIT_CHECK_LAUNCH("grit_embed_gather_f32");
+  return GRIT_OK;
+}
+
+int grit_rmsnorm_fwd_f32in(const float* x, const void* w, void* y, int64_t T, int H, float eps, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && w && y, GRIT_E_BADARG, "grit_rmsnorm_fwd_f32in: null pointer");
+  GRIT_REQUIRE(T >= 0 && H > 0, GRIT_E_BADARG, "grit_rmsnorm_fwd_f32in: bad sizes");
+  GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_rmsnorm_fwd_f32in: H=%d must be a multiple of 8", H);
+  GRIT_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), GRIT_E_BADARG, "grit_rmsnorm_fwd_f32in: pointers must be 16-byte aligned");
+  const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const float4* xp = (const float4*)x;
+  const uint2* wp = (const uint2*)w;
+  uint2* yp = (uint2*)y;
+  switch (H % 256 == 0 ? H / 256 : 0) {
+    case 1: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<1>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+    case 2: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<2>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+    case 4: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<4>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+    case 8: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<8>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+    case 16: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<16>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+    default: hipLaunchKernelGGL(rmsnorm_fwd_f32in_generic_k, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+  }
+  GRIT_CHECK_LAUNCH("grit_rmsnorm_fwd_f32in");
   return GRIT_OK;
 }
 

@@ -600,6 +600,50 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     const int frow = ln_e & 15, kq = ln_e >> 4;
     char* xp = smem + STAGE_BYTES + (wid < 4 ? HALF_BYTES : 3 * HALF_BYTES) + (wid & 3) * 4096;
     const int64_t mbase = m0 + wr * 128;
+    if constexpr (EPI == GRIT_EPI_RESIDUAL_F32) {
+      // fp32 residual stream: C (fp32, may alias the residual) = residual + acc, nothing rounded.  A row block of the wave is 16 rows x
+      // 256 B of fp32: the lane's four 16-byte fragments pieces go into the wave's 4 KiB transposition space (unit ^= row & 7: conflict-free
+      // ds_write_b128 / ds_read_b128), come back with 16 lanes on the 16 pieces of ONE row -- 4 rows x 256 B = 8 full lines per load /
+      // store instruction instead of 16 rows x 64 B -- and meet the residual, fetched four row blocks ahead (ring of 4 x 4 float4).
+      const float* R32 = reinterpret_cast<const float*>(Rsd);
+      float* C32 = reinterpret_cast<float*>(C);
+      const int tr4 = ln_e >> 4, tu16 = ln_e & 15;
+      const int ncol32 = n0 + wc * 64 + tu16 * 4;
+      float4 rpre32[4][4];
+      auto r32_fetch = [&](int i) {
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+          const int64_t m = mbase + i * 16 + p4 * 4 + tr4;
+          rpre32[i & 3][p4] = (m < M && ncol32 < N) ? *reinterpret_cast<const float4*>(R32 + m * ldr + ncol32) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r32_fetch(i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (PERSIST && (i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4_t*>(xp + frow * 256 + (((j * 4 + kq) ^ (frow & 7)) << 4)) = acc[i][j];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                     // lgkmcnt(0): the wave's own pieces are in the buffer
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+          const int row = p4 * 4 + tr4;
+          const float4 piece = *reinterpret_cast<const float4*>(xp + row * 256 + ((tu16 ^ (row & 7)) << 4));
+          const int64_t m = mbase + i * 16 + row;
+          const float4 rv = rpre32[i & 3][p4];
+          if (m < M && ncol32 < N)
+            *reinterpret_cast<float4*>(C32 + m * ldc + ncol32) = make_float4(piece.x + rv.x, piece.y + rv.y, piece.z + rv.z, piece.w + rv.w);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                     // the pieces are in registers before the buffer is rewritten
+        asm volatile("" ::: "memory");
+        if (i + 4 < 8) r32_fetch(i + 4);
+      }
+      return;
+    }
     const int tr = ln_e >> 3, tu = ln_e & 7;                                   // transposed side: row (+ 8) and 16-byte unit of the row
     const int ncol_t = n0 + wrow(tu >> 1) + (tu & 1) * 8;
     uint4 rpre[8][2];
@@ -744,7 +788,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   // at the same moment = 64 MB at ~7 TB/s -- the seam of a lock-stepped launch is an HBM burst, not an issue problem.
   // SWIGLU_BWD (round 3, second half): two 16-byte loads + two 16-byte stores per 8 outputs made the direct form the slowest epilogue of the
   // training step (1135 TF on the d_act GEMM against 1400-1470 for the other dense launches of a chunk); through the turn they are full lines.
-  constexpr bool LDS_EPI = (EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_RESIDUAL || EPI == GRIT_EPI_SWIGLU_BWD) && !GRIT_SWB_DIRECT(EPI);
+  constexpr bool LDS_EPI = (EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_RESIDUAL || EPI == GRIT_EPI_SWIGLU_BWD || EPI == GRIT_EPI_RESIDUAL_F32) && !GRIT_SWB_DIRECT(EPI);
 
   if constexpr (!PERSIST) {
     for (int kt = 0; kt < nk; kt += 2) {
@@ -1110,6 +1154,10 @@ extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t 
       GRIT_REQUIRE(residual && ldr % 8 == 0 && ldr >= N && ldc >= N && aligned16(residual), GRIT_E_BADARG,
                    "grit_gemm_bf16_nt: RESIDUAL epilogue needs residual with ldr >= N");
       return launch_gemm<GRIT_EPI_RESIDUAL>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
+    case GRIT_EPI_RESIDUAL_F32:
+      GRIT_REQUIRE(residual && ldr % 4 == 0 && ldr >= N && ldc >= N && ldc % 4 == 0 && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_bf16_nt: RESIDUAL_F32 epilogue needs an fp32 residual with ldr >= N (C and residual are fp32, ldc / ldr in floats)");
+      return launch_gemm<GRIT_EPI_RESIDUAL_F32>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
     case GRIT_EPI_SWIGLU:
       GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_bf16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
       return launch_gemm<GRIT_EPI_SWIGLU>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);

@@ -22,7 +22,7 @@ from dataclasses import dataclass
 import torch
 
 from . import ops
-from ._lib import EPI_RESIDUAL, EPI_SWIGLU, GritHipError
+from ._lib import EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_SWIGLU, GritHipError
 
 BF16 = torch.bfloat16
 
@@ -139,6 +139,11 @@ class MistralEncoderEngine:
         self.causal = False             # True: causal attention ('cc' embedding attention of the reference's attn string)
         self.window_keys = 0            # causal attention: keys a query sees (sliding_window_keys(); 0 = no window).  The bidirectional
                                         # path ignores it, as the reference
+        # Precision policy of the residual stream (DESIGN §2 "depth"): False = the reference's bf16 arithmetic (hidden_states rounded to
+        # bf16 after every residual add, the Linear output rounded before it: what its bf16 run computes); True = the stream lives in
+        # fp32 ([T,H] fp32 workspace, GRIT_EPI_RESIDUAL_F32 / grit_rmsnorm_fwd_f32in): every GEMM still takes bf16 operands, but nothing
+        # accumulates rounding error across layers -- closer to the reference's fp32 run than its own bf16 run is.
+        self.residual_fp32 = False
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -238,12 +243,15 @@ class MistralEncoderEngine:
         """Activation buffers for T token rows: one allocation sized for the largest T seen, handed out as row-slices
         (ragged / packed batches change T every call)."""
         cap = self._ws.get("cap", 0)
+        if cap and (self._ws["h"].dtype == torch.float32) != bool(self.residual_fp32):
+            cap = 0                       # the precision policy changed: the residual stream's buffer has the other dtype
         if cap < T:
             c, dev = self.cfg, self.device
             qkv_w = (c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim
             self._ws.clear()
             mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
-            self._ws.update(cap=T, h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim))
+            h = torch.empty((T, c.hidden_size), dtype=torch.float32 if self.residual_fp32 else BF16, device=dev)
+            self._ws.update(cap=T, h=h, x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim))
             if c.num_local_experts:           # every token visits two experts: 2T rows of expert activations
                 self._ws.update(act2=torch.empty((2 * T, c.intermediate_size), dtype=BF16, device=dev),
                                 y2=torch.empty((2 * T, c.hidden_size), dtype=BF16, device=dev))
@@ -255,8 +263,10 @@ class MistralEncoderEngine:
         """h += MLP(x) in place (x = post-attention RMSNorm output): dense SwiGLU MLP or Mixtral's sparse-MoE block."""
         if not self.cfg.num_local_experts:
             ops.gemm_nt(x, L.wgu, out=ws["act"], epilogue=EPI_SWIGLU)
-            ops.gemm_nt(ws["act"], L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.gemm_nt(ws["act"], L.wdown, out=h, epilogue=self._epi_res(), residual=h)
             return
+        if self.residual_fp32:
+            raise GritHipError("native encoder: residual_fp32 is built for the dense (Mistral) MLP only")
         T = x.shape[0]
         experts, weights, counts, row_token, rows = ops.moe_route(x, L.wgate)
         if self.record_routing is not None:
@@ -264,6 +274,9 @@ class MistralEncoderEngine:
         ops.gemm_nt_grouped(x, L.w13, counts, 2 * T, out=ws["act2"], epilogue=EPI_SWIGLU, a_rows=row_token)
         ops.gemm_nt_grouped(ws["act2"], L.w2, counts, 2 * T, out=ws["y2"])
         ops.moe_combine(ws["y2"], rows, weights, h, out=h)
+
+    def _epi_res(self) -> int:
+        return EPI_RESIDUAL_F32 if self.residual_fp32 else EPI_RESIDUAL
 
     def _window(self, S: int) -> int:
         """``window`` argument of the attention kernels for sequences of up to S tokens (0: every earlier key is inside the window)."""
@@ -308,7 +321,7 @@ class MistralEncoderEngine:
                 kvw = qkv.view(B, S, nq + 2 * nkv, d)
                 kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).contiguous(), kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).contiguous()))
             ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, causal=self.causal, window=window)
-            ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.gemm_nt(ctx, L.wo, out=h, epilogue=self._epi_res(), residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)
         ops.rmsnorm(h, self.norm, eps, out=x)
@@ -360,7 +373,7 @@ class MistralEncoderEngine:
             ops.rmsnorm(h, L.ln1, eps, out=x)
             ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, positions=pos, out=qkv)
             ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal, window=window)
-            ops.gemm_nt(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.gemm_nt(ctx, L.wo, out=h, epilogue=self._epi_res(), residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)
         ops.rmsnorm(h, self.norm, eps, out=x)

@@ -5,8 +5,8 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import (EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, POOL_MODES,
-                   check)
+from ._lib import (EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_STORE, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE,
+                   POOL_MODES, check)
 
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 
@@ -93,18 +93,27 @@ def embed_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | Non
     T = ids.numel()
     if out is None:
         out = torch.empty((T, H), dtype=BF16, device=table.device)
+    if out.dtype == F32:        # fp32 residual stream: rows widened (exact)
+        check(_lib.load().grit_embed_gather_f32(_chk(table, BF16, "table"), _chk(ids, I64, "ids"), _chk(out, F32, "out"), T, H, V, _stream()),
+              "grit_embed_gather_f32")
+        return out
     check(_lib.load().grit_embed_gather(_chk(table, BF16, "table"), _chk(ids, I64, "ids"), _chk(out, BF16, "out"), T, H, V, _stream()),
           "grit_embed_gather")
     return out
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    """bf16 rows: the reference's bf16 arithmetic.  fp32 rows (the encoder's fp32 residual stream): one rounding, bf16 out."""
     H = x.shape[-1]
     T = x.numel() // H
     if out is None:
-        out = torch.empty_like(x)
-    check(_lib.load().grit_rmsnorm_fwd(_chk(x, BF16, "x"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), T, H, float(eps), _stream()),
-          "grit_rmsnorm_fwd")
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    if x.dtype == F32:
+        check(_lib.load().grit_rmsnorm_fwd_f32in(_chk(x, F32, "x"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), T, H, float(eps), _stream()),
+              "grit_rmsnorm_fwd_f32in")
+    else:
+        check(_lib.load().grit_rmsnorm_fwd(_chk(x, BF16, "x"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), T, H, float(eps), _stream()),
+              "grit_rmsnorm_fwd")
     return out
 
 
@@ -194,17 +203,18 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     N = w.shape[0]
     assert w.shape[1] == K, (a.shape, w.shape)
     n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE) else (2 * N if epilogue == EPI_SWIGLU_BWD else N)
+    odt = F32 if epilogue == EPI_RESIDUAL_F32 else BF16       # RESIDUAL_F32: out and residual are the fp32 residual stream
     if out is None:
-        out = torch.empty((M, n_out), dtype=BF16, device=a.device)
+        out = torch.empty((M, n_out), dtype=odt, device=a.device)
     assert out.shape == (M, n_out)
     rp, ldr = 0, 0
-    if epilogue in (EPI_RESIDUAL, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD):
+    if epilogue in (EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD):
         assert residual is not None and residual.shape == (M, 2 * N if epilogue == EPI_SWIGLU_BWD else N)
-        rp, ldr = _chk2d(residual, BF16, "residual"), residual.stride(0)
+        rp, ldr = _chk2d(residual, odt, "residual"), residual.stride(0)
     ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K, tag=f"N={N},K={K},epi={epilogue}") if _timer is not None else None
     if ev:
         ev[0].record()
-    check(_lib.load().grit_gemm_bf16_nt(_chk2d(a, BF16, "a"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), M, N, K, a.stride(0),
+    check(_lib.load().grit_gemm_bf16_nt(_chk2d(a, BF16, "a"), _chk2d(w, BF16, "w"), _chk2d(out, odt, "out"), M, N, K, a.stride(0),
                                         w.stride(0), out.stride(0), epilogue, rp, ldr, _stream()), "grit_gemm_bf16_nt")
     if ev:
         ev[1].record()

@@ -48,9 +48,12 @@ enum {
                             the per-lane LDS-DMA source address, the arithmetic is GRIT_EPI_SWIGLU's                         */
   GRIT_EPI_SWIGLU_STACKED_SAVE = 5, /* SWIGLU_STACKED that ALSO writes the bf16 pre-activations [gate | up] ([M, N], leading dimension
                             ldr) through the `residual` pointer (an OUTPUT here): what the backward pass keeps (training forward)   */
-  GRIT_EPI_SWIGLU_BWD = 6 /* backward of SwiGLU fused behind the dgrad GEMM d_act = d_h @ W_down^T (N = intermediate size):
+  GRIT_EPI_SWIGLU_BWD = 6, /* backward of SwiGLU fused behind the dgrad GEMM d_act = d_h @ W_down^T (N = intermediate size):
                             `residual` = saved [gate | up] ([M, 2N], ldr); C = [d_gate | d_up] ([M, 2N], ldc >= 2N):
                             d_gate = d_act * up * s (1 + gate (1 - s)), d_up = d_act * gate * s, s = sigmoid(gate), d_act = bf16(acc)  */
+  GRIT_EPI_RESIDUAL_F32 = 7 /* fp32 residual stream (the encoder's high-precision mode): C and residual are FP32 [M, N] (ldc / ldr in
+                            floats, residual may alias C): C = residual + acc, no rounding of the Linear output or of the sum -- what
+                            hidden_states = residual + hidden_states (:769,:775) computes when the reference runs in fp32           */
 };
 
 /* pooling modes: gritlm/gritlm.py:188-214 */
@@ -69,6 +72,12 @@ int grit_embed_gather(const void* table, const int64_t* ids, void* out, int64_t 
 
 /* MistralRMSNorm.forward, :84-89: y = w * bf16(x * rsqrt(mean(x^2) + eps)), fp32 math. x,y [T,H] bf16. */
 int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, float eps, void* stream);
+
+/* The fp32 residual stream of the encoder's high-precision mode (GRIT_EPI_RESIDUAL_F32): embed_tokens widened to fp32 (exact), and
+ * MistralRMSNorm (:84-89) of an fp32 row with ONE rounding, y = bf16(w * (x * rsqrt(mean(x^2) + eps))) -- the bf16 operand of the next
+ * projection.  out / x: [T,H] fp32, 16-byte aligned; w, y bf16. */
+int grit_embed_gather_f32(const void* table, const int64_t* ids, float* out, int64_t T, int H, int64_t V, void* stream);
+int grit_rmsnorm_fwd_f32in(const float* x, const void* w, void* y, int64_t T, int H, float eps, void* stream);
 
 /* apply_rotary_pos_emb, :138-163, in place on the q and k heads of a fused [T, row_stride] bf16 buffer
  * (columns [0,(nq+nkv)*d) hold q heads then k heads); positions are t % S (:984-989).

@@ -185,6 +185,50 @@ def gen_encoder_7b_l1(batch=2, seq=512, min_len=200, seed_w=0, seed_x=777, n_pro
     np.savez_compressed(os.path.join(HERE, f"encoder_{cfg_name}.npz"), **out)
 
 
+@torch.no_grad()
+def gen_encoder_depth32(layers=32, n_probe=16):
+    """ALL 32 layers at the true GritLM-7B layer shape through the REFERENCE's MistralModel(is_causal=False)
+    (scripts/modeling_mistral_gritlm.py:936-1096) + GritLM.pooling + normalise (gritlm/gritlm.py:156-158, :178-218): the full-depth pin
+    (VERDICT r03 #1f).  Weights = bench.oracle_full_depth_case (the same bf16-representable arrays in every layer, so the fixture's
+    model is regenerated from a seed anywhere; the reference module holds ONE decoder layer object applied 32 times).  Three cases, each
+    with the reference's fp32 run AND its own bf16 run:
+      short : 1 doc x 64 tokens, no padding   (what the numpy oracle replays in the CPU suite)
+      ragged: 2 docs x 512 tokens, one padded (the explicit 4-D mask path, :1017-1020)
+      full  : 1 doc x 512 tokens, no padding  (the mask-is-None path of _prepare_4d_attention_mask_for_sdpa)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = dict(layers=layers)
+    for tag, (docs, seq, pad) in {"short": (1, 64, 0), "ragged": (2, 512, 150), "full": (1, 512, 0)}.items():
+        cfg, w, ids, mask = bench.oracle_full_depth_case(sample_docs=docs, seq=seq, layers=layers)
+        if pad:
+            mask = mask.copy(); mask[-1, seq - pad:] = 0
+        hc = synth.hf_config(dict(cfg, num_hidden_layers=1))
+        hc.use_cache = False
+        hc._attn_implementation = "sdpa"
+        model = REFMOD.MistralModel(hc).eval()
+        sd = {k: torch.from_numpy(v) for k, v in w.items() if not k.startswith("layers.") or k.startswith("layers.0.")}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+        for li in range(1, layers):              # every layer of the case holds the SAME arrays (checked, not assumed)
+            assert all(w[f"layers.{li}.{k[len('layers.0.'):]}"] is w[k] for k in w if k.startswith("layers.0."))
+        model.layers = torch.nn.ModuleList([model.layers[0]] * layers)
+        tid, tmask = torch.from_numpy(ids), torch.from_numpy(mask)
+        g = ref_gritlm_shell("mean")
+        h32 = model(input_ids=tid, attention_mask=tmask, is_causal=False)[0]
+        e32 = torch.nn.functional.normalize(g.pooling(h32, tmask.clone()), dim=-1)
+        hb = model.to(torch.bfloat16)(input_ids=tid, attention_mask=tmask, is_causal=False)[0]
+        eb = torch.nn.functional.normalize(g.pooling(hb, tmask.clone()).float(), dim=-1)
+        valid = np.argwhere(mask.reshape(-1) > 0)[:, 0]
+        probe = np.sort(np.random.default_rng(5).choice(valid, size=n_probe, replace=False))
+        cosd = float((1 - torch.nn.functional.cosine_similarity(e32, eb, dim=1)).max())
+        out.update({f"{tag}_input_ids": ids, f"{tag}_attention_mask": mask, f"{tag}_emb": e32.numpy(), f"{tag}_emb_bf16": eb.numpy(),
+                    f"{tag}_probe_rows": probe, f"{tag}_probe_hidden": h32.reshape(-1, h32.shape[-1])[probe].numpy(),
+                    f"{tag}_ref_bf16_one_minus_cos_vs_fp32": np.float32(cosd)})
+        print(f"  depth{layers} {tag}: reference bf16-vs-fp32 1-cos {cosd:.3e}")
+        del model
+    np.savez_compressed(os.path.join(HERE, f"encoder_7b-depth{layers}.npz"), **out)
+
+
 def gen_train_7b_l1():
     """Contrastive step (direct forward + backward, gritlm/training/model.py:168-222) of the reference at the TRUE 7B layer shape, one
     layer, fp32 on CPU: 2 queries + 4 passages (group size 2), ragged, tau 0.02, mean pooling.  Stored: loss, reps, per-parameter
@@ -641,6 +685,8 @@ if __name__ == "__main__":
         gen_sliding_window(); sys.exit(0)
     if sys.argv[1:] == ["generative"]:
         gen_generative(); sys.exit(0)
+    if sys.argv[1:] == ["depth32"]:          # only the full-depth fixture (~2 min on 8 cores)
+        gen_encoder_depth32(); sys.exit(0)
     if sys.argv[1:] == ["7b-l1"]:            # only the 7B-layer-shape fixtures (1.4 GB of fp32 weights, ~2 min on 8 cores)
         gen_encoder_7b_l1(); gen_train_7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["train-mixtral"]:
@@ -667,4 +713,5 @@ if __name__ == "__main__":
     print("encoder 7b-l1"); gen_encoder_7b_l1()
     print("train 7b-l1"); gen_train_7b_l1()
     print("train mixtral"); gen_train_mixtral(); gen_generative_mixtral()
+    print("encoder depth 32"); gen_encoder_depth32()
     print("done")

@@ -12,7 +12,7 @@ import torch
 import gritlm_oracle as O
 import synth
 from gritlm_amd import ops
-from gritlm_amd._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU
+from gritlm_amd._lib import EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_STORE, EPI_SWIGLU
 from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine, swiglu_interleave
 
 DEV = "cuda"
@@ -103,6 +103,43 @@ def check_gemm(M, N, K, epi=EPI_STORE, seed=7):
     if not ok:
         _dump(f"gemm_{M}_{N}_{K}_{epi}", a=a, w=w, out=out, ref=ref.astype(np.float32))
     return _res(f"gemm[M={M},N={N},K={K},epi={epi}]", ok, max_err_over_tol=err)
+
+
+def check_gemm_residual_f32(M=520, N=512, K=192, seed=27, in_place=True):
+    """GRIT_EPI_RESIDUAL_F32 (the fp32 residual stream): C = R + A W^T with fp32 R / C and NOTHING rounded -- against fp64 of the same bf16
+    operands, to fp32 accumulation accuracy (1e-5 relative to the row scale), in place and out of place, ragged M / N edges."""
+    a, w = rnd((M, K), seed), rnd((N, K), seed + 1, 0.05)
+    r = np.random.default_rng(seed + 2).standard_normal((M, N)).astype(np.float32) * 3.0        # NOT bf16-representable on purpose
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + r.astype(np.float64)
+    rt = torch.from_numpy(r).to(DEV)
+    if in_place:
+        out = rt
+        ops.gemm_nt(bf(a), bf(w), out=out, epilogue=EPI_RESIDUAL_F32, residual=rt)
+    else:
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        ops.gemm_nt(bf(a), bf(w), out=out, epilogue=EPI_RESIDUAL_F32, residual=rt)
+    got = out.cpu().numpy().astype(np.float64)
+    scale = float(np.sqrt(np.mean(ref ** 2)))
+    err = float(np.max(np.abs(got - ref)) / scale)
+    return _res(f"gemm_residual_f32[M={M},N={N},K={K},in_place={in_place}]", np.isfinite(got).all() and err < 2e-5, max_err_over_rms=err)
+
+
+def check_f32_stream_ops(T=37, H=4096):
+    """grit_embed_gather_f32 (exact widening) and grit_rmsnorm_fwd_f32in (fp32 rows, ONE rounding) vs numpy."""
+    tab = rnd((97, H), 1)
+    ids = np.random.default_rng(2).integers(0, 97, size=(T,))
+    out = torch.empty((T, H), dtype=torch.float32, device=DEV)
+    ops.embed_gather(bf(tab), torch.from_numpy(ids).to(DEV), out=out)
+    same = np.array_equal(out.cpu().numpy(), tab[ids])
+    x = np.random.default_rng(3).standard_normal((T, H)).astype(np.float32) * 2.0
+    w = O.bf16_round(1 + 0.1 * rnd((H,), 4))
+    y = f32(ops.rmsnorm(torch.from_numpy(x).to(DEV), bf(w), 1e-5))
+    x64 = x.astype(np.float64)
+    ref = w * (x64 * (1.0 / np.sqrt((x64 ** 2).mean(-1, keepdims=True) + 1e-5)))
+    refb = O.bf16_round(ref.astype(np.float32))
+    exact = float(np.mean(y == refb))
+    err = float(np.max(np.abs(y - ref) / (np.abs(ref) + 1e-3)))
+    return _res(f"f32_stream_ops[T={T},H={H}]", same and err < 5e-3 and exact > 0.99, gather_exact=same, rms_max_rel=err, rms_exact_frac=exact)
 
 
 def check_gemm_pair(M1=300, N1=272, M2=520, N2=720, K=192, accumulate=True, seed=17):
@@ -632,6 +669,38 @@ def check_encoder_golden(cfg_name):
     return _res(f"encoder[{cfg_name}] vs reference golden", ok, **out)
 
 
+def check_encoder_fp32_residual(cfg_name):
+    """The engine with the fp32 residual stream (residual_fp32: GRIT_EPI_RESIDUAL_F32, grit_rmsnorm_fwd_f32in, grit_embed_gather_f32)
+    against the reference's FP32 run (fixture): hidden states must be CLOSER to fp32 than with the bf16 stream and than the reference's
+    own bf16 run, embeddings within the north-star's 1e-4; padded == packed bit for bit."""
+    g = np.load(os.path.join(GOLDEN, f"encoder_{cfg_name}.npz"))
+    eng, cfg, w = build_engine(cfg_name, int(g["seed_w"]))
+    ids, mask = g["input_ids"], g["attention_mask"]
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    valid = mask.astype(bool)
+    if "last_hidden_state" in g.files:
+        ref32, refb = g["last_hidden_state"], g["last_hidden_state_bf16"]
+        rel = lambda a, b: float(np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid]))
+        pick = lambda h: h
+    else:                                                  # 7b-l1: probe rows only
+        ref32, refb = g["probe_hidden"], g["probe_hidden_bf16"]
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        pick = lambda h: h.reshape(-1, h.shape[-1])[g["probe_rows"]]
+    h_b = pick(f32(eng.forward(tid, tm)))
+    eng.residual_fp32 = True
+    h_f = pick(f32(eng.forward(tid, tm)))
+    r_b, r_f, r_ref = rel(h_b, ref32), rel(h_f, ref32), rel(refb, ref32)
+    out = dict(rel_bf16_stream=r_b, rel_fp32_stream=r_f, rel_refbf16=r_ref)
+    ok = r_f < 1.02 * r_b and r_f < r_ref and not np.isnan(h_f).any()      # (the final RMSNorm's bf16 output rounding is in both)
+    for method in ("mean", "weightedmean"):
+        e_pad = eng.encode_pooled(tid, tm, method, True, packed=False)
+        e_pack = eng.encode_pooled(tid, tm, method, True, packed=True)
+        d = float(np.max(1 - np.sum(f32(e_pad) * g[f"emb_{method}"], axis=1)))
+        out[f"{method}_1-cos"] = d
+        ok &= d < 1e-4 and bool(torch.equal(e_pad, e_pack))
+    return _res(f"encoder[{cfg_name}] fp32 residual stream vs reference fp32", ok, **out)
+
+
 def check_encoder_7b_layer():
     """One layer at the TRUE GritLM-7B layer shape vs the fixture produced by the reference's MistralModel(is_causal=False)
     (tests/golden/encoder_7b-l1.npz: fp32 and bf16 runs).  Every GEMM runs at the bench's N and K (6144x4096, 4096x4096, 28672x4096,
@@ -692,37 +761,65 @@ def check_gemm_fullshape(M, N, K, epi=EPI_STORE, seed=91, samples=4096):
 
 
 # ---------------------------------------------------------------------------------------------- sparse MoE (Mixtral)
-def check_full_depth_parity(docs=2, seq=512, layers=32):
-    """All 32 layers at the 7B layer shape (scripts/modeling_mistral_gritlm.py:936-1096): the HIP engine vs the fp32
-    oracle on identical bf16-representable weights, with the stock Hugging Face module in bf16 on this GPU (oracle/torch_reference.py,
-    bit-equal to the reference on the reference-generated fixtures) as the yardstick of what bf16 costs over 32 layers.  The case is
-    the one bench.py reports as ``parity_full_depth`` (same builder), on ``docs`` ragged documents."""
+# Full-depth bounds (1 - cos of the pooled embedding against the reference's FP32 run, 32 layers, 7B layer shape).  Numeric constants,
+# not ratios to a yardstick (VERDICT r03 #1c).  What they are anchored on: the reference's OWN bf16 run on this fixture is 4.6e-4 ..
+# 6.0e-4 away from its fp32 run (stored in the fixture); the engine with the reference's bf16 rounding points measures 4.3e-4 .. 5.4e-4
+# (rounds 3-4), with the fp32 residual stream 1e-5 class (round 4, profiles/r04_depth_parity.json).
+FULL_DEPTH_BOUND_BF16_RESIDUAL = 1.0e-3
+FULL_DEPTH_BOUND_FP32_RESIDUAL = 1.0e-4          # the north-star's tolerance
+
+
+def check_full_depth_parity(residual_fp32=False):
+    """All 32 layers at the 7B layer shape (scripts/modeling_mistral_gritlm.py:936-1096) against embeddings the REFERENCE ITSELF produced
+    (tests/golden/encoder_7b-depth32.npz: its fp32 run and its own bf16 run; `ragged` = 2 x 512 with one padded row -> the explicit-mask
+    path, `full` = 1 x 512 all valid -> the mask-is-None path of :1017-1020).  The engine is held to a NUMERIC bound on 1 - cos against
+    the reference's fp32 embeddings; the padded and the packed engine paths must agree bit for bit; the fp32 stock module on this GPU (the
+    comparator bench.py uses on its own weights) must reproduce the fixture; the stock bf16 module under both mask rules is reported."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
     import bench
     import torch_reference as TR
-    cfg, w, ids, mask = bench.oracle_full_depth_case(sample_docs=docs, seq=seq, layers=layers)
-    mask = mask.copy(); mask[-1, seq - 150:] = 0                    # one ragged row: padding handled over the full depth too
-    ref = bench.oracle_full_depth_run(cfg, w, ids, mask)
+    g = np.load(os.path.join(GOLDEN, "encoder_7b-depth32.npz"))
+    layers = int(g["layers"])
+    bound = FULL_DEPTH_BOUND_FP32_RESIDUAL if residual_fp32 else FULL_DEPTH_BOUND_BF16_RESIDUAL
+    cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
+    cfg, w, _, _ = bench.oracle_full_depth_case(sample_docs=1, seq=64, layers=layers)
     sd = {k: torch.from_numpy(v) for k, v in w.items()}
     eng = MistralEncoderEngine.from_state_dict(EncoderConfig.from_dict(cfg), sd, DEV)
-    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
-    e_pad = eng.encode_pooled(tid, tm, "mean", True, packed=False)
-    e_pack = eng.encode_pooled(tid, tm, "mean", True, packed=True)
-    same = bool(torch.equal(e_pad, e_pack))
+    eng.residual_fp32 = residual_fp32
+    det, ok = {}, True
+    embs = {}
+    for tag in ("ragged", "full"):
+        tid, tm = torch.from_numpy(g[f"{tag}_input_ids"]).to(DEV), torch.from_numpy(g[f"{tag}_attention_mask"]).to(DEV)
+        e_pad = eng.encode_pooled(tid, tm, "mean", True, packed=False)
+        e_pack = eng.encode_pooled(tid, tm, "mean", True, packed=True)
+        same = bool(torch.equal(e_pad, e_pack))
+        hip = cosd(f32(e_pad), g[f"{tag}_emb"])
+        det[f"{tag}_vs_ref_fp32"] = hip
+        det[f"{tag}_vs_ref_bf16"] = cosd(f32(e_pad), g[f"{tag}_emb_bf16"])
+        det[f"{tag}_ref_bf16_vs_ref_fp32"] = float(g[f"{tag}_ref_bf16_one_minus_cos_vs_fp32"])
+        det[f"{tag}_packed_identical"] = same
+        ok = ok and same and bool(np.isfinite(f32(e_pad)).all()) and hip < bound
+        embs[tag] = (tid, tm)
     del eng
     torch.cuda.empty_cache()
-    hf = TR.build_model(cfg, torch.bfloat16, DEV, state_dict=sd)
-    e_hf = f32(TR.encode(hf, tid, tm))
-    del hf
-    torch.cuda.empty_cache()
-    cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
-    hip, stock, cross = cosd(f32(e_pad), ref), cosd(e_hf, ref), cosd(f32(e_pad), e_hf)
-    ok = same and np.isfinite(f32(e_pad)).all() and (hip < 1e-4 or hip <= 1.25 * stock)
-    return _res(f"full-depth parity [L={layers},B={docs},S={seq}]", ok, one_minus_cos_vs_fp32_oracle=hip, stock_hf_bf16_vs_fp32_oracle=stock,
-                engine_vs_stock_hf_bf16=cross, packed_identical=same)
+    if not residual_fp32:                    # the comparators, once
+        hf = TR.build_model(cfg, torch.float32, DEV, state_dict=sd)
+        for tag, (tid, tm) in embs.items():
+            d = cosd(f32(TR.encode(hf, tid, tm)), g[f"{tag}_emb"])
+            det[f"{tag}_stock_fp32_gpu_vs_ref_fp32"] = d
+            ok = ok and d < 1e-6
+        del hf
+        torch.cuda.empty_cache()
+        hb = TR.build_model(cfg, torch.bfloat16, DEV, state_dict=sd)
+        tid, tm = embs["full"]
+        det["full_stock_bf16_gpu_mask_none"] = cosd(f32(TR.encode(hb, tid, tm, mask_rule="reference")), g["full_emb"])
+        det["full_stock_bf16_gpu_mask_4d"] = cosd(f32(TR.encode(hb, tid, tm, mask_rule="explicit")), g["full_emb"])
+        del hb
+        torch.cuda.empty_cache()
+    return _res(f"full-depth parity [L={layers},residual_fp32={residual_fp32}]", ok, bound=bound, **det)
 
 
 def check_moe_router(T=777, H=512, E=8):
@@ -2167,6 +2264,12 @@ ALL_CHECKS = [
     ("gemm_residual", check_gemm, dict(M=520, N=512, K=192, epi=EPI_RESIDUAL)),
     ("gemm_swiglu", check_gemm, dict(M=300, N=1024, K=256, epi=EPI_SWIGLU)),
     ("gemm_swiglu_edge", check_gemm, dict(M=70, N=576, K=64, epi=EPI_SWIGLU)),
+    ("gemm_residual_f32", check_gemm_residual_f32, {}),
+    ("gemm_residual_f32_edge", check_gemm_residual_f32, dict(M=300, N=272, K=128, in_place=False)),
+    ("gemm_residual_f32_persistent", check_gemm_residual_f32, dict(M=8192, N=4096, K=512, seed=29)),      # 512 tiles >= 2 per CU: the persistent form
+    ("f32_stream_ops", check_f32_stream_ops, {}),
+    ("f32_stream_ops_768", check_f32_stream_ops, dict(T=9, H=768)),
+    ("f32_stream_ops_264", check_f32_stream_ops, dict(T=5, H=264)),
     ("gemm_pair", check_gemm_pair, {}),
     ("gemm_pair_store", check_gemm_pair, dict(M1=17, N1=1536, M2=1024, N2=256, K=256, accumulate=False)),
     ("gemm_pair_wgrad_shape", check_gemm_pair, dict(M1=4096, N1=14336, M2=6144, N2=4096, K=2048)),
@@ -2245,7 +2348,11 @@ ALL_CHECKS = [
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
     ("encoder_7b_layer", check_encoder_7b_layer, {}),
+    ("encoder_tiny_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="tiny")),
+    ("encoder_gqa_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="gqa")),
+    ("encoder_7b_layer_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="7b-l1")),
     ("full_depth_parity_32_layers", check_full_depth_parity, {}),
+    ("full_depth_parity_32_layers_fp32_residual", check_full_depth_parity, dict(residual_fp32=True)),
     ("gemm_full_swiglu_28672x4096", check_gemm_fullshape, dict(M=4096, N=28672, K=4096, epi=EPI_SWIGLU)),
     ("gemm_full_residual_4096x14336", check_gemm_fullshape, dict(M=4096, N=4096, K=14336, epi=EPI_RESIDUAL)),
     ("gemm_full_store_6144x4096", check_gemm_fullshape, dict(M=4096, N=6144, K=4096)),

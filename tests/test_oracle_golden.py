@@ -98,6 +98,66 @@ def test_torch_reference_equals_reference_fixture(golden_dir, cfg_name):
     assert np.all(1 - np.sum(e * g["emb_mean"], axis=1) < 1e-6)
 
 
+def _depth32_case(g, tag):
+    import bench
+    ids, mask = g[f"{tag}_input_ids"], g[f"{tag}_attention_mask"]
+    cfg, w, i2, _ = bench.oracle_full_depth_case(sample_docs=ids.shape[0], seq=ids.shape[1], layers=int(g["layers"]))
+    assert np.array_equal(i2, ids)                                         # generator determinism: the fixture's model is regenerated here
+    return cfg, w, ids, mask
+
+
+def test_full_depth_oracle_matches_reference(golden_dir):
+    """ALL 32 layers at the 7B layer shape: the numpy oracle against the REFERENCE's own fp32 run (tests/golden/encoder_7b-depth32.npz,
+    `short` case: 1 doc x 64 tokens; 0.9 TFLOP of fp32 BLAS) -- the full depth is pinned on the reference, not on the oracle."""
+    g = _load(golden_dir, "encoder_7b-depth32.npz")
+    cfg, w, ids, mask = _depth32_case(g, "short")
+    h = O.mistral_encode(w, cfg, ids, mask, acc_dtype=np.float32)
+    hp, ref = h.reshape(-1, h.shape[-1])[g["short_probe_rows"]], g["short_probe_hidden"]
+    assert np.linalg.norm(hp - ref) / np.linalg.norm(ref) < 2e-5, np.linalg.norm(hp - ref) / np.linalg.norm(ref)
+    e = O.l2_normalize(O.pooling(h, mask, "mean"))
+    assert np.all(1 - np.sum(e * g["short_emb"], axis=1) < 1e-6)
+    # what bf16 costs the REFERENCE at this depth (its own bf16 run against its own fp32 run): the yardstick the GPU checks quote
+    for tag in ("short", "ragged", "full"):
+        d = 1 - np.sum(g[f"{tag}_emb"] * g[f"{tag}_emb_bf16"], axis=1)
+        assert np.all(d < 2e-3) and np.all(d > 1e-5), d
+
+
+def test_torch_reference_full_depth_and_mask_rule(golden_dir):
+    """oracle/torch_reference.py at full depth, BOTH mask paths of the reference (:1017-1020): the all-valid `short` case takes the
+    mask-is-None path, and must equal the reference's fp32 run; with the explicit 4-D mask the stock module gives the same answer on the
+    host (fp32: the two SDPA paths agree to rounding)."""
+    import torch
+    import torch_reference as TR
+    g = _load(golden_dir, "encoder_7b-depth32.npz")
+    cfg, w, ids, mask = _depth32_case(g, "short")
+    assert TR.reference_mask(torch.from_numpy(mask), torch.float32) is None
+    padded = mask.copy(); padded[0, -1] = 0
+    assert TR.reference_mask(torch.from_numpy(padded), torch.float32) is not None
+    sd = {k: torch.from_numpy(v) for k, v in w.items() if not k.startswith("layers.") or k.startswith("layers.0.")}
+    model = TR.build_model(dict(cfg, num_hidden_layers=1), torch.float32, "cpu", sd)
+    model.layers = torch.nn.ModuleList([model.layers[0]] * int(g["layers"]))      # the fixture's model: one layer's arrays, 32 times
+    tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    for rule in ("reference", "explicit"):
+        e = TR.encode(model, tid, tm, mask_rule=rule).numpy()
+        assert np.all(1 - np.sum(e * g["short_emb"], axis=1) < 1e-6), rule
+    h1 = TR.hidden_states(model, tid, tm, layers=1)
+    assert not torch.allclose(h1, TR.hidden_states(model, tid, tm)), "`layers` must truncate the stack"
+
+
+def test_torch_reference_stack_equals_stock_forward():
+    """The restated layer loop of torch_reference.hidden_states == the stock MistralModel.forward, bit for bit, when both get the explicit mask."""
+    import torch
+    import torch_reference as TR
+    cfg = synth.CONFIGS["gqa"]
+    model = TR.build_model(cfg, torch.float32, "cpu")
+    ids, mask = synth.make_batch(cfg, 3, 72, 5, 20)
+    tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    with torch.no_grad():
+        stock = model(input_ids=tid, attention_mask=TR.bidirectional_mask(tm, model.dtype))[0]
+    assert torch.equal(stock, TR.hidden_states(model, tid, tm, "explicit"))
+    assert torch.equal(stock, TR.hidden_states(model, tid, tm, "reference"))        # padded batch: the reference builds the same mask
+
+
 def test_encoder_7b_layer_shape_matches_reference(golden_dir):
     """Oracle vs the reference at the TRUE 7B layer shape (H 4096, I 14336, 32/8 heads, one layer, 2 x 512 ragged tokens):
     full-K (4096 / 14336) accumulation, 64 probe rows of last_hidden_state + pooled embeddings."""
