@@ -35,7 +35,7 @@ def _resources(src):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src,needle,count", [("gemm_bf16.hip", "gemm_bf16_nt_k", 14), ("attention.hip", "attn_bidir_fwd_k", 4)])
+@pytest.mark.parametrize("src,needle,count", [("gemm_bf16.hip", "gemm_bf16_nt_k", 16), ("attention.hip", "attn_bidir_fwd_k", 4)])
 def test_mfma_kernels_do_not_spill(src, needle, count):
     ks = [k for k in _resources(src) if needle in k["name"]]
     assert len(ks) == count, [k["name"] for k in ks]
