@@ -13,11 +13,13 @@ no data-path collective, weak scaling); value = docs of all ranks / max-over-ran
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline:     dominant kernel (gemm_bf16_nt, bf16 MFMA bound) measured live with HIP events,
-  parity_full_depth: HIP engine vs the fp32 numpy oracle through all 32 layers on identical weights (and stock HF bf16 as yardstick),
+  parity_full_depth: the engine's embeddings of the timed batch vs the reference-equivalent module in FP32 on this GPU on the engine's own
+                weights (numeric bounds, both precision policies), + the fixture model against the fp32 numpy oracle,
   cpu_baseline: the reference's CPU encode (stock transformers.MistralModel + bidirectional mask + pooling, bit-equal to the reference
                 on the reference-generated fixtures; oracle/torch_reference.py) timed on this host's cores on a bounded sample (N = 1 only),
   rocm_torch_baseline: the same Python on this GPU through stock PyTorch-ROCm (bf16, sdpa) at the full config -- what a user gets today,
-  contrastive:  BASELINE configs[2] as stated (256 pairs x (1 + 8) x 512 tokens per GPU, GradCache chunk 32).
+  contrastive:  BASELINE configs[2] as stated (256 pairs x (1 + 8) x 512 tokens per GPU, GradCache chunk 32), 3 timed steps,
+  mixtral_8x7b_seq2048 / rag_doc_caching: BASELINE configs[3] / configs[4] as time-boxed child processes (N = 1 only; --no-mixtral / --no-rag).
 """
 import argparse
 import json
@@ -88,6 +90,63 @@ def vendor_gemm_comparator(dev, M=DOCS * SEQ):
     return out
 
 
+def vendor_gemm_sustained(dev, layers=8, passes=2, M=DOCS * SEQ):
+    """The like-for-like form of the comparator (tools/gemm_sustained_ab.py): the four GEMMs of a layer walked over `layers`
+    DISTINCT weight sets (nothing stays in the 256 MB Infinity Cache between uses), passes alternating between this repository's kernel
+    with its fused RoPE / residual / SwiGLU epilogues and torch.matmul (hipBLASLt, plain store) on the SAME operands, HIP events per launch."""
+    from gritlm_amd import ops
+    from gritlm_amd._lib import EPI_RESIDUAL, EPI_SWIGLU
+    from gritlm_amd.encoder import rope_tables
+    BF, H, I, NQKV = torch.bfloat16, 4096, 14336, 6144
+    g = torch.Generator(device=dev).manual_seed(0)
+    mk = lambda *s: (torch.randn(s, generator=g, device=dev, dtype=torch.float32) * (0.02 if s[0] != M else 1.0)).to(BF)
+    Ls = [dict(qkv=mk(NQKV, H), o=mk(H, H), gu=mk(2 * I, H), down=mk(H, I)) for _ in range(layers)]
+    x, ctx, act, res = mk(M, H), mk(M, H), mk(M, I), mk(M, H)
+    o_qkv, o_h = torch.empty((M, NQKV), device=dev, dtype=BF), torch.empty((M, H), device=dev, dtype=BF)
+    o_act, o_gu = torch.empty((M, I), device=dev, dtype=BF), torch.empty((M, 2 * I), device=dev, dtype=BF)
+    cos, sin = rope_tables(SEQ, 128, 10000.0, True, dev)
+    flops = {"qkv": 2.0 * M * NQKV * H, "o_proj": 2.0 * M * H * H, "gate_up": 2.0 * M * 2 * I * H, "down": 2.0 * M * H * I}
+    ev = {k: {n: [] for n in flops} for k in ("ours", "vendor")}
+
+    def timed(kind, name, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        ev[kind][name].append((e0, e1))
+
+    def one_pass(kind):
+        for L in Ls:
+            if kind == "ours":
+                timed(kind, "qkv", lambda: ops.gemm_nt_rope(x, L["qkv"], cos, sin, 40 * 128, S=SEQ, out=o_qkv))
+                timed(kind, "o_proj", lambda: ops.gemm_nt(ctx, L["o"], out=o_h, epilogue=EPI_RESIDUAL, residual=res))
+                timed(kind, "gate_up", lambda: ops.gemm_nt(x, L["gu"], out=o_act, epilogue=EPI_SWIGLU))
+                timed(kind, "down", lambda: ops.gemm_nt(act, L["down"], out=o_h, epilogue=EPI_RESIDUAL, residual=res))
+            else:
+                timed(kind, "qkv", lambda: torch.matmul(x, L["qkv"].t(), out=o_qkv))
+                timed(kind, "o_proj", lambda: torch.matmul(ctx, L["o"].t(), out=o_h))
+                timed(kind, "gate_up", lambda: torch.matmul(x, L["gu"].t(), out=o_gu))
+                timed(kind, "down", lambda: torch.matmul(act, L["down"].t(), out=o_h))
+
+    one_pass("ours"); one_pass("vendor")                    # warm-up: also brings the chip to its sustained clock
+    for k in ev:
+        for n in ev[k]:
+            ev[k][n].clear()
+    for _ in range(passes):
+        one_pass("ours"); one_pass("vendor")
+    torch.cuda.synchronize()
+    out, tot = {"layers_of_distinct_weights": layers, "passes": passes}, {}
+    for k in ev:
+        tf = tt = 0.0
+        for n, fl in flops.items():
+            ms = [p.elapsed_time(q) for p, q in ev[k][n]]
+            out[f"{k}_{n}_tflops"] = fl * len(ms) / (sum(ms) * 1e-3) / 1e12
+            tf += fl * len(ms); tt += sum(ms) * 1e-3
+        tot[k] = out[f"{k}_flop_weighted_tflops"] = tf / tt / 1e12
+    out["ours_over_vendor"] = tot["ours"] / tot["vendor"]
+    del Ls, x, ctx, act, res, o_qkv, o_h, o_act, o_gu
+    torch.cuda.empty_cache()
+    return out
+
+
 def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, steps=1, warmup=1, ragged_pairs=32):
     """Second headline metric: contrastive pairs/s on BASELINE configs[2] as stated -- per rank 256 queries + 2048 passages
     (1 positive + 7 negatives each) @ seq512, GradCache chunk 32 (scripts/training/train_gritlm_7b.sh:60-67; gritlm/training/run.py:93-104).
@@ -123,14 +182,18 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
         dist.barrier()
     torch.cuda.synchronize()
     gc.profile = {}
+    marks = [torch.cuda.Event(enable_timing=True)]
     t0 = time.perf_counter()
+    marks[0].record()
     for _ in range(steps):
         loss = step()
+        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -173,7 +236,9 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
         + 4.0 * cfg.num_hidden_layers * SEQ * 4096
     alg_flops_per_pair = 3.0 * eng_flops * SEQ * (1 + group)          # fwd + bwd = 3 x forward; recompute passes are overhead
     return {"metric": "contrastive pairs/sec @ seq512", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_min": step_ms[0],
+            "pairs_per_s_per_gpu_best_step": pairs / step_ms[0] * 1e3,
+            "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
             "gradcache_pass1_rows_per_call": gc.pass1_chunk_size,      # pass 1 keeps nothing: several chunks per call, same bits
             "global_batch": world * pairs, "loss": float(loss), "peak_hbm_gib": peak_gb,
             "includes": "GradCache pass 1 + rep all-gather + InfoNCE + pass 2 fwd/bwd + grad all-reduce + AdamW",
@@ -182,6 +247,27 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
             "mfma_roofline_frac": pairs_per_s / world * alg_flops_per_pair / (MFMA_BF16_PEAK_TFLOPS * 1e12),
             "per_step_ms": prof,
             **({"ragged_batch": ragged} if ragged is not None else {})}
+
+
+def secondary_leg(script: str, argv: list, timeout_s: float, keep: tuple) -> dict:
+    """BASELINE configs[3] / configs[4] as time-boxed secondary legs (VERDICT r03 #2c): the tool runs in a CHILD process (its own HIP context
+    and allocator: 108 / 174 GB of weights + KV never meet the parent's caches; a hang or an out-of-memory there cannot cost the primary
+    line), one JSON line back, the fields in `keep` copied into the bench line."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", script)] + [str(x) for x in argv]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"{script} exceeded its {timeout_s:.0f} s box", "cmd": " ".join(cmd[1:])}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"{script} rc={r.returncode}: {r.stderr[-300:]}", "cmd": " ".join(cmd[1:])}
+    d = json.loads(lines[-1])
+    out = {k: d[k] for k in keep if k in d}
+    out["cmd"] = "python " + " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd[1:])
+    out["leg_wall_s"] = time.perf_counter() - t0
+    return out
 
 
 def self_launch(n: int) -> int:
@@ -291,14 +377,84 @@ def deadline_guard(budget_s: float, late_line, emit=None):
     return done
 
 
+# Numeric bounds on 1 - cos of the pooled embeddings against the reference's arithmetic in FP32 after all 32 layers (VERDICT r03 #1c: constants,
+# not ratios to a yardstick).  Anchors: profiles/r04_depth_parity.json and tests/golden/encoder_7b-depth32.npz (DESIGN section 2 "depth").
+#   fixture model (the same layer 32 times, uniform +-0.035 weights; the reference's OWN bf16 run of it is 4.6e-4 .. 6.0e-4 from its fp32 run):
+FULL_DEPTH_BOUND_BF16_RESIDUAL = 7.0e-4          # measured 4.3e-4 .. 5.4e-4 (default precision policy: the reference's bf16 rounding points)
+FULL_DEPTH_BOUND_FP32_RESIDUAL = 4.5e-4          # measured 2.9e-4 .. 3.4e-4 (opt-in fp32 residual stream)
+#   bench model (32 DISTINCT N(0, 0.02) layers, the first 32 documents of the timed 256 x 512 batch):
+BENCH_BOUND_BF16_RESIDUAL = 1.0e-3               # measured max 7.1e-4 / mean 6.4e-4 over 32 documents
+BENCH_BOUND_FP32_RESIDUAL = 6.5e-4               # measured max 4.5e-4 / mean 4.1e-4
+NORTH_STAR_NOTE = ("north_star asks < 1e-4; at depth 32 no implementation with bf16 MFMA operands reaches it on these synthetic models: the error grows "
+                   "linearly with depth (~1.4e-5 per layer with the reference's bf16 rounding points, ~0.9e-5 with the fp32 residual stream: "
+                   "independent operand roundings of x, q|k|v, P, ctx, act in every layer), < 1e-4 holds up to depth 8 and every <= 1-layer pin "
+                   "at the 7B shape is at 1e-5; the reference's own bf16 run is further from its fp32 run than the engine is "
+                   "(profiles/r04_depth_parity.json)")
+
+
+def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32, chunk=8, time_steps=3):
+    """`encode()` at configs[1], not a synthetic side case (VERDICT r03 #1a): the engine's embeddings of the first `docs` documents of the TIMED
+    batch against the reference-equivalent module (oracle/torch_reference.py: the stock transformers module driven with the reference's mask
+    rule -- no mask for an all-valid batch, modeling_mistral_gritlm.py:1017-1020 --, pinned bit for bit on reference-generated fixtures) in
+    FP32 on this GPU, loaded from the ENGINE'S OWN weights (gritlm/gritlm.py:129-158, scripts/modeling_mistral_gritlm.py:936-1096).  Both
+    precision policies of the engine are held to numeric bounds; the stock module in bf16 on this GPU is reported, it bounds nothing."""
+    import torch_reference as TR
+    from gritlm_amd import ops
+    cfgd = dict(TR.SHAPE_7B, num_hidden_layers=layers)
+    n = min(docs, ids.shape[0])
+    si, sm = ids[:n].contiguous(), mask[:n].contiguous()
+
+    def omc(a, b):
+        d = 1.0 - torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)
+        return {"max_one_minus_cos": float(d.max()), "mean_one_minus_cos": float(d.mean())}
+
+    def stock(dtype, rule):
+        m = TR.build_model(cfgd, dtype, dev, state_dict=hf_sd)
+        e = torch.cat([TR.encode(m, si[i:i + chunk], sm[i:i + chunk], mask_rule=rule) for i in range(0, n, chunk)]).float()
+        del m
+        torch.cuda.empty_cache()
+        return e
+
+    ref = stock(torch.float32, "reference")
+    e_stock = stock(torch.bfloat16, "reference")
+    out = {"what": f"the first {n} documents of the timed batch ({ids.shape[0]} x {ids.shape[1]}, the bench's own {layers}-layer weights): HIP engine vs "
+                   "the reference-equivalent module in FP32 on this GPU loaded from the engine's weights (oracle/torch_reference.py, reference "
+                   "mask rule); 1 - cos per document",
+           "docs": n, "layers": layers}
+    d = omc(emb_default[:n], ref)
+    out["engine_bf16_residual_default"] = {**d, "bound": BENCH_BOUND_BF16_RESIDUAL, "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_BF16_RESIDUAL}
+    eng.residual_fp32 = True
+    try:
+        e32 = ops.pool_norm(eng.forward(si, sm, borrow=True), sm, "mean", True).float().clone()
+        d = omc(e32, ref)
+        rate = None
+        if time_steps:
+            ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(time_steps):
+                ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
+            torch.cuda.synchronize()
+            rate = ids.shape[0] * time_steps / (time.perf_counter() - t0)
+    finally:
+        eng.residual_fp32 = False
+        eng._ws.clear()
+    out["engine_fp32_residual_opt_in"] = {**d, "bound": BENCH_BOUND_FP32_RESIDUAL, "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_FP32_RESIDUAL,
+                                          "docs_per_s": rate, "how": "MistralEncoderEngine.residual_fp32 = True / GritLM(..., residual_fp32=True)"}
+    out["stock_module_bf16_this_gpu"] = {**omc(e_stock, ref), "what": "stock transformers module, bf16, sdpa, the reference's mask rule, same weights, "
+                                         "through PyTorch-ROCm: what the reference's Python computes on this GPU (reported; bounds nothing)"}
+    out["engine_default_vs_stock_module_bf16"] = omc(emb_default[:n], e_stock)
+    out["within_bound"] = bool(out["engine_bf16_residual_default"]["within_bound"] and out["engine_fp32_residual_opt_in"]["within_bound"])
+    return out
+
+
 def full_depth_parity(dev):
-    """32-layer parity datum: the HIP engine on the SAME weights and token ids the ``cpu_baseline_numpy_oracle`` leg
-    pushes through all 32 fp32 layers (1 doc x 512 tokens, 7B layer shape), and -- as the yardstick -- the stock Hugging Face module in
-    bf16 on this GPU on the same weights: how far does ANY bf16 implementation of scripts/modeling_mistral_gritlm.py:936-1096 land from
-    the fp32 result after 32 layers."""
+    """32-layer datum on the FIXTURE model (the model of tests/golden/encoder_7b-depth32.npz, which the reference itself ran): the HIP engine
+    on the SAME weights and token ids the ``cpu_baseline_numpy_oracle`` leg pushes through all 32 fp32 layers (1 doc x 512 tokens, 7B
+    layer shape).  Numeric bound (FULL_DEPTH_BOUND_BF16_RESIDUAL); the GPU test `full_depth_parity_32_layers` holds the same engine to
+    the reference-generated embeddings of that fixture."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
-    import torch_reference as TR
     from gritlm_amd import ops
     from gritlm_amd.encoder import EncoderConfig, MistralEncoderEngine
     cfg, w, ids, mask = oracle_full_depth_case()
@@ -308,20 +464,17 @@ def full_depth_parity(dev):
     sd = {k: torch.from_numpy(v) for k, v in w.items()}
     eng = MistralEncoderEngine.from_state_dict(EncoderConfig.from_dict(cfg), sd, dev)
     tid, tm = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
-    e_hip = ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy()
+    cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
+    hip = cosd(ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy(), ref)
+    eng.residual_fp32 = True
+    hip32 = cosd(ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy(), ref)
     del eng
     torch.cuda.empty_cache()
-    hf = TR.build_model(cfg, torch.bfloat16, dev, state_dict=sd)
-    e_hf = TR.encode(hf, tid, tm).float().cpu().numpy()
-    del hf
-    torch.cuda.empty_cache()
-    cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
-    hip, stock = cosd(e_hip, ref), cosd(e_hf, ref)
-    return {"what": "1 doc x 512 tokens through all 32 layers at the 7B layer shape, identical bf16-representable weights on every side",
-            "one_minus_cos_vs_fp32_oracle": hip, "stock_hf_bf16_one_minus_cos_vs_fp32_oracle": stock,
-            "one_minus_cos_vs_stock_hf_bf16": cosd(e_hip, e_hf),
-            "bound": "north_star: < 1e-4, or no further from fp32 than the reference's own bf16 run (stock HF bf16 on this GPU)",
-            "within_bound": bool(hip < 1e-4 or hip <= 1.25 * stock)}, {
+    return {"what": "1 doc x 512 tokens through all 32 layers at the 7B layer shape (the repeated-layer model of tests/golden/encoder_7b-depth32.npz), "
+                    "HIP engine vs the fp32 numpy oracle on identical bf16-representable weights",
+            "one_minus_cos_vs_fp32_oracle": hip, "bound": FULL_DEPTH_BOUND_BF16_RESIDUAL,
+            "fp32_residual_opt_in_one_minus_cos_vs_fp32_oracle": hip32, "fp32_residual_bound": FULL_DEPTH_BOUND_FP32_RESIDUAL,
+            "within_bound": bool(hip < FULL_DEPTH_BOUND_BF16_RESIDUAL and hip32 < FULL_DEPTH_BOUND_FP32_RESIDUAL)}, {
             "value": ids.shape[0] / dt, "unit": "docs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
             "sample": f"numpy oracle (oracle/gritlm_oracle.py, fp32 OpenBLAS), {ids.shape[0]} doc(s) x {ids.shape[1]} tok through all "
                       f"{cfg['num_hidden_layers']} layers, {dt:.2f} s", "seconds": dt}
@@ -371,8 +524,10 @@ def main():
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-batch (padded vs packed) leg")
     ap.add_argument("--pairs", type=int, default=256, help="contrastive pairs per GPU per step (BASELINE configs[2]: 256)")
     ap.add_argument("--chunk", type=int, default=32, help="GradCache chunk size (BASELINE configs[2]: 32)")
-    ap.add_argument("--contrastive-steps", type=int, default=1)
+    ap.add_argument("--contrastive-steps", type=int, default=3, help="timed contrastive steps (after one warm-up step); ~52 s each at configs[2]")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm encode on this GPU")
+    ap.add_argument("--no-mixtral", action="store_true", help="skip the BASELINE configs[3] leg (Mixtral-8x7B shape, 64 x seq2048)")
+    ap.add_argument("--no-rag", action="store_true", help="skip the BASELINE configs[4] leg (512 passages x seq2048 with KV + 128 new tokens)")
     ap.add_argument("--dry-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo ranks, a tiny Hugging Face model on the host instead of the HIP engine; "
                          "the line is marked INVALID (tests/test_bench_cli.py)")
@@ -444,9 +599,14 @@ def main():
     sync()
     if not dry:
         ops.set_timer(timer)
+    marks = []                          # one HIP event per step boundary on the launch stream (no sync inside the timed region)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if not dry:
+            marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
         emb = step()
+    if not dry:
+        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
     sync()
     if dist is not None:
         dist.barrier()
@@ -454,6 +614,7 @@ def main():
     dt = time.perf_counter() - t0
     if not dry:
         ops.set_timer(None)
+    step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
     assert torch.isfinite(emb).all(), "non-finite embeddings"
     flops_per_token = 0.0 if dry else eng.flops_per_token(SEQ)
 
@@ -502,7 +663,7 @@ def main():
             vendor = vendor_gemm_comparator(dev)
         except Exception as e:  # noqa: BLE001
             vendor = {"error": repr(e)[:200]}
-    torch_baseline = None
+    torch_baseline = parity_sw = vendor_sustained = None
     if baselines:
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -517,6 +678,14 @@ def main():
             del e_hf
         except Exception as e:  # noqa: BLE001
             torch_baseline = {"error": repr(e)[:300]}
+        try:
+            parity_sw = parity_same_weights(eng, hf_sd, ids, mask, emb_engine, dev, args.layers)
+        except Exception as e:  # noqa: BLE001
+            parity_sw = {"error": repr(e)[:300]}
+        try:
+            vendor_sustained = vendor_gemm_sustained(dev)
+        except Exception as e:  # noqa: BLE001
+            vendor_sustained = {"error": repr(e)[:200]}
         del hf_sd, eng
         torch.cuda.empty_cache()
     line = None
@@ -526,6 +695,10 @@ def main():
         line = {
             "metric": "encoded docs/sec @ seq512", "value": docs_per_s, "unit": "docs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            **({"per_step": {"what": "HIP events at the step boundaries on the launch stream of rank 0 (SURVEY 8d: median and min next to "
+                                     "the mean the contract's `value` is computed from)", "median_ms": step_ms[len(step_ms) // 2],
+                             "min_ms": step_ms[0], "max_ms": step_ms[-1], "docs_per_s_median_step": DOCS / step_ms[len(step_ms) // 2] * 1e3,
+                             "docs_per_s_best_step": DOCS / step_ms[0] * 1e3}} if step_ms else {}),
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "GritLM-7B (Mistral-7B shape, 32L, random-init) bf16 bidirectional encode, batch 256 x seq512, "
                                    "mean pooling + L2 normalise, per GPU", "docs_per_step_per_gpu": DOCS, "seq_len": SEQ,
@@ -562,7 +735,7 @@ def main():
             line["contrastive"] = {"error": f"contrastive leg exceeded its deadline on {world} ranks; primary line emitted by the deadline guard"}
             line["collectives"] = {"backend": backend, "ranks": world, "encode_data_path_collectives": 0}
             return json.dumps(line)
-        guard = deadline_guard(float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "480")), _late_line, emit)
+        guard = deadline_guard(float(os.environ.get("GRIT_BENCH_CONTRASTIVE_DEADLINE_S", "900")), _late_line, emit)
     contrastive = None
     if not args.no_contrastive:
         try:
@@ -578,6 +751,12 @@ def main():
     if rank == 0:
         if vendor is not None:
             line["roofline"]["vendor_gemm_tflops_same_shapes_no_epilogue"] = vendor
+            vs = {"what": "this kernel (epilogues fused) / hipBLASLt behind torch.matmul (plain store), same GPU, same process"}
+            if "flop_weighted" in vendor:
+                vs["in_model_over_5_launch_comparator"] = line["roofline"]["achieved"] / vendor["flop_weighted"]
+            if vendor_sustained is not None:
+                vs["sustained_interleaved"] = vendor_sustained
+            line["roofline"]["vs_vendor_same_run"] = vs
         if ragged is not None:
             line["ragged_batch"] = ragged
         if contrastive is not None:
@@ -597,9 +776,29 @@ def main():
         if not multi and not dry and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             try:
-                line["parity_full_depth"], line["cpu_baseline_numpy_oracle"] = full_depth_parity(dev)
+                fixture_datum, line["cpu_baseline_numpy_oracle"] = full_depth_parity(dev)
             except Exception as e:  # noqa: BLE001
-                line["parity_full_depth"] = {"error": repr(e)[:300]}
+                fixture_datum = {"error": repr(e)[:300]}
+            line["parity_full_depth"] = {
+                "vs_reference_fp32_same_weights": parity_sw, "fixture_model_vs_fp32_numpy_oracle": fixture_datum,
+                "depth_curve": "profiles/r04_depth_parity.json (1 - cos at depth 1/2/4/8/16/32, both engine policies, stock bf16 under both mask rules)",
+                "north_star": NORTH_STAR_NOTE,
+                "within_bound": bool((parity_sw or {}).get("within_bound")) and bool(fixture_datum.get("within_bound"))}
+        if not multi and not dry:
+            import gc as _gc
+            _gc.collect()
+            torch.cuda.empty_cache()
+            if not args.no_mixtral:
+                line["mixtral_8x7b_seq2048"] = secondary_leg(
+                    "mixtral_bench.py", ["--docs", 64, "--seq", 2048, "--steps", 3, "--warmup", 1], 420,
+                    ("metric", "value", "unit", "ms_per_step", "tokens_per_s", "config", "roofline", "model_flops_utilisation", "hbm_allocated_gb",
+                     "expert_load_max_over_mean", "finite", "kernels"))
+            if not args.no_rag:
+                line["rag_doc_caching"] = secondary_leg(
+                    "rag_cache_bench.py", ["--passages", 512, "--seq", 2048, "--new-tokens", 128, "--queries", 4], 600,
+                    ("metric", "passages", "seq", "encode_s", "passages_per_s", "encode_tokens_per_s", "encode_mfma_roofline_frac", "kv_cache_gb",
+                     "generate_s_per_query", "decode_tokens_per_s", "decode_path", "native_decode", "decode_frac_of_weight_streaming_roofline",
+                     "hbm_allocated_gb"))
         emit(json.dumps(line))
         emitted.append(True)
     if dist is not None:

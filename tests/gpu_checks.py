@@ -768,8 +768,7 @@ def check_gemm_fullshape(M, N, K, epi=EPI_STORE, seed=91, samples=4096):
 # 3.4e-4.  The kernels are bit-reproducible, so the margin covers nothing but a re-generated fixture.  The north-star's 1e-4 is not
 # reachable at depth 32 with bf16 MFMA operands: the error grows linearly with depth (1e-5 per layer, independent per-layer operand
 # roundings) in BOTH modes and in the reference's own bf16 run.
-FULL_DEPTH_BOUND_BF16_RESIDUAL = 7.0e-4
-FULL_DEPTH_BOUND_FP32_RESIDUAL = 4.5e-4
+# (the constants live in bench.py, which reports against the same numbers: FULL_DEPTH_BOUND_BF16_RESIDUAL = 7.0e-4, _FP32_RESIDUAL = 4.5e-4)
 
 
 def check_full_depth_parity(residual_fp32=False):
@@ -786,7 +785,7 @@ def check_full_depth_parity(residual_fp32=False):
     import torch_reference as TR
     g = np.load(os.path.join(GOLDEN, "encoder_7b-depth32.npz"))
     layers = int(g["layers"])
-    bound = FULL_DEPTH_BOUND_FP32_RESIDUAL if residual_fp32 else FULL_DEPTH_BOUND_BF16_RESIDUAL
+    bound = bench.FULL_DEPTH_BOUND_FP32_RESIDUAL if residual_fp32 else bench.FULL_DEPTH_BOUND_BF16_RESIDUAL
     cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
     cfg, w, _, _ = bench.oracle_full_depth_case(sample_docs=1, seq=64, layers=layers)
     sd = {k: torch.from_numpy(v) for k, v in w.items()}

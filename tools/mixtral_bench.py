@@ -50,7 +50,12 @@ print(json.dumps({
     "metric": f"encoded docs/sec @ seq{a.seq} (Mixtral-8x7B shape, sparse MoE top-2)", "value": docs_per_s, "unit": "docs/s", "n_gpus": 1,
     "steps": a.steps, "ms_per_step": dt / a.steps * 1e3, "dtype": "bf16", "data": "synthetic, random-init weights",
     "config": {"workload": f"Mixtral-8x7B shape, {a.layers}L, 8 experts top-2, batch {a.docs} x seq{a.seq}, mean pool + normalise"},
-    "model_flops_utilisation": docs_per_s * flops_doc / 2.5e15, "weights_init_s": t_init, "hbm_allocated_gb": torch.cuda.max_memory_allocated() / 1e9,
+    "model_flops_utilisation": docs_per_s * flops_doc / 2.5e15,
+    "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_k (grouped launches: expert GEMMs)", "peak": 2500.0, "unit": "TFLOP/s",
+                 "achieved": ks["gemm_bf16_nt_grouped"]["work"] / (ks["gemm_bf16_nt_grouped"]["total_ms"] * 1e-3) / 1e12,
+                 "frac": ks["gemm_bf16_nt_grouped"]["work"] / (ks["gemm_bf16_nt_grouped"]["total_ms"] * 1e-3) / 1e12 / 2500.0,
+                 "whole_step_frac": docs_per_s * flops_doc / 2.5e15},
+    "tokens_per_s": docs_per_s * a.seq, "weights_init_s": t_init, "hbm_allocated_gb": torch.cuda.max_memory_allocated() / 1e9,
     "expert_load_max_over_mean": float((counts.max(dim=1)[0] / counts.mean(dim=1)).mean()), "finite": bool(torch.isfinite(e).all()),
     "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 2), "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12}
                 for k, v in ks.items()}}))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] "RAG doc-caching": encode passages with get_cache=True (native bidirectional pass that also emits the per-layer
 post-RoPE K/V, gritlm/gritlm.py:131-140, rag/eval.py:124-150) and generate tokens for a query REUSING a passage's KV (rag/eval.py:237-246,
-cache == "doc").  Encoding + KV emission run on the HIP engine; the token-by-token decode is the Hugging Face module (causal decode
-kernels are not built).   python tools/rag_cache_bench.py [--passages 512 --seq 2048 --new-tokens 128] [--tiny --cpu]"""
+cache == "doc").  Encoding + KV emission run on the HIP engine; the token-by-token decode is timed twice: the Hugging Face module's
+generate() on the spliced cache (what the reference does) and the native decoder (gritlm_amd/decoder.py, csrc/decode.hip).   python tools/rag_cache_bench.py [--passages 512 --seq 2048 --new-tokens 128] [--tiny --cpu]"""
 import argparse
 import json
 import os
@@ -151,7 +151,10 @@ if m.engine is not None:
 tokens = a.passages * a.seq
 kv_gb = sum(sum(x.numel() * x.element_size() for x in ((l.keys, l.values) if hasattr(l, "keys") else l)) for c in caches
             for l in (c.layers if hasattr(c, "layers") else c)) / 1e9
+enc_frac = (tokens / t_enc) * m.engine.flops_per_token(a.seq) / 2.5e15 if m.engine is not None else None
 print(json.dumps({"metric": "RAG doc-caching: encode passages (+KV) and generate from the cached KV", "passages": a.passages, "seq": a.seq,
+                  "encode_mfma_roofline_frac": enc_frac,
+                  "decode_frac_of_weight_streaming_roofline": (native["hbm_roofline_ms_per_token"] / native["decode_ms_per_token"]) if native else None,
                   "encode_s": t_enc, "passages_per_s": a.passages / t_enc, "encode_tokens_per_s": tokens / t_enc, "kv_cache_gb": kv_gb,
                   "native_engine": m.engine is not None, "generate_s_per_query": t_gen / a.queries, "new_tokens_per_query": n_new / a.queries,
                   "decode_tokens_per_s": n_new / t_gen, "decode_path": "Hugging Face generate() on the spliced cache", "native_decode": native,
