@@ -213,6 +213,21 @@ class MistralEncoderEngine:
         eng.norm = nrm()
         return eng
 
+    def replica(self, device) -> "MistralEncoderEngine":
+        """A copy of this engine on another GPU (the repacked weights are copied device to device; precision policy, attention mode and
+        window are inherited): one replica per visible GPU is what in-process multi-GPU encode runs on (gritlm_amd/gritlm.py)."""
+        eng = type(self)(self.cfg, device)
+        mv = lambda t: None if t is None else t.to(eng.device)
+        eng.embed, eng.norm = mv(self.embed), mv(self.norm)
+        for L in self.layers:
+            R = _Layer()
+            for k in _Layer.__slots__:
+                if hasattr(L, k):
+                    setattr(R, k, mv(getattr(L, k)))
+            eng.layers.append(R)
+        eng.causal, eng.window_keys, eng.residual_fp32 = self.causal, self.window_keys, self.residual_fp32
+        return eng
+
     def to_hf_state_dict(self) -> dict:
         """The engine's (repacked) weights under the Hugging Face ``MistralModel`` names (inverse of ``from_state_dict``: the fused QKV
         matrix split back, the gate / up rows de-interleaved); dense MLP only.  bench.py / the tests load the STOCK module from it to
@@ -345,39 +360,61 @@ class MistralEncoderEngine:
                       instr_len: torch.Tensor | None = None, packed: bool | None = None) -> torch.Tensor:
         """pool(normalise(encoder(ids))) -> [B,H] fp32.  With a right-padded batch the padding is dropped before the first
         kernel ("packed" rows, cu_seqlens): GEMMs, norms and attention only ever see real tokens -- the reference's SDPA path
-        computes every padded row.  Results are bit-identical to the padded path."""
+        computes every padded row.  Results are bit-identical to the padded path.
+
+        HOST tensors (what the tokenizer returns) are the preferred input: the batch geometry -- right-padded or not, row lengths,
+        cu_seqlens, the packed token list -- is then derived on the host, only real tokens cross PCIe, and the call issues its launches
+        without a single device synchronisation (the host runs ahead: the next batch is tokenised, and in-process multi-GPU encode
+        feeds the other replicas, while this one computes).  Device tensors take the same path with three small syncs."""
         c = self.cfg
         B, S = input_ids.shape
         window = self._window(S)
-        mask = attention_mask.to(device=self.device, dtype=torch.int64)
-        ids = input_ids.to(device=self.device, dtype=torch.int64)
-        if packed is None:
-            packed = self.is_right_padded(mask) and bool((mask.sum(dim=1) > 0).all())
-        if not packed:
-            h = self.forward(ids, mask, borrow=True)
-            return ops.pool_norm(h, mask.contiguous(), method, normalize, instr_len)
-        lens = mask.sum(dim=1).to(torch.int32)
-        cu = torch.zeros((B + 1,), dtype=torch.int32, device=self.device)
-        cu[1:] = torch.cumsum(lens, dim=0)
-        keep = mask.bool()
-        pids = ids[keep].contiguous()                                        # row-major order == sequence order
-        pos = (torch.arange(S, device=self.device, dtype=torch.int32).unsqueeze(0).expand(B, S))[keep].contiguous()
-        T = int(pids.numel())
-        max_len = int(lens.max().item())
-        ws = self._workspace(T)
-        h, x, qkv, ctx = ws["h"], ws["x"], ws["qkv"], ws["ctx"]
-        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
-        cos, sin = self._rope_tables(S)
-        ops.embed_gather(self.embed, pids, out=h)
-        for L in self.layers:
-            ops.rmsnorm(h, L.ln1, eps, out=x)
-            ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, positions=pos, out=qkv)
-            ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal, window=window)
-            ops.gemm_nt(ctx, L.wo, out=h, epilogue=self._epi_res(), residual=h)
-            ops.rmsnorm(h, L.ln2, eps, out=x)
-            self._mlp(L, x, h, ws)
-        ops.rmsnorm(h, self.norm, eps, out=x)
-        return ops.pool_norm_varlen(x, cu, method, normalize, instr_len)
+        with torch.cuda.device(self.device):
+            if attention_mask.device.type == "cpu" and input_ids.device.type == "cpu":
+                m = attention_mask != 0
+                lens_h = m.sum(dim=1)
+                if packed is None:
+                    packed = bool(((torch.arange(S).unsqueeze(0) < lens_h.unsqueeze(1)) == m).all()) and bool((lens_h > 0).all())
+                if packed:
+                    pids = input_ids.to(torch.int64)[m].contiguous().to(self.device, non_blocking=True)
+                    pos = torch.arange(S, dtype=torch.int32).unsqueeze(0).expand(B, S)[m].contiguous().to(self.device, non_blocking=True)
+                    cu_h = torch.zeros((B + 1,), dtype=torch.int32)
+                    cu_h[1:] = torch.cumsum(lens_h, dim=0)
+                    cu = cu_h.to(self.device, non_blocking=True)
+                    T, max_len = int(cu_h[-1]), int(lens_h.max())
+            else:
+                attention_mask = attention_mask.to(device=self.device, dtype=torch.int64)
+                input_ids = input_ids.to(device=self.device, dtype=torch.int64)
+                if packed is None:
+                    packed = self.is_right_padded(attention_mask) and bool((attention_mask.sum(dim=1) > 0).all())
+                if packed:
+                    lens = attention_mask.sum(dim=1).to(torch.int32)
+                    cu = torch.zeros((B + 1,), dtype=torch.int32, device=self.device)
+                    cu[1:] = torch.cumsum(lens, dim=0)
+                    keep = attention_mask.bool()
+                    pids = input_ids[keep].contiguous()                              # row-major order == sequence order
+                    pos = (torch.arange(S, device=self.device, dtype=torch.int32).unsqueeze(0).expand(B, S))[keep].contiguous()
+                    T, max_len = int(pids.numel()), int(lens.max().item())
+            if instr_len is not None:
+                instr_len = instr_len.to(self.device)
+            if not packed:
+                mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+                h = self.forward(input_ids.to(device=self.device, dtype=torch.int64), mask, borrow=True)
+                return ops.pool_norm(h, mask, method, normalize, instr_len)
+            ws = self._workspace(T)
+            h, x, qkv, ctx = ws["h"], ws["x"], ws["qkv"], ws["ctx"]
+            nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+            cos, sin = self._rope_tables(S)
+            ops.embed_gather(self.embed, pids, out=h)
+            for L in self.layers:
+                ops.rmsnorm(h, L.ln1, eps, out=x)
+                ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, positions=pos, out=qkv)
+                ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal, window=window)
+                ops.gemm_nt(ctx, L.wo, out=h, epilogue=self._epi_res(), residual=h)
+                ops.rmsnorm(h, L.ln2, eps, out=x)
+                self._mlp(L, x, h, ws)
+            ops.rmsnorm(h, self.norm, eps, out=x)
+            return ops.pool_norm_varlen(x, cu, method, normalize, instr_len)
 
     def flops_per_token(self, S: int) -> float:
         """Algorithmic forward FLOPs per token: projections + MLP + attention core."""

@@ -63,6 +63,8 @@ class GritLM(torch.nn.Module):
         from transformers import AutoModel, AutoModelForCausalLM, AutoTokenizer
 
         native = kwargs.pop("native", "auto")   # "auto" | True | False  (extension over the reference)
+        devices = kwargs.pop("devices", None)   # extension: the GPUs in-process multi-GPU encode uses (default: every visible one)
+        residual_fp32 = bool(kwargs.pop("residual_fp32", False))   # extension: fp32 residual stream in the native engine
         if mode == "embedding":
             if any(tag in model_name_or_path for tag in ("gtr", "t5", "instructor")):
                 from transformers import T5EncoderModel
@@ -86,7 +88,9 @@ class GritLM(torch.nn.Module):
         self.normalized = normalized
         self.pooling_method = pooling_method
         self.device = device
-        self.num_gpus = 1            # one process per GPU; multi-GPU encode shards the sentence list per rank
+        self.num_gpus = 1
+        self.engines = []            # in-process multi-GPU encode: one engine replica per GPU (set by _parallelize)
+        self._residual_fp32 = residual_fp32
         self.embed_eos = embed_eos
         self.attn = attn
         if (attn is not None) and attn not in _VALID_ATTN:
@@ -108,6 +112,10 @@ class GritLM(torch.nn.Module):
             if "device_map" not in kwargs and not kwargs.get("load_in_4bit", False) and not kwargs.get("load_in_8bit", False):
                 self.model.to(self.device)
             self._maybe_build_engine()
+            if "device_map" not in kwargs and not kwargs.get("load_in_4bit", False) and not kwargs.get("load_in_8bit", False):
+                # Parallelise embedding models unless a specific device is named, e.g. `cuda:1` (reference :69-75)
+                if mode == "embedding" and (not isinstance(self.device, str) or ":" not in self.device):
+                    self._parallelize(devices)
 
     # ------------------------------------------------------------------ native engine
     def _backbone(self):
@@ -122,6 +130,10 @@ class GritLM(torch.nn.Module):
         eligible = (dev.type == "cuda" and getattr(cfg, "model_type", "") in ("mistral", "mixtral") and self.attn is not None
                     and self.attn[:2] in ("bb", "cc") and self.model.dtype == torch.bfloat16)
         if not eligible:
+            if dev.type == "cuda" and getattr(cfg, "model_type", "") in ("mistral", "mixtral"):
+                # a Mistral on the GPU that silently takes the Hugging Face path is a 1.4x slower encode nobody asked for: say why
+                print(f"GritLM: native HIP engine NOT bound (attn={self.attn}, dtype={self.model.dtype}; it implements bf16 weights with "
+                      f"'bb..' / 'cc..' embedding attention) -- encode() runs on the Hugging Face module")
             if self._native is True:
                 raise RuntimeError("native=True but this configuration is not implemented by the HIP engine "
                                    f"(device={dev}, model_type={getattr(cfg, 'model_type', None)}, attn={self.attn}, dtype={self.model.dtype})")
@@ -135,6 +147,51 @@ class GritLM(torch.nn.Module):
         self.engine.causal = self.attn[:2] == "cc"       # 'cc..': causal embedding attention (e.g. lasttoken / weightedmean models)
         from .encoder import sliding_window_keys
         self.engine.window_keys = sliding_window_keys(getattr(cfg, "sliding_window", None), getattr(cfg, "_attn_implementation", None))
+        self.engine.residual_fp32 = bool(getattr(self, "_residual_fp32", False))
+
+    def _parallelize(self, devices=None):
+        """The reference wraps an embedding model in ``nn.DataParallel`` over every visible GPU and multiplies ``batch_size`` by their
+        number (gritlm/gritlm.py:69-75, :106-107): ONE process, ONE ``GritLM``, all GPUs (evaluation/eval_mteb.py constructs it that way).
+        Here: one ENGINE REPLICA per GPU, all driven from this process -- every (batch_size x num_gpus) batch is tokenised once, its rows
+        are dealt to the replicas in DataParallel's order (contiguous chunks of ceil(B / n) rows), each replica's launches are issued
+        asynchronously on its own device (host-side batch geometry: no synchronisation between issue and result), and the pooled rows come
+        back to the first device for the one concatenation.  No collective, no ``nn.DataParallel`` module replication per call.
+        Models the engine does not implement keep the reference's behaviour (``nn.DataParallel`` around the Hugging Face module)."""
+        if self.engine is None:
+            n = torch.cuda.device_count() if torch.cuda.is_available() and torch.device(self.device).type == "cuda" else 0
+            if n > 1:
+                self.num_gpus = n
+                print(f"----------Using {self.num_gpus} data-parallel GPUs----------")
+                self.model = torch.nn.DataParallel(self.model)
+            return
+        if devices is None:
+            devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+        devices = [torch.device(d) for d in devices]
+        if len(devices) <= 1:
+            return
+        first = self.engine.device.index if self.engine.device.index is not None else torch.cuda.current_device()
+        self.engines = [self.engine if (d.index == first) else self.engine.replica(d) for d in devices]
+        self.num_gpus = len(self.engines)
+        print(f"----------Using {self.num_gpus} data-parallel GPUs (one native engine replica each)----------")
+
+    @staticmethod
+    def _row_chunks(n_rows: int, n_parts: int):
+        """Row ranges ``torch.chunk`` / DataParallel's scatter give: contiguous chunks of ceil(n_rows / n_parts) rows, the last one shorter,
+        trailing parts dropped when the rows run out."""
+        size = -(-n_rows // n_parts) if n_rows else 0
+        return [(s, min(s + size, n_rows)) for s in range(0, n_rows, size)] if size else []
+
+    def _encode_native(self, inputs, n_instr):
+        """One tokenised batch (HOST tensors) through the native engine(s): pooled, normalised rows [B, H] fp32 on the first engine's device."""
+        engines = getattr(self, "engines", None) or [self.engine]
+        ids, mask = inputs["input_ids"], inputs["attention_mask"]
+        parts = []
+        for eng, (a, b) in zip(engines, self._row_chunks(ids.shape[0], len(engines))):
+            il = None if n_instr is None else torch.full((b - a,), n_instr, dtype=torch.int32, device=eng.device)
+            parts.append(eng.encode_pooled(ids[a:b], mask[a:b], self.pooling_method, bool(self.normalized), il))
+        if len(parts) == 1:
+            return parts[0]
+        return torch.cat([p.to(engines[0].device, non_blocking=True) for p in parts], dim=0)
 
     def native_decoder(self):
         """Greedy decoder on the HIP kernels (gritlm_amd.decoder.MistralDecoder) sharing the engine's weights; use it where the reference
@@ -210,17 +267,16 @@ class GritLM(torch.nn.Module):
         for start in tqdm(range(0, len(sentences), batch_size), desc="Batches", disable=len(sentences) < 256):
             texts = [instruction + s + self.embed_eos for s in sentences[start:start + batch_size]]
             inputs = self.tokenizer(texts, padding=True, truncation=True, return_tensors="pt", max_length=max_length,
-                                    add_special_tokens=add_special_tokens).to(self.device)
+                                    add_special_tokens=add_special_tokens)
             if self.engine is not None and not get_cache and self.projection is None and self.pooling_method in POOL_MODES:
-                # native fast path: padding dropped before the first kernel, pool + normalise fused (engine.encode_pooled)
-                il = None
-                if n_instr is not None:
-                    il = torch.full((inputs["input_ids"].shape[0],), n_instr, dtype=torch.int32, device=self.engine.device)
-                emb = self.engine.encode_pooled(inputs["input_ids"], inputs["attention_mask"], self.pooling_method, bool(self.normalized), il)
+                # native fast path: the tokenizer's HOST tensors go straight to the engine(s) -- padding dropped before the first kernel,
+                # pool + normalise fused, no device synchronisation per batch (engine.encode_pooled)
+                emb = self._encode_native(inputs, n_instr)
                 if recast or self.pooling_method == "cls":
                     emb = emb.to(self.model.dtype)
                 chunks.append(emb)
                 continue
+            inputs = inputs.to(self.device)
             hidden, cache = self._hidden_states(inputs, get_cache)
             if get_cache:
                 assert len(kv_caches) == 0, "Can only get cache for one batch at a time"

@@ -982,6 +982,34 @@ def check_gritlm_native_encode():
     return _res("GritLM.encode native vs reference GritLM.encode goldens", ok, **out)
 
 
+def check_gritlm_multi_gpu_in_process():
+    """In-process multi-GPU encode (gritlm/gritlm.py:69-75, :106-107: ONE GritLM in ONE process over every GPU, batch_size x num_gpus):
+    mode='embedding' with a device string that names no index builds one engine replica per listed GPU.  A one-GPU box can run (a) the
+    one-element list (no replicas, num_gpus 1), (b) TWO replicas that both live on cuda:0 -- a real `replica()` copy of the weights, the
+    DataParallel row split, both launch sequences issued back to back with no synchronisation, the cross-replica concatenation -- and
+    must get the single-engine embeddings back BIT FOR BIT (batch-invariant kernels, host-side geometry), in sentence order."""
+    import tempfile
+    from gritlm_amd import GritLM
+    sents = synth.make_sentences(23, seed=9, min_words=2, max_words=40)
+    instr = "Represent the sentence: "
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        m1 = GritLM(d16, mode="embedding", pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, devices=["cuda:0"])
+        ok &= m1.engine is not None and m1.num_gpus == 1 and m1.engines == []
+        base = m1.encode(sents, batch_size=8, max_length=64, instruction=instr)
+        m2 = GritLM(d16, mode="embedding", pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, devices=["cuda:0"])
+        rep = m2.engine.replica("cuda:0")
+        ok &= rep.embed.data_ptr() != m2.engine.embed.data_ptr() and bool(torch.equal(rep.layers[0].wqkv, m2.engine.layers[0].wqkv))
+        m2.engines, m2.num_gpus = [m2.engine, rep], 2
+        two = m2.encode(sents, batch_size=4, max_length=64, instruction=instr)          # 4 x 2 replicas: the same batches of 8
+        out["bit_identical_to_one_engine"] = bool(np.array_equal(base, two))
+        t = m2.encode(sents[:5], batch_size=2, max_length=64, convert_to_tensor=True)
+        out["odd_split_max_abs_diff"] = float(np.max(np.abs(t.float().cpu().numpy() - m1.encode(sents[:5], batch_size=4, max_length=64))))
+        ok &= out["bit_identical_to_one_engine"] and out["odd_split_max_abs_diff"] == 0.0 and t.shape == (5, 256)
+    return _res("GritLM in-process multi-GPU encode (two replicas, DataParallel row split)", ok, **out)
+
+
 def check_gritlm_native_mixtral():
     """gritlm_amd.GritLM on a (tiny) Mixtral checkpoint directory: model_type 'mixtral' binds the native MoE engine (from the
     installed transformers' fused expert parameters) and encode() matches the oracle on the same tokens."""
@@ -2353,6 +2381,7 @@ ALL_CHECKS = [
     ("encoder_tiny_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="tiny")),
     ("encoder_gqa_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="gqa")),
     ("encoder_7b_layer_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="7b-l1")),
+    ("gritlm_multi_gpu_in_process", check_gritlm_multi_gpu_in_process, {}),
     ("full_depth_parity_32_layers", check_full_depth_parity, {}),
     ("full_depth_parity_32_layers_fp32_residual", check_full_depth_parity, dict(residual_fp32=True)),
     ("gemm_full_swiglu_28672x4096", check_gemm_fullshape, dict(M=4096, N=28672, K=4096, epi=EPI_SWIGLU)),

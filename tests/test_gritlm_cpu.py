@@ -82,3 +82,49 @@ def test_pooling_mutates_mask_like_the_reference(golden_dir, dirs):
         out = m.pooling(torch.from_numpy(g["hidden"]), mask)
         np.testing.assert_allclose(out.numpy(), g[f"pool_{method}"], rtol=1e-5, atol=1e-6)
         np.testing.assert_array_equal(mask.numpy(), g[f"mask_after_{method}"])
+
+
+# ---------------------------------------------------------------------------------------------- in-process multi-GPU encode (host logic)
+def test_row_chunks_are_dataparallel_scatter_chunks():
+    """gritlm/gritlm.py:69-75: the reference scatters a batch with nn.DataParallel = torch.chunk along dim 0."""
+    for n_rows in (0, 1, 2, 5, 7, 8, 9, 16, 255, 256, 2048):
+        for parts in (1, 2, 3, 4, 8):
+            want = [int(c.numel()) for c in torch.arange(n_rows).chunk(parts)] if n_rows else []
+            got = GritLM._row_chunks(n_rows, parts)
+            assert [b - a for a, b in got] == want, (n_rows, parts, got, want)
+            assert all(got[i][1] == got[i + 1][0] for i in range(len(got) - 1)) and (not got or (got[0][0] == 0 and got[-1][1] == n_rows))
+
+
+class _FakeEngine:
+    """Stands in for one engine replica: 'embeds' a row as (sum of its real token ids, number of real tokens, rows in the call, replica id);
+    records what it was handed."""
+
+    def __init__(self, tag):
+        self.device, self.tag, self.calls = torch.device("cpu"), tag, []
+
+    def encode_pooled(self, ids, mask, method, normalize, instr_len=None):
+        assert ids.device.type == "cpu" and mask.device.type == "cpu", "the tokenizer's HOST tensors go to the replicas"
+        self.calls.append((tuple(ids.shape), None if instr_len is None else int(instr_len[0])))
+        m = mask.to(torch.float32)
+        return torch.stack([(ids * mask).sum(1).float(), m.sum(1), torch.full((ids.shape[0],), float(ids.shape[0])),
+                            torch.full((ids.shape[0],), float(self.tag))], dim=1)
+
+
+def test_two_replica_split_keeps_row_order_and_scales_the_batch(dirs):
+    """One process, one GritLM, two engine replicas (the reference: nn.DataParallel over 2 GPUs, batch_size x 2): every
+    (batch_size x 2) batch is tokenised ONCE (one padding length), its rows are dealt in contiguous halves, results come back in
+    sentence order; the instruction length reaches every replica."""
+    m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu")
+    sents = synth.make_sentences(11, seed=5, min_words=3, max_words=30)
+    m.engine, m.engines, m.num_gpus = _FakeEngine(0), [], 1
+    one = m.encode(sents, batch_size=4, max_length=64)
+    e0, e1 = _FakeEngine(0), _FakeEngine(1)
+    m.engine, m.engines, m.num_gpus = e0, [e0, e1], 2
+    two = m.encode(sents, batch_size=2, max_length=64, instruction="Represent: ")          # 2 x 2 GPUs = batches of 4 sentences
+    assert [c[0][0] for c in e0.calls] == [2, 2, 2] and [c[0][0] for c in e1.calls] == [2, 2, 1]       # 4 + 4 + 3 rows -> (2,2) (2,2) (2,1)
+    assert all(c[1] == e0.calls[0][1] and c[1] > 0 for c in e0.calls + e1.calls)
+    assert e0.calls[0][0][1] == e1.calls[0][0][1], "both halves of a batch share the batch's padding length"
+    np.testing.assert_array_equal(two[:, 3], np.array([0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1], dtype=np.float32))
+    m.engine, m.engines, m.num_gpus = e0, [e0, e1], 2
+    plain = m.encode(sents, batch_size=2, max_length=64)
+    np.testing.assert_array_equal(plain[:, :2], one[:, :2])                    # same rows, same order, whichever replica computed them
