@@ -28,13 +28,27 @@ def enabled() -> bool:
 class GatherHandle:
     """Result of an asynchronous gather: ``wait()`` orders torch's current stream behind the collective and returns the tensors."""
 
-    def __init__(self, q_all, p_all, event, keep):
+    def __init__(self, q_all, p_all, event, keep, device=None):
         self.q_all, self.p_all, self._event, self._keep = q_all, p_all, event, keep
+        self._device = device if device is not None else (q_all if q_all is not None else p_all).device
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self._event)
+        """Order the COLLECTIVE'S DEVICE's current stream behind the gather (not whatever device happens to be current)."""
+        if self._event is not None:
+            torch.cuda.current_stream(self._device).wait_event(self._event)
+            self._event = None
         self._keep = None
         return self.q_all, self.p_all
+
+    def __del__(self):
+        # A handle dropped without wait() (an exception between add() and finish()) must not hand its buffers back to the caching
+        # allocator while the collective still reads / writes them on the side stream: the outputs were allocated, and the inputs produced,
+        # on the compute stream, so ordering that stream behind the collective makes every later reuse of the memory safe (ADVICE r03).
+        try:
+            if self._event is not None:
+                torch.cuda.current_stream(self._device).wait_event(self._event)
+        except Exception:  # noqa: BLE001  -- interpreter shutdown
+            pass
 
 
 class NativeComm:
@@ -90,7 +104,7 @@ class NativeComm:
         # no record_stream(): the handle keeps the inputs alive until wait() has ordered the compute stream behind the collective, after
         # which the allocator may reuse them in compute-stream order (and a CU-masked stream can then be destroyed without the caching
         # allocator still holding it)
-        return GatherHandle(q_all, p_all, ev, (q, p))
+        return GatherHandle(q_all, p_all, ev, (q, p), self.device)
 
     def close(self):
         if getattr(self, "handle", None) is not None:

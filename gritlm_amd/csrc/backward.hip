@@ -231,12 +231,15 @@ __global__ void __launch_bounds__(256) swiglu_bwd_k(const uint16_t* __restrict__
 __global__ void __launch_bounds__(256) embed_scatter_sorted_k(const uint4* __restrict__ dh, const int64_t* __restrict__ sorted_ids,
                                                               const int64_t* __restrict__ order, uint4* __restrict__ grad, int64_t T, int HC,
                                                               int64_t V) {
+  // ids are clamped to [0, V) BEFORE the runs are detected: a sorted sequence stays sorted under the clamp, so all out-of-range ids fall
+  // into the run of row 0 / row V - 1 and every gradient row still has exactly one owning workgroup (clamping per run, as round 3 did,
+  // let two distinct out-of-range ids -- or -1 and 0 -- update the same row from two workgroups without synchronisation: ADVICE r03)
+  auto clampv = [V](int64_t x) { return x < 0 ? (int64_t)0 : (x >= V ? V - 1 : x); };
   const int64_t i = blockIdx.x;
-  const int64_t id = sorted_ids[i];
-  if (i > 0 && sorted_ids[i - 1] == id) return;
+  const int64_t row = clampv(sorted_ids[i]);
+  if (i > 0 && clampv(sorted_ids[i - 1]) == row) return;
   int64_t end = i + 1;
-  while (end < T && sorted_ids[end] == id) ++end;
-  const int64_t row = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  while (end < T && clampv(sorted_ids[end]) == row) ++end;
   for (int c = threadIdx.x; c < HC; c += 256) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int64_t j = i; j < end; ++j) {

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -914,14 +915,24 @@ static int device_cu_count() {
   return v;
 }
 
-// Tile-queue counters of the persistent launches: a ring of CTR_SETS sets of 8 counters (one per XCD) in a module-scope device array
-// (the library never allocates).  A launch takes the next set of the ring, clears it with a 32-byte memset node on ITS stream and
-// hands it to the kernel: launches on one stream are ordered behind each other, launches on different streams use different sets
-// (the ring is 4096 launches long).
-constexpr int CTR_SETS = 4096;
+// Tile-queue counters of the persistent launches: CTR_SETS sets of 8 counters (one per XCD) in a module-scope device array (the library
+// never allocates), organised as ONE RING PER STREAM: up to CTR_STREAMS (device, stream) pairs each own CTR_PER_STREAM consecutive sets.
+// A launch takes the next set of ITS STREAM'S ring, clears it with a 32-byte memset node on that stream and hands it to the kernel.
+// Why per stream: a set is re-cleared CTR_PER_STREAM launches later, and only stream order guarantees that the kernel that used it has
+// finished by then -- with one process-wide ring (round 3) a persistent kernel still pending on another stream (a side stream, an
+// autograd worker's stream, a stream parked on an event) could have had its live queue re-zeroed after the ring wrapped: tiles computed
+// twice or skipped, silently.  A 17th concurrent (device, stream) pair gets no ring and takes the per-tile launch form.
+constexpr int CTR_STREAMS = 16, CTR_PER_STREAM = 256, CTR_SETS = CTR_STREAMS * CTR_PER_STREAM;
 __device__ unsigned int g_tile_ctr[CTR_SETS * 8];
+struct CtrRing {
+  int dev;
+  hipStream_t st;
+  uint32_t next;
+  bool used;
+};
 static unsigned int* next_counter_set(hipStream_t st) {
-  static std::atomic<uint32_t> ring{0};
+  static std::mutex mu;
+  static CtrRing rings[CTR_STREAMS];
   static std::atomic<unsigned int*> base[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -932,7 +943,21 @@ static unsigned int* next_counter_set(hipStream_t st) {
     b = (unsigned int*)p;
     base[dev & 63].store(b, std::memory_order_release);
   }
-  unsigned int* set = b + (size_t)(ring.fetch_add(1, std::memory_order_relaxed) % CTR_SETS) * 8;
+  int slot = -1;
+  uint32_t idx = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < CTR_STREAMS && slot < 0; ++i)
+      if (rings[i].used && rings[i].dev == dev && rings[i].st == st) slot = i;
+    for (int i = 0; i < CTR_STREAMS && slot < 0; ++i)
+      if (!rings[i].used) {
+        rings[i] = CtrRing{dev, st, 0u, true};
+        slot = i;
+      }
+    if (slot < 0) return nullptr;                     // more concurrent streams than rings: per-tile launch form
+    idx = rings[slot].next++ % CTR_PER_STREAM;
+  }
+  unsigned int* set = b + ((size_t)slot * CTR_PER_STREAM + idx) * 8;
   if (hipMemsetAsync(set, 0, 8 * sizeof(unsigned int), st) != hipSuccess) return nullptr;
   return set;
 }

@@ -63,6 +63,10 @@ class GritLM(torch.nn.Module):
         from transformers import AutoModel, AutoModelForCausalLM, AutoTokenizer
 
         native = kwargs.pop("native", "auto")   # "auto" | True | False  (extension over the reference)
+        # the attention path decides how many keys a causal query sees under config.sliding_window (encoder.sliding_window_keys): taken
+        # from the caller's explicit `attn_implementation=` (forwarded to from_pretrained as in the reference) rather than from the
+        # PRIVATE config._attn_implementation, whose default differs between transformers releases ('eager' on 4.36-4.x, None on 5.x)
+        self._attn_impl = kwargs.get("attn_implementation")
         devices = kwargs.pop("devices", None)   # extension: the GPUs in-process multi-GPU encode uses (default: every visible one)
         residual_fp32 = bool(kwargs.pop("residual_fp32", False))   # extension: fp32 residual stream in the native engine
         if mode == "embedding":
@@ -146,7 +150,12 @@ class GritLM(torch.nn.Module):
         self.engine = MistralEncoderEngine.from_state_dict(ecfg, self._backbone().state_dict(), dev)
         self.engine.causal = self.attn[:2] == "cc"       # 'cc..': causal embedding attention (e.g. lasttoken / weightedmean models)
         from .encoder import sliding_window_keys
-        self.engine.window_keys = sliding_window_keys(getattr(cfg, "sliding_window", None), getattr(cfg, "_attn_implementation", None))
+        impl = getattr(self, "_attn_impl", None) or getattr(cfg, "_attn_implementation", None) or "sdpa"      # the reference's default: sdpa
+        self.engine.window_keys = sliding_window_keys(getattr(cfg, "sliding_window", None), impl)
+        if self.engine.causal and getattr(cfg, "sliding_window", None):
+            print(f"GritLM: causal embedding attention with config.sliding_window={cfg.sliding_window} on the '{impl}' path of the reference: "
+                  + (f"a query sees {self.engine.window_keys} keys" if self.engine.window_keys else "no window (the sdpa path applies none)")
+                  + "; pass attn_implementation= to choose, or set engine.window_keys")
         self.engine.residual_fp32 = bool(getattr(self, "_residual_fp32", False))
 
     def _parallelize(self, devices=None):

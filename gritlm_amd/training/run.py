@@ -129,10 +129,16 @@ def main(argv=None):
                 torch.save(model.projection.state_dict(), os.path.join(ck, "projection.pt"))
             torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
             torch.save(sched.state_dict(), os.path.join(ck, "scheduler.pt"))
-            torch.save({"cpu": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else []},
-                       os.path.join(ck, "rng_state.pth"))
             with open(os.path.join(ck, "trainer_state.json"), "w") as f:
                 json.dump({"global_step": step_, "micro_batches_done": step_ * gas, "world_size": world}, f)
+        if dist.is_initialized():
+            dist.barrier()                  # the directory exists on every rank's view before the per-rank files go in
+        # every rank's OWN generators (HF Trainer: rng_state_{rank}.pth; one rank: rng_state.pth): the CPU generator and the generator of
+        # the device this rank computes on.  (Round 3 wrote rank 0's states only and restored them on every rank.)
+        os.makedirs(ck, exist_ok=True)
+        cuda_state = torch.cuda.get_rng_state(torch.device(device)) if torch.device(device).type == "cuda" else None
+        torch.save({"cpu": torch.get_rng_state(), "cuda": cuda_state},
+                   os.path.join(ck, "rng_state.pth" if world == 1 else f"rng_state_{rank}.pth"))
         if dist.is_initialized():
             dist.barrier()
 
@@ -169,12 +175,15 @@ def main(argv=None):
         opt.load_state_dict(torch.load(os.path.join(ck, "optimizer.pt"), map_location=device))
         sched.load_state_dict(torch.load(os.path.join(ck, "scheduler.pt")))
         step, micro_done = int(st["global_step"]), int(st["micro_batches_done"])
-        rng_path = os.path.join(ck, "rng_state.pth")
+        rng_path = os.path.join(ck, "rng_state.pth" if world == 1 else f"rng_state_{rank}.pth")
         if os.path.exists(rng_path):
             rng = torch.load(rng_path, map_location="cpu")
             torch.set_rng_state(rng["cpu"])
-            if rng["cuda"] and torch.cuda.is_available() and len(rng["cuda"]) == torch.cuda.device_count():
-                torch.cuda.set_rng_state_all(rng["cuda"])
+            cs = rng.get("cuda")
+            if torch.is_tensor(cs) and torch.device(device).type == "cuda":
+                torch.cuda.set_rng_state(cs, torch.device(device))
+            elif isinstance(cs, (list, tuple)) and cs and torch.cuda.is_available() and len(cs) == torch.cuda.device_count():
+                torch.cuda.set_rng_state_all(cs)             # a round-3 checkpoint (rank 0's states of every visible device)
         if model.train_engine is not None:
             model.train_engine.weights_updated()
         logger.info("resumed from %s at step %d", ck, step)

@@ -362,7 +362,10 @@ int grit_knn_topk(const float* queries, const float* embeddings, int Q, int64_t 
 /* embedding backward (nn.Embedding's weight gradient, scripts/modeling_mistral_gritlm.py:918,994), deterministic: no atomics.
  * order [T] int64 = a STABLE argsort of the token ids, sorted_ids[i] = ids[order[i]]; dh [T,H] bf16; grad [V,H] bf16 (in/out):
  * grad[id, :] = bf16(grad[id, :] + sum of dh[t, :] over the tokens t with ids[t] == id, added in token order in fp32).
- * Rows of ids that do not occur are neither read nor written. */
+ * Rows of ids that do not occur are neither read nor written.  Ids outside [0, V) are clamped to row 0 / row V - 1 BEFORE the runs of
+ * equal ids are formed (a sorted sequence stays sorted under the clamp), so every gradient row has exactly one writer whatever the ids.
+ * One workgroup sums one run: a run of thousands of rows (the pad token of a padded batch) is a serial tail of about 1 us per 8 rows --
+ * the packed training path never feeds pad rows in. */
 int grit_embed_scatter_add_sorted(const void* dh, const int64_t* sorted_ids, const int64_t* order, void* grad, int64_t T, int H,
                                   int64_t V, void* stream);
 
