@@ -63,6 +63,9 @@ _SIGNATURES = {
     "grit_moe_index": (_i, [_p, _l, _i, _p, _p, _p, _p, _p]),
     "grit_moe_combine": (_i, [_p, _p, _p, _p, _p, _l, _i, _p]),
     "grit_moe_combine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p]),
+    "grit_moe_router_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
+    "grit_moe_router_wgrad_workspace_floats": (_l, [_l, _i, _i]),
+    "grit_moe_router_wgrad": (_i, [_p, _p, _p, _p, _l, _i, _i, _p]),
     "grit_gemm_bf16_nt_grouped_epi": (_i, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _l, _i, _p]),
     "grit_pool_norm_varlen_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "grit_infonce_rows_fwd_bwd": (_i, [_p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

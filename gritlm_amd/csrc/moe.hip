@@ -74,6 +74,143 @@ __global__ void __launch_bounds__(256) moe_router_top2_k(const uint16_t* __restr
   }
 }
 
+// ---- router backward (training; scripts/modeling_mixtral_gritlm.py:843-849 differentiated): w = renormalised top-2 of softmax(x Wg^T).
+//      One wave per token, gate matrix in LDS (the forward router's structure): the wave recomputes the token's E logits in fp32, forms
+//        p = softmax(logits);  s = p[e0] + p[e1];  w_k = p[e_k] / s;  dsel_k = (dw_k - sum_j dw_j w_j) / s;  inner = sum_k dsel_k p[e_k]
+//        dlogits[e] = p[e] * ((e == e_k ? dsel_k : 0) - inner)  (+ aux_dlogits[t, e]: the auxiliary load-balancing loss's pull)
+//      writes the [T, E] fp32 gradient of the logits and, in the same pass over the row,
+//        dx_out[t, :] = bf16(f32(dx_in[t, :]) + sum_e dlogits[e] * Wg[e, :])          (the gate Linear's input gradient joins the experts')
+//      HBM-bound byte work: x read, dx_in read, dx_out written, once each.
+template <int E>
+__global__ void __launch_bounds__(256) moe_router_bwd_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gate_w,
+                                                        const int32_t* __restrict__ experts, const float* __restrict__ dw,
+                                                        const float* __restrict__ aux, const uint16_t* __restrict__ dx_in,
+                                                        uint16_t* __restrict__ dx_out, float* __restrict__ dlogits, int64_t T, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* gw = reinterpret_cast<uint4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HC = H >> 3;
+  for (int i = tid; i < E * HC; i += 256) gw[i] = reinterpret_cast<const uint4*>(gate_w)[i];
+  __syncthreads();
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < T; t += (int64_t)gridDim.x * 4) {
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    const uint4* xr = reinterpret_cast<const uint4*>(x) + t * HC;
+    for (int c0 = lane; c0 < HC; c0 += 8 * 64) {
+      uint4 xv8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv8[u] = (c0 + 64 * u < HC) ? xr[c0 + 64 * u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 64 * u;
+        if (c >= HC) break;
+        const uint4 xv = xv8[u];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint4 wv = gw[e * HC + c];
+          float a_ = acc[e];
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.x), __builtin_bit_cast(bf16x2_t, wv.x), a_, false);
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.y), __builtin_bit_cast(bf16x2_t, wv.y), a_, false);
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.z), __builtin_bit_cast(bf16x2_t, wv.z), a_, false);
+          a_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xv.w), __builtin_bit_cast(bf16x2_t, wv.w), a_, false);
+          acc[e] = a_;
+        }
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { acc[e] = wave_sum(acc[e]); mx = fmaxf(mx, acc[e]); }      // fp32 logits (the backward's recompute keeps them unrounded)
+    float p[E], den = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { p[e] = expf(acc[e] - mx); den += p[e]; }
+    const float rden = 1.0f / den;
+    const int e0 = experts[2 * t], e1 = experts[2 * t + 1];
+    const float dw0 = dw[2 * t], dw1 = dw[2 * t + 1];
+    float pe0 = 0.f, pe1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { p[e] *= rden; pe0 = (e == e0) ? p[e] : pe0; pe1 = (e == e1) ? p[e] : pe1; }
+    const float ssel = pe0 + pe1;
+    const float g = (dw0 * pe0 + dw1 * pe1) / ssel;                 // sum_j dw_j w_j
+    const float ds0 = (dw0 - g) / ssel, ds1 = (dw1 - g) / ssel;
+    const float inner = ds0 * pe0 + ds1 * pe1;
+    float dl[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float dpe = (e == e0 ? ds0 : 0.f) + (e == e1 ? ds1 : 0.f);
+      dl[e] = p[e] * (dpe - inner) + (aux != nullptr ? aux[t * E + e] : 0.f);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) dlogits[t * E + e] = dl[e];
+    }
+    // dx_out = dx_in + dlogits @ Wg
+    const uint4* dir = dx_in != nullptr ? reinterpret_cast<const uint4*>(dx_in) + t * HC : nullptr;
+    uint4* dor = reinterpret_cast<uint4*>(dx_out) + t * HC;
+    for (int c = lane; c < HC; c += 64) {
+      const uint4 dv = dir != nullptr ? dir[c] : make_uint4(0, 0, 0, 0);
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint4 wv = gw[e * HC + c];
+        o[0] = fmaf(dl[e], bflo(wv.x), o[0]); o[1] = fmaf(dl[e], bfhi(wv.x), o[1]);
+        o[2] = fmaf(dl[e], bflo(wv.y), o[2]); o[3] = fmaf(dl[e], bfhi(wv.y), o[3]);
+        o[4] = fmaf(dl[e], bflo(wv.z), o[4]); o[5] = fmaf(dl[e], bfhi(wv.z), o[5]);
+        o[6] = fmaf(dl[e], bflo(wv.w), o[6]); o[7] = fmaf(dl[e], bfhi(wv.w), o[7]);
+      }
+      dor[c] = make_uint4(pack2bf(bflo(dv.x) + o[0], bfhi(dv.x) + o[1]), pack2bf(bflo(dv.y) + o[2], bfhi(dv.y) + o[3]),
+                          pack2bf(bflo(dv.z) + o[4], bfhi(dv.z) + o[5]), pack2bf(bflo(dv.w) + o[6], bfhi(dv.w) + o[7]));
+    }
+  }
+}
+
+// ---- gate weight gradient: dWg[e, h] = sum_t dlogits[t, e] * x[t, h].  Deterministic two-level sum: workgroup (column block, slab) owns
+//      512 columns (one dword = two bf16 columns per thread) of a slab of RW_SLAB tokens and writes fp32 partials [slab, E, H]; the
+//      reduce kernel adds the slabs in slab order and folds the sum into the bf16 gradient the way `grad.add_(dW.to(bf16))` does.
+constexpr int RW_SLAB = 512;
+template <int E>
+__global__ void __launch_bounds__(256) moe_router_wgrad_k(const uint16_t* __restrict__ x, const float* __restrict__ dlogits, float* __restrict__ part,
+                                                          int64_t T, int H) {
+  const int col = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 2;
+  const int64_t t0 = (int64_t)blockIdx.y * RW_SLAB;
+  const int64_t t1 = t0 + RW_SLAB < T ? t0 + RW_SLAB : T;
+  float a0[E], a1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+  if (col < H) {
+    const uint16_t* xc = x + col;
+    int64_t t = t0;
+    for (; t + 4 <= t1; t += 4) {                      // four row dwords in flight per thread
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint32_t*>(xc + (t + u) * H);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* d = dlogits + (t + u) * E;        // wave-uniform address: scalar loads
+#pragma unroll
+        for (int e = 0; e < E; ++e) { a0[e] = fmaf(d[e], bflo(v[u]), a0[e]); a1[e] = fmaf(d[e], bfhi(v[u]), a1[e]); }
+      }
+    }
+    for (; t < t1; ++t) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(xc + t * H);
+      const float* d = dlogits + t * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { a0[e] = fmaf(d[e], bflo(v), a0[e]); a1[e] = fmaf(d[e], bfhi(v), a1[e]); }
+    }
+    float* po = part + (int64_t)blockIdx.y * E * H + col;
+#pragma unroll
+    for (int e = 0; e < E; ++e) *reinterpret_cast<float2*>(po + (int64_t)e * H) = make_float2(a0[e], a1[e]);
+  }
+}
+
+__global__ void __launch_bounds__(256) moe_router_wgrad_reduce_k(const float* __restrict__ part, uint16_t* __restrict__ grad, int nslab, int64_t EH) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= EH) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += part[(int64_t)k * EH + i];
+  grad[i] = (uint16_t)f2bf(bf2f(grad[i]) + round_bf(s));            // grad.add_(dW.to(bfloat16)) in bf16 arithmetic
+}
+
 // ---- index: stable counting sort of the n = 2T (token, k) entries by expert, three launches:
 //      (1) per-chunk expert histograms (4096 entries per workgroup), (2) one small workgroup turns them into chunk bases,
 //      (3) every workgroup ranks its chunk in entry order (ballot + popcount per expert, running bases across the 16 rounds of 256).
@@ -251,6 +388,60 @@ extern "C" int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* 
   } while (0)
   if (E == 4) GRIT_ROUTER(4); else if (E == 8) GRIT_ROUTER(8); else GRIT_ROUTER(16);
   GRIT_CHECK_LAUNCH("grit_moe_router_top2");
+  return GRIT_OK;
+}
+
+// Router backward of the sparse-MoE block (training).  dw [T,2] fp32 = d loss / d routing weights (grit_moe_combine_bwd), experts [T,2] the
+// forward's selection, aux_dlogits [T,E] fp32 or NULL; dx_in [T,H] bf16 or NULL (the experts' input gradient); outputs dx_out [T,H] bf16
+// (may alias dx_in) and dlogits [T,E] fp32.
+extern "C" int grit_moe_router_bwd(const void* x, const void* gate_w, const int32_t* experts, const float* dw, const float* aux_dlogits,
+                                   const void* dx_in, void* dx_out, float* dlogits, int64_t T, int H, int E, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && gate_w && experts && dw && dx_out && dlogits, GRIT_E_BADARG, "grit_moe_router_bwd: null pointer");
+  GRIT_REQUIRE(T > 0 && T < (1ll << 40) && H > 0 && H % 8 == 0, GRIT_E_BADARG, "grit_moe_router_bwd: bad sizes T=%lld H=%d", (long long)T, H);
+  GRIT_REQUIRE(E == 4 || E == 8 || E == 16, GRIT_E_UNSUPPORTED, "grit_moe_router_bwd: num_experts=%d (4, 8 and 16 are built)", E);
+  GRIT_REQUIRE((size_t)E * H * 2 <= 160 * 1024, GRIT_E_UNSUPPORTED, "grit_moe_router_bwd: gate [%d,%d] exceeds LDS", E, H);
+  GRIT_REQUIRE(aligned16(x) && aligned16(gate_w) && aligned16(dx_out) && (!dx_in || aligned16(dx_in)), GRIT_E_BADARG,
+               "grit_moe_router_bwd: pointers must be 16-byte aligned");
+  const size_t lds = (size_t)E * H * 2;
+  int64_t nb = (T + 3) / 4;
+  if (nb > 1024) nb = 1024;
+  hipStream_t st = (hipStream_t)stream;
+#define GRIT_ROUTER_BWD(E_)                                                                                                   \
+  do {                                                                                                                        \
+    static std::atomic<uint64_t> optin_{0};                                                                                   \
+    lds_optin_once(moe_router_bwd_k<E_>, optin_, 160 * 1024);                                                                 \
+    hipLaunchKernelGGL(moe_router_bwd_k<E_>, dim3((unsigned)nb), dim3(256), lds, st, (const uint16_t*)x, (const uint16_t*)gate_w, experts, dw, \
+                       aux_dlogits, (const uint16_t*)dx_in, (uint16_t*)dx_out, dlogits, T, H);                                \
+  } while (0)
+  if (E == 4) GRIT_ROUTER_BWD(4); else if (E == 8) GRIT_ROUTER_BWD(8); else GRIT_ROUTER_BWD(16);
+  GRIT_CHECK_LAUNCH("grit_moe_router_bwd");
+  return GRIT_OK;
+}
+
+extern "C" int64_t grit_moe_router_wgrad_workspace_floats(int64_t T, int H, int E) {
+  if (T <= 0 || T > (1ll << 40) || H <= 0 || H > (1 << 20) || E <= 0 || E > MOE_MAX_E) return 0;       // 0 for sizes the compute call rejects
+  return ((T + RW_SLAB - 1) / RW_SLAB) * (int64_t)E * H;
+}
+
+// gate.weight gradient: grad [E,H] bf16 (in/out) += bf16(dlogits^T [E,T] @ x [T,H]); workspace: grit_moe_router_wgrad_workspace_floats floats.
+extern "C" int grit_moe_router_wgrad(const void* x, const float* dlogits, void* grad, float* workspace, int64_t T, int H, int E, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && dlogits && grad && workspace, GRIT_E_BADARG, "grit_moe_router_wgrad: null pointer");
+  GRIT_REQUIRE(T > 0 && T < (1ll << 40) && H > 0 && H <= (1 << 20) && H % 2 == 0, GRIT_E_BADARG, "grit_moe_router_wgrad: bad sizes T=%lld H=%d", (long long)T, H);
+  GRIT_REQUIRE(E == 4 || E == 8 || E == 16, GRIT_E_UNSUPPORTED, "grit_moe_router_wgrad: num_experts=%d (4, 8 and 16 are built)", E);
+  const int64_t nslab = (T + RW_SLAB - 1) / RW_SLAB;
+  GRIT_REQUIRE(nslab <= 65535, GRIT_E_UNSUPPORTED, "grit_moe_router_wgrad: T=%lld exceeds 65535 slabs of %d tokens", (long long)T, RW_SLAB);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((H / 2 + 255) / 256), (unsigned)nslab);
+  if (E == 4) hipLaunchKernelGGL(moe_router_wgrad_k<4>, grid, dim3(256), 0, st, (const uint16_t*)x, dlogits, workspace, T, H);
+  else if (E == 8) hipLaunchKernelGGL(moe_router_wgrad_k<8>, grid, dim3(256), 0, st, (const uint16_t*)x, dlogits, workspace, T, H);
+  else hipLaunchKernelGGL(moe_router_wgrad_k<16>, grid, dim3(256), 0, st, (const uint16_t*)x, dlogits, workspace, T, H);
+  GRIT_CHECK_LAUNCH("grit_moe_router_wgrad");
+  const int64_t EH = (int64_t)E * H;
+  hipLaunchKernelGGL(moe_router_wgrad_reduce_k, dim3((unsigned)((EH + 255) / 256)), dim3(256), 0, st, (const float*)workspace, (uint16_t*)grad,
+                     (int)nslab, EH);
+  GRIT_CHECK_LAUNCH("grit_moe_router_wgrad: reduce");
   return GRIT_OK;
 }
 

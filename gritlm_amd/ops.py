@@ -327,6 +327,25 @@ def moe_combine_bwd(dout: torch.Tensor, y: torch.Tensor, row_token: torch.Tensor
     return dy, dw
 
 
+def moe_router_bwd(x: torch.Tensor, gate_w: torch.Tensor, experts: torch.Tensor, dw: torch.Tensor, dx_in: torch.Tensor | None,
+                   gate_grad: torch.Tensor, aux_dlogits: torch.Tensor | None = None, return_dlogits: bool = False):
+    """Backward of the router (softmax -> top-2 -> renormalise through the gate Linear): returns dx [T,H] bf16 = dx_in + dlogits @ gate_w and
+    accumulates gate_grad [E,H] bf16 += bf16(dlogits^T @ x).  dw [T,2] fp32 comes from moe_combine_bwd; aux_dlogits [T,E] fp32 optional."""
+    T, H = x.shape
+    E = gate_w.shape[0]
+    lib = _lib.load()
+    dlogits = torch.empty((T, E), dtype=F32, device=x.device)
+    dx = torch.empty((T, H), dtype=BF16, device=x.device)
+    check(lib.grit_moe_router_bwd(_chk(x, BF16, "x"), _chk(gate_w, BF16, "gate_w"), _chk(experts, I32, "experts"), _chk(dw, F32, "dw"),
+                                  0 if aux_dlogits is None else _chk(aux_dlogits, F32, "aux_dlogits"),
+                                  0 if dx_in is None else _chk(dx_in, BF16, "dx_in"), dx.data_ptr(), dlogits.data_ptr(), T, H, E, _stream()),
+          "grit_moe_router_bwd")
+    ws = torch.empty((int(lib.grit_moe_router_wgrad_workspace_floats(T, H, E)),), dtype=F32, device=x.device)
+    check(lib.grit_moe_router_wgrad(_chk(x, BF16, "x"), dlogits.data_ptr(), _chk(gate_grad, BF16, "gate_grad"), ws.data_ptr(), T, H, E, _stream()),
+          "grit_moe_router_wgrad")
+    return (dx, dlogits) if return_dlogits else dx
+
+
 def moe_route(x: torch.Tensor, gate_w: torch.Tensor):
     """Top-2 routing of x [T,H] -> (experts [T,2] i32, weights [T,2] f32, counts [E] i32, row_token [2T] i32, rows [T,2] i32)."""
     T, H = x.shape

@@ -506,7 +506,7 @@ class MixtralTrainEngine(MistralTrainEngine):
                 -> grouped dgrad to the sorted inputs -> sum of a token's two rows; per-expert weight gradients with the dense NT
                 GEMM on the expert's row segment (ONE host sync per layer for the 8 row counts -- the training GEMMs are
                 milliseconds long; the inference path stays sync-free); the router's softmax / top-2 / renormalise backward and
-                its two skinny GEMMs ([T,E] x [E,H]) run as torch fp32 ops on the [T,E] logits.
+                its two skinny products ([T,E] x [E,H], [E,T] x [T,H]) are HIP kernels too (grit_moe_router_bwd / _wgrad, csrc/moe.hip).
 
     The router auxiliary loss (load_balancing_loss_func, :80-153) belongs to the generative branch only (the reference adds it inside
     MixtralForCausalLM.forward, which GritLMTrainModel calls with output_router_logits=True for a Mixtral; never for the embedding
@@ -578,20 +578,11 @@ class MixtralTrainEngine(MistralTrainEngine):
                 self._wgrad(dy[seg], sv["act"][seg], L.gdown[e], ("dy_e", "act_e"))
                 self._wgrad(dgu[seg], x_sorted[seg], L.ggu[e], ("dgu_e", "x_e"))
                 off += n
-        # ---- router: w = renormalised top-2 of softmax(x2 Wg^T); d w arrives from the combine backward
-        with torch.enable_grad():
-            xf = sv["x2"].detach().to(F32).requires_grad_(True)
-            wg = L.wgate.detach().to(F32).requires_grad_(True)
-            logits = xf @ wg.t()
-            p = torch.softmax(logits, dim=-1)
-            sel = torch.gather(p, 1, sv["experts"].to(torch.int64))
-            w = sel / sel.sum(dim=-1, keepdim=True)
-            obj = (w * dw).sum()
-            if self._aux_dlogits is not None:      # + the auxiliary load-balancing loss's pull on this layer's logits
-                obj = obj + (logits * self._aux_dlogits[li]).sum()
-            obj.backward()
-        L.wgate.grad.add_(wg.grad.to(BF16))
-        return (dx2.to(F32) + xf.grad).to(BF16)
+        # ---- router: w = renormalised top-2 of softmax(x2 Wg^T); d w arrives from the combine backward.  Native (round 4): one kernel
+        #      recomputes the fp32 logits, differentiates softmax / top-2 / renormalise (+ the auxiliary loss's pull on this layer's
+        #      logits), and adds dlogits @ Wg to the experts' input gradient; a fixed-order two-level sum gives the gate's weight gradient
+        aux = None if self._aux_dlogits is None else self._aux_dlogits[li].to(F32).contiguous()
+        return ops.moe_router_bwd(sv["x2"], L.wgate.data, sv["experts"], dw, dx2, L.wgate.grad, aux_dlogits=aux)
 
     def _router_aux_loss(self, saved, want_grad: bool):
         """load_balancing_loss_func (scripts/modeling_mixtral_gritlm.py:80-153) over the router logits of every layer of one forward:

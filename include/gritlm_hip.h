@@ -166,6 +166,19 @@ int grit_moe_combine(const void* y, const int32_t* rows, const float* weights, c
 int grit_moe_combine_bwd(const void* dout, const void* y, const int32_t* row_token, const int32_t* rows, const float* weights,
                          void* dy, float* dw, int64_t T, int H, void* stream);
 
+/* Router backward (autograd of `routing_weights = softmax(gate(x), float); topk(2); /= sum` , scripts/modeling_mixtral_gritlm.py:843-849,
+ * through the gate Linear): x [T,H] bf16 (the block's input), gate_w [E,H] bf16, experts [T,2] int32 (the forward's selection), dw [T,2] fp32
+ * (d loss / d routing weights: grit_moe_combine_bwd), aux_dlogits [T,E] fp32 or NULL (added to the logits' gradient: the auxiliary
+ * load-balancing loss).  The logits are recomputed in fp32.  Outputs: dlogits [T,E] fp32 and dx_out [T,H] bf16 = bf16(f32(dx_in) +
+ * dlogits @ gate_w); dx_in [T,H] bf16 or NULL = the experts' share of the input gradient; dx_out may alias dx_in.  E in {4, 8, 16}. */
+int grit_moe_router_bwd(const void* x, const void* gate_w, const int32_t* experts, const float* dw, const float* aux_dlogits,
+                        const void* dx_in, void* dx_out, float* dlogits, int64_t T, int H, int E, void* stream);
+
+/* gate.weight gradient: grad [E,H] bf16 (in/out) = bf16(f32(grad) + f32(bf16(dlogits^T [E,T] @ x [T,H]))) -- `grad.add_(dW.to(bf16))`;
+ * fp32 sums in a fixed two-level order (bit-reproducible).  workspace: grit_moe_router_wgrad_workspace_floats(T, H, E) floats. */
+int64_t grit_moe_router_wgrad_workspace_floats(int64_t T, int H, int E);
+int grit_moe_router_wgrad(const void* x, const float* dlogits, void* grad, float* workspace, int64_t T, int H, int E, void* stream);
+
 /* grit_gemm_bf16_nt_grouped with the training epilogues of the expert MLP (forward with saved pre-activations, backward):
  * STORE, SWIGLU, SWIGLU_STACKED (w = [gate rows; up rows] per expert, the layout of `experts.gate_up_proj`), SWIGLU_STACKED_SAVE
  * (additionally writes bf16 [gate | up] of every sorted row through `residual`, ldr >= N), SWIGLU_BWD (C = [d_gate | d_up] from the

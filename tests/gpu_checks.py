@@ -982,6 +982,51 @@ def check_gritlm_native_encode():
     return _res("GritLM.encode native vs reference GritLM.encode goldens", ok, **out)
 
 
+def check_moe_router_bwd(T=1531, H=512, E=8, aux=True):
+    """grit_moe_router_bwd / grit_moe_router_wgrad (csrc/moe.hip) against torch autograd of the reference's routing arithmetic
+    (scripts/modeling_mixtral_gritlm.py:843-849: softmax in fp32 -> top-2 -> renormalise) through the gate Linear, in fp32 on the same
+    bf16 operands -- the torch expression the training engine evaluated until round 3.  dlogits to 2e-5 relative, dx and the gate gradient
+    to one bf16 ulp of their values; a second run must reproduce the gate gradient bit for bit (fixed two-level summation order)."""
+    g = torch.Generator(device=DEV).manual_seed(71)
+    x = (torch.randn((T, H), generator=g, device=DEV) * 1.0).to(torch.bfloat16)
+    wg = (torch.randn((E, H), generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    dw = torch.randn((T, 2), generator=g, device=DEV)
+    dx_in = torch.randn((T, H), generator=g, device=DEV).to(torch.bfloat16)
+    auxg = torch.randn((T, E), generator=g, device=DEV) * 0.1 if aux else None
+    grad0 = (torch.randn((E, H), generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+    experts = ops.moe_route(x, wg)[0]
+    with torch.enable_grad():
+        xf = x.float().requires_grad_(True)
+        wf = wg.float().requires_grad_(True)
+        logits = xf @ wf.t()
+        logits.retain_grad()
+        p = torch.softmax(logits, dim=-1)
+        sel = torch.gather(p, 1, experts.to(torch.int64))
+        w = sel / sel.sum(dim=-1, keepdim=True)
+        obj = (w * dw).sum()
+        if aux:
+            obj = obj + (logits * auxg).sum()
+        obj.backward()
+    dx_ref = (dx_in.float() + xf.grad)
+    g_ref = grad0.float() + wf.grad.to(torch.bfloat16).float()
+    outs = []
+    for _ in range(2):
+        gg = grad0.clone()
+        dx, dl = ops.moe_router_bwd(x, wg, experts, dw, dx_in, gg, aux_dlogits=auxg, return_dlogits=True)
+        outs.append((dx, dl, gg))
+    dx, dl, gg = outs[0]
+    e_dl = float((dl - logits.grad).abs().max() / logits.grad.abs().max())
+    e_dx = float(((dx.float() - dx_ref).abs() / (dx_ref.abs() * 2 ** -7 + 1e-3)).max())         # in bf16 ulps of the value (+ a floor)
+    e_g = float(((gg.float() - g_ref).abs() / (g_ref.abs() * 2 ** -7 + 2e-2 * wf.grad.abs().mean())).max())
+    same = bool(torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0]))
+    # no dx_in: the gate's input gradient alone
+    dx_only = ops.moe_router_bwd(x, wg, experts, dw, None, grad0.clone(), aux_dlogits=auxg)
+    e_only = float(((dx_only.float() - xf.grad).abs() / (xf.grad.abs() * 2 ** -7 + 1e-3)).max())
+    ok = e_dl < 2e-5 and e_dx <= 1.0 and e_g <= 1.0 and e_only <= 1.0 and same
+    return _res(f"moe_router_bwd[T={T},H={H},E={E},aux={aux}]", ok, dlogits_rel=e_dl, dx_ulps=e_dx, gate_grad_ulps=e_g, dx_only_ulps=e_only,
+                reproducible=same)
+
+
 def check_gritlm_multi_gpu_in_process():
     """In-process multi-GPU encode (gritlm/gritlm.py:69-75, :106-107: ONE GritLM in ONE process over every GPU, batch_size x num_gpus):
     mode='embedding' with a device string that names no index builds one engine replica per listed GPU.  A one-GPU box can run (a) the
@@ -2381,6 +2426,9 @@ ALL_CHECKS = [
     ("encoder_tiny_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="tiny")),
     ("encoder_gqa_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="gqa")),
     ("encoder_7b_layer_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="7b-l1")),
+    ("moe_router_bwd", check_moe_router_bwd, {}),
+    ("moe_router_bwd_e4_no_aux", check_moe_router_bwd, dict(T=300, H=256, E=4, aux=False)),
+    ("moe_router_bwd_e16_h4096", check_moe_router_bwd, dict(T=1100, H=4096, E=16, aux=True)),
     ("gritlm_multi_gpu_in_process", check_gritlm_multi_gpu_in_process, {}),
     ("full_depth_parity_32_layers", check_full_depth_parity, {}),
     ("full_depth_parity_32_layers_fp32_residual", check_full_depth_parity, dict(residual_fp32=True)),
