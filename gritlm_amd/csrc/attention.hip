@@ -547,6 +547,441 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   }
 }
 
+
+// ====================================================================================================================================
+// W64 forward (round 4): the bidirectional kernel restructured around ONE wave per SIMD with 64 query rows per wave.
+//
+// Why (profiles/r03_attn_fwd_ablation.log): in the kernel above a wave owns 32 query rows, so every
+// v_mfma_f32_32x32x16_bf16 needs a fresh 1 KiB operand fragment from LDS -- at the matrix pipe's rate that alone is half of the LDS
+// bandwidth, before the LDS-DMA's writes -- and with everything else ablated the structure ends at 0.53 of the pipe.  Here a wave owns
+// TWO 32-row query groups: every K / V fragment read from LDS feeds two products, the per-tile costs (barrier, waits, mask word,
+// DMA issue) are paid once per 64 rows, and the wave has the whole register file of its SIMD (oacc 128 + two score sets 128 + Q 64 + P 32
+// + fragments: ~450 of 512).  With one wave per SIMD nobody else fills the matrix pipe during the softmax, so the loop is software
+// pipelined IN the wave: the QK products of tile n + 1 are issued between the exponentials of tile n (K runs one tile ahead of V in the
+// ring: at iteration n the LDS holds V(n) and K(n+1), the DMA of V(n+1) and K(n+2) is in flight).
+//
+// Geometry: 128-thread workgroups (2 waves = 128 query rows, the same block size and XCD-aware grid as above), two workgroups per CU
+// (80 KiB of LDS each) = four waves = one per SIMD.  A workgroup walks its `qpw` blocks of one (batch, head) as ONE flat tile stream
+// (block, tile): the bidirectional tile range is the same for every block, so the ring never notices a block boundary; the next
+// block's Q rows are fetched under the previous block's last tiles.  Per-row arithmetic (accumulation order of both products, the
+// per-row deferred rescale) is that of the kernel above: the results are BIT-IDENTICAL to it (tools/attn_w64_ab.py), packed == padded.
+constexpr int W64_XPOSE_BYTES = 8192;                                          // per wave: 64 rows x 128 B (Q in / O out)
+constexpr int W64_LDS_BYTES = 2 * ATT_STAGE_BYTES + 2 * W64_XPOSE_BYTES;       // 80 KiB
+
+template <bool VARLEN>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
+               uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride,
+               float scale_log2, int qpw, int ngx, int n_sets) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gqa = nq / nkv, U = gqa * ngx;
+  const int kx = (int)blockIdx.x >> 3;
+  const int set = (kx / U) * 8 + ((int)blockIdx.x & 7), member = kx % U;
+  if (set >= n_sets) return;
+  const int b = set / nkv, hk = set - b * nkv;
+  const int h = hk * gqa + member % gqa;
+  const int qb_first = (member / gqa) * qpw;
+  int S = S_arg;
+  int64_t row0 = (int64_t)b * S_arg;
+  if constexpr (VARLEN) {
+    row0 = cu_seqlens[b];
+    S = cu_seqlens[b + 1] - cu_seqlens[b];
+  }
+  if (qb_first * ATT_QB >= S) return;
+  const int nqb = (S + ATT_QB - 1) / ATT_QB;
+  const int nblk = (nqb - qb_first) < qpw ? (nqb - qb_first) : qpw;
+
+  const char* q_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)h * ATT_D);
+  const char* k_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + hk) * ATT_D);
+  const char* v_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + nkv + hk) * ATT_D);
+  char* o_base = reinterpret_cast<char*>(out + row0 * out_stride + (int64_t)h * ATT_D);
+  const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
+  const int ql = lane & 31, hi = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+  // ---- LDS-DMA roles: wave w stages keys 32w .. 32w+31 of a tile: eight 1-KiB pieces for K and eight for V (4 keys each); piece i and
+  //      piece i + 4 differ by 16 key rows (same swizzle: (4i + lane>>4) & 15), which goes into the instruction's SCALAR offset
+  const int st_key = 32 * wv + (lane >> 4);
+  const uint32_t v_unit_b = (uint32_t)(((lane & 15) ^ (4 * ((lane >> 4) & 3))) << 4);
+  const uint32_t v_delta_b = (uint32_t)nkv * ATT_D * 2u;
+  const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u + v_delta_b), 0x00020000);
+  uint32_t pc_k[4], pc_v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pc_k[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
+    pc_v[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + v_unit_b + v_delta_b;
+  }
+  // piece p = 0..15 of a tile: p < 8 -> K piece p, else V piece p - 8
+  auto stage_piece = [&](int t, int buf, int p) {
+    const int is_v = p >> 3, i = p & 7;
+    char* dst = smem + buf * ATT_STAGE_BYTES + (is_v ? K_LDS_BYTES : 0) + wv * 8192 + i * 1024;
+    const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB + (i >> 2) * 16) * qkv_stride_b;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(is_v ? pc_v[i & 3] : pc_k[i & 3]), (int)soff, 0, 0);
+  };
+
+  // ---- Q fragments of the wave's two 32-row groups: qf[g][ks], lane holds Q[64 wave + 32 g + ql][16 ks + 8 hi .. + 8]
+  bf16x8_t qf[2][8];
+  char* xs = smem + 2 * ATT_STAGE_BYTES + wv * W64_XPOSE_BYTES;
+  const int q_swz = (ql >> 1) & 7;
+  // one 64-column half of the wave's 64 rows through the transposition buffer: eight DMA instructions of 8 rows x 128 B
+  auto q_stage_half = [&](int qb, int half) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 8 * j + x_row;
+      int qr = qb * ATT_QB + wave * 64 + r;
+      qr = qr < S ? qr : S - 1;
+      const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, 0);
+    }
+  };
+  auto q_read_half = [&](int half) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const char* rp = xs + (32 * g + ql) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[g][half * 4 + ks] = *reinterpret_cast<const bf16x8_t*>(rp + (((2 * ks + hi) ^ q_swz) << 4));
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                           // lgkmcnt(0): the reads have left the buffer
+    asm volatile("" ::: "memory");
+  };
+
+  // number of KV tiles with at least one valid key
+  int NT = 0;
+  const uint64_t* bits = nullptr;
+  if constexpr (VARLEN) {
+    NT = (S + 63) >> 6;
+  } else {
+    const int W = (S + 63) >> 6;
+    bits = key_bits + (int64_t)b * W;
+    for (int w = W - 1; w >= 0; --w)
+      if (bits[w] != 0) { NT = w + 1; break; }
+  }
+  if (NT == 0) NT = 1;                          // every key masked: one tile, all scores -inf (rows come out as zeros, like the kernel above)
+
+  // ---- pipe fill: K(0), V(0) -> stage 0; the first block's Q rows straight from global memory; K(1) -> K half of stage 1
+#pragma unroll
+  for (int p = 0; p < 16; ++p) stage_piece(0, 0, p);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int qr0 = qb_first * ATT_QB + wave * 64 + 32 * g + ql;
+    const char* qp = q_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[g][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+  }
+  {
+    const int t1 = NT > 1 ? 1 : 0;              // stream position 1 (tile 1, or tile 0 again when the sequence has one tile)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_piece(t1, 1, p);
+  }
+
+  const int kf_row = ql * 256, kf_x = lane & 15;
+  const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + ((((lane >> 2) & 3) * 4) << 4) + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  f32x16_t oacc[2][4];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    m_run[g] = -INFINITY; l_run[g] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
+  }
+
+  // K fragment reads (inline asm, counted lgkmcnt) and the four products of a k-slice: one K fragment pair feeds BOTH query groups
+#define W64_K_READ(KS)                                                                                                              \
+  do {                                                                                                                              \
+    const uint32_t ka = kbase ^ (uint32_t)((KS) << 5);                                                                              \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(kr[(KS) % 3][0]) : "v"(ka));                                                          \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(kr[(KS) % 3][1]) : "v"(ka));                                              \
+  } while (0)
+#define W64_K_MMA(KS, N, DST)                                                                                                       \
+  do {                                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % 3][0]), "+v"(kr[(KS) % 3][1]) : : "memory");                          \
+    DST[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[0][KS], (KS) == 0 ? zero16 : DST[0][0], 0, 0, 0);       \
+    DST[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[1][KS], (KS) == 0 ? zero16 : DST[1][0], 0, 0, 0);       \
+    DST[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[0][KS], (KS) == 0 ? zero16 : DST[0][1], 0, 0, 0);       \
+    DST[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[1][KS], (KS) == 0 ? zero16 : DST[1][1], 0, 0, 0);       \
+  } while (0)
+  // QK of one tile: K fragments two k-slices ahead of their products; STEP(KS) = what rides behind the products of k-slice KS
+#define W64_QK(DST, STEP)                                                                                                           \
+  do {                                                                                                                              \
+    bf16x8_t kr[3][2];                                                                                                              \
+    W64_K_READ(0); W64_K_READ(1);                                                                                                   \
+    W64_K_READ(2); W64_K_MMA(0, 4, DST); STEP(0);                                                                                   \
+    W64_K_READ(3); W64_K_MMA(1, 4, DST); STEP(1);                                                                                   \
+    W64_K_READ(4); W64_K_MMA(2, 4, DST); STEP(2);                                                                                   \
+    W64_K_READ(5); W64_K_MMA(3, 4, DST); STEP(3);                                                                                   \
+    W64_K_READ(6); W64_K_MMA(4, 4, DST); STEP(4);                                                                                   \
+    W64_K_READ(7); W64_K_MMA(5, 4, DST); STEP(5);                                                                                   \
+    W64_K_MMA(6, 2, DST); STEP(6);                                                                                                  \
+    W64_K_MMA(7, 0, DST); STEP(7);                                                                                                  \
+  } while (0)
+#define W64_NOSTEP(KS) do { } while (0)
+
+  ATT_WAIT_VM0();                               // K(0), V(0), K(1), Q of the first block
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ONE accumulator set for the scores ([group][32-key half]; the matrix pipe's destination, AGPRs): an iteration first copies the scores
+  // of its tile into arch VGPRs (`sc`, where the softmax works on them) and then lets the QK products of the NEXT tile overwrite the set.
+  // (Two ping-pong sets kept 256 AGPRs busy -- oacc 128 + 2 x 64 -- and pushed Q, P and the fragments into 173 spilled registers.)
+  f32x16_t sacc[2][2];
+  {
+    const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)smem) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
+    W64_QK(sacc, W64_NOSTEP);
+  }
+
+  const int N = nblk * NT;                      // flat tile stream of the workgroup
+  int t = 0, qi = 0;                            // tile inside the block, block index
+  bool skip_wait = true;                        // the top-of-iteration DMA wait is not needed right after a pipe fill / a block epilogue
+
+  // one iteration of the stream: softmax + PV of tile n, QK of tile n + 1
+  for (int n = 0; n < N; ++n) {               // (the body is written out in the loop: as a lambda that mutates t / qi / skip_wait
+    const bool has_next = n + 1 < N;          //  through reference captures, hipcc kept the three in scratch memory, and every reload
+                                              //  came with an s_waitcnt vmcnt(0) that drained the LDS-DMA queue)
+    const bool last_of_block = (t + 1 == NT);
+    const bool more = qi + 1 < nblk;
+    const int qb = qb_first + qi;
+    if (!skip_wait) ATT_WAIT_VM0();             // K(n+1), V(n) (and a Q half) requested one iteration ago
+    skip_wait = false;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // this iteration's sixteen pieces: K(n+2) -> K half of stage n & 1 (K(n) is dead), V(n+1) -> V half of stage (n+1) & 1 (V(n-1) is dead);
+    // past the end of the stream they re-stage a tile nobody reads
+    int tk = t + 2; tk = tk >= NT ? tk - NT : tk; tk = tk >= NT ? tk - NT : tk;     // (t + 2) mod NT for NT >= 1
+    const int tv = (t + 1 == NT) ? 0 : t + 1;
+    const int kbuf = n & 1, vbuf = (n + 1) & 1;
+    // next block's Q rows: first half requested two tiles before the block ends, read after this block's last QK products
+    if (more && NT >= 3 && t + 3 == NT) q_stage_half(qb + 1, 0);
+    if (more && last_of_block) {
+      if (NT == 1) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); q_read_half(0); q_stage_half(qb + 1, 1); ATT_WAIT_VM0(); }
+      q_read_half(1);
+    }
+    const char* v_lds = smem + (n & 1) * ATT_STAGE_BYTES + K_LDS_BYTES;
+    uint64_t word;
+    if constexpr (VARLEN) {
+      const int rem = S - t * ATT_KB;
+      word = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    } else {
+      word = bits[t];
+    }
+    bool fast = (word == ~0ull);
+    {
+      int fast_i = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);
+      asm volatile("" : "+s"(fast_i));
+      fast = fast_i != 0;
+    }
+    // the tile's scores leave the accumulator set (it is the destination of the QK products issued below)
+    f32x16_t sc[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        sc[g][kb] = sacc[g][kb];
+        asm volatile("" : "+v"(sc[g][kb]));
+      }
+    // ---- row maxima + (rare) rescale, both groups
+    float m_use[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float mx = -INFINITY;
+      if (fast) {
+        float m4[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const int kb = c4 >> 1, r0 = (c4 & 1) * 8;
+          m4[c4] = fmaxf(fmaxf(sc[g][kb][r0], sc[g][kb][r0 + 1]), sc[g][kb][r0 + 2]);
+#pragma unroll
+          for (int r = 3; r < 8; ++r) m4[c4] = fmaxf(m4[c4], sc[g][kb][r0 + r]);
+        }
+        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      } else {
+        const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const uint32_t wsel = kb ? whi : wlo;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kbit = (r & 3) + 8 * (r >> 2);
+            const float sv = ((wsel >> kbit) & 1u) ? sc[g][kb][r] : -INFINITY;
+            sc[g][kb][r] = sv;
+            mx = fmaxf(mx, sv);
+          }
+        }
+      }
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2;
+      }
+      const float m_new = fmaxf(m_run[g], mx);
+      const bool grow = !(m_new - m_run[g] <= 8.0f);
+      if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+        const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = grow ? __builtin_amdgcn_exp2f(m_run[g] - m_ref) : 1.0f;
+        m_run[g] = grow ? m_new : m_run[g];
+        l_run[g] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[g][db][r] *= alpha;
+      }
+      m_use[g] = (m_run[g] == -INFINITY) ? 0.f : m_run[g];
+    }
+    float psum[2] = {0.f, 0.f};
+    uint32_t pk8[2][2][2][4];                   // [group][32-key half][16-key quarter][packed pair]
+    // exponentials of one eighth of the tile's scores: group KS >> 2, key half (KS >> 1) & 1, quarter KS & 1
+#define W64_PSLICE(KS)                                                                                                              \
+  do {                                                                                                                              \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                              \
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj], scale_log2, -m_use[(KS) >> 2]));      \
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj + 1], scale_log2, -m_use[(KS) >> 2]));  \
+      psum[(KS) >> 2] += p0 + p1;                                                                                                   \
+      pk8[(KS) >> 2][((KS) >> 1) & 1][(KS) & 1][jj] = pack2bf_hw(p0, p1);                                                           \
+    }                                                                                                                               \
+  } while (0)
+#define W64_PIECES(KS) do { stage_piece(tk, kbuf, (KS)); stage_piece(tv, vbuf, 8 + (KS)); asm volatile("" ::: "memory"); } while (0)
+#define W64_STEP(KS) do { W64_PIECES(KS); W64_PSLICE(KS); __builtin_amdgcn_sched_barrier(0); } while (0)
+    if (has_next) {
+      // ---- ONE section: the QK products of tile n + 1, the DMA pieces behind them, the exponentials of tile n between them
+      const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(smem + ((n + 1) & 1) * ATT_STAGE_BYTES)) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
+      __builtin_amdgcn_s_setprio(1);
+      W64_QK(sacc, W64_STEP);
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) { W64_PIECES(ks); }
+      W64_PSLICE(0); W64_PSLICE(1); W64_PSLICE(2); W64_PSLICE(3); W64_PSLICE(4); W64_PSLICE(5); W64_PSLICE(6); W64_PSLICE(7);
+    }
+#undef W64_STEP
+#undef W64_PIECES
+#undef W64_PSLICE
+    l_run[0] += psum[0];
+    l_run[1] += psum[1];
+    // the next block's Q: this block's last QK products (tile NT - 1, issued in the iteration of tile NT - 2) have read qf
+    if (more && NT >= 2 && t + 2 == NT) {
+      if (NT == 2) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); }
+      q_read_half(0);
+      q_stage_half(qb + 1, 1);
+    }
+    // ---- O^T += V^T P^T, both groups on every V fragment
+    {
+      const uint32_t vbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)v_lds);
+      uint32_t va[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) va[db] = vbase + (uint32_t)(vt_lane ^ (db << 6));
+      s16x4_t vr[2][4][2];
+#define W64_TR_GROUP(G, BUF)                                                                                                          \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][0]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH));                \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][1]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH + 8 * V_PITCH)); \
+  }
+#define W64_TR_WAIT(N, BUF)                                                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                            \
+               : "+v"(vr[BUF][0][0]), "+v"(vr[BUF][0][1]), "+v"(vr[BUF][1][0]), "+v"(vr[BUF][1][1]), "+v"(vr[BUF][2][0]),              \
+                 "+v"(vr[BUF][2][1]), "+v"(vr[BUF][3][0]), "+v"(vr[BUF][3][1]))
+#define W64_TR_MMA(G, BUF)                                                                                                            \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    const s16x4_t v0 = vr[BUF][db][0], v1 = vr[BUF][db][1];                                                                           \
+    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                                   \
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(pk8[g][(G) >> 1][(G) & 1][0], pk8[g][(G) >> 1][(G) & 1][1],         \
+                                                                  pk8[g][(G) >> 1][(G) & 1][2], pk8[g][(G) >> 1][(G) & 1][3]));       \
+      oacc[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[g][db], 0, 0, 0);                                            \
+    }                                                                                                                                 \
+  }
+      W64_TR_GROUP(0, 0)
+      W64_TR_GROUP(1, 1)
+      W64_TR_WAIT(8, 0);
+      W64_TR_MMA(0, 0)
+      W64_TR_GROUP(2, 0)
+      W64_TR_WAIT(8, 1);
+      W64_TR_MMA(1, 1)
+      W64_TR_GROUP(3, 1)
+      W64_TR_WAIT(8, 0);
+      W64_TR_MMA(2, 0)
+      W64_TR_WAIT(0, 1);
+      W64_TR_MMA(3, 1)
+#undef W64_TR_GROUP
+#undef W64_TR_WAIT
+#undef W64_TR_MMA
+    }
+
+    if (!last_of_block) { ++t; continue; }
+
+    // ---- block epilogue: everything requested during this tile is waited for BEFORE the stores go out (vmcnt counts stores; the next
+    //      iteration then starts without a DMA wait and the stores drain under it)
+    ATT_WAIT_VM0();
+    skip_wait = true;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
+      const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+      const int q_g0 = qb * ATT_QB + wave * 64 + 32 * g;                          // first row of the group
+      char* xg = xs + g * 4096;                                                     // 32 rows x 128 B of the wave's buffer
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        char* wp = xg + (ln & 31) * 128;
+#pragma unroll
+        for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            const int db = half * 2 + dbl;
+            float a[4], bq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[g][db][8 * gp + e] * inv_l),
+                                                               __float_as_uint(oacc[g][db][8 * gp + 4 + e] * inv_l), false, false);
+              a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
+            }
+            *reinterpret_cast<uint4*>(wp + (((dbl * 4 + gp * 2 + hi) ^ q_swz) << 4)) =
+                make_uint4(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]), pack2bf_hw(bq[0], bq[1]), pack2bf_hw(bq[2], bq[3]));
+          }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("" ::: "memory");
+        uint4 piece[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) piece[j] = *reinterpret_cast<const uint4*>(xg + j * 1024 + ln * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 8 * j + x_row;
+          const int qr = q_g0 + r;
+          if (qr < S) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int att_u32x4_t;
+            att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(o_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4)));
+            const att_u32x4_t pv = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+            *op = pv;
+          }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("" ::: "memory");
+      }
+      const int q_row = q_g0 + ql;
+      if (q_row < S && lse != nullptr && hi == 0) {
+        if constexpr (VARLEN) lse[(row0 + q_row) * nq + h] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        else lse[((int64_t)b * nq + h) * S + q_row] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+      }
+      m_run[g] = -INFINITY; l_run[g] = 0.f;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
+    }
+    t = 0; ++qi;
+  }
+#undef W64_K_READ
+#undef W64_K_MMA
+#undef W64_QK
+#undef W64_NOSTEP
+}
+
 }  // namespace grit
 
 using namespace grit;
@@ -572,6 +1007,21 @@ static void attn_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const ui
   attn_lds_optin(attn_bidir_fwd_k<VARLEN, CAUSAL>, optin);
   hipLaunchKernelGGL((attn_bidir_fwd_k<VARLEN, CAUSAL>), grid, dim3(256), ATT_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
                      out_stride, scale_log2, qpw, ngx, n_sets, window);
+}
+
+template <bool VARLEN>
+static void attn_w64_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
+                            int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets) {
+  static std::atomic<uint64_t> optin{0};
+  attn_lds_optin(attn_fwd_w64_k<VARLEN>, optin);
+  hipLaunchKernelGGL((attn_fwd_w64_k<VARLEN>), grid, dim3(128), W64_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride, out_stride,
+                     scale_log2, qpw, ngx, n_sets);
+}
+// which forward the bidirectional entry points launch: the W64 kernel (default) or the round-3 kernel (GRIT_ATTN_FWD=v3; A/B knob, read per
+// call so that one process can time both)
+static bool attn_use_w64() {
+  const char* e = getenv("GRIT_ATTN_FWD");
+  return e == nullptr || e[0] != 'v';
 }
 
 struct AttnGeom {
@@ -614,6 +1064,9 @@ static int attn_fwd_padded(const char* name, bool causal, int window, const void
   if (causal)
     attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
+  else if (attn_use_w64())
+    attn_w64_launch<false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
+                           out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
   else
     attn_launch<false, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
                               out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
@@ -639,6 +1092,9 @@ static int attn_fwd_varlen(const char* name, bool causal, int window, const void
   if (causal)
     attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
+  else if (attn_use_w64())
+    attn_w64_launch<true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
+                          out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
   else
     attn_launch<true, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);

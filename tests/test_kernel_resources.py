@@ -35,6 +35,18 @@ def _resources(src):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_w64_attention_uses_the_whole_register_file_without_spilling():
+    """The W64 attention forward runs ONE wave per SIMD on purpose (64 query rows per wave: oacc 128 + scores 64 in AGPRs, Q in AGPRs, the
+    softmax's copy of the scores, P and the fragments in arch VGPRs): <= 512 registers, no spill, no scratch -- a scratch reload's vmcnt(0)
+    would drain the LDS-DMA queue in the middle of the tile loop."""
+    ks = [k for k in _resources("attention.hip") if "attn_fwd_w64_k" in k["name"]]
+    assert len(ks) == 2, [k["name"] for k in ks]
+    for k in ks:
+        assert int(k["VGPRs Spill"]) == 0 and int(k["ScratchSize [bytes/lane]"]) == 0, k
+        assert int(k["VGPRs"]) <= 256 and int(k["AGPRs"]) <= 256 and int(k["Occupancy [waves/SIMD]"]) >= 1, k
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("src,needle,count", [("gemm_bf16.hip", "gemm_bf16_nt_k", 16), ("attention.hip", "attn_bidir_fwd_k", 4)])
 def test_mfma_kernels_do_not_spill(src, needle, count):
     ks = [k for k in _resources(src) if needle in k["name"]]
