@@ -217,7 +217,7 @@ class MistralEncoderEngine:
         """A copy of this engine on another GPU (the repacked weights are copied device to device; precision policy, attention mode and
         window are inherited): one replica per visible GPU is what in-process multi-GPU encode runs on (gritlm_amd/gritlm.py)."""
         eng = type(self)(self.cfg, device)
-        mv = lambda t: None if t is None else t.to(eng.device)
+        mv = lambda t: None if t is None else t.to(eng.device, copy=True)       # a real copy even when the replica shares the device (tests)
         eng.embed, eng.norm = mv(self.embed), mv(self.norm)
         for L in self.layers:
             R = _Layer()

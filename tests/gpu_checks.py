@@ -1041,11 +1041,13 @@ def check_gritlm_multi_gpu_in_process():
     with tempfile.TemporaryDirectory() as td:
         d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
         m1 = GritLM(d16, mode="embedding", pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, devices=["cuda:0"])
-        ok &= m1.engine is not None and m1.num_gpus == 1 and m1.engines == []
+        out["one_device_list"] = bool(m1.engine is not None and m1.num_gpus == 1 and m1.engines == [])
+        ok &= out["one_device_list"]
         base = m1.encode(sents, batch_size=8, max_length=64, instruction=instr)
         m2 = GritLM(d16, mode="embedding", pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, devices=["cuda:0"])
         rep = m2.engine.replica("cuda:0")
-        ok &= rep.embed.data_ptr() != m2.engine.embed.data_ptr() and bool(torch.equal(rep.layers[0].wqkv, m2.engine.layers[0].wqkv))
+        out["replica_is_a_copy"] = bool(rep.embed.data_ptr() != m2.engine.embed.data_ptr() and torch.equal(rep.layers[0].wqkv, m2.engine.layers[0].wqkv))
+        ok &= out["replica_is_a_copy"]
         m2.engines, m2.num_gpus = [m2.engine, rep], 2
         two = m2.encode(sents, batch_size=4, max_length=64, instruction=instr)          # 4 x 2 replicas: the same batches of 8
         out["bit_identical_to_one_engine"] = bool(np.array_equal(base, two))
