@@ -552,57 +552,69 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 // W64 forward (round 4): the bidirectional kernel restructured around ONE wave per SIMD with 64 query rows per wave.
 //
 // Why (profiles/r03_attn_fwd_ablation.log): in the kernel above a wave owns 32 query rows, so every
-// v_mfma_f32_32x32x16_bf16 needs a fresh 1 KiB operand fragment from LDS -- at the matrix pipe's rate that alone is half of the LDS
-// bandwidth, before the LDS-DMA's writes -- and with everything else ablated the structure ends at 0.53 of the pipe.  Here a wave owns
-// TWO 32-row query groups: every K / V fragment read from LDS feeds two products, the per-tile costs (barrier, waits, mask word,
-// DMA issue) are paid once per 64 rows, and the wave has the whole register file of its SIMD (oacc 128 + two score sets 128 + Q 64 + P 32
-// + fragments: ~450 of 512).  With one wave per SIMD nobody else fills the matrix pipe during the softmax, so the loop is software
-// pipelined IN the wave: the QK products of tile n + 1 are issued between the exponentials of tile n (K runs one tile ahead of V in the
-// ring: at iteration n the LDS holds V(n) and K(n+1), the DMA of V(n+1) and K(n+2) is in flight).
+// v_mfma_f32_32x32x16_bf16 needs a fresh 1 KiB operand fragment from LDS and a K/V tile is staged (8 LDS-DMA pieces per wave) for 32
+// products per wave; with everything else ablated that structure ends at 0.53 of the pipe.  Here a wave owns TWO 32-row query groups:
+// every K / V fragment read from LDS feeds two products, a tile costs a wave 8 DMA pieces per 64 products, and the per-tile rendezvous
+// (barrier, DMA wait, mask word) is paid once per 256 query rows.  The wave has the whole register file of its SIMD (oacc 128 + one score
+// set 64 + Q 64 in AGPRs; the softmax's copy of the scores, P and the fragments in arch VGPRs).  With one wave per SIMD nobody else fills
+// the matrix pipe during the softmax, so the loop is software pipelined IN the wave: iteration n issues
+//     QK(n+1)  between the exponentials of tile n  (K runs one tile ahead of V in the ring: the LDS holds V(n) and K(n+1), the DMA of
+//              V(n+1) and K(n+2) is in flight),
+//     PV(n)    between the row statistics of tile n + 1 (score copy-out, mask, row maxima, the per-row "does the maximum move" decision).
 //
-// Geometry: 128-thread workgroups (2 waves = 128 query rows, the same block size and XCD-aware grid as above), two workgroups per CU
-// (80 KiB of LDS each) = four waves = one per SIMD.  A workgroup walks its `qpw` blocks of one (batch, head) as ONE flat tile stream
-// (block, tile): the bidirectional tile range is the same for every block, so the ring never notices a block boundary; the next
-// block's Q rows are fetched under the previous block's last tiles.  Per-row arithmetic (accumulation order of both products, the
-// per-row deferred rescale) is that of the kernel above: the results are BIT-IDENTICAL to it (tools/attn_w64_ab.py), packed == padded.
+// Geometry: 256-thread workgroups (4 waves x 64 rows = 256-row query blocks), ONE workgroup per CU.  A workgroup walks `bpw` consecutive
+// blocks of one K/V set (batch, kv head) -- block j = (head j / nqb of the GQA group, query block j % nqb) -- as ONE flat tile stream: the
+// bidirectional tile range is the same for every block of the set, so the ring never notices a block boundary, the K/V tiles stay in
+// the XCD's L2 for all heads of the group, and the next block's Q rows are fetched under the previous block's last tiles: one cold
+// prologue per workgroup (64 tile iterations at B 256 x S 512).  The first version of this kernel ran two-wave workgroups (128 rows) two
+// per CU: 16 DMA pieces per wave and tile with no partner wave to cover their issue cost, 0.65x of the kernel above
+// (profiles/r04_attn_w64_first_build_ab.json); it was bit-identical, as this one is: per-row arithmetic (accumulation order of both
+// products, the per-row deferred rescale) is that of the kernel above (tools/attn_w64_ab.py), packed == padded.
+// a + b as ONE v_add_f32: under plain -O3 hipcc SLP-packs the row-sum adds of neighbouring scores into v_pk_add_f32, which beside MFMAs costs
+// more than the two scalar adds it replaces (guide: 'packed f32 VALU ... an anti-lever beside MFMAs'); same IEEE sum, same bits
+__device__ __forceinline__ float w64_add(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+constexpr int W64_QB = 256;                                                    // query rows per workgroup block
 constexpr int W64_XPOSE_BYTES = 8192;                                          // per wave: 64 rows x 128 B (Q in / O out)
-constexpr int W64_LDS_BYTES = 2 * ATT_STAGE_BYTES + 2 * W64_XPOSE_BYTES;       // 80 KiB
+constexpr int W64_LDS_BYTES = 2 * ATT_STAGE_BYTES + 4 * W64_XPOSE_BYTES;       // 96 KiB
 
 template <bool VARLEN>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride,
-               float scale_log2, int qpw, int ngx, int n_sets) {
+               float scale_log2, int bpw, int parts, int n_sets) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int gqa = nq / nkv, U = gqa * ngx;
+  const int gqa = nq / nkv;
+  // XCD-aware decode (as above): the k-th workgroup of XCD x belongs to K/V set (k / parts) * 8 + x, part k % parts of its blocks
   const int kx = (int)blockIdx.x >> 3;
-  const int set = (kx / U) * 8 + ((int)blockIdx.x & 7), member = kx % U;
+  const int set = (kx / parts) * 8 + ((int)blockIdx.x & 7), part = kx % parts;
   if (set >= n_sets) return;
   const int b = set / nkv, hk = set - b * nkv;
-  const int h = hk * gqa + member % gqa;
-  const int qb_first = (member / gqa) * qpw;
   int S = S_arg;
   int64_t row0 = (int64_t)b * S_arg;
   if constexpr (VARLEN) {
     row0 = cu_seqlens[b];
     S = cu_seqlens[b + 1] - cu_seqlens[b];
   }
-  if (qb_first * ATT_QB >= S) return;
-  const int nqb = (S + ATT_QB - 1) / ATT_QB;
-  const int nblk = (nqb - qb_first) < qpw ? (nqb - qb_first) : qpw;
+  const int nqb = (S + W64_QB - 1) / W64_QB;
+  const int nb_set = gqa * nqb;                 // blocks of this set: (head of the group, query block)
+  const int j0 = part * bpw;
+  if (j0 >= nb_set) return;                     // uniform per workgroup
+  const int nblk = (nb_set - j0) < bpw ? (nb_set - j0) : bpw;
 
-  const char* q_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)h * ATT_D);
+  const char* q_set = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)hk * gqa * ATT_D);        // + head-in-group * 256 B
   const char* k_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + hk) * ATT_D);
-  const char* v_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + nkv + hk) * ATT_D);
-  char* o_base = reinterpret_cast<char*>(out + row0 * out_stride + (int64_t)h * ATT_D);
+  char* o_set = reinterpret_cast<char*>(out + row0 * out_stride + (int64_t)hk * gqa * ATT_D);
   const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
   const int ql = lane & 31, hi = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
 
-  // ---- LDS-DMA roles: wave w stages keys 32w .. 32w+31 of a tile: eight 1-KiB pieces for K and eight for V (4 keys each); piece i and
-  //      piece i + 4 differ by 16 key rows (same swizzle: (4i + lane>>4) & 15), which goes into the instruction's SCALAR offset
-  const int st_key = 32 * wv + (lane >> 4);
+  // ---- LDS-DMA roles (as above): wave w stages keys 16w .. 16w+15 of a tile, four 1-KiB pieces for K and four for V
+  const int st_key = 16 * wv + (lane >> 4);
   const uint32_t v_unit_b = (uint32_t)(((lane & 15) ^ (4 * ((lane >> 4) & 3))) << 4);
   const uint32_t v_delta_b = (uint32_t)nkv * ATT_D * 2u;
   const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u + v_delta_b), 0x00020000);
@@ -612,30 +624,35 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
     pc_k[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
     pc_v[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + v_unit_b + v_delta_b;
   }
-  // piece p = 0..15 of a tile: p < 8 -> K piece p, else V piece p - 8
+  // piece p = 0..7 of a tile: p < 4 -> K piece p, else V piece p - 4
   auto stage_piece = [&](int t, int buf, int p) {
-    const int is_v = p >> 3, i = p & 7;
-    char* dst = smem + buf * ATT_STAGE_BYTES + (is_v ? K_LDS_BYTES : 0) + wv * 8192 + i * 1024;
-    const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB + (i >> 2) * 16) * qkv_stride_b;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(is_v ? pc_v[i & 3] : pc_k[i & 3]), (int)soff, 0, 0);
+    const int is_v = p >> 2, i = p & 3;
+    char* dst = smem + buf * ATT_STAGE_BYTES + (is_v ? K_LDS_BYTES : 0) + wv * 4096 + i * 1024;
+    const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(is_v ? pc_v[i] : pc_k[i]), (int)tile_b, 0, 0);
   };
 
   // ---- Q fragments of the wave's two 32-row groups: qf[g][ks], lane holds Q[64 wave + 32 g + ql][16 ks + 8 hi .. + 8]
   bf16x8_t qf[2][8];
   char* xs = smem + 2 * ATT_STAGE_BYTES + wv * W64_XPOSE_BYTES;
   const int q_swz = (ql >> 1) & 7;
+  // block j of the set -> byte offset of its head inside a row, first row of the block
+  auto blk_head_b = [&](int j) { return (uint32_t)(j / nqb) * (uint32_t)(ATT_D * 2); };
+  auto blk_row0 = [&](int j) { return (j % nqb) * W64_QB; };
   // one 64-column half of the wave's 64 rows through the transposition buffer: eight DMA instructions of 8 rows x 128 B
-  auto q_stage_half = [&](int qb, int half) {
+  auto q_stage_half = [&](int j, int half) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int x_row = ln >> 3, x_unit = ln & 7;
+    const char* qb_base = q_set + blk_head_b(j);
+    const int r0 = blk_row0(j) + wave * 64;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = 8 * j + x_row;
-      int qr = qb * ATT_QB + wave * 64 + r;
+    for (int jj = 0; jj < 8; ++jj) {
+      const int r = 8 * jj + x_row;
+      int qr = r0 + r;
       qr = qr < S ? qr : S - 1;
       const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(qb_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + jj * 1024), 16, 0, 0);
     }
   };
   auto q_read_half = [&](int half) {
@@ -662,21 +679,32 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
       if (bits[w] != 0) { NT = w + 1; break; }
   }
   if (NT == 0) NT = 1;                          // every key masked: one tile, all scores -inf (rows come out as zeros, like the kernel above)
+  auto tile_word = [&](int t) -> uint64_t {
+    if constexpr (VARLEN) {
+      const int rem = S - t * ATT_KB;
+      return rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    } else {
+      return bits[t];
+    }
+  };
 
   // ---- pipe fill: K(0), V(0) -> stage 0; the first block's Q rows straight from global memory; K(1) -> K half of stage 1
 #pragma unroll
-  for (int p = 0; p < 16; ++p) stage_piece(0, 0, p);
+  for (int p = 0; p < 8; ++p) stage_piece(0, 0, p);
+  {
+    const char* qb_base = q_set + blk_head_b(j0);
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int qr0 = qb_first * ATT_QB + wave * 64 + 32 * g + ql;
-    const char* qp = q_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
+    for (int g = 0; g < 2; ++g) {
+      const int qr0 = blk_row0(j0) + wave * 64 + 32 * g + ql;
+      const char* qp = qb_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[g][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+      for (int ks = 0; ks < 8; ++ks) qf[g][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+    }
   }
   {
     const int t1 = NT > 1 ? 1 : 0;              // stream position 1 (tile 1, or tile 0 again when the sequence has one tile)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) stage_piece(t1, 1, p);
+    for (int p = 0; p < 4; ++p) stage_piece(t1, 1, p);
   }
 
   const int kf_row = ql * 256, kf_x = lane & 15;
@@ -699,131 +727,122 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
     asm volatile("ds_read_b128 %0, %1" : "=v"(kr[(KS) % 3][0]) : "v"(ka));                                                          \
     asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(kr[(KS) % 3][1]) : "v"(ka));                                              \
   } while (0)
-#define W64_K_MMA(KS, N, DST)                                                                                                       \
+#define W64_K_MMA(KS, N)                                                                                                            \
   do {                                                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % 3][0]), "+v"(kr[(KS) % 3][1]) : : "memory");                          \
-    DST[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[0][KS], (KS) == 0 ? zero16 : DST[0][0], 0, 0, 0);       \
-    DST[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[1][KS], (KS) == 0 ? zero16 : DST[1][0], 0, 0, 0);       \
-    DST[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[0][KS], (KS) == 0 ? zero16 : DST[0][1], 0, 0, 0);       \
-    DST[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[1][KS], (KS) == 0 ? zero16 : DST[1][1], 0, 0, 0);       \
+    sacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[0][KS], (KS) == 0 ? zero16 : sacc[0][0], 0, 0, 0);     \
+    sacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[1][KS], (KS) == 0 ? zero16 : sacc[1][0], 0, 0, 0);     \
+    sacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[0][KS], (KS) == 0 ? zero16 : sacc[0][1], 0, 0, 0);     \
+    sacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[1][KS], (KS) == 0 ? zero16 : sacc[1][1], 0, 0, 0);     \
   } while (0)
   // QK of one tile: K fragments two k-slices ahead of their products; STEP(KS) = what rides behind the products of k-slice KS
-#define W64_QK(DST, STEP)                                                                                                           \
+#define W64_QK(STEP)                                                                                                                \
   do {                                                                                                                              \
     bf16x8_t kr[3][2];                                                                                                              \
     W64_K_READ(0); W64_K_READ(1);                                                                                                   \
-    W64_K_READ(2); W64_K_MMA(0, 4, DST); STEP(0);                                                                                   \
-    W64_K_READ(3); W64_K_MMA(1, 4, DST); STEP(1);                                                                                   \
-    W64_K_READ(4); W64_K_MMA(2, 4, DST); STEP(2);                                                                                   \
-    W64_K_READ(5); W64_K_MMA(3, 4, DST); STEP(3);                                                                                   \
-    W64_K_READ(6); W64_K_MMA(4, 4, DST); STEP(4);                                                                                   \
-    W64_K_READ(7); W64_K_MMA(5, 4, DST); STEP(5);                                                                                   \
-    W64_K_MMA(6, 2, DST); STEP(6);                                                                                                  \
-    W64_K_MMA(7, 0, DST); STEP(7);                                                                                                  \
+    W64_K_READ(2); W64_K_MMA(0, 4); STEP(0);                                                                                        \
+    W64_K_READ(3); W64_K_MMA(1, 4); STEP(1);                                                                                        \
+    W64_K_READ(4); W64_K_MMA(2, 4); STEP(2);                                                                                        \
+    W64_K_READ(5); W64_K_MMA(3, 4); STEP(3);                                                                                        \
+    W64_K_READ(6); W64_K_MMA(4, 4); STEP(4);                                                                                        \
+    W64_K_READ(7); W64_K_MMA(5, 4); STEP(5);                                                                                        \
+    W64_K_MMA(6, 2); STEP(6);                                                                                                       \
+    W64_K_MMA(7, 0); STEP(7);                                                                                                       \
   } while (0)
 #define W64_NOSTEP(KS) do { } while (0)
+
+  // ---- row statistics of a tile whose scores sit in the accumulator set: the scores move to arch VGPRs (`sc`, where the softmax works on
+  //      them; the set is the destination of the next QK products), masked keys become -inf, and every row learns its new maximum and
+  //      whether it has to move its reference maximum (per row: a row's bits never depend on its wave mates).  Slice I = (group I >> 1,
+  //      32-key half I & 1); the statistics of tile n + 1 are computed one slice behind each quarter of the PV products of tile n.
+  f32x16_t sacc[2][2];                          // ONE accumulator set for the scores ([group][32-key half]; AGPRs)
+  f32x16_t sc[2][2];                            // the softmax's copy (arch VGPRs)
+  float mxp[2], m_new[2];
+  bool grow[2];
+#define W64_STAT_SLICE(I, WORD, FAST)                                                                                               \
+  do {                                                                                                                              \
+    constexpr int g_ = (I) >> 1, kb_ = (I) & 1;                                                                                     \
+    sc[g_][kb_] = sacc[g_][kb_];                                                                                                    \
+    asm volatile("" : "+v"(sc[g_][kb_]));                                                                                           \
+    float mx_;                                                                                                                      \
+    if (FAST) {                                                                                                                     \
+      float ma_ = fmaxf(fmaxf(sc[g_][kb_][0], sc[g_][kb_][1]), sc[g_][kb_][2]);                                                     \
+      float mb_ = fmaxf(fmaxf(sc[g_][kb_][8], sc[g_][kb_][9]), sc[g_][kb_][10]);                                                    \
+      _Pragma("unroll") for (int r = 3; r < 8; ++r) { ma_ = fmaxf(ma_, sc[g_][kb_][r]); mb_ = fmaxf(mb_, sc[g_][kb_][8 + r]); }     \
+      mx_ = fmaxf(ma_, mb_);                                                                                                        \
+    } else {                                                                                                                        \
+      const uint32_t wsel_ = kb_ ? (uint32_t)((WORD) >> (32 + 4 * hi)) : (uint32_t)((WORD) >> (4 * hi));                            \
+      mx_ = -INFINITY;                                                                                                              \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                              \
+        const int kbit = (r & 3) + 8 * (r >> 2);                                                                                    \
+        const float sv_ = ((wsel_ >> kbit) & 1u) ? sc[g_][kb_][r] : -INFINITY;                                                      \
+        sc[g_][kb_][r] = sv_;                                                                                                       \
+        mx_ = fmaxf(mx_, sv_);                                                                                                      \
+      }                                                                                                                             \
+    }                                                                                                                               \
+    mxp[g_] = kb_ ? fmaxf(mxp[g_], mx_) : mx_;                                                                                      \
+    if (kb_) {                                                                                                                      \
+      const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxp[g_]), __float_as_uint(mxp[g_]), false, false);          \
+      const float mt_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * scale_log2;                                       \
+      m_new[g_] = fmaxf(m_run[g_], mt_);                                                                                            \
+      grow[g_] = !(m_new[g_] - m_run[g_] <= 8.0f);                                                                                  \
+    }                                                                                                                               \
+  } while (0)
 
   ATT_WAIT_VM0();                               // K(0), V(0), K(1), Q of the first block
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-
-  // ONE accumulator set for the scores ([group][32-key half]; the matrix pipe's destination, AGPRs): an iteration first copies the scores
-  // of its tile into arch VGPRs (`sc`, where the softmax works on them) and then lets the QK products of the NEXT tile overwrite the set.
-  // (Two ping-pong sets kept 256 AGPRs busy -- oacc 128 + 2 x 64 -- and pushed Q, P and the fragments into 173 spilled registers.)
-  f32x16_t sacc[2][2];
   {
     const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)smem) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
-    W64_QK(sacc, W64_NOSTEP);
+    W64_QK(W64_NOSTEP);
   }
+  W64_STAT_SLICE(0, 0ull, true); W64_STAT_SLICE(1, 0ull, true); W64_STAT_SLICE(2, 0ull, true); W64_STAT_SLICE(3, 0ull, true);
+  uint64_t word_cur = tile_word(0);             // mask word of the tile whose softmax the next iteration runs
 
   const int N = nblk * NT;                      // flat tile stream of the workgroup
-  int t = 0, qi = 0;                            // tile inside the block, block index
-  bool skip_wait = true;                        // the top-of-iteration DMA wait is not needed right after a pipe fill / a block epilogue
+  int t = 0, qi = 0;                            // tile inside the block, block index (j0 + qi)
+  bool skip_wait = true;                        // no DMA wait at the top right after the pipe fill / a block epilogue
 
-  // one iteration of the stream: softmax + PV of tile n, QK of tile n + 1
-  for (int n = 0; n < N; ++n) {               // (the body is written out in the loop: as a lambda that mutates t / qi / skip_wait
-    const bool has_next = n + 1 < N;          //  through reference captures, hipcc kept the three in scratch memory, and every reload
-                                              //  came with an s_waitcnt vmcnt(0) that drained the LDS-DMA queue)
-    const bool last_of_block = (t + 1 == NT);
+  for (int n = 0; n < N; ++n) {                 // (the body is written out in the loop: as a lambda that mutates t / qi / skip_wait through
+    const bool has_next = n + 1 < N;            //  reference captures hipcc kept the three in scratch memory, and every reload came with an
+    const bool last_of_block = (t + 1 == NT);   //  s_waitcnt vmcnt(0) that drained the LDS-DMA queue)
     const bool more = qi + 1 < nblk;
-    const int qb = qb_first + qi;
+    const int jb = j0 + qi;
     if (!skip_wait) ATT_WAIT_VM0();             // K(n+1), V(n) (and a Q half) requested one iteration ago
     skip_wait = false;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // this iteration's sixteen pieces: K(n+2) -> K half of stage n & 1 (K(n) is dead), V(n+1) -> V half of stage (n+1) & 1 (V(n-1) is dead);
+    // this iteration's eight pieces: K(n+2) -> K half of stage n & 1 (K(n) is dead), V(n+1) -> V half of stage (n+1) & 1 (V(n-1) is dead);
     // past the end of the stream they re-stage a tile nobody reads
     int tk = t + 2; tk = tk >= NT ? tk - NT : tk; tk = tk >= NT ? tk - NT : tk;     // (t + 2) mod NT for NT >= 1
     const int tv = (t + 1 == NT) ? 0 : t + 1;
     const int kbuf = n & 1, vbuf = (n + 1) & 1;
     // next block's Q rows: first half requested two tiles before the block ends, read after this block's last QK products
-    if (more && NT >= 3 && t + 3 == NT) q_stage_half(qb + 1, 0);
+    if (more && NT >= 3 && t + 3 == NT) q_stage_half(jb + 1, 0);
     if (more && last_of_block) {
-      if (NT == 1) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); q_read_half(0); q_stage_half(qb + 1, 1); ATT_WAIT_VM0(); }
+      if (NT == 1) { q_stage_half(jb + 1, 0); ATT_WAIT_VM0(); q_read_half(0); q_stage_half(jb + 1, 1); ATT_WAIT_VM0(); }
       q_read_half(1);
     }
     const char* v_lds = smem + (n & 1) * ATT_STAGE_BYTES + K_LDS_BYTES;
-    uint64_t word;
-    if constexpr (VARLEN) {
-      const int rem = S - t * ATT_KB;
-      word = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-    } else {
-      word = bits[t];
-    }
-    bool fast = (word == ~0ull);
+    // The statistics of this tile were computed under the previous tile's PV products WITHOUT looking at the key mask (that pass has to
+    // stay free of branches to be interleaved with the products).  A tile with masked keys -- a sequence's ragged tail, a mask with holes
+    // -- redoes them here from the accumulator set, which still holds the tile's scores: a rare, wave-uniform branch.
     {
-      int fast_i = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);
-      asm volatile("" : "+s"(fast_i));
-      fast = fast_i != 0;
-    }
-    // the tile's scores leave the accumulator set (it is the destination of the QK products issued below)
-    f32x16_t sc[2][2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        sc[g][kb] = sacc[g][kb];
-        asm volatile("" : "+v"(sc[g][kb]));
+      int masked = __builtin_amdgcn_readfirstlane(word_cur != ~0ull ? 1 : 0);
+      asm volatile("" : "+s"(masked));
+      if (masked) {
+        W64_STAT_SLICE(0, word_cur, false); W64_STAT_SLICE(1, word_cur, false); W64_STAT_SLICE(2, word_cur, false); W64_STAT_SLICE(3, word_cur, false);
       }
-    // ---- row maxima + (rare) rescale, both groups
+    }
+    word_cur = tile_word(tv);                   // the next tile's word: a scalar load with a whole iteration of latency cover
+    // ---- the (rare) move of reference maxima decided by the statistics pass, both groups
     float m_use[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      float mx = -INFINITY;
-      if (fast) {
-        float m4[4];
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-          const int kb = c4 >> 1, r0 = (c4 & 1) * 8;
-          m4[c4] = fmaxf(fmaxf(sc[g][kb][r0], sc[g][kb][r0 + 1]), sc[g][kb][r0 + 2]);
-#pragma unroll
-          for (int r = 3; r < 8; ++r) m4[c4] = fmaxf(m4[c4], sc[g][kb][r0 + r]);
-        }
-        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-      } else {
-        const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const uint32_t wsel = kb ? whi : wlo;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kbit = (r & 3) + 8 * (r >> 2);
-            const float sv = ((wsel >> kbit) & 1u) ? sc[g][kb][r] : -INFINITY;
-            sc[g][kb][r] = sv;
-            mx = fmaxf(mx, sv);
-          }
-        }
-      }
-      {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2;
-      }
-      const float m_new = fmaxf(m_run[g], mx);
-      const bool grow = !(m_new - m_run[g] <= 8.0f);
-      if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
-        const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = grow ? __builtin_amdgcn_exp2f(m_run[g] - m_ref) : 1.0f;
-        m_run[g] = grow ? m_new : m_run[g];
+      if (__builtin_amdgcn_ballot_w64(grow[g]) != 0ull) {
+        const float m_ref = (m_new[g] == -INFINITY) ? 0.f : m_new[g];
+        const float alpha = grow[g] ? __builtin_amdgcn_exp2f(m_run[g] - m_ref) : 1.0f;
+        m_run[g] = grow[g] ? m_new[g] : m_run[g];
         l_run[g] *= alpha;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -837,38 +856,37 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
     // exponentials of one eighth of the tile's scores: group KS >> 2, key half (KS >> 1) & 1, quarter KS & 1
 #define W64_PSLICE(KS)                                                                                                              \
   do {                                                                                                                              \
+    float nm_ = -m_use[(KS) >> 2];              /* laundered HERE: otherwise hipcc hoists all 64 scale-and-subtract fmas of the tile   \
+                                                   in front of the section, where nothing covers them */                             \
+    asm volatile("" : "+v"(nm_));                                                                                                   \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                              \
-      const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj], scale_log2, -m_use[(KS) >> 2]));      \
-      const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj + 1], scale_log2, -m_use[(KS) >> 2]));  \
-      psum[(KS) >> 2] += p0 + p1;                                                                                                   \
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj], scale_log2, nm_));      \
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj + 1], scale_log2, nm_));  \
+      psum[(KS) >> 2] = w64_add(psum[(KS) >> 2], w64_add(p0, p1));                                                                  \
       pk8[(KS) >> 2][((KS) >> 1) & 1][(KS) & 1][jj] = pack2bf_hw(p0, p1);                                                           \
     }                                                                                                                               \
   } while (0)
-#define W64_PIECES(KS) do { stage_piece(tk, kbuf, (KS)); stage_piece(tv, vbuf, 8 + (KS)); asm volatile("" ::: "memory"); } while (0)
-#define W64_STEP(KS) do { W64_PIECES(KS); W64_PSLICE(KS); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W64_PIECE(KS) do { if ((KS) < 4) stage_piece(tk, kbuf, (KS)); else stage_piece(tv, vbuf, (KS)); asm volatile("" ::: "memory"); } while (0)
+#define W64_STEP(KS) do { W64_PIECE(KS); W64_PSLICE(KS); __builtin_amdgcn_sched_barrier(0); } while (0)
     if (has_next) {
-      // ---- ONE section: the QK products of tile n + 1, the DMA pieces behind them, the exponentials of tile n between them
+      // ---- ONE section: the QK products of tile n + 1, one DMA piece behind each k-slice, the exponentials of tile n between them
       const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(smem + ((n + 1) & 1) * ATT_STAGE_BYTES)) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
-      __builtin_amdgcn_s_setprio(1);
-      W64_QK(sacc, W64_STEP);
-      __builtin_amdgcn_s_setprio(0);
+      W64_QK(W64_STEP);
     } else {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { W64_PIECES(ks); }
       W64_PSLICE(0); W64_PSLICE(1); W64_PSLICE(2); W64_PSLICE(3); W64_PSLICE(4); W64_PSLICE(5); W64_PSLICE(6); W64_PSLICE(7);
     }
 #undef W64_STEP
-#undef W64_PIECES
+#undef W64_PIECE
 #undef W64_PSLICE
     l_run[0] += psum[0];
     l_run[1] += psum[1];
     // the next block's Q: this block's last QK products (tile NT - 1, issued in the iteration of tile NT - 2) have read qf
     if (more && NT >= 2 && t + 2 == NT) {
-      if (NT == 2) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); }
+      if (NT == 2) { q_stage_half(jb + 1, 0); ATT_WAIT_VM0(); }
       q_read_half(0);
-      q_stage_half(qb + 1, 1);
+      q_stage_half(jb + 1, 1);
     }
-    // ---- O^T += V^T P^T, both groups on every V fragment
+    // ---- O^T += V^T P^T, both groups on every V fragment; behind each quarter of the products one slice of the NEXT tile's statistics
     {
       const uint32_t vbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)v_lds);
       uint32_t va[4];
@@ -894,6 +912,8 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
       oacc[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[g][db], 0, 0, 0);                                            \
     }                                                                                                                                 \
   }
+      // (the statistics read the accumulator set, which the QK section above has just filled with tile n + 1; past the end of the
+      //  stream there is nothing to prepare)
       W64_TR_GROUP(0, 0)
       W64_TR_GROUP(1, 1)
       W64_TR_WAIT(8, 0);
@@ -902,10 +922,17 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
       W64_TR_WAIT(8, 1);
       W64_TR_MMA(1, 1)
       W64_TR_GROUP(3, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      // the statistics of tile n + 1 ride on the SECOND half of the products (by then half of P and one V fragment set are dead: the scores'
+      // arch-VGPR copy, 64 registers that live into the next iteration, does not meet them); unconditional and branch-free (past the end
+      // of the stream they chew on stale scores and nobody looks at the result)
       W64_TR_WAIT(8, 0);
       W64_TR_MMA(2, 0)
+      W64_STAT_SLICE(0, 0ull, true); W64_STAT_SLICE(1, 0ull, true);
+      __builtin_amdgcn_sched_barrier(0);
       W64_TR_WAIT(0, 1);
       W64_TR_MMA(3, 1)
+      W64_STAT_SLICE(2, 0ull, true); W64_STAT_SLICE(3, 0ull, true);
 #undef W64_TR_GROUP
 #undef W64_TR_WAIT
 #undef W64_TR_MMA
@@ -914,17 +941,20 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
     if (!last_of_block) { ++t; continue; }
 
     // ---- block epilogue: everything requested during this tile is waited for BEFORE the stores go out (vmcnt counts stores; the next
-    //      iteration then starts without a DMA wait and the stores drain under it)
+    //      iteration then starts without a DMA wait and the stores drain under it).  The statistics of the next block's first tile
+    //      (computed above against this block's m_run) are redone against the fresh maxima below.
     ATT_WAIT_VM0();
     skip_wait = true;
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int x_row = ln >> 3, x_unit = ln & 7;
+    char* ob_base = o_set + blk_head_b(jb);
+    const int h_blk = hk * gqa + jb / nqb;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
       const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-      const int q_g0 = qb * ATT_QB + wave * 64 + 32 * g;                          // first row of the group
+      const int q_g0 = blk_row0(jb) + wave * 64 + 32 * g;                           // first row of the group
       char* xg = xs + g * 4096;                                                     // 32 rows x 128 B of the wave's buffer
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -956,7 +986,7 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
           const int qr = q_g0 + r;
           if (qr < S) {
             typedef __attribute__((ext_vector_type(4))) unsigned int att_u32x4_t;
-            att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(o_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4)));
+            att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(ob_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4)));
             const att_u32x4_t pv = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
             *op = pv;
           }
@@ -967,15 +997,27 @@ attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ ke
       }
       const int q_row = q_g0 + ql;
       if (q_row < S && lse != nullptr && hi == 0) {
-        if constexpr (VARLEN) lse[(row0 + q_row) * nq + h] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
-        else lse[((int64_t)b * nq + h) * S + q_row] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        if constexpr (VARLEN) lse[(row0 + q_row) * nq + h_blk] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        else lse[((int64_t)b * nq + h_blk) * S + q_row] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
       }
       m_run[g] = -INFINITY; l_run[g] = 0.f;
 #pragma unroll
       for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
     }
+    if (has_next) {
+      // redo the two row decisions of the next block's first tile against the reset maxima: m_new = tile maximum, grow = true unless NaN-free
+      // comparison says otherwise (identical to what the kernel above computes for a block's first tile)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxp[g]), __float_as_uint(mxp[g]), false, false);
+        const float mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2;
+        m_new[g] = fmaxf(m_run[g], mt);
+        grow[g] = !(m_new[g] - m_run[g] <= 8.0f);
+      }
+    }
     t = 0; ++qi;
   }
+#undef W64_STAT_SLICE
 #undef W64_K_READ
 #undef W64_K_MMA
 #undef W64_QK
@@ -990,12 +1032,12 @@ using namespace grit;
 // prologue) -- as many as 4 while the launch still has >= 4 workgroups per CU-slot pair -- and the XCD-aware 1-D grid.
 // the 80 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
 template <typename KernelT>
-static void attn_lds_optin(KernelT kernel, std::atomic<uint64_t>& done) {
+static void attn_lds_optin(KernelT kernel, std::atomic<uint64_t>& done, int bytes = ATT_LDS_BYTES) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if (!(done.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done.fetch_or(bit, std::memory_order_release);
   }
 }
@@ -1010,12 +1052,19 @@ static void attn_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const ui
 }
 
 template <bool VARLEN>
-static void attn_w64_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
-                            int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets) {
+static void attn_w64_launch(hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
+                            int B, int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2) {
   static std::atomic<uint64_t> optin{0};
-  attn_lds_optin(attn_fwd_w64_k<VARLEN>, optin);
-  hipLaunchKernelGGL((attn_fwd_w64_k<VARLEN>), grid, dim3(128), W64_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride, out_stride,
-                     scale_log2, qpw, ngx, n_sets);
+  attn_lds_optin(attn_fwd_w64_k<VARLEN>, optin, W64_LDS_BYTES);
+  // blocks per workgroup: a whole K/V set (all heads of the GQA group x all query blocks: one cold prologue, K/V hot in L2) unless the
+  // launch would then leave CUs idle -- halve until there are two workgroups per CU or one block each
+  const int n_sets = B * nkv, nb_set = (nq / nkv) * ((S + W64_QB - 1) / W64_QB);
+  int bpw = nb_set;
+  while (bpw > 1 && (int64_t)n_sets * ((nb_set + bpw - 1) / bpw) < 512) bpw = (bpw + 1) / 2;
+  const int parts = (nb_set + bpw - 1) / bpw;
+  const unsigned grid = (unsigned)(8 * ((n_sets + 7) / 8) * parts);
+  hipLaunchKernelGGL((attn_fwd_w64_k<VARLEN>), dim3(grid), dim3(256), W64_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
+                     out_stride, scale_log2, bpw, parts, n_sets);
 }
 // which forward the bidirectional entry points launch: the W64 kernel (default) or the round-3 kernel (GRIT_ATTN_FWD=v3; A/B knob, read per
 // call so that one process can time both)
@@ -1065,8 +1114,8 @@ static int attn_fwd_padded(const char* name, bool causal, int window, const void
     attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   else if (attn_use_w64())
-    attn_w64_launch<false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
-                           out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
+    attn_w64_launch<false>((hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, B, S, nq, nkv, qkv_stride,
+                           out_stride, scale * 1.4426950408889634f);
   else
     attn_launch<false, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
                               out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
@@ -1093,8 +1142,8 @@ static int attn_fwd_varlen(const char* name, bool causal, int window, const void
     attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   else if (attn_use_w64())
-    attn_w64_launch<true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
-                          out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets);
+    attn_w64_launch<true>((hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, B, max_len, nq, nkv, qkv_stride,
+                          out_stride, scale * 1.4426950408889634f);
   else
     attn_launch<true, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
