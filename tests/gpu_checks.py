@@ -982,6 +982,68 @@ def check_gritlm_native_encode():
     return _res("GritLM.encode native vs reference GritLM.encode goldens", ok, **out)
 
 
+def check_attn_w64_equals_default():
+    """The opt-in W64 attention forward (csrc/attention.hip, GRIT_ATTN_FWD=w64: 64 query rows per wave, one wave per SIMD, in-wave QK /
+    softmax pipeline; measured 0.70-0.75x of the default kernel in round 4 and kept as the record of that structure) performs the default
+    kernel's per-row arithmetic in the same order: outputs and LSE rows must be BIT-IDENTICAL -- ragged tails, masks with holes, one- /
+    two- / three-tile sequences, a fully masked row, packed rows, a spiked key that forces the rescale branch."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    D = 128
+
+    def both(fn):
+        os.environ.pop("GRIT_ATTN_FWD", None)
+        a = fn()
+        os.environ["GRIT_ATTN_FWD"] = "w64"
+        try:
+            b = fn()
+        finally:
+            os.environ.pop("GRIT_ATTN_FWD", None)
+        torch.cuda.synchronize()
+        eq = lambda x, y: bool(torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x.view(torch.int32),
+                                           y.view(torch.int16) if y.dtype == torch.bfloat16 else y.view(torch.int32)))
+        return eq(a[0], b[0]) and eq(a[1], b[1])
+
+    det, ok = {}, True
+    for (B, S, nq, nkv, kind) in [(2, 64, 8, 2, "full"), (3, 130, 8, 2, "ragged"), (4, 200, 8, 2, "holes"), (2, 192, 8, 2, "allmasked_row"),
+                                   (3, 512, 32, 8, "ragged"), (2, 1024, 8, 8, "full")]:
+        mask = torch.ones((B, S), dtype=torch.int64, device=DEV)
+        if kind == "ragged":
+            lens = torch.randint(1, S + 1, (B,), generator=g, device=DEV); lens[0] = S
+            mask = (torch.arange(S, device=DEV).unsqueeze(0) < lens.unsqueeze(1)).to(torch.int64)
+        elif kind == "holes":
+            mask = (torch.rand((B, S), generator=g, device=DEV) > 0.3).to(torch.int64); mask[:, S - 50:] = 0; mask[0, :] = 1
+        elif kind == "allmasked_row":
+            mask[1, :] = 0
+        qkv = torch.randn((B * S, (nq + 2 * nkv) * D), generator=g, device=DEV).to(torch.bfloat16)
+        qkv[S // 2, nq * D:(nq + 1) * D] *= 6.0
+        bits = ops.mask_pack(mask.contiguous())
+
+        def run(qkv=qkv, bits=bits, B=B, S=S, nq=nq, nkv=nkv):
+            out = torch.full((B * S, nq * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+            lse = torch.full((B, nq, S), float("nan"), dtype=torch.float32, device=DEV)
+            ops.attn_bidir(qkv, bits, B, S, nq, nkv, D, out=out, lse=lse)
+            return out, lse
+        e = both(run)
+        det[f"padded_{B}x{S}_{kind}"] = e
+        ok &= e
+    for lens_l, nq, nkv in [([1], 4, 2), ([65, 3], 8, 2), ([128, 129, 127], 8, 2), ([300, 511, 512, 64, 90, 17], 32, 8)]:
+        lens = torch.tensor(lens_l, dtype=torch.int32, device=DEV)
+        cu = torch.zeros((len(lens_l) + 1,), dtype=torch.int32, device=DEV)
+        cu[1:] = torch.cumsum(lens, 0)
+        T = int(cu[-1])
+        qkv = torch.randn((T, (nq + 2 * nkv) * D), generator=g, device=DEV).to(torch.bfloat16)
+
+        def run(qkv=qkv, cu=cu, mx=max(lens_l), nq=nq, nkv=nkv, T=T):
+            out = torch.full((T, nq * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+            lse = torch.full((T, nq), float("nan"), dtype=torch.float32, device=DEV)
+            ops.attn_bidir_varlen(qkv, cu, mx, nq, nkv, D, out=out, lse=lse)
+            return out, lse
+        e = both(run)
+        det["packed_" + "_".join(map(str, lens_l))] = e
+        ok &= e
+    return _res("attention forward: opt-in W64 kernel == default kernel, bit for bit", ok, **det)
+
+
 def check_moe_router_bwd(T=1531, H=512, E=8, aux=True):
     """grit_moe_router_bwd / grit_moe_router_wgrad (csrc/moe.hip) against torch autograd of the reference's routing arithmetic
     (scripts/modeling_mixtral_gritlm.py:843-849: softmax in fp32 -> top-2 -> renormalise) through the gate Linear, in fp32 on the same
@@ -2428,6 +2490,7 @@ ALL_CHECKS = [
     ("encoder_tiny_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="tiny")),
     ("encoder_gqa_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="gqa")),
     ("encoder_7b_layer_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="7b-l1")),
+    ("attn_w64_equals_default", check_attn_w64_equals_default, {}),
     ("moe_router_bwd", check_moe_router_bwd, {}),
     ("moe_router_bwd_e4_no_aux", check_moe_router_bwd, dict(T=300, H=256, E=4, aux=False)),
     ("moe_router_bwd_e16_h4096", check_moe_router_bwd, dict(T=1100, H=4096, E=16, aux=True)),
