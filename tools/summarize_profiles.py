@@ -6,7 +6,7 @@ import json
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/prof_{tag}"
 shutil.copy(f"{src}/bench_stats/bench_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy(f"{src}/bench_stats.json", f"profiles/{tag}_bench_under_rocprof.json")
