@@ -1119,6 +1119,64 @@ def check_gritlm_multi_gpu_in_process():
     return _res("GritLM in-process multi-GPU encode (two replicas, DataParallel row split)", ok, **out)
 
 
+def check_gritlm_api_variants():
+    """The drop-in surface beyond plain mean pooling (gritlm/gritlm.py:92-176, :178-218): every pooling method, `recast`, `embed_eos`,
+    `add_special_tokens=False`, `max_length` truncation under an instruction, `convert_to_tensor`, a single string, `encode_corpus` on
+    title / text dicts, `encode_queries` -- the native engine against the SAME wrapper on its Hugging Face path (`native=False`; that
+    path is the reference's code shape and is pinned on the reference's own outputs on the CPU, tests/test_gritlm_cpu.py).  Output
+    dtype / shape / device must agree exactly, values to 1 - cos < 1e-4 (2-layer model: both bf16 paths are within 2e-5 of fp32)."""
+    import tempfile
+    from gritlm_amd import GritLM
+    sents = synth.make_sentences(13, seed=21, min_words=1, max_words=70)
+    instr = "Given a query, retrieve passages: "
+    det, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        nat = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16)
+        hf = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, native=False)
+        ok &= nat.engine is not None and hf.engine is None
+        eos = nat.tokenizer.eos_token or ""
+
+        def cmp(tag, **kw):
+            nonlocal ok
+            a, b = nat.encode(sents, batch_size=5, **kw), hf.encode(sents, batch_size=5, **kw)
+            same_kind = type(a) is type(b) and a.shape == b.shape and a.dtype == b.dtype
+            af = a.float().cpu().numpy() if torch.is_tensor(a) else a
+            bf_ = b.float().cpu().numpy() if torch.is_tensor(b) else b
+            if nat.normalized:
+                d = float(np.max(1 - np.sum(af * bf_, axis=-1)))
+            else:
+                d = float(np.max(1 - np.sum(af * bf_, axis=-1) / (np.linalg.norm(af, axis=-1) * np.linalg.norm(bf_, axis=-1))))
+            det[tag] = d
+            ok &= bool(same_kind) and d < 1e-4 and bool(np.isfinite(af).all())
+
+        for method in ("mean", "weightedmean", "lasttoken", "cls"):
+            nat.pooling_method = hf.pooling_method = method
+            cmp(f"{method}", max_length=64)
+            cmp(f"{method}_instr", max_length=64, instruction=instr)
+        nat.pooling_method = hf.pooling_method = "mean"
+        cmp("recast_tensor", max_length=64, recast=True, convert_to_tensor=True)
+        cmp("truncated_under_instruction", max_length=12, instruction=instr)
+        cmp("no_special_tokens", max_length=64, add_special_tokens=False)
+        cmp("embed_instruction", max_length=64, instruction=instr, embed_instruction=True)
+        if eos and eos in nat.tokenizer.vocab:
+            nat.embed_eos = hf.embed_eos = eos
+            cmp("embed_eos", max_length=64)
+            nat.embed_eos = hf.embed_eos = ""
+        nat.normalized = hf.normalized = False
+        cmp("not_normalized", max_length=64)
+        nat.normalized = hf.normalized = True
+        one_n, one_h = nat.encode(sents[3], max_length=64), hf.encode(sents[3], max_length=64)
+        ok &= one_n.shape == one_h.shape == (256,) and float(1 - np.sum(one_n * one_h)) < 1e-4
+        docs = [{"title": "T " + s[:10], "text": s} if i % 2 else {"text": s} for i, s in enumerate(sents)]
+        cn, ch = nat.encode_corpus(docs, batch_size=4, max_length=64), hf.encode_corpus(docs, batch_size=4, max_length=64)
+        det["corpus_dicts"] = float(np.max(1 - np.sum(cn * ch, axis=1)))
+        qn, qh = nat.encode_queries(sents[:4], max_length=64, instruction=instr), hf.encode_queries(sents[:4], max_length=64, instruction=instr)
+        det["queries"] = float(np.max(1 - np.sum(qn * qh, axis=1)))
+        ok &= det["corpus_dicts"] < 1e-4 and det["queries"] < 1e-4
+    return _res("GritLM API variants: native engine vs the wrapper's Hugging Face path", ok, **det)
+
+
 def check_gritlm_native_mixtral():
     """gritlm_amd.GritLM on a (tiny) Mixtral checkpoint directory: model_type 'mixtral' binds the native MoE engine (from the
     installed transformers' fused expert parameters) and encode() matches the oracle on the same tokens."""
@@ -2518,6 +2576,7 @@ ALL_CHECKS = [
     ("packed_encode", check_packed_encode, {}),
     ("packed_encode_tiny", check_packed_encode, dict(cfg_name="tiny", B=3, S=260)),
     ("gritlm_native_encode", check_gritlm_native_encode, {}),
+    ("gritlm_api_variants", check_gritlm_api_variants, {}),
     ("gritlm_native_mixtral", check_gritlm_native_mixtral, {}),
     ("get_cache", check_get_cache, {}),
     ("train_direct", check_train_step, dict(mode="direct")),
