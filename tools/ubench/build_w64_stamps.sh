@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../../gritlm_amd/csrc"
 mkdir -p ../../tools/ubench/_build/stamps_obj
 for f in *.hip; do
-  extra=""; [ "$f" = attention.hip ] && extra="-DW64_STAMPS"
+  extra=""; [ "$f" = attention.hip ] && extra="${W64_EXTRA:--DW64_STAMPS}"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c "$f" -o ../../tools/ubench/_build/stamps_obj/"${f%.hip}.o" &
 done
 wait

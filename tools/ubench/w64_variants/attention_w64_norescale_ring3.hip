@@ -1,0 +1,1289 @@
+// Bidirectional (non-causal) flash attention forward for gfx950, GQA, head_dim 128, key-padding bitmask.
+//
+// Replaces repeat_kv + the additive [B,1,S,S] mask + F.scaled_dot_product_attention of
+// scripts/modeling_mistral_gritlm.py (:182-191, :1017-1036, :690-698).  No repeat_kv copy (the kv head is
+// index arithmetic), no mask tensor (one uint64 per 64 keys), no S x S score matrix.
+//
+// Structure: one 256-thread workgroup walks up to `qpw` consecutive 128-row query blocks of one (batch, head); each wave owns 32 rows of
+// a block; two workgroups per CU.  The K/V tile stream runs THROUGH the block seams (the first tile of the next block is staged, and
+// its Q rows are fetched into the same registers, under the last tile of the current one), so the per-block prologue (Q + first-tile latency) is paid once
+// per workgroup and the output stores of a block drain under the next block's first tile.  Workgroups that share K/V (the GQA
+// group's heads x query-block groups of one (batch, kv head)) are dealt to the SAME XCD back to back (block v runs on XCD v % 8).
+// KV tiles of 64 keys go HBM -> LDS by direct LDS-DMA (buffer_load ... lds, 16 B per lane, 1 KiB = 4 key rows per wave instruction;
+// the descriptor's range check zero-fills rows past the sequence) into a two-stage ring: the eight pieces of tile t+1 are issued
+// BETWEEN the QK products of tile t and land under its softmax and PV products -- no staging registers, no ds_write pass, one barrier
+// per tile.  Every LDS fragment read of the tile loop is inline asm with counted lgkmcnt (round 3): K fragments two k-slices ahead of
+// their products, V fragments in four groups of 8 with the first two requested in front of the softmax; nothing in the loop makes hipcc
+// wait for more than it needs (its own lgkmcnt(0) / vmcnt(0) in front of builtin LDS reads, scalar loads and ds_bpermute cost 12 %).  Both images are row-major [key][256 B] with the 16-byte
+// units XOR-swizzled through the per-lane SOURCE address (the LDS image of a DMA is lane-linear): K unit ^= key & 15
+// (conflict-free ds_read_b128 of a 32-key fragment), V unit ^= 4 (key & 3) (conflict-free ds_read_b64_tr_b16: the 16 lanes of a
+// transposing read touch 4 keys x 32 B, the XOR puts them -- and the second 16-lane group -- on 16 distinct units of one 256-B bank row).
+//   S^T = K Q^T     v_mfma_f32_32x32x16_bf16(A = K rows, B = Q)  -> lane (q = lane&31) holds 32 keys' scores
+//   O^T = V^T P^T   v_mfma_f32_32x32x16_bf16(A = V^T rows, B = P) -> lane (q = lane&31) holds 64 of its d's
+// Both products are "swapped" so that every softmax statistic (max, sum, rescale) is lane-local: the only
+// cross-lane traffic per tile is one v_permlane32_swap for the row max.  The P operand needs no
+// permlane/LDS round trip: the MFMA contraction index is permuted identically on the V^T side
+// (key(kb,c,hi,j) = 32kb + 16c + 8(j>>2) + 4hi + (j&3)): two transposing 8-byte LDS reads whose per-lane
+// addresses select exactly those keys.
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "common.h"
+
+// s_waitcnt vmcnt(0) through the builtin (gfx9 encoding: expcnt 7, lgkmcnt 15 = "don't wait"): unlike an asm statement the waitcnt
+// insertion pass SEES it, so it does not add its own vmcnt(0) in front of the first MFMA that reads the re-fetched Q registers -- that
+// wait would sit behind the freshly issued DMA of the next tile and serialise it
+#define ATT_WAIT_VM0()                      \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_waitcnt(0x0F70);     \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+
+#ifndef ATT_DEFER_MAX
+#define ATT_DEFER_MAX 1
+#endif
+// (ATT_DEFER_MAX and ATT_ABLATE_STORES are the A/B knobs of tools/ubench/attn_ab.cpp.  The levers of round 3 -- asm reads, spread /
+//  buffer-addressed / unconditional DMA pieces, early V reads, s_setprio over QK, xor K addresses, hoisted mask word, permlane row
+//  maximum -- were each A/B'd as a compile-time variant against the kernel of the previous commit, bit-identical every time
+//  (profiles/r03_attn_fwd_ab_asm_reads.log, 773 -> 870 TF at B 256 x S 512); the variants are resolved in this file, the round-2
+//  kernel is rebuilt from git history by tools/ubench/build_attn_ab.sh.)
+
+namespace grit {
+
+constexpr int ATT_D = 128;
+constexpr int ATT_QB = 128;   // query rows per workgroup
+constexpr int ATT_KB = 64;    // keys per tile
+constexpr int V_PITCH = 256;  // bytes per key row of the row-major V image
+constexpr int K_LDS_BYTES = ATT_KB * ATT_D * 2;  // 16384
+constexpr int V_LDS_BYTES = ATT_KB * V_PITCH;    // 16384
+constexpr int ATT_STAGE_BYTES = K_LDS_BYTES + V_LDS_BYTES;   // 32 KiB per stage, two stages
+constexpr int ATT_XPOSE_BYTES = 4096;                         // per wave: 32 rows x 128 B, the Q-in / O-out transposition buffer
+constexpr int ATT_LDS_BYTES = 2 * ATT_STAGE_BYTES + 4 * ATT_XPOSE_BYTES;   // 80 KiB: two workgroups fill the CU's 160 KiB exactly
+typedef const __attribute__((address_space(1))) void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ uint32_t lo16(uint32_t w) { return w & 0xffffu; }
+__device__ __forceinline__ uint32_t hi16(uint32_t w) { return w >> 16; }
+
+// VARLEN: sequences are packed back to back (no padding rows at all); cu_seqlens[b] is the first row of sequence b and
+// every key of a sequence is valid, so the key bitmask is synthesised from the length.
+// CAUSAL: additionally key <= query (the generative branch of unified training, MistralSdpaAttention with is_causal=True,
+// modeling_mistral_gritlm.py:690-698 / :1017-1036); tiles past the workgroup's last query are skipped.
+// CAUSAL with window > 0 (Mistral's sliding window, modeling_mistral_gritlm.py:381-385 / the sliding-window causal mask of
+// _prepare_4d_causal_attention_mask, :1005-1036): a query sees the `window` keys q - window + 1 .. q; tiles that lie wholly in front
+// of a query block's first visible key are skipped as well.
+template <bool VARLEN, bool CAUSAL>
+__global__ void __launch_bounds__(256, 2)
+attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
+                 uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride,
+                 int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets, int window) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];          // 256: the asm read addresses OR / XOR lane constants into bits 7:4
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware decode: the k-th workgroup of XCD x belongs to K/V set (k / U) * 8 + x, U = (heads per kv head) x (query-block groups)
+  const int gqa = nq / nkv, U = gqa * ngx;
+  const int kx = (int)blockIdx.x >> 3;
+  const int set = (kx / U) * 8 + ((int)blockIdx.x & 7), member = kx % U;
+  if (set >= n_sets) return;
+  const int b = set / nkv, hk = set - b * nkv;
+  const int h = hk * gqa + member % gqa;
+  const int qb_first = (member / gqa) * qpw;
+  int S = S_arg;
+  int64_t row0 = (int64_t)b * S_arg;
+  if constexpr (VARLEN) {
+    row0 = cu_seqlens[b];
+    S = cu_seqlens[b + 1] - cu_seqlens[b];
+  }
+  if (qb_first * ATT_QB >= S) return;            // uniform per workgroup
+  const int nqb = (S + ATT_QB - 1) / ATT_QB;
+  const int nblk = (nqb - qb_first) < qpw ? (nqb - qb_first) : qpw;
+
+  // Global addressing = workgroup-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit per-lane pointers to keep
+  // alive (or spill) around the tile loop.  The launcher guarantees rows * stride * 2 < 2^31.
+  const char* q_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)h * ATT_D);
+  const char* k_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + hk) * ATT_D);
+  const char* v_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + nkv + hk) * ATT_D);
+  char* o_base = reinterpret_cast<char*>(out + row0 * out_stride + (int64_t)h * ATT_D);
+  const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
+
+  const int ql = lane & 31, hi = lane >> 5;
+
+  // ---- LDS-DMA roles: wave w stages keys 16w .. 16w+15 of a tile, four 1-KiB instructions for K and four for V (4 keys each);
+  //      lane -> key 16w + 4i + (lane>>4), physical 16-byte unit lane&15, which holds the LOGICAL unit (lane&15) ^ swizzle(key)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int st_key = 16 * wv + (lane >> 4);                                     // + 4i
+  const uint32_t v_unit_b = (uint32_t)(((lane & 15) ^ (4 * ((lane >> 4) & 3))) << 4);   // V: unit ^= 4 (key & 3); key & 3 == (lane>>4) & 3
+  auto stage_tile = [&](int t, int buf) {
+    char* kdst = smem + buf * ATT_STAGE_BYTES + wv * 4096;
+    char* vdst = kdst + K_LDS_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = t * ATT_KB + st_key + 4 * i;
+      key = key < S ? key : S - 1;
+      const uint32_t k_unit_b = (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);   // K: unit ^= key & 15
+      const uint32_t row_b = (uint32_t)key * qkv_stride_b;
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(k_base + (row_b + k_unit_b)), (att_lptr_t)(kdst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(v_base + (row_b + v_unit_b)), (att_lptr_t)(vdst + i * 1024), 16, 0, 0);
+    }
+  };
+  // one 1-KiB piece of a tile (the eight pieces of the next tile are issued BETWEEN the QK products of the current one --
+  // an LDS-DMA instruction costs 60-185 issue cycles (guide, 'LDS-DMA piece issue cost'), eight of them in front of the first K read
+  // held the whole tile back; between MFMAs the cost sits under the matrix pipe)
+  // Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): the descriptor's range check zero-fills rows past the sequence (their
+  // keys are masked anyway: finite K -> score -> -inf, P = 0 x finite V), so a piece needs no per-lane clamp / 32-bit multiply: the
+  // lane's offset inside a tile (row + swizzled unit; V: + the distance of the V heads from the K heads) is a constant VGPR per piece,
+  // the tile's row offset ONE scalar operand for all eight pieces, and ONE descriptor serves K and V (a V row of the last valid key
+  // ends exactly at num_records; the next row of either operand starts (nq + nkv) x 256 - 256 >= 0 bytes behind it).
+  const uint32_t v_delta_b = (uint32_t)nkv * ATT_D * 2u;
+  const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u + v_delta_b), 0x00020000);
+  uint32_t pc_k[4], pc_v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pc_k[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
+    pc_v[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + v_unit_b + v_delta_b;
+  }
+  auto stage_piece = [&](int t, int buf, int i, int is_v) {
+    char* dst = smem + buf * ATT_STAGE_BYTES + wv * 4096 + (is_v ? K_LDS_BYTES : 0) + i * 1024;
+    const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(is_v ? pc_v[i] : pc_k[i]), (int)tile_b, 0, 0);
+  };
+  // the first tile's DMA goes out before anything else (tile 0 always exists: S > 0); with a window the first tile of the first block
+  // is known only after the key bitmask has been scanned (below)
+  if (!(CAUSAL && window > 0)) stage_tile(0, 0);
+
+  // ---- Q fragments (B operand): lane holds Q[q][16ks + 8hi .. +8] of query block qb.  A row-per-lane global load touches 32 rows x 32 B
+  //      per instruction (measured: the per-block Q fetch + O store in that shape cost 18 % of the kernel at S = 512), so Q comes
+  //      in through the wave's private 4 KiB transposition buffer instead, one 64-column half (32 rows x 128 B) at a time: LDS-DMA of
+  //      whole 128-byte row segments (4 instructions x 8 rows, 16-byte units swizzled by (row>>1)&7), then ds_read_b128 of the half's
+  //      four k-slices.
+  bf16x8_t qf[8];
+  char* xs = smem + 2 * ATT_STAGE_BYTES + wv * ATT_XPOSE_BYTES;
+  const int q_swz = (ql >> 1) & 7;                                               // swizzle of the lane's own row
+  // (per-block address arithmetic is recomputed from a laundered lane id where it is used: hoisted to kernel entry it would be spilled
+  //  around the tile loop, and a scratch reload's vmcnt wait would sit in front of the hand-placed DMA)
+  auto q_stage_half = [&](int qb, int half) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;                                  // row (+ 8j) and physical unit of a DMA piece
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 8 * j + x_row;
+      int qr = qb * ATT_QB + wave * 32 + r;
+      qr = qr < S ? qr : S - 1;
+      const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);   // logical unit held by physical unit x_unit of row r
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(q_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + j * 1024), 16, 0, 0);
+    }
+  };
+  auto q_read_half = [&](int half) {
+    const char* rp = xs + ql * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[half * 4 + ks] = *reinterpret_cast<const bf16x8_t*>(rp + (((2 * ks + hi) ^ q_swz) << 4));
+    // the reads must have left the buffer before it is refilled (DMA) or rewritten (O staging)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                           // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+  };
+  // the workgroup's FIRST block takes its Q rows straight from global memory (row-per-lane loads, one round trip that overlaps the
+  // first tile's DMA; two dependent passes through the 4 KiB buffer would put two memory latencies in front of the first product)
+  {
+    const int qr0 = qb_first * ATT_QB + wave * 32 + ql;
+    const char* qp = q_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+    }
+  }
+
+  // number of KV tiles that contain at least one valid key (trailing padding is never loaded)
+  int ntiles_all = 0;
+  const uint64_t* bits = nullptr;
+  if constexpr (VARLEN) {
+    ntiles_all = (S + 63) >> 6;
+  } else {
+    const int W = (S + 63) >> 6;
+    bits = key_bits + (int64_t)b * W;
+    for (int w = W - 1; w >= 0; --w)
+      if (bits[w] != 0) { ntiles_all = w + 1; break; }
+  }
+
+  // K fragment address: row = 32kb + (lane&31), d-slot = 2ks + hi, swizzle by row&15 == lane&15
+  const int kf_row = ql * 256, kf_x = lane & 15;
+  // V fragment (A operand of O^T += V^T P^T) straight from the ROW-MAJOR V image with ds_read_b64_tr_b16: in every 16-lane group lane j
+  // points at V[k0 + j/4][d0 + 4 (j%4)] and lane c receives V[k0 .. k0+3][d0 + c] (the hardware transposes the group's 4 x 16 block);
+  // d0 = 32db + 16 ((lane>>4)&1) makes c <-> the MFMA row lane&31, k0 = 32kb + 16c + 4hi (+8 for the second half of the k-slice)
+  // (key & 3) of every key a lane addresses is (lane>>2)&3, so the V swizzle turns the d-block offset db*64 into (db ^ r)*64, r = (lane>>2)&3:
+  // vt_lane carries r in byte bits 7:6 and the read address of d-block db is vt_lane ^ (db << 6)
+  const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + ((((lane >> 2) & 3) * 4) << 4) + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+
+  // KV tiles [t0, t1) of query block qb
+  auto tile_range = [&](int qb, int& t0, int& t1) {
+    t0 = 0;
+    t1 = ntiles_all;
+    if constexpr (CAUSAL) {
+      const int lim = 2 * qb + 2;               // tiles holding keys <= the last query of this block
+      t1 = t1 < lim ? t1 : lim;
+      if (window > 0) {
+        const int lo = qb * ATT_QB - window + 1;                // first key the block's FIRST query sees
+        t0 = lo > 0 ? lo >> 6 : 0;
+        t0 = t0 < t1 ? t0 : (t1 > 0 ? t1 - 1 : 0);             // never an empty range while the sequence has keys (the K/V stream
+      }                                                        // through the block seams counts on one tile per block); its keys are
+    }                                                          // then masked for every row
+  };
+  if (CAUSAL && window > 0) {
+    int f0, f1;
+    tile_range(qb_first, f0, f1);
+    stage_tile(f0, 0);
+  }
+
+  int gt = 0;                                   // tiles consumed so far by this workgroup: tile g lives in stage g & 1
+  ATT_WAIT_VM0();                               // first tile + first Q rows
+  for (int qi = 0; qi < nblk; ++qi) {
+    const int qb = qb_first + qi;
+    const int q_row = qb * ATT_QB + wave * 32 + ql;
+    int t_first, ntiles, next_first = 0, next_end;
+    tile_range(qb, t_first, ntiles);
+    const bool more = qi + 1 < nblk;
+    if (more) tile_range(qb + 1, next_first, next_end);
+
+    f32x16_t oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int t = t_first; t < ntiles; ++t, ++gt) {
+      // tile t has landed (this wave's share: vmcnt; everybody's: the barrier) and every wave is done reading the other stage.  The
+      // first tile of a block was waited for before the block loop / at the seam (before the previous block stored its output:
+      // vmcnt counts stores, and the stores should drain under this tile, not in front of it).
+      if (t > t_first) ATT_WAIT_VM0();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // the eight pieces are issued unconditionally: behind the workgroup's very last tile they re-stage that tile into the idle stage
+      // (nobody reads it; the wait in front of the block's output stores covers it) instead of costing a uniform branch per piece
+      const int st_t = (t + 1 < ntiles) ? t + 1 : (more ? next_first : t), st_buf = (gt + 1) & 1;
+      // next block's Q, first 64 columns: fetched a whole tile ahead (the buffer is idle), so the wait at the top of the last tile
+      // already covers it
+      if (more && t + 2 == ntiles) q_stage_half(qb + 1, 0);
+      const char* k_lds = smem + (gt & 1) * ATT_STAGE_BYTES;
+      const char* v_lds = k_lds + K_LDS_BYTES;
+      // the tile's key-mask word is fetched HERE (a scalar load; its latency sits under the QK products) and turned into `fast` before
+      // the asm LDS reads of the PV products are requested: fetched where it is used, hipcc's lgkmcnt(0) for the scalar load waited for
+      // the load's own round trip AND for the sixteen V reads just issued -- once per tile
+      uint64_t word;
+      if constexpr (VARLEN) {
+        const int rem = S - t * ATT_KB;
+        word = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+      } else {
+        word = bits[t];
+      }
+      bool fast = (word == ~0ull);
+      if constexpr (CAUSAL) {
+        const int qw0 = qb * ATT_QB + wave * 32;                   // this wave's first query
+        // tile reaches past the wave's first query, or starts in front of the first key the wave's LAST query sees: per-lane bounds
+        if (t * ATT_KB + ATT_KB - 1 > qw0 || (window > 0 && t * ATT_KB < qw0 + 32 - window)) {
+          const int n = q_row - t * ATT_KB + 1;                    // keys of this tile the lane's query may see
+          word &= n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+          if (window > 0) {
+            const int lo = n - window;                             // keys of this tile in front of the lane's window
+            word &= lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+          }
+          fast = false;
+        }
+      }
+
+      // ---- S^T = K Q^T (scores for 64 keys x 32 q per wave)
+      // the two 32-key halves are two INDEPENDENT accumulation chains, issued alternately: a v_mfma_f32_32x32x16_bf16 occupies the pipe
+      // for 32 cycles but its result is ready after 64, so a product that accumulates onto the one issued just before it has to
+      // wait (hipcc keeps MFMA source order; A/B against "8 products on one half, then 8 on the other": +2.5-4.5 %, bit-identical)
+      f32x16_t sacc[2];
+      // K fragments as inline-asm ds_read_b128 with counted lgkmcnt, requested two k-slices (2 reads each) ahead of the products that
+      // consume them (hipcc issues them in small batches and waits lgkmcnt(0) seven times per tile)
+      {
+        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // (2 ks + hi) ^ kf_x == (2 ks) ^ (hi ^ kf_x): one per-tile base with the lane's constant in address bits 7:4, one v_xor per k-slice
+        const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)k_lds) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
+        bf16x8_t kr[8][2];
+#define ATT_K_READ(KS)                                                                                                              \
+  do {                                                                                                                              \
+    const uint32_t ka = kbase ^ (uint32_t)((KS) << 5);                                                                              \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(kr[KS][0]) : "v"(ka));                                                                \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(kr[KS][1]) : "v"(ka));                                                    \
+  } while (0)
+#define ATT_K_MMA(KS, N)                                                                                                            \
+  do {                                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[KS][0]), "+v"(kr[KS][1]) : : "memory");                                      \
+    sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][0], qf[KS], (KS) == 0 ? zero16 : sacc[0], 0, 0, 0);                    \
+    sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][1], qf[KS], (KS) == 0 ? zero16 : sacc[1], 0, 0, 0);                    \
+    stage_piece(st_t, st_buf, (KS) >> 1, (KS) & 1);                                                                                 \
+    asm volatile("" ::: "memory");                                                                                                  \
+  } while (0)
+        // K fragments two k-slices ahead of their products (three ahead: no gain); one LDS-DMA piece of the next tile behind every
+        // product pair; s_setprio 1 over the section: 0 .. +2 % (over the PV section as well: -1.5 %)
+        __builtin_amdgcn_s_setprio(1);
+        ATT_K_READ(0); ATT_K_READ(1);
+        ATT_K_READ(2); ATT_K_MMA(0, 4);
+        ATT_K_READ(3); ATT_K_MMA(1, 4);
+        ATT_K_READ(4); ATT_K_MMA(2, 4);
+        ATT_K_READ(5); ATT_K_MMA(3, 4);
+        ATT_K_READ(6); ATT_K_MMA(4, 4);
+        ATT_K_READ(7); ATT_K_MMA(5, 4);
+        ATT_K_MMA(6, 2); ATT_K_MMA(7, 0);
+        __builtin_amdgcn_s_setprio(0);
+#undef ATT_K_READ
+#undef ATT_K_MMA
+      }
+
+      // the next block's Q rows replace this block's as soon as its last QK product has read them: the fetch lands under the
+      // softmax and PV of the last tile, no second register set
+      const bool q_next = more && t + 1 == ntiles;
+      if (q_next) {                 // this block's last QK products have read qf: refill it for the next block
+        if (ntiles - t_first == 1) { q_stage_half(qb + 1, 0); ATT_WAIT_VM0(); }
+        q_read_half(0);
+        q_stage_half(qb + 1, 1);    // the other 64 columns land under the softmax and the PV products
+      }
+
+      // The transposing V reads as inline asm with COUNTED lgkmcnt: hipcc's wait-count pass treats a ds_read_b64_tr_b16 builtin as aliasing the
+      // pending LDS-DMA and puts an s_waitcnt vmcnt(0) in front of the first one -- the NEXT tile's DMA then had to land before this
+      // tile's PV products could start.  Four groups (kb, c) of 8 reads feed 4 MFMAs each; group g + 1 is requested before group g is
+      // waited for (lgkmcnt(8): LDS returns in order), two register sets of 16.  The first two groups are requested HERE,
+      // in front of the softmax (the V tile has been in LDS since the barrier at the top of the tile; the K fragments' registers are free).
+      const uint32_t vbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)v_lds);
+      uint32_t va[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) va[db] = vbase + (uint32_t)(vt_lane ^ (db << 6));
+      s16x4_t vr[2][4][2];
+#define ATT_TR_GROUP(G, BUF)                                                                                                          \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][0]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH));                \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][1]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH + 8 * V_PITCH)); \
+  }
+      {
+        int fast_i = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);   // wave-uniform; made opaque HERE so that the compare -- and with it hipcc's wait for the
+        asm volatile("" : "+s"(fast_i));            // mask word's scalar load -- sits in front of the V reads, not behind them
+        fast = fast_i != 0;
+      }
+      ATT_TR_GROUP(0, 0)
+      ATT_TR_GROUP(1, 1)
+
+      // ---- mask + online softmax (all lane-local except one exchange with lane^32)
+      float mx = -INFINITY;
+      if (fast) {                   // every key of the tile is valid (all tiles but a ragged last one): no per-element mask
+        // four independent chains (max is exact: any order gives the same bits); one chain of 16 dependent v_max3 is a latency chain
+        float m4[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const int kb = c4 >> 1, r0 = (c4 & 1) * 8;
+          m4[c4] = fmaxf(fmaxf(sacc[kb][r0], sacc[kb][r0 + 1]), sacc[kb][r0 + 2]);
+#pragma unroll
+          for (int r = 3; r < 8; ++r) m4[c4] = fmaxf(m4[c4], sacc[kb][r0 + r]);
+        }
+        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      } else {
+        const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const uint32_t wsel = kb ? whi : wlo;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kbit = (r & 3) + 8 * (r >> 2);  // key within the 32-block, minus 4*hi (already shifted)
+            const float s = ((wsel >> kbit) & 1u) ? sacc[kb][r] : -INFINITY;
+            sacc[kb][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        }
+      }
+      {
+        // max over the two 32-lane halves through v_permlane32_swap (a VALU instruction): __shfl_xor is a ds_bpermute, an LDS-queue
+        // instruction whose lgkmcnt(0) also waits for the V reads requested in front of the softmax
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2;      // scale > 0: max commutes with the scaling
+      }
+      const float m_new = fmaxf(m_run, mx);
+#if ATT_DEFER_MAX
+      // deferred rescale: a row keeps its old reference maximum as long as its maximum grows by less than 2^8 (P <= 256, exact in
+      // the bf16 exponent range; l and O stay consistent with m_run); when NO row of the wave has to move, the 64 accumulator
+      // multiplies + exp2 of the rescale are skipped.  The decision is per row (rows that stay multiply by exactly 1), so a row's
+      // result never depends on which other rows share its wave -- the packed and the padded layout stay bit-identical.
+      const bool grow = !(m_new - m_run <= 8.0f);                 // also true for m_run = -inf (first tile, or all keys masked so far)
+      if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+        const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_ref) : 1.0f;  // m_run = -inf -> 0
+        m_run = grow ? m_new : m_run;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
+      const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+#else
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+      m_run = m_new;
+#endif
+      float psum = 0.f;
+      bf16x8_t pb[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          uint32_t pk[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            // exp2(s*scale - m): one fma + one v_exp per score (masked scores are -inf -> 0)
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj], scale_log2, -m_use));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj + 1], scale_log2, -m_use));
+            psum += p0 + p1;
+            pk[jj] = pack2bf_hw(p0, p1);
+          }
+          pb[kb][c] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+        }
+#if ATT_DEFER_MAX
+      l_run += psum;
+#else
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#endif
+
+
+      // ---- O^T += V^T P^T   (the four d-blocks are four independent accumulators: round-robin, never the same one twice in a row)
+      {
+#define ATT_TR_WAIT(N, BUF)                                                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                            \
+               : "+v"(vr[BUF][0][0]), "+v"(vr[BUF][0][1]), "+v"(vr[BUF][1][0]), "+v"(vr[BUF][1][1]), "+v"(vr[BUF][2][0]),              \
+                 "+v"(vr[BUF][2][1]), "+v"(vr[BUF][3][0]), "+v"(vr[BUF][3][1]))
+#define ATT_TR_MMA(G, BUF)                                                                                                            \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    const s16x4_t v0 = vr[BUF][db][0], v1 = vr[BUF][db][1];                                                                           \
+    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
+    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[(G) >> 1][(G) & 1], oacc[db], 0, 0, 0);                                 \
+  }
+        ATT_TR_WAIT(8, 0);
+        ATT_TR_MMA(0, 0)
+        ATT_TR_GROUP(2, 0)
+        ATT_TR_WAIT(8, 1);
+        ATT_TR_MMA(1, 1)
+        ATT_TR_GROUP(3, 1)
+        ATT_TR_WAIT(8, 0);
+        ATT_TR_MMA(2, 0)
+        ATT_TR_WAIT(0, 1);
+        ATT_TR_MMA(3, 1)
+#undef ATT_TR_GROUP
+#undef ATT_TR_WAIT
+#undef ATT_TR_MMA
+      }
+    }
+
+    // ---- block seam: the next block's first tile and Q rows (issued one tile ago) are waited for BEFORE this block's stores go out
+    ATT_WAIT_VM0();
+    if (more) q_read_half(1);
+
+    // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);     // (once per block; through v_permlane32_swap like the tile maximum: measured 2 % slower at S >= 2048)
+    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    // full-line stores through the transposition buffer (a row-per-lane store touches 32 lines x 32 B per instruction): one 64-column
+    // half at a time, every lane writes its 4 pieces of the half (unit ^= (row>>1)&7), then stores 16 B of an 8-row x 128-B piece
+    const int q_wave0 = qb * ATT_QB + wave * 32;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;                                  // row (+ 8j) and physical unit of a store piece
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      char* wp = xs + (ln & 31) * 128;
+#pragma unroll
+      for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          // v_permlane32_swap exchanges the two 32-lane halves of the register groups g and g+1, so that a lane ends up with 8
+          // CONSECUTIVE dims of its row (half 0: group g, half 1: group g+1): one 16-byte piece
+          const int db = half * 2 + dbl;
+          float a[4], bq[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[db][8 * gp + e] * inv_l),
+                                                             __float_as_uint(oacc[db][8 * gp + 4 + e] * inv_l), false, false);
+            a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
+          }
+          *reinterpret_cast<uint4*>(wp + (((dbl * 4 + gp * 2 + hi) ^ q_swz) << 4)) =
+              make_uint4(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]), pack2bf_hw(bq[0], bq[1]), pack2bf_hw(bq[2], bq[3]));
+        }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                         // lgkmcnt(0): the wave's own writes are in the buffer
+      asm volatile("" ::: "memory");
+      uint4 piece[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) piece[j] = *reinterpret_cast<const uint4*>(xs + j * 1024 + ln * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + x_row;
+        const int qr = q_wave0 + r;
+#ifdef ATT_ABLATE_STORES
+        if (qr < S && scale_log2 < -1e30f)
+#else
+        if (qr < S)
+#endif
+        {
+          typedef __attribute__((ext_vector_type(4))) unsigned int att_u32x4_t;
+          att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(o_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4)));
+          const att_u32x4_t pv = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+          *op = pv;
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                         // the pieces are in registers before the buffer is reused
+      asm volatile("" ::: "memory");
+    }
+    if (q_row < S && lse != nullptr && hi == 0) {
+      if constexpr (VARLEN) lse[(row0 + q_row) * nq + h] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;  // [T, nq]
+      else lse[((int64_t)b * nq + h) * S + q_row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    }
+  }
+}
+
+
+// ====================================================================================================================================
+// W64 forward (round 4): the bidirectional kernel restructured around ONE wave per SIMD with 64 query rows per wave.
+//
+// Why (profiles/r03_attn_fwd_ablation.log): in the kernel above a wave owns 32 query rows, so every
+// v_mfma_f32_32x32x16_bf16 needs a fresh 1 KiB operand fragment from LDS and a K/V tile is staged (8 LDS-DMA pieces per wave) for 32
+// products per wave; with everything else ablated that structure ends at 0.53 of the pipe.  Here a wave owns TWO 32-row query groups:
+// every K / V fragment read from LDS feeds two products, a tile costs a wave 8 DMA pieces per 64 products, and the per-tile rendezvous
+// (barrier, DMA wait, mask word) is paid once per 256 query rows.  The wave has the whole register file of its SIMD (oacc 128 + one score
+// set 64 + Q 64 in AGPRs; the softmax's copy of the scores, P and the fragments in arch VGPRs).  With one wave per SIMD nobody else fills
+// the matrix pipe during the softmax, so the loop is software pipelined IN the wave: iteration n issues
+//     QK(n+1)  between the exponentials of tile n  (K runs one tile ahead of V in the ring: the LDS holds V(n) and K(n+1), the DMA of
+//              V(n+1) and K(n+2) is in flight),
+//     PV(n)    between the row statistics of tile n + 1 (score copy-out, mask, row maxima, the per-row "does the maximum move" decision).
+//
+// Geometry: 256-thread workgroups (4 waves x 64 rows = 256-row query blocks), ONE workgroup per CU.  A workgroup walks `bpw` consecutive
+// blocks of one K/V set (batch, kv head) -- block j = (head j / nqb of the GQA group, query block j % nqb) -- as ONE flat tile stream: the
+// bidirectional tile range is the same for every block of the set, so the ring never notices a block boundary, the K/V tiles stay in
+// the XCD's L2 for all heads of the group, and the next block's Q rows are fetched under the previous block's last tiles: one cold
+// prologue per workgroup (64 tile iterations at B 256 x S 512).  The first version of this kernel ran two-wave workgroups (128 rows) two
+// per CU: 16 DMA pieces per wave and tile with no partner wave to cover their issue cost, 0.65x of the kernel above
+// (profiles/r04_attn_w64_first_build_ab.json); it was bit-identical, as this one is: per-row arithmetic (accumulation order of both
+// products, the per-row deferred rescale) is that of the kernel above (tools/attn_w64_ab.py), packed == padded.
+// Row-sum adds.  Written as plain C: an inline-asm v_add_f32 here (tried: it keeps hipcc from SLP-packing neighbouring adds into v_pk_add_f32,
+// which the guide prices above two scalar adds beside MFMAs) consumed v_exp_f32 results that the compiler did not know a VALU instruction
+// was about to read -- on the GPU 8 of 64 lanes summed the exponentials' INPUTS (negative denominators, zero outputs); found by dumping
+// l / m per row from a -DW64_DEBUG build.  hipcc's own adds get the wait states the transcendental unit needs.
+__device__ __forceinline__ float w64_add(float a, float b) { return a + b; }
+// -DW64_STAMPS (tools/ubench/build_w64_stamps.sh; never in the shipped library): shader-clock stamps at the section boundaries of the tile
+// loop, summed per section over wave 0's iterations and written over the first floats of `lse` by workgroup 0
+#ifdef W64_STAMPS
+#define W64_STAMP(I) do { const uint64_t now_ = __builtin_readcyclecounter(); st_acc[I] += (uint32_t)(now_ - st_last); st_last = now_; } while (0)
+#else
+#define W64_STAMP(I) do { } while (0)
+#endif
+constexpr int W64_QB = 256;                                                    // query rows per workgroup block
+constexpr int W64_XPOSE_BYTES = 8192;                                          // per wave: 64 rows x 128 B (Q in / O out)
+constexpr int W64_STAGES = 3;                                                  // K/V ring: the DMA runs TWO tile iterations ahead of its readers
+constexpr int W64_LDS_BYTES = W64_STAGES * ATT_STAGE_BYTES + 4 * W64_XPOSE_BYTES + 64;   // 128 KiB + the redo flag
+
+template <bool VARLEN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
+               uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride,
+               float scale_log2, int bpw, int parts, int n_sets) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gqa = nq / nkv;
+  // XCD-aware decode (as above): the k-th workgroup of XCD x belongs to K/V set (k / parts) * 8 + x, part k % parts of its blocks
+  const int kx = (int)blockIdx.x >> 3;
+  const int set = (kx / parts) * 8 + ((int)blockIdx.x & 7), part = kx % parts;
+  if (set >= n_sets) return;
+  const int b = set / nkv, hk = set - b * nkv;
+  int S = S_arg;
+  int64_t row0 = (int64_t)b * S_arg;
+  if constexpr (VARLEN) {
+    row0 = cu_seqlens[b];
+    S = cu_seqlens[b + 1] - cu_seqlens[b];
+  }
+  const int nqb = (S + W64_QB - 1) / W64_QB;
+  const int nb_set = gqa * nqb;                 // blocks of this set: (head of the group, query block)
+  const int j0 = part * bpw;
+  if (j0 >= nb_set) return;                     // uniform per workgroup
+  const int nblk = (nb_set - j0) < bpw ? (nb_set - j0) : bpw;
+
+  const char* q_set = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)hk * gqa * ATT_D);        // + head-in-group * 256 B
+  const char* k_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + hk) * ATT_D);
+  char* o_set = reinterpret_cast<char*>(out + row0 * out_stride + (int64_t)hk * gqa * ATT_D);
+  const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
+  const int ql = lane & 31, hi = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+
+  // ---- LDS-DMA roles (as above): wave w stages keys 16w .. 16w+15 of a tile, four 1-KiB pieces for K and four for V
+  const int st_key = 16 * wv + (lane >> 4);
+  const uint32_t v_unit_b = (uint32_t)(((lane & 15) ^ (4 * ((lane >> 4) & 3))) << 4);
+  const uint32_t v_delta_b = (uint32_t)nkv * ATT_D * 2u;
+  const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u + v_delta_b), 0x00020000);
+  // piece p = 0..7 of a tile: p < 4 -> K piece p, else V piece p - 4.  The per-lane offset inside a tile (row + swizzled unit) is recomputed
+  // from a laundered lane id at every piece (~3 VALU instructions): as eight loop-invariant VGPRs they were what hipcc spilled, and a scratch
+  // reload in this loop waits with vmcnt(0) on the very DMA queue the three-stage ring keeps in flight
+  auto stage_piece = [&](int t, int buf, int p) {
+    const int is_v = p >> 2, i = p & 3;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const uint32_t row_b = (uint32_t)(16 * wv + 4 * i + (ln >> 4)) * qkv_stride_b;
+    const uint32_t unit_b = is_v ? ((uint32_t)(((ln & 15) ^ (4 * ((ln >> 4) & 3))) << 4) + v_delta_b)
+                                 : (uint32_t)(((ln & 15) ^ ((4 * i + (ln >> 4)) & 15)) << 4);
+    char* dst = smem + buf * ATT_STAGE_BYTES + (is_v ? K_LDS_BYTES : 0) + wv * 4096 + i * 1024;
+    const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(row_b + unit_b), (int)tile_b, 0, 0);
+  };
+
+  // ---- Q fragments of the wave's two 32-row groups: qf[g][ks], lane holds Q[64 wave + 32 g + ql][16 ks + 8 hi .. + 8]
+  bf16x8_t qf[2][8];
+  char* xs = smem + W64_STAGES * ATT_STAGE_BYTES + wv * W64_XPOSE_BYTES;
+  volatile int* redo_flag = reinterpret_cast<volatile int*>(smem + W64_STAGES * ATT_STAGE_BYTES + 4 * W64_XPOSE_BYTES);
+  const int q_swz = (ql >> 1) & 7;
+  // block j of the set -> byte offset of its head inside a row, first row of the block
+  auto blk_head_b = [&](int j) { return (uint32_t)(j / nqb) * (uint32_t)(ATT_D * 2); };
+  auto blk_row0 = [&](int j) { return (j % nqb) * W64_QB; };
+  // one 64-column half of the wave's 64 rows through the transposition buffer: eight DMA instructions of 8 rows x 128 B
+  auto q_stage_half = [&](int j, int half) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;
+    const char* qb_base = q_set + blk_head_b(j);
+    const int r0 = blk_row0(j) + wave * 64;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int r = 8 * jj + x_row;
+      int qr = r0 + r;
+      qr = qr < S ? qr : S - 1;
+      const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);
+      __builtin_amdgcn_global_load_lds((att_gptr_t)(qb_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + jj * 1024), 16, 0, 0);
+    }
+  };
+  auto q_read_half = [&](int half) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const char* rp = xs + (32 * g + ql) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[g][half * 4 + ks] = *reinterpret_cast<const bf16x8_t*>(rp + (((2 * ks + hi) ^ q_swz) << 4));
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                           // lgkmcnt(0): the reads have left the buffer
+    asm volatile("" ::: "memory");
+  };
+
+  // number of KV tiles with at least one valid key
+  int NT = 0;
+  const uint64_t* bits = nullptr;
+  if constexpr (VARLEN) {
+    NT = (S + 63) >> 6;
+  } else {
+    const int W = (S + 63) >> 6;
+    bits = key_bits + (int64_t)b * W;
+    for (int w = W - 1; w >= 0; --w)
+      if (bits[w] != 0) { NT = w + 1; break; }
+  }
+  if (NT == 0) NT = 1;                          // every key masked: one tile, all scores -inf (rows come out as zeros, like the kernel above)
+  auto tile_word = [&](int t) -> uint64_t {
+    if constexpr (VARLEN) {
+      const int rem = S - t * ATT_KB;
+      return rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    } else {
+      return bits[t];
+    }
+  };
+
+  // the first Q rows of a block straight from global memory (pipe fills only: one round trip under the first tiles' DMA)
+  auto q_load_direct = [&](int j) {
+    const char* qb_base = q_set + blk_head_b(j);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int qr0 = blk_row0(j) + wave * 64 + 32 * g + ql;
+      const char* qp = qb_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[g][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+    }
+  };
+  auto mod_nt = [&](int x) { while (x >= NT) x -= NT; return x; };       // x < NT + 3
+
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // (lane constants of the fragment addresses are rebuilt from a laundered lane id where they are used, for the same reason as the pieces')
+  auto k_base_of = [&](int stage) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    return ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(smem + stage * ATT_STAGE_BYTES)) + (uint32_t)((ln & 31) * 256)) |
+           (uint32_t)((((ln >> 5) ^ (ln & 15)) & 15) << 4);
+  };
+  auto vt_lane_of = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    return (((ln & 15) >> 2) + 4 * (ln >> 5)) * V_PITCH + ((((ln >> 2) & 3) * 4) << 4) + (((ln >> 4) & 1) * 16 + 4 * (ln & 3)) * 2;
+  };
+
+  f32x16_t oacc[2][4];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    m_run[g] = -INFINITY; l_run[g] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
+  }
+
+  // K fragment reads (inline asm, counted lgkmcnt) and the four products of a k-slice: one K fragment pair feeds BOTH query groups
+#define W64_K_READ(KS)                                                                                                              \
+  do {                                                                                                                              \
+    const uint32_t ka = kbase ^ (uint32_t)((KS) << 5);                                                                              \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(kr[(KS) % 3][0]) : "v"(ka));                                                          \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(kr[(KS) % 3][1]) : "v"(ka));                                              \
+  } while (0)
+#define W64_K_MMA(KS, N)                                                                                                            \
+  do {                                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % 3][0]), "+v"(kr[(KS) % 3][1]) : : "memory");                          \
+    sacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[0][KS], (KS) == 0 ? zero16 : sacc[0][0], 0, 0, 0);     \
+    sacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[1][KS], (KS) == 0 ? zero16 : sacc[1][0], 0, 0, 0);     \
+    sacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[0][KS], (KS) == 0 ? zero16 : sacc[0][1], 0, 0, 0);     \
+    sacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[1][KS], (KS) == 0 ? zero16 : sacc[1][1], 0, 0, 0);     \
+  } while (0)
+  // QK of one tile (needs `kbase` in scope): K fragments two k-slices ahead of their products, THREE register sets (with two, the read of
+  // k-slice KS + 2 landed in the registers of k-slice KS while its four queued MFMAs had not all fetched them: garbage scores on the GPU);
+  // STEP(KS) = what rides behind k-slice KS
+#define W64_QK(STEP)                                                                                                                \
+  do {                                                                                                                              \
+    bf16x8_t kr[3][2];                                                                                                              \
+    W64_K_READ(0); W64_K_READ(1);                                                                                                   \
+    W64_K_READ(2); W64_K_MMA(0, 4); STEP(0);                                                                                        \
+    W64_K_READ(3); W64_K_MMA(1, 4); STEP(1);                                                                                        \
+    W64_K_READ(4); W64_K_MMA(2, 4); STEP(2);                                                                                        \
+    W64_K_READ(5); W64_K_MMA(3, 4); STEP(3);                                                                                        \
+    W64_K_READ(6); W64_K_MMA(4, 4); STEP(4);                                                                                        \
+    W64_K_READ(7); W64_K_MMA(5, 4); STEP(5);                                                                                        \
+    W64_K_MMA(6, 2); STEP(6);                                                                                                       \
+    W64_K_MMA(7, 0); STEP(7);                                                                                                       \
+  } while (0)
+#define W64_NOSTEP(KS) do { } while (0)
+
+  // ---- row statistics of a tile whose scores sit in the accumulator set: the scores move to arch VGPRs (`sc`, where the softmax works on
+  //      them; the set is the destination of the next QK products), masked keys become -inf, and every row learns the tile's maximum
+  //      `mt` (scaled).  Slice I = (group I >> 1, 32-key half I & 1).  Branch-free in its FAST form: the statistics of tile n + 1 are
+  //      interleaved with the second half of the PV products of tile n.
+  f32x16_t sacc[2][2];                          // ONE accumulator set for the scores ([group][32-key half]; AGPRs)
+  f32x16_t sc[2][2];                            // the softmax's copy (arch VGPRs)
+  float mxp[2], mt[2];
+#define W64_STAT_SLICE(I, WORD, FAST)                                                                                               \
+  do {                                                                                                                              \
+    constexpr int g_ = (I) >> 1, kb_ = (I) & 1;                                                                                     \
+    sc[g_][kb_] = sacc[g_][kb_];                                                                                                    \
+    asm volatile("" : "+v"(sc[g_][kb_]));                                                                                           \
+    float mx_;                                                                                                                      \
+    if (FAST) {                                                                                                                     \
+      float ma_ = fmaxf(fmaxf(sc[g_][kb_][0], sc[g_][kb_][1]), sc[g_][kb_][2]);                                                     \
+      float mb_ = fmaxf(fmaxf(sc[g_][kb_][8], sc[g_][kb_][9]), sc[g_][kb_][10]);                                                    \
+      _Pragma("unroll") for (int r = 3; r < 8; ++r) { ma_ = fmaxf(ma_, sc[g_][kb_][r]); mb_ = fmaxf(mb_, sc[g_][kb_][8 + r]); }     \
+      mx_ = fmaxf(ma_, mb_);                                                                                                        \
+    } else {                                                                                                                        \
+      const uint32_t wsel_ = kb_ ? (uint32_t)((WORD) >> (32 + 4 * hi)) : (uint32_t)((WORD) >> (4 * hi));                            \
+      mx_ = -INFINITY;                                                                                                              \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                              \
+        const int kbit = (r & 3) + 8 * (r >> 2);                                                                                    \
+        const float sv_ = ((wsel_ >> kbit) & 1u) ? sc[g_][kb_][r] : -INFINITY;                                                      \
+        sc[g_][kb_][r] = sv_;                                                                                                       \
+        mx_ = fmaxf(mx_, sv_);                                                                                                      \
+      }                                                                                                                             \
+    }                                                                                                                               \
+    mxp[g_] = kb_ ? fmaxf(mxp[g_], mx_) : mx_;                                                                                      \
+    if (kb_) {                                                                                                                      \
+      const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxp[g_]), __float_as_uint(mxp[g_]), false, false);          \
+      mt[g_] = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * scale_log2;                                                \
+    }                                                                                                                               \
+  } while (0)
+#define W64_STATS(WORD, FAST) do { W64_STAT_SLICE(0, WORD, FAST); W64_STAT_SLICE(1, WORD, FAST); W64_STAT_SLICE(2, WORD, FAST); W64_STAT_SLICE(3, WORD, FAST); } while (0)
+
+  // exponentials of one eighth of the tile's scores against the row's reference maximum: group KS >> 2, key half (KS >> 1) & 1, quarter KS & 1
+  float m_use[2], psum[2];
+  uint32_t pk8[2][2][2][4];                     // [group][32-key half][16-key quarter][packed pair]
+#define W64_PSLICE(KS)                                                                                                              \
+  do {                                                                                                                              \
+    float nm_ = -m_use[(KS) >> 2];              /* laundered HERE: otherwise hipcc hoists all 64 scale-and-subtract fmas of the tile   \
+                                                   in front of the section, where nothing covers them */                             \
+    asm volatile("" : "+v"(nm_));                                                                                                   \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                              \
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj], scale_log2, nm_));      \
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj + 1], scale_log2, nm_));  \
+      psum[(KS) >> 2] = w64_add(psum[(KS) >> 2], w64_add(p0, p1));                                                                  \
+      pk8[(KS) >> 2][((KS) >> 1) & 1][(KS) & 1][jj] = pack2bf_hw(p0, p1);                                                           \
+    }                                                                                                                               \
+  } while (0)
+
+  // O^T += V^T P^T from the V image at `vbase`, both groups on every V fragment; AFTER2 / AFTER3 = what rides behind the third / fourth quarter
+#define W64_TR_GROUP(G, BUF)                                                                                                          \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][0]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH));                \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][1]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH + 8 * V_PITCH)); \
+  }
+#define W64_TR_WAIT(N, BUF)                                                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                            \
+               : "+v"(vr[BUF][0][0]), "+v"(vr[BUF][0][1]), "+v"(vr[BUF][1][0]), "+v"(vr[BUF][1][1]), "+v"(vr[BUF][2][0]),              \
+                 "+v"(vr[BUF][2][1]), "+v"(vr[BUF][3][0]), "+v"(vr[BUF][3][1]))
+#define W64_TR_MMA(G, BUF)                                                                                                            \
+  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
+    const s16x4_t v0 = vr[BUF][db][0], v1 = vr[BUF][db][1];                                                                           \
+    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                                   \
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(pk8[g][(G) >> 1][(G) & 1][0], pk8[g][(G) >> 1][(G) & 1][1],         \
+                                                                  pk8[g][(G) >> 1][(G) & 1][2], pk8[g][(G) >> 1][(G) & 1][3]));       \
+      oacc[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[g][db], 0, 0, 0);                                            \
+    }                                                                                                                                 \
+  }
+#define W64_PV(VSTAGE, AFTER2, AFTER3)                                                                                                \
+  do {                                                                                                                                \
+    const uint32_t vbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)(smem + (VSTAGE) * ATT_STAGE_BYTES + K_LDS_BYTES)); \
+    uint32_t va[4];                                                                                                                   \
+    const int vt_lane = vt_lane_of();                                                                                                 \
+    _Pragma("unroll") for (int db = 0; db < 4; ++db) va[db] = vbase + (uint32_t)(vt_lane ^ (db << 6));                                \
+    s16x4_t vr[2][4][2];                                                                                                              \
+    W64_TR_GROUP(0, 0)                                                                                                                \
+    W64_TR_GROUP(1, 1)                                                                                                                \
+    W64_TR_WAIT(8, 0);                                                                                                                \
+    W64_TR_MMA(0, 0)                                                                                                                  \
+    W64_TR_GROUP(2, 0)                                                                                                                \
+    W64_TR_WAIT(8, 1);                                                                                                                \
+    W64_TR_MMA(1, 1)                                                                                                                  \
+    W64_TR_GROUP(3, 1)                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                \
+    W64_TR_WAIT(8, 0);                                                                                                                \
+    W64_TR_MMA(2, 0)                                                                                                                  \
+    AFTER2;                                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                \
+    W64_TR_WAIT(0, 1);                                                                                                                \
+    W64_TR_MMA(3, 1)                                                                                                                  \
+    AFTER3;                                                                                                                           \
+  } while (0)
+
+  // counted DMA wait: at most the 8 pieces of the previous iteration stay in flight (gfx9 s_waitcnt: vmcnt[3:0] = 8, expcnt / lgkmcnt "don't wait")
+#define W64_WAIT_VM8()                      \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_waitcnt(0x0F78);     \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+
+  // ---- pipe fill at a stream position whose tile is t0 (of block j) with ring index r0: K(t0), V(t0) -> stage r0; K(t0+1), V(t0+1) ->
+  //      stage r0 + 1; K(t0+2) -> K half of stage r0 + 2; the block's Q rows from global memory; QK(t0) on its own; its statistics
+  uint64_t word_cur;
+  auto prime = [&](int j, int t0, int r0) {
+    const int ta = mod_nt(t0 + 1), tb = mod_nt(t0 + 2);
+    const int r1 = r0 + 1 >= W64_STAGES ? r0 + 1 - W64_STAGES : r0 + 1, r2 = r0 + 2 >= W64_STAGES ? r0 + 2 - W64_STAGES : r0 + 2;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_piece(t0, r0, p);
+    q_load_direct(j);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage_piece(ta, r1, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) stage_piece(tb, r2, p);
+    ATT_WAIT_VM0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const uint32_t kbase = k_base_of(r0);
+      W64_QK(W64_NOSTEP);
+    }
+    W64_STATS(0ull, true);
+    word_cur = tile_word(t0);
+  };
+  if (tid == 0) *redo_flag = 0;
+  prime(j0, 0, 0);
+
+#ifdef W64_STAMPS
+  uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t st_last = __builtin_readcyclecounter();
+#endif
+  const int N = nblk * NT;                      // flat tile stream of the workgroup
+  const bool deep = NT >= 3;                    // the counted DMA wait needs the three-stage schedule (short sequences: wait for everything)
+  int t = 0, qi = 0, r = 0;                     // tile inside the block, block index (j0 + qi), ring index n % 3
+  bool skip_wait = true;                        // no DMA wait at the top right after a pipe fill / a block epilogue
+  bool unsafe = false;                          // a row's maximum left its reference maximum by more than 2^64: the block is redone (below)
+
+  for (int n = 0; n < N; ++n) {                 // (the body is written out in the loop: as a lambda that mutates t / qi / skip_wait through
+    const bool has_next = n + 1 < N;            //  reference captures hipcc kept the three in scratch memory, and every reload came with an
+    const bool last_of_block = (t + 1 == NT);   //  s_waitcnt vmcnt(0) that drained the LDS-DMA queue)
+    const bool more = qi + 1 < nblk;
+    const int jb = j0 + qi;
+    const int r1 = r + 1 >= W64_STAGES ? r + 1 - W64_STAGES : r + 1, r2 = r + 2 >= W64_STAGES ? r + 2 - W64_STAGES : r + 2;
+    W64_STAMP(5);                               // [5] block epilogue / loop overhead since the end of the previous PV
+    // K(n+1) and V(n) were requested TWO iterations ago; the 8 pieces of the previous iteration may stay in flight -- except when a Q half
+    // requested behind them is read in this iteration
+    if (!skip_wait) {
+      if (deep && !(more && last_of_block)) W64_WAIT_VM8(); else ATT_WAIT_VM0();
+    }
+    skip_wait = false;
+    W64_STAMP(0);                               // [0] the DMA wait
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    W64_STAMP(1);                               // [1] the barrier
+    // this iteration's eight pieces: K(n+3) -> K half of stage n % 3 (K(n) is dead), V(n+2) -> V half of stage (n+2) % 3 (V(n-1) is dead);
+    // past the end of the stream they re-stage tiles nobody reads
+    const int tk = mod_nt(t + 3), tv = mod_nt(t + 2), tn = (t + 1 == NT) ? 0 : t + 1;
+    const int kbuf = r, vbuf = r2;
+    // next block's Q rows: first half requested two tiles before the block ends, read after this block's last QK products
+    if (more && NT >= 3 && t + 3 == NT) q_stage_half(jb + 1, 0);
+    if (more && last_of_block) {
+      if (NT == 1) { q_stage_half(jb + 1, 0); ATT_WAIT_VM0(); q_read_half(0); q_stage_half(jb + 1, 1); ATT_WAIT_VM0(); }
+      q_read_half(1);
+    }
+    // The statistics of this tile were computed under the previous tile's PV products WITHOUT looking at the key mask (that pass has to
+    // stay free of branches to be interleaved with the products).  A tile with masked keys -- a sequence's ragged tail, a mask with holes
+    // -- redoes them here from the accumulator set, which still holds the tile's scores: a rare, wave-uniform branch.
+    {
+      int masked = __builtin_amdgcn_readfirstlane(word_cur != ~0ull ? 1 : 0);
+      asm volatile("" : "+s"(masked));
+      if (masked) W64_STATS(word_cur, false);
+    }
+    word_cur = tile_word(tn);                   // the next tile's word: a scalar load with a whole iteration of latency cover
+    // Reference maxima WITHOUT an in-loop rescale of the output accumulators (they live in AGPRs; any arch-VGPR arithmetic on them inside
+    // this loop makes hipcc copy all 128 out and back on EVERY tile: DESIGN section 8 (2)): a row adopts the first finite tile maximum it
+    // meets (everything accumulated before is exactly zero) and keeps it for the block; P = 2^(s - m) then stays below 2^64 unless a later
+    // maximum exceeds the reference by more than 64 binades -- such a block is redone with exact maxima after its last tile.
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const bool fresh = (m_run[g] == -INFINITY);
+      m_run[g] = fresh ? mt[g] : m_run[g];
+      unsafe = unsafe || (mt[g] - m_run[g] > 64.0f);
+      m_use[g] = (m_run[g] == -INFINITY) ? 0.f : m_run[g];
+    }
+    W64_STAMP(2);                               // [2] top: Q hand-over, masked redo, reference maxima
+    psum[0] = 0.f; psum[1] = 0.f;
+#define W64_PIECE(KS) do { if ((KS) < 4) stage_piece(tk, kbuf, (KS)); else stage_piece(tv, vbuf, (KS)); asm volatile("" ::: "memory"); } while (0)
+#define W64_STEP(KS) do { W64_PIECE(KS); W64_PSLICE(KS); __builtin_amdgcn_sched_barrier(0); } while (0)
+    if (has_next) {
+      // ---- ONE section: the QK products of tile n + 1, one DMA piece behind each k-slice, the exponentials of tile n between them
+      const uint32_t kbase = k_base_of(r1);
+      W64_QK(W64_STEP);
+    } else {
+      W64_PSLICE(0); W64_PSLICE(1); W64_PSLICE(2); W64_PSLICE(3); W64_PSLICE(4); W64_PSLICE(5); W64_PSLICE(6); W64_PSLICE(7);
+    }
+#undef W64_STEP
+#undef W64_PIECE
+    W64_STAMP(3);                               // [3] QK(n+1) || exponentials of tile n
+    l_run[0] += psum[0];
+    l_run[1] += psum[1];
+    // the next block's Q: this block's last QK products (tile NT - 1, issued in the iteration of tile NT - 2) have read qf
+    if (more && NT >= 2 && t + 2 == NT) {
+      if (NT == 2) { q_stage_half(jb + 1, 0); ATT_WAIT_VM0(); }
+      q_read_half(0);
+      q_stage_half(jb + 1, 1);
+    }
+    // ---- PV(n); the statistics of tile n + 1 ride on the SECOND half of the products (by then half of P and one V fragment set are dead:
+    //      the scores' arch-VGPR copy, 64 registers that live into the next iteration, does not meet them); unconditional and branch-free
+    //      (past the end of the stream they chew on stale scores and nobody looks at the result)
+    W64_PV(r, { W64_STAT_SLICE(0, 0ull, true); W64_STAT_SLICE(1, 0ull, true); }, { W64_STAT_SLICE(2, 0ull, true); W64_STAT_SLICE(3, 0ull, true); });
+    W64_STAMP(4);                               // [4] PV(n) || statistics of tile n + 1
+    r = r1;
+    if (!last_of_block) { ++t; continue; }
+
+    // ---- block end.  Everything requested during this tile is waited for BEFORE the stores go out (vmcnt counts stores; the next iteration
+    //      then starts without a DMA wait and the stores drain under it).
+    ATT_WAIT_VM0();
+    skip_wait = true;
+    // does any row of the workgroup need the block redone?  (two barriers per block; the flag lives behind the transposition buffers)
+    if (__builtin_amdgcn_ballot_w64(unsafe) != 0ull && lane == 0) *redo_flag = 1;
+    __syncthreads();                            // (fence + barrier: the flag write is visible; nothing is in flight here, the DMA queue was drained above)
+    const int redo = __builtin_amdgcn_readfirstlane(*redo_flag);
+    __syncthreads();
+    if (tid == 0) *redo_flag = 0;
+    unsafe = false;
+    if (redo) {
+      // ---- COLD: the block again with EXACT row maxima, two plain passes over its tiles through stage 0 (nothing in the ring is needed
+      //      any more: it is re-primed below); no rescale anywhere -- pass 1 finds the maxima, pass 2 accumulates against them
+      q_load_direct(jb);
+      float mx2[2] = {-INFINITY, -INFINITY};
+      for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) stage_piece(tt, 0, p);
+        ATT_WAIT_VM0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        { const uint32_t kbase = k_base_of(0); W64_QK(W64_NOSTEP); }
+        const uint64_t w_ = tile_word(tt);
+        W64_STATS(w_, false);
+        mx2[0] = fmaxf(mx2[0], mt[0]); mx2[1] = fmaxf(mx2[1], mt[1]);
+        __builtin_amdgcn_s_barrier();
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        m_run[g] = mx2[g]; l_run[g] = 0.f;
+        m_use[g] = (mx2[g] == -INFINITY) ? 0.f : mx2[g];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
+      }
+      for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) stage_piece(tt, 0, p);
+        ATT_WAIT_VM0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        { const uint32_t kbase = k_base_of(0); W64_QK(W64_NOSTEP); }
+        const uint64_t w_ = tile_word(tt);
+        W64_STATS(w_, false);
+        psum[0] = 0.f; psum[1] = 0.f;
+        W64_PSLICE(0); W64_PSLICE(1); W64_PSLICE(2); W64_PSLICE(3); W64_PSLICE(4); W64_PSLICE(5); W64_PSLICE(6); W64_PSLICE(7);
+        l_run[0] += psum[0]; l_run[1] += psum[1];
+        W64_PV(0, {}, {});
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_row = ln >> 3, x_unit = ln & 7;
+    char* ob_base = o_set + blk_head_b(jb);
+    const int h_blk = hk * gqa + jb / nqb;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
+      const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+      const int q_g0 = blk_row0(jb) + wave * 64 + 32 * g;                           // first row of the group
+      char* xg = xs + g * 4096;                                                     // 32 rows x 128 B of the wave's buffer
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        char* wp = xg + (ln & 31) * 128;
+#pragma unroll
+        for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            const int db = half * 2 + dbl;
+            float a[4], bq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[g][db][8 * gp + e] * inv_l),
+                                                               __float_as_uint(oacc[g][db][8 * gp + 4 + e] * inv_l), false, false);
+              a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
+            }
+            *reinterpret_cast<uint4*>(wp + (((dbl * 4 + gp * 2 + hi) ^ q_swz) << 4)) =
+                make_uint4(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]), pack2bf_hw(bq[0], bq[1]), pack2bf_hw(bq[2], bq[3]));
+          }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("" ::: "memory");
+        uint4 piece[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) piece[j] = *reinterpret_cast<const uint4*>(xg + j * 1024 + ln * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rr = 8 * j + x_row;
+          const int qr = q_g0 + rr;
+          if (qr < S) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int att_u32x4_t;
+            att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(ob_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((rr >> 1) & 7))) << 4)));
+            const att_u32x4_t pv = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+            *op = pv;
+          }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("" ::: "memory");
+      }
+      const int q_row = q_g0 + ql;
+      if (q_row < S && lse != nullptr && hi == 0) {
+#ifdef W64_DEBUG
+        lse[((int64_t)b * nq + h_blk) * S + q_row] = (h_blk == 0) ? l_tot : (h_blk == 1) ? l_run[g] : (h_blk == 2) ? psum[g] : m_run[g];
+#else
+        if constexpr (VARLEN) lse[(row0 + q_row) * nq + h_blk] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        else lse[((int64_t)b * nq + h_blk) * S + q_row] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+#endif
+      }
+      m_run[g] = -INFINITY; l_run[g] = 0.f;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
+    }
+    t = 0; ++qi;
+    if (redo && has_next) {                     // the redo used stage 0 and the Q registers: start the stream again at position n + 1
+      ATT_WAIT_VM0();                           // (the block's stores)
+      __builtin_amdgcn_s_barrier();
+      prime(j0 + qi, 0, r);
+    }
+  }
+#ifdef W64_STAMPS
+  if (blockIdx.x == 0 && tid == 0 && lse != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lse[i] = (float)st_acc[i];
+    lse[6] = (float)N;
+  }
+#endif
+#undef W64_WAIT_VM8
+#undef W64_PV
+#undef W64_TR_GROUP
+#undef W64_TR_WAIT
+#undef W64_TR_MMA
+#undef W64_PSLICE
+#undef W64_STATS
+#undef W64_STAT_SLICE
+#undef W64_K_READ
+#undef W64_K_MMA
+#undef W64_QK
+#undef W64_NOSTEP
+}
+
+}  // namespace grit
+
+using namespace grit;
+
+// Launch geometry: query blocks per workgroup (the K/V stream runs through the block seams, so more blocks per workgroup amortise the
+// prologue) -- as many as 4 while the launch still has >= 4 workgroups per CU-slot pair -- and the XCD-aware 1-D grid.
+// the 80 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
+template <typename KernelT>
+static void attn_lds_optin(KernelT kernel, std::atomic<uint64_t>& done, int bytes = ATT_LDS_BYTES) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
+template <bool VARLEN, bool CAUSAL>
+static void attn_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
+                        int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets,
+                        int window) {
+  static std::atomic<uint64_t> optin{0};
+  attn_lds_optin(attn_bidir_fwd_k<VARLEN, CAUSAL>, optin);
+  hipLaunchKernelGGL((attn_bidir_fwd_k<VARLEN, CAUSAL>), grid, dim3(256), ATT_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
+                     out_stride, scale_log2, qpw, ngx, n_sets, window);
+}
+
+template <bool VARLEN>
+static void attn_w64_launch(hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
+                            int B, int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2) {
+  static std::atomic<uint64_t> optin{0};
+  attn_lds_optin(attn_fwd_w64_k<VARLEN>, optin, W64_LDS_BYTES);
+  // blocks per workgroup: a whole K/V set (all heads of the GQA group x all query blocks: one cold prologue, K/V hot in L2) unless the
+  // launch would then leave CUs idle -- halve until there are two workgroups per CU or one block each
+  const int n_sets = B * nkv, nb_set = (nq / nkv) * ((S + W64_QB - 1) / W64_QB);
+  int bpw = nb_set;
+  while (bpw > 1 && (int64_t)n_sets * ((nb_set + bpw - 1) / bpw) < 512) bpw = (bpw + 1) / 2;
+  const int parts = (nb_set + bpw - 1) / bpw;
+  const unsigned grid = (unsigned)(8 * ((n_sets + 7) / 8) * parts);
+  hipLaunchKernelGGL((attn_fwd_w64_k<VARLEN>), dim3(grid), dim3(256), W64_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
+                     out_stride, scale_log2, bpw, parts, n_sets);
+}
+// which forward the bidirectional entry points launch: the 4-wave-per-workgroup / 32-rows-per-wave kernel at the top of this file (default), or
+// the W64 kernel (GRIT_ATTN_FWD=w64; read per call so that one process can time both).  W64 is bit-identical and, as measured in round 4,
+// 0.70-0.75x as fast (profiles/r04_attn_w64_ab.json, r04_attn_w64_stamps.json): it stays in the library as the
+// measured record of that structure and is held to bit equality by the GPU suite (attn_w64_equals_default).
+static bool attn_use_w64() {
+  const char* e = getenv("GRIT_ATTN_FWD");
+  return e != nullptr && e[0] == 'w';
+}
+
+struct AttnGeom {
+  int qpw, ngx, n_sets;
+  unsigned grid;
+};
+static AttnGeom attn_geom(int B, int max_len, int nq, int nkv, bool causal) {
+  const int nqb = (max_len + ATT_QB - 1) / ATT_QB;
+  static const int forced = getenv("GRIT_ATTN_QPW") ? atoi(getenv("GRIT_ATTN_QPW")) : 0;      // A/B knob
+  int qpw = 1;
+  // causal: consecutive query blocks see 2, 4, 6, ... KV tiles, so a workgroup walking 4 of them is up to 4x longer than its neighbour;
+  // 2 blocks per workgroup balance better (B 64 x S 2048: 869 -> 893 TF, profiles/r03_attn_fwd_ab_asm_reads.log)
+  for (int c = causal ? 2 : 4; c >= 1; c >>= 1)
+    if ((int64_t)B * nq * ((nqb + c - 1) / c) >= 2048 || c == 1) { qpw = c; break; }
+  if (forced > 0) qpw = forced;
+  if (qpw > nqb) qpw = nqb;
+  AttnGeom g;
+  g.qpw = qpw;
+  g.ngx = (nqb + qpw - 1) / qpw;
+  g.n_sets = B * nkv;
+  g.grid = (unsigned)(8 * ((g.n_sets + 7) / 8) * (nq / nkv) * g.ngx);
+  return g;
+}
+
+static int attn_fwd_padded(const char* name, bool causal, int window, const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
+                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(qkv && key_bits && out, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0 && S <= (1 << 30) && nq <= 65535 && nkv <= 65535, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
+  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
+  GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "%s: window=%d (>= 1 keys per query, causal attention only)", name, window);
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
+               GRIT_E_BADARG, "%s: bad strides", name);
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  GRIT_REQUIRE((int64_t)B * nq * ((S + ATT_QB - 1) / ATT_QB) < (1ll << 30), GRIT_E_UNSUPPORTED, "%s: grid too large", name);
+  GRIT_REQUIRE((int64_t)S * qkv_stride * 2 < (1ll << 31) && (int64_t)S * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
+  const AttnGeom g = attn_geom(B, S, nq, nkv, causal);
+  const dim3 grid(g.grid);
+  if (causal)
+    attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
+                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
+  else if (attn_use_w64())
+    attn_w64_launch<false>((hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, B, S, nq, nkv, qkv_stride,
+                           out_stride, scale * 1.4426950408889634f);
+  else
+    attn_launch<false, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
+                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
+  GRIT_CHECK_LAUNCH(name);
+  return GRIT_OK;
+}
+
+static int attn_fwd_varlen(const char* name, bool causal, int window, const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len,
+                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(qkv && cu_seqlens && out, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && max_len > 0 && nq > 0 && nkv > 0 && max_len <= (1 << 30) && nq <= 65535 && nkv <= 65535, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
+  GRIT_REQUIRE(nq % nkv == 0, GRIT_E_BADARG, "%s: nq=%d not a multiple of nkv=%d", name, nq, nkv);
+  GRIT_REQUIRE(window >= 0 && (causal || window == 0), GRIT_E_BADARG, "%s: window=%d (>= 1 keys per query, causal attention only)", name, window);
+  GRIT_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (int64_t)(nq + 2 * nkv) * d && out_stride % 8 == 0 && out_stride >= (int64_t)nq * d,
+               GRIT_E_BADARG, "%s: bad strides", name);
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(out), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  GRIT_REQUIRE((int64_t)B * nq * ((max_len + ATT_QB - 1) / ATT_QB) < (1ll << 30), GRIT_E_UNSUPPORTED, "%s: grid too large", name);
+  GRIT_REQUIRE((int64_t)max_len * qkv_stride * 2 < (1ll << 31) && (int64_t)max_len * out_stride * 2 < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
+  const AttnGeom g = attn_geom(B, max_len, nq, nkv, causal);
+  const dim3 grid(g.grid);
+  if (causal)
+    attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
+                            out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
+  else if (attn_use_w64())
+    attn_w64_launch<true>((hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, B, max_len, nq, nkv, qkv_stride,
+                          out_stride, scale * 1.4426950408889634f);
+  else
+    attn_launch<true, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
+                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
+  GRIT_CHECK_LAUNCH(name);
+  return GRIT_OK;
+}
+
+extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                   int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_padded("grit_attn_bidir_fwd", false, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+extern "C" int grit_attn_causal_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_padded("grit_attn_causal_fwd", true, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+extern "C" int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                          int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_varlen("grit_attn_bidir_varlen_fwd", false, 0, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream);
+}
+extern "C" int grit_attn_causal_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                           int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_varlen("grit_attn_causal_varlen_fwd", true, 0, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream);
+}
+
+// Sliding-window causal attention: query q sees keys q - window + 1 .. q (window >= 1; window >= S is plain causal attention).
+extern "C" int grit_attn_causal_window_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                           int d, int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream) {
+  GRIT_REQUIRE(window >= 1, GRIT_E_BADARG, "grit_attn_causal_window_fwd: window=%d must be >= 1", window);
+  return attn_fwd_padded("grit_attn_causal_window_fwd", true, window, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream);
+}
+extern "C" int grit_attn_causal_window_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                                  int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, int window,
+                                                  void* stream) {
+  GRIT_REQUIRE(window >= 1, GRIT_E_BADARG, "grit_attn_causal_window_varlen_fwd: window=%d must be >= 1", window);
+  return attn_fwd_varlen("grit_attn_causal_window_varlen_fwd", true, window, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride,
+                         out_stride, scale, stream);
+}
