@@ -572,6 +572,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 // products, the per-row deferred rescale) is that of the kernel above (tools/attn_w64_ab.py), packed == padded.
 // a + b as ONE v_add_f32: under plain -O3 hipcc SLP-packs the row-sum adds of neighbouring scores into v_pk_add_f32, which beside MFMAs costs
 // more than the two scalar adds it replaces (guide: 'packed f32 VALU ... an anti-lever beside MFMAs'); same IEEE sum, same bits
+// CAUTION (found with the no-rescale variant of this kernel): hipcc does not know that this asm statement is a VALU
+// instruction, so it does not keep the distance to a preceding v_exp_f32 that the transcendental unit needs -- in another schedule of the
+// same source 8 of 64 lanes read the exponentials' INPUTS.  In THIS build the schedule is safe (bit-identical to the default kernel on
+// every shape of the harness), and the GPU suite's attn_w64_equals_default re-checks that for every build of the library.
 __device__ __forceinline__ float w64_add(float a, float b) {
   float r;
   asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
