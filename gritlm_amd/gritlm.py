@@ -190,14 +190,16 @@ class GritLM(torch.nn.Module):
         size = -(-n_rows // n_parts) if n_rows else 0
         return [(s, min(s + size, n_rows)) for s in range(0, n_rows, size)] if size else []
 
-    def _encode_native(self, inputs, n_instr):
-        """One tokenised batch (HOST tensors) through the native engine(s): pooled, normalised rows [B, H] fp32 on the first engine's device."""
+    def _encode_native(self, inputs, n_instr, normalize=None):
+        """One tokenised batch (HOST tensors) through the native engine(s): pooled (and, by default, normalised) rows [B, H] fp32 on the first
+        engine's device."""
+        normalize = bool(self.normalized) if normalize is None else bool(normalize)
         engines = getattr(self, "engines", None) or [self.engine]
         ids, mask = inputs["input_ids"], inputs["attention_mask"]
         parts = []
         for eng, (a, b) in zip(engines, self._row_chunks(ids.shape[0], len(engines))):
             il = None if n_instr is None else torch.full((b - a,), n_instr, dtype=torch.int32, device=eng.device)
-            parts.append(eng.encode_pooled(ids[a:b], mask[a:b], self.pooling_method, bool(self.normalized), il))
+            parts.append(eng.encode_pooled(ids[a:b], mask[a:b], self.pooling_method, normalize, il))
         if len(parts) == 1:
             return parts[0]
         return torch.cat([p.to(engines[0].device, non_blocking=True) for p in parts], dim=0)
@@ -280,9 +282,14 @@ class GritLM(torch.nn.Module):
             if self.engine is not None and not get_cache and self.projection is None and self.pooling_method in POOL_MODES:
                 # native fast path: the tokenizer's HOST tensors go straight to the engine(s) -- padding dropped before the first kernel,
                 # pool + normalise fused, no device synchronisation per batch (engine.encode_pooled)
-                emb = self._encode_native(inputs, n_instr)
                 if recast or self.pooling_method == "cls":
-                    emb = emb.to(self.model.dtype)
+                    # the reference's order (gritlm.py:154-158): the pooled rows go back to the model dtype FIRST ('cls' never leaves it,
+                    # :188) and are normalised in that dtype
+                    emb = self._encode_native(inputs, n_instr, normalize=False).to(self.model.dtype)
+                    if self.normalized:
+                        emb = torch.nn.functional.normalize(emb, dim=-1).to(emb.dtype)
+                else:
+                    emb = self._encode_native(inputs, n_instr)
                 chunks.append(emb)
                 continue
             inputs = inputs.to(self.device)

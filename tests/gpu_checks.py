@@ -1132,40 +1132,50 @@ def check_gritlm_api_variants():
     det, ok = {}, True
     with tempfile.TemporaryDirectory() as td:
         d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        d32 = synth.build_mistral_dir(os.path.join(td, "m32"), "tiny", 0, "float32")
         nat = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16)
         hf = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, native=False)
-        ok &= nat.engine is not None and hf.engine is None
+        f32m = GritLM(d32, pooling_method="mean", attn="bbcc", device="cuda", native=False)          # the same wrapper in fp32: the truth
+        ok &= nat.engine is not None and hf.engine is None and f32m.engine is None
         eos = nat.tokenizer.eos_token or ""
+        cosd = lambda x, y: float(np.max(1 - np.sum(x * y, axis=-1) / (np.linalg.norm(x, axis=-1) * np.linalg.norm(y, axis=-1))))
 
         def cmp(tag, **kw):
+            """Averaging poolings: the two bf16 paths within 1e-4 of each other.  Single-token poolings ('cls', 'lasttoken'; also everything
+            that is rounded to bf16 before the normalisation) carry ONE token's bf16 noise un-averaged -- the BOS position of this model is
+            4e-3 from fp32 in the Hugging Face module's own bf16 run -- so there the native path is held to the fp32 run of the wrapper: no
+            further from it than 1.5x the Hugging Face bf16 path is (+ 1e-5)."""
             nonlocal ok
-            a, b = nat.encode(sents, batch_size=5, **kw), hf.encode(sents, batch_size=5, **kw)
+            for m_ in (nat, hf, f32m):
+                m_.pooling_method, m_.normalized, m_.embed_eos = nat.pooling_method, nat.normalized, nat.embed_eos
+            a, b, c = (m_.encode(sents, batch_size=5, **kw) for m_ in (nat, hf, f32m))
             same_kind = type(a) is type(b) and a.shape == b.shape and a.dtype == b.dtype
-            af = a.float().cpu().numpy() if torch.is_tensor(a) else a
-            bf_ = b.float().cpu().numpy() if torch.is_tensor(b) else b
-            if nat.normalized:
-                d = float(np.max(1 - np.sum(af * bf_, axis=-1)))
-            else:
-                d = float(np.max(1 - np.sum(af * bf_, axis=-1) / (np.linalg.norm(af, axis=-1) * np.linalg.norm(bf_, axis=-1))))
+            af, bf_, cf = (x.float().cpu().numpy() if torch.is_tensor(x) else x for x in (a, b, c))
+            d, d_nat, d_hf = cosd(af, bf_), cosd(af, cf), cosd(bf_, cf)
             det[tag] = d
-            ok &= bool(same_kind) and d < 1e-4 and bool(np.isfinite(af).all())
+            single = nat.pooling_method in ("cls", "lasttoken") or kw.get("recast")
+            if single:
+                det[tag + "_vs_fp32"], det[tag + "_hf_vs_fp32"] = d_nat, d_hf
+            ok &= bool(same_kind) and bool(np.isfinite(af).all()) and ((d_nat <= 1.5 * d_hf + 1e-5) if single else d < 1e-4)
 
         for method in ("mean", "weightedmean", "lasttoken", "cls"):
-            nat.pooling_method = hf.pooling_method = method
+            nat.pooling_method = method
             cmp(f"{method}", max_length=64)
             cmp(f"{method}_instr", max_length=64, instruction=instr)
-        nat.pooling_method = hf.pooling_method = "mean"
+        nat.pooling_method = "mean"
         cmp("recast_tensor", max_length=64, recast=True, convert_to_tensor=True)
         cmp("truncated_under_instruction", max_length=12, instruction=instr)
         cmp("no_special_tokens", max_length=64, add_special_tokens=False)
         cmp("embed_instruction", max_length=64, instruction=instr, embed_instruction=True)
         if eos and eos in nat.tokenizer.vocab:
-            nat.embed_eos = hf.embed_eos = eos
+            nat.embed_eos = eos
             cmp("embed_eos", max_length=64)
-            nat.embed_eos = hf.embed_eos = ""
-        nat.normalized = hf.normalized = False
+            nat.embed_eos = ""
+        nat.normalized = False
         cmp("not_normalized", max_length=64)
-        nat.normalized = hf.normalized = True
+        nat.normalized = True
+        for m_ in (hf, f32m):
+            m_.pooling_method, m_.normalized, m_.embed_eos = nat.pooling_method, nat.normalized, nat.embed_eos
         one_n, one_h = nat.encode(sents[3], max_length=64), hf.encode(sents[3], max_length=64)
         ok &= one_n.shape == one_h.shape == (256,) and float(1 - np.sum(one_n * one_h)) < 1e-4
         docs = [{"title": "T " + s[:10], "text": s} if i % 2 else {"text": s} for i, s in enumerate(sents)]
