@@ -104,6 +104,34 @@ __device__ __forceinline__ int wrow_of(int wc, int j) {
     __builtin_amdgcn_s_barrier();            \
     GRIT_SEG_FENCE();                        \
   } while (0)
+// K-loop barriers.  Default (round 2/3): two per phase -- load segment | B | 16 MFMAs | B -- with the second wave group one barrier
+// behind, so every barrier interval has one group in its MFMAs and the other in its load segment.  -DGRIT_GEMM_BAR1: ONE per phase,
+// group 0 takes it in FRONT of its MFMAs and group 1 BEHIND them:
+//     group 0:  L(p) | B(p) | M(p)  L(p+1) | B(p+1) | ...          group 1:  L(p) M(p) | B(p) | L(p+1) M(p+1) | B(p+1) | ...
+// so in every interval group 0's MFMAs still sit beside group 1's load segment and the other way round, but the matrix pipe changes
+// hands at a barrier only every other time (the mid-interval hand-over needs no rendezvous).  The hazards hold unchanged: what L(p)
+// reads was waited for by every wave (counted vmcnt at the end of its L(p-1)) in front of B(p-1), and L(p) runs behind B(p-1) in both
+// groups; a slot's last reads (phase q) are complete (lgkmcnt(0) at the top of M(q)) in front of B(q+1) in both groups, and the DMA
+// that refills it is issued in L(p), p >= q + 2, behind B(p-1).
+#ifdef GRIT_GEMM_BAR1
+#define GRIT_BAR_PRE()                                 \
+  do {                                                 \
+    GRIT_SEG_FENCE();                                  \
+    if (wr == 0) __builtin_amdgcn_s_barrier();         \
+    GRIT_SEG_FENCE();                                  \
+  } while (0)
+#define GRIT_BAR_POST()                                \
+  do {                                                 \
+    GRIT_SEG_FENCE();                                  \
+    if (wr == 1) __builtin_amdgcn_s_barrier();         \
+    GRIT_SEG_FENCE();                                  \
+  } while (0)
+#define GRIT_STAGGER(G) do { } while (0)
+#else
+#define GRIT_BAR_PRE() GRIT_BARRIER()
+#define GRIT_BAR_POST() GRIT_BARRIER()
+#define GRIT_STAGGER(G) do { if (wr == (G)) GRIT_BARRIER(); } while (0)
+#endif
 
 // A/B builds only (tools/ubench): -DGRIT_SWIGLU_BWD_DIRECT keeps the direct (row-per-lane) epilogue for SWIGLU_BWD
 #ifdef GRIT_SWIGLU_BWD_DIRECT
@@ -341,6 +369,45 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
       xf[ii][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
+// The barrier BEHIND an MFMA segment is executed GRIT_GEMM_BAR_EARLY products before the segment's end (round 4; default 1, i.e. in
+// front of the LAST product).  That barrier only hands the matrix pipe to the other wave group -- this wave's LDS reads completed at
+// the top of the segment and the products touch registers only, so every hazard rule above holds with the barrier anywhere inside the
+// segment -- and the other group's wake-up (barrier release -> lgkmcnt(0) -> s_setprio -> first v_mfma) now overlaps this group's last
+// product instead of following it.  Same-box interleaved A/B against the barrier behind the segment (-DGRIT_GEMM_BAR_EARLY=0), outputs
+// bit-identical on all 29 harness cases: q|k|v (RoPE) 1.024-1.025x, o_proj 1.020-1.026x, gate|up 1.010x, down 1.012-1.016x on two boxes;
+// 2 products early 0.92-0.94x (the two groups' products interleave and the finishing wave's load segment starts late; with the tail at
+// s_setprio 3: 1.006-1.018x), 3: 1.00-1.01x, 6: 0.97-0.99x.  The opposite change -- ONE barrier per phase, group 0 in front of its
+// products and group 1 behind them (-DGRIT_GEMM_BAR1) -- is 0.964-0.988x: without the mid-interval rendezvous a group that finishes its
+// load segment early issues its products BESIDE the other group's, and the pipe then idles at the end of the interval while the
+// other group loads alone.  profiles/r04_gemm_barrier_ab.log.
+#ifndef GRIT_GEMM_BAR_EARLY
+#define GRIT_GEMM_BAR_EARLY 1
+#endif
+#if GRIT_GEMM_BAR_EARLY > 0 && !defined(GRIT_GEMM_BAR1)
+#ifdef GRIT_GEMM_BAR_TAILPRIO
+#define GRIT_TAIL_PRIO() __builtin_amdgcn_s_setprio(GRIT_GEMM_BAR_TAILPRIO)
+#else
+#define GRIT_TAIL_PRIO() do { } while (0)
+#endif
+#define GRIT_MMA(WF, I0, J0)                                                                          \
+  do {                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                               \
+      const int ks = q_ >> 3, ii = (q_ >> 1) & 3, jj = q_ & 1;                                        \
+      acc[(I0) + ii][(J0) + jj] =                                                                     \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj], 0, 0, 0); \
+      if (q_ == 15 - (GRIT_GEMM_BAR_EARLY)) {                                                         \
+        GRIT_BARRIER();                                                                               \
+        GRIT_TAIL_PRIO();                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+  } while (0)
+#undef GRIT_BAR_POST
+#define GRIT_BAR_POST() GRIT_SEG_FENCE()
+#else
 #define GRIT_MMA(WF, I0, J0)                                                                          \
   do {                                                                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
@@ -353,11 +420,21 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                    \
   } while (0)
+#endif
   // load segment: the LDS reads are issued ahead of the two LDS-DMA instructions, then the counted wait:
   // vmcnt(8) = "all but the 4 newest half-tiles have landed"
   // WAIT: 1 = the counted wait; 2 = drain; 3 = the counted wait unless `skip_waits` (a wave-uniform run-time flag: ONE copy of the
   // first K-tile's code serves the first tile of a workgroup and the tiles that follow an epilogue -- two copies made hipcc spill a
   // fragment at their join, and a spill reload inside the K loop is a vmcnt(0))
+#ifdef GRIT_GEMM_LGKM_PRE   /* A/B: the fragment reads are waited for (and the priority raised) in FRONT of the barrier that starts the MFMA segment */
+#define GRIT_LSEG_TAIL()                                         \
+  do {                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_s_setprio(1);                               \
+  } while (0)
+#else
+#define GRIT_LSEG_TAIL() do { } while (0)
+#endif
 #define GRIT_LSEG_END(NREADS, WAIT)                                                                   \
   do {                                                                                                \
     __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);                                           \
@@ -365,6 +442,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     if constexpr ((WAIT) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                       \
     if constexpr ((WAIT) == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
     if constexpr ((WAIT) == 3) { if (!skip_waits) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }  \
+    GRIT_LSEG_TAIL();                                                                                 \
   } while (0)
 
   // One K-tile = 4 phases, one output quadrant (16 MFMAs) each.  Half-tile stream (issue order):
@@ -392,33 +470,33 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     stage(3, BUF ^ 1, k31);
     GRIT_PREFETCH_OFF(1);
     GRIT_LSEG_END(8, WAIT);           // W_h1(t) landed (read in phase 2)
-    GRIT_BARRIER();
+    GRIT_BAR_PRE();
     GRIT_MMA(wf0[BUF], 0, 0);
-    GRIT_BARRIER();
+    GRIT_BAR_POST();
     // phase 2: quadrant (A_h0, W_h1)
     GRIT_READ_W(wf1, 1, sb);
     stage(1, BUF ^ 1, k31);
     GRIT_PREFETCH_OFF(2);
     GRIT_LSEG_END(4, WAIT);           // A_h1(t) landed (read in phase 3)
-    GRIT_BARRIER();
+    GRIT_BAR_PRE();
     GRIT_MMA(wf1, 0, 2);
-    GRIT_BARRIER();
+    GRIT_BAR_POST();
     // phase 3: quadrant (A_h1, W_h1)
     GRIT_READ_X(1, sb);
     stage(2, BUF, k20);
     GRIT_PREFETCH_OFF(0);
     GRIT_LSEG_END(8, WAIT);           // W_h0(t+1) landed (read in phase 4)
-    GRIT_BARRIER();
+    GRIT_BAR_PRE();
     GRIT_MMA(wf1, 4, 2);
-    GRIT_BARRIER();
+    GRIT_BAR_POST();
     // phase 4: quadrant (A_h1, W_h0); W_h0 of the next K-tile -> the other buffer's fragment registers
     if constexpr (POS != 2) GRIT_READ_W(wf0[BUF ^ 1], 0, sbn);
     stage(0, BUF, k20);
     GRIT_PREFETCH_OFF(3);
     GRIT_LSEG_END(POS == 2 ? 0 : 4, POS == 2 ? 2 : WAIT);      // A_h0(t+1) landed (read in phase 1 of the next K-tile)
-    GRIT_BARRIER();
+    GRIT_BAR_PRE();
     GRIT_MMA(wf0[BUF], 4, 0);
-    GRIT_BARRIER();
+    GRIT_BAR_POST();
   };
   const std::integral_constant<int, 0> B0{};
   const std::integral_constant<int, 1> B1{};
@@ -439,7 +517,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // W_h0(0), A_h0(0)
   GRIT_BARRIER();
   GRIT_READ_W(wf0[0], 0, smem);
-  if (wr == 1) GRIT_BARRIER();        // the second wave group runs one barrier behind the first
+  GRIT_STAGGER(1);                    // the second wave group runs one barrier behind the first (BAR1: no stagger in the count)
 
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
   auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
@@ -796,7 +874,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       ktile(kclamp(kt + 1), kclamp(kt + 2), B0, MID);
       if (kt + 1 < nk) ktile(kclamp(kt + 2), kclamp(kt + 3), B1, MID);
     }
-    if (wr == 0) GRIT_BARRIER();        // barrier counts of the two groups match again
+    GRIT_STAGGER(0);                    // barrier counts of the two groups match again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must land before the LDS is released
     GRIT_SEG_FENCE();
     if constexpr (LDS_EPI) {
@@ -851,7 +929,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       // phase for the other one's last MFMAs) so that both run their epilogues at the same time -- left staggered, each group sat at
       // its next barrier for the whole length of the other group's epilogue (stamped: 2 x 4.3 k cycles per tile with the plain-store
       // epilogue, 2 x 13 k with the residual one) -- and the stagger is re-established in front of the next tile.
-      if (wr == 0) GRIT_BARRIER();
+      GRIT_STAGGER(0);
       if (tid == 0 && more) draw(tile_no & 1);             // queue position of the tile after the next one (this tile's slot is free)
       if constexpr (LDS_EPI) {
         // (the groups are in step: every wave has passed the last barrier of the last K-tile, so every read of the A_h1 / W_h1 slots of
@@ -866,7 +944,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       lane_consts();
       zero_acc();
       GRIT_READ_W(wf0[0], 0, smem);                        // W_h0(0) of the next tile: landed before the last K-tile's final wait
-      if (wr == 1) GRIT_BARRIER();                         // one barrier behind again
+      GRIT_STAGGER(1);                                     // one barrier behind again
       vtile = vnext; m0 = m0n; M = Mn; W = Wn; n0 = n0n; ++tile_no; skip_waits = true;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
