@@ -2110,6 +2110,50 @@ def check_knn_topk(Q=5, N=10000, H=256, k=10, transposed=False):
     return _res(f"knn_topk[Q={Q},N={N},H={H},k={k},transposed={transposed}]", bool(ok), max_score_err=float(np.max(np.abs(sc - ref_sc))))
 
 
+def check_rag_distributed_index():
+    """gritlm_amd.rag.DistributedIndex on the GPU (grit_knn_topk) against the REFERENCE's rag/index.py on the same saved index
+    (tests/golden/rag_index/: three shard files written by the reference's save_index, its search_knn result on four queries): the same
+    passages in the same order, scores to 1e-5; in-place column fill as rag/eval.py:145 does it; save -> load round trip on the GPU; a bf16
+    index; topk larger than the index."""
+    import json
+    import tempfile
+    from gritlm_amd import rag
+    gold = os.path.join(GOLDEN, "rag_index")
+    exp = json.load(open(os.path.join(gold, "expected.json")))
+    idx = rag.DistributedIndex()
+    idx.load_index(gold, exp["shards"])
+    ok = idx.is_in_gpu and idx.embeddings.is_cuda and idx.embeddings.shape == (exp["dim"], exp["n_passages"])
+    q = torch.tensor(exp["queries"], device=DEV)
+    docs, scores = idx.search_knn(q, exp["topk"])
+    ok &= [[d["id"] for d in row] for row in docs] == exp["docs_ids"]
+    err = float((torch.tensor(scores) - torch.tensor(exp["scores"])).abs().max())
+    ok &= err < 1e-5
+    # built the way rag/eval.py builds it: zero matrix, encode() output transposed into column blocks
+    passages = [p for p in exp["loaded"] if p is not None]
+    built = rag.DistributedIndex()
+    built.init_embeddings(passages, exp["dim"])
+    emb_rows = torch.tensor(exp["embeddings"], device=DEV).t().contiguous()          # [N, dim] as encode_corpus returns it
+    built.embeddings[:, 0:4] = emb_rows[0:4].T.to(built.dtype)
+    built.embeddings[:, 4:] = emb_rows[4:].T.to(built.dtype)
+    docs2, scores2 = built.search_knn(q.cpu(), exp["topk"])                           # host queries are moved to the index
+    ok &= [[d["id"] for d in row] for row in docs2] == exp["docs_ids"] and scores2 == scores
+    with tempfile.TemporaryDirectory() as td:
+        built.save_index(td, 2)
+        back = rag.DistributedIndex()
+        back.load_index(td, 2)
+        ok &= bool(torch.equal(back.embeddings, built.embeddings)) and back.doc_map == built.doc_map
+    everything, sc_all = built.search_knn(q, 64)
+    ok &= all(len(r) == len(passages) for r in everything) and all(r == sorted(r, reverse=True) for r in sc_all)
+    half = rag.DistributedIndex(dtype=torch.bfloat16)
+    half.init_embeddings(passages, exp["dim"])
+    half.embeddings[:, :] = emb_rows.T.to(torch.bfloat16)
+    d16, s16 = half.search_knn(q, 1)
+    ref16 = (q @ half.embeddings.float()).cpu()
+    ok &= [r[0]["id"] for r in d16] == [passages[int(c)]["id"] for c in ref16.argmax(dim=1)]
+    ok &= float((torch.tensor(s16)[:, 0] - ref16.max(dim=1).values).abs().max()) < 1e-5
+    return _res("rag_distributed_index", bool(ok), max_score_err_vs_reference=err)
+
+
 def check_cli_native(arch="mistral"):
     """python -m gritlm.training.run on the GPU: bf16 tiny Mistral (or Mixtral), (instruction, text) rows, GradCache switch, native engine."""
     import json
@@ -2628,6 +2672,7 @@ ALL_CHECKS = [
     ("knn_topk_small", check_knn_topk, dict(Q=2, N=37, H=64, k=37)),
     ("knn_topk_transposed_odd", check_knn_topk, dict(Q=33, N=4099, H=68, k=5, transposed=True)),    # [H,N] index, N % 4 != 0, 64 x 64 tiles
     ("knn_topk_q32", check_knn_topk, dict(Q=32, N=70000, H=128, k=10)),                              # the 32 x 128 tile on a long index
+    ("rag_distributed_index", check_rag_distributed_index, {}),
     ("cli_native", check_cli_native, {}),
     ("cli_native_mixtral", check_cli_native, dict(arch="mixtral")),
     ("cli_unified_native", check_cli_unified_native, {}),
