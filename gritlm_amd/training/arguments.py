@@ -48,3 +48,6 @@ class CustomTrainingArguments(TrainingArguments):
     split_emb_full: bool = field(default=False)
     emb_q_only: bool = field(default=False)
     emb_p_only: bool = field(default=False)
+    shard_optimizer: bool = field(default=False, metadata={"help": "(not a reference flag) AdamW state sharded over the data-parallel ranks: every "
+                                  "parameter has one owner rank that updates and broadcasts it (training/sharded_optim.py); what the "
+                                  "reference's FSDP configs buy for the 8x7B model, with whole bf16 replicas kept for the kernels"})

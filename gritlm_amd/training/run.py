@@ -53,7 +53,8 @@ def main(argv=None):
     bad = [k for k, v in unsupported.items() if v]
     if bad:
         raise NotImplementedError(f"{', '.join(bad)}: accepted by the reference's gritlm.training.run, not implemented by the MI355X-native "
-                                  f"entry point (full-parameter data-parallel training only)")
+                                  f"entry point (full-parameter data-parallel training only; --shard_optimizer shards the AdamW state "
+                                  f"over the ranks where the reference's configs use FSDP)")
 
     # GradCache switch, run.py:93-104: accumulation steps become chunks of one large contrastive batch
     gc_chunk = None
@@ -108,8 +109,16 @@ def main(argv=None):
     for p_ in model.parameters():                   # backbone AND the optional --projection head (the reference optimises model.parameters())
         if p_.requires_grad and id(p_) not in seen:
             seen.add(id(p_)); params.append(p_)
-    opt = torch.optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, betas=(args.adam_beta1, args.adam_beta2),
-                            eps=args.adam_epsilon)
+    sharded = bool(args.shard_optimizer) and world > 1
+    if sharded:        # ZeRO-1: AdamW's moments live on ONE rank per parameter; the owner updates and broadcasts (sharded_optim.py)
+        from .sharded_optim import ShardedAdamW
+        opt = ShardedAdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, betas=(args.adam_beta1, args.adam_beta2),
+                           eps=args.adam_epsilon)
+        logger.info("optimizer state sharded over %d ranks: this rank owns %.1f M of %.1f M parameter elements", world,
+                    opt.owned_elements() / 1e6, sum(p_.numel() for p_ in params) / 1e6)
+    else:
+        opt = torch.optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, betas=(args.adam_beta1, args.adam_beta2),
+                                eps=args.adam_epsilon)
     bs = args.per_device_train_batch_size
     if gen_bs is not None:
         assert bs >= gen_bs and bs % gen_bs == 0, "Full batch size must be divisible by the generative batch size"
@@ -117,7 +126,8 @@ def main(argv=None):
     micro_per_epoch = max(n_items // (bs * world), 1)
     steps_per_epoch = max(micro_per_epoch // gas, 1)                 # one optimizer step per `gas` micro-batches
     total = args.max_steps if args.max_steps > 0 else int(steps_per_epoch * args.num_train_epochs)
-    sched = get_scheduler(args.lr_scheduler_type, opt, num_warmup_steps=args.get_warmup_steps(total), num_training_steps=total)
+    sched = get_scheduler(args.lr_scheduler_type, opt.local if sharded else opt, num_warmup_steps=args.get_warmup_steps(total),
+                          num_training_steps=total)
     gc = GradCacheStep(model, gc_chunk) if gc_chunk else None
 
     def save_checkpoint(step_):
@@ -127,7 +137,8 @@ def main(argv=None):
             model.model.save_pretrained(ck, safe_serialization=args.save_safetensors)
             if model.projection is not None:
                 torch.save(model.projection.state_dict(), os.path.join(ck, "projection.pt"))
-            torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
+            if not sharded:
+                torch.save(opt.state_dict(), os.path.join(ck, "optimizer.pt"))
             torch.save(sched.state_dict(), os.path.join(ck, "scheduler.pt"))
             with open(os.path.join(ck, "trainer_state.json"), "w") as f:
                 json.dump({"global_step": step_, "micro_batches_done": step_ * gas, "world_size": world}, f)
@@ -139,6 +150,8 @@ def main(argv=None):
         cuda_state = torch.cuda.get_rng_state(torch.device(device)) if torch.device(device).type == "cuda" else None
         torch.save({"cpu": torch.get_rng_state(), "cuda": cuda_state},
                    os.path.join(ck, "rng_state.pth" if world == 1 else f"rng_state_{rank}.pth"))
+        if sharded:                         # one optimizer file per rank: the moments of the parameters it owns
+            torch.save(opt.state_dict(), os.path.join(ck, f"optimizer_shard_{rank}.pt"))
         if dist.is_initialized():
             dist.barrier()
 
@@ -172,7 +185,15 @@ def main(argv=None):
                     own[k_].copy_(v_.to(own[k_].dtype))
         if model.projection is not None:
             model.projection.load_state_dict(torch.load(os.path.join(ck, "projection.pt"), map_location=device))
-        opt.load_state_dict(torch.load(os.path.join(ck, "optimizer.pt"), map_location=device))
+        if sharded:
+            shard_path = os.path.join(ck, f"optimizer_shard_{rank}.pt")
+            if not os.path.exists(shard_path):
+                raise ValueError(f"{ck} holds no optimizer shard for rank {rank}: it was written without --shard_optimizer or by another world size")
+            opt.load_state_dict(torch.load(shard_path, map_location=device))
+        else:
+            if not os.path.exists(os.path.join(ck, "optimizer.pt")):
+                raise ValueError(f"{ck} holds no optimizer.pt (written with --shard_optimizer?): resume with the same flag and world size")
+            opt.load_state_dict(torch.load(os.path.join(ck, "optimizer.pt"), map_location=device))
         sched.load_state_dict(torch.load(os.path.join(ck, "scheduler.pt")))
         step, micro_done = int(st["global_step"]), int(st["micro_batches_done"])
         rng_path = os.path.join(ck, "rng_state.pth" if world == 1 else f"rng_state_{rank}.pth")
