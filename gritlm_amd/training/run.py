@@ -15,6 +15,7 @@ from __future__ import annotations
 import json
 import logging
 import os
+import random
 import time
 
 import torch
@@ -22,7 +23,7 @@ import torch.distributed as dist
 from transformers import AutoTokenizer, HfArgumentParser, get_scheduler, set_seed
 
 from .arguments import CustomTrainingArguments, DataArguments, ModelArguments
-from .data import EmbeddingCollator, EmbeddingDataset, GenerativeCollator, load_embedding_rows, load_generative_rows
+from .data import EmbeddingCollator, EmbeddingDataset, GenerativeCollator, ItemPicker, deal_to_rank, load_datasets, multi_dataset_order, pick_items
 from .gradcache import split_inputs
 from .gradcache import GradCacheStep, sync_gradients
 from .model import GritLMTrainModel
@@ -47,8 +48,7 @@ def main(argv=None):
     set_seed(args.seed)
 
     # flags of the reference CLI that this entry point does not implement must fail loudly, not train something else
-    unsupported = {"--lora": args.lora, "--qlora": args.qlora, "--num_samples": data_args.num_samples is not None,
-                   "--use_unique_indices": data_args.use_unique_indices, "--split_emb_full": args.split_emb_full,
+    unsupported = {"--lora": args.lora, "--qlora": args.qlora, "--split_emb_full": args.split_emb_full,
                    "--deepspeed": bool(getattr(args, "deepspeed", None)), "--fsdp": bool(getattr(args, "fsdp", None))}
     bad = [k for k, v in unsupported.items() if v]
     if bad:
@@ -75,16 +75,27 @@ def main(argv=None):
         tok.pad_token = tok.bos_token          # training pads with BOS (run.py:118-120), inference with EOS
 
     do_emb, do_gen = args.mode in ("embedding", "unified"), args.mode in ("unified", "generative")
-    rows = load_embedding_rows(data_args.train_data, data_args.max_example_num_per_dataset) if do_emb else []
-    gen_rows = load_generative_rows(data_args.train_data, data_args.max_example_num_per_dataset) if do_gen else []
+    # one data set per file (run.py:122-204): subsample / too-long-instruction filter / --num_samples cap per file, rows kept per file
+    # -> dataset_num_samples.json; several embedding files -> global batches drawn from ONE file each (CustomRandomSampler)
+    num_samples = None
+    if data_args.num_samples:
+        with open(data_args.num_samples) as f:
+            num_samples = json.load(f)
+    emb_sets, gen_sets, kept = load_datasets(data_args.train_data, args.mode, tok, data_args.query_max_len, data_args.passage_max_len,
+                                             data_args.generative_max_len, data_args.max_example_num_per_dataset, num_samples)
+    rows = [r for _, rs in emb_sets for r in rs] if do_emb else []
+    gen_rows = [t for _, ts in gen_sets for t in ts] if do_gen else []
+    ds_lens = [len(rs) for _, rs in emb_sets] if do_emb else []
+    if do_emb and not rows:
+        raise ValueError(f"--mode {args.mode} needs rows with a 'query' field in {data_args.train_data} (after the instruction-length filter)")
     if do_gen and not gen_rows:
         raise ValueError(f"--mode {args.mode} needs rows with a 'text' field in {data_args.train_data}")
-    if do_gen and isinstance(gen_rows[0], (tuple, list)):       # too long instructions leave nothing to learn from (run.py:166-176)
-        gen_rows = [r for r in gen_rows if len(tok.tokenize("<|user|>\n" + r[0] + "\n<|assistant|>\n")) < data_args.generative_max_len]
+    if len(ds_lens) > 1 and not args.dataloader_drop_last:       # run.py:334
+        raise AssertionError("Multiple datasets are only supported with dropping the last incomplete batch, set `--dataloader_drop_last`")
     os.makedirs(args.output_dir, exist_ok=True)
     if rank == 0:
         with open(os.path.join(args.output_dir, "dataset_num_samples.json"), "w") as f:
-            json.dump({os.path.basename(data_args.train_data.rstrip("/")): len(rows) + len(gen_rows)}, f)
+            json.dump(kept, f)
     max_len = max(data_args.query_max_len or 0, data_args.passage_max_len or 0, data_args.generative_max_len or 0)
     ds = EmbeddingDataset(rows, data_args.train_group_size, max_char_len=max_len * 10, seed=args.seed + rank) if do_emb else None
     collate = EmbeddingCollator(tok, data_args.query_max_len, data_args.passage_max_len)
@@ -213,16 +224,31 @@ def main(argv=None):
     t0, step0 = time.time(), step
     micro, skip = 0, micro_done                                      # resume: replay the permutations, skip the consumed micro-batches
     loss = loss_gen = None
+    # which row answers a data-set index (data.py:92-97, :132-137): in range -> itself, past the end -> a random row, and with
+    # --use_unique_indices the smaller data set of a unified run hands out this rank's share of its indices from a refilled set
+    pick_rng = random.Random(args.seed * 1000003 + rank)
+    unique = bool(data_args.use_unique_indices) and args.mode == "unified" and len(rows) != len(gen_rows)
+    emb_pick = ItemPicker(len(rows), pick_rng, unique and len(rows) < len(gen_rows), rank, world) if do_emb else None
+    gen_pick = ItemPicker(len(gen_rows), pick_rng, unique and len(gen_rows) < len(rows), rank, world) if do_gen else None
     while step < total:
-        order = torch.randperm(n_items, generator=gen).tolist()
-        order = order[rank::world]                                  # disjoint shards per rank
+        if len(ds_lens) > 1:
+            # several embedding data sets: every global batch (bs x gas x world consecutive indices) from one of them where possible; the
+            # per-device batches of a global batch are dealt to the ranks in turn (HF Trainer / accelerate: batch j goes to rank j % world)
+            g_order = multi_dataset_order(ds_lens, bs * gas * world, gen)
+            order = deal_to_rank(g_order, bs, rank, world)
+        else:
+            order = torch.randperm(n_items, generator=gen).tolist()
+            order = order[rank::world]                              # disjoint shards per rank
         for s in range(0, len(order) - bs + 1, bs):
             idx = order[s:s + bs]
-            if skip > 0:                                            # resume: advance the sampling RNG exactly as the consumed batches did
+            nth = 1 if gen_bs is None else bs // gen_bs             # a smaller generative batch: every nth sample (data.py:49-54, :131)
+            picks = [pick_items(emb_pick, gen_pick, i, want_gen=(k % nth == 0)) for k, i in enumerate(idx)]
+            eidx, gidx = [e for e, _ in picks], [g for _, g in picks if g is not None]
+            if skip > 0:                                            # resume: advance the sampling RNGs exactly as the consumed batches did
                 skip -= 1
                 if do_emb:
-                    for i in idx:
-                        ds[i % len(ds)]
+                    for j in eidx:
+                        ds[j]
                 continue
             micro += 1
             last_micro = micro % gas == 0                           # gradients are averaged over ranks / clipped / applied on this one
@@ -230,8 +256,7 @@ def main(argv=None):
             loss_gen = None
             if do_gen:
                 # generative first (gradcache_trainer.py:551-579): it has no collective, the embedding step does
-                take = idx if gen_bs is None else idx[::bs // gen_bs]
-                gb = collate_gen([gen_rows[i % len(gen_rows)] for i in take])
+                gb = collate_gen([gen_rows[j] for j in gidx])
                 gb = {k: v.to(device) for k, v in gb.items()}
                 if args.no_gen_gas or gc_chunk is None:
                     loss_gen = model(generative=gb).loss_gen
@@ -249,7 +274,7 @@ def main(argv=None):
                     if last_micro:
                         sync_gradients(model)
             if do_emb:
-                batch = collate([ds[i % len(ds)] for i in idx])
+                batch = collate([ds[j] for j in eidx])
                 q = {k: v.to(device) for k, v in batch["query"].items()}
                 p = {k: v.to(device) for k, v in batch["passage"].items()}
             if not do_emb:

@@ -132,7 +132,7 @@ def test_cli_unsupported_flags_raise(tmp_path):
     from gritlm_amd.training.run import main
     d = synth.build_mistral_dir(str(tmp_path / "m"), "tiny", 0, "float32")
     data = _toy(str(tmp_path / "toy.jsonl"))
-    for flag in (["--lora"], ["--qlora"], ["--use_unique_indices"], ["--num_samples", "x.json"], ["--split_emb_full"]):
+    for flag in (["--lora"], ["--qlora"], ["--split_emb_full"]):
         with pytest.raises(NotImplementedError):
             main(_base(tmp_path, d, data, "o", "--per_device_train_batch_size", "2", "--max_steps", "1", *flag))
     with pytest.raises(ValueError):          # run.py:105-106
