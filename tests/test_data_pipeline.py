@@ -124,8 +124,7 @@ def test_cli_on_several_embedding_files_draws_each_global_batch_from_one_file(to
     d.mkdir()
     _write(d / "a.jsonl", _emb_rows(16, "a"))
     _write(d / "b.jsonl", _emb_rows(9, "b"))
-    _write(d / "samples.json.skip", [])                                  # an empty file is skipped
-    os.remove(d / "samples.json.skip")
+    (d / "empty.jsonl").write_text("")                                   # an empty file is skipped
     (tmp_path / "num.json").write_text(json.dumps({"a.jsonl": 100, "b.jsonl": 100}))
     seen = []
     orig = D.EmbeddingCollator.__call__
