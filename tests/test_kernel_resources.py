@@ -54,3 +54,38 @@ def test_mfma_kernels_do_not_spill(src, needle, count):
     for k in ks:
         assert int(k["VGPRs Spill"]) == 0 and int(k["ScratchSize [bytes/lane]"]) == 0, k
         assert int(k["VGPRs"]) + int(k["AGPRs"]) <= 256 and int(k["Occupancy [waves/SIMD]"]) >= 2, k
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_gemm_k_loop_hands_the_matrix_pipe_over_one_product_early():
+    """ISA-level guard of the round-4 hand-over (csrc/gemm_bf16.hip, GRIT_GEMM_BAR_EARLY = 1): in the persistent RESIDUAL instantiation
+    every MFMA segment of the K loop is 15 products, s_barrier, ONE product, s_setprio 0 -- hipcc must neither move products across the
+    barrier nor merge segments (a barrier behind the last product costs 1-2.6 % per shape, two products early 6-8 %:
+    profiles/r04_gemm_barrier_ab.log) -- and no s_waitcnt vmcnt(0) (a drain of the LDS-DMA queue) sits between two segments of a K-tile."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "gemm.s")
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-o", out,
+                            os.path.join(ROOT, "gritlm_amd", "csrc", "gemm_bf16.hip")], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = open(out).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4grit14gemm_bf16_nt_kILi1ELb1E\w+:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    ops = [m.group(1) + (" " + m.group(2) if m.group(1) in ("s_setprio", "s_waitcnt") else "")
+           for m in (re.match(r"^\s+([a-z_0-9]+)\s*(.*)$", l) for l in lines[start:end]) if m]
+    # segments: maximal runs between an `s_setprio 1` and the next `s_setprio 0`
+    segs, cur = [], None
+    for op in ops:
+        if op.startswith("s_setprio 1"):
+            cur = []
+        elif op.startswith("s_setprio 0") and cur is not None:
+            segs.append(cur); cur = None
+        elif cur is not None:
+            cur.append(op)
+    full = [s for s in segs if sum(o.startswith("v_mfma") for o in s) == 16]
+    assert len(full) >= 16, (len(segs), len(full))                  # 4 segments per K-tile form, several forms (first / middle / last K-tile, two buffers)
+    for s in full:
+        assert s.count("s_barrier") == 1, s
+        b = s.index("s_barrier")
+        assert sum(o.startswith("v_mfma") for o in s[:b]) == 15 and sum(o.startswith("v_mfma") for o in s[b:]) == 1, s
+        assert not any(o.startswith("s_waitcnt") and "vmcnt(0)" in o for o in s), s
