@@ -75,12 +75,22 @@ __device__ __forceinline__ uint32_t hi16(uint32_t w) { return w >> 16; }
 // CAUSAL with window > 0 (Mistral's sliding window, modeling_mistral_gritlm.py:381-385 / the sliding-window causal mask of
 // _prepare_4d_causal_attention_mask, :1005-1036): a query sees the `window` keys q - window + 1 .. q; tiles that lie wholly in front
 // of a query block's first visible key are skipped as well.
-template <bool VARLEN, bool CAUSAL>
+// F16 (round 5, the encoder's "f16_operands" precision policy): q | k | v and the output hold IEEE fp16, P is rounded to fp16 --
+// v_mfma_f32_32x32x16_f16 runs at the bf16 rate, the LDS-DMA staging and the transposing reads are 16-bit-format-agnostic, so the
+// instruction stream is the bf16 one with the two MFMA opcodes and the two pack instructions exchanged.  The deferred rescale keeps
+// P <= 2^8, far inside the fp16 range; the output is a convex combination of V rows: nothing here can overflow.
+__device__ __forceinline__ f32x16_t mma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16_t mma32(f16x8_t a, f16x8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <bool F16> struct att_frag { typedef bf16x8_t type; };
+template <> struct att_frag<true> { typedef f16x8_t type; };
+
+template <bool VARLEN, bool CAUSAL, bool F16 = false>
 __global__ void __launch_bounds__(256, 2)
 attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
                  uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride,
                  int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets, int window) {
   extern __shared__ __attribute__((aligned(256))) char smem[];          // 256: the asm read addresses OR / XOR lane constants into bits 7:4
+  typedef typename att_frag<F16>::type frag_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware decode: the k-th workgroup of XCD x belongs to K/V set (k / U) * 8 + x, U = (heads per kv head) x (query-block groups)
@@ -159,7 +169,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   //      in through the wave's private 4 KiB transposition buffer instead, one 64-column half (32 rows x 128 B) at a time: LDS-DMA of
   //      whole 128-byte row segments (4 instructions x 8 rows, 16-byte units swizzled by (row>>1)&7), then ds_read_b128 of the half's
   //      four k-slices.
-  bf16x8_t qf[8];
+  frag_t qf[8];
   char* xs = smem + 2 * ATT_STAGE_BYTES + wv * ATT_XPOSE_BYTES;
   const int q_swz = (ql >> 1) & 7;                                               // swizzle of the lane's own row
   // (per-block address arithmetic is recomputed from a laundered lane id where it is used: hoisted to kernel entry it would be spilled
@@ -180,7 +190,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   auto q_read_half = [&](int half) {
     const char* rp = xs + ql * 128;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[half * 4 + ks] = *reinterpret_cast<const bf16x8_t*>(rp + (((2 * ks + hi) ^ q_swz) << 4));
+    for (int ks = 0; ks < 4; ++ks) qf[half * 4 + ks] = *reinterpret_cast<const frag_t*>(rp + (((2 * ks + hi) ^ q_swz) << 4));
     // the reads must have left the buffer before it is refilled (DMA) or rewritten (O staging)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);                                           // lgkmcnt(0)
@@ -193,7 +203,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     const char* qp = q_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+      qf[ks] = *reinterpret_cast<const frag_t*>(qp + ks * 32);
     }
   }
 
@@ -306,7 +316,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // (2 ks + hi) ^ kf_x == (2 ks) ^ (hi ^ kf_x): one per-tile base with the lane's constant in address bits 7:4, one v_xor per k-slice
         const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)k_lds) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
-        bf16x8_t kr[8][2];
+        frag_t kr[8][2];
 #define ATT_K_READ(KS)                                                                                                              \
   do {                                                                                                                              \
     const uint32_t ka = kbase ^ (uint32_t)((KS) << 5);                                                                              \
@@ -316,8 +326,8 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 #define ATT_K_MMA(KS, N)                                                                                                            \
   do {                                                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[KS][0]), "+v"(kr[KS][1]) : : "memory");                                      \
-    sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][0], qf[KS], (KS) == 0 ? zero16 : sacc[0], 0, 0, 0);                    \
-    sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[KS][1], qf[KS], (KS) == 0 ? zero16 : sacc[1], 0, 0, 0);                    \
+    sacc[0] = mma32(kr[KS][0], qf[KS], (KS) == 0 ? zero16 : sacc[0]);                                                               \
+    sacc[1] = mma32(kr[KS][1], qf[KS], (KS) == 0 ? zero16 : sacc[1]);                                                               \
     stage_piece(st_t, st_buf, (KS) >> 1, (KS) & 1);                                                                                 \
     asm volatile("" ::: "memory");                                                                                                  \
   } while (0)
@@ -426,7 +436,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       m_run = m_new;
 #endif
       float psum = 0.f;
-      bf16x8_t pb[2][2];
+      frag_t pb[2][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -438,9 +448,9 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
             const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj], scale_log2, -m_use));
             const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * c + 2 * jj + 1], scale_log2, -m_use));
             psum += p0 + p1;
-            pk[jj] = pack2bf_hw(p0, p1);
+            pk[jj] = pack2_op<F16>(p0, p1);
           }
-          pb[kb][c] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+          pb[kb][c] = __builtin_bit_cast(frag_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
         }
 #if ATT_DEFER_MAX
       l_run += psum;
@@ -462,8 +472,8 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 #define ATT_TR_MMA(G, BUF)                                                                                                            \
   _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
     const s16x4_t v0 = vr[BUF][db][0], v1 = vr[BUF][db][1];                                                                           \
-    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
-    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[(G) >> 1][(G) & 1], oacc[db], 0, 0, 0);                                 \
+    const frag_t vf = __builtin_bit_cast(frag_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
+    oacc[db] = mma32(vf, pb[(G) >> 1][(G) & 1], oacc[db]);                                                                            \
   }
         ATT_TR_WAIT(8, 0);
         ATT_TR_MMA(0, 0)
@@ -512,7 +522,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
             a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
           }
           *reinterpret_cast<uint4*>(wp + (((dbl * 4 + gp * 2 + hi) ^ q_swz) << 4)) =
-              make_uint4(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]), pack2bf_hw(bq[0], bq[1]), pack2bf_hw(bq[2], bq[3]));
+              make_uint4(pack2_op<F16>(a[0], a[1]), pack2_op<F16>(a[2], a[3]), pack2_op<F16>(bq[0], bq[1]), pack2_op<F16>(bq[2], bq[3]));
         }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);                                         // lgkmcnt(0): the wave's own writes are in the buffer
@@ -548,510 +558,6 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 }
 
 
-// ====================================================================================================================================
-// W64 forward (round 4): the bidirectional kernel restructured around ONE wave per SIMD with 64 query rows per wave.
-//
-// Why (profiles/r03_attn_fwd_ablation.log): in the kernel above a wave owns 32 query rows, so every
-// v_mfma_f32_32x32x16_bf16 needs a fresh 1 KiB operand fragment from LDS and a K/V tile is staged (8 LDS-DMA pieces per wave) for 32
-// products per wave; with everything else ablated that structure ends at 0.53 of the pipe.  Here a wave owns TWO 32-row query groups:
-// every K / V fragment read from LDS feeds two products, a tile costs a wave 8 DMA pieces per 64 products, and the per-tile rendezvous
-// (barrier, DMA wait, mask word) is paid once per 256 query rows.  The wave has the whole register file of its SIMD (oacc 128 + one score
-// set 64 + Q 64 in AGPRs; the softmax's copy of the scores, P and the fragments in arch VGPRs).  With one wave per SIMD nobody else fills
-// the matrix pipe during the softmax, so the loop is software pipelined IN the wave: iteration n issues
-//     QK(n+1)  between the exponentials of tile n  (K runs one tile ahead of V in the ring: the LDS holds V(n) and K(n+1), the DMA of
-//              V(n+1) and K(n+2) is in flight),
-//     PV(n)    between the row statistics of tile n + 1 (score copy-out, mask, row maxima, the per-row "does the maximum move" decision).
-//
-// Geometry: 256-thread workgroups (4 waves x 64 rows = 256-row query blocks), ONE workgroup per CU.  A workgroup walks `bpw` consecutive
-// blocks of one K/V set (batch, kv head) -- block j = (head j / nqb of the GQA group, query block j % nqb) -- as ONE flat tile stream: the
-// bidirectional tile range is the same for every block of the set, so the ring never notices a block boundary, the K/V tiles stay in
-// the XCD's L2 for all heads of the group, and the next block's Q rows are fetched under the previous block's last tiles: one cold
-// prologue per workgroup (64 tile iterations at B 256 x S 512).  The first version of this kernel ran two-wave workgroups (128 rows) two
-// per CU: 16 DMA pieces per wave and tile with no partner wave to cover their issue cost, 0.65x of the kernel above
-// (profiles/r04_attn_w64_first_build_ab.json); it was bit-identical, as this one is: per-row arithmetic (accumulation order of both
-// products, the per-row deferred rescale) is that of the kernel above (tools/attn_w64_ab.py), packed == padded.
-// a + b as ONE v_add_f32: under plain -O3 hipcc SLP-packs the row-sum adds of neighbouring scores into v_pk_add_f32, which beside MFMAs costs
-// more than the two scalar adds it replaces (guide: 'packed f32 VALU ... an anti-lever beside MFMAs'); same IEEE sum, same bits
-// CAUTION (found with the no-rescale variant of this kernel): hipcc does not know that this asm statement is a VALU
-// instruction, so it does not keep the distance to a preceding v_exp_f32 that the transcendental unit needs -- in another schedule of the
-// same source 8 of 64 lanes read the exponentials' INPUTS.  In THIS build the schedule is safe (bit-identical to the default kernel on
-// every shape of the harness), and the GPU suite's attn_w64_equals_default re-checks that for every build of the library.
-__device__ __forceinline__ float w64_add(float a, float b) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// -DW64_STAMPS (tools/ubench/build_w64_stamps.sh; never in the shipped library): shader-clock stamps at the section boundaries of the tile
-// loop, summed per section over wave 0's iterations and written over the first floats of `lse` by workgroup 0
-#ifdef W64_STAMPS
-#define W64_STAMP(I) do { const uint64_t now_ = __builtin_readcyclecounter(); st_acc[I] += (uint32_t)(now_ - st_last); st_last = now_; } while (0)
-#else
-#define W64_STAMP(I) do { } while (0)
-#endif
-constexpr int W64_QB = 256;                                                    // query rows per workgroup block
-constexpr int W64_XPOSE_BYTES = 8192;                                          // per wave: 64 rows x 128 B (Q in / O out)
-constexpr int W64_LDS_BYTES = 2 * ATT_STAGE_BYTES + 4 * W64_XPOSE_BYTES;       // 96 KiB
-
-template <bool VARLEN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-attn_fwd_w64_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key_bits, const int32_t* __restrict__ cu_seqlens,
-               uint16_t* __restrict__ out, float* __restrict__ lse, int S_arg, int nq, int nkv, int64_t qkv_stride, int64_t out_stride,
-               float scale_log2, int bpw, int parts, int n_sets) {
-  extern __shared__ __attribute__((aligned(256))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int gqa = nq / nkv;
-  // XCD-aware decode (as above): the k-th workgroup of XCD x belongs to K/V set (k / parts) * 8 + x, part k % parts of its blocks
-  const int kx = (int)blockIdx.x >> 3;
-  const int set = (kx / parts) * 8 + ((int)blockIdx.x & 7), part = kx % parts;
-  if (set >= n_sets) return;
-  const int b = set / nkv, hk = set - b * nkv;
-  int S = S_arg;
-  int64_t row0 = (int64_t)b * S_arg;
-  if constexpr (VARLEN) {
-    row0 = cu_seqlens[b];
-    S = cu_seqlens[b + 1] - cu_seqlens[b];
-  }
-  const int nqb = (S + W64_QB - 1) / W64_QB;
-  const int nb_set = gqa * nqb;                 // blocks of this set: (head of the group, query block)
-  const int j0 = part * bpw;
-  if (j0 >= nb_set) return;                     // uniform per workgroup
-  const int nblk = (nb_set - j0) < bpw ? (nb_set - j0) : bpw;
-
-  const char* q_set = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)hk * gqa * ATT_D);        // + head-in-group * 256 B
-  const char* k_base = reinterpret_cast<const char*>(qkv + row0 * qkv_stride + (int64_t)(nq + hk) * ATT_D);
-  char* o_set = reinterpret_cast<char*>(out + row0 * out_stride + (int64_t)hk * gqa * ATT_D);
-  const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
-  const int ql = lane & 31, hi = lane >> 5;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-
-  // ---- LDS-DMA roles (as above): wave w stages keys 16w .. 16w+15 of a tile, four 1-KiB pieces for K and four for V
-  const int st_key = 16 * wv + (lane >> 4);
-  const uint32_t v_unit_b = (uint32_t)(((lane & 15) ^ (4 * ((lane >> 4) & 3))) << 4);
-  const uint32_t v_delta_b = (uint32_t)nkv * ATT_D * 2u;
-  const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u + v_delta_b), 0x00020000);
-  uint32_t pc_k[4], pc_v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    pc_k[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + (uint32_t)(((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) << 4);
-    pc_v[i] = (uint32_t)(st_key + 4 * i) * qkv_stride_b + v_unit_b + v_delta_b;
-  }
-  // piece p = 0..7 of a tile: p < 4 -> K piece p, else V piece p - 4
-  auto stage_piece = [&](int t, int buf, int p) {
-    const int is_v = p >> 2, i = p & 3;
-    char* dst = smem + buf * ATT_STAGE_BYTES + (is_v ? K_LDS_BYTES : 0) + wv * 4096 + i * 1024;
-    const uint32_t tile_b = (uint32_t)__builtin_amdgcn_readfirstlane(t * ATT_KB) * qkv_stride_b;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (att_lptr_t)dst, 16, (int)(is_v ? pc_v[i] : pc_k[i]), (int)tile_b, 0, 0);
-  };
-
-  // ---- Q fragments of the wave's two 32-row groups: qf[g][ks], lane holds Q[64 wave + 32 g + ql][16 ks + 8 hi .. + 8]
-  bf16x8_t qf[2][8];
-  char* xs = smem + 2 * ATT_STAGE_BYTES + wv * W64_XPOSE_BYTES;
-  const int q_swz = (ql >> 1) & 7;
-  // block j of the set -> byte offset of its head inside a row, first row of the block
-  auto blk_head_b = [&](int j) { return (uint32_t)(j / nqb) * (uint32_t)(ATT_D * 2); };
-  auto blk_row0 = [&](int j) { return (j % nqb) * W64_QB; };
-  // one 64-column half of the wave's 64 rows through the transposition buffer: eight DMA instructions of 8 rows x 128 B
-  auto q_stage_half = [&](int j, int half) {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int x_row = ln >> 3, x_unit = ln & 7;
-    const char* qb_base = q_set + blk_head_b(j);
-    const int r0 = blk_row0(j) + wave * 64;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int r = 8 * jj + x_row;
-      int qr = r0 + r;
-      qr = qr < S ? qr : S - 1;
-      const uint32_t unit_b = (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4);
-      __builtin_amdgcn_global_load_lds((att_gptr_t)(qb_base + ((uint32_t)qr * qkv_stride_b + unit_b)), (att_lptr_t)(xs + jj * 1024), 16, 0, 0);
-    }
-  };
-  auto q_read_half = [&](int half) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const char* rp = xs + (32 * g + ql) * 128;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[g][half * 4 + ks] = *reinterpret_cast<const bf16x8_t*>(rp + (((2 * ks + hi) ^ q_swz) << 4));
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                           // lgkmcnt(0): the reads have left the buffer
-    asm volatile("" ::: "memory");
-  };
-
-  // number of KV tiles with at least one valid key
-  int NT = 0;
-  const uint64_t* bits = nullptr;
-  if constexpr (VARLEN) {
-    NT = (S + 63) >> 6;
-  } else {
-    const int W = (S + 63) >> 6;
-    bits = key_bits + (int64_t)b * W;
-    for (int w = W - 1; w >= 0; --w)
-      if (bits[w] != 0) { NT = w + 1; break; }
-  }
-  if (NT == 0) NT = 1;                          // every key masked: one tile, all scores -inf (rows come out as zeros, like the kernel above)
-  auto tile_word = [&](int t) -> uint64_t {
-    if constexpr (VARLEN) {
-      const int rem = S - t * ATT_KB;
-      return rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-    } else {
-      return bits[t];
-    }
-  };
-
-  // ---- pipe fill: K(0), V(0) -> stage 0; the first block's Q rows straight from global memory; K(1) -> K half of stage 1
-#pragma unroll
-  for (int p = 0; p < 8; ++p) stage_piece(0, 0, p);
-  {
-    const char* qb_base = q_set + blk_head_b(j0);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int qr0 = blk_row0(j0) + wave * 64 + 32 * g + ql;
-      const char* qp = qb_base + ((uint32_t)(qr0 < S ? qr0 : S - 1) * qkv_stride_b + (uint32_t)hi * 16u);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) qf[g][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
-    }
-  }
-  {
-    const int t1 = NT > 1 ? 1 : 0;              // stream position 1 (tile 1, or tile 0 again when the sequence has one tile)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) stage_piece(t1, 1, p);
-  }
-
-  const int kf_row = ql * 256, kf_x = lane & 15;
-  const int vt_lane = (((lane & 15) >> 2) + 4 * hi) * V_PITCH + ((((lane >> 2) & 3) * 4) << 4) + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
-  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  f32x16_t oacc[2][4];
-  float m_run[2], l_run[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    m_run[g] = -INFINITY; l_run[g] = 0.f;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
-  }
-
-  // K fragment reads (inline asm, counted lgkmcnt) and the four products of a k-slice: one K fragment pair feeds BOTH query groups
-#define W64_K_READ(KS)                                                                                                              \
-  do {                                                                                                                              \
-    const uint32_t ka = kbase ^ (uint32_t)((KS) << 5);                                                                              \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(kr[(KS) % 3][0]) : "v"(ka));                                                          \
-    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(kr[(KS) % 3][1]) : "v"(ka));                                              \
-  } while (0)
-#define W64_K_MMA(KS, N)                                                                                                            \
-  do {                                                                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % 3][0]), "+v"(kr[(KS) % 3][1]) : : "memory");                          \
-    sacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[0][KS], (KS) == 0 ? zero16 : sacc[0][0], 0, 0, 0);     \
-    sacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][0], qf[1][KS], (KS) == 0 ? zero16 : sacc[1][0], 0, 0, 0);     \
-    sacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[0][KS], (KS) == 0 ? zero16 : sacc[0][1], 0, 0, 0);     \
-    sacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[(KS) % 3][1], qf[1][KS], (KS) == 0 ? zero16 : sacc[1][1], 0, 0, 0);     \
-  } while (0)
-  // QK of one tile: K fragments two k-slices ahead of their products; STEP(KS) = what rides behind the products of k-slice KS
-#define W64_QK(STEP)                                                                                                                \
-  do {                                                                                                                              \
-    bf16x8_t kr[3][2];                                                                                                              \
-    W64_K_READ(0); W64_K_READ(1);                                                                                                   \
-    W64_K_READ(2); W64_K_MMA(0, 4); STEP(0);                                                                                        \
-    W64_K_READ(3); W64_K_MMA(1, 4); STEP(1);                                                                                        \
-    W64_K_READ(4); W64_K_MMA(2, 4); STEP(2);                                                                                        \
-    W64_K_READ(5); W64_K_MMA(3, 4); STEP(3);                                                                                        \
-    W64_K_READ(6); W64_K_MMA(4, 4); STEP(4);                                                                                        \
-    W64_K_READ(7); W64_K_MMA(5, 4); STEP(5);                                                                                        \
-    W64_K_MMA(6, 2); STEP(6);                                                                                                       \
-    W64_K_MMA(7, 0); STEP(7);                                                                                                       \
-  } while (0)
-#define W64_NOSTEP(KS) do { } while (0)
-
-  // ---- row statistics of a tile whose scores sit in the accumulator set: the scores move to arch VGPRs (`sc`, where the softmax works on
-  //      them; the set is the destination of the next QK products), masked keys become -inf, and every row learns its new maximum and
-  //      whether it has to move its reference maximum (per row: a row's bits never depend on its wave mates).  Slice I = (group I >> 1,
-  //      32-key half I & 1); the statistics of tile n + 1 are computed one slice behind each quarter of the PV products of tile n.
-  f32x16_t sacc[2][2];                          // ONE accumulator set for the scores ([group][32-key half]; AGPRs)
-  f32x16_t sc[2][2];                            // the softmax's copy (arch VGPRs)
-  float mxp[2], m_new[2];
-  bool grow[2];
-#define W64_STAT_SLICE(I, WORD, FAST)                                                                                               \
-  do {                                                                                                                              \
-    constexpr int g_ = (I) >> 1, kb_ = (I) & 1;                                                                                     \
-    sc[g_][kb_] = sacc[g_][kb_];                                                                                                    \
-    asm volatile("" : "+v"(sc[g_][kb_]));                                                                                           \
-    float mx_;                                                                                                                      \
-    if (FAST) {                                                                                                                     \
-      float ma_ = fmaxf(fmaxf(sc[g_][kb_][0], sc[g_][kb_][1]), sc[g_][kb_][2]);                                                     \
-      float mb_ = fmaxf(fmaxf(sc[g_][kb_][8], sc[g_][kb_][9]), sc[g_][kb_][10]);                                                    \
-      _Pragma("unroll") for (int r = 3; r < 8; ++r) { ma_ = fmaxf(ma_, sc[g_][kb_][r]); mb_ = fmaxf(mb_, sc[g_][kb_][8 + r]); }     \
-      mx_ = fmaxf(ma_, mb_);                                                                                                        \
-    } else {                                                                                                                        \
-      const uint32_t wsel_ = kb_ ? (uint32_t)((WORD) >> (32 + 4 * hi)) : (uint32_t)((WORD) >> (4 * hi));                            \
-      mx_ = -INFINITY;                                                                                                              \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                              \
-        const int kbit = (r & 3) + 8 * (r >> 2);                                                                                    \
-        const float sv_ = ((wsel_ >> kbit) & 1u) ? sc[g_][kb_][r] : -INFINITY;                                                      \
-        sc[g_][kb_][r] = sv_;                                                                                                       \
-        mx_ = fmaxf(mx_, sv_);                                                                                                      \
-      }                                                                                                                             \
-    }                                                                                                                               \
-    mxp[g_] = kb_ ? fmaxf(mxp[g_], mx_) : mx_;                                                                                      \
-    if (kb_) {                                                                                                                      \
-      const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxp[g_]), __float_as_uint(mxp[g_]), false, false);          \
-      const float mt_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * scale_log2;                                       \
-      m_new[g_] = fmaxf(m_run[g_], mt_);                                                                                            \
-      grow[g_] = !(m_new[g_] - m_run[g_] <= 8.0f);                                                                                  \
-    }                                                                                                                               \
-  } while (0)
-
-  ATT_WAIT_VM0();                               // K(0), V(0), K(1), Q of the first block
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  {
-    const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)smem) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
-    W64_QK(W64_NOSTEP);
-  }
-  W64_STAT_SLICE(0, 0ull, true); W64_STAT_SLICE(1, 0ull, true); W64_STAT_SLICE(2, 0ull, true); W64_STAT_SLICE(3, 0ull, true);
-  uint64_t word_cur = tile_word(0);             // mask word of the tile whose softmax the next iteration runs
-
-#ifdef W64_STAMPS
-  uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t st_last = __builtin_readcyclecounter();
-#endif
-  const int N = nblk * NT;                      // flat tile stream of the workgroup
-  int t = 0, qi = 0;                            // tile inside the block, block index (j0 + qi)
-  bool skip_wait = true;                        // no DMA wait at the top right after the pipe fill / a block epilogue
-
-  for (int n = 0; n < N; ++n) {                 // (the body is written out in the loop: as a lambda that mutates t / qi / skip_wait through
-    const bool has_next = n + 1 < N;            //  reference captures hipcc kept the three in scratch memory, and every reload came with an
-    const bool last_of_block = (t + 1 == NT);   //  s_waitcnt vmcnt(0) that drained the LDS-DMA queue)
-    const bool more = qi + 1 < nblk;
-    const int jb = j0 + qi;
-    W64_STAMP(5);                               // [5] block epilogue / loop overhead since the end of the previous PV
-    if (!skip_wait) ATT_WAIT_VM0();             // K(n+1), V(n) (and a Q half) requested one iteration ago
-    skip_wait = false;
-    W64_STAMP(0);                               // [0] the DMA wait
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    W64_STAMP(1);                               // [1] the barrier
-    // this iteration's eight pieces: K(n+2) -> K half of stage n & 1 (K(n) is dead), V(n+1) -> V half of stage (n+1) & 1 (V(n-1) is dead);
-    // past the end of the stream they re-stage a tile nobody reads
-    int tk = t + 2; tk = tk >= NT ? tk - NT : tk; tk = tk >= NT ? tk - NT : tk;     // (t + 2) mod NT for NT >= 1
-    const int tv = (t + 1 == NT) ? 0 : t + 1;
-    const int kbuf = n & 1, vbuf = (n + 1) & 1;
-    // next block's Q rows: first half requested two tiles before the block ends, read after this block's last QK products
-    if (more && NT >= 3 && t + 3 == NT) q_stage_half(jb + 1, 0);
-    if (more && last_of_block) {
-      if (NT == 1) { q_stage_half(jb + 1, 0); ATT_WAIT_VM0(); q_read_half(0); q_stage_half(jb + 1, 1); ATT_WAIT_VM0(); }
-      q_read_half(1);
-    }
-    const char* v_lds = smem + (n & 1) * ATT_STAGE_BYTES + K_LDS_BYTES;
-    // The statistics of this tile were computed under the previous tile's PV products WITHOUT looking at the key mask (that pass has to
-    // stay free of branches to be interleaved with the products).  A tile with masked keys -- a sequence's ragged tail, a mask with holes
-    // -- redoes them here from the accumulator set, which still holds the tile's scores: a rare, wave-uniform branch.
-    {
-      int masked = __builtin_amdgcn_readfirstlane(word_cur != ~0ull ? 1 : 0);
-      asm volatile("" : "+s"(masked));
-      if (masked) {
-        W64_STAT_SLICE(0, word_cur, false); W64_STAT_SLICE(1, word_cur, false); W64_STAT_SLICE(2, word_cur, false); W64_STAT_SLICE(3, word_cur, false);
-      }
-    }
-    word_cur = tile_word(tv);                   // the next tile's word: a scalar load with a whole iteration of latency cover
-    // ---- the (rare) move of reference maxima decided by the statistics pass, both groups
-    float m_use[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      if (__builtin_amdgcn_ballot_w64(grow[g]) != 0ull) {
-        const float m_ref = (m_new[g] == -INFINITY) ? 0.f : m_new[g];
-        const float alpha = grow[g] ? __builtin_amdgcn_exp2f(m_run[g] - m_ref) : 1.0f;
-        m_run[g] = grow[g] ? m_new[g] : m_run[g];
-        l_run[g] *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[g][db][r] *= alpha;
-      }
-      m_use[g] = (m_run[g] == -INFINITY) ? 0.f : m_run[g];
-    }
-    W64_STAMP(2);                               // [2] top: Q hand-over, masked redo, rescale
-    float psum[2] = {0.f, 0.f};
-    uint32_t pk8[2][2][2][4];                   // [group][32-key half][16-key quarter][packed pair]
-    // exponentials of one eighth of the tile's scores: group KS >> 2, key half (KS >> 1) & 1, quarter KS & 1
-#define W64_PSLICE(KS)                                                                                                              \
-  do {                                                                                                                              \
-    float nm_ = -m_use[(KS) >> 2];              /* laundered HERE: otherwise hipcc hoists all 64 scale-and-subtract fmas of the tile   \
-                                                   in front of the section, where nothing covers them */                             \
-    asm volatile("" : "+v"(nm_));                                                                                                   \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                              \
-      const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj], scale_log2, nm_));      \
-      const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[(KS) >> 2][((KS) >> 1) & 1][8 * ((KS) & 1) + 2 * jj + 1], scale_log2, nm_));  \
-      psum[(KS) >> 2] = w64_add(psum[(KS) >> 2], w64_add(p0, p1));                                                                  \
-      pk8[(KS) >> 2][((KS) >> 1) & 1][(KS) & 1][jj] = pack2bf_hw(p0, p1);                                                           \
-    }                                                                                                                               \
-  } while (0)
-#define W64_PIECE(KS) do { if ((KS) < 4) stage_piece(tk, kbuf, (KS)); else stage_piece(tv, vbuf, (KS)); asm volatile("" ::: "memory"); } while (0)
-#define W64_STEP(KS) do { W64_PIECE(KS); W64_PSLICE(KS); __builtin_amdgcn_sched_barrier(0); } while (0)
-    if (has_next) {
-      // ---- ONE section: the QK products of tile n + 1, one DMA piece behind each k-slice, the exponentials of tile n between them
-      const uint32_t kbase = ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(smem + ((n + 1) & 1) * ATT_STAGE_BYTES)) + (uint32_t)kf_row) | (uint32_t)((hi ^ kf_x) << 4);
-      W64_QK(W64_STEP);
-    } else {
-      W64_PSLICE(0); W64_PSLICE(1); W64_PSLICE(2); W64_PSLICE(3); W64_PSLICE(4); W64_PSLICE(5); W64_PSLICE(6); W64_PSLICE(7);
-    }
-#undef W64_STEP
-#undef W64_PIECE
-#undef W64_PSLICE
-    W64_STAMP(3);                               // [3] QK(n+1) || exponentials of tile n
-    l_run[0] += psum[0];
-    l_run[1] += psum[1];
-    // the next block's Q: this block's last QK products (tile NT - 1, issued in the iteration of tile NT - 2) have read qf
-    if (more && NT >= 2 && t + 2 == NT) {
-      if (NT == 2) { q_stage_half(jb + 1, 0); ATT_WAIT_VM0(); }
-      q_read_half(0);
-      q_stage_half(jb + 1, 1);
-    }
-    // ---- O^T += V^T P^T, both groups on every V fragment; behind each quarter of the products one slice of the NEXT tile's statistics
-    {
-      const uint32_t vbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)v_lds);
-      uint32_t va[4];
-#pragma unroll
-      for (int db = 0; db < 4; ++db) va[db] = vbase + (uint32_t)(vt_lane ^ (db << 6));
-      s16x4_t vr[2][4][2];
-#define W64_TR_GROUP(G, BUF)                                                                                                          \
-  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][0]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH));                \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[BUF][db][1]) : "v"(va[db]), "i"(((G) >> 1) * 32 * V_PITCH + ((G) & 1) * 16 * V_PITCH + 8 * V_PITCH)); \
-  }
-#define W64_TR_WAIT(N, BUF)                                                                                                           \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                            \
-               : "+v"(vr[BUF][0][0]), "+v"(vr[BUF][0][1]), "+v"(vr[BUF][1][0]), "+v"(vr[BUF][1][1]), "+v"(vr[BUF][2][0]),              \
-                 "+v"(vr[BUF][2][1]), "+v"(vr[BUF][3][0]), "+v"(vr[BUF][3][1]))
-#define W64_TR_MMA(G, BUF)                                                                                                            \
-  _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                                  \
-    const s16x4_t v0 = vr[BUF][db][0], v1 = vr[BUF][db][1];                                                                           \
-    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, (__attribute__((ext_vector_type(8))) short){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}); \
-    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                                   \
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(pk8[g][(G) >> 1][(G) & 1][0], pk8[g][(G) >> 1][(G) & 1][1],         \
-                                                                  pk8[g][(G) >> 1][(G) & 1][2], pk8[g][(G) >> 1][(G) & 1][3]));       \
-      oacc[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[g][db], 0, 0, 0);                                            \
-    }                                                                                                                                 \
-  }
-      // (the statistics read the accumulator set, which the QK section above has just filled with tile n + 1; past the end of the
-      //  stream there is nothing to prepare)
-      W64_TR_GROUP(0, 0)
-      W64_TR_GROUP(1, 1)
-      W64_TR_WAIT(8, 0);
-      W64_TR_MMA(0, 0)
-      W64_TR_GROUP(2, 0)
-      W64_TR_WAIT(8, 1);
-      W64_TR_MMA(1, 1)
-      W64_TR_GROUP(3, 1)
-      __builtin_amdgcn_sched_barrier(0);
-      // the statistics of tile n + 1 ride on the SECOND half of the products (by then half of P and one V fragment set are dead: the scores'
-      // arch-VGPR copy, 64 registers that live into the next iteration, does not meet them); unconditional and branch-free (past the end
-      // of the stream they chew on stale scores and nobody looks at the result)
-      W64_TR_WAIT(8, 0);
-      W64_TR_MMA(2, 0)
-      W64_STAT_SLICE(0, 0ull, true); W64_STAT_SLICE(1, 0ull, true);
-      __builtin_amdgcn_sched_barrier(0);
-      W64_TR_WAIT(0, 1);
-      W64_TR_MMA(3, 1)
-      W64_STAT_SLICE(2, 0ull, true); W64_STAT_SLICE(3, 0ull, true);
-#undef W64_TR_GROUP
-#undef W64_TR_WAIT
-#undef W64_TR_MMA
-    }
-
-    W64_STAMP(4);                               // [4] PV(n) || statistics of tile n + 1
-    if (!last_of_block) { ++t; continue; }
-
-    // ---- block epilogue: everything requested during this tile is waited for BEFORE the stores go out (vmcnt counts stores; the next
-    //      iteration then starts without a DMA wait and the stores drain under it).  The statistics of the next block's first tile
-    //      (computed above against this block's m_run) are redone against the fresh maxima below.
-    ATT_WAIT_VM0();
-    skip_wait = true;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int x_row = ln >> 3, x_unit = ln & 7;
-    char* ob_base = o_set + blk_head_b(jb);
-    const int h_blk = hk * gqa + jb / nqb;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
-      const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-      const int q_g0 = blk_row0(jb) + wave * 64 + 32 * g;                           // first row of the group
-      char* xg = xs + g * 4096;                                                     // 32 rows x 128 B of the wave's buffer
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        char* wp = xg + (ln & 31) * 128;
-#pragma unroll
-        for (int dbl = 0; dbl < 2; ++dbl)
-#pragma unroll
-          for (int gp = 0; gp < 2; ++gp) {
-            const int db = half * 2 + dbl;
-            float a[4], bq[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[g][db][8 * gp + e] * inv_l),
-                                                               __float_as_uint(oacc[g][db][8 * gp + 4 + e] * inv_l), false, false);
-              a[e] = __uint_as_float(sw[0]); bq[e] = __uint_as_float(sw[1]);
-            }
-            *reinterpret_cast<uint4*>(wp + (((dbl * 4 + gp * 2 + hi) ^ q_swz) << 4)) =
-                make_uint4(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]), pack2bf_hw(bq[0], bq[1]), pack2bf_hw(bq[2], bq[3]));
-          }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        asm volatile("" ::: "memory");
-        uint4 piece[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) piece[j] = *reinterpret_cast<const uint4*>(xg + j * 1024 + ln * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 8 * j + x_row;
-          const int qr = q_g0 + r;
-          if (qr < S) {
-            typedef __attribute__((ext_vector_type(4))) unsigned int att_u32x4_t;
-            att_u32x4_t* op = reinterpret_cast<att_u32x4_t*>(ob_base + ((uint32_t)qr * out_stride_b + (uint32_t)((half * 8 + (x_unit ^ ((r >> 1) & 7))) << 4)));
-            const att_u32x4_t pv = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
-            *op = pv;
-          }
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        asm volatile("" ::: "memory");
-      }
-      const int q_row = q_g0 + ql;
-      if (q_row < S && lse != nullptr && hi == 0) {
-        if constexpr (VARLEN) lse[(row0 + q_row) * nq + h_blk] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
-        else lse[((int64_t)b * nq + h_blk) * S + q_row] = (m_run[g] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
-      }
-      m_run[g] = -INFINITY; l_run[g] = 0.f;
-#pragma unroll
-      for (int db = 0; db < 4; ++db) oacc[g][db] = zero16;
-    }
-    if (has_next) {
-      // redo the two row decisions of the next block's first tile against the reset maxima: m_new = tile maximum, grow = true unless NaN-free
-      // comparison says otherwise (identical to what the kernel above computes for a block's first tile)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxp[g]), __float_as_uint(mxp[g]), false, false);
-        const float mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * scale_log2;
-        m_new[g] = fmaxf(m_run[g], mt);
-        grow[g] = !(m_new[g] - m_run[g] <= 8.0f);
-      }
-    }
-    t = 0; ++qi;
-  }
-#ifdef W64_STAMPS
-  if (blockIdx.x == 0 && tid == 0 && lse != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) lse[i] = (float)st_acc[i];
-    lse[6] = (float)N;
-  }
-#endif
-#undef W64_STAT_SLICE
-#undef W64_K_READ
-#undef W64_K_MMA
-#undef W64_QK
-#undef W64_NOSTEP
-}
-
 }  // namespace grit
 
 using namespace grit;
@@ -1069,38 +575,14 @@ static void attn_lds_optin(KernelT kernel, std::atomic<uint64_t>& done, int byte
     done.fetch_or(bit, std::memory_order_release);
   }
 }
-template <bool VARLEN, bool CAUSAL>
+template <bool VARLEN, bool CAUSAL, bool F16 = false>
 static void attn_launch(dim3 grid, hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
                         int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2, int qpw, int ngx, int n_sets,
                         int window) {
   static std::atomic<uint64_t> optin{0};
-  attn_lds_optin(attn_bidir_fwd_k<VARLEN, CAUSAL>, optin);
-  hipLaunchKernelGGL((attn_bidir_fwd_k<VARLEN, CAUSAL>), grid, dim3(256), ATT_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
+  attn_lds_optin(attn_bidir_fwd_k<VARLEN, CAUSAL, F16>, optin);
+  hipLaunchKernelGGL((attn_bidir_fwd_k<VARLEN, CAUSAL, F16>), grid, dim3(256), ATT_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
                      out_stride, scale_log2, qpw, ngx, n_sets, window);
-}
-
-template <bool VARLEN>
-static void attn_w64_launch(hipStream_t st, const uint16_t* qkv, const uint64_t* key_bits, const int32_t* cu, uint16_t* out, float* lse,
-                            int B, int S, int nq, int nkv, int64_t qkv_stride, int64_t out_stride, float scale_log2) {
-  static std::atomic<uint64_t> optin{0};
-  attn_lds_optin(attn_fwd_w64_k<VARLEN>, optin, W64_LDS_BYTES);
-  // blocks per workgroup: a whole K/V set (all heads of the GQA group x all query blocks: one cold prologue, K/V hot in L2) unless the
-  // launch would then leave CUs idle -- halve until there are two workgroups per CU or one block each
-  const int n_sets = B * nkv, nb_set = (nq / nkv) * ((S + W64_QB - 1) / W64_QB);
-  int bpw = nb_set;
-  while (bpw > 1 && (int64_t)n_sets * ((nb_set + bpw - 1) / bpw) < 512) bpw = (bpw + 1) / 2;
-  const int parts = (nb_set + bpw - 1) / bpw;
-  const unsigned grid = (unsigned)(8 * ((n_sets + 7) / 8) * parts);
-  hipLaunchKernelGGL((attn_fwd_w64_k<VARLEN>), dim3(grid), dim3(256), W64_LDS_BYTES, st, qkv, key_bits, cu, out, lse, S, nq, nkv, qkv_stride,
-                     out_stride, scale_log2, bpw, parts, n_sets);
-}
-// which forward the bidirectional entry points launch: the 4-wave-per-workgroup / 32-rows-per-wave kernel at the top of this file (default), or
-// the W64 kernel (GRIT_ATTN_FWD=w64; read per call so that one process can time both).  W64 is bit-identical and, as measured in round 4,
-// 0.70-0.75x as fast (profiles/r04_attn_w64_ab.json, r04_attn_w64_stamps.json): it stays in the library as the
-// measured record of that structure and is held to bit equality by the GPU suite (attn_w64_equals_default).
-static bool attn_use_w64() {
-  const char* e = getenv("GRIT_ATTN_FWD");
-  return e != nullptr && e[0] == 'w';
 }
 
 struct AttnGeom {
@@ -1126,7 +608,7 @@ static AttnGeom attn_geom(int B, int max_len, int nq, int nkv, bool causal) {
 }
 
 static int attn_fwd_padded(const char* name, bool causal, int window, const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S,
-                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream, bool f16 = false) {
   GRIT_REQUIRE(qkv && key_bits && out, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(B > 0 && S > 0 && nq > 0 && nkv > 0 && S <= (1 << 30) && nq <= 65535 && nkv <= 65535, GRIT_E_BADARG, "%s: bad sizes", name);
   GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
@@ -1143,9 +625,9 @@ static int attn_fwd_padded(const char* name, bool causal, int window, const void
   if (causal)
     attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
-  else if (attn_use_w64())
-    attn_w64_launch<false>((hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, B, S, nq, nkv, qkv_stride,
-                           out_stride, scale * 1.4426950408889634f);
+  else if (f16)
+    attn_launch<false, false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
+                                    out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, 0);
   else
     attn_launch<false, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
                               out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
@@ -1154,7 +636,7 @@ static int attn_fwd_padded(const char* name, bool causal, int window, const void
 }
 
 static int attn_fwd_varlen(const char* name, bool causal, int window, const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len,
-                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+                           int nq, int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream, bool f16 = false) {
   GRIT_REQUIRE(qkv && cu_seqlens && out, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(B > 0 && max_len > 0 && nq > 0 && nkv > 0 && max_len <= (1 << 30) && nq <= 65535 && nkv <= 65535, GRIT_E_BADARG, "%s: bad sizes", name);
   GRIT_REQUIRE(d == ATT_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
@@ -1171,9 +653,9 @@ static int attn_fwd_varlen(const char* name, bool causal, int window, const void
   if (causal)
     attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
-  else if (attn_use_w64())
-    attn_w64_launch<true>((hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, B, max_len, nq, nkv, qkv_stride,
-                          out_stride, scale * 1.4426950408889634f);
+  else if (f16)
+    attn_launch<true, false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
+                                   out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, 0);
   else
     attn_launch<true, false>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
@@ -1184,6 +666,16 @@ static int attn_fwd_varlen(const char* name, bool causal, int window, const void
 extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   return attn_fwd_padded("grit_attn_bidir_fwd", false, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
+}
+// fp16-operand policy: qkv and out hold IEEE fp16 (bidirectional attention only: the embedding path)
+extern "C" int grit_attn_bidir_f16_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                       int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_padded("grit_attn_bidir_f16_fwd", false, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream, true);
+}
+extern "C" int grit_attn_bidir_varlen_f16_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                              int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
+  return attn_fwd_varlen("grit_attn_bidir_varlen_f16_fwd", false, 0, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride, scale,
+                         stream, true);
 }
 extern "C" int grit_attn_causal_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
                                     int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {

@@ -53,6 +53,27 @@ __device__ __forceinline__ uint32_t pack2bf_hw(float lo, float hi) {
 }
 __device__ __forceinline__ float round_bf(float f) { return __uint_as_float(f2bf(f) << 16); }
 
+// ---- fp16 operands (the "f16_operands" precision policy of the encoder: same MFMA rate as bf16, 3 more mantissa bits) ----
+// v_cvt_pk_f16_f32 (RNE, gfx950) for two conversions; values beyond 65504 become inf -- every kernel that rounds to f16 ORs
+// h2_nonfinite() of what it stores into a per-device flag word (f16_flag_ptr()) that the host reads after the forward pass.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_pk_t;
+__device__ __forceinline__ uint32_t pack2h_hw(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_pk_t){lo, hi}, f16x2_pk_t));
+}
+__device__ __forceinline__ float hlo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_pk_t, w)[0]; }
+__device__ __forceinline__ float hhi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_pk_t, w)[1]; }
+// non-zero iff one of the two packed halves is inf / nan (exponent field all ones): strip the signs, add 1 to the exponent's top bit
+__device__ __forceinline__ uint32_t h2_nonfinite(uint32_t pk) { return ((pk & 0x7fff7fffu) + 0x04000400u) & 0x80008000u; }
+// operand-format switch of the templated kernels: F16 = false -> bf16 (the reference's arithmetic type), true -> fp16
+template <bool F16>
+__device__ __forceinline__ uint32_t pack2_op(float lo, float hi) {
+  if constexpr (F16) return pack2h_hw(lo, hi);
+  else return pack2bf_hw(lo, hi);
+}
+// host: device address of this device's f16 overflow flag word (elementwise.hip; nullptr if the symbol lookup fails)
+unsigned int* f16_flag_ptr();
+
 // Rotary embedding arithmetic with a FIXED contraction (one rounded product + one fma), so every kernel that rotates -- rope_k, the QKV
 // GEMM's epilogue in both launch forms, the decode kernels -- produces the same bits whatever the surrounding code makes the compiler
 // prefer:  lo = x1*cos - x2*sin,  hi = x2*cos + x1*sin   (modeling_mistral_gritlm.py:138-163, x*cos + rotate_half(x)*sin)

@@ -106,9 +106,10 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_generic_k(const uint4* __rest
 // RMSNorm of an fp32 residual stream: x [T,H] fp32 -> y bf16 = bf16(w * (x * rsqrt(mean(x^2) + eps))), ONE rounding (what the reference
 // computes when it runs in fp32, :84-89, rounded once to the bf16 operand the next GEMM takes).  One wave per row; a lane owns the
 // float4 at index c*64 + lane of every 256-element chunk c, so every load instruction covers 1 KiB contiguous and every store 512 B.
-template <int NCH>   // H = NCH * 256
+// F16: y = fp16 (the "f16_operands" policy; w stays bf16); a value beyond the fp16 range sets the overflow flag word `ovf`.
+template <int NCH, bool F16 = false>   // H = NCH * 256
 __global__ void __launch_bounds__(256) rmsnorm_fwd_f32in_reg_k(const float4* __restrict__ x, const uint2* __restrict__ w,
-                                                               uint2* __restrict__ y, int64_t T, int H, float eps) {
+                                                               uint2* __restrict__ y, int64_t T, int H, float eps, unsigned int* ovf) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -123,15 +124,22 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_f32in_reg_k(const float4* __r
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)H + eps);
   uint2* yr = y + row * HQ;
+  uint32_t bad = 0;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const uint2 ww = w[c * 64 + lane];
-    yr[c * 64 + lane] = make_uint2(pack2bf_hw(bflo(ww.x) * (v[c].x * rs), bfhi(ww.x) * (v[c].y * rs)),
-                                   pack2bf_hw(bflo(ww.y) * (v[c].z * rs), bfhi(ww.y) * (v[c].w * rs)));
+    const uint2 o = make_uint2(pack2_op<F16>(bflo(ww.x) * (v[c].x * rs), bfhi(ww.x) * (v[c].y * rs)),
+                               pack2_op<F16>(bflo(ww.y) * (v[c].z * rs), bfhi(ww.y) * (v[c].w * rs)));
+    if constexpr (F16) bad |= h2_nonfinite(o.x) | h2_nonfinite(o.y);
+    yr[c * 64 + lane] = o;
+  }
+  if constexpr (F16) {
+    if (bad != 0 && ovf != nullptr) atomicOr(ovf, 1u);
   }
 }
+template <bool F16 = false>
 __global__ void __launch_bounds__(256) rmsnorm_fwd_f32in_generic_k(const float4* __restrict__ x, const uint2* __restrict__ w,
-                                                                   uint2* __restrict__ y, int64_t T, int H, float eps) {
+                                                                   uint2* __restrict__ y, int64_t T, int H, float eps, unsigned int* ovf) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -142,11 +150,38 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_f32in_generic_k(const float4*
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)H + eps);
   uint2* yr = y + row * HQ;
+  uint32_t bad = 0;
   for (int c = lane; c < HQ; c += 64) {
     const float4 a = xr[c];
     const uint2 ww = w[c];
-    yr[c] = make_uint2(pack2bf_hw(bflo(ww.x) * (a.x * rs), bfhi(ww.x) * (a.y * rs)), pack2bf_hw(bflo(ww.y) * (a.z * rs), bfhi(ww.y) * (a.w * rs)));
+    const uint2 o = make_uint2(pack2_op<F16>(bflo(ww.x) * (a.x * rs), bfhi(ww.x) * (a.y * rs)), pack2_op<F16>(bflo(ww.y) * (a.z * rs), bfhi(ww.y) * (a.w * rs)));
+    if constexpr (F16) bad |= h2_nonfinite(o.x) | h2_nonfinite(o.y);
+    yr[c] = o;
   }
+  if constexpr (F16) {
+    if (bad != 0 && ovf != nullptr) atomicOr(ovf, 1u);
+  }
+}
+
+// ---------------------------------------------------------------- fp16 overflow flag of the "f16_operands" policy
+// One word per device (module-scope device variable: the library never allocates).  Every kernel that rounds to fp16 ORs 1 into it when
+// it stores an inf / nan; grit_f16_overflow_flag() reads (and optionally clears) it on the caller's stream.
+__device__ unsigned int g_f16_overflow[1];
+unsigned int* f16_flag_ptr() {
+  static unsigned int* cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  unsigned int* p = __atomic_load_n(&cached[dev & 63], __ATOMIC_ACQUIRE);
+  if (p == nullptr) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_f16_overflow)) != hipSuccess || q == nullptr) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    p = (unsigned int*)q;
+    __atomic_store_n(&cached[dev & 63], p, __ATOMIC_RELEASE);
+  }
+  return p;
 }
 
 // ---------------------------------------------------------------- RoPE (in place on q,k of the fused qkv rows)
@@ -325,14 +360,59 @@ int grit_rmsnorm_fwd_f32in(const float* x, const void* w, void* y, int64_t T, in
   const uint2* wp = (const uint2*)w;
   uint2* yp = (uint2*)y;
   switch (H % 256 == 0 ? H / 256 : 0) {
-    case 1: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<1>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
-    case 2: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<2>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
-    case 4: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<4>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
-    case 8: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<8>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
-    case 16: hipLaunchKernelGGL(rmsnorm_fwd_f32in_reg_k<16>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
-    default: hipLaunchKernelGGL(rmsnorm_fwd_f32in_generic_k, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+    case 1: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<1, false>), grid, block, 0, st, xp, wp, yp, T, H, eps, (unsigned int*)nullptr); break;
+    case 2: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<2, false>), grid, block, 0, st, xp, wp, yp, T, H, eps, (unsigned int*)nullptr); break;
+    case 4: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<4, false>), grid, block, 0, st, xp, wp, yp, T, H, eps, (unsigned int*)nullptr); break;
+    case 8: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<8, false>), grid, block, 0, st, xp, wp, yp, T, H, eps, (unsigned int*)nullptr); break;
+    case 16: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<16, false>), grid, block, 0, st, xp, wp, yp, T, H, eps, (unsigned int*)nullptr); break;
+    default: hipLaunchKernelGGL(rmsnorm_fwd_f32in_generic_k<false>, grid, block, 0, st, xp, wp, yp, T, H, eps, (unsigned int*)nullptr); break;
   }
   GRIT_CHECK_LAUNCH("grit_rmsnorm_fwd_f32in");
+  return GRIT_OK;
+}
+
+/* fp16-operand policy: the same RMSNorm of the fp32 residual stream, y rounded once to IEEE fp16 (w stays bf16) */
+int grit_rmsnorm_fwd_f32in_f16(const float* x, const void* w, void* y, int64_t T, int H, float eps, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && w && y, GRIT_E_BADARG, "grit_rmsnorm_fwd_f32in_f16: null pointer");
+  GRIT_REQUIRE(T >= 0 && H > 0, GRIT_E_BADARG, "grit_rmsnorm_fwd_f32in_f16: bad sizes");
+  GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_rmsnorm_fwd_f32in_f16: H=%d must be a multiple of 8", H);
+  GRIT_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), GRIT_E_BADARG, "grit_rmsnorm_fwd_f32in_f16: pointers must be 16-byte aligned");
+  unsigned int* ovf = f16_flag_ptr();
+  GRIT_REQUIRE(ovf != nullptr, GRIT_E_LAUNCH, "grit_rmsnorm_fwd_f32in_f16: the overflow flag word of this device is not reachable");
+  const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const float4* xp = (const float4*)x;
+  const uint2* wp = (const uint2*)w;
+  uint2* yp = (uint2*)y;
+  switch (H % 256 == 0 ? H / 256 : 0) {
+    case 1: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<1, true>), grid, block, 0, st, xp, wp, yp, T, H, eps, ovf); break;
+    case 2: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<2, true>), grid, block, 0, st, xp, wp, yp, T, H, eps, ovf); break;
+    case 4: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<4, true>), grid, block, 0, st, xp, wp, yp, T, H, eps, ovf); break;
+    case 8: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<8, true>), grid, block, 0, st, xp, wp, yp, T, H, eps, ovf); break;
+    case 16: hipLaunchKernelGGL((rmsnorm_fwd_f32in_reg_k<16, true>), grid, block, 0, st, xp, wp, yp, T, H, eps, ovf); break;
+    default: hipLaunchKernelGGL(rmsnorm_fwd_f32in_generic_k<true>, grid, block, 0, st, xp, wp, yp, T, H, eps, ovf); break;
+  }
+  GRIT_CHECK_LAUNCH("grit_rmsnorm_fwd_f32in_f16");
+  return GRIT_OK;
+}
+
+/* The current device's fp16 overflow flag: *host_flag = 1 when a kernel of the f16_operands policy has stored an inf / nan since the last
+ * clear, else 0.  Runs on `stream` and WAITS for it (one 4-byte D2H copy); clear != 0 resets the flag behind the read. */
+int grit_f16_overflow_flag(int* host_flag, int clear, void* stream) {
+  GRIT_REQUIRE(host_flag != nullptr, GRIT_E_BADARG, "grit_f16_overflow_flag: null pointer");
+  unsigned int* ovf = f16_flag_ptr();
+  GRIT_REQUIRE(ovf != nullptr, GRIT_E_LAUNCH, "grit_f16_overflow_flag: the overflow flag word of this device is not reachable");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned int v = 0;
+  hipError_t e = hipMemcpyAsync(&v, ovf, sizeof(v), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && clear) e = hipMemsetAsync(ovf, 0, sizeof(v), st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    set_error("grit_f16_overflow_flag: %s", hipGetErrorString(e));
+    return GRIT_E_LAUNCH;
+  }
+  *host_flag = v != 0 ? 1 : 0;
   return GRIT_OK;
 }
 

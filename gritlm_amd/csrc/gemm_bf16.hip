@@ -144,12 +144,26 @@ __device__ __forceinline__ int wrow_of(int wc, int j) {
 // seams of the persistent tile loop
 __device__ unsigned long long g_stamps[8 * 2 * 64 * 8];      // [workgroup slot][wave group][tile][point]
 #endif
-template <int EPI, bool PERSIST>
+// MFMA of one 16x16x32 step in the operand format of the instantiation
+__device__ __forceinline__ f32x4_t mma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4_t mma16(f16x8_t a, f16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// F16 (round 5, the encoder's "f16_operands" precision policy): A and W hold IEEE fp16 instead of bf16 -- v_mfma_f32_16x16x32_f16 runs at
+// the bf16 rate and the 16-bit staging (LDS-DMA, swizzle, fragment reads) is format-agnostic, so the K loop is the same instruction
+// stream with one opcode changed.  The epilogues round ONCE, fp32 accumulator -> f16 (the bf16 instantiations reproduce the reference's
+// bf16 op-by-op roundings: Linear output, rotation, silu, product): STORE, ROPE (rotation on the fp32 accumulators), SWIGLU
+// (silu(gate) * up in fp32) and RESIDUAL_F32 (nothing rounded).  Values that do not fit fp16 (|v| >= 65520 -> inf) set the device's
+// overflow flag word `ovf` (common.h h2_nonfinite): the host turns it into an error instead of a silently saturated embedding.
+template <int EPI, bool PERSIST, bool F16 = false>
 __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W_all,
                                                       uint16_t* C, const uint16_t* Rsd, int64_t M_all,
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                                                       int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope,
-                                                      unsigned int* tile_ctr, GemmSecond second) {
+                                                      unsigned int* tile_ctr, GemmSecond second, unsigned int* ovf) {
+  static_assert(!F16 || EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_ROPE || EPI == GRIT_EPI_SWIGLU || EPI == GRIT_EPI_RESIDUAL_F32,
+                "fp16 operands: forward epilogues only");
+  using frag_t = std::conditional_t<F16, f16x8_t, bf16x8_t>;
+  uint32_t ovf_acc = 0;                                        // F16: OR of h2_nonfinite() over everything this lane stores
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // pair launch (non-persistent, dense): pick the problem of this workgroup from its position in the XCD-remapped order of the WHOLE
   // grid, then continue with that problem's operands and a problem-local tile id (remap = 3: "already remapped")
@@ -360,15 +374,15 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   };
   zero_acc();
 
-  bf16x8_t wf0[2][2][2], wf1[2][2], xf[4][2];                      // [buffer][fragment][k-step]
+  frag_t wf0[2][2][2], wf1[2][2], xf[4][2];                        // [buffer][fragment][k-step]
 #define GRIT_READ_W(WF, H, SB)                                                                        \
   _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-      WF[jj][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + w_off + (H) * HALF_BYTES + jj * 2048 + s_off[ks])
+      WF[jj][ks] = *reinterpret_cast<const frag_t*>((SB) + w_off + (H) * HALF_BYTES + jj * 2048 + s_off[ks])
 #define GRIT_READ_X(H, SB)                                                                            \
   _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-      xf[ii][ks] = *reinterpret_cast<const bf16x8_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
+      xf[ii][ks] = *reinterpret_cast<const frag_t*>((SB) + a_off + (H) * HALF_BYTES + ii * 2048 + s_off[ks])
 // The barrier BEHIND an MFMA segment is executed GRIT_GEMM_BAR_EARLY products before the segment's end (round 4; default 1, i.e. in
 // front of the LAST product).  That barrier only hands the matrix pipe to the other wave group -- this wave's LDS reads completed at
 // the top of the segment and the products touch registers only, so every hazard rule above holds with the barrier anywhere inside the
@@ -397,7 +411,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                               \
       const int ks = q_ >> 3, ii = (q_ >> 1) & 3, jj = q_ & 1;                                        \
       acc[(I0) + ii][(J0) + jj] =                                                                     \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj], 0, 0, 0); \
+          mma16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj]);                                   \
       if (q_ == 15 - (GRIT_GEMM_BAR_EARLY)) {                                                         \
         GRIT_BARRIER();                                                                               \
         GRIT_TAIL_PRIO();                                                                             \
@@ -417,7 +431,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
       _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                \
         _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                              \
           acc[(I0) + ii][(J0) + jj] =                                                                 \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj], 0, 0, 0); \
+              mma16(WF[jj][ks], xf[ii][ks], acc[(I0) + ii][(J0) + jj]);                                   \
     __builtin_amdgcn_s_setprio(0);                                                                    \
   } while (0)
 #endif
@@ -550,8 +564,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t xr = pack2bf_hw(acc[i][p2][r], acc[i][p2 + 2][r]);     // q/k = bf16(linear) first (:655-657)
-            const float x1 = bflo(xr), x2 = bfhi(xr);
+            float x1 = acc[i][p2][r], x2 = acc[i][p2 + 2][r];                     // F16: the rotation runs on the fp32 accumulators
+            if constexpr (!F16) {
+              const uint32_t xr = pack2bf_hw(x1, x2);                             // q/k = bf16(linear) first (:655-657)
+              x1 = bflo(xr); x2 = bfhi(xr);
+            }
             acc[i][p2][r] = rope_lo(x1, x2, cc[r], ss[r]);
             acc[i][p2 + 2][r] = rope_hi(x1, x2, cc[r], ss[r]);
           }
@@ -582,18 +599,25 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
         float o0[4], o1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          if constexpr (F16) {            // one rounding: silu(gate) * up in fp32, rounded to f16 by the store below
+            o0[r] = silu_f(acc[i][0][r]) * acc[i][1][r];
+            o1[r] = silu_f(acc[i][2][r]) * acc[i][3][r];
+          } else {
           // bf16 roundings through v_cvt_pk_bf16_f32 (RNE, two per instruction) instead of the 5-op bit trick
           const uint32_t gu0 = pack2bf_hw(acc[i][0][r], acc[i][1][r]), gu1 = pack2bf_hw(acc[i][2][r], acc[i][3][r]);
           const uint32_t ss = pack2bf_hw(silu_f(bflo(gu0)), silu_f(bflo(gu1)));
           o0[r] = bflo(ss) * bfhi(gu0);
           o1[r] = bfhi(ss) * bfhi(gu1);
+          }
           const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o0[r]), __float_as_uint(o1[r]), false, false);
           o0[r] = __uint_as_float(sw[0]); o1[r] = __uint_as_float(sw[1]);
         }
         const int oc = (nb >> 1) + (kq & 1) * 16 + (kq >> 1) * 8;
-        if (2 * oc < N)
-          *reinterpret_cast<uint4*>(C + m * ldc + oc) = make_uint4(pack2bf_hw(o0[0], o0[1]), pack2bf_hw(o0[2], o0[3]), pack2bf_hw(o1[0], o1[1]),
-                                                                  pack2bf_hw(o1[2], o1[3]));
+        if (2 * oc < N) {
+          const uint4 ov = make_uint4(pack2_op<F16>(o0[0], o0[1]), pack2_op<F16>(o0[2], o0[3]), pack2_op<F16>(o1[0], o1[1]), pack2_op<F16>(o1[2], o1[3]));
+          if constexpr (F16) ovf_acc |= h2_nonfinite(ov.x) | h2_nonfinite(ov.y) | h2_nonfinite(ov.z) | h2_nonfinite(ov.w);
+          *reinterpret_cast<uint4*>(C + m * ldc + oc) = ov;
+        }
         if constexpr (EPI == GRIT_EPI_SWIGLU_STACKED_SAVE) {
           // the bf16 pre-activations the backward pass needs, [gate | up] at the SAME columns as the activation (the exchange that gives
           // the lane 8 consecutive activation columns gives it the 8 matching gate and up columns)
@@ -657,7 +681,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           *reinterpret_cast<uint4*>(C + m * ldc + N + n) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
           continue;
         }
-        const uint4 pk = make_uint4(pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3]), pack2bf_hw(v[4], v[5]), pack2bf_hw(v[6], v[7]));
+        const uint4 pk = make_uint4(pack2_op<F16>(v[0], v[1]), pack2_op<F16>(v[2], v[3]), pack2_op<F16>(v[4], v[5]), pack2_op<F16>(v[6], v[7]));
+        if constexpr (F16) ovf_acc |= h2_nonfinite(pk.x) | h2_nonfinite(pk.y) | h2_nonfinite(pk.z) | h2_nonfinite(pk.w);
         *reinterpret_cast<uint4*>(C + m * ldc + n) = pk;
       }
     }
@@ -774,8 +799,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
             const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const uint32_t xr = pack2bf_hw(acc[i][p2][r], acc[i][p2 + 2][r]);   // q/k = bf16(linear) first (:655-657)
-              const float x1 = bflo(xr), x2 = bfhi(xr);
+              float x1 = acc[i][p2][r], x2 = acc[i][p2 + 2][r];
+              if constexpr (!F16) {
+                const uint32_t xr = pack2bf_hw(x1, x2);                           // q/k = bf16(linear) first (:655-657)
+                x1 = bflo(xr); x2 = bfhi(xr);
+              }
               acc[i][p2][r] = rope_lo(x1, x2, cc[r], ss[r]);
               acc[i][p2 + 2][r] = rope_hi(x1, x2, cc[r], ss[r]);
             }
@@ -787,17 +815,23 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
         float o0[4], o1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          if constexpr (F16) {
+            o0[r] = silu_f(acc[i][0][r]) * acc[i][1][r];
+            o1[r] = silu_f(acc[i][2][r]) * acc[i][3][r];
+          } else {
           const uint32_t gu0 = pack2bf_hw(acc[i][0][r], acc[i][1][r]), gu1 = pack2bf_hw(acc[i][2][r], acc[i][3][r]);
           const uint32_t ss = pack2bf_hw(silu_f(bflo(gu0)), silu_f(bflo(gu1)));
           o0[r] = bflo(ss) * bfhi(gu0);
           o1[r] = bfhi(ss) * bfhi(gu1);
+          }
           const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o0[r]), __float_as_uint(o1[r]), false, false);
           o0[r] = __uint_as_float(sw[0]); o1[r] = __uint_as_float(sw[1]);
         }
         // 16 rows x 64 B (32 output columns of the wave): unit q of the row, swizzled by (row >> 1) & 3
         const int q = (kq & 1) * 2 + (kq >> 1);
-        *reinterpret_cast<uint4*>(xb + frow * 64 + ((q ^ ((frow >> 1) & 3)) << 4)) =
-            make_uint4(pack2bf_hw(o0[0], o0[1]), pack2bf_hw(o0[2], o0[3]), pack2bf_hw(o1[0], o1[1]), pack2bf_hw(o1[2], o1[3]));
+        const uint4 ov = make_uint4(pack2_op<F16>(o0[0], o0[1]), pack2_op<F16>(o0[2], o0[3]), pack2_op<F16>(o1[0], o1[1]), pack2_op<F16>(o1[2], o1[3]));
+        if constexpr (F16) ovf_acc |= h2_nonfinite(ov.x) | h2_nonfinite(ov.y) | h2_nonfinite(ov.z) | h2_nonfinite(ov.w);
+        *reinterpret_cast<uint4*>(xb + frow * 64 + ((q ^ ((frow >> 1) & 3)) << 4)) = ov;
       } else {
 #pragma unroll
         for (int jp = 0; jp < 4; jp += 2) {
@@ -808,8 +842,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
             lo[r] = __uint_as_float(sw[0]); hi4[r] = __uint_as_float(sw[1]);
           }
           const int pidx = (jp + (kq & 1)) * 2 + (kq >> 1);                      // 16-byte unit of the row: fragment jp + (kq & 1), half kq >> 1
-          *reinterpret_cast<uint4*>(xb + frow * 128 + ((pidx ^ (frow & 7)) << 4)) =
-              make_uint4(pack2bf_hw(lo[0], lo[1]), pack2bf_hw(lo[2], lo[3]), pack2bf_hw(hi4[0], hi4[1]), pack2bf_hw(hi4[2], hi4[3]));
+          const uint4 ov = make_uint4(pack2_op<F16>(lo[0], lo[1]), pack2_op<F16>(lo[2], lo[3]), pack2_op<F16>(hi4[0], hi4[1]), pack2_op<F16>(hi4[2], hi4[3]));
+          if constexpr (F16) ovf_acc |= h2_nonfinite(ov.x) | h2_nonfinite(ov.y) | h2_nonfinite(ov.z) | h2_nonfinite(ov.w);
+          *reinterpret_cast<uint4*>(xb + frow * 128 + ((pidx ^ (frow & 7)) << 4)) = ov;
         }
       }
       asm volatile("" ::: "memory");
@@ -950,6 +985,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GRIT_SEG_FENCE();
   }
+  if constexpr (F16) {
+    if (ovf_acc != 0 && ovf != nullptr) atomicOr(ovf, 1u);     // (rows beyond M are computed from clamped, valid rows: no false alarms)
+  }
 #undef GRIT_READ_W
 #undef GRIT_PREFETCH_OFF
 #undef GRIT_OFF_NOW
@@ -1052,10 +1090,15 @@ static void ensure_lds_optin(KernelT kernel, std::atomic<uint64_t>& done, int by
   }
 }
 
-template <int EPI>
+template <int EPI, bool F16 = false>
 static int launch_gemm(const void* A, const void* W, void* C, const void* R, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                        int64_t ldc, int64_t ldr, hipStream_t st, GemmGroups grp = GemmGroups{nullptr, nullptr, 0, 0},
                        GemmRope rope = GemmRope{nullptr, nullptr, nullptr, 0, 0}) {
+  unsigned int* ovf = nullptr;
+  if constexpr (F16) {
+    ovf = f16_flag_ptr();
+    GRIT_REQUIRE(ovf != nullptr, GRIT_E_LAUNCH, "grit_gemm_f16_nt: the overflow flag word of this device is not reachable");
+  }
   const int tiles_m = grp.counts ? (int)(M / BM) + grp.n_groups : (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
   static std::atomic<uint64_t> optin{0}, optin_p{0};
   const GemmKnobs& kn = gemm_knobs();
@@ -1075,19 +1118,19 @@ static int launch_gemm(const void* A, const void* W, void* C, const void* R, int
       n_cu % 8 == 0 && off32) {
     unsigned int* ctr = next_counter_set(st);
     if (ctr != nullptr) {
-      ensure_lds_optin(gemm_bf16_nt_k<EPI, true>, optin_p, PERSIST_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, true>), dim3((unsigned)n_cu), dim3(512), PERSIST_LDS_BYTES, st, (const uint16_t*)A,
+      ensure_lds_optin(gemm_bf16_nt_k<EPI, true, F16>, optin_p, PERSIST_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, true, F16>), dim3((unsigned)n_cu), dim3(512), PERSIST_LDS_BYTES, st, (const uint16_t*)A,
                          (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm,
-                         remap_mode, grp, rope, ctr, GemmSecond{});
+                         remap_mode, grp, rope, ctr, GemmSecond{}, ovf);
       GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt (persistent)");
       return GRIT_OK;
     }
     (void)hipGetLastError();          // no counter set (symbol lookup / memset refused, e.g. inside a stream capture): per-tile launch
   }
-  ensure_lds_optin(gemm_bf16_nt_k<EPI, false>, optin, 2 * STAGE_BYTES);
-  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
+  ensure_lds_optin(gemm_bf16_nt_k<EPI, false, F16>, optin, 2 * STAGE_BYTES);
+  hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false, F16>), dim3(nblocks), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A, (const uint16_t*)W,
                      (uint16_t*)C, (const uint16_t*)R, M, N, K, lda, ldw, ldc, ldr, tiles_m, tiles_n, kn.gm, remap_mode, grp, rope,
-                     (unsigned int*)nullptr, GemmSecond{});
+                     (unsigned int*)nullptr, GemmSecond{}, ovf);
   GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt");
   return GRIT_OK;
 }
@@ -1103,7 +1146,8 @@ static int launch_gemm_pair(const void* A1, const void* W1, void* C1, const void
   ensure_lds_optin(gemm_bf16_nt_k<EPI, false>, optin, 2 * STAGE_BYTES);
   hipLaunchKernelGGL((gemm_bf16_nt_k<EPI, false>), dim3((unsigned)(tm1 * tn1 + tm2 * tn2)), dim3(512), 2 * STAGE_BYTES, st, (const uint16_t*)A1,
                      (const uint16_t*)W1, (uint16_t*)C1, (const uint16_t*)R1, M1, N1, K, lda1, ldw1, ldc1, ldr1, tm1, tn1, kn.gm, 1,
-                     GemmGroups{nullptr, nullptr, 0, 0}, GemmRope{nullptr, nullptr, nullptr, 0, 0}, (unsigned int*)nullptr, sec);
+                     GemmGroups{nullptr, nullptr, 0, 0}, GemmRope{nullptr, nullptr, nullptr, 0, 0}, (unsigned int*)nullptr, sec,
+                     (unsigned int*)nullptr);
   GRIT_CHECK_LAUNCH("grit_gemm_bf16_nt_pair");
   return GRIT_OK;
 }
@@ -1280,4 +1324,58 @@ extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t 
       GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_bf16_nt: unknown epilogue %d", epilogue);
   }
   return GRIT_OK;
+}
+
+// ---- fp16-operand instantiations (the encoder's "f16_operands" precision policy; forward only, dense) ----
+// Same contract as grit_gemm_bf16_nt with A, W (and C for STORE / SWIGLU) holding IEEE fp16.  STORE: C = f16(acc); SWIGLU: C =
+// f16(silu(gate) * up) from the fp32 accumulators (one rounding; interleaved weight rows, grit_swiglu_block()); RESIDUAL_F32: C (fp32)
+// = residual (fp32) + acc.  A result beyond the fp16 range sets the device's overflow flag (grit_f16_overflow_flag).
+extern "C" int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                                int64_t ldc, int epilogue, const void* residual, int64_t ldr, void* stream) {
+  if (M == 0) return GRIT_OK;
+  GRIT_REQUIRE(A && W && C, GRIT_E_BADARG, "grit_gemm_f16_nt: null pointer");
+  GRIT_REQUIRE(M >= 0 && N > 0 && K > 0, GRIT_E_BADARG, "grit_gemm_f16_nt: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+  GRIT_REQUIRE(K % 64 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt: K=%d must be a multiple of 64", K);
+  GRIT_REQUIRE(N % 16 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt: N=%d must be a multiple of 16", N);
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K, GRIT_E_BADARG,
+               "grit_gemm_f16_nt: bad leading dimensions lda=%lld ldw=%lld ldc=%lld", (long long)lda, (long long)ldw, (long long)ldc);
+  GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C), GRIT_E_BADARG, "grit_gemm_f16_nt: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt: too many tiles");
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case GRIT_EPI_STORE:
+      GRIT_REQUIRE(ldc >= N, GRIT_E_BADARG, "grit_gemm_f16_nt: ldc < N");
+      return launch_gemm<GRIT_EPI_STORE, true>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    case GRIT_EPI_RESIDUAL_F32:
+      GRIT_REQUIRE(residual && ldr % 4 == 0 && ldr >= N && ldc >= N && ldc % 4 == 0 && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_f16_nt: RESIDUAL_F32 epilogue needs an fp32 residual with ldr >= N (C and residual are fp32, ldc / ldr in floats)");
+      return launch_gemm<GRIT_EPI_RESIDUAL_F32, true>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
+    case GRIT_EPI_SWIGLU:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU, true>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    default:
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_f16_nt: epilogue %d not available (STORE, SWIGLU, RESIDUAL_F32)", epilogue);
+  }
+  return GRIT_OK;
+}
+
+// grit_gemm_bf16_nt_rope on fp16 operands: the rotation runs on the fp32 accumulators with the UNROUNDED fp32 tables the caller passes,
+// q | k | v are rounded once, to fp16.
+extern "C" int grit_gemm_f16_nt_rope(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
+                                     const float* cos_tab, const float* sin_tab, const int32_t* positions, int S, int table_rows,
+                                     int rope_cols, void* stream) {
+  if (M == 0) return GRIT_OK;
+  GRIT_REQUIRE(A && W && C && cos_tab && sin_tab, GRIT_E_BADARG, "grit_gemm_f16_nt_rope: null pointer");
+  GRIT_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, GRIT_E_BADARG, "grit_gemm_f16_nt_rope: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+  GRIT_REQUIRE(N % 128 == 0 && rope_cols % 128 == 0 && rope_cols >= 0 && rope_cols <= N, GRIT_E_UNSUPPORTED,
+               "grit_gemm_f16_nt_rope: N=%d and rope_cols=%d must be multiples of the head size 128", N, rope_cols);
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N, GRIT_E_BADARG,
+               "grit_gemm_f16_nt_rope: bad leading dimensions");
+  GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(cos_tab) && aligned16(sin_tab), GRIT_E_BADARG,
+               "grit_gemm_f16_nt_rope: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((positions != nullptr) ? table_rows > 0 : (S > 0 && table_rows >= S), GRIT_E_BADARG,
+               "grit_gemm_f16_nt_rope: positions or S (<= table rows) required");
+  GRIT_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt_rope: too many tiles");
+  const GemmRope rope{cos_tab, sin_tab, positions, S > 0 ? S : 1, rope_cols};
+  return launch_gemm<GRIT_EPI_ROPE, true>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, (hipStream_t)stream, GemmGroups{nullptr, nullptr, 0, 0}, rope);
 }

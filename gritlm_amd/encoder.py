@@ -25,6 +25,18 @@ from . import ops
 from ._lib import EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_SWIGLU, GritHipError
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+
+# Precision policies of the forward pass (DESIGN "precision"):
+#   "bf16"           the reference's bf16 arithmetic, op by op (hidden_states rounded to bf16 after every residual add, the Linear output
+#                    before it, q|k|v before the rotation, gate / up / silu separately): what its bf16 run computes.  Default.
+#   "fp32_residual"  bf16 MFMA operands, residual stream in fp32 (GRIT_EPI_RESIDUAL_F32 / grit_rmsnorm_fwd_f32in).
+#   "f16_operands"   fp32 residual stream AND every MFMA operand (RMSNorm output, q|k|v, P, attention output, SwiGLU activation, weights)
+#                    in IEEE fp16, each rounded once from fp32: same MFMA rate, 3 more mantissa bits -- the policy that meets the
+#                    north-star tolerance (1 - cos < 1e-4 against the reference's fp32 run) at depth 32.  bf16 checkpoints convert to fp16
+#                    exactly for 6.1e-5 <= |w| < 65520; an activation beyond the fp16 range raises (check_f16_overflow), it never saturates
+#                    silently.  Dense (Mistral) models, bidirectional attention.
+PRECISIONS = ("bf16", "fp32_residual", "f16_operands")
 
 
 @dataclass
@@ -96,7 +108,7 @@ def rope_tables(seq_len: int, head_dim: int, theta: float, round_bf16: bool, dev
 
 
 class _Layer:
-    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "wgate", "w13", "w2")
+    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "wgate", "w13", "w2", "h16")     # h16: fp16 copies (wqkv, wo, wgu, wdown), built on first use
 
 
 def sliding_window_keys(sliding_window, attn_implementation: str | None = "sdpa") -> int:
@@ -139,11 +151,55 @@ class MistralEncoderEngine:
         self.causal = False             # True: causal attention ('cc' embedding attention of the reference's attn string)
         self.window_keys = 0            # causal attention: keys a query sees (sliding_window_keys(); 0 = no window).  The bidirectional
                                         # path ignores it, as the reference
-        # Precision policy of the residual stream (DESIGN §2 "depth"): False = the reference's bf16 arithmetic (hidden_states rounded to
-        # bf16 after every residual add, the Linear output rounded before it: what its bf16 run computes); True = the stream lives in
-        # fp32 ([T,H] fp32 workspace, GRIT_EPI_RESIDUAL_F32 / grit_rmsnorm_fwd_f32in): every GEMM still takes bf16 operands, but nothing
-        # accumulates rounding error across layers -- closer to the reference's fp32 run than its own bf16 run is.
-        self.residual_fp32 = False
+        self.precision = "bf16"         # one of PRECISIONS (module docstring above)
+        self.f16_weight_stats = None    # f16_operands: {"subnormal": n, "overflow": n, "total": n} of the bf16 -> fp16 weight conversion
+
+    # `residual_fp32` (rounds 3-4: a bool) is kept as a view of `precision`: True <-> the stream lives in fp32
+    @property
+    def residual_fp32(self) -> bool:
+        return self.precision != "bf16"
+
+    @residual_fp32.setter
+    def residual_fp32(self, v: bool):
+        self.precision = "fp32_residual" if v else "bf16"
+
+    def set_precision(self, precision: str):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision={precision!r}: one of {PRECISIONS}")
+        if precision == "f16_operands":
+            if self.cfg.num_local_experts:
+                raise GritHipError("native encoder: precision='f16_operands' is built for the dense (Mistral) MLP only")
+            if self.causal:
+                raise GritHipError("native encoder: precision='f16_operands' is built for bidirectional attention only")
+        self.precision = precision
+        return self
+
+    def _f16_weights(self, L: _Layer):
+        """fp16 copies of a layer's four GEMM weights (14.5 GB for the 7B shape next to 288 GB of HBM), converted on first use.  bf16 ->
+        fp16 is exact for normal fp16 values; what is not exact is COUNTED: |w| < 2^-14 becomes subnormal (absolute error <= 3e-8),
+        |w| >= 65520 would become inf and is refused."""
+        h = getattr(L, "h16", None)
+        if h is None:
+            st = self.f16_weight_stats or {"subnormal": 0, "overflow": 0, "total": 0}
+            h = []
+            for w in (L.wqkv, L.wo, L.wgu, L.wdown):
+                a = w.abs()
+                st["subnormal"] += int(((a < 6.103515625e-05) & (a > 0)).sum())
+                st["overflow"] += int((a >= 65520.0).sum())
+                st["total"] += w.numel()
+                h.append(w.to(F16))
+            if st["overflow"]:
+                raise GritHipError(f"precision='f16_operands': {st['overflow']} weights exceed the fp16 range (|w| >= 65520)")
+            self.f16_weight_stats = st
+            L.h16 = h = tuple(h)
+        return h
+
+    def check_f16_overflow(self, clear: bool = True) -> None:
+        """Raise if a kernel of the f16_operands policy produced a value beyond the fp16 range since the last check (waits for the
+        device's current stream: call it where the embeddings are copied to the host anyway)."""
+        if self.precision == "f16_operands" and ops.f16_overflow_flag(self.device, clear):
+            raise GritHipError("precision='f16_operands': an activation exceeded the fp16 range (|v| >= 65520) in this forward pass; "
+                               "the embeddings of this call are invalid -- run this model with precision='fp32_residual' or 'bf16'")
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -222,10 +278,10 @@ class MistralEncoderEngine:
         for L in self.layers:
             R = _Layer()
             for k in _Layer.__slots__:
-                if hasattr(L, k):
+                if hasattr(L, k) and k != "h16":                            # (fp16 copies are rebuilt on the replica's first use)
                     setattr(R, k, mv(getattr(L, k)))
             eng.layers.append(R)
-        eng.causal, eng.window_keys, eng.residual_fp32 = self.causal, self.window_keys, self.residual_fp32
+        eng.causal, eng.window_keys, eng.precision = self.causal, self.window_keys, self.precision
         return eng
 
     def to_hf_state_dict(self) -> dict:
@@ -258,27 +314,32 @@ class MistralEncoderEngine:
         """Activation buffers for T token rows: one allocation sized for the largest T seen, handed out as row-slices
         (ragged / packed batches change T every call)."""
         cap = self._ws.get("cap", 0)
-        if cap and (self._ws["h"].dtype == torch.float32) != bool(self.residual_fp32):
-            cap = 0                       # the precision policy changed: the residual stream's buffer has the other dtype
+        if cap and self._ws.get("policy") != self.precision:
+            cap = 0                       # the precision policy changed: the residual stream / the operands have another dtype
         if cap < T:
             c, dev = self.cfg, self.device
             qkv_w = (c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim
             self._ws.clear()
-            mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
+            opd = F16 if self.precision == "f16_operands" else BF16
+            mk = lambda n: torch.empty((T, n), dtype=opd, device=dev)
             h = torch.empty((T, c.hidden_size), dtype=torch.float32 if self.residual_fp32 else BF16, device=dev)
-            self._ws.update(cap=T, h=h, x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim))
+            self._ws.update(cap=T, policy=self.precision, h=h, x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim))
+            # last_hidden_state stays bf16 in every policy (the pooling kernels' input; one rounding of the final RMSNorm, averaged over the
+            # sequence by the pooling: 3e-7 of 1 - cos, profiles/r05_precision_budget.json "only_out_bf16")
+            self._ws.update(xo=self._ws["x"] if opd == BF16 else torch.empty((T, c.hidden_size), dtype=BF16, device=dev))
             if c.num_local_experts:           # every token visits two experts: 2T rows of expert activations
                 self._ws.update(act2=torch.empty((2 * T, c.intermediate_size), dtype=BF16, device=dev),
                                 y2=torch.empty((2 * T, c.hidden_size), dtype=BF16, device=dev))
             else:
                 self._ws.update(act=mk(c.intermediate_size))
-        return {k: (v[:2 * T] if k in ("act2", "y2") else v[:T]) for k, v in self._ws.items() if k != "cap"}
+        return {k: (v[:2 * T] if k in ("act2", "y2") else v[:T]) for k, v in self._ws.items() if k not in ("cap", "policy")}
 
     def _mlp(self, L: _Layer, x: torch.Tensor, h: torch.Tensor, ws: dict):
         """h += MLP(x) in place (x = post-attention RMSNorm output): dense SwiGLU MLP or Mixtral's sparse-MoE block."""
         if not self.cfg.num_local_experts:
-            ops.gemm_nt(x, L.wgu, out=ws["act"], epilogue=EPI_SWIGLU)
-            ops.gemm_nt(ws["act"], L.wdown, out=h, epilogue=self._epi_res(), residual=h)
+            _, _, wgu, wdown = self._weights(L)
+            ops.gemm_nt(x, wgu, out=ws["act"], epilogue=EPI_SWIGLU)
+            ops.gemm_nt(ws["act"], wdown, out=h, epilogue=self._epi_res(), residual=h)
             return
         if self.residual_fp32:
             raise GritHipError("native encoder: residual_fp32 is built for the dense (Mistral) MLP only")
@@ -293,15 +354,20 @@ class MistralEncoderEngine:
     def _epi_res(self) -> int:
         return EPI_RESIDUAL_F32 if self.residual_fp32 else EPI_RESIDUAL
 
+    def _weights(self, L: _Layer):
+        """(wqkv, wo, wgu, wdown) in the operand format of the current policy"""
+        return self._f16_weights(L) if self.precision == "f16_operands" else (L.wqkv, L.wo, L.wgu, L.wdown)
+
     def _window(self, S: int) -> int:
         """``window`` argument of the attention kernels for sequences of up to S tokens (0: every earlier key is inside the window)."""
         return int(self.window_keys) if self.causal and 0 < self.window_keys < S else 0
 
     def _rope_tables(self, S: int):
-        t = self._rope.get(S)
+        rounded = self.rope_bf16 and self.precision != "f16_operands"      # f16_operands: the unrounded fp32 tables (fp32 rotation)
+        t = self._rope.get((S, rounded))
         if t is None:
-            t = rope_tables(S, self.cfg.head_dim, self.cfg.rope_theta, self.rope_bf16, self.device)
-            self._rope[S] = t
+            t = rope_tables(S, self.cfg.head_dim, self.cfg.rope_theta, rounded, self.device)
+            self._rope[(S, rounded)] = t
         return t
 
     # ------------------------------------------------------------------ forward
@@ -322,25 +388,29 @@ class MistralEncoderEngine:
         if attention_mask is None:
             attention_mask = torch.ones((B, S), dtype=torch.int64, device=self.device)
         mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        if self.precision == "f16_operands":
+            self.set_precision(self.precision)        # (re-checks the model kind / attention mode the policy is built for)
         ws = self._workspace(T)
-        h, x, qkv, ctx = ws["h"], ws["x"], ws["qkv"], ws["ctx"]
+        h, x, qkv, ctx, xo = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["xo"]
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         cos, sin = self._rope_tables(S)
         bits = ops.mask_pack(mask)
         ops.embed_gather(self.embed, ids, out=h)
         kv = []
         for L in self.layers:
+            wqkv, wo = self._weights(L)[:2]
             ops.rmsnorm(h, L.ln1, eps, out=x)
-            ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)       # q/k/v projections + RoPE in the epilogue
-            if return_kv:
+            ops.gemm_nt_rope(x, wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)         # q/k/v projections + RoPE in the epilogue
+            if return_kv:                                                               # (the KV cache format is bf16 in every policy)
                 kvw = qkv.view(B, S, nq + 2 * nkv, d)
-                kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).contiguous(), kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).contiguous()))
+                kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).to(BF16).contiguous(),
+                           kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).to(BF16).contiguous()))
             ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, causal=self.causal, window=window)
-            ops.gemm_nt(ctx, L.wo, out=h, epilogue=self._epi_res(), residual=h)
+            ops.gemm_nt(ctx, wo, out=h, epilogue=self._epi_res(), residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)
-        ops.rmsnorm(h, self.norm, eps, out=x)
-        out = x.view(B, S, c.hidden_size)
+        ops.rmsnorm(h, self.norm, eps, out=xo)
+        out = xo.view(B, S, c.hidden_size)
         out = out if borrow else out.clone()
         return (out, kv) if return_kv else out
 
@@ -401,20 +471,23 @@ class MistralEncoderEngine:
                 mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
                 h = self.forward(input_ids.to(device=self.device, dtype=torch.int64), mask, borrow=True)
                 return ops.pool_norm(h, mask, method, normalize, instr_len)
+            if self.precision == "f16_operands":
+                self.set_precision(self.precision)
             ws = self._workspace(T)
-            h, x, qkv, ctx = ws["h"], ws["x"], ws["qkv"], ws["ctx"]
+            h, x, qkv, ctx, xo = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["xo"]
             nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
             cos, sin = self._rope_tables(S)
             ops.embed_gather(self.embed, pids, out=h)
             for L in self.layers:
+                wqkv, wo = self._weights(L)[:2]
                 ops.rmsnorm(h, L.ln1, eps, out=x)
-                ops.gemm_nt_rope(x, L.wqkv, cos, sin, (nq + nkv) * d, positions=pos, out=qkv)
+                ops.gemm_nt_rope(x, wqkv, cos, sin, (nq + nkv) * d, positions=pos, out=qkv)
                 ops.attn_bidir_varlen(qkv, cu, max_len, nq, nkv, d, out=ctx, causal=self.causal, window=window)
-                ops.gemm_nt(ctx, L.wo, out=h, epilogue=self._epi_res(), residual=h)
+                ops.gemm_nt(ctx, wo, out=h, epilogue=self._epi_res(), residual=h)
                 ops.rmsnorm(h, L.ln2, eps, out=x)
                 self._mlp(L, x, h, ws)
-            ops.rmsnorm(h, self.norm, eps, out=x)
-            return ops.pool_norm_varlen(x, cu, method, normalize, instr_len)
+            ops.rmsnorm(h, self.norm, eps, out=xo)
+            return ops.pool_norm_varlen(xo, cu, method, normalize, instr_len)
 
     def flops_per_token(self, S: int) -> float:
         """Algorithmic forward FLOPs per token: projections + MLP + attention core."""

@@ -68,7 +68,14 @@ class GritLM(torch.nn.Module):
         # PRIVATE config._attn_implementation, whose default differs between transformers releases ('eager' on 4.36-4.x, None on 5.x)
         self._attn_impl = kwargs.get("attn_implementation")
         devices = kwargs.pop("devices", None)   # extension: the GPUs in-process multi-GPU encode uses (default: every visible one)
-        residual_fp32 = bool(kwargs.pop("residual_fp32", False))   # extension: fp32 residual stream in the native engine
+        # extension: precision policy of the native engine (gritlm_amd.encoder.PRECISIONS): "bf16" = the reference's bf16 arithmetic
+        # (default), "fp32_residual", "f16_operands" (fp32 stream + fp16 MFMA operands: 1 - cos < 1e-4 against the reference's fp32 run at
+        # depth 32).  `residual_fp32=True` (round 4) is kept as an alias of precision="fp32_residual".
+        residual_fp32 = bool(kwargs.pop("residual_fp32", False))
+        precision = kwargs.pop("precision", None) or ("fp32_residual" if residual_fp32 else "bf16")
+        from .encoder import PRECISIONS
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision={precision!r}: one of {PRECISIONS}")
         if mode == "embedding":
             if any(tag in model_name_or_path for tag in ("gtr", "t5", "instructor")):
                 from transformers import T5EncoderModel
@@ -94,7 +101,7 @@ class GritLM(torch.nn.Module):
         self.device = device
         self.num_gpus = 1
         self.engines = []            # in-process multi-GPU encode: one engine replica per GPU (set by _parallelize)
-        self._residual_fp32 = residual_fp32
+        self._precision = precision
         self.embed_eos = embed_eos
         self.attn = attn
         if (attn is not None) and attn not in _VALID_ATTN:
@@ -156,7 +163,7 @@ class GritLM(torch.nn.Module):
             print(f"GritLM: causal embedding attention with config.sliding_window={cfg.sliding_window} on the '{impl}' path of the reference: "
                   + (f"a query sees {self.engine.window_keys} keys" if self.engine.window_keys else "no window (the sdpa path applies none)")
                   + "; pass attn_implementation= to choose, or set engine.window_keys")
-        self.engine.residual_fp32 = bool(getattr(self, "_residual_fp32", False))
+        self.engine.set_precision(getattr(self, "_precision", "bf16"))
 
     def _parallelize(self, devices=None):
         """The reference wraps an embedding model in ``nn.DataParallel`` over every visible GPU and multiplies ``batch_size`` by their
@@ -174,11 +181,29 @@ class GritLM(torch.nn.Module):
                 self.model = torch.nn.DataParallel(self.model)
             return
         if devices is None:
+            # Inside a one-process-per-GPU launch (torchrun / torch.distributed: every rank sees every GPU unless the launcher pins
+            # CUDA_VISIBLE_DEVICES) each rank owns ONE device: replicating onto all visible GPUs would put world_size copies of the model
+            # on every GPU.  There the engine stays on its own device; pass `devices=[...]` to ask for in-process replicas explicitly.
+            import os
+            in_dist = (torch.distributed.is_available() and torch.distributed.is_initialized()) or any(
+                os.environ.get(k) is not None for k in ("LOCAL_RANK", "RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"))
+            if in_dist:
+                return
             devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
-        devices = [torch.device(d) for d in devices]
+        cur = torch.cuda.current_device()
+        norm, seen = [], set()
+        for d in devices:                        # "cuda" (no index) means the current device; a device named twice is used once
+            d = torch.device(d)
+            if d.type != "cuda":
+                raise ValueError(f"devices={devices}: in-process multi-GPU encode runs on CUDA devices")
+            idx = cur if d.index is None else d.index
+            if idx not in seen:
+                seen.add(idx)
+                norm.append(torch.device("cuda", idx))
+        devices = norm
         if len(devices) <= 1:
             return
-        first = self.engine.device.index if self.engine.device.index is not None else torch.cuda.current_device()
+        first = self.engine.device.index if self.engine.device.index is not None else cur
         self.engines = [self.engine if (d.index == first) else self.engine.replica(d) for d in devices]
         self.num_gpus = len(self.engines)
         print(f"----------Using {self.num_gpus} data-parallel GPUs (one native engine replica each)----------")
@@ -311,6 +336,9 @@ class GritLM(torch.nn.Module):
         else:
             # ONE device->host copy for the whole call (the reference syncs per batch, :164)
             result = torch.cat(chunks, dim=0).to(torch.float32).cpu().numpy()
+        if self.engine is not None and self.engine.precision == "f16_operands":
+            for eng in (getattr(self, "engines", None) or [self.engine]):       # raises if an activation left the fp16 range in this call
+                eng.check_f16_overflow()
         if single:
             result = result[0]
         if get_cache:

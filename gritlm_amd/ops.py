@@ -8,7 +8,7 @@ from . import _lib
 from ._lib import (EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_STORE, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE,
                    POOL_MODES, check)
 
-BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
+BF16, F16, F32, I64, I32 = torch.bfloat16, torch.float16, torch.float32, torch.int64, torch.int32
 
 
 def _stream():
@@ -103,12 +103,16 @@ def embed_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | Non
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
-    """bf16 rows: the reference's bf16 arithmetic.  fp32 rows (the encoder's fp32 residual stream): one rounding, bf16 out."""
+    """bf16 rows: the reference's bf16 arithmetic.  fp32 rows (the encoder's fp32 residual stream): one rounding, bf16 out -- or fp16 out
+    when ``out`` is an fp16 tensor (the f16_operands policy; w stays bf16)."""
     H = x.shape[-1]
     T = x.numel() // H
     if out is None:
         out = torch.empty(x.shape, dtype=BF16, device=x.device)
-    if x.dtype == F32:
+    if x.dtype == F32 and out.dtype == F16:
+        check(_lib.load().grit_rmsnorm_fwd_f32in_f16(_chk(x, F32, "x"), _chk(w, BF16, "w"), _chk(out, F16, "out"), T, H, float(eps), _stream()),
+              "grit_rmsnorm_fwd_f32in_f16")
+    elif x.dtype == F32:
         check(_lib.load().grit_rmsnorm_fwd_f32in(_chk(x, F32, "x"), _chk(w, BF16, "w"), _chk(out, BF16, "out"), T, H, float(eps), _stream()),
               "grit_rmsnorm_fwd_f32in")
     else:
@@ -153,14 +157,19 @@ def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
     T, stride = qkv.shape
     B = cu_seqlens.numel() - 1
     if out is None:
-        out = torch.empty((T, nq * d), dtype=BF16, device=qkv.device)
+        out = torch.empty((T, nq * d), dtype=qkv.dtype, device=qkv.device)
     if scale is None:
         scale = d ** -0.5
     ev = _timer.span("attn_bidir_fwd", 0.0) if _timer is not None else None
     if ev:
         ev[0].record()
     fn, wa = _attn_entry("varlen_fwd", causal, window)
-    check(fn(_chk(qkv, BF16, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, BF16, "out"),
+    odt = BF16
+    if qkv.dtype == F16:            # f16_operands policy (bidirectional only)
+        if causal:
+            raise _lib.GritHipError("attn_bidir_varlen: fp16 operands are built for the bidirectional (embedding) attention only")
+        fn, wa, odt = _lib.load().grit_attn_bidir_varlen_f16_fwd, (), F16
+    check(fn(_chk(qkv, odt, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, odt, "out"),
              0 if lse is None else _chk(lse, F32, "lse"), B, int(max_len), nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()),
           "grit_attn_bidir_varlen_fwd")
     if ev:
@@ -203,7 +212,10 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     N = w.shape[0]
     assert w.shape[1] == K, (a.shape, w.shape)
     n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE) else (2 * N if epilogue == EPI_SWIGLU_BWD else N)
-    odt = F32 if epilogue == EPI_RESIDUAL_F32 else BF16       # RESIDUAL_F32: out and residual are the fp32 residual stream
+    opd = a.dtype if a.dtype == F16 else BF16                 # fp16 operands: the f16_operands policy (STORE, SWIGLU, RESIDUAL_F32)
+    odt = F32 if epilogue == EPI_RESIDUAL_F32 else opd        # RESIDUAL_F32: out and residual are the fp32 residual stream
+    if opd == F16 and epilogue not in (EPI_STORE, EPI_SWIGLU, EPI_RESIDUAL_F32):
+        raise _lib.GritHipError(f"gemm_nt: epilogue {epilogue} is not built for fp16 operands (STORE, SWIGLU, RESIDUAL_F32)")
     if out is None:
         out = torch.empty((M, n_out), dtype=odt, device=a.device)
     assert out.shape == (M, n_out)
@@ -211,11 +223,12 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     if epilogue in (EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD):
         assert residual is not None and residual.shape == (M, 2 * N if epilogue == EPI_SWIGLU_BWD else N)
         rp, ldr = _chk2d(residual, odt, "residual"), residual.stride(0)
-    ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K, tag=f"N={N},K={K},epi={epilogue}") if _timer is not None else None
+    name = "gemm_f16_nt" if opd == F16 else "gemm_bf16_nt"
+    ev = _timer.span(name, 2.0 * M * N * K, tag=f"N={N},K={K},epi={epilogue}") if _timer is not None else None
     if ev:
         ev[0].record()
-    check(_lib.load().grit_gemm_bf16_nt(_chk2d(a, BF16, "a"), _chk2d(w, BF16, "w"), _chk2d(out, odt, "out"), M, N, K, a.stride(0),
-                                        w.stride(0), out.stride(0), epilogue, rp, ldr, _stream()), "grit_gemm_bf16_nt")
+    check(getattr(_lib.load(), "grit_" + name)(_chk2d(a, opd, "a"), _chk2d(w, opd, "w"), _chk2d(out, odt, "out"), M, N, K, a.stride(0),
+                                               w.stride(0), out.stride(0), epilogue, rp, ldr, _stream()), "grit_" + name)
     if ev:
         ev[1].record()
     return out
@@ -248,15 +261,17 @@ def gemm_nt_rope(a: torch.Tensor, w: torch.Tensor, cos: torch.Tensor, sin: torch
     in one launch.  Positions: ``positions`` int32 [M] (packed rows) or row % S."""
     M, K = a.shape
     N = w.shape[0]
+    opd = a.dtype if a.dtype == F16 else BF16                 # fp16 operands: rotation on the fp32 accumulators, one rounding
     if out is None:
-        out = torch.empty((M, N), dtype=BF16, device=a.device)
-    ev = _timer.span("gemm_bf16_nt", 2.0 * M * N * K, tag=f"N={N},K={K},epi=3") if _timer is not None else None
+        out = torch.empty((M, N), dtype=opd, device=a.device)
+    name = "gemm_f16_nt" if opd == F16 else "gemm_bf16_nt"
+    ev = _timer.span(name, 2.0 * M * N * K, tag=f"N={N},K={K},epi=3") if _timer is not None else None
     if ev:
         ev[0].record()
-    check(_lib.load().grit_gemm_bf16_nt_rope(_chk2d(a, BF16, "a"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), M, N, K, a.stride(0), w.stride(0),
-                                             out.stride(0), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"),
-                                             0 if positions is None else _chk(positions, I32, "positions"), int(S), cos.shape[0], int(rope_cols),
-                                             _stream()), "grit_gemm_bf16_nt_rope")
+    check(getattr(_lib.load(), "grit_" + name + "_rope")(_chk2d(a, opd, "a"), _chk2d(w, opd, "w"), _chk2d(out, opd, "out"), M, N, K, a.stride(0),
+                                                         w.stride(0), out.stride(0), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"),
+                                                         0 if positions is None else _chk(positions, I32, "positions"), int(S), cos.shape[0],
+                                                         int(rope_cols), _stream()), "grit_" + name + "_rope")
     if ev:
         ev[1].record()
     return out
@@ -375,6 +390,16 @@ def moe_combine(y: torch.Tensor, rows: torch.Tensor, weights: torch.Tensor, resi
     return out
 
 
+def f16_overflow_flag(device, clear: bool = True) -> bool:
+    """True when a kernel of the f16_operands policy stored an inf / nan on ``device`` since the last clear.  Waits for the device's
+    current stream (one 4-byte D2H copy): call it once per encode, next to the copy of the embeddings."""
+    import ctypes
+    flag = ctypes.c_int(0)
+    with torch.cuda.device(device):
+        check(_lib.load().grit_f16_overflow_flag(ctypes.byref(flag), int(clear), _stream()), "grit_f16_overflow_flag")
+    return bool(flag.value)
+
+
 def mask_pack(mask: torch.Tensor) -> torch.Tensor:
     B, S = mask.shape
     bits = torch.empty((B, (S + 63) // 64), dtype=I64, device=mask.device)   # uint64 payload in int64 storage
@@ -388,14 +413,19 @@ def attn_bidir(qkv: torch.Tensor, key_bits: torch.Tensor, B: int, S: int, nq: in
     T, stride = qkv.shape
     assert T == B * S
     if out is None:
-        out = torch.empty((T, nq * d), dtype=BF16, device=qkv.device)
+        out = torch.empty((T, nq * d), dtype=qkv.dtype, device=qkv.device)
     if scale is None:
         scale = d ** -0.5
     ev = _timer.span("attn_bidir_fwd", 4.0 * B * nq * S * S * d) if _timer is not None else None
     if ev:
         ev[0].record()
     fn, wa = _attn_entry("fwd", causal, window)
-    check(fn(_chk(qkv, BF16, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, BF16, "out"),
+    odt = BF16
+    if qkv.dtype == F16:            # f16_operands policy (bidirectional only)
+        if causal:
+            raise _lib.GritHipError("attn_bidir: fp16 operands are built for the bidirectional (embedding) attention only")
+        fn, wa, odt = _lib.load().grit_attn_bidir_f16_fwd, (), F16
+    check(fn(_chk(qkv, odt, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, odt, "out"),
              0 if lse is None else _chk(lse, F32, "lse"), B, S, nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()), "grit_attn_bidir_fwd")
     if ev:
         ev[1].record()
@@ -680,7 +710,7 @@ def _on_tensor_device(fn):
 
 # Every public function of this module that launches kernels is wrapped; host-only helpers are listed, so a new op is guarded by default
 # and tests/test_abi.py::test_every_public_op_is_device_guarded fails if a launcher slips through.
-_HOST_ONLY = ("set_timer", "check", "attn_decode_workspace")
+_HOST_ONLY = ("set_timer", "check", "attn_decode_workspace", "f16_overflow_flag")
 for _name, _fn in list(globals().items()):
     if callable(_fn) and getattr(_fn, "__module__", None) == __name__ and not _name.startswith("_") and not isinstance(_fn, type) \
             and _name not in _HOST_ONLY:

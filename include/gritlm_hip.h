@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 2
+#define GRIT_ABI_VERSION 3
 
 enum {
   GRIT_OK = 0,
@@ -131,6 +131,41 @@ int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, void* out, fl
  * lse (nullable) is [T, nq]. */
 int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
                                int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+
+/* ---- fp16-operand precision policy of the embedding path ("f16_operands", round 5) ----------------------------------------------
+ * The reference states its outputs in fp32 terms (README cosine tables; north-star tolerance 1 - cos < 1e-4 against the fp32 run of
+ * scripts/modeling_mistral_gritlm.py:936-1096).  With bf16 MFMA operands the error of a 32-layer forward is ~4e-4 even with an fp32
+ * residual stream (profiles/r04_depth_parity.json): the 8-bit mantissa of the operands is the floor.  v_mfma_f32_*_f16 runs at the bf16
+ * rate with 3 more mantissa bits, and bf16 weights convert to fp16 exactly for 6.1e-5 <= |w| < 65520 (smaller ones lose at most 3e-8
+ * absolute).  In this policy the residual stream is fp32 (grit_embed_gather_f32, GRIT_EPI_RESIDUAL_F32) and every MFMA operand --
+ * RMSNorm output, q | k | v, P, the attention output, the SwiGLU activation, the weights -- is fp16, each rounded ONCE from fp32.
+ * Every kernel that rounds to fp16 flags a result beyond the fp16 range (inf / nan stored) in a per-device word that
+ * grit_f16_overflow_flag reads: the host raises instead of returning a silently saturated embedding. */
+
+/* MistralRMSNorm (:84-89) of an fp32 row, y = fp16(w * (x * rsqrt(mean(x^2) + eps))); w bf16, y fp16 [T,H]. */
+int grit_rmsnorm_fwd_f32in_f16(const float* x, const void* w, void* y, int64_t T, int H, float eps, void* stream);
+
+/* grit_gemm_bf16_nt on fp16 operands (A, W fp16; fp32 accumulate).  Epilogues: GRIT_EPI_STORE (C = fp16(acc)), GRIT_EPI_SWIGLU
+ * (C = fp16(silu(gate) * up) evaluated in fp32, interleaved weight rows), GRIT_EPI_RESIDUAL_F32 (C, residual fp32: C = residual + acc). */
+int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int epilogue,
+                     const void* residual, int64_t ldr, void* stream);
+
+/* grit_gemm_bf16_nt_rope on fp16 operands: the rotation (:138-163) runs on the fp32 accumulators with the fp32 tables as passed (build
+ * them unrounded), q | k | v are rounded once, to fp16. */
+int grit_gemm_f16_nt_rope(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
+                          const float* cos_tab, const float* sin_tab, const int32_t* positions, int S, int table_rows, int rope_cols,
+                          void* stream);
+
+/* grit_attn_bidir_fwd / grit_attn_bidir_varlen_fwd with qkv and out in fp16 (P rounded to fp16, fp32 statistics and accumulators). */
+int grit_attn_bidir_f16_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv, int d,
+                            int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+int grit_attn_bidir_varlen_f16_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq, int nkv,
+                                   int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+
+/* *host_flag = 1 if a kernel of this policy stored an inf / nan on the current device since the last clear, else 0.  Enqueues a 4-byte
+ * D2H copy (and, with clear != 0, the reset) on `stream` and WAITS for that stream: the one entry point of this library that
+ * synchronises, meant to be called once per encode() next to the copy of the embeddings. */
+int grit_f16_overflow_flag(int* host_flag, int clear, void* stream);
 
 /* ---- sparse MoE MLP (Mixtral): scripts/modeling_mixtral_gritlm.py:797-882 ---------------------- */
 

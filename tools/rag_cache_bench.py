@@ -55,7 +55,7 @@ m = GritLM.__new__(GritLM)
 torch.nn.Module.__init__(m)
 m.model, m.tokenizer, m.device, m.embedding_attr, m.projection = lm, tok, dev, "model", None
 m.pooling_method, m.normalized, m.attn, m.embed_eos, m.num_gpus, m.engine, m._native = "mean", True, "bbcc", "", 1, None, None
-m.engines, m._residual_fp32 = [], False
+m.engines, m._precision = [], "bf16"
 m.generate = lm.generate
 m._maybe_build_engine()
 t_init = time.perf_counter() - t0
