@@ -385,11 +385,15 @@ FULL_DEPTH_BOUND_FP32_RESIDUAL = 4.5e-4          # measured 2.9e-4 .. 3.4e-4 (op
 #   bench model (32 DISTINCT N(0, 0.02) layers, the first 32 documents of the timed 256 x 512 batch):
 BENCH_BOUND_BF16_RESIDUAL = 1.0e-3               # measured max 7.1e-4 / mean 6.4e-4 over 32 documents
 BENCH_BOUND_FP32_RESIDUAL = 6.5e-4               # measured max 4.5e-4 / mean 4.1e-4
-NORTH_STAR_NOTE = ("north_star asks < 1e-4; at depth 32 no implementation with bf16 MFMA operands reaches it on these synthetic models: the error grows "
-                   "linearly with depth (~1.4e-5 per layer with the reference's bf16 rounding points, ~0.9e-5 with the fp32 residual stream: "
-                   "independent operand roundings of x, q|k|v, P, ctx, act in every layer), < 1e-4 holds up to depth 8 and every <= 1-layer pin "
-                   "at the 7B shape is at 1e-5; the reference's own bf16 run is further from its fp32 run than the engine is "
-                   "(profiles/r04_depth_parity.json)")
+#   precision="f16_operands" (round 5: fp32 residual stream + fp16 MFMA operands) is held to the NORTH-STAR's own tolerance on both models;
+#   the CPU emulation of the policy predicts 4e-6 at depth 32 (profiles/r05_precision_budget.json)
+FULL_DEPTH_BOUND_F16_OPERANDS = 1.0e-4
+BENCH_BOUND_F16_OPERANDS = 1.0e-4
+NORTH_STAR_NOTE = ("north_star asks 1 - cos < 1e-4 against the reference's fp32 encode().  With bf16 MFMA operands no implementation reaches it at depth "
+                   "32 on these synthetic models (the error grows linearly with depth: independent 8-bit-mantissa roundings of x, q|k|v, P, ctx, act "
+                   "in every layer; the reference's own bf16 run is further from its fp32 run than the engine is, profiles/r04_depth_parity.json). "
+                   "precision='f16_operands' (fp32 residual stream, every MFMA operand in fp16 -- same MFMA rate, 3 more mantissa bits, overflow "
+                   "flagged) is the policy held to 1e-4 here; the per-operand error budget it was derived from is profiles/r05_precision_budget.json")
 
 
 def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32, chunk=8, time_steps=3):
@@ -423,28 +427,44 @@ def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32
            "docs": n, "layers": layers}
     d = omc(emb_default[:n], ref)
     out["engine_bf16_residual_default"] = {**d, "bound": BENCH_BOUND_BF16_RESIDUAL, "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_BF16_RESIDUAL}
-    eng.residual_fp32 = True
-    try:
-        e32 = ops.pool_norm(eng.forward(si, sm, borrow=True), sm, "mean", True).float().clone()
-        d = omc(e32, ref)
-        rate = None
-        if time_steps:
-            ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(time_steps):
+    def opt_in(policy):
+        eng.set_precision(policy)
+        try:
+            e = ops.pool_norm(eng.forward(si, sm, borrow=True), sm, "mean", True).float().clone()
+            d = omc(e, ref)
+            rate = None
+            if time_steps:
                 ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
-            torch.cuda.synchronize()
-            rate = ids.shape[0] * time_steps / (time.perf_counter() - t0)
-    finally:
-        eng.residual_fp32 = False
-        eng._ws.clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(time_steps):
+                    ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
+                torch.cuda.synchronize()
+                rate = ids.shape[0] * time_steps / (time.perf_counter() - t0)
+            extra = {}
+            if policy == "f16_operands":
+                st = eng.f16_weight_stats or {}
+                extra = {"fp16_overflow_flag": bool(ops.f16_overflow_flag(eng.device)),
+                         "weights_subnormal_in_fp16_frac": st.get("subnormal", 0) / max(st.get("total", 1), 1)}
+        finally:
+            eng.set_precision("bf16")
+            eng._ws.clear()
+        return d, rate, extra
+
+    d, rate, _ = opt_in("fp32_residual")
     out["engine_fp32_residual_opt_in"] = {**d, "bound": BENCH_BOUND_FP32_RESIDUAL, "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_FP32_RESIDUAL,
-                                          "docs_per_s": rate, "how": "MistralEncoderEngine.residual_fp32 = True / GritLM(..., residual_fp32=True)"}
+                                          "docs_per_s": rate, "how": "GritLM(..., precision='fp32_residual') / engine.set_precision('fp32_residual')"}
+    d, rate, extra = opt_in("f16_operands")
+    out["engine_f16_operands_opt_in"] = {**d, "bound": BENCH_BOUND_F16_OPERANDS,
+                                         "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_F16_OPERANDS and not extra.get("fp16_overflow_flag", True),
+                                         "docs_per_s": rate, **extra, "how": "GritLM(..., precision='f16_operands') / engine.set_precision('f16_operands'): "
+                                         "fp32 residual stream, fp16 MFMA operands (x, q|k|v, P, ctx, act, weights), one rounding each"}
     out["stock_module_bf16_this_gpu"] = {**omc(e_stock, ref), "what": "stock transformers module, bf16, sdpa, the reference's mask rule, same weights, "
                                          "through PyTorch-ROCm: what the reference's Python computes on this GPU (reported; bounds nothing)"}
     out["engine_default_vs_stock_module_bf16"] = omc(emb_default[:n], e_stock)
-    out["within_bound"] = bool(out["engine_bf16_residual_default"]["within_bound"] and out["engine_fp32_residual_opt_in"]["within_bound"])
+    out["within_bound"] = bool(out["engine_bf16_residual_default"]["within_bound"] and out["engine_fp32_residual_opt_in"]["within_bound"]
+                               and out["engine_f16_operands_opt_in"]["within_bound"])
+    out["north_star_met"] = bool(out["engine_f16_operands_opt_in"]["max_one_minus_cos"] < 1e-4 and not out["engine_f16_operands_opt_in"].get("fp16_overflow_flag", True))
     return out
 
 
@@ -466,15 +486,21 @@ def full_depth_parity(dev):
     tid, tm = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
     cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
     hip = cosd(ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy(), ref)
-    eng.residual_fp32 = True
+    eng.set_precision("fp32_residual")
     hip32 = cosd(ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy(), ref)
+    eng.set_precision("f16_operands")
+    hip16 = cosd(ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy(), ref)
+    ovf16 = bool(ops.f16_overflow_flag(eng.device))
     del eng
     torch.cuda.empty_cache()
     return {"what": "1 doc x 512 tokens through all 32 layers at the 7B layer shape (the repeated-layer model of tests/golden/encoder_7b-depth32.npz), "
                     "HIP engine vs the fp32 numpy oracle on identical bf16-representable weights",
             "one_minus_cos_vs_fp32_oracle": hip, "bound": FULL_DEPTH_BOUND_BF16_RESIDUAL,
             "fp32_residual_opt_in_one_minus_cos_vs_fp32_oracle": hip32, "fp32_residual_bound": FULL_DEPTH_BOUND_FP32_RESIDUAL,
-            "within_bound": bool(hip < FULL_DEPTH_BOUND_BF16_RESIDUAL and hip32 < FULL_DEPTH_BOUND_FP32_RESIDUAL)}, {
+            "f16_operands_opt_in_one_minus_cos_vs_fp32_oracle": hip16, "f16_operands_bound": FULL_DEPTH_BOUND_F16_OPERANDS,
+            "f16_operands_overflow_flag": ovf16, "north_star_met": bool(hip16 < 1e-4 and not ovf16),
+            "within_bound": bool(hip < FULL_DEPTH_BOUND_BF16_RESIDUAL and hip32 < FULL_DEPTH_BOUND_FP32_RESIDUAL
+                                 and hip16 < FULL_DEPTH_BOUND_F16_OPERANDS and not ovf16)}, {
             "value": ids.shape[0] / dt, "unit": "docs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
             "sample": f"numpy oracle (oracle/gritlm_oracle.py, fp32 OpenBLAS), {ids.shape[0]} doc(s) x {ids.shape[1]} tok through all "
                       f"{cfg['num_hidden_layers']} layers, {dt:.2f} s", "seconds": dt}
@@ -757,6 +783,9 @@ def main():
             if vendor_sustained is not None:
                 vs["sustained_interleaved"] = vendor_sustained
             line["roofline"]["vs_vendor_same_run"] = vs
+            # the box-independent ratios again at the TOP level (a reader of the first-level keys sees them: VERDICT r04 #8)
+            line["gemm_over_vendor_in_model"] = vs.get("in_model_over_5_launch_comparator")
+            line["gemm_over_vendor_sustained"] = (vendor_sustained or {}).get("ours_over_vendor")
         if ragged is not None:
             line["ragged_batch"] = ragged
         if contrastive is not None:
@@ -781,9 +810,18 @@ def main():
                 fixture_datum = {"error": repr(e)[:300]}
             line["parity_full_depth"] = {
                 "vs_reference_fp32_same_weights": parity_sw, "fixture_model_vs_fp32_numpy_oracle": fixture_datum,
-                "depth_curve": "profiles/r04_depth_parity.json (1 - cos at depth 1/2/4/8/16/32, both engine policies, stock bf16 under both mask rules)",
+                "depth_curve": "profiles/r04_depth_parity.json (1 - cos at depth 1/2/4/8/16/32, both bf16-operand policies, stock bf16 under both mask "
+                               "rules); profiles/r05_precision_budget.json (per-operand error budget, emulated)",
                 "north_star": NORTH_STAR_NOTE,
-                "within_bound": bool((parity_sw or {}).get("within_bound")) and bool(fixture_datum.get("within_bound"))}
+                "within_bound": bool((parity_sw or {}).get("within_bound")) and bool(fixture_datum.get("within_bound")),
+                "north_star_met": bool((parity_sw or {}).get("north_star_met")) and bool(fixture_datum.get("north_star_met"))}
+            # top-level copies (VERDICT r04 #8 / ADVICE r04): does every policy hold its numeric bound, and does the f16_operands policy meet
+            # the north-star's 1 - cos < 1e-4 on the timed batch AND on the reference-run fixture model
+            line["parity_within_bound"] = line["parity_full_depth"]["within_bound"]
+            line["north_star_met"] = line["parity_full_depth"]["north_star_met"]
+            f16 = (parity_sw or {}).get("engine_f16_operands_opt_in") or {}
+            line["north_star_policy"] = {"precision": "f16_operands", "max_one_minus_cos_timed_batch": f16.get("max_one_minus_cos"),
+                                         "docs_per_s": f16.get("docs_per_s"), "docs_per_s_over_default": (f16.get("docs_per_s") or 0.0) / docs_per_s}
         if not multi and not dry:
             import gc as _gc
             _gc.collect()

@@ -336,7 +336,7 @@ class GritLM(torch.nn.Module):
         else:
             # ONE device->host copy for the whole call (the reference syncs per batch, :164)
             result = torch.cat(chunks, dim=0).to(torch.float32).cpu().numpy()
-        if self.engine is not None and self.engine.precision == "f16_operands":
+        if self.engine is not None and getattr(self.engine, "precision", None) == "f16_operands":
             for eng in (getattr(self, "engines", None) or [self.engine]):       # raises if an activation left the fp16 range in this call
                 eng.check_f16_overflow()
         if single:

@@ -128,3 +128,52 @@ def test_two_replica_split_keeps_row_order_and_scales_the_batch(dirs):
     m.engine, m.engines, m.num_gpus = e0, [e0, e1], 2
     plain = m.encode(sents, batch_size=2, max_length=64)
     np.testing.assert_array_equal(plain[:, :2], one[:, :2])                    # same rows, same order, whichever replica computed them
+
+
+class _ReplicaEngine:
+    """engine stand-in for `_parallelize`: records which devices it was replicated onto"""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.made = []
+
+    def replica(self, d):
+        self.made.append(torch.device(d))
+        return _ReplicaEngine(d)
+
+
+def test_parallelize_stays_on_one_device_inside_a_distributed_launch(dirs, monkeypatch):
+    """in a one-process-per-GPU launch every rank sees every GPU; auto-replication there would put world_size copies
+    of the model on each GPU.  `_parallelize` must do nothing when LOCAL_RANK / RANK is set (or torch.distributed is initialised) unless
+    the caller names `devices=` explicitly; device lists are normalised ('cuda' == the current device, duplicates dropped)."""
+    m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    m.engine = _ReplicaEngine("cuda:0")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    m.engines, m.num_gpus = [], 1
+    m._parallelize(None)
+    assert m.engines == [] and m.num_gpus == 1 and m.engine.made == []
+    m._parallelize(["cuda:0", "cuda:2"])                       # explicit request: honoured even under a launcher
+    assert m.num_gpus == 2 and m.engine.made == [torch.device("cuda:2")] and m.engines[0] is m.engine
+    monkeypatch.delenv("LOCAL_RANK")
+    monkeypatch.delenv("RANK", raising=False)
+    m.engine = _ReplicaEngine("cuda:0")
+    m.engines, m.num_gpus = [], 1
+    m._parallelize(None)                                       # plain single-process use: one replica per visible GPU, as the reference
+    assert m.num_gpus == 4 and m.engine.made == [torch.device("cuda", i) for i in (1, 2, 3)]
+    m.engine = _ReplicaEngine("cuda")                          # index None == current device: no second copy on the same GPU
+    m.engines, m.num_gpus = [], 1
+    m._parallelize(["cuda", "cuda:0", "cuda:1", "cuda:1"])
+    assert m.num_gpus == 2 and m.engine.made == [torch.device("cuda:1")]
+
+
+def test_precision_keyword_is_validated(dirs):
+    """`precision=` (extension): one of gritlm_amd.encoder.PRECISIONS; `residual_fp32=True` stays an alias of 'fp32_residual'."""
+    from gritlm_amd.encoder import PRECISIONS
+    assert PRECISIONS == ("bf16", "fp32_residual", "f16_operands")
+    with pytest.raises(ValueError, match="precision"):
+        GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", precision="fp8")
+    assert GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", residual_fp32=True)._precision == "fp32_residual"
+    assert GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", precision="f16_operands")._precision == "f16_operands"
+    assert GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu")._precision == "bf16"

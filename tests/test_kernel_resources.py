@@ -35,20 +35,10 @@ def _resources(src):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_w64_attention_uses_the_whole_register_file_without_spilling():
-    """The W64 attention forward runs ONE wave per SIMD on purpose (64 query rows per wave: oacc 128 + scores 64 in AGPRs, Q in AGPRs, the
-    softmax's copy of the scores, P and the fragments in arch VGPRs): <= 512 registers, no spill, no scratch -- a scratch reload's vmcnt(0)
-    would drain the LDS-DMA queue in the middle of the tile loop."""
-    ks = [k for k in _resources("attention.hip") if "attn_fwd_w64_k" in k["name"]]
-    assert len(ks) == 2, [k["name"] for k in ks]
-    for k in ks:
-        assert int(k["VGPRs Spill"]) == 0 and int(k["ScratchSize [bytes/lane]"]) == 0, k
-        assert int(k["VGPRs"]) <= 256 and int(k["AGPRs"]) <= 256 and int(k["Occupancy [waves/SIMD]"]) >= 1, k
-
-
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src,needle,count", [("gemm_bf16.hip", "gemm_bf16_nt_k", 16), ("attention.hip", "attn_bidir_fwd_k", 4)])
+@pytest.mark.parametrize("src,needle,count", [("gemm_bf16.hip", "gemm_bf16_nt_k", 24), ("attention.hip", "attn_bidir_fwd_k", 6)])
 def test_mfma_kernels_do_not_spill(src, needle, count):
+    """(counts: 8 epilogues x {per-tile, persistent} bf16 GEMMs + the 4 forward epilogues x 2 of the fp16-operand policy; 4 bf16 attention
+    forwards + the 2 bidirectional fp16 ones)"""
     ks = [k for k in _resources(src) if needle in k["name"]]
     assert len(ks) == count, [k["name"] for k in ks]
     for k in ks:
@@ -57,7 +47,8 @@ def test_mfma_kernels_do_not_spill(src, needle, count):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_gemm_k_loop_hands_the_matrix_pipe_over_one_product_early():
+@pytest.mark.parametrize("inst,mfma", [("Li1ELb1ELb0E", "v_mfma_f32_16x16x32_bf16"), ("Li7ELb1ELb1E", "v_mfma_f32_16x16x32_f16")])
+def test_gemm_k_loop_hands_the_matrix_pipe_over_one_product_early(inst, mfma):
     """ISA-level guard of the round-4 hand-over (csrc/gemm_bf16.hip, GRIT_GEMM_BAR_EARLY = 1): in the persistent RESIDUAL instantiation
     every MFMA segment of the K loop is 15 products, s_barrier, ONE product, s_setprio 0 -- hipcc must neither move products across the
     barrier nor merge segments (a barrier behind the last product costs 1-2.6 % per shape, two products early 6-8 %:
@@ -69,7 +60,8 @@ def test_gemm_k_loop_hands_the_matrix_pipe_over_one_product_early():
                             os.path.join(ROOT, "gritlm_amd", "csrc", "gemm_bf16.hip")], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4grit14gemm_bf16_nt_kILi1ELb1E\w+:", l))
+    # (also for the fp16-operand instantiation of round 5 -- persistent RESIDUAL_F32 -- whose K loop must be the same stream, one opcode changed)
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4grit14gemm_bf16_nt_kI" + inst + r"\w+:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     ops = [m.group(1) + (" " + m.group(2) if m.group(1) in ("s_setprio", "s_waitcnt") else "")
            for m in (re.match(r"^\s+([a-z_0-9]+)\s*(.*)$", l) for l in lines[start:end]) if m]
@@ -82,6 +74,7 @@ def test_gemm_k_loop_hands_the_matrix_pipe_over_one_product_early():
             segs.append(cur); cur = None
         elif cur is not None:
             cur.append(op)
+    assert all(o.startswith(mfma) for sg in segs for o in sg if o.startswith("v_mfma")), "wrong MFMA opcode in the K loop"
     full = [s for s in segs if sum(o.startswith("v_mfma") for o in s) == 16]
     assert len(full) >= 16, (len(segs), len(full))                  # 4 segments per K-tile form, several forms (first / middle / last K-tile, two buffers)
     for s in full:
