@@ -830,12 +830,12 @@ def main():
                 line["mixtral_8x7b_seq2048"] = secondary_leg(
                     "mixtral_bench.py", ["--docs", 64, "--seq", 2048, "--steps", 3, "--warmup", 1], 420,
                     ("metric", "value", "unit", "ms_per_step", "tokens_per_s", "config", "roofline", "model_flops_utilisation", "hbm_allocated_gb",
-                     "expert_load_max_over_mean", "finite", "kernels"))
+                     "expert_load_max_over_mean", "finite", "kernels", "parity"))
             if not args.no_rag:
                 line["rag_doc_caching"] = secondary_leg(
                     "rag_cache_bench.py", ["--passages", 512, "--seq", 2048, "--new-tokens", 128, "--queries", 4], 600,
                     ("metric", "passages", "seq", "encode_s", "passages_per_s", "encode_tokens_per_s", "encode_mfma_roofline_frac", "kv_cache_gb",
-                     "generate_s_per_query", "decode_tokens_per_s", "decode_path", "native_decode", "decode_frac_of_weight_streaming_roofline",
+                     "generate_s_per_query", "decode_tokens_per_s", "decode_path", "native_decode", "decode_frac_of_weight_streaming_roofline", "parity",
                      "hbm_allocated_gb"))
         emit(json.dumps(line))
         emitted.append(True)

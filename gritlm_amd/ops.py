@@ -24,16 +24,25 @@ class KernelTimer:
         self.pairs: dict[str, list] = {}
         self.work: dict[str, float] = {}
         self.tags: dict[str, list] = {}
+        self.deferred: dict[str, list] = {}
 
-    def span(self, name: str, work: float = 0.0, tag: str | None = None):
+    def span(self, name: str, work=0.0, tag: str | None = None):
+        """``work``: FLOPs (or bytes) of the launch -- a float, or a 0-dim DEVICE tensor when the amount depends on device data (the packed
+        attention's sum of len^2): it is read at summary(), after the timed region, never inside it."""
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.pairs.setdefault(name, []).append((a, b))
+        if torch.is_tensor(work):
+            self.deferred.setdefault(name, []).append(work)
+            work = 0.0
         self.tags.setdefault(name, []).append((tag, work))
         self.work[name] = self.work.get(name, 0.0) + work
         return a, b
 
     def summary(self) -> dict:
         torch.cuda.synchronize()
+        for name, ws in self.deferred.items():
+            self.work[name] = self.work.get(name, 0.0) + float(sum(float(w) for w in ws))
+        self.deferred = {}
         out = {}
         for name, pairs in self.pairs.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
@@ -160,7 +169,10 @@ def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
         out = torch.empty((T, nq * d), dtype=qkv.dtype, device=qkv.device)
     if scale is None:
         scale = d ** -0.5
-    ev = _timer.span("attn_bidir_fwd", 0.0) if _timer is not None else None
+    ev = None
+    if _timer is not None:           # algorithmic FLOPs of the packed launch: 4 d nq sum(len^2) (half of it when causal), summed on the device
+        lens = (cu_seqlens[1:] - cu_seqlens[:-1]).double()
+        ev = _timer.span("attn_bidir_fwd", (lens * lens).sum() * (4.0 * nq * d * (0.5 if causal else 1.0)))
     if ev:
         ev[0].record()
     fn, wa = _attn_entry("varlen_fwd", causal, window)

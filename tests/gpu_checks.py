@@ -944,6 +944,100 @@ def check_mixtral_golden(cfg_name="moe-tiny"):
     return _res(f"mixtral encoder[{cfg_name}] vs reference golden", bool(ok), **out)
 
 
+def check_gemm_grouped_fullshape(N=28672, K=4096, epi=EPI_SWIGLU, rows=262144, seed=301, samples=4096):
+    """grit_gemm_bf16_nt_grouped at BASELINE configs[3]'s launch shape (Mixtral-8x7B, 64 docs x 2048 tokens, top-2: 262144 sorted rows
+    over 8 experts with UNEVEN counts incl. one that is no multiple of the 256-row tile and one tiny group; N 28672 / K 4096 with the
+    SwiGLU epilogue and the token gather folded into the A loads, or N 4096 / K 14336 STORE), spot-checked on random (row, column) pairs
+    of every group against fp64 dot products of the same bf16 operands (check_gemm_fullshape's tolerance)."""
+    E = 8
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    frac = torch.tensor([0.16, 0.09, 0.125, 0.14, 0.11, 0.135, 0.1299, 0.0001])
+    counts = (frac / frac.sum() * rows).long()
+    counts[0] += rows - int(counts.sum())
+    counts[3] += 77; counts[0] -= 77                                    # a count that is no multiple of anything
+    assert int(counts.sum()) == rows and int(counts.min()) > 0
+    T = rows // 2
+    a = torch.randn((T, K), device=DEV, generator=gen).to(torch.bfloat16)
+    a_rows = torch.randint(0, T, (rows,), device=DEV, generator=gen, dtype=torch.int32)
+    w = torch.empty((E, N, K), dtype=torch.bfloat16, device=DEV)
+    for e in range(E):
+        w[e].copy_((torch.randn((N, K), device=DEV, generator=gen) * 0.03).to(torch.bfloat16))
+    tcounts = counts.to(torch.int32).to(DEV)
+    I = N // 2
+    if epi == EPI_SWIGLU:
+        wi = torch.stack([swiglu_interleave(w[e, :I].contiguous(), w[e, I:].contiguous()) for e in range(E)]).contiguous()
+        out = ops.gemm_nt_grouped(a, wi, tcounts, rows, epilogue=epi, a_rows=a_rows)
+        del wi
+    else:
+        out = ops.gemm_nt_grouped(a, w, tcounts, rows, a_rows=a_rows)
+    ncols = I if epi == EPI_SWIGLU else N
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum(counts.numpy())])
+    worst, finite = 0.0, bool(torch.isfinite(out).all())
+    for e in range(E):
+        c = int(counts[e])
+        n_s = max(64, samples // E)
+        r_loc = np.unique(np.concatenate([rng.integers(0, c, n_s), np.arange(min(c, 16)), np.arange(max(c - 16, 0), c)]))
+        rr = torch.from_numpy(off[e] + r_loc).to(DEV)
+        cc = torch.from_numpy(rng.integers(0, ncols, rr.numel())).to(DEV)
+        cc[:8] = torch.arange(8, device=DEV); cc[-8:] = torch.arange(ncols - 8, ncols, device=DEV)
+        a64 = a[a_rows[rr].long()].double()
+        if epi == EPI_SWIGLU:
+            gt = (a64 * w[e, :I][cc].double()).sum(1).float().to(torch.bfloat16).double()
+            ut = (a64 * w[e, I:][cc].double()).sum(1).float().to(torch.bfloat16).double()
+            ref = torch.nn.functional.silu(gt).float().to(torch.bfloat16).double() * ut
+        else:
+            ref = (a64 * w[e][cc].double()).sum(1)
+        got = out[rr, cc].double()
+        scale = float(ref.pow(2).mean().sqrt()) + 1e-9
+        worst = max(worst, float(((got - ref).abs() / (1.2e-2 * ref.abs() + 1e-2 * scale)).max()))
+    return _res(f"gemm_grouped_fullshape[rows={rows},N={N},K={K},epi={epi}]", worst < 1.0 and finite, max_err_over_tol=worst,
+                counts=counts.tolist())
+
+
+def check_mixtral_layer_true_shape():
+    """ONE layer at the TRUE Mixtral-8x7B layer shape (E 8, H 4096, I 14336, 32/8 heads) vs the fixture the REFERENCE's
+    MixtralModel(is_causal=False) produced (tests/golden/encoder_8x7b-l1.npz: scripts/modeling_mixtral_gritlm.py:815-882; fp32 and bf16
+    runs, probe rows, the routing of every token and the router's 2nd-vs-3rd margin).  The grouped GEMMs run at configs[3]'s N / K with 8
+    uneven expert row counts.  Numeric criteria: (1) every valid token whose router margin exceeds 1e-2 (bf16 logits noise is ~1e-3)
+    takes the fp32 reference's two experts, overall agreement >= 0.97 (the reference's own bf16 run: 0.984); (2) probe rows that took the
+    reference's experts: relative l2 error < 3.5e-2 (the reference's own bf16 run on the same rows: 2.4e-2); (3) pooled embeddings within
+    1.5e-3 of the fp32 reference's (its own bf16 run: 3e-4 .. 7.7e-4 -- tokens that sit on a routing tie go to another expert in ANY
+    bf16 run, so the 1e-4 of the dense fixtures does not apply); (4) packed == padded bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "encoder_8x7b-l1.npz"))
+    eng, cfg, w = build_engine("8x7b-l1", int(g["seed_w"]))
+    del w
+    ids, mask = g["input_ids"], g["attention_mask"]
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    eng.record_routing = []
+    h = f32(eng.forward(tid, tm))
+    routing = np.sort(eng.record_routing[0].cpu().numpy().reshape(-1, 2), axis=-1)
+    eng.record_routing = None
+    valid = mask.astype(bool).reshape(-1)
+    r32 = np.sort(g["routing"], axis=-1).reshape(-1, 2)
+    agree_tok = (routing == r32).all(-1)
+    margin = g["router_margin_2nd_vs_3rd"].reshape(-1)
+    clear = valid & (margin > 1e-2)
+    out = dict(routing_agree=float(agree_tok[valid].mean()), routing_agree_of_bf16_ref=float((np.sort(g["routing_bf16"], -1).reshape(-1, 2) == r32).all(-1)[valid].mean()),
+               clear_margin_tokens=int(clear.sum()), clear_margin_agree=float(agree_tok[clear].mean()))
+    ok = out["clear_margin_agree"] == 1.0 and out["routing_agree"] >= 0.97 and not np.isnan(h).any()
+    probe = g["probe_rows"]
+    pa = agree_tok[probe]
+    hp = h.reshape(-1, h.shape[-1])[probe]
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    out["probe_rows_same_experts"] = int(pa.sum())
+    out["rel_ours_vs_fp32"] = rel(hp[pa], g["probe_hidden"][pa]); out["rel_refbf16_vs_fp32"] = rel(g["probe_hidden_bf16"][pa], g["probe_hidden"][pa])
+    ok &= pa.sum() >= 56 and out["rel_ours_vs_fp32"] < 3.5e-2
+    for method in ("mean", "weightedmean"):
+        e = f32(eng.encode_pooled(tid, tm, method, True, packed=False))
+        ep = f32(eng.encode_pooled(tid, tm, method, True, packed=True))
+        c32 = float(np.max(1 - np.sum(e * g[f"emb_{method}"], axis=1)))
+        out[f"{method}_1-cos"] = c32
+        out[f"{method}_1-cos_of_bf16ref"] = float(np.max(1 - np.sum(g[f"emb_{method}_bf16"] * g[f"emb_{method}"], axis=1)))
+        ok &= c32 < 1.5e-3 and np.array_equal(e, ep)
+    return _res("mixtral layer at the true 8x7B shape vs reference golden", bool(ok), **out)
+
+
 def check_encoder_vs_oracle_bf16(cfg_name="tiny", B=3, S=130):
     """Different shape than the golden (S not a multiple of 64), against the bf16-emulating oracle."""
     eng, cfg, w = build_engine(cfg_name, 5)
@@ -1206,9 +1300,11 @@ def check_attention_f16(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=211, p
 
 def check_encoder_f16_operands(cfg_name):
     """The engine under precision='f16_operands' (fp32 residual stream, every MFMA operand fp16) against the reference's FP32 run
-    (reference-generated fixture): hidden states at least 4x closer to fp32 than the fp32-residual policy with bf16 operands (the
-    emulation, profiles/r05_precision_budget.json, predicts ~8x per operand rounding), embeddings within 1e-5 (north-star: 1e-4), padded ==
-    packed bit for bit, no overflow flagged, and the weight conversion exact apart from the counted subnormals."""
+    (reference-generated fixture): pooled embeddings within 1e-5 of the fp32 reference (north-star: 1e-4) AND at least 10x closer than
+    the fp32-residual policy with bf16 operands on the same inputs (the emulation, profiles/r05_precision_budget.json, predicts ~64x in
+    1 - cos: 3 mantissa bits), hidden states no further than that policy's (both carry the bf16 rounding of last_hidden_state, the
+    pooling kernels' input format, which dominates the per-element error of the fp16 policy), padded == packed bit for bit, no overflow
+    flagged, and the weight conversion exact apart from the counted subnormals."""
     g = np.load(os.path.join(GOLDEN, f"encoder_{cfg_name}.npz"))
     eng, cfg, w = build_engine(cfg_name, int(g["seed_w"]))
     ids, mask = g["input_ids"], g["attention_mask"]
@@ -1224,21 +1320,20 @@ def check_encoder_f16_operands(cfg_name):
         pick = lambda h: h.reshape(-1, h.shape[-1])[g["probe_rows"]]
     eng.set_precision("fp32_residual")
     r_b = rel(pick(f32(eng.forward(tid, tm))), ref32)
+    omc = lambda e, m: float(np.max(1 - np.sum(f32(e).astype(np.float64) * g[f"emb_{m}"].astype(np.float64), axis=1)))
+    d_b = {m: omc(eng.encode_pooled(tid, tm, m, True, packed=False), m) for m in ("mean", "weightedmean")}
     eng.set_precision("f16_operands")
     _f16_flag()
     h_f = pick(f32(eng.forward(tid, tm)))
     r_f = rel(h_f, ref32)
-    # both carry the bf16 rounding of last_hidden_state (2^-9 relative, ~1.1e-3 rms): compare what is left after removing it in quadrature
-    floor = 2.0 ** -9 / np.sqrt(3.0)
-    ex = lambda r: float(np.sqrt(max(r * r - floor * floor, 0.0)))
-    out = dict(rel_bf16_operands=r_b, rel_f16_operands=r_f, excess_bf16=ex(r_b), excess_f16=ex(r_f), out_rounding_floor=float(floor))
-    ok = r_f <= r_b and ex(r_f) < 0.25 * ex(r_b) + 1e-4 and not np.isnan(h_f).any()
+    out = dict(rel_hidden_bf16_operands=r_b, rel_hidden_f16_operands=r_f)
+    ok = r_f <= r_b and not np.isnan(h_f).any()
     for method in ("mean", "weightedmean"):
         e_pad = eng.encode_pooled(tid, tm, method, True, packed=False)
         e_pack = eng.encode_pooled(tid, tm, method, True, packed=True)
-        d = float(np.max(1 - np.sum(f32(e_pad).astype(np.float64) * g[f"emb_{method}"].astype(np.float64), axis=1)))
-        out[f"{method}_1-cos"] = d
-        ok &= d < 1e-5 and bool(torch.equal(e_pad, e_pack))
+        d = omc(e_pad, method)
+        out[f"{method}_1-cos"] = d; out[f"{method}_1-cos_bf16_operands"] = d_b[method]
+        ok &= d < 1e-5 and d < 0.1 * d_b[method] and bool(torch.equal(e_pad, e_pack))
     st = eng.f16_weight_stats
     out["subnormal_weights"], out["overflow_flag"] = st["subnormal"], _f16_flag()
     ok &= st["overflow"] == 0 and not out["overflow_flag"]
@@ -2933,6 +3028,9 @@ ALL_CHECKS = [
     ("moe_block", check_moe_block, {}),
     ("mixtral_tiny", check_mixtral_golden, dict(cfg_name="moe-tiny")),
     ("mixtral_gqa", check_mixtral_golden, dict(cfg_name="moe-gqa")),
+    ("mixtral_layer_true_shape_8x7b", check_mixtral_layer_true_shape, {}),
+    ("gemm_grouped_full_swiglu_28672x4096", check_gemm_grouped_fullshape, {}),
+    ("gemm_grouped_full_store_4096x14336", check_gemm_grouped_fullshape, dict(N=4096, K=14336, epi=EPI_STORE, seed=303)),
     ("causal_encode", check_causal_encode, {}),
     ("sliding_window_encode", check_sliding_window_encode, {}),
     ("generative_window", check_generative_window, {}),

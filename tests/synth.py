@@ -33,6 +33,11 @@ CONFIGS = {
     "moe-gqa": dict(vocab_size=384, hidden_size=512, intermediate_size=768, num_hidden_layers=3,
                     num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=1e6,
                     num_local_experts=8, num_experts_per_tok=2),
+    # ONE layer at the true Mixtral-8x7B layer shape (E 8, H 4096, I 14336, 32/8 heads), small vocabulary: the parity fixture at the shape
+    # BASELINE configs[3] runs (5.6 GB of fp32 expert weights)
+    "8x7b-l1": dict(vocab_size=4096, hidden_size=4096, intermediate_size=14336, num_hidden_layers=1,
+                    num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=1e6,
+                    num_local_experts=8, num_experts_per_tok=2),
     "8x7b": dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
                  num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=1e6,
                  num_local_experts=8, num_experts_per_tok=2),

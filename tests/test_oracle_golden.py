@@ -332,3 +332,48 @@ def test_pool_normalize_backward_finite_difference():
             hp = h.copy(); hp[idx] += eps; hm = h.copy(); hm[idx] -= eps
             fd = (f(hp) - f(hm)) / (2 * eps)
             assert abs(fd - g[idx]) < 2e-3, (method, idx, fd, g[idx])
+
+
+@pytest.mark.parametrize("cfg_name", ["moe-tiny", "moe-gqa"])
+def test_mixtral_fp32_restatement(golden_dir, cfg_name):
+    """oracle/torch_reference.py::mixtral_hidden_states_fp32 (the layer-streamed fp32 restatement tools/mixtral_bench.py checks the
+    configs[3] leg against) reproduces the REFERENCE's MixtralModel(is_causal=False) fp32 outputs and pooled embeddings
+    (scripts/modeling_mixtral_gritlm.py:815-934, fixtures generated by the reference itself) -- and so does the engine-weight route
+    (repacked QKV / interleaved expert weights widened back), which is what the GPU leg uses."""
+    import torch
+    import torch_reference as TR
+    g = _load(golden_dir, f"encoder_{cfg_name}.npz")
+    cfg = synth.CONFIGS[cfg_name]
+    w = synth.make_weights(cfg, int(g["seed_w"]))
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    nq, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    args = (cfg["num_hidden_layers"], sd["embed_tokens.weight"], sd["norm.weight"], ids, mask, nq, nkv, cfg["hidden_size"] // nq,
+            cfg["rms_norm_eps"], cfg["rope_theta"])
+    wl = lambda li: TR.mixtral_layer_weights_from_state_dict(sd, li, cfg["num_local_experts"])
+    h = TR.mixtral_hidden_states_fp32(wl, *args).numpy()
+    valid = g["attention_mask"].astype(bool)
+    assert np.abs(h - g["last_hidden_state"])[valid].max() < 2e-5
+    e = TR.mixtral_encode_fp32(wl, *args).numpy()
+    assert np.all(1 - np.sum(e * g["emb_mean"], axis=1) < 1e-6)
+
+    # the route the GPU leg takes: weights widened back from an engine-style repack (fused QKV, gate / up rows interleaved in blocks of 16)
+    class _L:
+        pass
+
+    class _E:
+        pass
+    blk, eng = 16, _E()
+    eng.cfg = type("C", (), dict(num_attention_heads=nq, num_key_value_heads=nkv, head_dim=cfg["hidden_size"] // nq,
+                                 intermediate_size=cfg["intermediate_size"], hidden_size=cfg["hidden_size"], num_local_experts=cfg["num_local_experts"]))()
+    eng.layers = []
+    for li in range(cfg["num_hidden_layers"]):
+        W, L = wl(li), _L()
+        I, H, E = cfg["intermediate_size"], cfg["hidden_size"], cfg["num_local_experts"]
+        L.wqkv = torch.cat([W["wq"], W["wk"], W["wv"]]).bfloat16(); L.wo = W["wo"].bfloat16(); L.wgate = W["gate"].bfloat16()
+        L.ln1, L.ln2 = W["ln1"].bfloat16(), W["ln2"].bfloat16()
+        L.w13 = torch.stack([W["w1"].view(E, I // blk, blk, H), W["w3"].view(E, I // blk, blk, H)], dim=2).reshape(E, 2 * I, H).bfloat16()
+        L.w2 = W["w2"].bfloat16()
+        eng.layers.append(L)
+    h2 = TR.mixtral_hidden_states_fp32(lambda li: TR.mixtral_layer_weights_from_engine(eng, li, blk), *args).numpy()
+    assert np.array_equal(h2, h)                       # the fixtures' weights are bf16-representable: the round trip is exact

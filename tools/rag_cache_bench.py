@@ -135,25 +135,57 @@ if m.engine is not None:
     dec.generate(q_ids[:1], 4 * a.new_tokens, past_key_values=slices(0))
     torch.cuda.synchronize()
     t_long = time.perf_counter() - t0
-    # logits of the first generated position: native vs the Hugging Face module on the same cached KV (random-init weights give nearly
-    # flat logits, so token identity is not a meaningful comparison; the logit vectors are)
-    pc = passage_cache(0)
-    plen = pc.get_seq_length()
-    hf_logits = lm(input_ids=q_ids[:1], past_key_values=pc, attention_mask=torch.ones((1, plen + q_ids.shape[1]), dtype=torch.long, device=dev),
-                   position_ids=torch.arange(plen, plen + q_ids.shape[1], device=dev).unsqueeze(0)).logits[0, -1].float()
-    _, nat_logits = dec.generate(q_ids[:1], 2, past_key_values=slices(0), return_logits=True)
-    nat_logits = nat_logits[0, 0].float()
-    cos = float(torch.nn.functional.cosine_similarity(hf_logits - hf_logits.mean(), nat_logits - nat_logits.mean(), dim=0))
-    native = {"generate_s_per_query": t_nat / a.queries, "first_logits_vs_hf_cosine": cos,
-              "first_logits_vs_hf_max_abs": float((hf_logits - nat_logits).abs().max()), "first_logits_std": float(hf_logits.std()), "tokens_per_s_incl_prompt_and_cache_copy": a.new_tokens * a.queries / t_nat,
+    # PARITY of the decode path (VERDICT r04 #2c): TEACHER-FORCED next-token logits of the native decoder against the reference-equivalent
+    # module IN FP32 (the same weights widened, exact) on the SAME cached passage KV and the same query prefix, at several prefix lengths.
+    # Random-init weights give nearly flat logits, so greedy-token identity says nothing (a 2 % match is the expected outcome of two
+    # correct bf16 implementations); the centred logit VECTORS do: 1 - cos and relative l2 against fp32, numeric bounds.  The stock
+    # bf16 module through PyTorch-ROCm (what the reference's generate() computes on this GPU) is measured beside it.
+    import copy
+    lm32 = copy.deepcopy(lm).float()
+    ks = [k for k in (1, 7, q_ids.shape[1]) if k <= q_ids.shape[1]]
+    with torch.no_grad():
+        def module_logits(mod, dt):
+            pc = passage_cache(0)
+            if dt != dtype:
+                pc32 = DynamicCache()
+                for li, (k_, v_) in enumerate(slices(0)):
+                    pc32.update(k_.to(dt).clone(), v_.to(dt).clone(), li)
+                pc = pc32
+            plen = pc.get_seq_length()
+            return mod(input_ids=q_ids[:1], past_key_values=pc, attention_mask=torch.ones((1, plen + q_ids.shape[1]), dtype=torch.long, device=dev),
+                       position_ids=torch.arange(plen, plen + q_ids.shape[1], device=dev).unsqueeze(0)).logits[0].float()
+        ref_logits = module_logits(lm32, torch.float32)              # [query tokens, V]: position k-1 = next-token logits after k tokens
+        hf_logits_all = module_logits(lm, dtype)
+    del lm32
+    torch.cuda.empty_cache()
+
+    def cmp(x, r):
+        x, r = x.double() - x.double().mean(), r.double() - r.double().mean()
+        top = lambda t: set(torch.topk(t, 10).indices.tolist())
+        return {"one_minus_cos": float(1 - torch.nn.functional.cosine_similarity(x, r, dim=0)), "rel_l2": float((x - r).norm() / r.norm()),
+                "top10_overlap": len(top(x) & top(r)) / 10.0, "argmax_equal": bool(x.argmax() == r.argmax())}
+    per_k, per_k_hf = {}, {}
+    for k in ks:
+        _, nl = dec.generate(q_ids[:1, :k], 1, past_key_values=slices(0), return_logits=True)
+        per_k[str(k)] = cmp(nl[0, 0].float(), ref_logits[k - 1])
+        per_k_hf[str(k)] = cmp(hf_logits_all[k - 1], ref_logits[k - 1])
+    BOUND_COS, BOUND_L2 = 2.0e-3, 7.0e-2            # bf16 arithmetic over 32 layers: the encoder measures 7e-4 of 1 - cos on this model family
+    worst_cos = max(v["one_minus_cos"] for v in per_k.values()); worst_l2 = max(v["rel_l2"] for v in per_k.values())
+    parity = {"what": "teacher-forced next-token logits (centred) after k query tokens on top of one cached 2048-token passage: native decoder "
+                      "(bf16, csrc/decode.hip) vs the reference-equivalent Hugging Face module in FP32 on the same weights, the same cached KV "
+                      "and the same prefix", "prefix_lengths": ks, "native_vs_fp32": per_k, "stock_bf16_module_vs_fp32": per_k_hf,
+              "max_one_minus_cos": worst_cos, "max_rel_l2": worst_l2, "bound_one_minus_cos": BOUND_COS, "bound_rel_l2": BOUND_L2,
+              "logits_std": float(ref_logits[-1].std()), "within_bound": bool(worst_cos < BOUND_COS and worst_l2 < BOUND_L2)}
+    native = {"generate_s_per_query": t_nat / a.queries, "parity": parity,
+              "tokens_per_s_incl_prompt_and_cache_copy": a.new_tokens * a.queries / t_nat,
               "decode_ms_per_token": (t_long - t_nat / a.queries) / (3 * a.new_tokens) * 1e3,
-              "first_tokens_equal_to_hf": float((first.cpu() == hf_tokens.cpu()).float().mean()),
               "hbm_roofline_ms_per_token": sum(p.numel() for p in lm.parameters()) * 2 / 8e12 * 1e3}
 tokens = a.passages * a.seq
 kv_gb = sum(sum(x.numel() * x.element_size() for x in ((l.keys, l.values) if hasattr(l, "keys") else l)) for c in caches
             for l in (c.layers if hasattr(c, "layers") else c)) / 1e9
 enc_frac = (tokens / t_enc) * m.engine.flops_per_token(a.seq) / 2.5e15 if m.engine is not None else None
 print(json.dumps({"metric": "RAG doc-caching: encode passages (+KV) and generate from the cached KV", "passages": a.passages, "seq": a.seq,
+                  "parity": native["parity"] if native else None,
                   "encode_mfma_roofline_frac": enc_frac,
                   "decode_frac_of_weight_streaming_roofline": (native["hbm_roofline_ms_per_token"] / native["decode_ms_per_token"]) if native else None,
                   "encode_s": t_enc, "passages_per_s": a.passages / t_enc, "encode_tokens_per_s": tokens / t_enc, "kv_cache_gb": kv_gb,
