@@ -1037,7 +1037,11 @@ static int device_cu_count() {
 // Why per stream: a set is re-cleared CTR_PER_STREAM launches later, and only stream order guarantees that the kernel that used it has
 // finished by then -- with one process-wide ring (round 3) a persistent kernel still pending on another stream (a side stream, an
 // autograd worker's stream, a stream parked on an event) could have had its live queue re-zeroed after the ring wrapped: tiles computed
-// twice or skipped, silently.  A 17th concurrent (device, stream) pair gets no ring and takes the per-tile launch form.
+// twice or skipped, silently.  Rings are RECLAIMED (round 5): when every slot is taken, the least recently used
+// ring whose stream has nothing pending (hipStreamQuery == success -- its kernels are done, its counters dead -- or the handle is no
+// longer a stream at all: a destroyed side stream) goes to the new (device, stream) pair, so 8 GPUs x (compute + side stream) plus
+// re-created CU-masked communication streams no longer exhaust the table for the life of the process.  Only when all CTR_STREAMS rings
+// have work in flight does a launch take the per-tile form (reported once on stderr).
 constexpr int CTR_STREAMS = 16, CTR_PER_STREAM = 256, CTR_SETS = CTR_STREAMS * CTR_PER_STREAM;
 __device__ unsigned int g_tile_ctr[CTR_SETS * 8];
 struct CtrRing {
@@ -1045,6 +1049,7 @@ struct CtrRing {
   hipStream_t st;
   uint32_t next;
   bool used;
+  uint64_t last_use;
 };
 static unsigned int* next_counter_set(hipStream_t st) {
   static std::mutex mu;
@@ -1062,15 +1067,38 @@ static unsigned int* next_counter_set(hipStream_t st) {
   int slot = -1;
   uint32_t idx = 0;
   {
+    static uint64_t tick = 0;
+    static bool warned = false;
     std::lock_guard<std::mutex> lk(mu);
     for (int i = 0; i < CTR_STREAMS && slot < 0; ++i)
       if (rings[i].used && rings[i].dev == dev && rings[i].st == st) slot = i;
     for (int i = 0; i < CTR_STREAMS && slot < 0; ++i)
       if (!rings[i].used) {
-        rings[i] = CtrRing{dev, st, 0u, true};
+        rings[i] = CtrRing{dev, st, 0u, true, 0};
         slot = i;
       }
-    if (slot < 0) return nullptr;                     // more concurrent streams than rings: per-tile launch form
+    if (slot < 0) {
+      // reclaim: least recently used ring whose stream is idle (or gone).  A ring of THIS device only: its counter sets live in this
+      // device's copy of g_tile_ctr, and a stream of another device cannot be queried without switching devices.
+      uint64_t best = ~0ull;
+      for (int i = 0; i < CTR_STREAMS; ++i) {
+        if (rings[i].dev != dev || rings[i].last_use >= best) continue;
+        const hipError_t q = hipStreamQuery(rings[i].st);
+        if (q == hipErrorNotReady) continue;          // work in flight: its counters may be live
+        if (q != hipSuccess) (void)hipGetLastError();  // invalid handle: the stream was destroyed
+        best = rings[i].last_use;
+        slot = i;
+      }
+      if (slot >= 0) rings[slot] = CtrRing{dev, st, 0u, true, 0};
+    }
+    if (slot < 0) {                                   // every ring busy: per-tile launch form
+      if (!warned) {
+        warned = true;
+        fprintf(stderr, "gritlm_hip: %d streams with persistent GEMMs in flight; further streams take the per-tile launch form\n", CTR_STREAMS);
+      }
+      return nullptr;
+    }
+    rings[slot].last_use = ++tick;
     idx = rings[slot].next++ % CTR_PER_STREAM;
   }
   unsigned int* set = b + ((size_t)slot * CTR_PER_STREAM + idx) * 8;

@@ -104,7 +104,8 @@ class DistributedIndex:
             if overwrite_saved_passages or not os.path.exists(ppath):
                 with open(ppath, "wb") as f:
                     pickle.dump([self.doc_map[i] for i in range(start, stop)], f, protocol=pickle.HIGHEST_PROTOCOL)
-            torch.save(self.embeddings[:, start:stop], self._get_saved_embedding_path(path, shard))
+            # .clone(): torch.save of a column VIEW writes the whole underlying storage into every shard file
+            torch.save(self.embeddings[:, start:stop].clone(), self._get_saved_embedding_path(path, shard))
 
     def load_index(self, path: str, total_saved_shards: int):
         """This rank's ``total_saved_shards / world`` shard files, in shard order (no index structure: the matrix IS the index)."""
@@ -122,7 +123,14 @@ class DistributedIndex:
     def _compute_scores_and_indices(self, allqueries: torch.Tensor, topk: int):
         """index.py:97-104 (``queries @ embeddings`` -> ``torch.topk``) on the native kernel: scores [Q, topk] fp32 descending and
         the column of each.  ``topk`` larger than the shard returns the whole shard."""
-        emb = self.embeddings if self.embeddings.dtype == torch.float32 else self.embeddings.to(torch.float32)
+        emb = self.embeddings
+        if emb.dtype != torch.float32:
+            # the kernel takes fp32: widen a bf16 / fp16 index ONCE and keep the copy until the index tensor is replaced or written to
+            # (ADVICE r04: a fresh full-size copy per search_knn call tripled the footprint and re-read the whole index per query batch)
+            key = (emb.data_ptr(), tuple(emb.shape), emb.dtype, emb._version)
+            if getattr(self, "_emb32_key", None) != key:
+                self._emb32, self._emb32_key = emb.to(torch.float32), key
+            emb = self._emb32
         q = allqueries.to(device=emb.device, dtype=torch.float32).contiguous()
         return ops.knn_topk(q, emb, min(topk, emb.shape[1]), transposed=True)
 

@@ -142,6 +142,37 @@ def check_f32_stream_ops(T=37, H=4096):
     return _res(f"f32_stream_ops[T={T},H={H}]", same and err < 5e-3 and exact > 0.99, gather_exact=same, rms_max_rel=err, rms_exact_frac=exact)
 
 
+def check_gemm_counter_rings_are_reclaimed(n_streams=40):
+    """The persistent GEMM's tile-queue counter rings (csrc/gemm_bf16.hip: 16 rings keyed by (device, stream)): more streams than rings over
+    the life of a process must keep working AND keep the persistent form -- an idle stream's ring is reclaimed -- with results
+    bit-identical to the default stream's; streams that are all busy at once fall back to the per-tile form, same bits."""
+    M, N, K = 8192, 4096, 512                                      # 512 tiles >= 2 per CU: the persistent form
+    g = torch.Generator(device=DEV).manual_seed(77)
+    a = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    ref = ops.gemm_nt(a, w)
+    torch.cuda.synchronize()
+    same = True
+    for i in range(n_streams):                                     # one after the other: every earlier stream is idle when the next one starts
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            out = ops.gemm_nt(a, w)
+        st.synchronize()
+        same &= bool(torch.equal(out, ref))
+        del st
+    streams = [torch.cuda.Stream() for _ in range(24)]             # 24 streams busy at the same time: some take the per-tile form
+    outs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                o = ops.gemm_nt(a, w)
+            outs.append(o)
+    torch.cuda.synchronize()
+    same_busy = all(bool(torch.equal(o, ref)) for o in outs)
+    return _res(f"gemm counter rings reclaimed [{n_streams} sequential + 24 concurrent streams]", same and same_busy, sequential_identical=same,
+                concurrent_identical=same_busy)
+
+
 def check_gemm_pair(M1=300, N1=272, M2=520, N2=720, K=192, accumulate=True, seed=17):
     """grit_gemm_bf16_nt_pair: two problems in one launch must give the bits of two grit_gemm_bf16_nt launches (strided operands too)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -2902,6 +2933,7 @@ ALL_CHECKS = [
     ("f32_stream_ops", check_f32_stream_ops, {}),
     ("f32_stream_ops_768", check_f32_stream_ops, dict(T=9, H=768)),
     ("f32_stream_ops_264", check_f32_stream_ops, dict(T=5, H=264)),
+    ("gemm_counter_rings_reclaimed", check_gemm_counter_rings_are_reclaimed, {}),
     ("gemm_pair", check_gemm_pair, {}),
     ("gemm_pair_store", check_gemm_pair, dict(M1=17, N1=1536, M2=1024, N2=256, K=256, accumulate=False)),
     ("gemm_pair_wgrad_shape", check_gemm_pair, dict(M1=4096, N1=14336, M2=6144, N2=4096, K=2048)),
