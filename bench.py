@@ -432,28 +432,33 @@ def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32
         try:
             e = ops.pool_norm(eng.forward(si, sm, borrow=True), sm, "mean", True).float().clone()
             d = omc(e, ref)
-            rate = None
+            rate, extra = None, {}
             if time_steps:
                 ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
                 torch.cuda.synchronize()
+                tm = ops.KernelTimer()                 # the same per-launch HIP events as the primary timed region
+                ops.set_timer(tm)
                 t0 = time.perf_counter()
                 for _ in range(time_steps):
                     ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
                 torch.cuda.synchronize()
                 rate = ids.shape[0] * time_steps / (time.perf_counter() - t0)
-            extra = {}
+                ops.set_timer(None)
+                extra["kernels"] = {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3), "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12,
+                                        **({"by_shape_tflops": {t: round(x["work"] / (x["total_ms"] * 1e-3) / 1e12, 1) for t, x in v["by_tag"].items()}}
+                                           if "by_tag" in v else {})} for k, v in tm.summary().items()}
             if policy == "f16_operands":
                 st = eng.f16_weight_stats or {}
-                extra = {"fp16_overflow_flag": bool(ops.f16_overflow_flag(eng.device)),
-                         "weights_subnormal_in_fp16_frac": st.get("subnormal", 0) / max(st.get("total", 1), 1)}
+                extra.update({"fp16_overflow_flag": bool(ops.f16_overflow_flag(eng.device)),
+                              "weights_subnormal_in_fp16_frac": st.get("subnormal", 0) / max(st.get("total", 1), 1)})
         finally:
             eng.set_precision("bf16")
             eng._ws.clear()
         return d, rate, extra
 
-    d, rate, _ = opt_in("fp32_residual")
+    d, rate, extra = opt_in("fp32_residual")
     out["engine_fp32_residual_opt_in"] = {**d, "bound": BENCH_BOUND_FP32_RESIDUAL, "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_FP32_RESIDUAL,
-                                          "docs_per_s": rate, "how": "GritLM(..., precision='fp32_residual') / engine.set_precision('fp32_residual')"}
+                                          "docs_per_s": rate, **extra, "how": "GritLM(..., precision='fp32_residual') / engine.set_precision('fp32_residual')"}
     d, rate, extra = opt_in("f16_operands")
     out["engine_f16_operands_opt_in"] = {**d, "bound": BENCH_BOUND_F16_OPERANDS,
                                          "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_F16_OPERANDS and not extra.get("fp16_overflow_flag", True),

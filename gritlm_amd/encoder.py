@@ -356,7 +356,9 @@ class MistralEncoderEngine:
 
     def _weights(self, L: _Layer):
         """(wqkv, wo, wgu, wdown) in the operand format of the current policy"""
-        return self._f16_weights(L) if self.precision == "f16_operands" else (L.wqkv, L.wo, L.wgu, L.wdown)
+        if self.precision == "f16_operands":
+            return self._f16_weights(L)
+        return (L.wqkv, L.wo, getattr(L, "wgu", None), getattr(L, "wdown", None))        # (MoE layers have no dense MLP weights)
 
     def _window(self, S: int) -> int:
         """``window`` argument of the attention kernels for sequences of up to S tokens (0: every earlier key is inside the window)."""

@@ -8,9 +8,10 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/prof_{tag}"
-shutil.copy(f"{src}/bench_stats/bench_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
-shutil.copy(f"{src}/bench_stats.json", f"profiles/{tag}_bench_under_rocprof.json")
 import os
+if os.path.exists(f"{src}/bench_stats/bench_kernel_stats.csv"):       # (a PMC-only run -- the f16 probe, tag r05_f16 -- has no bench stats)
+    shutil.copy(f"{src}/bench_stats/bench_kernel_stats.csv", f"profiles/{tag}_bench_kernel_stats.csv")
+    shutil.copy(f"{src}/bench_stats.json", f"profiles/{tag}_bench_under_rocprof.json")
 if os.path.exists(f"{src}/bench_contrastive/bench_kernel_stats.csv"):      # encode + one contrastive (GradCache) step
     shutil.copy(f"{src}/bench_contrastive/bench_kernel_stats.csv", f"profiles/{tag}_bench_with_contrastive_kernel_stats.csv")
 
@@ -21,12 +22,14 @@ def load(path):
     rows = [r for r in csv.DictReader(open(path)) if "gemm_bf16" in r["Kernel_Name"]]
     # o_proj and down_proj are the SAME instantiation since the persistent form took over K = 14336 (<1, true>, same grid): tools/gemm_probe.py
     # launches o_proj first, so the first half of that instantiation's dispatches (by start time) is o_proj, the second half down_proj
-    starts = sorted({int(r["Start_Timestamp"]) for r in rows if "<1, true>" in r["Kernel_Name"]})
+    # (round 5: a third template argument, F16; the fp16 policy's o_proj / down are <7, true, true>)
+    both = lambda n: any(t in n for t in ("<1, true>", "<1, true, false>", "<7, true, true>"))
+    starts = sorted({int(r["Start_Timestamp"]) for r in rows if both(r["Kernel_Name"])})
     split = starts[len(starts) // 2] if len(starts) >= 2 else None
     for r in rows:
         name = r["Kernel_Name"]
         key = name.split("(")[0].replace("void ", "")
-        if "<1, true>" in name and split is not None:
+        if both(name) and split is not None:
             key += "#o_proj" if int(r["Start_Timestamp"]) < split else "#down"
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
@@ -49,9 +52,11 @@ for k, v in out.items():
     shape_tag = k.split("#")[1] if "#" in k else ""
     targs = [t.strip() for t in k.split("#")[0].split("<")[1].strip(">").split(",")]
     epi, persist = targs[0], (targs[1] if len(targs) > 1 else "false")
+    f16 = len(targs) > 2 and targs[2] == "true"
     if shape_tag:
         persist += "#" + shape_tag
-    v["shape"] = shapes.get((epi, persist), f"epilogue {epi}, persistent {persist}")
+    shapes.update({("7", "true#o_proj"): "o_proj N=4096 K=4096 (RESIDUAL_F32, persistent)", ("7", "true#down"): "down N=4096 K=14336 (RESIDUAL_F32, persistent)"})
+    v["shape"] = shapes.get((epi, persist), f"epilogue {epi}, persistent {persist}") + (" [fp16 operands]" if f16 else "")
     weights[k] = 1
     g = v["GRBM_GUI_ACTIVE"] / 8            # the counter is summed over the 8 XCDs
     v["avg_duration_s_under_pmc"] = durs[k]
@@ -69,6 +74,6 @@ for k, v in out.items():
     print(k, f"dur={v['avg_duration_s_under_pmc']*1e3:.2f}ms clock={v['effective_clock_ghz']:.2f}GHz mfma_busy={v['mfma_busy_frac_of_simd_cycles']:.3f} "
              f"traffic={v['hbm_side_bytes_per_launch']/1e9:.1f}GB lds_conflicts={v['SQ_LDS_BANK_CONFLICT']:.0f}")
 print("avg traffic per launch (GB):", avg / 1e9)
-rows = list(csv.DictReader(open(f"profiles/{tag}_bench_kernel_stats.csv")))
+rows = list(csv.DictReader(open(f"profiles/{tag}_bench_kernel_stats.csv"))) if os.path.exists(f"profiles/{tag}_bench_kernel_stats.csv") else []
 for r in rows[:8]:
     print(r["Name"][:60].ljust(60), r["Calls"].rjust(5), f'{float(r["TotalDurationNs"])/1e6:9.1f} ms', r["Percentage"])
