@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
 // hardware pack (v_cvt_pk_bf16_f32, RNE): one instruction for two conversions.  Written as a vector conversion, NOT as inline asm: the
 // compiler then knows it is a VALU write and inserts the wait states an MFMA that reads the result as SrcA/B needs -- with an opaque asm
-// statement directly in front of the MFMA, part of the lanes saw stale operands (found with the tr-read attention variant)
+// statement directly in front of the MFMA, part of the lanes saw stale operands (found with the tr-read attention variant, NOTEBOOK.md §8)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_pk_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_pk_t;
 __device__ __forceinline__ uint32_t pack2bf_hw(float lo, float hi) {

@@ -3,7 +3,7 @@
 A register spill inside these kernels is not a small cost: the reload is a scratch load, scratch loads share the vmcnt counter with the
 hand-placed LDS-DMA stream, and hipcc waits for them with ``s_waitcnt vmcnt(0)`` -- one spilled accumulator fragment in the persistent
 GEMM's first K-tile drained the DMA queue once per tile and cost the K = 14336 launches the whole gain of the persistent form
-("what the compiler left in the persistent loop").  So: zero VGPR spills and zero scratch in every instantiation, and the
+(NOTEBOOK.md §4, "what the compiler left in the persistent loop").  So: zero VGPR spills and zero scratch in every instantiation, and the
 occupancy the launch geometry counts on (two waves per SIMD)."""
 import os
 import re

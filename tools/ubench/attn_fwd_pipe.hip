@@ -1,6 +1,6 @@
 // NON-SHIPPING PROTOTYPE (round 3, tools/ubench only; built by tools/ubench/build_attn_proto.sh, compared with the shipped kernel by
 // tools/ubench/attn_ab.bin): gritlm_amd/csrc/attention.hip with ONE structural change -- in-wave software pipeline: QK of tile t + 1 between the exponentials of tile t (bidirectional blocks of >= 3 tiles; everything else runs the shipped loop).
-// Result: profiles/r03_attn_fwd_prototypes_ab.log, DESIGN.md section 8 (2).  Not part of libgritlm_hip.so.
+// Result: profiles/r03_attn_fwd_prototypes_ab.log, NOTEBOOK.md section 8 (2).  Not part of libgritlm_hip.so.
 // Bidirectional (non-causal) flash attention forward for gfx950, GQA, head_dim 128, key-padding bitmask.
 //
 // Replaces repeat_kv + the additive [B,1,S,S] mask + F.scaled_dot_product_attention of

@@ -1,6 +1,6 @@
 // NON-SHIPPING PROTOTYPE (round 3, tools/ubench only; built by tools/ubench/build_attn_proto.sh, compared with the shipped kernel by
 // tools/ubench/attn_ab.bin): gritlm_amd/csrc/attention.hip with ONE structural change -- packed fp32 (v_pk_fma_f32 / v_pk_add_f32) scale-and-shift and row sum in the softmax block.
-// Result: profiles/r03_attn_fwd_prototypes_ab.log, DESIGN.md section 8 (2).  Not part of libgritlm_hip.so.
+// Result: profiles/r03_attn_fwd_prototypes_ab.log, NOTEBOOK.md section 8 (2).  Not part of libgritlm_hip.so.
 // Bidirectional (non-causal) flash attention forward for gfx950, GQA, head_dim 128, key-padding bitmask.
 //
 // Replaces repeat_kv + the additive [B,1,S,S] mask + F.scaled_dot_product_attention of

@@ -1,4 +1,4 @@
-// Microbenchmark behind DESIGN.md "GEMM experiments": what do LDS-DMA (global_load_lds), ds_read_b128 and MFMA cost alone and
+// Microbenchmark behind NOTEBOOK.md "GEMM experiments": what do LDS-DMA (global_load_lds), ds_read_b128 and MFMA cost alone and
 // together on one CU-resident workgroup per CU (512 threads, 128 KiB LDS, the GEMM's geometry)?
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/lds_dma_mfma.hip -o gpurun_out/ubench && gpurun_out/ubench
 // Per "iteration" (= one GEMM K-tile) a workgroup does, depending on the mode bits:
