@@ -374,19 +374,26 @@ class MistralEncoderEngine:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None = None, borrow: bool = False,
-                return_kv: bool = False):
+    def forward(self, input_ids: torch.Tensor | None, attention_mask: torch.Tensor | None = None, borrow: bool = False,
+                return_kv: bool = False, inputs_embeds: torch.Tensor | None = None, layer_range: tuple | None = None,
+                final_norm: bool = True):
         """last_hidden_state [B,S,H] bf16 (after the final RMSNorm), is_causal=False semantics.
 
         ``borrow=True`` returns a view of the engine's workspace (valid until the next forward).
         ``return_kv=True`` additionally returns, per layer, the post-RoPE keys and the values as
         ``(k [B,nkv,S,d], v [B,nkv,S,d])`` -- what ``use_cache=True`` hands back in the reference
-        (gritlm/gritlm.py:131-140; RAG doc caching, rag/eval.py:132-142)."""
+        (gritlm/gritlm.py:131-140; RAG doc caching, rag/eval.py:132-142).
+        ``inputs_embeds`` [B,S,H] replaces the embedding lookup (the reference's forward takes it too, modeling_mistral_gritlm.py:944, :993-994);
+        ``layer_range=(a, b)`` runs decoder layers a .. b-1 only and ``final_norm=False`` returns the residual stream itself: together they
+        push a GIVEN hidden state through chosen layers -- the teacher-forced per-layer parity of the Mixtral leg (tools/mixtral_bench.py)."""
         c = self.cfg
-        B, S = input_ids.shape
+        if inputs_embeds is not None:
+            B, S = inputs_embeds.shape[:2]
+        else:
+            B, S = input_ids.shape
         T = B * S
         window = self._window(S)
-        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
+        ids = None if inputs_embeds is not None else input_ids.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
         if attention_mask is None:
             attention_mask = torch.ones((B, S), dtype=torch.int64, device=self.device)
         mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
@@ -397,9 +404,12 @@ class MistralEncoderEngine:
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         cos, sin = self._rope_tables(S)
         bits = ops.mask_pack(mask)
-        ops.embed_gather(self.embed, ids, out=h)
+        if inputs_embeds is not None:
+            h.copy_(inputs_embeds.to(self.device).reshape(T, c.hidden_size))
+        else:
+            ops.embed_gather(self.embed, ids, out=h)
         kv = []
-        for L in self.layers:
+        for L in (self.layers if layer_range is None else self.layers[layer_range[0]:layer_range[1]]):
             wqkv, wo = self._weights(L)[:2]
             ops.rmsnorm(h, L.ln1, eps, out=x)
             ops.gemm_nt_rope(x, wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)         # q/k/v projections + RoPE in the epilogue
@@ -411,8 +421,11 @@ class MistralEncoderEngine:
             ops.gemm_nt(ctx, wo, out=h, epilogue=self._epi_res(), residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)
             self._mlp(L, x, h, ws)
-        ops.rmsnorm(h, self.norm, eps, out=xo)
-        out = xo.view(B, S, c.hidden_size)
+        if final_norm:
+            ops.rmsnorm(h, self.norm, eps, out=xo)
+            out = xo.view(B, S, c.hidden_size)
+        else:
+            out = h.view(B, S, c.hidden_size)
         out = out if borrow else out.clone()
         return (out, kv) if return_kv else out
 

@@ -1077,6 +1077,26 @@ def check_mixtral_layer_true_shape():
     return _res("mixtral layer at the true 8x7B shape vs reference golden", bool(ok), **out)
 
 
+def check_inputs_embeds_and_layer_range(cfg_name="gqa"):
+    """`forward(inputs_embeds=...)` (the reference's forward takes it too, modeling_mistral_gritlm.py:944) == the embedding lookup, bit for
+    bit; `layer_range` + `final_norm=False` compose: layer 0 alone, then layers 1.. on its output, equals the whole forward (the bf16
+    residual stream is what crosses the cut) -- the mechanism of the Mixtral leg's teacher-forced per-layer parity; dense and MoE."""
+    det, ok = {}, True
+    for name in (cfg_name, "moe-tiny"):
+        eng, cfg, w = build_engine(name, 1)
+        ids, mask = synth.make_batch(cfg, 3, 70, seed=11, min_len=20)
+        tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+        full = eng.forward(tid, tm)
+        emb = eng.embed[tid]                                                   # [B,S,H] bf16
+        a = eng.forward(None, tm, inputs_embeds=emb)
+        h1 = eng.forward(None, tm, inputs_embeds=emb, layer_range=(0, 1), final_norm=False)
+        b = eng.forward(None, tm, inputs_embeds=h1, layer_range=(1, len(eng.layers)))
+        det[f"{name}_inputs_embeds_identical"] = bool(torch.equal(a, full))
+        det[f"{name}_layer_cut_identical"] = bool(torch.equal(b, full))
+        ok &= det[f"{name}_inputs_embeds_identical"] and det[f"{name}_layer_cut_identical"]
+    return _res("forward(inputs_embeds, layer_range, final_norm) composes to the full forward", ok, **det)
+
+
 def check_encoder_vs_oracle_bf16(cfg_name="tiny", B=3, S=130):
     """Different shape than the golden (S not a multiple of 64), against the bf16-emulating oracle."""
     eng, cfg, w = build_engine(cfg_name, 5)
@@ -3019,6 +3039,7 @@ ALL_CHECKS = [
     ("encoder_tiny", check_encoder_golden, dict(cfg_name="tiny")),
     ("encoder_gqa", check_encoder_golden, dict(cfg_name="gqa")),
     ("encoder_oracle", check_encoder_vs_oracle_bf16, {}),
+    ("inputs_embeds_and_layer_range", check_inputs_embeds_and_layer_range, {}),
     ("encoder_7b_layer", check_encoder_7b_layer, {}),
     ("encoder_tiny_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="tiny")),
     ("encoder_gqa_fp32_residual", check_encoder_fp32_residual, dict(cfg_name="gqa")),

