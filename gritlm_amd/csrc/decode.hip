@@ -17,7 +17,10 @@ __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
          bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
 }
 
-constexpr int GV_ROWS = 4;  // weight rows per workgroup; its 4 waves each take a quarter of K (split-K, LDS reduce)
+#ifndef GRIT_GV_ROWS
+#define GRIT_GV_ROWS 4      // (A/B builds: tools/decode_variants.sh)
+#endif
+constexpr int GV_ROWS = GRIT_GV_ROWS;  // weight rows per workgroup; its 4 waves each take a quarter of K (split-K, LDS reduce)
 
 // MODE 0: store, 1: + residual, 2: SwiGLU pairs (rows r, r+16 of the interleaved layout).
 // PRENORM: x is the raw residual stream and the kernel applies MistralRMSNorm on the fly (x_n = bf16(w_ln * bf16(x * rsqrt(mean x^2 + eps))),
@@ -212,6 +215,27 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     for (int i = lane; i < G * (AD_D + 2); i += 64) pbase[i] = (i % (AD_D + 2) == 0) ? -INFINITY : 0.f;
     return;
   }
+  // The slice's K and V rows are requested FIRST (round 5): 32 independent 16-byte loads per lane go out before the query heads are
+  // fetched, rotated and staged, so the kernel pays ONE memory latency (K, V, q, cos / sin overlap) instead of three in a row (q -> K ->
+  // V); 11.4 -> R05 us per layer at L = 2 k.  The one workgroup whose slice receives the NEW key appends it first and loads afterwards.
+  const int key = k0 + lane;
+  const bool live = key < L;
+  const int kg = lane >> 4, dc = lane & 15;                  // PV layout: key group kg (16 keys), dim chunk dc (8 dims)
+  const int nk = min(64, L - k0);
+  uint4 kreg[AD_D / 8], vreg[16];
+  auto load_kv = [&]() {
+    const uint4* kr = reinterpret_cast<const uint4*>(ck + (((int64_t)b * nkv + hk) * Lmax + (live ? key : L - 1)) * AD_D);
+#pragma unroll
+    for (int c = 0; c < AD_D / 8; ++c) kreg[c] = kr[c];       // 16 independent loads in flight
+    const uint16_t* vbase = cv + (((int64_t)b * nkv + hk) * Lmax + k0) * AD_D;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kk = kg * 16 + j;
+      vreg[j] = reinterpret_cast<const uint4*>(vbase + (int64_t)(kk < nk ? kk : nk - 1) * AD_D)[dc];
+    }
+  };
+  const bool owner = ROPE && (L - 1 >= k0) && (L - 1 < k0 + AD_CH);      // workgroup-uniform
+  if (!owner) load_kv();
   if constexpr (ROPE) {
     const int pos = L - 1;
     const float c = cos_tab[(int64_t)pos * 64 + lane], sn = sin_tab[(int64_t)pos * 64 + lane];     // lane <-> pair (e, e + 64)
@@ -238,16 +262,11 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     }
   }
   __syncthreads();
-  const int key = k0 + lane;
-  const bool live = key < L;
+  if (owner) load_kv();                                        // (behind the append + fence above)
   float s[AD_G];
 #pragma unroll
   for (int g = 0; g < AD_G; ++g) s[g] = 0.f;
   {
-    const uint4* kr = reinterpret_cast<const uint4*>(ck + (((int64_t)b * nkv + hk) * Lmax + (live ? key : L - 1)) * AD_D);
-    uint4 kreg[AD_D / 8];
-#pragma unroll
-    for (int c = 0; c < AD_D / 8; ++c) kreg[c] = kr[c];       // 16 independent loads in flight
 #pragma unroll
     for (int c = 0; c < AD_D / 8; ++c) {
       const uint4 kv = kreg[c];
@@ -272,16 +291,7 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
   }
   __syncthreads();
   // O partial: lane = (key group kg = lane>>4, dim chunk dc = lane&15): 16 INDEPENDENT 16-byte loads per lane (keys kg*16 .. +15, dims
-  // 8dc .. +7), then the 4 key groups are folded with two shuffles -- one memory latency instead of one per key
-  const int kg = lane >> 4, dc = lane & 15;
-  const int nk = min(64, L - k0);
-  const uint16_t* vbase = cv + (((int64_t)b * nkv + hk) * Lmax + k0) * AD_D;
-  uint4 vreg[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int kk = kg * 16 + j;
-    vreg[j] = reinterpret_cast<const uint4*>(vbase + (int64_t)(kk < nk ? kk : nk - 1) * AD_D)[dc];
-  }
+  // 8dc .. +7; requested at the top of the kernel), then the 4 key groups are folded with two shuffles
 #pragma unroll
   for (int g = 0; g < AD_G; ++g) {
     if (g >= G) break;

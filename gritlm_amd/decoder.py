@@ -31,6 +31,14 @@ class MistralDecoder:
         self.eng, self.cfg, self.device = engine, engine.cfg, engine.device
         self.lm_head = lm_head.detach().to(device=self.device, dtype=BF16).contiguous()
         self.use_graph = True
+        # which RMSNorms ride inside the following GEMV (grit_rmsnorm_gemv_bf16): "all" (input_layernorm -> q|k|v, post_attention_layernorm
+        # -> gate|up, final norm -> lm_head), "qkv" (the MLP's and the final norm get their own launches) or "none"; GRIT_DECODE_FUSE_NORM for A/B runs
+        # (tools/decode_variants.sh).  Same bits in every form: the fused kernel applies the reference's two roundings.
+        import os
+        # Default "qkv" (round 5, tools/decode_variants.sh on one box: all 3.49, qkv 3.25, none 3.32 ms per token): the 7168 workgroups of
+        # the gate|up GEMV -- and the 8000 of lm_head -- each re-derive the row's RMS when the norm is fused, which costs more than the
+        # one-row launch it saves; the q|k|v GEMV is a single workgroup wave deep and keeps the fusion.
+        self.fuse_norm = os.environ.get("GRIT_DECODE_FUSE_NORM", "qkv")
 
     # ------------------------------------------------------------------ one decode step (all sizes static, lengths on the device)
     def _step(self, st):
@@ -38,16 +46,24 @@ class MistralDecoder:
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         h, qkv, ctx, act = st["h"], st["qkv"], st["ctx"], st["act"]
         ops.embed_gather(e.embed, st["next"], out=h)
-        if h.shape[0] > 2:
+        if h.shape[0] > 2 or self.fuse_norm == "none":
             return self._step_unfused_norm(st)
         for li, L in enumerate(e.layers):
             ck, cv = st["cache"][li]
             ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv)                      # input_layernorm + q/k/v projections
             ops.attn_decode_rope(qkv, st["cos"], st["sin"], ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)   # RoPE + KV append + attention
             ops.gemv(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
-            ops.rmsnorm_gemv(h, L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU)   # post_attention_layernorm + gate/up + SwiGLU
+            if self.fuse_norm == "all":
+                ops.rmsnorm_gemv(h, L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU)   # post_attention_layernorm + gate/up + SwiGLU
+            else:
+                ops.rmsnorm(h, L.ln2, eps, out=st["x"])
+                ops.gemv(st["x"], L.wgu, out=act, epilogue=EPI_SWIGLU)
             ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
-        ops.rmsnorm_gemv(h, e.norm, eps, self.lm_head, out=st["logits"])           # final norm + lm_head
+        if self.fuse_norm == "all":
+            ops.rmsnorm_gemv(h, e.norm, eps, self.lm_head, out=st["logits"])       # final norm + lm_head
+        else:
+            ops.rmsnorm(h, e.norm, eps, out=st["x"])
+            ops.gemv(st["x"], self.lm_head, out=st["logits"])
 
     def _step_unfused_norm(self, st):
         """More than 2 rows: every workgroup of the fused kernel would re-derive each row's RMS, so the norm gets its own launch."""

@@ -51,7 +51,9 @@ eng.record_routing = None
 #      restated in FP32 (oracle/torch_reference.py::mixtral_encode_fp32, pinned on the reference-generated Mixtral fixtures).
 #      Two data.  (1) TEACHER-FORCED, per layer -- the bound: the fp32 run's residual stream entering layers 0, L/2 and L-1 is handed to
 #      the engine (`inputs_embeds`, `layer_range`), and the stream leaving the layer is compared token by token: routing agreement (all
-#      tokens; tokens whose 2nd-vs-3rd router margin exceeds 0.05 must agree), per-row relative error on tokens that took the same experts.
+#      tokens >= 0.97; EVERY token whose router logits separate the 2nd from the 3rd choice by more than 4.0 -- the logits of this
+#      random-init router have a standard deviation of ~30 and bf16 noise in x moves them by ~0.5 -- must take the fp32 run's experts),
+#      per-row relative error on tokens that took the same experts.
 #      (2) END TO END, all layers free-running -- reported, bounds nothing: top-2 routing is a discontinuous function of x, a token that
 #      takes another expert once has a perturbed state from then on and re-decides its routing in every later layer (random-init experts
 #      are unrelated functions), so a bf16 run and an fp32 run of a 32-layer random-init MoE decorrelate token by token; the reference's
@@ -83,10 +85,10 @@ if a.parity_docs > 0:
                 r_eng = eng.record_routing[0].view(1, a.seq, 2).sort(-1)[0].to(sel.device)
                 eng.record_routing = None
                 same = (r_eng == sel).all(-1)[0]
-                clear = margin[0] > 0.05
+                clear = margin[0] > 4.0
                 d = per_layer[li]
                 d["agree"].append(float(same.float().mean())); d["clear_n"] += int(clear.sum())
-                d["clear_agree"].append(float(same[clear].float().mean()) if bool(clear.any()) else 1.0)
+                d["clear_agree"].append(bool(same[clear].all()))
                 xo, xi, g = x_out[0][same], x_in[0][same], got[0][same]
                 d["row_rel"].append(((g - xo).norm(dim=1) / xo.norm(dim=1)).cpu())
                 d["upd_rel"].append(((g - xo).norm(dim=1) / (xo - xi).norm(dim=1)).cpu())
@@ -98,10 +100,10 @@ if a.parity_docs > 0:
     tf, ok = {}, True
     for li, d in per_layer.items():
         rr, ur = torch.cat(d["row_rel"]), torch.cat(d["upd_rel"])
-        tf[str(li)] = {"routing_agree": min(d["agree"]), "clear_margin_tokens": d["clear_n"], "clear_margin_agree": min(d["clear_agree"]),
+        tf[str(li)] = {"routing_agree": min(d["agree"]), "clear_gap_tokens": d["clear_n"], "clear_gap_all_agree": all(d["clear_agree"]),
                        "row_rel_median": float(rr.median()), "row_rel_p90": float(rr.quantile(0.9)), "row_rel_max": float(rr.max()),
                        "update_rel_median": float(ur.median())}
-        ok = ok and tf[str(li)]["routing_agree"] >= B_AGREE and tf[str(li)]["clear_margin_agree"] == 1.0 and tf[str(li)]["row_rel_median"] < B_ROW
+        ok = ok and tf[str(li)]["routing_agree"] >= B_AGREE and tf[str(li)]["clear_gap_all_agree"] and tf[str(li)]["row_rel_median"] < B_ROW
     parity = {"what": f"the first {n} documents of the timed batch ({a.seq} tokens each): HIP engine (bf16, the reference's arithmetic type) vs the reference's "
                       "bidirectional Mixtral restated in FP32 on the engine's own weights (oracle/torch_reference.py, pinned on the reference-generated "
                       "fixtures).  teacher_forced_per_layer: the fp32 run's residual stream entering the layer is given to the engine, the stream "
@@ -110,7 +112,7 @@ if a.parity_docs > 0:
                       "embeddings -- reported only: top-2 routing is discontinuous, a re-routed token re-decides every later layer, and a bf16 and an "
                       "fp32 run of a random-init 32-layer MoE decorrelate token by token (the reference's own bf16 run re-routes 1.6 % of the tokens of "
                       "ONE layer at this shape: tests/golden/encoder_8x7b-l1.npz)",
-              "docs": n, "teacher_forced_per_layer": tf, "bounds": {"routing_agree_min": B_AGREE, "clear_margin_agree": 1.0, "row_rel_median_max": B_ROW},
+              "docs": n, "teacher_forced_per_layer": tf, "bounds": {"routing_agree_min": B_AGREE, "tokens_with_logit_gap_above_4_all_agree": True, "row_rel_median_max": B_ROW},
               "end_to_end": {"max_one_minus_cos": float(omc.max()), "mean_one_minus_cos": float(omc.mean())},
               "within_bound": bool(ok and torch.isfinite(e_eng).all()), "fp32_reference_seconds": time.perf_counter() - t0p}
     del refs, e_ref
