@@ -198,16 +198,48 @@ constexpr int AD_D = 128, AD_CH = 64, AD_G = 8;   // up to 8 query heads per kv 
 // ROPE: q arrives un-rotated in the fused qkv row; every workgroup rotates its G query heads itself (position lens[b]) and the one whose
 // slice contains that position also rotates the new k, appends k and v to the cache and then reads them back like any other key --
 // the RoPE + KV-append launch of a decode step disappears.
-template <bool ROPE>
+// All-reduce of NG independent values over the 64 lanes in registers: four row rotations by DPP (all-reduce inside every 16-lane row),
+// then v_permlane16_swap / v_permlane32_swap for the rows (gfx950) -- no LDS-queue instruction.  (`wave_max` / `wave_sum` of common.h
+// are six DEPENDENT ds_bpermute round trips each, ~3 us for the eight reductions of a GQA group of four when they run one after the
+// other; here the NG chains are interleaved step by step.)  Sum order differs from wave_sum's: used only where no bit pattern is pinned.
+template <int NG, bool IS_MAX>
+__device__ __forceinline__ void wave_allreduce(float (&v)[NG]) {
+  auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+#define GRIT_DPP_STEP(CTRL)                                                                                                      \
+  _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                                               \
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v[g]), (CTRL), 0xf, 0xf, false);                                 \
+    v[g] = op(v[g], __int_as_float(t));                                                                                          \
+  }
+  GRIT_DPP_STEP(0x121)      // row_ror:1
+  GRIT_DPP_STEP(0x122)      // row_ror:2
+  GRIT_DPP_STEP(0x124)      // row_ror:4
+  GRIT_DPP_STEP(0x128)      // row_ror:8
+#undef GRIT_DPP_STEP
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[g]), __float_as_uint(v[g]), false, false);
+    v[g] = op(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g]), __float_as_uint(v[g]), false, false);
+    v[g] = op(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+  }
+}
+
+// G = query heads per kv head, a TEMPLATE argument (round 5): with the run-time G of rounds 1-4 every loop over the heads carried an
+// `if (g >= G) break`, the compiler could neither unroll nor interleave the heads' dot products and reductions, and the one wave of a
+// workgroup executed them back to back -- the kernel was bound by its own dependent-instruction chains (11.4 us per layer at L = 2 k
+// for 32 KB of K / V per workgroup), not by memory.
+template <bool ROPE, int G>
 __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__ q, uint16_t* __restrict__ ck, uint16_t* __restrict__ cv,
                                                     const int32_t* __restrict__ lens, float* __restrict__ part, const float* __restrict__ cos_tab,
                                                     const float* __restrict__ sin_tab, int nq, int nkv, int Lmax, int64_t q_stride, float scale,
                                                     int max_splits) {
-  __shared__ float qs[AD_G][AD_D];           // query heads of this kv head, pre-scaled
-  __shared__ float ps[AD_G][64];             // probabilities of the 64 keys
+  __shared__ __attribute__((aligned(16))) float qs[G][AD_D];   // query heads of this kv head, pre-scaled
+  __shared__ float ps[G][64];                                  // probabilities of the 64 keys
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x;
-  const int G = nq / nkv;
   const int L = lens[b] + 1;                 // keys 0 .. lens[b] (the new token was appended)
   const int k0 = split * AD_CH;
   float* pbase = part + (((int64_t)b * nkv + hk) * max_splits + split) * G * (AD_D + 2);
@@ -215,9 +247,8 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     for (int i = lane; i < G * (AD_D + 2); i += 64) pbase[i] = (i % (AD_D + 2) == 0) ? -INFINITY : 0.f;
     return;
   }
-  // The slice's K and V rows are requested FIRST (round 5): 32 independent 16-byte loads per lane go out before the query heads are
-  // fetched, rotated and staged, so the kernel pays ONE memory latency (K, V, q, cos / sin overlap) instead of three in a row (q -> K ->
-  // V); 11.4 -> R05 us per layer at L = 2 k.  The one workgroup whose slice receives the NEW key appends it first and loads afterwards.
+  // The slice's K and V rows are requested FIRST: 32 independent 16-byte loads per lane go out before the query heads are fetched,
+  // rotated and staged.  The one workgroup whose slice receives the NEW key appends it first and loads afterwards.
   const int key = k0 + lane;
   const bool live = key < L;
   const int kg = lane >> 4, dc = lane & 15;                  // PV layout: key group kg (16 keys), dim chunk dc (8 dims)
@@ -240,16 +271,21 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     const int pos = L - 1;
     const float c = cos_tab[(int64_t)pos * 64 + lane], sn = sin_tab[(int64_t)pos * 64 + lane];     // lane <-> pair (e, e + 64)
     const uint16_t* row = q + (int64_t)b * q_stride;
+    float x1[G], x2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {                             // all 2 G loads in flight before the first use
+      x1[g] = bf2f(row[(int64_t)(hk * G + g) * AD_D + lane]); x2[g] = bf2f(row[(int64_t)(hk * G + g) * AD_D + 64 + lane]);
+    }
+#pragma unroll
     for (int g = 0; g < G; ++g) {
-      const float x1 = bf2f(row[(int64_t)(hk * G + g) * AD_D + lane]), x2 = bf2f(row[(int64_t)(hk * G + g) * AD_D + 64 + lane]);
-      const uint32_t r = pack2bf(rope_lo(x1, x2, c, sn), rope_hi(x1, x2, c, sn));                     // one rounding, as rope_k
+      const uint32_t r = pack2bf(rope_lo(x1[g], x2[g], c, sn), rope_hi(x1[g], x2[g], c, sn));         // one rounding, as rope_k
       qs[g][lane] = bflo(r) * scale; qs[g][64 + lane] = bfhi(r) * scale;
     }
-    if (pos >= k0 && pos < k0 + AD_CH) {                  // this workgroup owns the new key: rotate k, append k and v
+    if (owner) {                                          // this workgroup owns the new key: rotate k, append k and v
       const uint16_t* kr = row + (int64_t)(nq + hk) * AD_D;
       const uint16_t* vr = row + (int64_t)(nq + nkv + hk) * AD_D;
-      const float x1 = bf2f(kr[lane]), x2 = bf2f(kr[64 + lane]);
-      const uint32_t r = pack2bf(rope_lo(x1, x2, c, sn), rope_hi(x1, x2, c, sn));
+      const float y1 = bf2f(kr[lane]), y2 = bf2f(kr[64 + lane]);
+      const uint32_t r = pack2bf(rope_lo(y1, y2, c, sn), rope_hi(y1, y2, c, sn));
       uint16_t* kd = ck + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D;
       kd[lane] = (uint16_t)(r & 0xffff); kd[64 + lane] = (uint16_t)(r >> 16);
       reinterpret_cast<uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D)[lane] = reinterpret_cast<const uint32_t*>(vr)[lane];
@@ -263,55 +299,62 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
   }
   __syncthreads();
   if (owner) load_kv();                                        // (behind the append + fence above)
-  float s[AD_G];
+  float s[G];
 #pragma unroll
-  for (int g = 0; g < AD_G; ++g) s[g] = 0.f;
-  {
+  for (int g = 0; g < G; ++g) s[g] = 0.f;
 #pragma unroll
-    for (int c = 0; c < AD_D / 8; ++c) {
-      const uint4 kv = kreg[c];
-      const float kf[8] = {bflo(kv.x), bfhi(kv.x), bflo(kv.y), bfhi(kv.y), bflo(kv.z), bfhi(kv.z), bflo(kv.w), bfhi(kv.w)};
+  for (int c = 0; c < AD_D / 8; ++c) {
+    const uint4 kv = kreg[c];
+    const float kf[8] = {bflo(kv.x), bfhi(kv.x), bflo(kv.y), bfhi(kv.y), bflo(kv.z), bfhi(kv.z), bflo(kv.w), bfhi(kv.w)};
 #pragma unroll
-      for (int g = 0; g < AD_G; ++g) {
-        if (g >= G) break;
-        const float* qg = &qs[g][c * 8];
-        s[g] += kf[0] * qg[0] + kf[1] * qg[1] + kf[2] * qg[2] + kf[3] * qg[3] + kf[4] * qg[4] + kf[5] * qg[5] + kf[6] * qg[6] + kf[7] * qg[7];
-      }
+    for (int g = 0; g < G; ++g) {
+      const float4 qa = *reinterpret_cast<const float4*>(&qs[g][c * 8]), qb = *reinterpret_cast<const float4*>(&qs[g][c * 8 + 4]);
+      s[g] += kf[0] * qa.x + kf[1] * qa.y + kf[2] * qa.z + kf[3] * qa.w + kf[4] * qb.x + kf[5] * qb.y + kf[6] * qb.z + kf[7] * qb.w;
     }
   }
-  float mg[AD_G], lg[AD_G];
+  float mg[G], lg[G];
 #pragma unroll
-  for (int g = 0; g < AD_G; ++g) {
-    if (g >= G) break;
-    const float sv = live ? s[g] : -INFINITY;
-    mg[g] = wave_max(sv);
-    const float p = live ? __expf(sv - mg[g]) : 0.f;
-    lg[g] = wave_sum(p);
+  for (int g = 0; g < G; ++g) mg[g] = live ? s[g] : -INFINITY;
+  wave_allreduce<G, true>(mg);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float p = live ? __expf(s[g] - mg[g]) : 0.f;
+    lg[g] = p;
     ps[g][lane] = p;
   }
+  wave_allreduce<G, false>(lg);
   __syncthreads();
   // O partial: lane = (key group kg = lane>>4, dim chunk dc = lane&15): 16 INDEPENDENT 16-byte loads per lane (keys kg*16 .. +15, dims
-  // 8dc .. +7; requested at the top of the kernel), then the 4 key groups are folded with two shuffles
+  // 8dc .. +7; requested at the top of the kernel), then the 4 key groups are folded through the two row swaps
+  float o[G][8];
 #pragma unroll
-  for (int g = 0; g < AD_G; ++g) {
-    if (g >= G) break;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint4 v = vreg[j];
+    const float vf[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
       const float p = ps[g][kg * 16 + j];            // 0 for keys past the sequence
-      const uint4 v = vreg[j];
-      o[0] += p * bflo(v.x); o[1] += p * bfhi(v.x); o[2] += p * bflo(v.y); o[3] += p * bfhi(v.y);
-      o[4] += p * bflo(v.z); o[5] += p * bfhi(v.z); o[6] += p * bflo(v.w); o[7] += p * bfhi(v.w);
-    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      o[e] += __shfl_xor(o[e], 16, 64);
-      o[e] += __shfl_xor(o[e], 32, 64);
+      for (int e = 0; e < 8; ++e) o[g][e] += p * vf[e];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                    // fold the four key groups (rows of 16 lanes): same dims sit 16 / 32 lanes apart
+      const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[g][e]), __float_as_uint(o[g][e]), false, false);
+      const float t = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+      const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+      o[g][e] = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
     }
     float* pg = pbase + g * (AD_D + 2);
     if (kg == 0) {
-      *reinterpret_cast<float4*>(pg + 2 + 8 * dc) = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(pg + 2 + 8 * dc + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      *reinterpret_cast<float4*>(pg + 2 + 8 * dc) = make_float4(o[g][0], o[g][1], o[g][2], o[g][3]);
+      *reinterpret_cast<float4*>(pg + 2 + 8 * dc + 4) = make_float4(o[g][4], o[g][5], o[g][6], o[g][7]);
     }
     if (lane == 0) { pg[0] = mg[g]; pg[1] = lg[g]; }
   }
@@ -319,36 +362,40 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
 
 __global__ void __launch_bounds__(128) attn_decode_combine_k(const float* __restrict__ part, uint16_t* __restrict__ out, int nq, int nkv,
                                                              int max_splits, int64_t out_stride) {
-  __shared__ float fs[512];                  // per split: exp(m_s - m) ; [max_splits] then l in fs[max_splits]
-  __shared__ float red[2];
-  const int h = blockIdx.x, b = blockIdx.y, e = threadIdx.x;
+  // (round 5) every wave derives the global maximum and the denominator for itself, in registers: the (m_s, l_s) pairs of all splits
+  // are fetched in ONE pass (two loads per split and lane, all in flight), reduced with the register all-reduce above -- one memory
+  // round trip and one barrier (the rescale factors go through LDS) instead of three of each
+  __shared__ float fs[2][512];               // per wave: exp(m_s - m) of every split
+  const int h = blockIdx.x, b = blockIdx.y, e = threadIdx.x, lane = e & 63, wave = e >> 6;
   const int G = nq / nkv, hk = h / G, g = h - hk * G;
   const int64_t sstride = (int64_t)G * (AD_D + 2);
   const float* base = part + ((int64_t)b * nkv + hk) * max_splits * sstride + g * (AD_D + 2);
-  // pass 1 (parallel over the splits): global max and the per-split rescale factors
-  float m = -INFINITY;
-  for (int s = e; s < max_splits; s += 128) m = fmaxf(m, base[s * sstride]);
-  m = wave_max(m);
-  if ((e & 63) == 0) red[e >> 6] = m;
-  __syncthreads();
-  m = fmaxf(red[0], red[1]);
-  float l = 0.f;
-  for (int s = e; s < max_splits; s += 128) {
-    const float ms = base[s * sstride];
-    const float f = ms == -INFINITY ? 0.f : __expf(ms - m);
-    fs[s] = f;
-    l += base[s * sstride + 1] * f;
+  float ms[8], ls[8];                        // max_splits <= 512 = 8 per lane
+  float m[1] = {-INFINITY};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int sp = lane + 64 * i;
+    ms[i] = sp < max_splits ? base[sp * sstride] : -INFINITY;
+    ls[i] = sp < max_splits ? base[sp * sstride + 1] : 0.f;
   }
-  l = wave_sum(l);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[0] = fmaxf(m[0], ms[i]);
+  wave_allreduce<1, true>(m);
+  float l[1] = {0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int sp = lane + 64 * i;
+    const float f = ms[i] == -INFINITY ? 0.f : __expf(ms[i] - m[0]);
+    if (sp < max_splits) fs[wave][sp] = f;
+    l[0] += ls[i] * f;
+  }
+  wave_allreduce<1, false>(l);
   __syncthreads();
-  if ((e & 63) == 0) red[e >> 6] = l;
-  __syncthreads();
-  l = red[0] + red[1];
-  // pass 2: thread e owns output dim e; the loads of different splits are independent
+  // thread e owns output dim e; the loads of different splits are independent
   float acc = 0.f;
 #pragma unroll 8
-  for (int s = 0; s < max_splits; ++s) acc += base[s * sstride + 2 + e] * fs[s];
-  out[(int64_t)b * out_stride + (int64_t)h * AD_D + e] = (uint16_t)f2bf(l > 0.f ? acc / l : 0.f);
+  for (int sp = 0; sp < max_splits; ++sp) acc += base[sp * sstride + 2 + e] * fs[wave][sp];
+  out[(int64_t)b * out_stride + (int64_t)h * AD_D + e] = (uint16_t)f2bf(l[0] > 0.f ? acc / l[0] : 0.f);
 }
 
 // ---- greedy sampling + advance: next[b] = argmax_v logits[b, v] (lowest index on ties), lens[b] += 1
@@ -487,12 +534,20 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
   const int splits = (Lmax + AD_CH - 1) / AD_CH;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)splits, (unsigned)nkv, (unsigned)B);
-  if (cos_tab)
-    hipLaunchKernelGGL(attn_decode_k<true>, grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace, cos_tab,
-                       sin_tab, nq, nkv, Lmax, q_stride, scale, splits);
-  else
-    hipLaunchKernelGGL(attn_decode_k<false>, grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
-                       (const float*)nullptr, (const float*)nullptr, nq, nkv, Lmax, q_stride, scale, splits);
+#define GRIT_AD_LAUNCH(R, GG)                                                                                                           \
+  hipLaunchKernelGGL((attn_decode_k<R, GG>), grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace, \
+                     cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits)
+#define GRIT_AD_BY_G(R)                                                                                                                 \
+  switch (nq / nkv) {                                                                                                                   \
+    case 1: GRIT_AD_LAUNCH(R, 1); break;                                                                                                \
+    case 2: GRIT_AD_LAUNCH(R, 2); break;                                                                                                \
+    case 4: GRIT_AD_LAUNCH(R, 4); break;                                                                                                \
+    case 8: GRIT_AD_LAUNCH(R, 8); break;                                                                                                \
+    default: GRIT_REQUIRE(false, GRIT_E_UNSUPPORTED, "%s: %d query heads per kv head (1, 2, 4 or 8 are built)", name, nq / nkv);       \
+  }
+  if (cos_tab) { GRIT_AD_BY_G(true) } else { GRIT_AD_BY_G(false) }
+#undef GRIT_AD_BY_G
+#undef GRIT_AD_LAUNCH
   GRIT_CHECK_LAUNCH(name);
   hipLaunchKernelGGL(attn_decode_combine_k, dim3((unsigned)nq, (unsigned)B), dim3(AD_D), 0, st, (const float*)workspace, (uint16_t*)out, nq, nkv,
                      splits, out_stride);
