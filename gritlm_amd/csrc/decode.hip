@@ -31,14 +31,11 @@ constexpr int GV_ROWS = GRIT_GV_ROWS;  // weight rows per workgroup; its 4 waves
 // The accumulators are EXACT integers, so the sum does not depend on the order the workgroups arrive in (decode stays reproducible):
 // a partial below 2^23 is added as round(partial * 2^30) to the LOW word, a larger one as partial * 2^8 (an integer: its ulp is >= 1) to
 // the HIGH word; sum of squares = low * 2^-30 + high * 2^-8.
-// Layout: [row][low / high][SS_SLOTS][SS_PAD words]: every slot sits in its OWN 128-byte line -- with the 16 slots of the first version in
-// one line the 1024 atomics of a launch serialised in one L2 atomic unit and the residual GEMVs ran 3.6 us longer each
-// (profiles/r05_decode_kernel_stats_*: 14.3 -> 17.9 us); a workgroup adds into slot blockIdx % SS_SLOTS.
-constexpr int SS_SLOTS = 32, SS_PAD = 16;
+constexpr int SS_SLOTS = 16;
 __device__ __forceinline__ float ss_total(const unsigned long long* __restrict__ ss, int b) {
   unsigned long long lo = 0, hi = 0;
 #pragma unroll
-  for (int j = 0; j < SS_SLOTS; ++j) { lo += ss[((b * 2 + 0) * SS_SLOTS + j) * SS_PAD]; hi += ss[((b * 2 + 1) * SS_SLOTS + j) * SS_PAD]; }
+  for (int j = 0; j < SS_SLOTS; ++j) { lo += ss[(b * 2 + 0) * SS_SLOTS + j]; hi += ss[(b * 2 + 1) * SS_SLOTS + j]; }
   return (float)((double)lo * 0x1p-30 + (double)hi * 0x1p-8);
 }
 template <int NB, int MODE, int NORM>
@@ -168,9 +165,9 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
         for (int i = 0; i < GV_ROWS; ++i) part += sqs[i * NB + t];          // fixed order
         const int slot = (int)(blockIdx.x & (SS_SLOTS - 1));
         if (part < 8388608.f)
-          atomicAdd(&ss_out[((t * 2 + 0) * SS_SLOTS + slot) * SS_PAD], (unsigned long long)(part * 0x1p30f));
+          atomicAdd(&ss_out[(t * 2 + 0) * SS_SLOTS + slot], (unsigned long long)(part * 0x1p30f));
         else
-          atomicAdd(&ss_out[((t * 2 + 1) * SS_SLOTS + slot) * SS_PAD], (unsigned long long)(fminf(part, 7.0e13f) * 256.f));
+          atomicAdd(&ss_out[(t * 2 + 1) * SS_SLOTS + slot], (unsigned long long)(fminf(part, 7.0e13f) * 256.f));
       }
     }
   }
@@ -539,20 +536,20 @@ extern "C" int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, floa
   return gemv_entry("grit_rmsnorm_gemv_bf16", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream);
 }
 
-// The sum-of-squares hand-over between the GEMVs of a decode step (round 5): `sumsq` = uint64 [B, 2, 32, 16] of device memory (32 slots, one 128-byte line each), ZEROED by the
+// The sum-of-squares hand-over between the GEMVs of a decode step (round 5): `sumsq` = uint64 [B, 2, 16] of device memory, ZEROED by the
 // caller before the producing launch.  grit_gemv_bf16_sumsq = grit_gemv_bf16 with GRIT_EPI_RESIDUAL that also adds the squares of the
 // bf16 values it stores (the new residual stream) into it; grit_rmsnorm_gemv_bf16_presummed = grit_rmsnorm_gemv_bf16 that takes the
 // row's sum of squares from it instead of re-deriving it in every workgroup.  Integer accumulation: order-independent, exact.
 extern "C" int grit_gemv_bf16_sumsq(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
                                     const void* residual, int64_t ldr, void* sumsq, void* stream) {
-  GRIT_REQUIRE(sumsq && ((uintptr_t)sumsq & 127u) == 0, GRIT_E_BADARG, "grit_gemv_bf16_sumsq: sumsq must be a non-null, 8-byte aligned pointer");
+  GRIT_REQUIRE(sumsq && ((uintptr_t)sumsq & 7u) == 0, GRIT_E_BADARG, "grit_gemv_bf16_sumsq: sumsq must be a non-null, 8-byte aligned pointer");
   GRIT_REQUIRE(B <= 2, GRIT_E_UNSUPPORTED, "grit_gemv_bf16_sumsq: B=%d rows (the fused decode step runs 1 or 2)", B);
   return gemv_entry("grit_gemv_bf16_sumsq", x, W, out, nullptr, 0.f, B, N, K, ldx, ldw, ldo, GRIT_EPI_RESIDUAL, residual, ldr, stream, nullptr,
                     (unsigned long long*)sumsq);
 }
 extern "C" int grit_rmsnorm_gemv_bf16_presummed(const void* x, const void* sumsq, const void* ln_weight, float eps, const void* W, void* out, int B,
                                                 int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
-  GRIT_REQUIRE(ln_weight && sumsq && ((uintptr_t)sumsq & 127u) == 0, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16_presummed: null or misaligned pointer");
+  GRIT_REQUIRE(ln_weight && sumsq && ((uintptr_t)sumsq & 7u) == 0, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16_presummed: null or misaligned pointer");
   GRIT_REQUIRE(B <= 2, GRIT_E_UNSUPPORTED, "grit_rmsnorm_gemv_bf16_presummed: B=%d rows (the fused decode step runs 1 or 2)", B);
   GRIT_REQUIRE(epilogue == GRIT_EPI_STORE || epilogue == GRIT_EPI_SWIGLU, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16_presummed: epilogue %d (STORE, SWIGLU)", epilogue);
   return gemv_entry("grit_rmsnorm_gemv_bf16_presummed", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream,

@@ -117,7 +117,7 @@ class MistralDecoder:
         return dict(h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk((nq + 2 * nkv) * d), ctx=mk(nq * d), act=mk(c.intermediate_size),
                     logits=mk(self.lm_head.shape[0]), next=torch.zeros((B,), dtype=I64, device=dev), lens=torch.zeros((B,), dtype=I32, device=dev),
                     step=torch.zeros((1,), dtype=I32, device=dev), cos=cos, sin=sin, ws=ops.attn_decode_workspace(B, nq, nkv, Lmax, dev),
-                    ss=torch.zeros((2 * c.num_hidden_layers + 1, B, 2, 32, 16), dtype=I64, device=dev),      # sum-of-squares hand-over slots
+                    ss=torch.zeros((2 * c.num_hidden_layers + 1, B, 2, 16), dtype=I64, device=dev),      # sum-of-squares hand-over slots
                     cache=[(torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev), torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev))
                            for _ in range(c.num_hidden_layers)])
 

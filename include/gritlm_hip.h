@@ -375,7 +375,7 @@ int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, float eps, cons
                            int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
 /* RoPE (:138-163) of the new token's q and k at position lens[b] + append of its k, v to the cache, one launch: q is rotated in place in
  * qkv [B, qkv_stride]; cos/sin tables [Lmax, d/2] fp32 as grit_rope_qk_inplace. */
-/* The sum-of-squares hand-over between the GEMVs of a decode step: `sumsq` = uint64 [B, 2, 32, 16] of device memory (32 slots of one 128-byte line each; 128-byte aligned), ZEROED by the caller
+/* The sum-of-squares hand-over between the GEMVs of a decode step: `sumsq` = uint64 [B, 2, 16] of device memory, ZEROED by the caller
  * before the producing launch (B <= 2).  grit_gemv_bf16_sumsq = grit_gemv_bf16 with GRIT_EPI_RESIDUAL (hidden_states = residual +
  * o_proj / down_proj output, modeling_mistral_gritlm.py:769,:775) that also adds the squares of the bf16 values it stores into `sumsq`;
  * grit_rmsnorm_gemv_bf16_presummed = grit_rmsnorm_gemv_bf16 (MistralRMSNorm :84-89 + the next nn.Linear) that takes the row's sum of

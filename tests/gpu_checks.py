@@ -2489,11 +2489,11 @@ def check_gemv_sumsq_handover(B=1, N=4096, K=4096, seed=401):
     res = torch.randn((B, N), generator=g, device=DEV).to(torch.bfloat16)
     res[:, 5] = 3.0e4; res[:, N - 7] = -2.5e3                                 # massive activations: a partial above 2^23
     ref = ops.gemv(x, w, epilogue=EPI_RESIDUAL, residual=res)
-    ss = torch.zeros((B, 2, 32, 16), dtype=torch.int64, device=DEV)
+    ss = torch.zeros((B, 2, 16), dtype=torch.int64, device=DEV)
     out = torch.empty_like(ref)
     ops.gemv_residual_sumsq(x, w, out, res, ss)
     same = bool(torch.equal(out, ref))
-    dec = lambda t: t[:, 0, :, 0].double().sum(-1) * 2.0 ** -30 + t[:, 1, :, 0].double().sum(-1) * 2.0 ** -8
+    dec = lambda t: t[:, 0].double().sum(-1) * 2.0 ** -30 + t[:, 1].double().sum(-1) * 2.0 ** -8
     want = out.double().pow(2).sum(-1)
     e1 = float(((dec(ss) - want).abs() / want).max())
     ops.gemv_residual_sumsq(x, w, out, res, ss)                              # accumulates: twice the sum
@@ -2504,7 +2504,7 @@ def check_gemv_sumsq_handover(B=1, N=4096, K=4096, seed=401):
     x0 = torch.randn((B, 512), generator=g, device=DEV).to(torch.bfloat16)
     wp = (torch.randn((K, 512), generator=g, device=DEV) * 0.05).to(torch.bfloat16)
     z = torch.zeros((B, K), dtype=torch.bfloat16, device=DEV)
-    ss2 = torch.zeros((B, 2, 32, 16), dtype=torch.int64, device=DEV)
+    ss2 = torch.zeros((B, 2, 16), dtype=torch.int64, device=DEV)
     hrow = torch.empty((B, K), dtype=torch.bfloat16, device=DEV)
     ops.gemv_residual_sumsq(x0, wp, hrow, h, ss2)                            # hrow = h + x0 wp^T: a produced residual row with its statistic
     ln = (1 + 0.1 * torch.randn((K,), generator=g, device=DEV)).to(torch.bfloat16)
