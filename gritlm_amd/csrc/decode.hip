@@ -23,27 +23,12 @@ __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
 constexpr int GV_ROWS = GRIT_GV_ROWS;  // weight rows per workgroup; its 4 waves each take a quarter of K (split-K, LDS reduce)
 
 // MODE 0: store, 1: + residual, 2: SwiGLU pairs (rows r, r+16 of the interleaved layout).
-// NORM 1 ("pre-norm"): x is the raw residual stream and the kernel applies MistralRMSNorm on the fly (x_n = bf16(w_ln * bf16(x * rsqrt(mean
-// x^2 + eps))), modeling_mistral_gritlm.py:84-89) -- saves the separate RMSNorm launch of a decode step; every workgroup derives the row's
-// sum of squares itself.  NORM 2 ("pre-summed", round 5): the same, with the sum of squares HANDED OVER by the kernel that produced x --
-// the residual GEMV (MODE 1 with `ss_out`) adds its four outputs' squares into SS_SLOTS integer accumulators per row, the consumer reads
-// 2 x 16 words instead of the whole row: the 7168 workgroups of the gate|up GEMV no longer repeat a reduction over 8 KB each.
-// The accumulators are EXACT integers, so the sum does not depend on the order the workgroups arrive in (decode stays reproducible):
-// a partial below 2^23 is added as round(partial * 2^30) to the LOW word, a larger one as partial * 2^8 (an integer: its ulp is >= 1) to
-// the HIGH word; sum of squares = low * 2^-30 + high * 2^-8.
-constexpr int SS_SLOTS = 16;
-__device__ __forceinline__ float ss_total(const unsigned long long* __restrict__ ss, int b) {
-  unsigned long long lo = 0, hi = 0;
-#pragma unroll
-  for (int j = 0; j < SS_SLOTS; ++j) { lo += ss[(b * 2 + 0) * SS_SLOTS + j]; hi += ss[(b * 2 + 1) * SS_SLOTS + j]; }
-  return (float)((double)lo * 0x1p-30 + (double)hi * 0x1p-8);
-}
-template <int NB, int MODE, int NORM>
+// PRENORM: x is the raw residual stream and the kernel applies MistralRMSNorm on the fly (x_n = bf16(w_ln * bf16(x * rsqrt(mean x^2 + eps))),
+// modeling_mistral_gritlm.py:84-89) -- saves the separate RMSNorm launch of a decode step (a 1-row kernel is pure launch latency).
+template <int NB, int MODE, bool PRENORM>
 __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
                                                    const uint16_t* __restrict__ res, const uint16_t* __restrict__ ln_w, float eps, int B, int N,
-                                                   int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr,
-                                                   const unsigned long long* __restrict__ ss_in, unsigned long long* __restrict__ ss_out) {
-  constexpr bool PRENORM = NORM != 0;
+                                                   int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr) {
   __shared__ float red[4][GV_ROWS][NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int unit = blockIdx.x;                                // one unit = GV_ROWS weight rows
@@ -79,11 +64,7 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     for (int i = 0; i < GV_ROWS; ++i) wv[i] = wload(i, c0);
   }
   float inv[NB];
-  if (NORM == 2) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) inv[b] = rsqrtf(ss_total(ss_in, b < B ? b : 0) / (float)K + eps);
-  }
-  if (NORM == 1) {
+  if (PRENORM) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float ss = 0.f;
@@ -143,32 +124,12 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
         out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_f(round_bf(g))) * round_bf(u));
       }
     }
-  } else {
-    float sq = 0.f;                                            // square of the bf16 value this thread stores (0 outside the matrix)
-    if (t < GV_ROWS * NB) {
-      const int i = t / NB, b = t - i * NB, n = unit * GV_ROWS + i;
-      if (n < N && b < B) {
-        float v = red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b];
-        if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
-        const uint32_t hb = f2bf(v);
-        out[(int64_t)b * ldo + n] = (uint16_t)hb;
-        sq = bf2f((uint16_t)hb) * bf2f((uint16_t)hb);
-      }
-    }
-    if (MODE == 1 && ss_out != nullptr) {                      // hand the row's sum of squares to the next pre-summed GEMV
-      __shared__ float sqs[GV_ROWS * NB];
-      if (t < GV_ROWS * NB) sqs[t] = sq;
-      __syncthreads();
-      if (t < NB && t < B) {
-        float part = 0.f;
-#pragma unroll
-        for (int i = 0; i < GV_ROWS; ++i) part += sqs[i * NB + t];          // fixed order
-        const int slot = (int)(blockIdx.x & (SS_SLOTS - 1));
-        if (part < 8388608.f)
-          atomicAdd(&ss_out[(t * 2 + 0) * SS_SLOTS + slot], (unsigned long long)(part * 0x1p30f));
-        else
-          atomicAdd(&ss_out[(t * 2 + 1) * SS_SLOTS + slot], (unsigned long long)(fminf(part, 7.0e13f) * 256.f));
-      }
+  } else if (t < GV_ROWS * NB) {
+    const int i = t / NB, b = t - i * NB, n = unit * GV_ROWS + i;
+    if (n < N && b < B) {
+      float v = red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b];
+      if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
+      out[(int64_t)b * ldo + n] = (uint16_t)f2bf(v);
     }
   }
 }
@@ -482,15 +443,14 @@ __global__ void bump_k(int32_t* v) { v[0] += 1; }
 
 using namespace grit;
 
-template <int MODE, int PRENORM>
+template <int MODE, bool PRENORM>
 static int launch_gemv(const void* x, const void* W, void* out, const void* res, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
-                       int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st, const unsigned long long* ss_in = nullptr,
-                       unsigned long long* ss_out = nullptr) {
+                       int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st) {
   const int units = MODE == 2 ? (N / 2 + GV_ROWS / 2 - 1) / (GV_ROWS / 2) : (N + GV_ROWS - 1) / GV_ROWS;
   const dim3 grid((unsigned)units);
 #define GRIT_GEMV(NB_)                                                                                                                    \
   hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out,   \
-                     (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr, ss_in, ss_out)
+                     (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr)
   if (B == 1) GRIT_GEMV(1); else if (B == 2) GRIT_GEMV(2); else if (B <= 4) GRIT_GEMV(4); else GRIT_GEMV(8);
 #undef GRIT_GEMV
   GRIT_CHECK_LAUNCH("grit_gemv_bf16");
@@ -498,8 +458,7 @@ static int launch_gemv(const void* x, const void* W, void* out, const void* res,
 }
 
 static int gemv_entry(const char* name, const void* x, const void* W, void* out, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
-                      int64_t ldw, int64_t ldo, int epilogue, const void* residual, int64_t ldr, void* stream,
-                      const unsigned long long* ss_in = nullptr, unsigned long long* ss_out = nullptr) {
+                      int64_t ldw, int64_t ldo, int epilogue, const void* residual, int64_t ldr, void* stream) {
   if (B == 0) return GRIT_OK;
   GRIT_REQUIRE(x && W && out, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(B > 0 && B <= 8, GRIT_E_UNSUPPORTED, "%s: B=%d rows (1..8; larger batches use grit_gemm_bf16_nt)", name, B);
@@ -507,19 +466,15 @@ static int gemv_entry(const char* name, const void* x, const void* W, void* out,
   GRIT_REQUIRE(aligned16(x) && aligned16(W) && (!ln_w || aligned16(ln_w)), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
   hipStream_t st = (hipStream_t)stream;
   const bool pn = ln_w != nullptr;
-  GRIT_REQUIRE(!ss_in || pn, GRIT_E_BADARG, "%s: a handed-over sum of squares needs the norm weight", name);
-  GRIT_REQUIRE(!ss_out || epilogue == GRIT_EPI_RESIDUAL, GRIT_E_BADARG, "%s: the sum of squares is emitted by the RESIDUAL epilogue only", name);
   switch (epilogue) {
     case GRIT_EPI_STORE: GRIT_REQUIRE(ldo >= N, GRIT_E_BADARG, "%s: ldo < N", name);
-      return ss_in ? launch_gemv<0, 2>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st, ss_in)
-             : pn  ? launch_gemv<0, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
-                   : launch_gemv<0, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+      return pn ? launch_gemv<0, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                : launch_gemv<0, false>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
     case GRIT_EPI_RESIDUAL: GRIT_REQUIRE(residual && ldo >= N && ldr >= N && !pn, GRIT_E_BADARG, "%s: RESIDUAL needs residual, ldo, ldr >= N (no pre-norm)", name);
-      return launch_gemv<1, 0>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st, nullptr, ss_out);
+      return launch_gemv<1, false>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
     case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "%s: SWIGLU needs N %% 32 == 0, ldo >= N/2", name);
-      return ss_in ? launch_gemv<2, 2>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st, ss_in)
-             : pn  ? launch_gemv<2, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
-                   : launch_gemv<2, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+      return pn ? launch_gemv<2, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                : launch_gemv<2, false>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
     default: GRIT_REQUIRE(false, GRIT_E_BADARG, "%s: unknown epilogue %d", name, epilogue);
   }
   return GRIT_OK;
@@ -534,26 +489,6 @@ extern "C" int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, floa
                                       int64_t ldw, int64_t ldo, int epilogue, void* stream) {
   GRIT_REQUIRE(ln_weight, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16: null pointer");
   return gemv_entry("grit_rmsnorm_gemv_bf16", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream);
-}
-
-// The sum-of-squares hand-over between the GEMVs of a decode step (round 5): `sumsq` = uint64 [B, 2, 16] of device memory, ZEROED by the
-// caller before the producing launch.  grit_gemv_bf16_sumsq = grit_gemv_bf16 with GRIT_EPI_RESIDUAL that also adds the squares of the
-// bf16 values it stores (the new residual stream) into it; grit_rmsnorm_gemv_bf16_presummed = grit_rmsnorm_gemv_bf16 that takes the
-// row's sum of squares from it instead of re-deriving it in every workgroup.  Integer accumulation: order-independent, exact.
-extern "C" int grit_gemv_bf16_sumsq(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
-                                    const void* residual, int64_t ldr, void* sumsq, void* stream) {
-  GRIT_REQUIRE(sumsq && ((uintptr_t)sumsq & 7u) == 0, GRIT_E_BADARG, "grit_gemv_bf16_sumsq: sumsq must be a non-null, 8-byte aligned pointer");
-  GRIT_REQUIRE(B <= 2, GRIT_E_UNSUPPORTED, "grit_gemv_bf16_sumsq: B=%d rows (the fused decode step runs 1 or 2)", B);
-  return gemv_entry("grit_gemv_bf16_sumsq", x, W, out, nullptr, 0.f, B, N, K, ldx, ldw, ldo, GRIT_EPI_RESIDUAL, residual, ldr, stream, nullptr,
-                    (unsigned long long*)sumsq);
-}
-extern "C" int grit_rmsnorm_gemv_bf16_presummed(const void* x, const void* sumsq, const void* ln_weight, float eps, const void* W, void* out, int B,
-                                                int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
-  GRIT_REQUIRE(ln_weight && sumsq && ((uintptr_t)sumsq & 7u) == 0, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16_presummed: null or misaligned pointer");
-  GRIT_REQUIRE(B <= 2, GRIT_E_UNSUPPORTED, "grit_rmsnorm_gemv_bf16_presummed: B=%d rows (the fused decode step runs 1 or 2)", B);
-  GRIT_REQUIRE(epilogue == GRIT_EPI_STORE || epilogue == GRIT_EPI_SWIGLU, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16_presummed: epilogue %d (STORE, SWIGLU)", epilogue);
-  return gemv_entry("grit_rmsnorm_gemv_bf16_presummed", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream,
-                    (const unsigned long long*)sumsq, nullptr);
 }
 
 extern "C" int grit_rope_kv_append(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens, int B,

@@ -35,11 +35,10 @@ class MistralDecoder:
         # -> gate|up, final norm -> lm_head), "qkv" (the MLP's and the final norm get their own launches) or "none"; GRIT_DECODE_FUSE_NORM for A/B runs
         # (tools/decode_variants.sh).  Same bits in every form: the fused kernel applies the reference's two roundings.
         import os
-        # "presum" (default, round 5): every norm rides inside its GEMV AND takes the row's sum of squares from the residual GEMV that
-        # produced the row (grit_gemv_bf16_sumsq -> grit_rmsnorm_gemv_bf16_presummed): no norm launch, no per-workgroup reduction.
-        # History on one box (tools/decode_variants.sh): all 3.49, qkv 3.25, none 3.32 ms per token -- with "all" the 7168 workgroups of
-        # the gate|up GEMV and the 8000 of lm_head each re-derived the row's RMS, which cost more than the one-row launch it saved.
-        self.fuse_norm = os.environ.get("GRIT_DECODE_FUSE_NORM", "presum")
+        # Default "qkv" (round 5, tools/decode_variants.sh on one box: all 3.49, qkv 3.25, none 3.32 ms per token): the 7168 workgroups of
+        # the gate|up GEMV -- and the 8000 of lm_head -- each re-derive the row's RMS when the norm is fused, which costs more than the
+        # one-row launch it saves; the q|k|v GEMV is a single workgroup wave deep and keeps the fusion.
+        self.fuse_norm = os.environ.get("GRIT_DECODE_FUSE_NORM", "qkv")
 
     # ------------------------------------------------------------------ one decode step (all sizes static, lengths on the device)
     def _step(self, st):
@@ -49,8 +48,6 @@ class MistralDecoder:
         ops.embed_gather(e.embed, st["next"], out=h)
         if h.shape[0] > 2 or self.fuse_norm == "none":
             return self._step_unfused_norm(st)
-        if self.fuse_norm == "presum":
-            return self._step_presum(st)
         for li, L in enumerate(e.layers):
             ck, cv = st["cache"][li]
             ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv)                      # input_layernorm + q/k/v projections
@@ -67,26 +64,6 @@ class MistralDecoder:
         else:
             ops.rmsnorm(h, e.norm, eps, out=st["x"])
             ops.gemv(st["x"], self.lm_head, out=st["logits"])
-
-    def _step_presum(self, st):
-        """B <= 2: 5 launches per layer, no norm launch and no norm reduction outside the GEMV that writes the row: o_proj / down_proj add
-        the squares of the residual row they store into st["ss"][slot], the following norm + GEMV reads them."""
-        c, e = self.cfg, self.eng
-        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
-        h, qkv, ctx, act, ss = st["h"], st["qkv"], st["ctx"], st["act"], st["ss"]
-        ss.zero_()                                                                  # one fill per step (a memset node of the HIP graph)
-        n = len(e.layers)
-        for li, L in enumerate(e.layers):
-            ck, cv = st["cache"][li]
-            if li == 0:
-                ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv)                  # the embedding row: nobody produced its sum of squares
-            else:
-                ops.rmsnorm_gemv_presummed(h, ss[2 * li], L.ln1, eps, L.wqkv, out=qkv)
-            ops.attn_decode_rope(qkv, st["cos"], st["sin"], ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)
-            ops.gemv_residual_sumsq(ctx, L.wo, h, h, ss[2 * li + 1])
-            ops.rmsnorm_gemv_presummed(h, ss[2 * li + 1], L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU)
-            ops.gemv_residual_sumsq(act, L.wdown, h, h, ss[2 * li + 2])
-        ops.rmsnorm_gemv_presummed(h, ss[2 * n], e.norm, eps, self.lm_head, out=st["logits"])
 
     def _step_unfused_norm(self, st):
         """More than 2 rows: every workgroup of the fused kernel would re-derive each row's RMS, so the norm gets its own launch."""
@@ -117,7 +94,6 @@ class MistralDecoder:
         return dict(h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk((nq + 2 * nkv) * d), ctx=mk(nq * d), act=mk(c.intermediate_size),
                     logits=mk(self.lm_head.shape[0]), next=torch.zeros((B,), dtype=I64, device=dev), lens=torch.zeros((B,), dtype=I32, device=dev),
                     step=torch.zeros((1,), dtype=I32, device=dev), cos=cos, sin=sin, ws=ops.attn_decode_workspace(B, nq, nkv, Lmax, dev),
-                    ss=torch.zeros((2 * c.num_hidden_layers + 1, B, 2, 16), dtype=I64, device=dev),      # sum-of-squares hand-over slots
                     cache=[(torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev), torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev))
                            for _ in range(c.num_hidden_layers)])
 

@@ -595,33 +595,6 @@ def rmsnorm_gemv(x: torch.Tensor, ln_w: torch.Tensor, eps: float, w: torch.Tenso
     return out
 
 
-def gemv_residual_sumsq(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, residual: torch.Tensor, sumsq: torch.Tensor) -> torch.Tensor:
-    """gemv(..., epilogue=RESIDUAL) that also adds the squares of the stored row into ``sumsq`` (int64 [B, 2, 16], zeroed by the caller):
-    the hand-over that lets the next RMSNorm + GEMV skip its own reduction (decode step, B <= 2)."""
-    B, K = x.shape
-    N = w.shape[0]
-    assert sumsq.shape == (B, 2, 16)
-    check(_lib.load().grit_gemv_bf16_sumsq(_chk2d(x, BF16, "x"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), B, N, K, x.stride(0), w.stride(0),
-                                           out.stride(0), _chk2d(residual, BF16, "residual"), residual.stride(0), _chk(sumsq, I64, "sumsq"),
-                                           _stream()), "grit_gemv_bf16_sumsq")
-    return out
-
-
-def rmsnorm_gemv_presummed(x: torch.Tensor, sumsq: torch.Tensor, ln_w: torch.Tensor, eps: float, w: torch.Tensor, out: torch.Tensor | None = None,
-                           epilogue: int = EPI_STORE) -> torch.Tensor:
-    """rmsnorm_gemv with the row's sum of squares taken from ``sumsq`` (filled by gemv_residual_sumsq)."""
-    B, K = x.shape
-    N = w.shape[0]
-    n_out = N // 2 if epilogue == EPI_SWIGLU else N
-    assert sumsq.shape == (B, 2, 16)
-    if out is None:
-        out = torch.empty((B, n_out), dtype=BF16, device=x.device)
-    check(_lib.load().grit_rmsnorm_gemv_bf16_presummed(_chk2d(x, BF16, "x"), _chk(sumsq, I64, "sumsq"), _chk(ln_w, BF16, "ln_w"), float(eps),
-                                                       _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), B, N, K, x.stride(0), w.stride(0),
-                                                       out.stride(0), epilogue, _stream()), "grit_rmsnorm_gemv_bf16_presummed")
-    return out
-
-
 def rope_kv_append(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor,
                    nq: int, nkv: int, d: int):
     B, _, Lmax, _ = cache_k.shape

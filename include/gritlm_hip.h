@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 4
+#define GRIT_ABI_VERSION 3
 
 enum {
   GRIT_OK = 0,
@@ -375,16 +375,6 @@ int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, float eps, cons
                            int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
 /* RoPE (:138-163) of the new token's q and k at position lens[b] + append of its k, v to the cache, one launch: q is rotated in place in
  * qkv [B, qkv_stride]; cos/sin tables [Lmax, d/2] fp32 as grit_rope_qk_inplace. */
-/* The sum-of-squares hand-over between the GEMVs of a decode step: `sumsq` = uint64 [B, 2, 16] of device memory, ZEROED by the caller
- * before the producing launch (B <= 2).  grit_gemv_bf16_sumsq = grit_gemv_bf16 with GRIT_EPI_RESIDUAL (hidden_states = residual +
- * o_proj / down_proj output, modeling_mistral_gritlm.py:769,:775) that also adds the squares of the bf16 values it stores into `sumsq`;
- * grit_rmsnorm_gemv_bf16_presummed = grit_rmsnorm_gemv_bf16 (MistralRMSNorm :84-89 + the next nn.Linear) that takes the row's sum of
- * squares from `sumsq` instead of re-deriving it in every workgroup.  The accumulators are exact integers (partial * 2^30 in the low word,
- * partials >= 2^23 as partial * 2^8 in the high word): the sum does not depend on the arrival order of the workgroups. */
-int grit_gemv_bf16_sumsq(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
-                         const void* residual, int64_t ldr, void* sumsq, void* stream);
-int grit_rmsnorm_gemv_bf16_presummed(const void* x, const void* sumsq, const void* ln_weight, float eps, const void* W, void* out, int B, int N,
-                                     int K, int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
 int grit_rope_kv_append(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens, int B,
                         int nq, int nkv, int d, int Lmax, int64_t qkv_stride, void* stream);
 /* Append the (already rotated) k, v of one new token per sequence: qkv [B, qkv_stride] -> cache_{k,v}[b, h, lens[b], :],
