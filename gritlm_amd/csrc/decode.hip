@@ -371,6 +371,11 @@ __global__ void __launch_bounds__(128) attn_decode_combine_k(const float* __rest
   const int64_t sstride = (int64_t)G * (AD_D + 2);
   const float* base = part + ((int64_t)b * nkv + hk) * max_splits * sstride + g * (AD_D + 2);
   float ms[8], ls[8];                        // max_splits <= 512 = 8 per lane
+  // the partial outputs of the first 64 splits (L <= 4096: all of them) are requested NOW, beside the (m_s, l_s) pairs: they do not
+  // depend on the rescale factors, so the kernel pays one memory round trip instead of two
+  float pv[64];
+#pragma unroll
+  for (int sp = 0; sp < 64; ++sp) pv[sp] = sp < max_splits ? base[sp * sstride + 2 + e] : 0.f;
   float m[1] = {-INFINITY};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -393,8 +398,10 @@ __global__ void __launch_bounds__(128) attn_decode_combine_k(const float* __rest
   __syncthreads();
   // thread e owns output dim e; the loads of different splits are independent
   float acc = 0.f;
+#pragma unroll
+  for (int sp = 0; sp < 64; ++sp) acc += pv[sp] * (sp < max_splits ? fs[wave][sp] : 0.f);      // same order as the loop below
 #pragma unroll 8
-  for (int sp = 0; sp < max_splits; ++sp) acc += base[sp * sstride + 2 + e] * fs[wave][sp];
+  for (int sp = 64; sp < max_splits; ++sp) acc += base[sp * sstride + 2 + e] * fs[wave][sp];
   out[(int64_t)b * out_stride + (int64_t)h * AD_D + e] = (uint16_t)f2bf(l[0] > 0.f ? acc / l[0] : 0.f);
 }
 

@@ -67,7 +67,10 @@ __device__ __forceinline__ uint4 norm8(const uint4& x, const uint4& w, float rs)
   return o;
 }
 
-template <int NCH>
+// PW (a handful of rows: the decode step's one-row norms): the weight row is requested together with x, in front of the reduction --
+// a launch that small is one dependent chain, and the weights' L2 round trip otherwise FOLLOWS the reduction (4.6 us per launch at
+// T = 1).  With many rows other waves hide that latency and the 32 extra registers would only cost occupancy, so PW is off there.
+template <int NCH, bool PW = false>
 __global__ void __launch_bounds__(256) rmsnorm_fwd_reg_k(const uint4* __restrict__ x, const uint4* __restrict__ w,
                                                          uint4* __restrict__ y, int64_t T, int H, float eps) {
   const int lane = threadIdx.x & 63;
@@ -75,9 +78,13 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_reg_k(const uint4* __restrict
   if (row >= T) return;
   const int HC = H >> 3;
   const uint4* xr = x + row * HC;
-  uint4 v[NCH];
+  uint4 v[NCH], wv[PW ? NCH : 1];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) v[c] = xr[c * 64 + lane];
+  if constexpr (PW) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) wv[c] = w[c * 64 + lane];
+  }
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) ss += sumsq8(v[c]);
@@ -85,7 +92,7 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_reg_k(const uint4* __restrict
   const float rs = rsqrtf(ss / (float)H + eps);
   uint4* yr = y + row * HC;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) yr[c * 64 + lane] = norm8(v[c], w[c * 64 + lane], rs);
+  for (int c = 0; c < NCH; ++c) yr[c * 64 + lane] = norm8(v[c], PW ? wv[c] : w[c * 64 + lane], rs);
 }
 
 __global__ void __launch_bounds__(256) rmsnorm_fwd_generic_k(const uint4* __restrict__ x, const uint4* __restrict__ w,
@@ -324,7 +331,10 @@ int grit_rmsnorm_fwd(const void* x, const void* w, void* y, int64_t T, int H, fl
       case 1: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<1>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
       case 2: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<2>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
       case 4: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<4>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
-      case 8: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<8>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
+      case 8:
+        if (T <= 16) hipLaunchKernelGGL((rmsnorm_fwd_reg_k<8, true>), grid, block, 0, st, xp, wp, yp, T, H, eps);
+        else hipLaunchKernelGGL(rmsnorm_fwd_reg_k<8>, grid, block, 0, st, xp, wp, yp, T, H, eps);
+        break;
       case 16: hipLaunchKernelGGL(rmsnorm_fwd_reg_k<16>, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
       default: hipLaunchKernelGGL(rmsnorm_fwd_generic_k, grid, block, 0, st, xp, wp, yp, T, H, eps); break;
     }
