@@ -1,12 +1,13 @@
 #!/bin/bash
-# rocprofv3 --pmc passes (own runs, --kernel-trace only) on tools/attn_pmc_probe.py: the default attention forward and the opt-in W64 kernel
-# -> gpurun_out/attn_pmc_r04/summary.json (copy to profiles/r04_attn_fwd_pmc.json)
+# rocprofv3 --pmc passes (own runs, --kernel-trace only) on tools/attn_pmc_probe.py: the bf16 and the fp16 instantiation of the attention
+# forward at B 256 x S 512 and B 32 x S 2048 -> gpurun_out/attn_pmc_<tag>/summary.json (copy to profiles/<tag>_attn_fwd_pmc.json)
+TAG=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/attn_pmc_r04; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/attn_pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 for pass in "a:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU" "b:GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
   name=${pass%%:*}; ctrs=${pass#*:}
-  RAW=/tmp/attn_pmc_raw_r04/$name; rm -rf $RAW; mkdir -p $RAW
+  RAW=/tmp/attn_pmc_raw_$TAG/$name; rm -rf $RAW; mkdir -p $RAW
   timeout 280 rocprofv3 --kernel-trace --pmc $ctrs -d $RAW -o a --output-format csv -- python tools/attn_pmc_probe.py > $OUT/$name.log 2>&1
   cp $(find $RAW -name "*counter_collection.csv" | head -1) $OUT/$name.csv 2>/dev/null
 done
@@ -17,10 +18,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(f"{out}/?.csv")):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "attn_bidir_fwd_k" in n: k = "default (attn_bidir_fwd_k)"
-        elif "attn_fwd_w64_k" in n: k = "w64 (attn_fwd_w64_k)"
+        if "attn_bidir_fwd_k<false, false, true>" in n: k = "fp16 operands (attn_bidir_fwd_k<false,false,true>)"
+        elif "attn_bidir_fwd_k<false, false, false>" in n: k = "bf16 (attn_bidir_fwd_k<false,false,false>)"
         else: continue
-        key = f"{k} grid {r['Grid_Size']}"
+        key = f"{k} {'B256xS512' if int(r['Grid_Size']) == 2097152 else 'B32xS2048'}"
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r["Counter_Name"] in ("SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
             agg[key]["_dur_ns_" + r["Counter_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

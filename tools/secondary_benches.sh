@@ -1,7 +1,7 @@
 #!/bin/bash
 # The stand-alone benches behind README's second table, one after the other on the GPU box: bash tools/secondary_benches.sh <tag>
 # -> gpurun_out/<tag>_*.json|log  (copy what is to be judged into profiles/).
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 run() { name=$1; shift; timeout 300 "$@" > gpurun_out/${TAG}_$name 2> gpurun_out/${TAG}_$name.err; echo "$name rc=$? $(tail -c 300 gpurun_out/${TAG}_$name | tr '\n' ' ')"; }
