@@ -56,6 +56,11 @@ def scenarios():
         "f16_operands_fp32_residual": policy("f16", lin="-", h="-"),
         "f16_operands_fp32_residual_flush_subnormal_weights": policy("f16", lin="-", h="-", flush_w=True),
         "f16_operands_bf16_out_fp32_residual": policy("f16", lin="-", h="-", out="bf16"),
+        # what a MIXED policy would cost: o_proj and down back on bf16 MFMA operands (ctx, act in bf16: 37 % of the GEMM FLOPs at the bf16
+        # clock), x / q|k|v / P in fp16 -- priced here, not built
+        "mixed_f16_x_qkv_p__bf16_ctx_act_out_fp32_residual": policy("f16", lin="-", h="-", out="bf16", ctx="bf16", act="bf16"),
+        # an fp16 residual stream instead of the fp32 one (16-bit epilogue / norm traffic), everything else as f16_operands
+        "f16_operands_f16_residual": policy("f16", lin="-", out="bf16"),
     }
     for fmt in ("bf16", "f16"):
         for c in ("x", "qkv", "p", "ctx", "act", "out"):
