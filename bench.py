@@ -447,7 +447,7 @@ def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32
                 extra["kernels"] = {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3), "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12,
                                         **({"by_shape_tflops": {t: round(x["work"] / (x["total_ms"] * 1e-3) / 1e12, 1) for t, x in v["by_tag"].items()}}
                                            if "by_tag" in v else {})} for k, v in tm.summary().items()}
-            if policy == "f16_operands":
+            if policy in ("f16_operands", "f16_stream"):
                 st = eng.f16_weight_stats or {}
                 extra.update({"fp16_overflow_flag": bool(ops.f16_overflow_flag(eng.device)),
                               "weights_subnormal_in_fp16_frac": st.get("subnormal", 0) / max(st.get("total", 1), 1)})
@@ -467,8 +467,13 @@ def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32
     out["stock_module_bf16_this_gpu"] = {**omc(e_stock, ref), "what": "stock transformers module, bf16, sdpa, the reference's mask rule, same weights, "
                                          "through PyTorch-ROCm: what the reference's Python computes on this GPU (reported; bounds nothing)"}
     out["engine_default_vs_stock_module_bf16"] = omc(emb_default[:n], e_stock)
+    d, rate, extra = opt_in("f16_stream")
+    out["engine_f16_stream_opt_in"] = {**d, "bound": BENCH_BOUND_F16_OPERANDS,
+                                       "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_F16_OPERANDS and not extra.get("fp16_overflow_flag", True),
+                                       "docs_per_s": rate, **extra, "how": "GritLM(..., precision='f16_stream'): f16_operands with the residual stream "
+                                       "itself in fp16 (16-bit residual epilogues and norms; an activation of the stream beyond 65504 raises)"}
     out["within_bound"] = bool(out["engine_bf16_residual_default"]["within_bound"] and out["engine_fp32_residual_opt_in"]["within_bound"]
-                               and out["engine_f16_operands_opt_in"]["within_bound"])
+                               and out["engine_f16_operands_opt_in"]["within_bound"] and out["engine_f16_stream_opt_in"]["within_bound"])
     out["north_star_met"] = bool(out["engine_f16_operands_opt_in"]["max_one_minus_cos"] < 1e-4 and not out["engine_f16_operands_opt_in"].get("fp16_overflow_flag", True))
     return out
 
@@ -496,6 +501,9 @@ def full_depth_parity(dev):
     eng.set_precision("f16_operands")
     hip16 = cosd(ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy(), ref)
     ovf16 = bool(ops.f16_overflow_flag(eng.device))
+    eng.set_precision("f16_stream")
+    hip16s = cosd(ops.pool_norm(eng.forward(tid, tm, borrow=True), tm, "mean", True).float().cpu().numpy(), ref)
+    ovf16 = ovf16 or bool(ops.f16_overflow_flag(eng.device))
     del eng
     torch.cuda.empty_cache()
     return {"what": "1 doc x 512 tokens through all 32 layers at the 7B layer shape (the repeated-layer model of tests/golden/encoder_7b-depth32.npz), "
@@ -503,9 +511,10 @@ def full_depth_parity(dev):
             "one_minus_cos_vs_fp32_oracle": hip, "bound": FULL_DEPTH_BOUND_BF16_RESIDUAL,
             "fp32_residual_opt_in_one_minus_cos_vs_fp32_oracle": hip32, "fp32_residual_bound": FULL_DEPTH_BOUND_FP32_RESIDUAL,
             "f16_operands_opt_in_one_minus_cos_vs_fp32_oracle": hip16, "f16_operands_bound": FULL_DEPTH_BOUND_F16_OPERANDS,
-            "f16_operands_overflow_flag": ovf16, "north_star_met": bool(hip16 < 1e-4 and not ovf16),
+            "f16_stream_opt_in_one_minus_cos_vs_fp32_oracle": hip16s,
+            "f16_operands_overflow_flag": ovf16, "north_star_met": bool(hip16 < 1e-4 and hip16s < 1e-4 and not ovf16),
             "within_bound": bool(hip < FULL_DEPTH_BOUND_BF16_RESIDUAL and hip32 < FULL_DEPTH_BOUND_FP32_RESIDUAL
-                                 and hip16 < FULL_DEPTH_BOUND_F16_OPERANDS and not ovf16)}, {
+                                 and hip16 < FULL_DEPTH_BOUND_F16_OPERANDS and hip16s < FULL_DEPTH_BOUND_F16_OPERANDS and not ovf16)}, {
             "value": ids.shape[0] / dt, "unit": "docs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
             "sample": f"numpy oracle (oracle/gritlm_oracle.py, fp32 OpenBLAS), {ids.shape[0]} doc(s) x {ids.shape[1]} tok through all "
                       f"{cfg['num_hidden_layers']} layers, {dt:.2f} s", "seconds": dt}
@@ -824,9 +833,15 @@ def main():
             # the north-star's 1 - cos < 1e-4 on the timed batch AND on the reference-run fixture model
             line["parity_within_bound"] = line["parity_full_depth"]["within_bound"]
             line["north_star_met"] = line["parity_full_depth"]["north_star_met"]
-            f16 = (parity_sw or {}).get("engine_f16_operands_opt_in") or {}
-            line["north_star_policy"] = {"precision": "f16_operands", "max_one_minus_cos_timed_batch": f16.get("max_one_minus_cos"),
-                                         "docs_per_s": f16.get("docs_per_s"), "docs_per_s_over_default": (f16.get("docs_per_s") or 0.0) / docs_per_s}
+            # the policies that meet 1 - cos < 1e-4 on the timed batch, and the fastest of them
+            cands = {k: (parity_sw or {}).get(f"engine_{k}_opt_in") or {} for k in ("f16_operands", "f16_stream")}
+            ok_c = {k: v for k, v in cands.items() if v.get("within_bound") and (v.get("max_one_minus_cos") or 1.0) < 1e-4}
+            best = max(ok_c, key=lambda k: ok_c[k].get("docs_per_s") or 0.0) if ok_c else "f16_operands"
+            line["north_star_policy"] = {"precision": best, "max_one_minus_cos_timed_batch": cands[best].get("max_one_minus_cos"),
+                                         "docs_per_s": cands[best].get("docs_per_s"),
+                                         "docs_per_s_over_default": (cands[best].get("docs_per_s") or 0.0) / docs_per_s,
+                                         "all": {k: {"max_one_minus_cos": v.get("max_one_minus_cos"), "docs_per_s": v.get("docs_per_s"),
+                                                     "docs_per_s_over_default": (v.get("docs_per_s") or 0.0) / docs_per_s} for k, v in cands.items()}}
         if not multi and not dry:
             import gc as _gc
             _gc.collect()

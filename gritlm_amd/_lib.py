@@ -28,6 +28,7 @@ _SIGNATURES = {
     "grit_embed_gather_f32": (_i, [_p, _p, _p, _l, _i, _l, _p]),
     "grit_rmsnorm_fwd_f32in": (_i, [_p, _p, _p, _l, _i, _f, _p]),
     "grit_rmsnorm_fwd_f32in_f16": (_i, [_p, _p, _p, _l, _i, _f, _p]),
+    "grit_rmsnorm_fwd_f16in": (_i, [_p, _p, _p, _i, _l, _i, _f, _p]),
     "grit_gemm_f16_nt": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
     "grit_gemm_f16_nt_rope": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _p, _p, _p, _i, _i, _i, _p]),
     "grit_attn_bidir_f16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),

@@ -71,6 +71,21 @@ __device__ __forceinline__ uint32_t pack2_op(float lo, float hi) {
   if constexpr (F16) return pack2h_hw(lo, hi);
   else return pack2bf_hw(lo, hi);
 }
+// packed fp16 add (v_pk_add_f16): the correctly rounded fp16 sums of two pairs of fp16 values
+__device__ __forceinline__ uint32_t pk_add_f16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_pk_t, a) + __builtin_bit_cast(f16x2_pk_t, b));
+}
+// 16-bit unpack in the operand format (e.g. the residual reads of the GEMM's RESIDUAL epilogue: an fp16 residual stream under F16)
+template <bool F16>
+__device__ __forceinline__ float lo16_op(uint32_t w) {
+  if constexpr (F16) return hlo(w);
+  else return bflo(w);
+}
+template <bool F16>
+__device__ __forceinline__ float hi16_op(uint32_t w) {
+  if constexpr (F16) return hhi(w);
+  else return bfhi(w);
+}
 // host: device address of this device's f16 overflow flag word (elementwise.hip; nullptr if the symbol lookup fails)
 unsigned int* f16_flag_ptr();
 

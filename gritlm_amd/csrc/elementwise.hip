@@ -170,6 +170,66 @@ __global__ void __launch_bounds__(256) rmsnorm_fwd_f32in_generic_k(const float4*
   }
 }
 
+// RMSNorm of an fp16 residual stream (the "f16_stream" policy): x [T,H] fp16 -> y = round(w * (x * rsqrt(mean(x^2) + eps))) in fp32 with ONE
+// rounding, to fp16 (OUT_F16: the operand of the next GEMM) or to bf16 (last_hidden_state, the pooling kernels' input).  w is bf16.
+template <bool OUT_F16>
+__device__ __forceinline__ uint4 norm8_h16(const uint4& x, const uint4& w, float rs) {
+  uint4 o;
+  o.x = pack2_op<OUT_F16>(bflo(w.x) * (hlo(x.x) * rs), bfhi(w.x) * (hhi(x.x) * rs));
+  o.y = pack2_op<OUT_F16>(bflo(w.y) * (hlo(x.y) * rs), bfhi(w.y) * (hhi(x.y) * rs));
+  o.z = pack2_op<OUT_F16>(bflo(w.z) * (hlo(x.z) * rs), bfhi(w.z) * (hhi(x.z) * rs));
+  o.w = pack2_op<OUT_F16>(bflo(w.w) * (hlo(x.w) * rs), bfhi(w.w) * (hhi(x.w) * rs));
+  return o;
+}
+__device__ __forceinline__ float sumsq8_h16(const uint4& v) {
+  float s = 0.f, a;
+  a = hlo(v.x); s += a * a; a = hhi(v.x); s += a * a;
+  a = hlo(v.y); s += a * a; a = hhi(v.y); s += a * a;
+  a = hlo(v.z); s += a * a; a = hhi(v.z); s += a * a;
+  a = hlo(v.w); s += a * a; a = hhi(v.w); s += a * a;
+  return s;
+}
+template <int NCH, bool OUT_F16>      // NCH > 0: H = NCH * 512, row held in registers; NCH = 0: any H % 8 == 0
+__global__ void __launch_bounds__(256) rmsnorm_fwd_h16_k(const uint4* __restrict__ x, const uint4* __restrict__ w, uint4* __restrict__ y,
+                                                         int64_t T, int H, float eps, unsigned int* ovf) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const int HC = H >> 3;
+  const uint4* xr = x + row * HC;
+  uint4* yr = y + row * HC;
+  uint32_t bad = 0;
+  if constexpr (NCH > 0) {
+    uint4 v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) v[c] = xr[c * 64 + lane];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) ss += sumsq8_h16(v[c]);
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint4 o = norm8_h16<OUT_F16>(v[c], w[c * 64 + lane], rs);
+      if constexpr (OUT_F16) bad |= h2_nonfinite(o.x) | h2_nonfinite(o.y) | h2_nonfinite(o.z) | h2_nonfinite(o.w);
+      yr[c * 64 + lane] = o;
+    }
+  } else {
+    float ss = 0.f;
+    for (int c = lane; c < HC; c += 64) ss += sumsq8_h16(xr[c]);
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    for (int c = lane; c < HC; c += 64) {
+      const uint4 o = norm8_h16<OUT_F16>(xr[c], w[c], rs);
+      if constexpr (OUT_F16) bad |= h2_nonfinite(o.x) | h2_nonfinite(o.y) | h2_nonfinite(o.z) | h2_nonfinite(o.w);
+      yr[c] = o;
+    }
+  }
+  if constexpr (OUT_F16) {
+    if (bad != 0 && ovf != nullptr) atomicOr(ovf, 1u);
+  }
+}
+
 // ---------------------------------------------------------------- fp16 overflow flag of the "f16_operands" policy
 // One word per device (module-scope device variable: the library never allocates).  Every kernel that rounds to fp16 ORs 1 into it when
 // it stores an inf / nan; grit_f16_overflow_flag() reads (and optionally clears) it on the caller's stream.
@@ -404,6 +464,39 @@ int grit_rmsnorm_fwd_f32in_f16(const float* x, const void* w, void* y, int64_t T
     default: hipLaunchKernelGGL(rmsnorm_fwd_f32in_generic_k<true>, grid, block, 0, st, xp, wp, yp, T, H, eps, ovf); break;
   }
   GRIT_CHECK_LAUNCH("grit_rmsnorm_fwd_f32in_f16");
+  return GRIT_OK;
+}
+
+/* fp16 residual stream (the "f16_stream" policy): MistralRMSNorm (:84-89) of an fp16 row, ONE rounding; y fp16 (out_is_f16 != 0: the next
+ * GEMM's operand) or bf16 (last_hidden_state for the pooling kernels); w bf16 */
+int grit_rmsnorm_fwd_f16in(const void* x, const void* w, void* y, int out_is_f16, int64_t T, int H, float eps, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && w && y, GRIT_E_BADARG, "grit_rmsnorm_fwd_f16in: null pointer");
+  GRIT_REQUIRE(T >= 0 && H > 0, GRIT_E_BADARG, "grit_rmsnorm_fwd_f16in: bad sizes");
+  GRIT_REQUIRE(H % 8 == 0, GRIT_E_UNSUPPORTED, "grit_rmsnorm_fwd_f16in: H=%d must be a multiple of 8", H);
+  GRIT_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), GRIT_E_BADARG, "grit_rmsnorm_fwd_f16in: pointers must be 16-byte aligned");
+  unsigned int* ovf = f16_flag_ptr();
+  GRIT_REQUIRE(ovf != nullptr, GRIT_E_LAUNCH, "grit_rmsnorm_fwd_f16in: the overflow flag word of this device is not reachable");
+  const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const uint4* xp = (const uint4*)x;
+  const uint4* wp = (const uint4*)w;
+  uint4* yp = (uint4*)y;
+#define GRIT_H16(NCH_)                                                                                                     \
+  do {                                                                                                                     \
+    if (out_is_f16) hipLaunchKernelGGL((rmsnorm_fwd_h16_k<NCH_, true>), grid, block, 0, st, xp, wp, yp, T, H, eps, ovf);   \
+    else hipLaunchKernelGGL((rmsnorm_fwd_h16_k<NCH_, false>), grid, block, 0, st, xp, wp, yp, T, H, eps, ovf);             \
+  } while (0)
+  switch (H % 512 == 0 ? H / 512 : 0) {
+    case 1: GRIT_H16(1); break;
+    case 2: GRIT_H16(2); break;
+    case 4: GRIT_H16(4); break;
+    case 8: GRIT_H16(8); break;
+    case 16: GRIT_H16(16); break;
+    default: GRIT_H16(0); break;
+  }
+#undef GRIT_H16
+  GRIT_CHECK_LAUNCH("grit_rmsnorm_fwd_f16in");
   return GRIT_OK;
 }
 

@@ -160,8 +160,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                                                       int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope,
                                                       unsigned int* tile_ctr, GemmSecond second, unsigned int* ovf) {
-  static_assert(!F16 || EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_ROPE || EPI == GRIT_EPI_SWIGLU || EPI == GRIT_EPI_RESIDUAL_F32,
+  static_assert(!F16 || EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_ROPE || EPI == GRIT_EPI_SWIGLU || EPI == GRIT_EPI_RESIDUAL_F32 ||
+                    EPI == GRIT_EPI_RESIDUAL,
                 "fp16 operands: forward epilogues only");
+
   using frag_t = std::conditional_t<F16, f16x8_t, bf16x8_t>;
   uint32_t ovf_acc = 0;                                        // F16: OR of h2_nonfinite() over everything this lane stores
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -533,6 +535,17 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
   GRIT_READ_W(wf0[0], 0, smem);
   GRIT_STAGGER(1);                    // the second wave group runs one barrier behind the first (BAR1: no stagger in the count)
 
+  // F16: the overflow bits of a tile are published at the END OF ITS EPILOGUE and the accumulator word cleared, so that it is not live
+  // across the K loop (in the persistent form one more live VGPR there pushed the RESIDUAL instantiation over the 256-register cliff:
+  // 35 spills = scratch reloads, each a vmcnt(0) drain of the LDS-DMA queue).  (Rows beyond M are computed from clamped, valid rows:
+  // no false alarms.)
+#define GRIT_OVF_FLUSH()                                                   \
+  do {                                                                     \
+    if constexpr (F16) {                                                   \
+      if (ovf_acc != 0 && ovf != nullptr) atomicOr(ovf, 1u);               \
+      ovf_acc = 0;                                                         \
+    }                                                                      \
+  } while (0)
   // ---- epilogue: lane holds C[m][n..n+3], m = frag row base + (lane&15), n = frag col base + (lane>>4)*4
   auto wrow = [&](int j) { return wrow_of<ROPE>(wc, j); };
   auto epilogue = [&](int64_t m0, int64_t M, int n0) {
@@ -659,8 +672,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           const uint32_t ra[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const uint32_t rr = pack2bf_hw(v[2 * e], v[2 * e + 1]);
-            v[2 * e] = bflo(rr) + bflo(ra[e]); v[2 * e + 1] = bfhi(rr) + bfhi(ra[e]);
+            const uint32_t rr = pack2_op<F16>(v[2 * e], v[2 * e + 1]);
+            v[2 * e] = lo16_op<F16>(rr) + lo16_op<F16>(ra[e]); v[2 * e + 1] = hi16_op<F16>(rr) + hi16_op<F16>(ra[e]);
           }
         }
         if constexpr (EPI == GRIT_EPI_SWIGLU_BWD) {
@@ -688,6 +701,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     }
   }
   }
+  GRIT_OVF_FLUSH();
   };
 
   // ---- epilogue through LDS (round 3; used by STORE / RESIDUAL, written for RoPE and SwiGLU too).  In the MFMA layout consecutive lanes hold
@@ -865,8 +879,15 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
           if constexpr (EPI == GRIT_EPI_RESIDUAL) {
             // the reference rounds the Linear output to bf16 before the residual add (:769,:775): `piece` holds the rounded values
             const uint4 rv = rpre[i][hh];
+            if constexpr (F16) {
+              // fp16 residual stream: f16(acc) + residual as ONE v_pk_add_f16 per pair -- the IEEE fp16 sum of two fp16 values, i.e. exactly
+              // what unpack / fp32 add / round would give, without the unpack temporaries (they spilled 35 VGPRs in the persistent form)
+              piece = make_uint4(pk_add_f16(piece.x, rv.x), pk_add_f16(piece.y, rv.y), pk_add_f16(piece.z, rv.z), pk_add_f16(piece.w, rv.w));
+              ovf_acc |= h2_nonfinite(piece.x) | h2_nonfinite(piece.y) | h2_nonfinite(piece.z) | h2_nonfinite(piece.w);
+            } else {
             piece = make_uint4(pack2bf_hw(bflo(piece.x) + bflo(rv.x), bfhi(piece.x) + bfhi(rv.x)), pack2bf_hw(bflo(piece.y) + bflo(rv.y), bfhi(piece.y) + bfhi(rv.y)),
                                pack2bf_hw(bflo(piece.z) + bflo(rv.z), bfhi(piece.z) + bfhi(rv.z)), pack2bf_hw(bflo(piece.w) + bflo(rv.w), bfhi(piece.w) + bfhi(rv.w)));
+            }
           }
           if constexpr (EPI == GRIT_EPI_SWIGLU_BWD) {
             // `piece` = d_act rounded to bf16 (what the un-fused path stores and re-reads), then the arithmetic of grit_swiglu_bwd
@@ -894,6 +915,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
         }
       }
     }
+    GRIT_OVF_FLUSH();
   };
   // Measured against the direct epilogue on the same box (ratios to the round-2 kernel, M = 131072; profiles/r03_gemm_ab_lds_epilogue.log):
   // RESIDUAL K = 4096 1.019 -> 1.049, K = 14336 1.003 -> 1.011, STORE 1.029 -> 1.039, RoPE 1.026 -> 1.025, SwiGLU 1.027 -> 1.017 (its output
@@ -985,9 +1007,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GRIT_SEG_FENCE();
   }
-  if constexpr (F16) {
-    if (ovf_acc != 0 && ovf != nullptr) atomicOr(ovf, 1u);     // (rows beyond M are computed from clamped, valid rows: no false alarms)
-  }
+#undef GRIT_OVF_FLUSH
 #undef GRIT_READ_W
 #undef GRIT_PREFETCH_OFF
 #undef GRIT_OFF_NOW
@@ -1356,7 +1376,8 @@ extern "C" int grit_gemm_bf16_nt(const void* A, const void* W, void* C, int64_t 
 
 // ---- fp16-operand instantiations (the encoder's "f16_operands" precision policy; forward only, dense) ----
 // Same contract as grit_gemm_bf16_nt with A, W (and C for STORE / SWIGLU) holding IEEE fp16.  STORE: C = f16(acc); SWIGLU: C =
-// f16(silu(gate) * up) from the fp32 accumulators (one rounding; interleaved weight rows, grit_swiglu_block()); RESIDUAL_F32: C (fp32)
+// f16(silu(gate) * up) from the fp32 accumulators (one rounding; interleaved weight rows, grit_swiglu_block()); RESIDUAL: C (fp16) =
+// f16(f16(acc) + residual) with an fp16 residual (the fp16 residual stream of the "f16_stream" policy); RESIDUAL_F32: C (fp32)
 // = residual (fp32) + acc.  A result beyond the fp16 range sets the device's overflow flag (grit_f16_overflow_flag).
 extern "C" int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                                 int64_t ldc, int epilogue, const void* residual, int64_t ldr, void* stream) {
@@ -1374,6 +1395,10 @@ extern "C" int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M
     case GRIT_EPI_STORE:
       GRIT_REQUIRE(ldc >= N, GRIT_E_BADARG, "grit_gemm_f16_nt: ldc < N");
       return launch_gemm<GRIT_EPI_STORE, true>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    case GRIT_EPI_RESIDUAL:
+      GRIT_REQUIRE(residual && ldr % 8 == 0 && ldr >= N && ldc >= N && aligned16(residual), GRIT_E_BADARG,
+                   "grit_gemm_f16_nt: RESIDUAL epilogue needs an fp16 residual with ldr >= N");
+      return launch_gemm<GRIT_EPI_RESIDUAL, true>(A, W, C, residual, M, N, K, lda, ldw, ldc, ldr, st);
     case GRIT_EPI_RESIDUAL_F32:
       GRIT_REQUIRE(residual && ldr % 4 == 0 && ldr >= N && ldc >= N && ldc % 4 == 0 && aligned16(residual), GRIT_E_BADARG,
                    "grit_gemm_f16_nt: RESIDUAL_F32 epilogue needs an fp32 residual with ldr >= N (C and residual are fp32, ldc / ldr in floats)");
@@ -1382,7 +1407,7 @@ extern "C" int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M
       GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
       return launch_gemm<GRIT_EPI_SWIGLU, true>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
     default:
-      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_f16_nt: epilogue %d not available (STORE, SWIGLU, RESIDUAL_F32)", epilogue);
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_f16_nt: epilogue %d not available (STORE, SWIGLU, RESIDUAL, RESIDUAL_F32)", epilogue);
   }
   return GRIT_OK;
 }

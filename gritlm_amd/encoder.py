@@ -36,7 +36,12 @@ F16 = torch.float16
 #                    north-star tolerance (1 - cos < 1e-4 against the reference's fp32 run) at depth 32.  bf16 checkpoints convert to fp16
 #                    exactly for 6.1e-5 <= |w| < 65520; an activation beyond the fp16 range raises (check_f16_overflow), it never saturates
 #                    silently.  Dense (Mistral) models, bidirectional attention.
-PRECISIONS = ("bf16", "fp32_residual", "f16_operands")
+#   "f16_stream"     "f16_operands" with the residual stream itself in fp16 (16-bit residual epilogues and norms, as in the bf16 policy):
+#                    1 - cos 6e-6 at depth 32 (emulated; the stream's 11-bit mantissa adds 2e-6 to the fp32 stream's 4e-6) at 0.975 of the
+#                    default's docs/s instead of 0.955.  The stream of a checkpoint with activations beyond 65504 does not fit: that raises
+#                    (the same flag); use "f16_operands" there.
+PRECISIONS = ("bf16", "fp32_residual", "f16_operands", "f16_stream")
+F16_POLICIES = ("f16_operands", "f16_stream")
 
 
 @dataclass
@@ -157,7 +162,7 @@ class MistralEncoderEngine:
     # `residual_fp32` (rounds 3-4: a bool) is kept as a view of `precision`: True <-> the stream lives in fp32
     @property
     def residual_fp32(self) -> bool:
-        return self.precision != "bf16"
+        return self.precision in ("fp32_residual", "f16_operands")
 
     @residual_fp32.setter
     def residual_fp32(self, v: bool):
@@ -166,11 +171,11 @@ class MistralEncoderEngine:
     def set_precision(self, precision: str):
         if precision not in PRECISIONS:
             raise ValueError(f"precision={precision!r}: one of {PRECISIONS}")
-        if precision == "f16_operands":
+        if precision in F16_POLICIES:
             if self.cfg.num_local_experts:
-                raise GritHipError("native encoder: precision='f16_operands' is built for the dense (Mistral) MLP only")
+                raise GritHipError(f"native encoder: precision='{precision}' is built for the dense (Mistral) MLP only")
             if self.causal:
-                raise GritHipError("native encoder: precision='f16_operands' is built for bidirectional attention only")
+                raise GritHipError(f"native encoder: precision='{precision}' is built for bidirectional attention only")
         self.precision = precision
         return self
 
@@ -189,7 +194,7 @@ class MistralEncoderEngine:
                 st["total"] += w.numel()
                 h.append(w.to(F16))
             if st["overflow"]:
-                raise GritHipError(f"precision='f16_operands': {st['overflow']} weights exceed the fp16 range (|w| >= 65520)")
+                raise GritHipError(f"precision='{self.precision}': {st['overflow']} weights exceed the fp16 range (|w| >= 65520)")
             self.f16_weight_stats = st
             L.h16 = h = tuple(h)
         return h
@@ -197,9 +202,22 @@ class MistralEncoderEngine:
     def check_f16_overflow(self, clear: bool = True) -> None:
         """Raise if a kernel of the f16_operands policy produced a value beyond the fp16 range since the last check (waits for the
         device's current stream: call it where the embeddings are copied to the host anyway)."""
-        if self.precision == "f16_operands" and ops.f16_overflow_flag(self.device, clear):
-            raise GritHipError("precision='f16_operands': an activation exceeded the fp16 range (|v| >= 65520) in this forward pass; "
-                               "the embeddings of this call are invalid -- run this model with precision='fp32_residual' or 'bf16'")
+        if self.precision in F16_POLICIES and ops.f16_overflow_flag(self.device, clear):
+            raise GritHipError(f"precision='{self.precision}': an activation exceeded the fp16 range (|v| >= 65520) in this forward pass; "
+                               "the embeddings of this call are invalid -- run this model with "
+                               + ("precision='f16_operands' (fp32 residual stream), " if self.precision == "f16_stream" else "")
+                               + "precision='fp32_residual' or 'bf16'")
+
+    def _embed_table(self):
+        """embed_tokens in the residual stream's format: bf16 (also the source of the exact widening into an fp32 stream), or an fp16 copy
+        (262 MB at V 32000) for the fp16 stream, converted on first use"""
+        if self.precision != "f16_stream":
+            return self.embed
+        if getattr(self, "_embed16", None) is None or self._embed16.shape != self.embed.shape:
+            if bool((self.embed.abs() >= 65520.0).any()):
+                raise GritHipError("precision='f16_stream': embedding weights exceed the fp16 range")
+            self._embed16 = self.embed.to(F16)
+        return self._embed16
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -320,9 +338,9 @@ class MistralEncoderEngine:
             c, dev = self.cfg, self.device
             qkv_w = (c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim
             self._ws.clear()
-            opd = F16 if self.precision == "f16_operands" else BF16
+            opd = F16 if self.precision in F16_POLICIES else BF16
             mk = lambda n: torch.empty((T, n), dtype=opd, device=dev)
-            h = torch.empty((T, c.hidden_size), dtype=torch.float32 if self.residual_fp32 else BF16, device=dev)
+            h = torch.empty((T, c.hidden_size), dtype=torch.float32 if self.residual_fp32 else opd, device=dev)
             self._ws.update(cap=T, policy=self.precision, h=h, x=mk(c.hidden_size), qkv=mk(qkv_w), ctx=mk(c.num_attention_heads * c.head_dim))
             # last_hidden_state stays bf16 in every policy (the pooling kernels' input; one rounding of the final RMSNorm, averaged over the
             # sequence by the pooling: 3e-7 of 1 - cos, profiles/r05_precision_budget.json "only_out_bf16")
@@ -356,7 +374,7 @@ class MistralEncoderEngine:
 
     def _weights(self, L: _Layer):
         """(wqkv, wo, wgu, wdown) in the operand format of the current policy"""
-        if self.precision == "f16_operands":
+        if self.precision in F16_POLICIES:
             return self._f16_weights(L)
         return (L.wqkv, L.wo, getattr(L, "wgu", None), getattr(L, "wdown", None))        # (MoE layers have no dense MLP weights)
 
@@ -365,7 +383,7 @@ class MistralEncoderEngine:
         return int(self.window_keys) if self.causal and 0 < self.window_keys < S else 0
 
     def _rope_tables(self, S: int):
-        rounded = self.rope_bf16 and self.precision != "f16_operands"      # f16_operands: the unrounded fp32 tables (fp32 rotation)
+        rounded = self.rope_bf16 and self.precision not in F16_POLICIES    # fp16 operands: the unrounded fp32 tables (fp32 rotation)
         t = self._rope.get((S, rounded))
         if t is None:
             t = rope_tables(S, self.cfg.head_dim, self.cfg.rope_theta, rounded, self.device)
@@ -397,7 +415,7 @@ class MistralEncoderEngine:
         if attention_mask is None:
             attention_mask = torch.ones((B, S), dtype=torch.int64, device=self.device)
         mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
-        if self.precision == "f16_operands":
+        if self.precision in F16_POLICIES:
             self.set_precision(self.precision)        # (re-checks the model kind / attention mode the policy is built for)
         ws = self._workspace(T)
         h, x, qkv, ctx, xo = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["xo"]
@@ -407,7 +425,7 @@ class MistralEncoderEngine:
         if inputs_embeds is not None:
             h.copy_(inputs_embeds.to(self.device).reshape(T, c.hidden_size))
         else:
-            ops.embed_gather(self.embed, ids, out=h)
+            ops.embed_gather(self._embed_table(), ids, out=h)
         kv = []
         for L in (self.layers if layer_range is None else self.layers[layer_range[0]:layer_range[1]]):
             wqkv, wo = self._weights(L)[:2]
@@ -486,13 +504,13 @@ class MistralEncoderEngine:
                 mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
                 h = self.forward(input_ids.to(device=self.device, dtype=torch.int64), mask, borrow=True)
                 return ops.pool_norm(h, mask, method, normalize, instr_len)
-            if self.precision == "f16_operands":
+            if self.precision in F16_POLICIES:
                 self.set_precision(self.precision)
             ws = self._workspace(T)
             h, x, qkv, ctx, xo = ws["h"], ws["x"], ws["qkv"], ws["ctx"], ws["xo"]
             nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
             cos, sin = self._rope_tables(S)
-            ops.embed_gather(self.embed, pids, out=h)
+            ops.embed_gather(self._embed_table(), pids, out=h)
             for L in self.layers:
                 wqkv, wo = self._weights(L)[:2]
                 ops.rmsnorm(h, L.ln1, eps, out=x)

@@ -70,7 +70,7 @@ class GritLM(torch.nn.Module):
         devices = kwargs.pop("devices", None)   # extension: the GPUs in-process multi-GPU encode uses (default: every visible one)
         # extension: precision policy of the native engine (gritlm_amd.encoder.PRECISIONS): "bf16" = the reference's bf16 arithmetic
         # (default), "fp32_residual", "f16_operands" (fp32 stream + fp16 MFMA operands: 1 - cos < 1e-4 against the reference's fp32 run at
-        # depth 32).  `residual_fp32=True` (round 4) is kept as an alias of precision="fp32_residual".
+        # depth 32), "f16_stream" (the same with the residual stream in fp16: faster, range-limited).  `residual_fp32=True` (round 4) is kept as an alias of precision="fp32_residual".
         residual_fp32 = bool(kwargs.pop("residual_fp32", False))
         precision = kwargs.pop("precision", None) or ("fp32_residual" if residual_fp32 else "bf16")
         from .encoder import PRECISIONS
@@ -336,7 +336,7 @@ class GritLM(torch.nn.Module):
         else:
             # ONE device->host copy for the whole call (the reference syncs per batch, :164)
             result = torch.cat(chunks, dim=0).to(torch.float32).cpu().numpy()
-        if self.engine is not None and getattr(self.engine, "precision", None) == "f16_operands":
+        if self.engine is not None and getattr(self.engine, "precision", None) in ("f16_operands", "f16_stream"):
             for eng in (getattr(self, "engines", None) or [self.engine]):       # raises if an activation left the fp16 range in this call
                 eng.check_f16_overflow()
         if single:

@@ -102,6 +102,10 @@ def embed_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor | Non
     T = ids.numel()
     if out is None:
         out = torch.empty((T, H), dtype=BF16, device=table.device)
+    if table.dtype == F16:      # fp16 residual stream: an fp16 copy of the table, rows copied (the gather moves 16-bit words)
+        check(_lib.load().grit_embed_gather(_chk(table, F16, "table"), _chk(ids, I64, "ids"), _chk(out, F16, "out"), T, H, V, _stream()),
+              "grit_embed_gather")
+        return out
     if out.dtype == F32:        # fp32 residual stream: rows widened (exact)
         check(_lib.load().grit_embed_gather_f32(_chk(table, BF16, "table"), _chk(ids, I64, "ids"), _chk(out, F32, "out"), T, H, V, _stream()),
               "grit_embed_gather_f32")
@@ -118,7 +122,10 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: torch.Tensor | No
     T = x.numel() // H
     if out is None:
         out = torch.empty(x.shape, dtype=BF16, device=x.device)
-    if x.dtype == F32 and out.dtype == F16:
+    if x.dtype == F16:          # fp16 residual stream: one rounding, to fp16 (the next operand) or to bf16 (last_hidden_state)
+        check(_lib.load().grit_rmsnorm_fwd_f16in(_chk(x, F16, "x"), _chk(w, BF16, "w"), _chk(out, out.dtype if out.dtype in (F16, BF16) else F16, "out"),
+                                                 int(out.dtype == F16), T, H, float(eps), _stream()), "grit_rmsnorm_fwd_f16in")
+    elif x.dtype == F32 and out.dtype == F16:
         check(_lib.load().grit_rmsnorm_fwd_f32in_f16(_chk(x, F32, "x"), _chk(w, BF16, "w"), _chk(out, F16, "out"), T, H, float(eps), _stream()),
               "grit_rmsnorm_fwd_f32in_f16")
     elif x.dtype == F32:
@@ -226,8 +233,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE) else (2 * N if epilogue == EPI_SWIGLU_BWD else N)
     opd = a.dtype if a.dtype == F16 else BF16                 # fp16 operands: the f16_operands policy (STORE, SWIGLU, RESIDUAL_F32)
     odt = F32 if epilogue == EPI_RESIDUAL_F32 else opd        # RESIDUAL_F32: out and residual are the fp32 residual stream
-    if opd == F16 and epilogue not in (EPI_STORE, EPI_SWIGLU, EPI_RESIDUAL_F32):
-        raise _lib.GritHipError(f"gemm_nt: epilogue {epilogue} is not built for fp16 operands (STORE, SWIGLU, RESIDUAL_F32)")
+    if opd == F16 and epilogue not in (EPI_STORE, EPI_SWIGLU, EPI_RESIDUAL, EPI_RESIDUAL_F32):
+        raise _lib.GritHipError(f"gemm_nt: epilogue {epilogue} is not built for fp16 operands (STORE, SWIGLU, RESIDUAL, RESIDUAL_F32)")
     if out is None:
         out = torch.empty((M, n_out), dtype=odt, device=a.device)
     assert out.shape == (M, n_out)

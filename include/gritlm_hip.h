@@ -146,7 +146,8 @@ int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void*
 int grit_rmsnorm_fwd_f32in_f16(const float* x, const void* w, void* y, int64_t T, int H, float eps, void* stream);
 
 /* grit_gemm_bf16_nt on fp16 operands (A, W fp16; fp32 accumulate).  Epilogues: GRIT_EPI_STORE (C = fp16(acc)), GRIT_EPI_SWIGLU
- * (C = fp16(silu(gate) * up) evaluated in fp32, interleaved weight rows), GRIT_EPI_RESIDUAL_F32 (C, residual fp32: C = residual + acc). */
+ * (C = fp16(silu(gate) * up) evaluated in fp32, interleaved weight rows), GRIT_EPI_RESIDUAL_F32 (C, residual fp32: C = residual + acc),
+ * GRIT_EPI_RESIDUAL (C, residual fp16: the fp16 residual stream, below). */
 int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int epilogue,
                      const void* residual, int64_t ldr, void* stream);
 
@@ -161,6 +162,12 @@ int grit_attn_bidir_f16_fwd(const void* qkv, const uint64_t* key_bits, void* out
                             int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
 int grit_attn_bidir_varlen_f16_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq, int nkv,
                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+
+/* "f16_stream" (the same policy with the residual stream itself in fp16 instead of fp32: 16-bit epilogue and norm traffic, 0.975 of
+ * the default's docs/s instead of 0.955; 1 - cos 6e-6 emulated): grit_embed_gather on an fp16 copy of the table (a 16-bit row copy),
+ * grit_gemm_f16_nt with GRIT_EPI_RESIDUAL (C = fp16(fp16(acc) + residual), residual fp16, may alias C), and MistralRMSNorm (:84-89) of an
+ * fp16 row with one rounding, to fp16 (out_is_f16 != 0) or to bf16 (last_hidden_state). */
+int grit_rmsnorm_fwd_f16in(const void* x, const void* w, void* y, int out_is_f16, int64_t T, int H, float eps, void* stream);
 
 /* *host_flag = 1 if a kernel of this policy stored an inf / nan on the current device since the last clear, else 0.  Enqueues a 4-byte
  * D2H copy (and, with clear != 0, the reset) on `stream` and WAITS for that stream: the one entry point of this library that

@@ -819,7 +819,7 @@ def check_full_depth_parity(residual_fp32=False, precision=None):
     precision = precision or ("fp32_residual" if residual_fp32 else "bf16")
     residual_fp32 = precision != "bf16"
     bound = {"bf16": bench.FULL_DEPTH_BOUND_BF16_RESIDUAL, "fp32_residual": bench.FULL_DEPTH_BOUND_FP32_RESIDUAL,
-             "f16_operands": bench.FULL_DEPTH_BOUND_F16_OPERANDS}[precision]          # f16_operands: the north-star's own 1e-4
+             "f16_operands": bench.FULL_DEPTH_BOUND_F16_OPERANDS, "f16_stream": bench.FULL_DEPTH_BOUND_F16_OPERANDS}[precision]   # fp16 policies: the north-star's own 1e-4
     cosd = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
     cfg, w, _, _ = bench.oracle_full_depth_case(sample_docs=1, seq=64, layers=layers)
     sd = {k: torch.from_numpy(v) for k, v in w.items()}
@@ -839,7 +839,7 @@ def check_full_depth_parity(residual_fp32=False, precision=None):
         det[f"{tag}_packed_identical"] = same
         ok = ok and same and bool(np.isfinite(f32(e_pad)).all()) and hip < bound
         embs[tag] = (tid, tm)
-    if precision == "f16_operands":
+    if precision in ("f16_operands", "f16_stream"):
         det["overflow_flag"] = ops.f16_overflow_flag(eng.device)
         det["subnormal_weight_frac"] = eng.f16_weight_stats["subnormal"] / max(eng.f16_weight_stats["total"], 1)
         ok = ok and not det["overflow_flag"]
@@ -1179,6 +1179,17 @@ def check_gemm_f16(M, N, K, epi=EPI_STORE, seed=107, subnormal_weights=False):
         ref = ref + r
         scale = float(np.sqrt(np.mean(ref ** 2)))
         err = float(np.max(np.abs(got - ref)) / scale) / 2e-5
+    elif epi == EPI_RESIDUAL:             # fp16 residual stream: C = f16(f16(acc) + residual), in place
+        r = f16r(rng.standard_normal((M, N)).astype(np.float32) * 3.0)
+        rt = fh(r)
+        ops.gemm_nt(fh(a), fh(w), out=rt, epilogue=epi, residual=rt)
+        assert rt.dtype == torch.float16
+        got = rt.float().cpu().numpy().astype(np.float64)
+        exact = f16r((f16r(ref.astype(np.float32)).astype(np.float64) + r).astype(np.float32)).astype(np.float64)   # the two roundings, from the fp64 product
+        scale = float(np.sqrt(np.mean(ref ** 2))) + 1e-12
+        tol = 2.0 ** -11 * (np.abs(ref) + np.abs(ref + r)) + 6.0e-8 + 2e-5 * scale
+        err = float(np.max(np.abs(got - (ref + r)) / tol))
+        err = max(err, 0.0 if float(np.mean(got == exact)) > 0.99 else 2.0)                                           # and bit-equal to the emulated roundings almost everywhere
     else:
         if epi == EPI_SWIGLU:
             I = N // 2
@@ -1288,6 +1299,12 @@ def check_f16_overflow_flag():
     cos, sin = rope_tables(128, 128, 10000.0, False, DEV)
     ops.gemm_nt_rope(big, w, cos, sin, 256, S=100)
     det["rope_overflow"] = _f16_flag(); ok &= det["rope_overflow"]
+    stream = fh(np.full((M, N), 6.0e4, dtype=np.float32))                      # fp16 residual stream near the top of the range: 6e4 + 512 > 65504
+    ops.gemm_nt(small, w, out=stream, epilogue=EPI_RESIDUAL, residual=stream)
+    det["f16_stream_residual_overflow"] = _f16_flag(); ok &= det["f16_stream_residual_overflow"]
+    stream = fh(np.full((M, N), 1.0e3, dtype=np.float32))
+    ops.gemm_nt(small, w, out=stream, epilogue=EPI_RESIDUAL, residual=stream)
+    det["f16_stream_residual_in_range"] = _f16_flag(); ok &= not det["f16_stream_residual_in_range"]
     x = torch.full((5, 256), 3.0, dtype=torch.float32, device=DEV)
     wn = torch.full((256,), 3.0e4, dtype=torch.bfloat16, device=DEV)           # 1.0 * 3e4 fits; x row has rms 3 -> normalised 1.0
     y = torch.empty((5, 256), dtype=torch.float16, device=DEV)
@@ -1311,6 +1328,30 @@ def check_f16_stream_ops(T=37, H=4096):
     exact = float(np.mean(y == f16r(ref.astype(np.float32))))
     err = float(np.max(np.abs(y - ref) / (np.abs(ref) + 1e-3)))
     return _res(f"f16_stream_ops[T={T},H={H}]", err < 6e-4 and exact > 0.99, rms_max_rel=err, rms_exact_frac=exact)
+
+
+def check_f16_stream_norm_and_gather(T=37, H=4096):
+    """The fp16 residual stream's own kernels: grit_rmsnorm_fwd_f16in (fp16 rows -> fp16 operand / bf16 last_hidden_state, ONE rounding,
+    vs fp64) and the embedding gather on an fp16 copy of the table (bit-exact rows)."""
+    rng = np.random.default_rng(13)
+    x = f16r(rng.standard_normal((T, H)).astype(np.float32) * 2.0)
+    w = O.bf16_round(1 + 0.1 * rnd((H,), 4))
+    x64 = x.astype(np.float64)
+    ref = w * (x64 * (1.0 / np.sqrt((x64 ** 2).mean(-1, keepdims=True) + 1e-5)))
+    det, ok = {}, True
+    for dt, rnd_fn, name, tol in ((torch.float16, f16r, "f16", 6e-4), (torch.bfloat16, O.bf16_round, "bf16", 5e-3)):
+        y = torch.empty((T, H), dtype=dt, device=DEV)
+        ops.rmsnorm(fh(x), bf(w), 1e-5, out=y)
+        y = y.float().cpu().numpy()
+        det[f"{name}_exact_frac"] = float(np.mean(y == rnd_fn(ref.astype(np.float32))))
+        det[f"{name}_max_rel"] = float(np.max(np.abs(y - ref) / (np.abs(ref) + 1e-3)))
+        ok &= det[f"{name}_exact_frac"] > 0.99 and det[f"{name}_max_rel"] < tol
+    tab = f16r(rng.standard_normal((97, H)).astype(np.float32))
+    ids = rng.integers(0, 97, size=(T,))
+    out = torch.empty((T, H), dtype=torch.float16, device=DEV)
+    ops.embed_gather(fh(tab), torch.from_numpy(ids).to(DEV), out=out)
+    det["gather_exact"] = bool(np.array_equal(out.float().cpu().numpy(), tab[ids])); ok &= det["gather_exact"]
+    return _res(f"f16 stream: rmsnorm_f16in + gather [T={T},H={H}]", ok, **det)
 
 
 def check_attention_f16(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=211, packed_lens=None):
@@ -1357,7 +1398,7 @@ def check_attention_f16(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=211, p
     return _res(f"attention_f16[B={B},S={S},nq={nq},nkv={nkv},{mask_kind if packed_lens is None else 'packed'}]", ok, **det)
 
 
-def check_encoder_f16_operands(cfg_name):
+def check_encoder_f16_operands(cfg_name, policy="f16_operands"):
     """The engine under precision='f16_operands' (fp32 residual stream, every MFMA operand fp16) against the reference's FP32 run
     (reference-generated fixture): pooled embeddings within 1e-5 of the fp32 reference (north-star: 1e-4) AND at least 10x closer than
     the fp32-residual policy with bf16 operands on the same inputs (the emulation, profiles/r05_precision_budget.json, predicts ~64x in
@@ -1381,7 +1422,7 @@ def check_encoder_f16_operands(cfg_name):
     r_b = rel(pick(f32(eng.forward(tid, tm))), ref32)
     omc = lambda e, m: float(np.max(1 - np.sum(f32(e).astype(np.float64) * g[f"emb_{m}"].astype(np.float64), axis=1)))
     d_b = {m: omc(eng.encode_pooled(tid, tm, m, True, packed=False), m) for m in ("mean", "weightedmean")}
-    eng.set_precision("f16_operands")
+    eng.set_precision(policy)
     _f16_flag()
     h_f = pick(f32(eng.forward(tid, tm)))
     r_f = rel(h_f, ref32)
@@ -1402,7 +1443,7 @@ def check_encoder_f16_operands(cfg_name):
     except Exception:      # noqa: BLE001
         out["check_passes"] = False
     ok &= out["check_passes"]
-    return _res(f"encoder[{cfg_name}] f16_operands policy vs reference fp32", ok, **out)
+    return _res(f"encoder[{cfg_name}] {policy} policy vs reference fp32", ok, **out)
 
 
 def check_f16_policy_raises_on_overflow():
@@ -3051,6 +3092,7 @@ ALL_CHECKS = [
     ("full_depth_parity_32_layers", check_full_depth_parity, {}),
     ("full_depth_parity_32_layers_fp32_residual", check_full_depth_parity, dict(residual_fp32=True)),
     ("full_depth_parity_32_layers_f16_operands", check_full_depth_parity, dict(precision="f16_operands")),
+    ("full_depth_parity_32_layers_f16_stream", check_full_depth_parity, dict(precision="f16_stream")),
     ("gemm_f16_256", check_gemm_f16, dict(M=256, N=256, K=64)),
     ("gemm_f16_edge", check_gemm_f16, dict(M=300, N=272, K=128)),
     ("gemm_f16_big", check_gemm_f16, dict(M=1024, N=768, K=512)),
@@ -3059,6 +3101,9 @@ ALL_CHECKS = [
     ("gemm_f16_swiglu_edge", check_gemm_f16, dict(M=70, N=576, K=64, epi=EPI_SWIGLU)),
     ("gemm_f16_residual_f32", check_gemm_f16, dict(M=520, N=512, K=192, epi=EPI_RESIDUAL_F32)),
     ("gemm_f16_residual_f32_persistent", check_gemm_f16, dict(M=8192, N=4096, K=512, epi=EPI_RESIDUAL_F32, seed=129)),
+    ("gemm_f16_residual_f16_stream", check_gemm_f16, dict(M=520, N=512, K=192, epi=EPI_RESIDUAL, seed=131)),
+    ("gemm_f16_residual_f16_stream_edge", check_gemm_f16, dict(M=300, N=272, K=128, epi=EPI_RESIDUAL, seed=133)),
+    ("gemm_f16_residual_f16_stream_persistent", check_gemm_f16, dict(M=8192, N=4096, K=512, epi=EPI_RESIDUAL, seed=135)),
     ("gemm_f16_rope", check_gemm_f16_rope, {}),
     ("gemm_f16_rope_packed", check_gemm_f16_rope, dict(M=513, nq=2, nkv=1, K=128, packed=True)),
     ("gemm_f16_rope_7b", check_gemm_f16_rope, dict(M=1024, nq=32, nkv=8, K=512, S=512)),
@@ -3068,6 +3113,8 @@ ALL_CHECKS = [
     ("f16_overflow_flag", check_f16_overflow_flag, {}),
     ("f16_stream_ops", check_f16_stream_ops, {}),
     ("f16_stream_ops_264", check_f16_stream_ops, dict(T=5, H=264)),
+    ("f16_stream_norm_and_gather", check_f16_stream_norm_and_gather, {}),
+    ("f16_stream_norm_and_gather_264", check_f16_stream_norm_and_gather, dict(T=5, H=264)),
     ("attn_f16_ragged", check_attention_f16, dict(mask_kind="ragged")),
     ("attn_f16_holes", check_attention_f16, dict(mask_kind="holes", S=257)),
     ("attn_f16_full_512", check_attention_f16, dict(B=1, S=512, nq=8, nkv=2, mask_kind="none")),
@@ -3075,6 +3122,9 @@ ALL_CHECKS = [
     ("encoder_tiny_f16_operands", check_encoder_f16_operands, dict(cfg_name="tiny")),
     ("encoder_gqa_f16_operands", check_encoder_f16_operands, dict(cfg_name="gqa")),
     ("encoder_7b_layer_f16_operands", check_encoder_f16_operands, dict(cfg_name="7b-l1")),
+    ("encoder_tiny_f16_stream", check_encoder_f16_operands, dict(cfg_name="tiny", policy="f16_stream")),
+    ("encoder_gqa_f16_stream", check_encoder_f16_operands, dict(cfg_name="gqa", policy="f16_stream")),
+    ("encoder_7b_layer_f16_stream", check_encoder_f16_operands, dict(cfg_name="7b-l1", policy="f16_stream")),
     ("f16_policy_raises_on_overflow", check_f16_policy_raises_on_overflow, {}),
     ("gritlm_f16_operands", check_gritlm_f16_operands, {}),
     ("gemm_full_swiglu_28672x4096", check_gemm_fullshape, dict(M=4096, N=28672, K=4096, epi=EPI_SWIGLU)),

@@ -171,7 +171,7 @@ def test_parallelize_stays_on_one_device_inside_a_distributed_launch(dirs, monke
 def test_precision_keyword_is_validated(dirs):
     """`precision=` (extension): one of gritlm_amd.encoder.PRECISIONS; `residual_fp32=True` stays an alias of 'fp32_residual'."""
     from gritlm_amd.encoder import PRECISIONS
-    assert PRECISIONS == ("bf16", "fp32_residual", "f16_operands")
+    assert PRECISIONS == ("bf16", "fp32_residual", "f16_operands", "f16_stream")
     with pytest.raises(ValueError, match="precision"):
         GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", precision="fp8")
     assert GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", residual_fp32=True)._precision == "fp32_residual"
