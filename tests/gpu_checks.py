@@ -1299,7 +1299,7 @@ def check_f16_overflow_flag():
     cos, sin = rope_tables(128, 128, 10000.0, False, DEV)
     ops.gemm_nt_rope(big, w, cos, sin, 256, S=100)
     det["rope_overflow"] = _f16_flag(); ok &= det["rope_overflow"]
-    stream = fh(np.full((M, N), 6.0e4, dtype=np.float32))                      # fp16 residual stream near the top of the range: 6e4 + 512 > 65504
+    stream = fh(np.full((M, N), 6.54e4, dtype=np.float32))                     # fp16 residual stream near the top of the range: 65408 + 512 > 65504
     ops.gemm_nt(small, w, out=stream, epilogue=EPI_RESIDUAL, residual=stream)
     det["f16_stream_residual_overflow"] = _f16_flag(); ok &= det["f16_stream_residual_overflow"]
     stream = fh(np.full((M, N), 1.0e3, dtype=np.float32))
