@@ -16,6 +16,8 @@ def test_committed_budget_says_what_the_design_claims():
     assert c["engine_bf16_residual(reference arithmetic)"] > 1e-4 and c["engine_bf16_operands_fp32_residual"] > 1e-4
     assert c["f16_operands_fp32_residual"] < 1e-5 and c["f16_operands_bf16_out_fp32_residual"] < 1e-5
     assert c["f16_operands_fp32_residual_flush_subnormal_weights"] < 1e-5          # even an MFMA that flushed subnormal weights would do
+    assert c["f16_operands_f16_residual"] < 1e-5                                   # the fp16 residual stream ("f16_stream") costs 2e-6
+    assert 1e-5 < c["mixed_f16_x_qkv_p__bf16_ctx_act_out_fp32_residual"] < 1e-4    # ctx / act back in bf16: priced, inside the tolerance, not built
     per_operand = {k: c[f"only_{k}_bf16"] for k in ("x", "qkv", "p", "ctx", "act", "out")}
     assert max(per_operand, key=per_operand.get) in ("x", "qkv") and per_operand["out"] < 1e-6
     for k in ("x", "qkv", "p", "ctx", "act"):
