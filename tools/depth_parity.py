@@ -56,7 +56,8 @@ def engine_emb(eng, ids, mask, depth, policy):
 
 def curve(eng, hf_sd, cfgd, ids, mask, dev, depths=DEPTHS, chunk=8):
     """1 - cos against the fp32 stock module for the four implementations, per depth."""
-    out = {k: {} for k in ("engine_bf16_residual", "engine_fp32_residual", "engine_f16_operands", "stock_bf16_reference_mask", "stock_bf16_explicit_mask")}
+    out = {k: {} for k in ("engine_bf16_residual", "engine_fp32_residual", "engine_f16_operands", "engine_f16_stream", "stock_bf16_reference_mask",
+                           "stock_bf16_explicit_mask")}
     f32m = TR.build_model(cfgd, torch.float32, dev, state_dict=hf_sd)
     ref = {}
     for d in depths:                       # fp32 reference, `chunk` documents at a time (fp32 sdpa on the explicit mask is memory-hungry)
@@ -74,6 +75,7 @@ def curve(eng, hf_sd, cfgd, ids, mask, dev, depths=DEPTHS, chunk=8):
         out["engine_bf16_residual"][str(d)] = omc(engine_emb(eng, ids, mask, d, False), ref[d])
         out["engine_fp32_residual"][str(d)] = omc(engine_emb(eng, ids, mask, d, True), ref[d])
         out["engine_f16_operands"][str(d)] = omc(engine_emb(eng, ids, mask, d, "f16_operands"), ref[d])
+        out["engine_f16_stream"][str(d)] = omc(engine_emb(eng, ids, mask, d, "f16_stream"), ref[d])
     eng.set_precision("bf16")
     return out, ref
 
@@ -104,7 +106,7 @@ def main():
         fi, fm = torch.from_numpy(g[f"{tag}_input_ids"]).to(dev), torch.from_numpy(g[f"{tag}_attention_mask"]).to(dev)
         r32, rb = torch.from_numpy(g[f"{tag}_emb"]).to(dev), torch.from_numpy(g[f"{tag}_emb_bf16"]).to(dev)
         fx[tag] = {"reference_bf16_cpu_vs_reference_fp32": omc(rb, r32)}
-        for name, hp in (("engine_bf16_residual", "bf16"), ("engine_fp32_residual", "fp32_residual"), ("engine_f16_operands", "f16_operands")):
+        for name, hp in (("engine_bf16_residual", "bf16"), ("engine_fp32_residual", "fp32_residual"), ("engine_f16_operands", "f16_operands"), ("engine_f16_stream", "f16_stream")):
             eng.set_precision(hp)
             e_pad = eng.encode_pooled(fi, fm, "mean", True, packed=False)
             e_pack = eng.encode_pooled(fi, fm, "mean", True, packed=True)
@@ -131,8 +133,9 @@ def main():
         print(json.dumps({k: v.get("32") for k, v in res["bench_model"].items() if isinstance(v, dict)}, indent=1), flush=True)
         if not args.no_timing:
             tim = {}
-            for name, hp in (("bf16_residual", "bf16"), ("fp32_residual", "fp32_residual"), ("f16_operands", "f16_operands"),
-                             ("bf16_residual_again", "bf16"), ("fp32_residual_again", "fp32_residual"), ("f16_operands_again", "f16_operands")):
+            for name, hp in (("bf16_residual", "bf16"), ("fp32_residual", "fp32_residual"), ("f16_operands", "f16_operands"), ("f16_stream", "f16_stream"),
+                             ("bf16_residual_again", "bf16"), ("fp32_residual_again", "fp32_residual"), ("f16_operands_again", "f16_operands"),
+                             ("f16_stream_again", "f16_stream")):
                 eng.set_precision(hp)
                 for _ in range(2):
                     ops.pool_norm(eng.forward(ids_all, mask_all, borrow=True), mask_all, "mean", True)
