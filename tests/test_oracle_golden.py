@@ -377,3 +377,26 @@ def test_mixtral_fp32_restatement(golden_dir, cfg_name):
         eng.layers.append(L)
     h2 = TR.mixtral_hidden_states_fp32(lambda li: TR.mixtral_layer_weights_from_engine(eng, li, blk), *args).numpy()
     assert np.array_equal(h2, h)                       # the fixtures' weights are bf16-representable: the round trip is exact
+
+
+def test_numeric_bounds_match_committed_fixtures(golden_dir):
+    """tests/golden/numeric_bounds.json (the yardsticks the GPU checks read instead of the fixtures' host-dependent `*_bf16` arrays) is
+    what make_bounds.py computes from the committed fixtures: regenerating a fixture on another host without re-freezing the bounds --
+    i.e. moving a tolerance silently -- fails here; every key a GPU check reads is present and positive or a fraction."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_bounds", os.path.join(golden_dir, "make_bounds.py"))
+    mb = importlib.util.module_from_spec(spec); spec.loader.exec_module(mb)
+    frozen = json.load(open(os.path.join(golden_dir, "numeric_bounds.json")))
+    assert frozen["frozen_on"]                                   # the generating host's CPU model is recorded
+    now = mb.compute()
+    assert set(now) == set(frozen["values"])
+    for k, v in now.items():
+        assert v == pytest.approx(frozen["values"][k], rel=1e-6, abs=1e-12), k
+        assert np.isfinite(v) and v >= 0.0, k
+    import re
+    src = open(os.path.join(os.path.dirname(golden_dir), "gpu_checks.py")).read()
+    for lit in re.findall(r'_yard\(\)\[f?"([^"]+)"\]', src):      # every key pattern a check reads resolves to frozen keys
+        pat = re.escape(lit)
+        pat = re.sub(r'\\\{[a-z_]+\\\}', r'[^/]+' if lit.startswith(("encoder_", "gritlm_")) else r'.+', pat)
+        assert any(re.fullmatch(pat, k) for k in frozen["values"]), lit
