@@ -55,6 +55,7 @@ _SIGNATURES = {
     "grit_gemm_bf16_nt_grouped": (_i, [_p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _i, _p]),
     "grit_gemv_bf16": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
     "grit_rmsnorm_gemv_bf16": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p]),
+    "grit_rmsnorm_gemv_bf16_deferred": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p]),
     "grit_rope_kv_append": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _p]),
     "grit_kv_append": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _p]),
     "grit_attn_decode_workspace_floats": (_l, [_i, _i, _i, _i]),

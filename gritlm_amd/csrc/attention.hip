@@ -51,6 +51,13 @@
 #ifndef ATT_PRIO_MODE
 #define ATT_PRIO_MODE 0
 #endif
+// ATT_TIMING (diagnostic build, tools/attn_phase_probe.py): thread 0 of every workgroup writes s_memtime stamps (cycles since kernel entry) as
+// raw u32 into the workgroup's LSE rows instead of the LSE -- where a workgroup's time goes between prologue, tiles, seams and stores.
+#ifdef ATT_TIMING
+#define ATT_STAMP() do { if (tid == 0 && att_ns < att_cap) { att_st[att_ns] = (uint32_t)(__builtin_readcyclecounter() - att_t0); ++att_ns; } } while (0)
+#else
+#define ATT_STAMP() do { } while (0)
+#endif
 #if ATT_PRIO_MODE == 0
 #define ATT_PRIO_QK_ENTER() __builtin_amdgcn_s_setprio(1)
 #define ATT_PRIO_QK_LEAVE() __builtin_amdgcn_s_setprio(0)
@@ -135,6 +142,18 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     S = cu_seqlens[b + 1] - cu_seqlens[b];
   }
   if (qb_first * ATT_QB >= S) return;            // uniform per workgroup
+#ifdef ATT_TIMING
+  const uint64_t att_t0 = __builtin_readcyclecounter();
+  uint32_t* att_st = reinterpret_cast<uint32_t*>(lse + ((int64_t)b * nq + h) * S_arg + (int64_t)qb_first * ATT_QB);
+  int att_ns = 0;
+  const int att_cap = qpw * ATT_QB;
+  ATT_STAMP();                                                                      // [0] = 0
+  if (tid == 0) {
+    att_st[att_ns++] = (uint32_t)__builtin_amdgcn_s_memrealtime();                   // [1] = 100 MHz wall clock at entry
+    att_st[att_ns++] = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);          // [2] = HW_REG_HW_ID
+    att_st[att_ns++] = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);         // [3] = HW_REG_XCC_ID
+  }
+#endif
   const int nqb = (S + ATT_QB - 1) / ATT_QB;
   const int nblk = (nqb - qb_first) < qpw ? (nqb - qb_first) : qpw;
 
@@ -277,6 +296,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
 
   int gt = 0;                                   // tiles consumed so far by this workgroup: tile g lives in stage g & 1
   ATT_WAIT_VM0();                               // first tile + first Q rows
+  ATT_STAMP();                                  // [4] prologue done
   for (int qi = 0; qi < nblk; ++qi) {
     const int qb = qb_first + qi;
     const int q_row = qb * ATT_QB + wave * 32 + ql;
@@ -299,6 +319,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       if (t > t_first) ATT_WAIT_VM0();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      ATT_STAMP();                              // per tile: past the barrier
       // the eight pieces are issued unconditionally: behind the workgroup's very last tile they re-stage that tile into the idle stage
       // (nobody reads it; the wait in front of the block's output stores covers it) instead of costing a uniform branch per piece
       const int st_t = (t + 1 < ntiles) ? t + 1 : (more ? next_first : t), st_buf = (gt + 1) & 1;
@@ -519,8 +540,10 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
     }
 
     // ---- block seam: the next block's first tile and Q rows (issued one tile ago) are waited for BEFORE this block's stores go out
+    ATT_STAMP();                                // block: tile loop done
     ATT_WAIT_VM0();
     if (more) q_read_half(1);
+    ATT_STAMP();                                // block: seam wait done
 
     // ---- epilogue: lane holds O[q][32db + 8g + 4hi + 0..3] in regs 4g..4g+3 of oacc[db]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);     // (once per block; through v_permlane32_swap like the tile maximum: measured 2 % slower at S >= 2048)
@@ -577,10 +600,15 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
       __builtin_amdgcn_s_waitcnt(0xC07F);                                         // the pieces are in registers before the buffer is reused
       asm volatile("" ::: "memory");
     }
+    ATT_STAMP();                                // block: output stores issued
+#ifdef ATT_TIMING
+    if (qi + 1 == nblk && tid == 0 && att_ns + 1 < att_cap) { att_st[att_ns++] = (uint32_t)__builtin_amdgcn_s_memrealtime(); att_st[att_ns++] = 0xffffffffu; }
+#else
     if (q_row < S && lse != nullptr && hi == 0) {
       if constexpr (VARLEN) lse[(row0 + q_row) * nq + h] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;  // [T, nq]
       else lse[((int64_t)b * nq + h) * S + q_row] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
+#endif
   }
 }
 

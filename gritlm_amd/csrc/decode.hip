@@ -23,13 +23,20 @@ __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
 constexpr int GV_ROWS = GRIT_GV_ROWS;  // weight rows per workgroup; its 4 waves each take a quarter of K (split-K, LDS reduce)
 
 // MODE 0: store, 1: + residual, 2: SwiGLU pairs (rows r, r+16 of the interleaved layout).
-// PRENORM: x is the raw residual stream and the kernel applies MistralRMSNorm on the fly (x_n = bf16(w_ln * bf16(x * rsqrt(mean x^2 + eps))),
-// modeling_mistral_gritlm.py:84-89) -- saves the separate RMSNorm launch of a decode step (a 1-row kernel is pure launch latency).
-template <int NB, int MODE, bool PRENORM>
+// PRENORM 1: x is the raw residual stream and the kernel applies MistralRMSNorm on the fly (x_n = bf16(w_ln * bf16(x * rsqrt(mean x^2 + eps))),
+// modeling_mistral_gritlm.py:84-89) -- saves the separate RMSNorm launch of a decode step (a 1-row kernel is pure launch latency), same bits
+// as the two launches.  Its price: the rounding needs the row's RMS BEFORE the first product, so every wave of every workgroup first reads
+// the whole row again (as much load traffic as the workgroup's weights) and reduces it.
+// PRENORM 2 (round 5, "deferred"): out = rsqrt(mean x^2 + eps) * sum_k W[n,k] (x[k] w_ln[k]) -- the scale is applied to the finished dot
+// product, the sum of squares is accumulated from the x pieces the lane loads for the product anyway (the four waves' split-K quarters
+// cover the row exactly once) and reduced beside it: no second pass over x, no dependency in front of the weight stream.  x_n is never
+// rounded to bf16 (the reference rounds it twice): one rounding fewer than the reference's arithmetic, not the same bits.
+template <int NB, int MODE, int PRENORM>
 __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
                                                    const uint16_t* __restrict__ res, const uint16_t* __restrict__ ln_w, float eps, int B, int N,
                                                    int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr) {
   __shared__ float red[4][GV_ROWS][NB];
+  __shared__ float red_ss[4][NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int unit = blockIdx.x;                                // one unit = GV_ROWS weight rows
   int rows[GV_ROWS];
@@ -64,7 +71,10 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     for (int i = 0; i < GV_ROWS; ++i) wv[i] = wload(i, c0);
   }
   float inv[NB];
-  if (PRENORM) {
+  float ssq[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) ssq[b] = 0.f;
+  if (PRENORM == 1) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float ss = 0.f;
@@ -94,7 +104,21 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       uint4 xv = reinterpret_cast<const uint4*>(x + (int64_t)(b < B ? b : 0) * ldx)[c];
-      if (PRENORM) {
+      if (PRENORM == 2) {
+        const float xf[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
+        const float lf[8] = {bflo(lw.x), bfhi(lw.x), bflo(lw.y), bfhi(lw.y), bflo(lw.z), bfhi(lw.z), bflo(lw.w), bfhi(lw.w)};
+        float xs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssq[b] += xf[e] * xf[e]; xs[e] = xf[e] * lf[e]; }
+#pragma unroll
+        for (int i = 0; i < GV_ROWS; ++i) {
+          const uint4 w = wv[i];
+          acc[i][b] += bflo(w.x) * xs[0] + bfhi(w.x) * xs[1] + bflo(w.y) * xs[2] + bfhi(w.y) * xs[3] + bflo(w.z) * xs[4] + bfhi(w.z) * xs[5] +
+                       bflo(w.w) * xs[6] + bfhi(w.w) * xs[7];
+        }
+        continue;
+      }
+      if (PRENORM == 1) {
         const float s_ = inv[b];
         xv.x = pack2bf(round_bf(bflo(xv.x) * s_) * bflo(lw.x), round_bf(bfhi(xv.x) * s_) * bfhi(lw.x));
         xv.y = pack2bf(round_bf(bflo(xv.y) * s_) * bflo(lw.y), round_bf(bfhi(xv.y) * s_) * bfhi(lw.y));
@@ -112,22 +136,33 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
       const float v = wave_sum(acc[i][b]);
       if (lane == 0) red[wave][i][b] = v;
     }
+  if (PRENORM == 2) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float v = wave_sum(ssq[b]);
+      if (lane == 0) red_ss[wave][b] = v;
+    }
+  }
   __syncthreads();
   // thread t < GV_ROWS*NB finishes output (row i, batch b)
   const int t = threadIdx.x;
+  auto row_scale = [&](int b) -> float {
+    return PRENORM == 2 ? rsqrtf((red_ss[0][b] + red_ss[1][b] + red_ss[2][b] + red_ss[3][b]) / (float)K + eps) : 1.0f;
+  };
   if (MODE == 2) {
     if (t < (GV_ROWS / 2) * NB) {
       const int i = t / NB, b = t - i * NB, p = unit * (GV_ROWS / 2) + i;
       if (p < N / 2 && b < B) {
-        const float g = red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b];
-        const float u = red[0][2 * i + 1][b] + red[1][2 * i + 1][b] + red[2][2 * i + 1][b] + red[3][2 * i + 1][b];
+        const float rs = row_scale(b);
+        const float g = (red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b]) * rs;
+        const float u = (red[0][2 * i + 1][b] + red[1][2 * i + 1][b] + red[2][2 * i + 1][b] + red[3][2 * i + 1][b]) * rs;
         out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_f(round_bf(g))) * round_bf(u));
       }
     }
   } else if (t < GV_ROWS * NB) {
     const int i = t / NB, b = t - i * NB, n = unit * GV_ROWS + i;
     if (n < N && b < B) {
-      float v = red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b];
+      float v = (red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b]) * row_scale(b);
       if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
       out[(int64_t)b * ldo + n] = (uint16_t)f2bf(v);
     }
@@ -450,7 +485,7 @@ __global__ void bump_k(int32_t* v) { v[0] += 1; }
 
 using namespace grit;
 
-template <int MODE, bool PRENORM>
+template <int MODE, int PRENORM>
 static int launch_gemv(const void* x, const void* W, void* out, const void* res, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
                        int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st) {
   const int units = MODE == 2 ? (N / 2 + GV_ROWS / 2 - 1) / (GV_ROWS / 2) : (N + GV_ROWS - 1) / GV_ROWS;
@@ -465,7 +500,7 @@ static int launch_gemv(const void* x, const void* W, void* out, const void* res,
 }
 
 static int gemv_entry(const char* name, const void* x, const void* W, void* out, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
-                      int64_t ldw, int64_t ldo, int epilogue, const void* residual, int64_t ldr, void* stream) {
+                      int64_t ldw, int64_t ldo, int epilogue, const void* residual, int64_t ldr, void* stream, bool deferred = false) {
   if (B == 0) return GRIT_OK;
   GRIT_REQUIRE(x && W && out, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(B > 0 && B <= 8, GRIT_E_UNSUPPORTED, "%s: B=%d rows (1..8; larger batches use grit_gemm_bf16_nt)", name, B);
@@ -475,13 +510,15 @@ static int gemv_entry(const char* name, const void* x, const void* W, void* out,
   const bool pn = ln_w != nullptr;
   switch (epilogue) {
     case GRIT_EPI_STORE: GRIT_REQUIRE(ldo >= N, GRIT_E_BADARG, "%s: ldo < N", name);
-      return pn ? launch_gemv<0, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
-                : launch_gemv<0, false>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+      return pn ? (deferred ? launch_gemv<0, 2>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                            : launch_gemv<0, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st))
+                : launch_gemv<0, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
     case GRIT_EPI_RESIDUAL: GRIT_REQUIRE(residual && ldo >= N && ldr >= N && !pn, GRIT_E_BADARG, "%s: RESIDUAL needs residual, ldo, ldr >= N (no pre-norm)", name);
-      return launch_gemv<1, false>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
+      return launch_gemv<1, 0>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
     case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "%s: SWIGLU needs N %% 32 == 0, ldo >= N/2", name);
-      return pn ? launch_gemv<2, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
-                : launch_gemv<2, false>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+      return pn ? (deferred ? launch_gemv<2, 2>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                            : launch_gemv<2, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st))
+                : launch_gemv<2, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
     default: GRIT_REQUIRE(false, GRIT_E_BADARG, "%s: unknown epilogue %d", name, epilogue);
   }
   return GRIT_OK;
@@ -496,6 +533,13 @@ extern "C" int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, floa
                                       int64_t ldw, int64_t ldo, int epilogue, void* stream) {
   GRIT_REQUIRE(ln_weight, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16: null pointer");
   return gemv_entry("grit_rmsnorm_gemv_bf16", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream);
+}
+
+// the DEFERRED form of the fused norm (PRENORM 2 above): one launch, no second pass over x; x_n is not rounded to bf16
+extern "C" int grit_rmsnorm_gemv_bf16_deferred(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K,
+                                               int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
+  GRIT_REQUIRE(ln_weight, GRIT_E_BADARG, "grit_rmsnorm_gemv_bf16_deferred: null pointer");
+  return gemv_entry("grit_rmsnorm_gemv_bf16_deferred", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream, true);
 }
 
 extern "C" int grit_rope_kv_append(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens, int B,

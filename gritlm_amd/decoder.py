@@ -33,7 +33,10 @@ class MistralDecoder:
         self.use_graph = True
         # which RMSNorms ride inside the following GEMV (grit_rmsnorm_gemv_bf16): "all" (input_layernorm -> q|k|v, post_attention_layernorm
         # -> gate|up, final norm -> lm_head), "qkv" (the MLP's and the final norm get their own launches) or "none"; GRIT_DECODE_FUSE_NORM for A/B runs
-        # (tools/decode_variants.sh).  Same bits in every form: the fused kernel applies the reference's two roundings.
+        # (tools/decode_variants.sh).  Same bits in these three forms: the fused kernel applies the reference's two roundings.
+        # "deferred" / "deferred_mlp": all three norms / the MLP's and the final one ride in the DEFERRED form (grit_rmsnorm_gemv_bf16_deferred:
+        # the row scale multiplies the finished dot products, no second pass over the row; x_n is not rounded to bf16 -- one rounding fewer
+        # than the reference's arithmetic).
         import os
         # Default "qkv" (round 5, tools/decode_variants.sh on one box: all 3.49, qkv 3.25, none 3.32 ms per token): the 7168 workgroups of
         # the gate|up GEMV -- and the 8000 of lm_head -- each re-derive the row's RMS when the norm is fused, which costs more than the
@@ -48,19 +51,22 @@ class MistralDecoder:
         ops.embed_gather(e.embed, st["next"], out=h)
         if h.shape[0] > 2 or self.fuse_norm == "none":
             return self._step_unfused_norm(st)
+        dm = self.fuse_norm in ("deferred", "deferred_mlp")           # MLP / final norm in the deferred form
+        dq = self.fuse_norm == "deferred"                              # q|k|v norm as well
+        fuse_mlp = dm or self.fuse_norm == "all"
         for li, L in enumerate(e.layers):
             ck, cv = st["cache"][li]
-            ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv)                      # input_layernorm + q/k/v projections
+            ops.rmsnorm_gemv(h, L.ln1, eps, L.wqkv, out=qkv, deferred=dq)         # input_layernorm + q/k/v projections
             ops.attn_decode_rope(qkv, st["cos"], st["sin"], ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)   # RoPE + KV append + attention
             ops.gemv(ctx, L.wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
-            if self.fuse_norm == "all":
-                ops.rmsnorm_gemv(h, L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU)   # post_attention_layernorm + gate/up + SwiGLU
+            if fuse_mlp:
+                ops.rmsnorm_gemv(h, L.ln2, eps, L.wgu, out=act, epilogue=EPI_SWIGLU, deferred=dm)   # post_attention_layernorm + gate/up + SwiGLU
             else:
                 ops.rmsnorm(h, L.ln2, eps, out=st["x"])
                 ops.gemv(st["x"], L.wgu, out=act, epilogue=EPI_SWIGLU)
             ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
-        if self.fuse_norm == "all":
-            ops.rmsnorm_gemv(h, e.norm, eps, self.lm_head, out=st["logits"])       # final norm + lm_head
+        if fuse_mlp:
+            ops.rmsnorm_gemv(h, e.norm, eps, self.lm_head, out=st["logits"], deferred=dm)       # final norm + lm_head
         else:
             ops.rmsnorm(h, e.norm, eps, out=st["x"])
             ops.gemv(st["x"], self.lm_head, out=st["logits"])

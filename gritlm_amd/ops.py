@@ -590,15 +590,17 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epil
 
 
 def rmsnorm_gemv(x: torch.Tensor, ln_w: torch.Tensor, eps: float, w: torch.Tensor, out: torch.Tensor | None = None,
-                 epilogue: int = EPI_STORE) -> torch.Tensor:
-    """gemv(rmsnorm(x, ln_w, eps), w) in one launch (decode step)."""
+                 epilogue: int = EPI_STORE, deferred: bool = False) -> torch.Tensor:
+    """gemv(rmsnorm(x, ln_w, eps), w) in one launch (decode step).  ``deferred``: the row scale multiplies the finished dot products
+    (no pass over x in front of the weight stream; x_n is not rounded to bf16: not the bits of the two launches)."""
     B, K = x.shape
     N = w.shape[0]
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out is None:
         out = torch.empty((B, n_out), dtype=BF16, device=x.device)
-    check(_lib.load().grit_rmsnorm_gemv_bf16(_chk2d(x, BF16, "x"), _chk(ln_w, BF16, "ln_w"), float(eps), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"),
-                                             B, N, K, x.stride(0), w.stride(0), out.stride(0), epilogue, _stream()), "grit_rmsnorm_gemv_bf16")
+    fn = _lib.load().grit_rmsnorm_gemv_bf16_deferred if deferred else _lib.load().grit_rmsnorm_gemv_bf16
+    check(fn(_chk2d(x, BF16, "x"), _chk(ln_w, BF16, "ln_w"), float(eps), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"),
+             B, N, K, x.stride(0), w.stride(0), out.stride(0), epilogue, _stream()), "grit_rmsnorm_gemv_bf16")
     return out
 
 

@@ -380,6 +380,12 @@ int grit_gemv_bf16(const void* x, const void* W, void* out, int B, int N, int K,
  * separate 1-row RMSNorm launch of a decode step.  Epilogues STORE and SWIGLU. */
 int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K,
                            int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
+/* The DEFERRED form: out = rsqrt(mean x^2 + eps) * (W (x * ln_weight)) -- the scale multiplies the finished dot products and the sum of
+ * squares is reduced beside them from the x pieces the product loads anyway, so nothing waits in front of the weight stream (the exact
+ * form above has to know the row's RMS before its first product).  x_n is never rounded to bf16 (the reference rounds it twice, :84-89):
+ * one rounding FEWER than the reference's arithmetic, not the same bits as RMSNorm followed by the GEMV.  Same arguments. */
+int grit_rmsnorm_gemv_bf16_deferred(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K,
+                                    int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
 /* RoPE (:138-163) of the new token's q and k at position lens[b] + append of its k, v to the cache, one launch: q is rotated in place in
  * qkv [B, qkv_stride]; cos/sin tables [Lmax, d/2] fp32 as grit_rope_qk_inplace. */
 int grit_rope_kv_append(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens, int B,

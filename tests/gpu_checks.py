@@ -2507,6 +2507,35 @@ def check_decode_fused_ops(B=2, H=512, N=768, nq=4, nkv=2, Lmax=256):
     return _res("decode fused ops (rmsnorm+gemv, rope+kv-append, rope+append+attention) == unfused kernels", ok)
 
 
+def check_decode_deferred_norm(B=2, H=4096, N=1024):
+    """grit_rmsnorm_gemv_bf16_deferred: out = rsqrt(mean x^2 + eps) * (W (x * w_ln)) against the same expression in fp64 -- the only
+    rounding is the bf16 output (2^-9 relative), the sum of squares is complete (every split-K quarter contributed), for 1 / 2 / 3 / 8 rows
+    and for the SwiGLU epilogue; and it stays within the bf16 noise of the exact fused form (which rounds x_n twice)."""
+    ok, det = True, {}
+    lnw, w = bf(1.0 + 0.1 * rnd((H,), 192)), bf(rnd((N, H), 193, 0.05))
+    wi = swiglu_interleave(w[:N // 2], w[N // 2:])
+    for Bi in (1, 2, 3, 8)[:4 if B >= 2 else 1]:
+        x = bf(3.0 * rnd((Bi, H), 191 + Bi))
+        xd, ld, wd = x.double(), lnw.double(), w.double()
+        inv = torch.rsqrt((xd * xd).mean(dim=1, keepdim=True) + 1e-5)
+        ref = ((xd * ld) @ wd.T) * inv
+        got = ops.rmsnorm_gemv(x, lnw, 1e-5, w, deferred=True).double()
+        scale = float(ref.pow(2).mean().sqrt())
+        e = float(((got - ref).abs() / (2.0 ** -8 * ref.abs() + 1e-3 * scale)).max())
+        exact = ops.rmsnorm_gemv(x, lnw, 1e-5, w).double()
+        e_exact = float(((exact - ref).abs() / (2.0 ** -8 * ref.abs() + 1e-3 * scale)).max())
+        d_forms = float((got - exact).norm() / exact.norm())
+        g, u = ref[:, :N // 2].float(), ref[:, N // 2:].float()
+        rb = lambda t: t.to(torch.bfloat16).float()
+        ref_sw = (rb(torch.nn.functional.silu(rb(g))) * rb(u)).double()
+        got_sw = ops.rmsnorm_gemv(x, lnw, 1e-5, wi, epilogue=EPI_SWIGLU, deferred=True).double()
+        sc_sw = float(ref_sw.pow(2).mean().sqrt())
+        e_sw = float(((got_sw - ref_sw).abs() / (2.0 ** -6 * ref_sw.abs() + 1e-2 * sc_sw)).max())
+        det[f"B{Bi}"] = dict(err_over_tol=e, exact_form_err_over_tol=e_exact, rel_diff_to_exact_form=d_forms, swiglu_err_over_tol=e_sw)
+        ok &= e < 1.0 and e_sw < 1.0 and d_forms < 1e-2 and bool(torch.isfinite(got).all())
+    return _res("deferred rmsnorm+gemv == rsqrt(mean x^2) * W (x * w_ln) in fp64 up to the output rounding", ok, **det)
+
+
 def check_attn_decode(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
     d = 128
     rng = np.random.default_rng(87)
@@ -3190,6 +3219,7 @@ ALL_CHECKS = [
     ("gemv_b8_residual", check_gemv, dict(B=8, N=515, K=1024, epi=EPI_RESIDUAL)),
     ("gemv_swiglu", check_gemv, dict(B=2, N=1024, K=256, epi=EPI_SWIGLU)),
     ("decode_fused_ops", check_decode_fused_ops, {}),
+    ("decode_deferred_norm", check_decode_deferred_norm, {}),
     ("attn_decode", check_attn_decode, {}),
     ("attn_decode_gqa4_b1", check_attn_decode, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
     ("native_generate", check_native_generate, {}),
