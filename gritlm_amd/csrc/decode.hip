@@ -31,28 +31,28 @@ constexpr int GV_ROWS = GRIT_GV_ROWS;  // weight rows per workgroup; its 4 waves
 // product, the sum of squares is accumulated from the x pieces the lane loads for the product anyway (the four waves' split-K quarters
 // cover the row exactly once) and reduced beside it: no second pass over x, no dependency in front of the weight stream.  x_n is never
 // rounded to bf16 (the reference rounds it twice): one rounding fewer than the reference's arithmetic, not the same bits.
-template <int NB, int MODE, int PRENORM>
+template <int NB, int MODE, int PRENORM, int R>
 __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
                                                    const uint16_t* __restrict__ res, const uint16_t* __restrict__ ln_w, float eps, int B, int N,
                                                    int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr) {
-  __shared__ float red[4][GV_ROWS][NB];
+  __shared__ float red[4][R][NB];
   __shared__ float red_ss[4][NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x;                                // one unit = GV_ROWS weight rows
-  int rows[GV_ROWS];
+  const int unit = blockIdx.x;                                // one unit = R weight rows
+  int rows[R];
   if (MODE == 2) {
-    // unit covers GV_ROWS/2 (gate, up) pairs: pair p -> gate row (p/16)*32 + p%16, up row = gate row + 16
-    const int p0 = unit * (GV_ROWS / 2);
+    // unit covers R/2 (gate, up) pairs: pair p -> gate row (p/16)*32 + p%16, up row = gate row + 16
+    const int p0 = unit * (R / 2);
 #pragma unroll
-    for (int i = 0; i < GV_ROWS / 2; ++i) {
+    for (int i = 0; i < R / 2; ++i) {
       int p = p0 + i; if (p > N / 2 - 1) p = N / 2 - 1;
       rows[2 * i] = (p >> 4) * 32 + (p & 15);
       rows[2 * i + 1] = rows[2 * i] + 16;
     }
   } else {
-    const int r0 = unit * GV_ROWS;
+    const int r0 = unit * R;
 #pragma unroll
-    for (int i = 0; i < GV_ROWS; ++i) rows[i] = r0 + i < N ? r0 + i : N - 1;
+    for (int i = 0; i < R; ++i) rows[i] = r0 + i < N ? r0 + i : N - 1;
   }
   const int KC = K >> 3;
   // The weights are streamed ONCE per token and shared with nobody: non-temporal loads (no L2 / Infinity Cache allocation that would only
@@ -65,10 +65,10 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
   const int c0 = wave * 64 + lane;
-  uint4 wv[GV_ROWS];
+  uint4 wv[R];
   if (c0 < KC) {
 #pragma unroll
-    for (int i = 0; i < GV_ROWS; ++i) wv[i] = wload(i, c0);
+    for (int i = 0; i < R; ++i) wv[i] = wload(i, c0);
   }
   float inv[NB];
   float ssq[NB];
@@ -87,9 +87,9 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
       inv[b] = rsqrtf(wave_sum(ss) / (float)K + eps);
     }
   }
-  float acc[GV_ROWS][NB];
+  float acc[R][NB];
 #pragma unroll
-  for (int i = 0; i < GV_ROWS; ++i)
+  for (int i = 0; i < R; ++i)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
   for (int c = c0; c < KC; c += 256) {
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     //  measured 8 % SLOWER at the 7B shape: 16 more registers per lane, fewer workgroups in flight; profiles/r03_decode_ab.log)
     if (c != c0) {
 #pragma unroll
-      for (int i = 0; i < GV_ROWS; ++i) wv[i] = wload(i, c);
+      for (int i = 0; i < R; ++i) wv[i] = wload(i, c);
     }
     uint4 lw = make_uint4(0, 0, 0, 0);
     if (PRENORM) lw = reinterpret_cast<const uint4*>(ln_w)[c];
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ssq[b] += xf[e] * xf[e]; xs[e] = xf[e] * lf[e]; }
 #pragma unroll
-        for (int i = 0; i < GV_ROWS; ++i) {
+        for (int i = 0; i < R; ++i) {
           const uint4 w = wv[i];
           acc[i][b] += bflo(w.x) * xs[0] + bfhi(w.x) * xs[1] + bflo(w.y) * xs[2] + bfhi(w.y) * xs[3] + bflo(w.z) * xs[4] + bfhi(w.z) * xs[5] +
                        bflo(w.w) * xs[6] + bfhi(w.w) * xs[7];
@@ -126,11 +126,11 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
         xv.w = pack2bf(round_bf(bflo(xv.w) * s_) * bflo(lw.w), round_bf(bfhi(xv.w) * s_) * bfhi(lw.w));
       }
 #pragma unroll
-      for (int i = 0; i < GV_ROWS; ++i) acc[i][b] += dot8(wv[i], xv);
+      for (int i = 0; i < R; ++i) acc[i][b] += dot8(wv[i], xv);
     }
   }
 #pragma unroll
-  for (int i = 0; i < GV_ROWS; ++i)
+  for (int i = 0; i < R; ++i)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float v = wave_sum(acc[i][b]);
@@ -144,14 +144,14 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     }
   }
   __syncthreads();
-  // thread t < GV_ROWS*NB finishes output (row i, batch b)
+  // thread t < R*NB finishes output (row i, batch b)
   const int t = threadIdx.x;
   auto row_scale = [&](int b) -> float {
     return PRENORM == 2 ? rsqrtf((red_ss[0][b] + red_ss[1][b] + red_ss[2][b] + red_ss[3][b]) / (float)K + eps) : 1.0f;
   };
   if (MODE == 2) {
-    if (t < (GV_ROWS / 2) * NB) {
-      const int i = t / NB, b = t - i * NB, p = unit * (GV_ROWS / 2) + i;
+    if (t < (R / 2) * NB) {
+      const int i = t / NB, b = t - i * NB, p = unit * (R / 2) + i;
       if (p < N / 2 && b < B) {
         const float rs = row_scale(b);
         const float g = (red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b]) * rs;
@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
         out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_f(round_bf(g))) * round_bf(u));
       }
     }
-  } else if (t < GV_ROWS * NB) {
-    const int i = t / NB, b = t - i * NB, n = unit * GV_ROWS + i;
+  } else if (t < R * NB) {
+    const int i = t / NB, b = t - i * NB, n = unit * R + i;
     if (n < N && b < B) {
       float v = (red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b]) * row_scale(b);
       if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
@@ -485,13 +485,13 @@ __global__ void bump_k(int32_t* v) { v[0] += 1; }
 
 using namespace grit;
 
-template <int MODE, int PRENORM>
+template <int MODE, int PRENORM, int R = GV_ROWS>
 static int launch_gemv(const void* x, const void* W, void* out, const void* res, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
                        int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st) {
-  const int units = MODE == 2 ? (N / 2 + GV_ROWS / 2 - 1) / (GV_ROWS / 2) : (N + GV_ROWS - 1) / GV_ROWS;
+  const int units = MODE == 2 ? (N / 2 + R / 2 - 1) / (R / 2) : (N + R - 1) / R;
   const dim3 grid((unsigned)units);
 #define GRIT_GEMV(NB_)                                                                                                                    \
-  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out,   \
+  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM, R>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out,   \
                      (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr)
   if (B == 1) GRIT_GEMV(1); else if (B == 2) GRIT_GEMV(2); else if (B <= 4) GRIT_GEMV(4); else GRIT_GEMV(8);
 #undef GRIT_GEMV
@@ -514,7 +514,14 @@ static int gemv_entry(const char* name, const void* x, const void* W, void* out,
                             : launch_gemv<0, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st))
                 : launch_gemv<0, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
     case GRIT_EPI_RESIDUAL: GRIT_REQUIRE(residual && ldo >= N && ldr >= N && !pn, GRIT_E_BADARG, "%s: RESIDUAL needs residual, ldo, ldr >= N (no pre-norm)", name);
-      return launch_gemv<1, 0>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
+      {
+        // rows per workgroup of the residual GEMVs (o_proj, down: N = 4096 -> 1024 workgroups of 4 rows are half a workgroup wave of the
+        // chip); GRIT_GV_ROWS_RES = 1 / 2 / 4 is the A/B knob (tools/decode_rows_ab.sh)
+        static const int rows_res = getenv("GRIT_GV_ROWS_RES") ? atoi(getenv("GRIT_GV_ROWS_RES")) : GV_ROWS;
+        if (rows_res == 2 && B <= 2) return launch_gemv<1, 0, 2>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
+        if (rows_res == 1 && B <= 2) return launch_gemv<1, 0, 1>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
+        return launch_gemv<1, 0>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
+      }
     case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "%s: SWIGLU needs N %% 32 == 0, ldo >= N/2", name);
       return pn ? (deferred ? launch_gemv<2, 2>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
                             : launch_gemv<2, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st))

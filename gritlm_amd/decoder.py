@@ -38,10 +38,11 @@ class MistralDecoder:
         # the row scale multiplies the finished dot products, no second pass over the row; x_n is not rounded to bf16 -- one rounding fewer
         # than the reference's arithmetic).
         import os
-        # Default "qkv" (round 5, tools/decode_variants.sh on one box: all 3.49, qkv 3.25, none 3.32 ms per token): the 7168 workgroups of
+        # The exact forms (round 5, tools/decode_variants.sh on one box: all 3.49, qkv 3.25, none 3.32 ms per token): the 7168 workgroups of
         # the gate|up GEMV -- and the 8000 of lm_head -- each re-derive the row's RMS when the norm is fused, which costs more than the
         # one-row launch it saves; the q|k|v GEMV is a single workgroup wave deep and keeps the fusion.
-        self.fuse_norm = os.environ.get("GRIT_DECODE_FUSE_NORM", "qkv")
+        # Default "deferred" (tools/decode_norm_ab.sh, one box: qkv 3.149, deferred_mlp 3.014, deferred 2.904, all 3.410 ms per token).
+        self.fuse_norm = os.environ.get("GRIT_DECODE_FUSE_NORM", "deferred")
 
     # ------------------------------------------------------------------ one decode step (all sizes static, lengths on the device)
     def _step(self, st):
