@@ -514,14 +514,10 @@ static int gemv_entry(const char* name, const void* x, const void* W, void* out,
                             : launch_gemv<0, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st))
                 : launch_gemv<0, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
     case GRIT_EPI_RESIDUAL: GRIT_REQUIRE(residual && ldo >= N && ldr >= N && !pn, GRIT_E_BADARG, "%s: RESIDUAL needs residual, ldo, ldr >= N (no pre-norm)", name);
-      {
-        // rows per workgroup of the residual GEMVs (o_proj, down: N = 4096 -> 1024 workgroups of 4 rows are half a workgroup wave of the
-        // chip); GRIT_GV_ROWS_RES = 1 / 2 / 4 is the A/B knob (tools/decode_rows_ab.sh)
-        static const int rows_res = getenv("GRIT_GV_ROWS_RES") ? atoi(getenv("GRIT_GV_ROWS_RES")) : GV_ROWS;
-        if (rows_res == 2 && B <= 2) return launch_gemv<1, 0, 2>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
-        if (rows_res == 1 && B <= 2) return launch_gemv<1, 0, 1>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
-        return launch_gemv<1, 0>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
-      }
+      // (rows per workgroup of these launches -- o_proj, down: N = 4096 -> 1024 workgroups of 4 rows, half a workgroup wave -- and the
+      //  number of K-loop pieces a lane keeps in flight were A/B'd on one box: 1 / 2 / 4 rows 2.914 / 2.902 / 2.903 ms per token; 2 / 4
+      //  pieces in flight 2.963 / 3.139 against 2.921 -- more requests in flight are SLOWER; profiles/r05_decode_{rows,unroll}_ab.log)
+      return launch_gemv<1, 0>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st);
     case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "%s: SWIGLU needs N %% 32 == 0, ldo >= N/2", name);
       return pn ? (deferred ? launch_gemv<2, 2>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
                             : launch_gemv<2, 1>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st))
