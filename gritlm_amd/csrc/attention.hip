@@ -44,29 +44,16 @@
 #ifndef ATT_DEFER_MAX
 #define ATT_DEFER_MAX 1
 #endif
-// ATT_PRIO_MODE (A/B knob, tools/attn_prio_variants.sh): how the two co-resident workgroups of a CU (one wave each per SIMD) are
-// arbitrated.  0 = both raise s_setprio over their QK section (round 3).  1..5 = STATIC ASYMMETRY: the wave in the odd slot of its SIMD
-// (HW_ID.WAVE_ID & 1; 4: HW_ID.TG_ID & 1; 5: (blockIdx >> 8) & 1) runs the whole kernel at a higher priority than its neighbour, so that
-// the neighbour is pushed into the complementary phase (its matrix section under this wave's softmax) instead of the two walking in step.
-#ifndef ATT_PRIO_MODE
-#define ATT_PRIO_MODE 0
-#endif
-// ATT_TIMING (diagnostic build, tools/attn_phase_probe.py): thread 0 of every workgroup writes s_memtime stamps (cycles since kernel entry) as
-// raw u32 into the workgroup's LSE rows instead of the LSE -- where a workgroup's time goes between prologue, tiles, seams and stores.
+// ATT_TIMING (diagnostic build, tools/attn_phase_probe.sh): thread 0 of every workgroup writes s_memtime stamps (cycles since kernel entry) as
+// raw u32 into the workgroup's LSE rows instead of the LSE -- where a workgroup's time goes between prologue, tiles, seams and stores
+// (profiles/r05_attn_phase_probe.json).  Three scheduling experiments built on that picture were measured and did NOT ship
+// (profiles/r05_attn_{prio,hpw}_ab.log; the variants are in git history, commits "ATT_PRIO_MODE" / "heads per workgroup"): a static
+// s_setprio asymmetry between the two co-resident workgroups (+-1 %), 2 / 4 heads of a kv group per workgroup (-2 % / -12 %), and
+// dropping the two lgkmcnt(0) of the output transposition (0 %).
 #ifdef ATT_TIMING
 #define ATT_STAMP() do { if (tid == 0 && att_ns < att_cap) { att_st[att_ns] = (uint32_t)(__builtin_readcyclecounter() - att_t0); ++att_ns; } } while (0)
 #else
 #define ATT_STAMP() do { } while (0)
-#endif
-#if ATT_PRIO_MODE == 0
-#define ATT_PRIO_QK_ENTER() __builtin_amdgcn_s_setprio(1)
-#define ATT_PRIO_QK_LEAVE() __builtin_amdgcn_s_setprio(0)
-#elif ATT_PRIO_MODE == 2      /* asymmetric base (0 / 2) + the QK raise on top of it */
-#define ATT_PRIO_QK_ENTER() do { if (att_hp) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); } while (0)
-#define ATT_PRIO_QK_LEAVE() do { if (att_hp) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); } while (0)
-#else                          /* 1, 3, 4, 5: no per-section flips */
-#define ATT_PRIO_QK_ENTER() do { } while (0)
-#define ATT_PRIO_QK_LEAVE() do { } while (0)
 #endif
 // (ATT_DEFER_MAX and ATT_ABLATE_STORES are the A/B knobs of tools/ubench/attn_ab.cpp.  The levers of round 3 -- asm reads, spread /
 //  buffer-addressed / unconditional DMA pieces, early V reads, s_setprio over QK, xor K addresses, hoisted mask word, permlane row
@@ -117,16 +104,6 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   typedef typename att_frag<F16>::type frag_t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if ATT_PRIO_MODE == 1 || ATT_PRIO_MODE == 2
-  const bool att_hp = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0;       // HW_REG_HW_ID.WAVE_ID[0]
-#elif ATT_PRIO_MODE == 4
-  const bool att_hp = (__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1) != 0;      // HW_REG_HW_ID.TG_ID[0]
-#elif ATT_PRIO_MODE == 5
-  const bool att_hp = (((int)blockIdx.x >> 8) & 1) != 0;
-#endif
-#if ATT_PRIO_MODE == 1 || ATT_PRIO_MODE == 2 || ATT_PRIO_MODE == 4 || ATT_PRIO_MODE == 5
-  if (att_hp) __builtin_amdgcn_s_setprio(2);
-#endif
   // XCD-aware decode: the k-th workgroup of XCD x belongs to K/V set (k / U) * 8 + x, U = (heads per kv head) x (query-block groups)
   const int gqa = nq / nkv, U = gqa * ngx;
   const int kx = (int)blockIdx.x >> 3;
@@ -381,7 +358,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
   } while (0)
         // K fragments two k-slices ahead of their products (three ahead: no gain); one LDS-DMA piece of the next tile behind every
         // product pair; s_setprio 1 over the section: 0 .. +2 % (over the PV section as well: -1.5 %)
-        ATT_PRIO_QK_ENTER();
+        __builtin_amdgcn_s_setprio(1);
         ATT_K_READ(0); ATT_K_READ(1);
         ATT_K_READ(2); ATT_K_MMA(0, 4);
         ATT_K_READ(3); ATT_K_MMA(1, 4);
@@ -390,7 +367,7 @@ attn_bidir_fwd_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ 
         ATT_K_READ(6); ATT_K_MMA(4, 4);
         ATT_K_READ(7); ATT_K_MMA(5, 4);
         ATT_K_MMA(6, 2); ATT_K_MMA(7, 0);
-        ATT_PRIO_QK_LEAVE();
+        __builtin_amdgcn_s_setprio(0);
 #undef ATT_K_READ
 #undef ATT_K_MMA
       }
