@@ -266,24 +266,34 @@ __device__ __forceinline__ void wave_allreduce(float (&v)[NG]) {
 // `if (g >= G) break`, the compiler could neither unroll nor interleave the heads' dot products and reductions, and the one wave of a
 // workgroup executed them back to back -- the kernel was bound by its own dependent-instruction chains (11.4 us per layer at L = 2 k
 // for 32 KB of K / V per workgroup), not by memory.
-template <bool ROPE, int G>
+// PH ("per head", G = 1): one workgroup per QUERY head instead of per kv head -- blockIdx.y is the query head, the gq heads of a kv group
+// are gq workgroups that read the same K / V slice (the duplicates hit L2) and each does a quarter of the arithmetic: the kernel is one
+// wave deep and bound by its own instruction stream (a slice of 64 keys x 4 heads is ~2000 dependent-free FMAs per lane), not by the
+// 32 KB it reads.  Every one of them rotates the new key itself; they write identical cache rows.
+template <bool ROPE, int G, bool PH = false>
 __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__ q, uint16_t* __restrict__ ck, uint16_t* __restrict__ cv,
                                                     const int32_t* __restrict__ lens, float* __restrict__ part, const float* __restrict__ cos_tab,
                                                     const float* __restrict__ sin_tab, int nq, int nkv, int Lmax, int64_t q_stride, float scale,
                                                     int max_splits) {
   __shared__ __attribute__((aligned(16))) float qs[G][AD_D];   // query heads of this kv head, pre-scaled
   __shared__ float ps[G][64];                                  // probabilities of the 64 keys
-  const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  __shared__ __attribute__((aligned(16))) uint16_t newk[AD_D]; // ROPE, owner workgroup: the new key (rotated) and value rows, handed to the
+  __shared__ __attribute__((aligned(16))) uint32_t newv[AD_D / 2];   // lanes that hold them in the K / V register layouts
+  const int gq = PH ? nq / nkv : G;                       // query heads per kv head in the q row / the partials' layout
+  const int split = blockIdx.x, hk = PH ? (int)blockIdx.y / gq : (int)blockIdx.y, b = blockIdx.z;
+  const int g0 = PH ? (int)blockIdx.y - hk * gq : 0;      // this workgroup's first (PH: only) head inside the group
   const int lane = threadIdx.x;
   const int L = lens[b] + 1;                 // keys 0 .. lens[b] (the new token was appended)
   const int k0 = split * AD_CH;
-  float* pbase = part + (((int64_t)b * nkv + hk) * max_splits + split) * G * (AD_D + 2);
+  float* pbase = part + ((((int64_t)b * nkv + hk) * max_splits + split) * gq + g0) * (AD_D + 2);
   if (k0 >= L) {                             // empty split: neutral element
     for (int i = lane; i < G * (AD_D + 2); i += 64) pbase[i] = (i % (AD_D + 2) == 0) ? -INFINITY : 0.f;
     return;
   }
   // The slice's K and V rows are requested FIRST: 32 independent 16-byte loads per lane go out before the query heads are fetched,
-  // rotated and staged.  The one workgroup whose slice receives the NEW key appends it first and loads afterwards.
+  // rotated and staged -- also in the one workgroup whose slice receives the NEW key (round 5: it used to append first and load
+  // afterwards, two memory latencies in a row on the kernel's critical path): its loads of the new key's cache row return whatever the
+  // slot held, and the rotated k / the v row replace those registers through LDS after the barrier.
   const int key = k0 + lane;
   const bool live = key < L;
   const int kg = lane >> 4, dc = lane & 15;                  // PV layout: key group kg (16 keys), dim chunk dc (8 dims)
@@ -301,7 +311,7 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     }
   };
   const bool owner = ROPE && (L - 1 >= k0) && (L - 1 < k0 + AD_CH);      // workgroup-uniform
-  if (!owner) load_kv();
+  load_kv();
   if constexpr (ROPE) {
     const int pos = L - 1;
     const float c = cos_tab[(int64_t)pos * 64 + lane], sn = sin_tab[(int64_t)pos * 64 + lane];     // lane <-> pair (e, e + 64)
@@ -309,7 +319,7 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     float x1[G], x2[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {                             // all 2 G loads in flight before the first use
-      x1[g] = bf2f(row[(int64_t)(hk * G + g) * AD_D + lane]); x2[g] = bf2f(row[(int64_t)(hk * G + g) * AD_D + 64 + lane]);
+      x1[g] = bf2f(row[(int64_t)(hk * gq + g0 + g) * AD_D + lane]); x2[g] = bf2f(row[(int64_t)(hk * gq + g0 + g) * AD_D + 64 + lane]);
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -323,17 +333,29 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
       const uint32_t r = pack2bf(rope_lo(y1, y2, c, sn), rope_hi(y1, y2, c, sn));
       uint16_t* kd = ck + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D;
       kd[lane] = (uint16_t)(r & 0xffff); kd[64 + lane] = (uint16_t)(r >> 16);
-      reinterpret_cast<uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D)[lane] = reinterpret_cast<const uint32_t*>(vr)[lane];
-      __threadfence_block();
+      const uint32_t vw = reinterpret_cast<const uint32_t*>(vr)[lane];
+      reinterpret_cast<uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D)[lane] = vw;
+      newk[lane] = (uint16_t)(r & 0xffff); newk[64 + lane] = (uint16_t)(r >> 16);
+      newv[lane] = vw;
     }
   } else {
     for (int i = lane; i < G * AD_D; i += 64) {
       const int g = i / AD_D, e = i - g * AD_D;
-      qs[g][e] = bf2f(q[(int64_t)b * q_stride + (int64_t)(hk * G + g) * AD_D + e]) * scale;
+      qs[g][e] = bf2f(q[(int64_t)b * q_stride + (int64_t)(hk * gq + g0 + g) * AD_D + e]) * scale;
     }
   }
   __syncthreads();
-  if (owner) load_kv();                                        // (behind the append + fence above)
+  if (owner) {                                                 // the new key's rows, from LDS into the register layouts
+    const int lk = L - 1 - k0;                                 // its index in the slice
+    if (lane == lk) {
+#pragma unroll
+      for (int c = 0; c < AD_D / 8; ++c) kreg[c] = reinterpret_cast<const uint4*>(newk)[c];
+    }
+    const uint4 nv = reinterpret_cast<const uint4*>(newv)[dc];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)                               // the new key is the slice's last one: every clamped row index (keys past
+      if (kg * 16 + j >= lk) vreg[j] = nv;                     // the sequence, probability 0) pointed at its slot as well
+  }
   float s[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) s[g] = 0.f;
@@ -588,6 +610,18 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
   const int splits = (Lmax + AD_CH - 1) / AD_CH;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)splits, (unsigned)nkv, (unsigned)B);
+  // one workgroup per query head (PH above) for GQA models: 8.74 -> 7.52 us per launch at L = 2 k, 32 / 8 heads (kernel trace,
+  // profiles/r05_decode_kernel_stats_perhead.csv); GRIT_ATTN_DECODE_PER_HEAD=0 is the A/B knob
+  static const int per_head = getenv("GRIT_ATTN_DECODE_PER_HEAD") ? atoi(getenv("GRIT_ATTN_DECODE_PER_HEAD")) : 1;
+  if (per_head && nq / nkv > 1) {
+    const dim3 gridh((unsigned)splits, (unsigned)nq, (unsigned)B);
+    if (cos_tab)
+      hipLaunchKernelGGL((attn_decode_k<true, 1, true>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
+                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits);
+    else
+      hipLaunchKernelGGL((attn_decode_k<false, 1, true>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
+                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits);
+  } else {
 #define GRIT_AD_LAUNCH(R, GG)                                                                                                           \
   hipLaunchKernelGGL((attn_decode_k<R, GG>), grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace, \
                      cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits)
@@ -602,6 +636,7 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
   if (cos_tab) { GRIT_AD_BY_G(true) } else { GRIT_AD_BY_G(false) }
 #undef GRIT_AD_BY_G
 #undef GRIT_AD_LAUNCH
+  }
   GRIT_CHECK_LAUNCH(name);
   hipLaunchKernelGGL(attn_decode_combine_k, dim3((unsigned)nq, (unsigned)B), dim3(AD_D), 0, st, (const float*)workspace, (uint16_t*)out, nq, nkv,
                      splits, out_stride);

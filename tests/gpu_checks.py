@@ -2496,6 +2496,8 @@ def check_decode_fused_ops(B=2, H=512, N=768, nq=4, nkv=2, Lmax=256):
     ok &= bool(torch.equal(q1[:, :nq * d], q2[:, :nq * d])) and bool(torch.equal(ck1, ck2)) and bool(torch.equal(cv1, cv2)) and float(ck1.abs().sum()) > 0
     # attention with RoPE + append folded in == rope_kv_append followed by attn_decode, bit for bit (caches included)
     ck3, cv3 = bf(rnd((B, nkv, Lmax, d), 95)), bf(rnd((B, nkv, Lmax, d), 96))
+    for bi in range(B):            # everything from the new token's slot on is NaN: the fused kernel requests its K / V rows before it
+        ck3[bi, :, int(lens[bi]):] = float("nan"); cv3[bi, :, int(lens[bi]):] = float("nan")     # appends -- nothing stale may leak
     ck4, cv4 = ck3.clone(), cv3.clone()
     qa, qb = qkv.clone(), qkv.clone()
     ws = ops.attn_decode_workspace(B, nq, nkv, Lmax, DEV)
@@ -2503,7 +2505,9 @@ def check_decode_fused_ops(B=2, H=512, N=768, nq=4, nkv=2, Lmax=256):
     ops.rope_kv_append(qa, cos, sin, ck3, cv3, lens, nq, nkv, d)
     ops.attn_decode(qa, ck3, cv3, lens, o3, ws, nq, nkv, d)
     ops.attn_decode_rope(qb, cos, sin, ck4, cv4, lens, o4, ws, nq, nkv, d)
-    ok &= bool(torch.equal(o3, o4)) and bool(torch.equal(ck3, ck4)) and bool(torch.equal(cv3, cv4))
+    nn = torch.nan_to_num
+    ok &= bool(torch.equal(o3, o4)) and bool(torch.isfinite(o4.float()).all()) and bool(torch.equal(nn(ck3), nn(ck4))) and bool(torch.equal(nn(cv3), nn(cv4)))
+    ok &= all(bool(torch.isfinite(ck4[bi, :, :int(lens[bi]) + 1].float()).all()) for bi in range(B))
     return _res("decode fused ops (rmsnorm+gemv, rope+kv-append, rope+append+attention) == unfused kernels", ok)
 
 
