@@ -2,6 +2,8 @@
 all arithmetic happens in libgritlm_hip.so.  Every function launches on torch's current HIP stream."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -58,6 +60,7 @@ class KernelTimer:
 
 
 _timer: KernelTimer | None = None
+_TAG_M = bool(os.environ.get("GRIT_TIMER_TAG_M"))          # tools/contrastive_shapes.py: the GEMM tags carry M as well (forward / dgrad / wgrad shapes apart)
 
 
 def set_timer(t: KernelTimer | None):
@@ -243,7 +246,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
         assert residual is not None and residual.shape == (M, 2 * N if epilogue == EPI_SWIGLU_BWD else N)
         rp, ldr = _chk2d(residual, odt, "residual"), residual.stride(0)
     name = "gemm_f16_nt" if opd == F16 else "gemm_bf16_nt"
-    ev = _timer.span(name, 2.0 * M * N * K, tag=f"N={N},K={K},epi={epilogue}") if _timer is not None else None
+    ev = _timer.span(name, 2.0 * M * N * K, tag=(f"M={M}," if _TAG_M else "") + f"N={N},K={K},epi={epilogue}") if _timer is not None else None
     if ev:
         ev[0].record()
     check(getattr(_lib.load(), "grit_" + name)(_chk2d(a, opd, "a"), _chk2d(w, opd, "w"), _chk2d(out, odt, "out"), M, N, K, a.stride(0),
@@ -261,7 +264,7 @@ def gemm_nt_pair(a1: torch.Tensor, w1: torch.Tensor, out1: torch.Tensor, a2: tor
     N1, N2 = w1.shape[0], w2.shape[0]
     assert K == K2 == w1.shape[1] == w2.shape[1] and out1.shape == (M1, N1) and out2.shape == (M2, N2)
     epi = EPI_RESIDUAL if accumulate else EPI_STORE
-    ev = _timer.span("gemm_bf16_nt", 2.0 * (M1 * N1 + M2 * N2) * K, tag=f"pair N={N1}+{N2},K={K},epi={epi}") if _timer is not None else None
+    ev = _timer.span("gemm_bf16_nt", 2.0 * (M1 * N1 + M2 * N2) * K, tag=(f"M={M1}+{M2}," if _TAG_M else "") + f"pair N={N1}+{N2},K={K},epi={epi}") if _timer is not None else None
     if ev:
         ev[0].record()
     o1, o2 = _chk2d(out1, BF16, "out1"), _chk2d(out2, BF16, "out2")
@@ -284,7 +287,7 @@ def gemm_nt_rope(a: torch.Tensor, w: torch.Tensor, cos: torch.Tensor, sin: torch
     if out is None:
         out = torch.empty((M, N), dtype=opd, device=a.device)
     name = "gemm_f16_nt" if opd == F16 else "gemm_bf16_nt"
-    ev = _timer.span(name, 2.0 * M * N * K, tag=f"N={N},K={K},epi=3") if _timer is not None else None
+    ev = _timer.span(name, 2.0 * M * N * K, tag=(f"M={M}," if _TAG_M else "") + f"N={N},K={K},epi=3") if _timer is not None else None
     if ev:
         ev[0].record()
     check(getattr(_lib.load(), "grit_" + name + "_rope")(_chk2d(a, opd, "a"), _chk2d(w, opd, "w"), _chk2d(out, opd, "out"), M, N, K, a.stride(0),
