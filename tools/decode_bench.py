@@ -18,12 +18,15 @@ ap.add_argument("--prefix", type=int, default=2048)
 ap.add_argument("--new", type=int, default=128)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--layers", type=int, default=32)
+ap.add_argument("--no-graph", action="store_true", help="eager launches (rocprofv3 --pmc cannot follow HIP-graph launches)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = EncoderConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=a.layers, num_attention_heads=32, num_key_value_heads=8, vocab_size=32000)
 eng = MistralEncoderEngine.random_init(cfg, dev, seed=0)
 lm_head = (torch.randn((32000, 4096), device=dev) * 0.02).to(torch.bfloat16)
 dec = MistralDecoder(eng, lm_head)
+if a.no_graph:
+    dec.use_graph = False
 g = torch.Generator(device=dev).manual_seed(3)
 doc = torch.randint(3, 32000, (a.batch, a.prefix), generator=g, device=dev)
 _, kv = eng.forward(doc, torch.ones_like(doc), return_kv=True)
