@@ -2561,7 +2561,7 @@ def check_attn_decode(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
     return _res(f"attn_decode[B={B},nq={nq},nkv={nkv},lens={list(lens)}]", worst < 1e-2 and not np.isnan(got).any(), max_abs=worst)
 
 
-def check_native_generate(cfg_name="tiny", P=21, new=10, rows=2, tol=0.06):
+def check_native_generate(cfg_name="tiny", P=21, new=10, rows=2, tol=0.06, fuse_norm=None):
     """Greedy generation on the native decoder: logits of every generated position vs the fp32 oracle run over the same token
     sequence (a) from a plain prompt (causal prefill), (b) on top of the cached K/V of a bidirectionally encoded document (the RAG
     doc-caching flow); tokens agree with the oracle's argmax wherever its top-2 margin is clear; HIP-graph replay == eager launches."""
@@ -2570,7 +2570,9 @@ def check_native_generate(cfg_name="tiny", P=21, new=10, rows=2, tol=0.06):
     rng = np.random.default_rng(97)
     lm = O.bf16_round((rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"])) * 0.05).astype(np.float32))
     dec = MistralDecoder(eng, torch.from_numpy(lm))
-    prompt = rng.integers(3, cfg["vocab_size"], size=(rows, P)).astype(np.int64)      # rows > 2: the un-fused RMSNorm decode step
+    if fuse_norm is not None:      # "none" / "qkv" / "all": the exact forms (rows > 2 then take the un-fused RMSNorm decode step); default: deferred
+        dec.fuse_norm = fuse_norm
+    prompt = rng.integers(3, cfg["vocab_size"], size=(rows, P)).astype(np.int64)
     ok, out = True, {}
 
     def judge(tag, toks, logits, ref_logits):
@@ -3228,6 +3230,7 @@ ALL_CHECKS = [
     ("attn_decode_gqa4_b1", check_attn_decode, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
     ("native_generate", check_native_generate, {}),
     ("native_generate_gqa", check_native_generate, dict(cfg_name="gqa", P=9, new=6, rows=3)),
+    ("native_generate_exact_fused_norm", check_native_generate, dict(fuse_norm="all")),
     # bf16 model vs the FP32 oracle at H = 4096 / I = 14336 (K = 14336 bf16 activations): measured 6.6 % of the logit spread, against
     # 1.5 % per layer for the reference's own bf16 run at this shape (encoder_7b-l1 fixture); greedy tokens must still agree
     ("native_generate_7b_layer_shape", check_native_generate, dict(cfg_name="7b-l2s", P=12, new=6, rows=1, tol=0.10)),
