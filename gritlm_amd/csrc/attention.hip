@@ -47,7 +47,7 @@
 // ATT_TIMING (diagnostic build, tools/attn_phase_probe.sh): thread 0 of every workgroup writes s_memtime stamps (cycles since kernel entry) as
 // raw u32 into the workgroup's LSE rows instead of the LSE -- where a workgroup's time goes between prologue, tiles, seams and stores
 // (profiles/r05_attn_phase_probe.json).  Three scheduling experiments built on that picture were measured and did NOT ship
-// (profiles/r05_attn_{prio,hpw}_ab.log; the variants are in git history, commits "ATT_PRIO_MODE" / "heads per workgroup"): a static
+// (profiles/r05_attn_{prio,hpw}_ab.log; the priority variants are in git history, commit "ATT_PRIO_MODE"): a static
 // s_setprio asymmetry between the two co-resident workgroups (+-1 %), 2 / 4 heads of a kv group per workgroup (-2 % / -12 %), and
 // dropping the two lgkmcnt(0) of the output transposition (0 %).
 #ifdef ATT_TIMING
