@@ -17,6 +17,35 @@ __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
          bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
 }
 
+// All-reduce of NG independent values over the 64 lanes in registers: four row rotations by DPP (all-reduce inside every 16-lane row),
+// then v_permlane16_swap / v_permlane32_swap for the rows (gfx950) -- no LDS-queue instruction.  (`wave_max` / `wave_sum` of common.h
+// are six DEPENDENT ds_bpermute round trips each, ~3 us for the eight reductions of a GQA group of four when they run one after the
+// other; here the NG chains are interleaved step by step.)  Sum order differs from wave_sum's: used only where no bit pattern is pinned.
+template <int NG, bool IS_MAX>
+__device__ __forceinline__ void wave_allreduce(float (&v)[NG]) {
+  auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+#define GRIT_DPP_STEP(CTRL)                                                                                                      \
+  _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                                               \
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v[g]), (CTRL), 0xf, 0xf, false);                                 \
+    v[g] = op(v[g], __int_as_float(t));                                                                                          \
+  }
+  GRIT_DPP_STEP(0x121)      // row_ror:1
+  GRIT_DPP_STEP(0x122)      // row_ror:2
+  GRIT_DPP_STEP(0x124)      // row_ror:4
+  GRIT_DPP_STEP(0x128)      // row_ror:8
+#undef GRIT_DPP_STEP
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[g]), __float_as_uint(v[g]), false, false);
+    v[g] = op(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g]), __float_as_uint(v[g]), false, false);
+    v[g] = op(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+  }
+}
+
 #ifndef GRIT_GV_ROWS
 #define GRIT_GV_ROWS 4      // (A/B builds: tools/decode_variants.sh)
 #endif
@@ -129,18 +158,29 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
       for (int i = 0; i < R; ++i) acc[i][b] += dot8(wv[i], xv);
     }
   }
+  // the wave's R x NB (+ NB) partial sums are reduced TOGETHER in registers (wave_allreduce: DPP row rotations + permlane swaps, the chains
+  // interleaved step by step) -- R x NB calls of wave_sum are as many chains of six dependent ds_bpermute round trips at the tail of a
+  // kernel that is one workgroup wave deep
+  {
+    float rv[R * NB + (PRENORM == 2 ? NB : 0)];
 #pragma unroll
-  for (int i = 0; i < R; ++i)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const float v = wave_sum(acc[i][b]);
-      if (lane == 0) red[wave][i][b] = v;
+      for (int b = 0; b < NB; ++b) rv[i * NB + b] = acc[i][b];
+    if (PRENORM == 2) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) rv[R * NB + b] = ssq[b];
     }
-  if (PRENORM == 2) {
+    wave_allreduce<R * NB + (PRENORM == 2 ? NB : 0), false>(rv);
+    if (lane == 0) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const float v = wave_sum(ssq[b]);
-      if (lane == 0) red_ss[wave][b] = v;
+      for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) red[wave][i][b] = rv[i * NB + b];
+      if (PRENORM == 2) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) red_ss[wave][b] = rv[R * NB + b];
+      }
     }
   }
   __syncthreads();
@@ -233,35 +273,6 @@ constexpr int AD_D = 128, AD_CH = 64, AD_G = 8;   // up to 8 query heads per kv 
 // ROPE: q arrives un-rotated in the fused qkv row; every workgroup rotates its G query heads itself (position lens[b]) and the one whose
 // slice contains that position also rotates the new k, appends k and v to the cache and then reads them back like any other key --
 // the RoPE + KV-append launch of a decode step disappears.
-// All-reduce of NG independent values over the 64 lanes in registers: four row rotations by DPP (all-reduce inside every 16-lane row),
-// then v_permlane16_swap / v_permlane32_swap for the rows (gfx950) -- no LDS-queue instruction.  (`wave_max` / `wave_sum` of common.h
-// are six DEPENDENT ds_bpermute round trips each, ~3 us for the eight reductions of a GQA group of four when they run one after the
-// other; here the NG chains are interleaved step by step.)  Sum order differs from wave_sum's: used only where no bit pattern is pinned.
-template <int NG, bool IS_MAX>
-__device__ __forceinline__ void wave_allreduce(float (&v)[NG]) {
-  auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
-#define GRIT_DPP_STEP(CTRL)                                                                                                      \
-  _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                                               \
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v[g]), (CTRL), 0xf, 0xf, false);                                 \
-    v[g] = op(v[g], __int_as_float(t));                                                                                          \
-  }
-  GRIT_DPP_STEP(0x121)      // row_ror:1
-  GRIT_DPP_STEP(0x122)      // row_ror:2
-  GRIT_DPP_STEP(0x124)      // row_ror:4
-  GRIT_DPP_STEP(0x128)      // row_ror:8
-#undef GRIT_DPP_STEP
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[g]), __float_as_uint(v[g]), false, false);
-    v[g] = op(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-  }
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g]), __float_as_uint(v[g]), false, false);
-    v[g] = op(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
-  }
-}
-
 // G = query heads per kv head, a TEMPLATE argument (round 5): with the run-time G of rounds 1-4 every loop over the heads carried an
 // `if (g >= G) break`, the compiler could neither unroll nor interleave the heads' dot products and reductions, and the one wave of a
 // workgroup executed them back to back -- the kernel was bound by its own dependent-instruction chains (11.4 us per layer at L = 2 k
