@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRIT_HIP_LIB") or os.path.join(_HERE, "libgritlm_hip.so")      # GRIT_HIP_LIB: A/B builds (tools/ubench)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gritlm_hip.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 GRIT_OK, GRIT_E_BADARG, GRIT_E_UNSUPPORTED, GRIT_E_LAUNCH, GRIT_E_RCCL = 0, -1, -2, -3, -4
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ROPE, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD, EPI_RESIDUAL_F32 = 0, 1, 2, 3, 4, 5, 6, 7
 POOL_MODES = {"mean": 0, "weightedmean": 1, "cls": 2, "lasttoken": 3}
@@ -53,6 +53,9 @@ _SIGNATURES = {
     "grit_pool_norm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt_rope": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _p, _p, _p, _i, _i, _i, _p]),
     "grit_gemm_bf16_nt_grouped": (_i, [_p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _i, _p]),
+    "grit_gemm_f16_nt_grouped": (_i, [_p, _p, _p, _p, _p, _i, _l, _i, _i, _l, _l, _l, _l, _i, _p]),
+    "grit_moe_router_top2_f32": (_i, [_p, _p, _f, _p, _p, _p, _l, _i, _i, _p]),
+    "grit_moe_combine_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _p]),
     "grit_gemv_bf16": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
     "grit_rmsnorm_gemv_bf16": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p]),
     "grit_rmsnorm_gemv_bf16_deferred": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p]),

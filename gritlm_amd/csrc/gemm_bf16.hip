@@ -160,8 +160,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_k(const uint16_t* __restrict
                                                       int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                                                       int tiles_m, int tiles_n, int GM, int remap, GemmGroups groups, GemmRope rope,
                                                       unsigned int* tile_ctr, GemmSecond second, unsigned int* ovf) {
-  static_assert(!F16 || EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_ROPE || EPI == GRIT_EPI_SWIGLU || EPI == GRIT_EPI_RESIDUAL_F32 ||
-                    EPI == GRIT_EPI_RESIDUAL,
+  static_assert(!F16 || EPI == GRIT_EPI_STORE || EPI == GRIT_EPI_ROPE || EPI == GRIT_EPI_SWIGLU || EPI == GRIT_EPI_SWIGLU_STACKED ||
+                    EPI == GRIT_EPI_RESIDUAL_F32 || EPI == GRIT_EPI_RESIDUAL,
                 "fp16 operands: forward epilogues only");
 
   using frag_t = std::conditional_t<F16, f16x8_t, bf16x8_t>;
@@ -1406,8 +1406,43 @@ extern "C" int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M
     case GRIT_EPI_SWIGLU:
       GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
       return launch_gemm<GRIT_EPI_SWIGLU, true>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
+    case GRIT_EPI_SWIGLU_STACKED:     // the training engine's [gate; up] weights (pass 1 of GradCache under an fp16 policy)
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU_STACKED, true>(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, st);
     default:
-      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_f16_nt: epilogue %d not available (STORE, SWIGLU, RESIDUAL, RESIDUAL_F32)", epilogue);
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_f16_nt: epilogue %d not available (STORE, SWIGLU, SWIGLU_STACKED, RESIDUAL, RESIDUAL_F32)", epilogue);
+  }
+  return GRIT_OK;
+}
+
+// grit_gemm_bf16_nt_grouped on fp16 operands (Mixtral's expert MLP under the "f16_operands" policy): A (gathered through a_rows), W
+// [E,N,K] and C in fp16, one rounding of the fp32 accumulator (SWIGLU / SWIGLU_STACKED: of silu(gate) * up evaluated in fp32).
+extern "C" int grit_gemm_f16_nt_grouped(const void* A, const int32_t* a_rows, const void* W, void* C, const int32_t* group_counts,
+                                        int num_groups, int64_t M_total, int N, int K, int64_t lda, int64_t ldw, int64_t w_group_stride,
+                                        int64_t ldc, int epilogue, void* stream) {
+  if (M_total == 0) return GRIT_OK;
+  GRIT_REQUIRE(A && W && C && group_counts, GRIT_E_BADARG, "grit_gemm_f16_nt_grouped: null pointer");
+  GRIT_REQUIRE(M_total >= 0 && N > 0 && K > 0 && num_groups > 0 && num_groups <= 1024, GRIT_E_BADARG, "grit_gemm_f16_nt_grouped: bad sizes");
+  GRIT_REQUIRE(K % 64 == 0 && N % 16 == 0, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt_grouped: K=%d must be a multiple of 64, N=%d of 16", K, N);
+  GRIT_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && w_group_stride % 8 == 0 && lda >= K && ldw >= K, GRIT_E_BADARG,
+               "grit_gemm_f16_nt_grouped: bad leading dimensions");
+  GRIT_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C), GRIT_E_BADARG, "grit_gemm_f16_nt_grouped: pointers must be 16-byte aligned");
+  GRIT_REQUIRE((int64_t)(M_total / BM + num_groups) * ((N + BN - 1) / BN) < (1ll << 31), GRIT_E_UNSUPPORTED,
+               "grit_gemm_f16_nt_grouped: too many tiles");
+  const GemmGroups grp{group_counts, a_rows, w_group_stride, num_groups};
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case GRIT_EPI_STORE:
+      GRIT_REQUIRE(ldc >= N, GRIT_E_BADARG, "grit_gemm_f16_nt_grouped: ldc < N");
+      return launch_gemm<GRIT_EPI_STORE, true>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    case GRIT_EPI_SWIGLU:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt_grouped: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU, true>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    case GRIT_EPI_SWIGLU_STACKED:
+      GRIT_REQUIRE(N % 64 == 0 && ldc >= N / 2, GRIT_E_UNSUPPORTED, "grit_gemm_f16_nt_grouped: SWIGLU epilogue needs N %% 64 == 0 and ldc >= N/2");
+      return launch_gemm<GRIT_EPI_SWIGLU_STACKED, true>(A, W, C, nullptr, M_total, N, K, lda, ldw, ldc, 0, st, grp);
+    default:
+      GRIT_REQUIRE(false, GRIT_E_BADARG, "grit_gemm_f16_nt_grouped: epilogue %d not available (STORE, SWIGLU, SWIGLU_STACKED)", epilogue);
   }
   return GRIT_OK;
 }

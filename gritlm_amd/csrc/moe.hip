@@ -74,6 +74,71 @@ __global__ void __launch_bounds__(256) moe_router_top2_k(const uint16_t* __restr
   }
 }
 
+// ---- router of the "f16_operands" policy (fp32 residual stream): NOTHING is rounded -- what the reference computes when the model runs in
+//      fp32 (scripts/modeling_mixtral_gritlm.py:843-849 with hidden_states fp32): logits = RMSNorm(h) Wg^T, softmax, top-2, renormalise.
+//      The kernel reads the residual stream h itself (fp32) and folds the post-attention RMSNorm in (deferred form: the row scale
+//      rsqrt(mean h^2 + eps) multiplies the finished dot products of (h * w_ln) with the gate rows), so the routing decision does not see
+//      the fp16 rounding of the expert GEMMs' A operand.  One wave per token, gate [E,H] + w_ln [H] (bf16, exact) staged in LDS.
+template <int E>
+__global__ void __launch_bounds__(256) moe_router_top2_f32_k(const float* __restrict__ h, const uint16_t* __restrict__ ln_w, float eps,
+                                                             const uint16_t* __restrict__ gate_w, int64_t T, int H,
+                                                             int32_t* __restrict__ experts, float* __restrict__ weights) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint2* gw = reinterpret_cast<uint2*>(smem);                   // [E][H/4] : 4 bf16 per entry
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HQ = H >> 2;
+  uint2* lw = gw + (size_t)E * HQ;                              // [H/4]
+  for (int i = tid; i < E * HQ; i += 256) gw[i] = reinterpret_cast<const uint2*>(gate_w)[i];
+  for (int i = tid; i < HQ; i += 256) lw[i] = reinterpret_cast<const uint2*>(ln_w)[i];
+  __syncthreads();
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < T; t += (int64_t)gridDim.x * 4) {
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    float ss = 0.f;
+    const float4* xr = reinterpret_cast<const float4*>(h) + t * HQ;
+    for (int c0 = lane; c0 < HQ; c0 += 8 * 64) {
+      float4 xv8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv8[u] = (c0 + 64 * u < HQ) ? xr[c0 + 64 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 64 * u;
+        if (c >= HQ) break;
+        const float4 xv = xv8[u];
+        const uint2 l = lw[c];
+        ss += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+        const float x0 = xv.x * bflo(l.x), x1 = xv.y * bfhi(l.x), x2 = xv.z * bflo(l.y), x3 = xv.w * bfhi(l.y);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint2 g = gw[e * HQ + c];
+          acc[e] += x0 * bflo(g.x) + x1 * bfhi(g.x) + x2 * bflo(g.y) + x3 * bfhi(g.y);
+        }
+      }
+    }
+    const float inv = rsqrtf(wave_sum(ss) / (float)H + eps);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { acc[e] = wave_sum(acc[e]) * inv; mx = fmaxf(mx, acc[e]); }
+    float p[E], den = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { p[e] = expf(acc[e] - mx); den += p[e]; }
+    int e0 = 0, e1 = -1;
+    float p0 = -1.f, p1 = -1.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {                    // descending, lowest index first on ties (torch.topk on equal values)
+      const float pe = p[e] / den;
+      if (pe > p0) { p1 = p0; e1 = e0; p0 = pe; e0 = e; }
+      else if (pe > p1) { p1 = pe; e1 = e; }
+    }
+    if (lane == 0) {
+      const float s = p0 + p1;
+      experts[2 * t] = e0; experts[2 * t + 1] = e1;
+      weights[2 * t] = p0 / s; weights[2 * t + 1] = p1 / s;
+    }
+  }
+}
+
 // ---- router backward (training; scripts/modeling_mixtral_gritlm.py:843-849 differentiated): w = renormalised top-2 of softmax(x Wg^T).
 //      One wave per token, gate matrix in LDS (the forward router's structure): the wave recomputes the token's E logits in fp32, forms
 //        p = softmax(logits);  s = p[e0] + p[e1];  w_k = p[e_k] / s;  dsel_k = (dw_k - sum_j dw_j w_j) / s;  inner = sum_k dsel_k p[e_k]
@@ -304,6 +369,34 @@ __global__ void __launch_bounds__(256) moe_combine_k(const uint16_t* __restrict_
   reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- combine of the "f16_operands" policy: out[t] (fp32) = res[t] (fp32) + w0 * y[r0] + w1 * y[r1], y fp16 (the grouped w2 GEMM's one
+//      rounding), everything else in fp32 -- the reference's arithmetic when the model runs in fp32 (:876-880, decoder :945)
+__global__ void __launch_bounds__(256) moe_combine_f32_k(const uint16_t* __restrict__ y, const int32_t* __restrict__ rows,
+                                                         const float* __restrict__ weights, const float* __restrict__ res,
+                                                         float* __restrict__ out, int64_t T, int H) {
+  const int HC = H >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * HC) return;
+  const int64_t t = i / HC;
+  const int c = (int)(i - t * HC);
+  const int r0 = rows[2 * t], r1 = rows[2 * t + 1];
+  const float w0 = weights[2 * t], w1 = weights[2 * t + 1];
+  const uint4 a = reinterpret_cast<const uint4*>(y)[(int64_t)r0 * HC + c];
+  const uint4 b = reinterpret_cast<const uint4*>(y)[(int64_t)r1 * HC + c];
+  const float4 ra = res ? reinterpret_cast<const float4*>(res)[2 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 rb = res ? reinterpret_cast<const float4*>(res)[2 * i + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  const float rv[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[2 * k] = rv[2 * k] + (w0 * hlo(av[k]) + w1 * hlo(bv[k]));
+    o[2 * k + 1] = rv[2 * k + 1] + (w0 * hhi(av[k]) + w1 * hhi(bv[k]));
+  }
+  reinterpret_cast<float4*>(out)[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
+  reinterpret_cast<float4*>(out)[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
 // ---- backward of combine (autograd of final_hidden_states += expert_out * routing_weight, modeling_mixtral_gritlm.py:861-880):
 //      one wave per routed row r:  dy[r] = bf16(w(r) * dout[token(r)]),  dw[token(r), slot(r)] = <y[r], dout[token(r)]>  (fp32)
 __global__ void __launch_bounds__(256) moe_combine_bwd_k(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y,
@@ -388,6 +481,47 @@ extern "C" int grit_moe_router_top2(const void* x, const void* gate_w, int32_t* 
   } while (0)
   if (E == 4) GRIT_ROUTER(4); else if (E == 8) GRIT_ROUTER(8); else GRIT_ROUTER(16);
   GRIT_CHECK_LAUNCH("grit_moe_router_top2");
+  return GRIT_OK;
+}
+
+// Router of the "f16_operands" policy: h [T,H] fp32 (the residual stream entering the block's RMSNorm), ln_w [H] bf16, gate_w [E,H] bf16 ->
+// experts [T,2] int32, weights [T,2] fp32 (NOT rounded).  See moe_router_top2_f32_k.
+extern "C" int grit_moe_router_top2_f32(const float* h, const void* ln_w, float eps, const void* gate_w, int32_t* experts, float* weights,
+                                        int64_t T, int H, int E, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(h && ln_w && gate_w && experts && weights, GRIT_E_BADARG, "grit_moe_router_top2_f32: null pointer");
+  GRIT_REQUIRE(T > 0 && H > 0 && H % 8 == 0, GRIT_E_BADARG, "grit_moe_router_top2_f32: bad sizes T=%lld H=%d", (long long)T, H);
+  GRIT_REQUIRE(E == 4 || E == 8 || E == 16, GRIT_E_UNSUPPORTED, "grit_moe_router_top2_f32: num_experts=%d (4, 8 and 16 are built)", E);
+  GRIT_REQUIRE((size_t)(E + 1) * H * 2 <= 160 * 1024, GRIT_E_UNSUPPORTED, "grit_moe_router_top2_f32: gate [%d,%d] + norm weight exceed LDS", E, H);
+  GRIT_REQUIRE(aligned16(h) && aligned16(gate_w) && aligned16(ln_w), GRIT_E_BADARG, "grit_moe_router_top2_f32: pointers must be 16-byte aligned");
+  const size_t lds = (size_t)(E + 1) * H * 2;
+  int64_t nb = (T + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  hipStream_t st = (hipStream_t)stream;
+#define GRIT_ROUTER32(E_)                                                                                                     \
+  do {                                                                                                                        \
+    static std::atomic<uint64_t> optin_{0};                                                                                   \
+    lds_optin_once(moe_router_top2_f32_k<E_>, optin_, 160 * 1024);                                                            \
+    hipLaunchKernelGGL(moe_router_top2_f32_k<E_>, dim3((unsigned)nb), dim3(256), lds, st, h, (const uint16_t*)ln_w, eps,      \
+                       (const uint16_t*)gate_w, T, H, experts, weights);                                                      \
+  } while (0)
+  if (E == 4) GRIT_ROUTER32(4); else if (E == 8) GRIT_ROUTER32(8); else GRIT_ROUTER32(16);
+  GRIT_CHECK_LAUNCH("grit_moe_router_top2_f32");
+  return GRIT_OK;
+}
+
+// Combine of the "f16_operands" policy: y [2T,H] fp16, residual (nullable) / out [T,H] fp32 (out may alias residual).
+extern "C" int grit_moe_combine_f32(const void* y, const int32_t* rows, const float* weights, const float* residual, float* out, int64_t T,
+                                    int H, void* stream) {
+  if (T == 0) return GRIT_OK;
+  GRIT_REQUIRE(y && rows && weights && out, GRIT_E_BADARG, "grit_moe_combine_f32: null pointer");
+  GRIT_REQUIRE(T > 0 && H > 0 && H % 8 == 0, GRIT_E_BADARG, "grit_moe_combine_f32: bad sizes");
+  GRIT_REQUIRE(aligned16(y) && aligned16(out) && (!residual || aligned16(residual)), GRIT_E_BADARG,
+               "grit_moe_combine_f32: pointers must be 16-byte aligned");
+  const int64_t n = T * (H >> 3);
+  hipLaunchKernelGGL(moe_combine_f32_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, rows, weights,
+                     residual, out, T, H);
+  GRIT_CHECK_LAUNCH("grit_moe_combine_f32");
   return GRIT_OK;
 }
 

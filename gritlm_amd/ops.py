@@ -236,8 +236,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, e
     n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE) else (2 * N if epilogue == EPI_SWIGLU_BWD else N)
     opd = a.dtype if a.dtype == F16 else BF16                 # fp16 operands: the f16_operands policy (STORE, SWIGLU, RESIDUAL_F32)
     odt = F32 if epilogue == EPI_RESIDUAL_F32 else opd        # RESIDUAL_F32: out and residual are the fp32 residual stream
-    if opd == F16 and epilogue not in (EPI_STORE, EPI_SWIGLU, EPI_RESIDUAL, EPI_RESIDUAL_F32):
-        raise _lib.GritHipError(f"gemm_nt: epilogue {epilogue} is not built for fp16 operands (STORE, SWIGLU, RESIDUAL, RESIDUAL_F32)")
+    if opd == F16 and epilogue not in (EPI_STORE, EPI_SWIGLU, EPI_SWIGLU_STACKED, EPI_RESIDUAL, EPI_RESIDUAL_F32):
+        raise _lib.GritHipError(f"gemm_nt: epilogue {epilogue} is not built for fp16 operands (STORE, SWIGLU, SWIGLU_STACKED, RESIDUAL, RESIDUAL_F32)")
     if out is None:
         out = torch.empty((M, n_out), dtype=odt, device=a.device)
     assert out.shape == (M, n_out)
@@ -302,20 +302,23 @@ def gemm_nt_rope(a: torch.Tensor, w: torch.Tensor, cos: torch.Tensor, sin: torch
 def gemm_nt_grouped(a: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, m_total: int, out: torch.Tensor | None = None,
                     epilogue: int = EPI_STORE, a_rows: torch.Tensor | None = None) -> torch.Tensor:
     """Grouped GEMM over ``w [E,N,K]``: sorted row r (group by group, ``counts`` int32 [E] on the device) is
-    a[a_rows[r]] @ w[g]^T.  ``m_total`` = number of sorted rows (2T for top-2 routing)."""
+    a[a_rows[r]] @ w[g]^T.  ``m_total`` = number of sorted rows (2T for top-2 routing).  fp16 ``a`` / ``w`` / ``out``: the fp16
+    instantiation (the "f16_operands" policy of the MoE engine; STORE, SWIGLU, SWIGLU_STACKED)."""
     E, N, K = w.shape
     assert a.shape[1] == K
-    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    opd = F16 if a.dtype == F16 else BF16
+    n_out = N // 2 if epilogue in (EPI_SWIGLU, EPI_SWIGLU_STACKED) else N
     if out is None:
-        out = torch.empty((m_total, n_out), dtype=BF16, device=a.device)
+        out = torch.empty((m_total, n_out), dtype=opd, device=a.device)
     assert out.shape == (m_total, n_out)
-    ev = _timer.span("gemm_bf16_nt_grouped", 2.0 * m_total * N * K) if _timer is not None else None
+    name = "gemm_f16_nt_grouped" if opd == F16 else "gemm_bf16_nt_grouped"
+    ev = _timer.span(name, 2.0 * m_total * N * K) if _timer is not None else None
     if ev:
         ev[0].record()
-    check(_lib.load().grit_gemm_bf16_nt_grouped(_chk2d(a, BF16, "a"), 0 if a_rows is None else _chk(a_rows, I32, "a_rows"),
-                                                _chk3d(w, BF16, "w"), _chk2d(out, BF16, "out"), _chk(counts, I32, "counts"), E, m_total, N, K,
-                                                a.stride(0), w.stride(1), w.stride(0), out.stride(0), epilogue, _stream()),
-          "grit_gemm_bf16_nt_grouped")
+    check(getattr(_lib.load(), "grit_" + name)(_chk2d(a, opd, "a"), 0 if a_rows is None else _chk(a_rows, I32, "a_rows"),
+                                               _chk3d(w, opd, "w"), _chk2d(out, opd, "out"), _chk(counts, I32, "counts"), E, m_total, N, K,
+                                               a.stride(0), w.stride(1), w.stride(0), out.stride(0), epilogue, _stream()),
+          "grit_" + name)
     if ev:
         ev[1].record()
     return out
@@ -402,14 +405,42 @@ def moe_route(x: torch.Tensor, gate_w: torch.Tensor):
 
 
 def moe_combine(y: torch.Tensor, rows: torch.Tensor, weights: torch.Tensor, residual: torch.Tensor | None, out: torch.Tensor | None = None):
+    """out[t] = residual[t] + w[t,0] y[rows[t,0]] + w[t,1] y[rows[t,1]].  bf16 y / residual / out: the reference's bf16 rounding points;
+    fp16 y with an fp32 residual / out: the "f16_operands" policy (fp32 arithmetic, nothing rounded)."""
     T = rows.shape[0]
     H = y.shape[1]
+    if y.dtype == F16:
+        if out is None:
+            out = torch.empty((T, H), dtype=F32, device=y.device)
+        check(_lib.load().grit_moe_combine_f32(_chk(y, F16, "y"), _chk(rows, I32, "rows"), _chk(weights, F32, "weights"),
+                                               0 if residual is None else _chk(residual, F32, "residual"), _chk(out, F32, "out"), T, H, _stream()),
+              "grit_moe_combine_f32")
+        return out
     if out is None:
         out = torch.empty((T, H), dtype=BF16, device=y.device)
     check(_lib.load().grit_moe_combine(_chk(y, BF16, "y"), _chk(rows, I32, "rows"), _chk(weights, F32, "weights"),
                                        0 if residual is None else _chk(residual, BF16, "residual"), _chk(out, BF16, "out"), T, H, _stream()),
           "grit_moe_combine")
     return out
+
+
+def moe_route_f32(h: torch.Tensor, ln_w: torch.Tensor, eps: float, gate_w: torch.Tensor):
+    """moe_route for the "f16_operands" policy: the routing decision is taken in fp32 on the residual stream h [T,H] itself (the
+    post-attention RMSNorm folded in, nothing rounded: grit_moe_router_top2_f32).  Same return tuple as moe_route."""
+    T, H = h.shape
+    E = gate_w.shape[0]
+    dev = h.device
+    experts = torch.empty((T, 2), dtype=I32, device=dev)
+    weights = torch.empty((T, 2), dtype=F32, device=dev)
+    counts = torch.empty((E,), dtype=I32, device=dev)
+    row_token = torch.empty((2 * T,), dtype=I32, device=dev)
+    rows = torch.empty((T, 2), dtype=I32, device=dev)
+    check(_lib.load().grit_moe_router_top2_f32(_chk(h, F32, "h"), _chk(ln_w, BF16, "ln_w"), float(eps), _chk(gate_w, BF16, "gate_w"),
+                                               experts.data_ptr(), weights.data_ptr(), T, H, E, _stream()), "grit_moe_router_top2_f32")
+    ws = torch.empty((int(_lib.load().grit_moe_index_workspace_ints(T, E)),), dtype=I32, device=dev)
+    check(_lib.load().grit_moe_index(experts.data_ptr(), T, E, counts.data_ptr(), row_token.data_ptr(), rows.data_ptr(), ws.data_ptr(), _stream()),
+          "grit_moe_index")
+    return experts, weights, counts, row_token, rows
 
 
 def f16_overflow_flag(device, clear: bool = True) -> bool:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 3
+#define GRIT_ABI_VERSION 4
 
 enum {
   GRIT_OK = 0,
@@ -146,8 +146,9 @@ int grit_attn_bidir_varlen_fwd(const void* qkv, const int32_t* cu_seqlens, void*
 int grit_rmsnorm_fwd_f32in_f16(const float* x, const void* w, void* y, int64_t T, int H, float eps, void* stream);
 
 /* grit_gemm_bf16_nt on fp16 operands (A, W fp16; fp32 accumulate).  Epilogues: GRIT_EPI_STORE (C = fp16(acc)), GRIT_EPI_SWIGLU
- * (C = fp16(silu(gate) * up) evaluated in fp32, interleaved weight rows), GRIT_EPI_RESIDUAL_F32 (C, residual fp32: C = residual + acc),
- * GRIT_EPI_RESIDUAL (C, residual fp16: the fp16 residual stream, below). */
+ * (C = fp16(silu(gate) * up) evaluated in fp32, interleaved weight rows; GRIT_EPI_SWIGLU_STACKED: the same on [gate; up] stacked rows --
+ * the training engine's weight layout, used by GradCache pass 1 under an fp16 policy), GRIT_EPI_RESIDUAL_F32 (C, residual fp32:
+ * C = residual + acc), GRIT_EPI_RESIDUAL (C, residual fp16: the fp16 residual stream, below). */
 int grit_gemm_f16_nt(const void* A, const void* W, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int epilogue,
                      const void* residual, int64_t ldr, void* stream);
 
@@ -184,6 +185,25 @@ int grit_f16_overflow_flag(int* host_flag, int clear, void* stream);
 int grit_gemm_bf16_nt_grouped(const void* A, const int32_t* a_rows, const void* W, void* C, const int32_t* group_counts,
                               int num_groups, int64_t M_total, int N, int K, int64_t lda, int64_t ldw,
                               int64_t w_group_stride, int64_t ldc, int epilogue, void* stream);
+
+/* grit_gemm_bf16_nt_grouped on fp16 operands (round 6: Mixtral's expert MLP under the "f16_operands" policy; replaces the expert loop of
+ * scripts/modeling_mixtral_gritlm.py:861-880 when the model runs at the north-star tolerance): A (gathered through a_rows), W [E,N,K] and C
+ * fp16, ONE rounding of the fp32 accumulator.  Epilogues: GRIT_EPI_STORE, GRIT_EPI_SWIGLU, GRIT_EPI_SWIGLU_STACKED.  Overflow is flagged
+ * like grit_gemm_f16_nt. */
+int grit_gemm_f16_nt_grouped(const void* A, const int32_t* a_rows, const void* W, void* C, const int32_t* group_counts,
+                             int num_groups, int64_t M_total, int N, int K, int64_t lda, int64_t ldw,
+                             int64_t w_group_stride, int64_t ldc, int epilogue, void* stream);
+
+/* Router of the "f16_operands" policy (:843-849 as the reference computes it in fp32: nothing rounded).  h [T,H] fp32 is the residual
+ * stream ENTERING the block's post-attention RMSNorm (:939); the norm (ln_w [H] bf16, eps) is folded in: logits = rsqrt(mean h^2 + eps) *
+ * ((h * ln_w) gate_w^T), softmax, top-2 (ties: lower index), renormalise.  experts [T,2] int32, weights [T,2] fp32 (not rounded). */
+int grit_moe_router_top2_f32(const float* h, const void* ln_w, float eps, const void* gate_w, int32_t* experts, float* weights, int64_t T,
+                             int H, int E, void* stream);
+
+/* Combine of the "f16_operands" policy (:876-880 + decoder :945 in fp32): out[t] = residual[t] + weights[t,0]*y[rows[t,0]] +
+ * weights[t,1]*y[rows[t,1]]; y [2T,H] fp16 (the grouped w2 GEMM's single rounding), residual (nullable) / out [T,H] fp32 (may alias). */
+int grit_moe_combine_f32(const void* y, const int32_t* rows, const float* weights, const float* residual, float* out, int64_t T, int H,
+                         void* stream);
 
 /* Router (:843-849): logits = bf16(x gate_w^T), softmax in fp32, top-2 (ties: lower index), renormalise, round to bf16.
  * x [T,H] bf16, gate_w [E,H] bf16 (E in {4,8,16}) -> experts [T,2] int32, weights [T,2] fp32 (bf16-representable). */
