@@ -135,12 +135,16 @@ class MistralDecoder:
         if past is None:
             # prefill: one causal pass over the prompt that also emits the post-RoPE K/V (the encoder engine's forward)
             mask = torch.ones((B, P), dtype=I64, device=dev) if attention_mask is None else attention_mask.to(device=dev, dtype=I64)
-            was = self.eng.causal
+            # (the fp16 policies are built for the bidirectional embedding pass: the causal prompt pass of a unified model runs in the
+            # reference's bf16 arithmetic -- what the decode kernels continue in -- and the engine's policy is restored afterwards)
+            was, pol = self.eng.causal, self.eng.precision
+            if pol in ("f16_operands", "f16_stream"):
+                self.eng.precision = "bf16"
             self.eng.causal = True
             try:
                 hidden, kv = self.eng.forward(ids, mask, borrow=True, return_kv=True)
             finally:
-                self.eng.causal = was
+                self.eng.causal, self.eng.precision = was, pol
             for li, (k, v) in enumerate(kv):
                 st["cache"][li][0][:, :, :P].copy_(k); st["cache"][li][1][:, :, :P].copy_(v)
             plen = mask.sum(dim=1).to(I32)

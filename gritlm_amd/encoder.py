@@ -35,13 +35,18 @@ F16 = torch.float16
 #                    in IEEE fp16, each rounded once from fp32: same MFMA rate, 3 more mantissa bits -- the policy that meets the
 #                    north-star tolerance (1 - cos < 1e-4 against the reference's fp32 run) at depth 32.  bf16 checkpoints convert to fp16
 #                    exactly for 6.1e-5 <= |w| < 65520; an activation beyond the fp16 range raises (check_f16_overflow), it never saturates
-#                    silently.  Dense (Mistral) models, bidirectional attention.
+#                    silently.  Bidirectional attention; dense (Mistral) and, since round 6, sparse-MoE (Mixtral) models -- there the routing
+#                    decision is taken in fp32 on the residual stream itself (grit_moe_router_top2_f32), the expert GEMMs run on fp16 copies
+#                    of w1|w3 / w2 (grit_gemm_f16_nt_grouped), the weighted combine adds into the fp32 stream (grit_moe_combine_f32).
 #   "f16_stream"     "f16_operands" with the residual stream itself in fp16 (16-bit residual epilogues and norms, as in the bf16 policy):
 #                    1 - cos 6e-6 at depth 32 (emulated; the stream's 11-bit mantissa adds 2e-6 to the fp32 stream's 4e-6) at 0.975 of the
 #                    default's docs/s instead of 0.955.  The stream of a checkpoint with activations beyond 65504 does not fit: that raises
 #                    (the same flag); use "f16_operands" there.
 PRECISIONS = ("bf16", "fp32_residual", "f16_operands", "f16_stream")
 F16_POLICIES = ("f16_operands", "f16_stream")
+# precision="auto" (GritLM): the ladder walked from the fastest policy that meets the north-star tolerance down to the ones with more
+# range -- a rung is left for good the first time one of its kernels flags a value beyond the fp16 range (gritlm.py::GritLM.encode)
+AUTO_LADDER = ("f16_stream", "f16_operands", "fp32_residual", "bf16")
 
 
 @dataclass
@@ -168,41 +173,63 @@ class MistralEncoderEngine:
     def residual_fp32(self, v: bool):
         self.precision = "fp32_residual" if v else "bf16"
 
+    def supported_precisions(self) -> tuple:
+        """The policies this engine's model kind / attention mode is built for, in AUTO_LADDER order."""
+        if self.causal:
+            return ("fp32_residual", "bf16") if not self.cfg.num_local_experts else ("bf16",)
+        if self.cfg.num_local_experts:
+            return ("f16_operands", "bf16")
+        return AUTO_LADDER
+
     def set_precision(self, precision: str):
         if precision not in PRECISIONS:
             raise ValueError(f"precision={precision!r}: one of {PRECISIONS}")
         if precision in F16_POLICIES:
-            if self.cfg.num_local_experts:
-                raise GritHipError(f"native encoder: precision='{precision}' is built for the dense (Mistral) MLP only")
+            if self.cfg.num_local_experts and precision != "f16_operands":
+                raise GritHipError(f"native encoder: precision='{precision}' is built for the dense (Mistral) MLP only "
+                                   "(the sparse-MoE engine routes on the fp32 residual stream: use 'f16_operands')")
             if self.causal:
                 raise GritHipError(f"native encoder: precision='{precision}' is built for bidirectional attention only")
+        if precision == "fp32_residual" and self.cfg.num_local_experts:
+            raise GritHipError("native encoder: precision='fp32_residual' is built for the dense (Mistral) MLP only")
         self.precision = precision
         return self
 
     def _f16_weights(self, L: _Layer):
-        """fp16 copies of a layer's four GEMM weights (14.5 GB for the 7B shape next to 288 GB of HBM), converted on first use.  bf16 ->
-        fp16 is exact for normal fp16 values; what is not exact is COUNTED: |w| < 2^-14 becomes subnormal (absolute error <= 3e-8),
-        |w| >= 65520 would become inf and is refused."""
+        """fp16 copies of a layer's GEMM weights (14.5 GB for the 7B shape, 93 GB for the 8x7B shape, next to 288 GB of HBM), converted on
+        first use: (wqkv, wo, wgu, wdown) of a dense layer, (wqkv, wo, w13, w2) of a sparse-MoE layer.  bf16 -> fp16 is exact for normal fp16
+        values; what is not exact is COUNTED: |w| < 2^-14 becomes subnormal (absolute error <= 3e-8), |w| >= 65520 would become inf and is
+        refused.  The copies are keyed on the sources' storage and version counters: weights reloaded or updated in place are converted again."""
+        src = (L.wqkv, L.wo, L.w13, L.w2) if self.cfg.num_local_experts else (L.wqkv, L.wo, L.wgu, L.wdown)
+        key = tuple((w.data_ptr(), w._version) for w in src)
         h = getattr(L, "h16", None)
-        if h is None:
+        if h is None or h[0] != key:
             st = self.f16_weight_stats or {"subnormal": 0, "overflow": 0, "total": 0}
-            h = []
-            for w in (L.wqkv, L.wo, L.wgu, L.wdown):
-                a = w.abs()
-                st["subnormal"] += int(((a < 6.103515625e-05) & (a > 0)).sum())
-                st["overflow"] += int((a >= 65520.0).sum())
-                st["total"] += w.numel()
-                h.append(w.to(F16))
+            out = []
+            for w in src:
+                # (counted slice by slice: the [E,2I,H] expert stacks are 12 GB each and abs() would double that)
+                for part in (w if w.dim() == 3 else (w,)):
+                    a = part.abs()
+                    st["subnormal"] += int(((a < 6.103515625e-05) & (a > 0)).sum())
+                    st["overflow"] += int((a >= 65520.0).sum())
+                    st["total"] += part.numel()
+                    del a
+                out.append(w.to(F16))
             if st["overflow"]:
                 raise GritHipError(f"precision='{self.precision}': {st['overflow']} weights exceed the fp16 range (|w| >= 65520)")
             self.f16_weight_stats = st
-            L.h16 = h = tuple(h)
-        return h
+            L.h16 = h = (key, tuple(out))
+        return h[1]
+
+    def f16_overflowed(self, clear: bool = True) -> bool:
+        """True when a kernel of an fp16 policy produced a value beyond the fp16 range on this engine's device since the last clear (waits
+        for the device's current stream: one 4-byte D2H copy)."""
+        return bool(ops.f16_overflow_flag(self.device, clear))
 
     def check_f16_overflow(self, clear: bool = True) -> None:
         """Raise if a kernel of the f16_operands policy produced a value beyond the fp16 range since the last check (waits for the
         device's current stream: call it where the embeddings are copied to the host anyway)."""
-        if self.precision in F16_POLICIES and ops.f16_overflow_flag(self.device, clear):
+        if self.precision in F16_POLICIES and self.f16_overflowed(clear):
             raise GritHipError(f"precision='{self.precision}': an activation exceeded the fp16 range (|v| >= 65520) in this forward pass; "
                                "the embeddings of this call are invalid -- run this model with "
                                + ("precision='f16_operands' (fp32 residual stream), " if self.precision == "f16_stream" else "")
@@ -213,11 +240,12 @@ class MistralEncoderEngine:
         (262 MB at V 32000) for the fp16 stream, converted on first use"""
         if self.precision != "f16_stream":
             return self.embed
-        if getattr(self, "_embed16", None) is None or self._embed16.shape != self.embed.shape:
+        key = (self.embed.data_ptr(), self.embed._version, tuple(self.embed.shape))
+        if getattr(self, "_embed16", None) is None or self._embed16[0] != key:       # (re-converted when the table is reloaded / updated in place)
             if bool((self.embed.abs() >= 65520.0).any()):
                 raise GritHipError("precision='f16_stream': embedding weights exceed the fp16 range")
-            self._embed16 = self.embed.to(F16)
-        return self._embed16
+            self._embed16 = (key, self.embed.to(F16))
+        return self._embed16[1]
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -346,8 +374,8 @@ class MistralEncoderEngine:
             # sequence by the pooling: 3e-7 of 1 - cos, profiles/r05_precision_budget.json "only_out_bf16")
             self._ws.update(xo=self._ws["x"] if opd == BF16 else torch.empty((T, c.hidden_size), dtype=BF16, device=dev))
             if c.num_local_experts:           # every token visits two experts: 2T rows of expert activations
-                self._ws.update(act2=torch.empty((2 * T, c.intermediate_size), dtype=BF16, device=dev),
-                                y2=torch.empty((2 * T, c.hidden_size), dtype=BF16, device=dev))
+                self._ws.update(act2=torch.empty((2 * T, c.intermediate_size), dtype=opd, device=dev),
+                                y2=torch.empty((2 * T, c.hidden_size), dtype=opd, device=dev))
             else:
                 self._ws.update(act=mk(c.intermediate_size))
         return {k: (v[:2 * T] if k in ("act2", "y2") else v[:T]) for k, v in self._ws.items() if k not in ("cap", "policy")}
@@ -359,14 +387,21 @@ class MistralEncoderEngine:
             ops.gemm_nt(x, wgu, out=ws["act"], epilogue=EPI_SWIGLU)
             ops.gemm_nt(ws["act"], wdown, out=h, epilogue=self._epi_res(), residual=h)
             return
-        if self.residual_fp32:
-            raise GritHipError("native encoder: residual_fp32 is built for the dense (Mistral) MLP only")
         T = x.shape[0]
-        experts, weights, counts, row_token, rows = ops.moe_route(x, L.wgate)
+        if self.precision == "f16_operands":
+            # the routing decision in fp32 on the residual stream itself (post-attention RMSNorm folded in: nothing rounded), the experts on
+            # fp16 operands, the weighted sum added into the fp32 stream
+            _, _, w13, w2 = self._f16_weights(L)
+            experts, weights, counts, row_token, rows = ops.moe_route_f32(h, L.ln2, self.cfg.rms_norm_eps, L.wgate)
+        else:
+            if self.residual_fp32:
+                raise GritHipError("native encoder: precision='fp32_residual' is built for the dense (Mistral) MLP only")
+            w13, w2 = L.w13, L.w2
+            experts, weights, counts, row_token, rows = ops.moe_route(x, L.wgate)
         if self.record_routing is not None:
             self.record_routing.append(experts.clone())
-        ops.gemm_nt_grouped(x, L.w13, counts, 2 * T, out=ws["act2"], epilogue=EPI_SWIGLU, a_rows=row_token)
-        ops.gemm_nt_grouped(ws["act2"], L.w2, counts, 2 * T, out=ws["y2"])
+        ops.gemm_nt_grouped(x, w13, counts, 2 * T, out=ws["act2"], epilogue=EPI_SWIGLU, a_rows=row_token)
+        ops.gemm_nt_grouped(ws["act2"], w2, counts, 2 * T, out=ws["y2"])
         ops.moe_combine(ws["y2"], rows, weights, h, out=h)
 
     def _epi_res(self) -> int:
@@ -375,7 +410,7 @@ class MistralEncoderEngine:
     def _weights(self, L: _Layer):
         """(wqkv, wo, wgu, wdown) in the operand format of the current policy"""
         if self.precision in F16_POLICIES:
-            return self._f16_weights(L)
+            return self._f16_weights(L)              # (a sparse-MoE layer: (wqkv, wo, w13, w2))
         return (L.wqkv, L.wo, getattr(L, "wgu", None), getattr(L, "wdown", None))        # (MoE layers have no dense MLP weights)
 
     def _window(self, S: int) -> int:
@@ -394,13 +429,15 @@ class MistralEncoderEngine:
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor | None, attention_mask: torch.Tensor | None = None, borrow: bool = False,
                 return_kv: bool = False, inputs_embeds: torch.Tensor | None = None, layer_range: tuple | None = None,
-                final_norm: bool = True):
+                final_norm: bool = True, kv_dtype: torch.dtype | None = BF16):
         """last_hidden_state [B,S,H] bf16 (after the final RMSNorm), is_causal=False semantics.
 
         ``borrow=True`` returns a view of the engine's workspace (valid until the next forward).
         ``return_kv=True`` additionally returns, per layer, the post-RoPE keys and the values as
         ``(k [B,nkv,S,d], v [B,nkv,S,d])`` -- what ``use_cache=True`` hands back in the reference
-        (gritlm/gritlm.py:131-140; RAG doc caching, rag/eval.py:132-142).
+        (gritlm/gritlm.py:131-140; RAG doc caching, rag/eval.py:132-142).  ``kv_dtype``: bf16 (the reference's cache format, the default) or
+        None = the operand format of the policy: under the fp16 policies the K / V the attention itself read, fp16, rounded ONCE from the fp32
+        accumulator of the q|k|v GEMM's epilogue (bf16 from them is a second rounding: at most 1/16 bf16 ulp more than a direct one).
         ``inputs_embeds`` [B,S,H] replaces the embedding lookup (the reference's forward takes it too, modeling_mistral_gritlm.py:944, :993-994);
         ``layer_range=(a, b)`` runs decoder layers a .. b-1 only and ``final_norm=False`` returns the residual stream itself: together they
         push a GIVEN hidden state through chosen layers -- the teacher-forced per-layer parity of the Mixtral leg (tools/mixtral_bench.py)."""
@@ -431,10 +468,11 @@ class MistralEncoderEngine:
             wqkv, wo = self._weights(L)[:2]
             ops.rmsnorm(h, L.ln1, eps, out=x)
             ops.gemm_nt_rope(x, wqkv, cos, sin, (nq + nkv) * d, S=S, out=qkv)         # q/k/v projections + RoPE in the epilogue
-            if return_kv:                                                               # (the KV cache format is bf16 in every policy)
+            if return_kv:
                 kvw = qkv.view(B, S, nq + 2 * nkv, d)
-                kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).to(BF16).contiguous(),
-                           kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).to(BF16).contiguous()))
+                kdt = qkv.dtype if kv_dtype is None else kv_dtype
+                kv.append((kvw[:, :, nq:nq + nkv].permute(0, 2, 1, 3).to(kdt).contiguous(),
+                           kvw[:, :, nq + nkv:].permute(0, 2, 1, 3).to(kdt).contiguous()))
             ops.attn_bidir(qkv, bits, B, S, nq, nkv, d, out=ctx, causal=self.causal, window=window)
             ops.gemm_nt(ctx, wo, out=h, epilogue=self._epi_res(), residual=h)
             ops.rmsnorm(h, L.ln2, eps, out=x)

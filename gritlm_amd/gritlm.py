@@ -73,9 +73,12 @@ class GritLM(torch.nn.Module):
         # depth 32), "f16_stream" (the same with the residual stream in fp16: faster, range-limited).  `residual_fp32=True` (round 4) is kept as an alias of precision="fp32_residual".
         residual_fp32 = bool(kwargs.pop("residual_fp32", False))
         precision = kwargs.pop("precision", None) or ("fp32_residual" if residual_fp32 else "bf16")
+        # "auto" (round 6): start on the fastest policy that meets the north-star tolerance ("f16_stream") and step down the ladder
+        # f16_stream -> f16_operands -> fp32_residual -> bf16 the first time a kernel flags a value beyond the fp16 range (checkpoints with
+        # massive activations): the affected call is re-run on the next rung, logged once; encode() never raises for range.
         from .encoder import PRECISIONS
-        if precision not in PRECISIONS:
-            raise ValueError(f"precision={precision!r}: one of {PRECISIONS}")
+        if precision not in PRECISIONS + ("auto",):
+            raise ValueError(f"precision={precision!r}: one of {PRECISIONS + ('auto',)}")
         if mode == "embedding":
             if any(tag in model_name_or_path for tag in ("gtr", "t5", "instructor")):
                 from transformers import T5EncoderModel
@@ -163,7 +166,35 @@ class GritLM(torch.nn.Module):
             print(f"GritLM: causal embedding attention with config.sliding_window={cfg.sliding_window} on the '{impl}' path of the reference: "
                   + (f"a query sees {self.engine.window_keys} keys" if self.engine.window_keys else "no window (the sdpa path applies none)")
                   + "; pass attn_implementation= to choose, or set engine.window_keys")
-        self.engine.set_precision(getattr(self, "_precision", "bf16"))
+        self.set_precision(getattr(self, "_precision", "bf16"))
+
+    def set_precision(self, precision: str):
+        """Precision policy of the native engine AND of every in-process replica (gritlm_amd.encoder.PRECISIONS, or "auto": the ladder)."""
+        from .encoder import AUTO_LADDER, PRECISIONS
+        if precision not in PRECISIONS + ("auto",):
+            raise ValueError(f"precision={precision!r}: one of {PRECISIONS + ('auto',)}")
+        self._precision = precision
+        if self.engine is None:
+            return self
+        self._auto = precision == "auto"
+        if self._auto:
+            sup = self.engine.supported_precisions()
+            self._ladder = [r for r in AUTO_LADDER if r in sup]
+            precision = self._ladder[0]
+        for eng in (getattr(self, "engines", None) or [self.engine]):
+            eng.set_precision(precision)
+        return self
+
+    @property
+    def precision(self) -> str:
+        """The policy the engine(s) currently run (under "auto": the rung the ladder stands on)."""
+        return self.engine.precision if self.engine is not None else self._precision
+
+    def _f16_flags(self) -> list:
+        """Read AND clear the fp16 overflow flag of every engine's device; returns the devices whose flag was set."""
+        if self.engine is None or getattr(self.engine, "precision", None) not in ("f16_operands", "f16_stream"):
+            return []
+        return [str(e.device) for e in (getattr(self, "engines", None) or [self.engine]) if e.f16_overflowed(clear=True)]
 
     def _parallelize(self, devices=None):
         """The reference wraps an embedding model in ``nn.DataParallel`` over every visible GPU and multiplies ``batch_size`` by their
@@ -185,9 +216,22 @@ class GritLM(torch.nn.Module):
             # CUDA_VISIBLE_DEVICES) each rank owns ONE device: replicating onto all visible GPUs would put world_size copies of the model
             # on every GPU.  There the engine stays on its own device; pass `devices=[...]` to ask for in-process replicas explicitly.
             import os
-            in_dist = (torch.distributed.is_available() and torch.distributed.is_initialized()) or any(
-                os.environ.get(k) is not None for k in ("LOCAL_RANK", "RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"))
+
+            def _n(k):
+                try:
+                    return int(os.environ.get(k, "1") or 1)
+                except ValueError:
+                    return 1
+            # a one-process-per-GPU launch = an initialised process group, torchrun's LOCAL_RANK, or a launcher that started MORE THAN ONE
+            # task (WORLD_SIZE / SLURM_NTASKS / OMPI_COMM_WORLD_SIZE > 1).  SLURM_LOCALID / RANK alone say nothing: SLURM sets SLURM_LOCALID=0
+            # in every step, including the reference's own single-task 8-GPU evaluation job (scripts/eval_mteb.sh: ntasks-per-node=1,
+            # gres=gpu:8, plain `python`), which must replicate over all 8 GPUs as the reference's nn.DataParallel does
+            in_dist = (torch.distributed.is_available() and torch.distributed.is_initialized()) or os.environ.get("LOCAL_RANK") is not None \
+                or max(_n("WORLD_SIZE"), _n("SLURM_NTASKS"), _n("OMPI_COMM_WORLD_SIZE")) > 1
             if in_dist:
+                if torch.cuda.device_count() > 1:
+                    print("GritLM: one-process-per-GPU launch detected (process group / LOCAL_RANK / more than one task): the engine stays "
+                          f"on {self.engine.device}; pass devices=[...] for in-process replicas")
                 return
             devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
         cur = torch.cuda.current_device()
@@ -287,6 +331,8 @@ class GritLM(torch.nn.Module):
         add_special_tokens: bool = True,
         **kwargs,
     ) -> np.ndarray:
+        if self.engine is not None and getattr(self.engine, "precision", None) in ("f16_operands", "f16_stream") and not kwargs.get("_ladder_rerun"):
+            self._f16_flags()            # sticky per-device flags of an earlier, unchecked forward must not be blamed on this call
         if self.num_gpus > 1:
             batch_size *= self.num_gpus
         single = isinstance(sentences, str)
@@ -336,9 +382,24 @@ class GritLM(torch.nn.Module):
         else:
             # ONE device->host copy for the whole call (the reference syncs per batch, :164)
             result = torch.cat(chunks, dim=0).to(torch.float32).cpu().numpy()
-        if self.engine is not None and getattr(self.engine, "precision", None) in ("f16_operands", "f16_stream"):
-            for eng in (getattr(self, "engines", None) or [self.engine]):       # raises if an activation left the fp16 range in this call
-                eng.check_f16_overflow()
+        flagged = self._f16_flags()       # every engine's flag is read and cleared (one 4-byte D2H each, next to the copy above)
+        if flagged:
+            pol = self.engine.precision
+            if getattr(self, "_auto", False):
+                # the ladder: this call's embeddings are invalid under `pol`; step down for good and run the call again
+                nxt = self._ladder[self._ladder.index(pol) + 1]
+                print(f"GritLM: precision='auto': an activation exceeded the fp16 range under '{pol}' on {', '.join(flagged)} -- this model "
+                      f"runs under '{nxt}' from now on (this call is re-run)")
+                for eng in (getattr(self, "engines", None) or [self.engine]):
+                    eng.set_precision(nxt)
+                return self.encode(sentences[0] if single else sentences, batch_size=batch_size // max(self.num_gpus, 1), max_length=max_length,
+                                   instruction=instruction, embed_instruction=embed_instruction, get_cache=get_cache,
+                                   convert_to_tensor=convert_to_tensor, recast=recast, add_special_tokens=add_special_tokens,
+                                   _ladder_rerun=True, **{k: v for k, v in kwargs.items() if k != "_ladder_rerun"})
+            from ._lib import GritHipError
+            raise GritHipError(f"precision='{pol}': an activation exceeded the fp16 range (|v| >= 65520) on {', '.join(flagged)} in this call; the "
+                               "embeddings of this call are invalid -- use precision='auto' (steps down by itself), "
+                               + ("'f16_operands' (fp32 residual stream), " if pol == "f16_stream" else "") + "'fp32_residual' or 'bf16'")
         if single:
             result = result[0]
         if get_cache:

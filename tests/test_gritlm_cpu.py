@@ -168,6 +168,58 @@ def test_parallelize_stays_on_one_device_inside_a_distributed_launch(dirs, monke
     assert m.num_gpus == 2 and m.engine.made == [torch.device("cuda:1")]
 
 
+def test_parallelize_replicates_in_a_single_task_slurm_job(dirs, monkeypatch):
+    """SLURM sets SLURM_LOCALID=0 in EVERY step, including the reference's own single-task 8-GPU evaluation job
+    (scripts/eval_mteb.sh: ntasks-per-node=1, gres=gpu:8, plain `python`), where the reference wraps the model in nn.DataParallel over all
+    GPUs (gritlm/gritlm.py:72-75).  SLURM_LOCALID / RANK alone must therefore NOT switch replication off; more than one task does."""
+    m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    for k in ("LOCAL_RANK", "RANK", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SLURM_LOCALID", "0"); monkeypatch.setenv("SLURM_NTASKS", "1"); monkeypatch.setenv("SLURM_PROCID", "0")
+    m.engine = _ReplicaEngine("cuda:0")
+    m.engines, m.num_gpus = [], 1
+    m._parallelize(None)
+    assert m.num_gpus == 8 and m.engine.made == [torch.device("cuda", i) for i in range(1, 8)]
+    monkeypatch.setenv("SLURM_NTASKS", "8")                     # srun with one task per GPU: every task keeps to its own device
+    m.engine = _ReplicaEngine("cuda:0")
+    m.engines, m.num_gpus = [], 1
+    m._parallelize(None)
+    assert m.num_gpus == 1 and m.engine.made == []
+    monkeypatch.setenv("SLURM_NTASKS", "1"); monkeypatch.setenv("WORLD_SIZE", "2")      # a launcher that exports WORLD_SIZE only
+    m._parallelize(None)
+    assert m.num_gpus == 1 and m.engine.made == []
+
+
+def test_precision_auto_ladder_is_host_logic(dirs):
+    """precision='auto' (round 6): validated, and GritLM.set_precision walks gritlm_amd.encoder.AUTO_LADDER restricted to what the engine's
+    model kind supports (dense bidirectional: all four rungs; sparse-MoE: f16_operands then bf16; causal: no fp16 rung)."""
+    from gritlm_amd.encoder import AUTO_LADDER
+    assert AUTO_LADDER == ("f16_stream", "f16_operands", "fp32_residual", "bf16")
+    m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", precision="auto")
+    assert m._precision == "auto" and m.engine is None and m.precision == "auto"
+
+    class _Eng:
+        def __init__(self, sup):
+            self.sup, self.precision, self.device = sup, "bf16", "cuda:0"
+
+        def supported_precisions(self):
+            return self.sup
+
+        def set_precision(self, p):
+            assert p in self.sup
+            self.precision = p
+    for sup, first in ((AUTO_LADDER, "f16_stream"), (("f16_operands", "bf16"), "f16_operands"), (("fp32_residual", "bf16"), "fp32_residual")):
+        m.engine, m.engines = _Eng(sup), []
+        m.set_precision("auto")
+        assert m._auto and m._ladder == [r for r in AUTO_LADDER if r in sup] and m.precision == first
+    m.set_precision("bf16")
+    assert not m._auto and m.precision == "bf16"
+    with pytest.raises(ValueError, match="precision"):
+        m.set_precision("fp8")
+
+
 def test_precision_keyword_is_validated(dirs):
     """`precision=` (extension): one of gritlm_amd.encoder.PRECISIONS; `residual_fp32=True` stays an alias of 'fp32_residual'."""
     from gritlm_amd.encoder import PRECISIONS
