@@ -19,10 +19,10 @@ import os
 import torch
 
 from .. import ops
-from .._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE
-from ..encoder import EncoderConfig, rope_tables, sliding_window_keys
+from .._lib import EPI_RESIDUAL, EPI_RESIDUAL_F32, EPI_STORE, EPI_SWIGLU_BWD, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, GritHipError
+from ..encoder import F16_POLICIES, EncoderConfig, rope_tables, sliding_window_keys
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
 
 
 def _pad_k(n: int) -> int:
@@ -96,6 +96,14 @@ class MistralTrainEngine:
         self.pair_wgrads = os.environ.get("GRIT_NO_WGRAD_PAIR") != "1"     # down_proj + q|k|v_proj weight gradients in one launch
         self._deferred_wgrad = None
         self.recompute = False          # gradient checkpointing (per-layer recompute in backward)
+        # Precision policy of the NO-GRAD forward (GradCache pass 1: the pass that defines the representations and the loss; round 6):
+        # "bf16" = the reference's bf16 arithmetic (the arithmetic of pass 2, whose saved activations the bf16 backward kernels read), or
+        # "f16_operands" / "f16_stream" = the encoder's fp16-operand policies (gritlm_amd/encoder.py) on fp16 copies of the packed weights,
+        # refreshed when the optimizer has changed them: the loss then matches the reference's fp32 loss to the north-star's 1e-3 at depth 32.
+        self.nograd_precision = "bf16"
+        self._w16 = {}                  # layer index -> (owner versions, fp16 (wqkv, wo, wgu, wdown))
+        self._embed16 = None
+        self._ws16 = {}
         self._router_log = None         # Mixtral: list collecting (logits fp32 [T,E], experts [T,2]) per layer while it is a list
         self._aux_dlogits = None        # Mixtral: d aux_loss / d router logits per layer during backward_lm
         c = self.cfg
@@ -206,8 +214,104 @@ class MistralTrainEngine:
             self._f32_norm_grads = torch.zeros((2 * len(self.layers) + 1, c.hidden_size), dtype=F32, device=self.device)
 
     def weights_updated(self):
-        """Call after optimizer.step(): transposed-weight cache is stale."""
+        """Call after optimizer.step(): the transposed-weight cache and the fp16 weight copies are stale (both are also keyed on the
+        Parameters' version counters, so an in-place update invalidates them even if this is never called)."""
         self._wT.clear()
+        self._w16.clear()
+        self._embed16 = None
+
+    def set_nograd_precision(self, precision: str):
+        if precision not in ("bf16",) + F16_POLICIES:
+            raise ValueError(f"nograd_precision={precision!r}: one of {('bf16',) + F16_POLICIES}")
+        if precision == "f16_stream" and self.cfg.num_local_experts:
+            raise GritHipError("training engine: the sparse-MoE block routes on the fp32 residual stream: use 'f16_operands'")
+        self.nograd_precision = precision
+        return self
+
+    def check_f16_overflow(self, clear: bool = True) -> None:
+        """Raise if a kernel of the fp16 no-grad forward produced a value beyond the fp16 range since the last check (synchronises)."""
+        if self.nograd_precision in F16_POLICIES and ops.f16_overflow_flag(self.device, clear):
+            raise GritHipError(f"nograd_precision='{self.nograd_precision}': an activation exceeded the fp16 range in the no-grad forward; "
+                               "the representations (and the loss) of this step are invalid -- use 'f16_operands' (fp32 residual stream) or 'bf16'")
+
+    def _all_owners(self, li: int):
+        at, _, _ = self.layers[li].mods
+        return (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.o_proj.weight) + tuple(self._mlp_owners(li, "gu")) \
+            + tuple(self._mlp_owners(li, "down"))
+
+    def _f16_weights(self, li: int):
+        """fp16 copies of layer li's packed GEMM weights (wqkv, wo, [gate; up] stacked, down) -- exact for 6.1e-5 <= |w| < 65520, refused
+        beyond -- converted when first needed after an optimizer update (14.5 GB for the 7B shape: ~10 ms of a 50 s step)."""
+        ver = tuple(p._version for p in self._all_owners(li))
+        hit = self._w16.get(li)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        L = self.layers[li]
+        out = []
+        for w in (L.wqkv, L.wo, L.wgu, L.wdown):
+            w16 = w.data.to(F16)
+            for part in (w16 if w16.dim() == 3 else (w16,)):            # (slice by slice: an expert stack is 12 GB)
+                if bool(torch.isinf(part).any()):
+                    raise GritHipError(f"nograd_precision='{self.nograd_precision}': weights of layer {li} exceed the fp16 range")
+            out.append(w16)
+        self._w16[li] = (ver, tuple(out))
+        return self._w16[li][1]
+
+    def _mlp_fwd_f16(self, li: int, L, x2, h, ws, w16):
+        """h += down(silu(gate(x2)) * up(x2)) on fp16 operands (x2 fp16; h the fp32 / fp16 residual stream, updated in place)."""
+        _, _, wgu, wdown = w16
+        ops.gemm_nt(x2, wgu, out=ws["act"], epilogue=EPI_SWIGLU_STACKED)
+        ops.gemm_nt(ws["act"], wdown, out=h, epilogue=EPI_RESIDUAL_F32 if h.dtype == F32 else EPI_RESIDUAL, residual=h)
+
+    def _ws16_buffers(self, T: int, stream_dtype):
+        c = self.cfg
+        cap = self._ws16.get("cap", 0)
+        if cap < T or self._ws16.get("sdt") != stream_dtype:
+            self._ws16.clear()
+            nq, nkv, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+            mk = lambda n, dt=F16, rows=T: torch.empty((rows, n), dtype=dt, device=self.device)
+            r = 2 if c.num_local_experts else 1
+            self._ws16.update(cap=T, sdt=stream_dtype, h=mk(c.hidden_size, stream_dtype), x=mk(c.hidden_size), qkv=mk((nq + 2 * nkv) * d),
+                              ctx=mk(nq * d), act=mk(c.intermediate_size, F16, r * T))
+            if c.num_local_experts:
+                self._ws16.update(y=mk(c.hidden_size, F16, 2 * T))
+        return {k: (v[:2 * T] if k == "y" or (k == "act" and c.num_local_experts) else v[:T]) for k, v in self._ws16.items() if k not in ("cap", "sdt")}
+
+    def _forward_nograd_f16(self, ids, geom, B, S):
+        """The no-grad forward under an fp16-operand policy: the encoder engine's data flow (gritlm_amd/encoder.py) on this engine's packed
+        parameters.  Returns last_hidden_state rows [T,H] bf16 (the pooling kernels' input; one rounding of the final RMSNorm)."""
+        c, pol = self.cfg, self.nograd_precision
+        if geom.causal:
+            raise GritHipError(f"nograd_precision='{pol}' is built for the bidirectional embedding pass only")
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        T = geom.T
+        t = self._rope.get((S, "f32"))
+        if t is None:
+            t = self._rope[(S, "f32")] = rope_tables(S, d, c.rope_theta, False, self.device)      # unrounded tables: the rotation runs in fp32
+        cos, sin = t
+        ws = self._ws16_buffers(T, F32 if pol == "f16_operands" else F16)
+        h, x, qkv, ctx = ws["h"], ws["x"], ws["qkv"], ws["ctx"]
+        if pol == "f16_stream":
+            key = (self.embed.data_ptr(), self.embed._version)
+            if self._embed16 is None or self._embed16[0] != key:
+                self._embed16 = (key, self.embed.data.to(F16))
+            ops.embed_gather(self._embed16[1], ids, out=h)
+        else:
+            ops.embed_gather(self.embed.data, ids, out=h)
+        epi = EPI_RESIDUAL_F32 if h.dtype == F32 else EPI_RESIDUAL
+        for li, L in enumerate(self.layers):
+            w16 = self._f16_weights(li)
+            ops.rmsnorm(h, L.ln1.data, eps, out=x)
+            if geom.packed:
+                ops.gemm_nt_rope(x, w16[0], cos, sin, (nq + nkv) * d, positions=geom.pos, out=qkv)
+                ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx)
+            else:
+                ops.gemm_nt_rope(x, w16[0], cos, sin, (nq + nkv) * d, S=S, out=qkv)
+                ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx)
+            ops.gemm_nt(ctx, w16[1], out=h, epilogue=epi, residual=h)
+            ops.rmsnorm(h, L.ln2.data, eps, out=x)
+            self._mlp_fwd_f16(li, L, x, h, ws, w16)
+        return ops.rmsnorm(h, self.norm.data, eps, out=torch.empty((T, c.hidden_size), dtype=BF16, device=self.device))
 
     # ------------------------------------------------------------------ helpers
     def _rope_tables(self, S):
@@ -321,11 +425,14 @@ class MistralTrainEngine:
         T = geom.T
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         H, I = c.hidden_size, c.intermediate_size
+        saved = SavedForward()
+        saved.ids, saved.mask, saved.geom, saved.B, saved.S, saved.layers = ids, mask, geom, B, S, []
+        if not save and not causal and self.nograd_precision in F16_POLICIES and self._router_log is None:
+            xf = self._forward_nograd_f16(ids, geom, B, S)
+            return (xf if geom.packed else xf.view(B, S, H)), saved
         cos, sin = self._rope_tables(S)
         mk = lambda n: torch.empty((T, n), dtype=BF16, device=dev)
         h = ops.embed_gather(self.embed.data, ids, out=mk(H))
-        saved = SavedForward()
-        saved.ids, saved.mask, saved.geom, saved.B, saved.S, saved.layers = ids, mask, geom, B, S, []
         # activation policy: save and not recompute -> every intermediate of every layer stays in HBM (3x forward FLOPs per step);
         # save and recompute -> only each layer's INPUT is kept and backward() re-runs the layer's forward first (the reference's
         # gradient checkpointing, gritlm/training/run.py:83-84: 4x forward FLOPs, ~1/17 of the activation memory);
@@ -546,6 +653,16 @@ class MixtralTrainEngine(MistralTrainEngine):
         if with_gu:
             buf["h_mid"] = torch.empty((T, c.hidden_size), dtype=BF16, device=self.device)
         return buf
+
+    def _mlp_fwd_f16(self, li: int, L, x2, h, ws, w16):
+        """The sparse-MoE block of the fp16 no-grad forward ("f16_operands": h is the fp32 residual stream): routing in fp32 on h itself
+        (post-attention RMSNorm folded in), experts on fp16 copies of the fused gate_up_proj / down_proj, combine into the fp32 stream."""
+        T = x2.shape[0]
+        _, _, wgu, wdown = w16
+        experts, weights, counts, row_token, rows = ops.moe_route_f32(h, L.ln2.data, self.cfg.rms_norm_eps, L.wgate.data)
+        ops.gemm_nt_grouped(x2, wgu, counts, 2 * T, out=ws["act"], epilogue=EPI_SWIGLU_STACKED, a_rows=row_token)
+        ops.gemm_nt_grouped(ws["act"], wdown, counts, 2 * T, out=ws["y"])
+        ops.moe_combine(ws["y"], rows, weights, h, out=h)
 
     def _mlp_fwd(self, L, h_mid, x2, buf, need_bwd: bool, h_out):
         T = x2.shape[0]

@@ -206,8 +206,19 @@ def pass1_chunk_rows(model, chunk_size: int) -> int:
 
 
 class GradCacheStep:
-    def __init__(self, model, chunk_size: int, pass1_chunk_size: "int | None" = None):
+    def __init__(self, model, chunk_size: int, pass1_chunk_size: "int | None" = None, precision: "str | None" = None):
+        """``precision`` (native engine only; "bf16" | "f16_operands" | "f16_stream"; default: GRIT_PASS1_PRECISION or the engine's current
+        setting): the policy of PASS 1, the no-grad forward that defines the representations and the loss.  Under the fp16 policies the
+        loss matches the reference's fp32 loss to 1e-3 at depth 32 (bf16: ~1e-2 at tau 0.02); pass 2 re-encodes in the reference's bf16
+        arithmetic either way (its saved activations feed the bf16 backward kernels), so the cached representation gradients meet a forward
+        whose representations differ from pass 1's by the bf16 policy's own error (1 - cos ~ 5e-4 at depth 32): measured in
+        tests/gpu_checks.py::check_gradcache_f16_pass1 and bench.py's contrastive `parity` object."""
         self.model = model
+        eng = getattr(model, "train_engine", None)
+        precision = precision or os.environ.get("GRIT_PASS1_PRECISION")
+        if precision and eng is not None:
+            eng.set_nograd_precision(precision)
+        self.precision = getattr(eng, "nograd_precision", "bf16") if eng is not None else "bf16"
         self.chunk_size = int(chunk_size)
         self.pass1_chunk_size = int(pass1_chunk_size) if pass1_chunk_size else pass1_chunk_rows(model, self.chunk_size)
         self.profile = None        # set to a dict to collect per-step timings (ms): loss (similarity GEMM + CE + rep grads), the
@@ -269,6 +280,7 @@ class GradCacheStep:
                 if cross and (gq if which == "q" else gp) is not None:
                     (gq if which == "q" else gp).flush()         # the tower's remainder goes out before the next tower starts
         q_reps, p_reps = torch.cat(q_list, dim=0), torch.cat(p_list, dim=0)
+        self.last_reps = (q_reps, p_reps)          # (pass 1's representations: parity probes read them)
         # loss + representation-gradient cache
         q_leaf, p_leaf = q_reps.detach().requires_grad_(), p_reps.detach().requires_grad_()
         gpu = q_reps.is_cuda

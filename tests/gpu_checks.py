@@ -1323,7 +1323,26 @@ def check_f16_overflow_flag():
     x[2, 7] = 1.0e3                                                             # one outlier: normalised ~ 15.6 x 3e4 > 65504
     ops.rmsnorm(x, wn, 1e-5, out=y)
     det["rmsnorm_overflow"] = _f16_flag(); ok &= det["rmsnorm_overflow"]
-    return _res("fp16 overflow flag (set by STORE / SWIGLU / RoPE / RMSNorm, sticky, clearable)", ok, **det)
+    # round 6: the fp16-stream norm (fp16 rows in) and the grouped fp16 GEMM (MoE experts), STORE and the stacked SwiGLU
+    from gritlm_amd._lib import EPI_SWIGLU_STACKED
+    xh = torch.full((5, 512), 3.0, dtype=torch.float16, device=DEV)
+    wn5 = torch.full((512,), 3.0e4, dtype=torch.bfloat16, device=DEV)
+    yh = torch.empty((5, 512), dtype=torch.float16, device=DEV)
+    ops.rmsnorm(xh, wn5, 1e-5, out=yh)
+    det["rmsnorm_f16in_in_range"] = _f16_flag(); ok &= not det["rmsnorm_f16in_in_range"]
+    xh[2, 7] = 1.0e3
+    ops.rmsnorm(xh, wn5, 1e-5, out=yh)
+    det["rmsnorm_f16in_overflow"] = _f16_flag(); ok &= det["rmsnorm_f16in_overflow"]
+    cnt = torch.tensor([200, 100], dtype=torch.int32, device=DEV)
+    w3 = torch.stack([w, w]).contiguous()
+    ops.gemm_nt_grouped(small, w3, cnt, M)
+    det["grouped_in_range"] = _f16_flag(); ok &= not det["grouped_in_range"]
+    mixed = small.clone(); mixed[250:] = 200.0                                 # only rows of the SECOND group overflow
+    ops.gemm_nt_grouped(mixed, w3, cnt, M)
+    det["grouped_store_overflow"] = _f16_flag(); ok &= det["grouped_store_overflow"]
+    ops.gemm_nt_grouped(mixed, w3, cnt, M, epilogue=EPI_SWIGLU_STACKED)
+    det["grouped_swiglu_stacked_overflow"] = _f16_flag(); ok &= det["grouped_swiglu_stacked_overflow"]
+    return _res("fp16 overflow flag (set by STORE / SWIGLU / RoPE / RMSNorm / grouped GEMM, sticky, clearable)", ok, **det)
 
 
 def check_f16_stream_ops(T=37, H=4096):
@@ -3027,6 +3046,465 @@ def _overlap_worker_solo(rank, port, model_dir, out):
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the fp16-operand policies beyond dense inference (sparse-MoE engine, GradCache pass 1, get_cache, the "auto" ladder)
+def check_gemm_f16_stacked(M=300, I=512, K=256):
+    """grit_gemm_f16_nt with GRIT_EPI_SWIGLU_STACKED ([gate; up] weights: the training engine's layout, used by GradCache pass 1 under an
+    fp16 policy) must be bit-identical to GRIT_EPI_SWIGLU on the pre-interleaved copy of the same fp16 weights."""
+    from gritlm_amd._lib import EPI_SWIGLU_STACKED
+    a, wg, wu = fh(f16r(rnd((M, K), 3))), fh(f16r(rnd((I, K), 4, 0.05))), fh(f16r(rnd((I, K), 5, 0.05)))
+    _f16_flag()
+    ref = ops.gemm_nt(a, swiglu_interleave(wg, wu), epilogue=EPI_SWIGLU)
+    got = ops.gemm_nt(a, torch.cat([wg, wu], dim=0).contiguous(), epilogue=EPI_SWIGLU_STACKED)
+    ok = bool(torch.equal(ref, got)) and ref.dtype == torch.float16 and not _f16_flag()
+    return _res(f"f16 swiglu stacked == interleaved [M={M},I={I},K={K}]", ok, max_abs=float((ref.float() - got.float()).abs().max()))
+
+
+def check_gemm_f16_grouped(counts=(300, 0, 17, 256, 513, 1, 0, 64), N=384, K=256, epi=EPI_STORE, seed=165):
+    """grit_gemm_f16_nt_grouped (device-side counts, gathered A rows) vs fp64 products of the same fp16 operands per group: ONE fp16
+    rounding of the accumulator (SWIGLU / SWIGLU_STACKED: of silu(gate) * up evaluated in fp32); empty and tiny groups included; the
+    stacked form equals the interleaved form bit for bit; un-gathered == gathered on pre-permuted rows."""
+    from gritlm_amd._lib import EPI_SWIGLU_STACKED
+    E, M = len(counts), int(sum(counts))
+    Tsrc = M // 2 + 5
+    a = f16r(rnd((Tsrc, K), seed))
+    w = f16r(rnd((E, N, K), seed + 1, 0.05))
+    rng = np.random.default_rng(seed + 2)
+    a_rows = rng.integers(0, Tsrc, size=M).astype(np.int32)
+    tcounts = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    ta, trows = fh(a), torch.from_numpy(a_rows).to(DEV)
+    _f16_flag()
+    ok = True
+    if epi == EPI_SWIGLU:
+        I = N // 2
+        wi = torch.stack([swiglu_interleave(fh(w[e, :I]), fh(w[e, I:])) for e in range(E)]).contiguous()
+        out_t = ops.gemm_nt_grouped(ta, wi, tcounts, M, epilogue=epi, a_rows=trows)
+        out_s = ops.gemm_nt_grouped(ta, fh(w), tcounts, M, epilogue=EPI_SWIGLU_STACKED, a_rows=trows)
+        ok &= bool(torch.equal(out_t, out_s))
+        wop = wi
+    else:
+        wop = fh(w)
+        out_t = ops.gemm_nt_grouped(ta, wop, tcounts, M, a_rows=trows)
+    ok &= out_t.dtype == torch.float16
+    out = out_t.float().cpu().numpy().astype(np.float64)
+    ref = np.zeros(out.shape, dtype=np.float64)
+    off = 0
+    for e, c in enumerate(counts):
+        full = a[a_rows[off:off + c]].astype(np.float64) @ w[e].astype(np.float64).T
+        if epi == EPI_SWIGLU:
+            g, u = full[:, :N // 2], full[:, N // 2:]
+            full = g / (1.0 + np.exp(-g)) * u
+        ref[off:off + c] = full
+        off += c
+    scale = float(np.sqrt(np.mean(ref ** 2))) + 1e-12
+    err = float(np.max(np.abs(out - ref) / (2.0 ** -11 * np.abs(ref) + 6.0e-8 + 2e-5 * scale)))
+    out2 = ops.gemm_nt_grouped(fh(a[a_rows]), wop, tcounts, M, epilogue=epi)
+    flag = _f16_flag()
+    ok &= err < 1.0 and bool(torch.equal(out_t, out2)) and not flag
+    return _res(f"gemm_f16_grouped[counts={list(counts)},N={N},K={K},epi={epi}]", bool(ok), max_err_over_tol=err, overflow_flag=flag)
+
+
+def check_moe_router_f32(T=777, H=512, E=8, eps=1e-5):
+    """grit_moe_router_top2_f32 (the routing of the f16_operands policy: fp32 residual stream in, the post-attention RMSNorm folded in,
+    nothing rounded) against the reference's arithmetic in fp64 (scripts/modeling_mixtral_gritlm.py:843-849 on RMSNorm(h)): the same two
+    experts for every token whose 2nd and 3rd logits are further apart than fp32 summation noise, routing weights within 2e-6; index
+    (counts, stable sort, inverse map) exact."""
+    rng = np.random.default_rng(261)
+    h = (rng.standard_normal((T, H)) * 3.0).astype(np.float32)
+    h[5] *= 1e3; h[6] *= 1e-3                                             # rows of very different scale: the norm is folded in
+    lnw = O.bf16_round(1.0 + 0.1 * rng.standard_normal(H).astype(np.float32))
+    gw = O.bf16_round(rng.standard_normal((E, H)).astype(np.float32) * 0.5)
+    th = torch.from_numpy(h).to(DEV)
+    experts, weights, counts, row_token, rows = ops.moe_route_f32(th, bf(lnw), eps, bf(gw))
+    h64 = h.astype(np.float64)
+    xn = lnw.astype(np.float64) * (h64 / np.sqrt(np.mean(h64 ** 2, axis=1, keepdims=True) + eps))
+    logits = xn @ gw.astype(np.float64).T
+    pr = np.exp(logits - logits.max(1, keepdims=True)); pr /= pr.sum(1, keepdims=True)
+    order = np.argsort(-pr, axis=1, kind="stable")
+    sel_ref = order[:, :2]
+    w_ref = np.take_along_axis(pr, sel_ref, axis=1); w_ref /= w_ref.sum(1, keepdims=True)
+    srt = np.sort(logits, axis=1)[:, ::-1]
+    clear = (srt[:, 1] - srt[:, 2] > 1e-3) & (srt[:, 0] - srt[:, 1] > 1e-3)
+    sel, wt = experts.cpu().numpy(), weights.cpu().numpy().astype(np.float64)
+    same = (sel == sel_ref).all(1)
+    werr = float(np.max(np.abs(wt - w_ref)[same])) if same.any() else 1.0
+    ok = bool(same[clear].all()) and clear.mean() > 0.99 and werr < 2e-6
+    flat = sel.reshape(-1)
+    ok &= np.array_equal(counts.cpu().numpy(), np.bincount(flat, minlength=E))
+    o2 = np.argsort(flat, kind="stable")
+    ok &= np.array_equal(row_token.cpu().numpy(), (o2 // 2).astype(np.int32))
+    inv = np.empty_like(o2); inv[o2] = np.arange(o2.size)
+    ok &= np.array_equal(rows.cpu().numpy().reshape(-1), inv.astype(np.int32))
+    return _res(f"moe router fp32 stream [T={T},H={H},E={E}]", bool(ok), clear_frac=float(clear.mean()), agree_all=float(same.mean()), max_weight_err=werr)
+
+
+def check_moe_combine_f32(T=333, H=512):
+    """grit_moe_combine_f32: out = residual + w0 y[r0] + w1 y[r1] in fp32 (y fp16) vs fp64; in place on the residual; residual = NULL."""
+    rng = np.random.default_rng(271)
+    y = f16r(rng.standard_normal((2 * T, H)).astype(np.float32))
+    res = rng.standard_normal((T, H)).astype(np.float32) * 5.0
+    perm = rng.permutation(2 * T).astype(np.int32).reshape(T, 2)
+    wts = rng.random((T, 2)).astype(np.float32)
+    ty, tr, tw = fh(y), torch.from_numpy(perm).to(DEV), torch.from_numpy(wts).to(DEV)
+    th = torch.from_numpy(res).to(DEV)
+    ops.moe_combine(ty, tr, tw, th, out=th)
+    ref = res.astype(np.float64) + wts[:, :1].astype(np.float64) * y[perm[:, 0]] + wts[:, 1:].astype(np.float64) * y[perm[:, 1]]
+    e1 = float(np.max(np.abs(th.cpu().numpy() - ref)) / np.sqrt(np.mean(ref ** 2)))
+    o2 = ops.moe_combine(ty, tr, tw, None)
+    ref2 = ref - res
+    e2 = float(np.max(np.abs(o2.cpu().numpy() - ref2)) / np.sqrt(np.mean(ref2 ** 2)))
+    return _res(f"moe combine fp32 [T={T},H={H}]", e1 < 2e-6 and e2 < 2e-6 and o2.dtype == torch.float32, rel_err=e1, rel_err_no_residual=e2)
+
+
+def check_mixtral_f16_operands(cfg_name="moe-tiny"):
+    """The sparse-MoE engine under precision='f16_operands' (fp32 stream, fp32 routing on the stream, fp16 expert GEMMs, fp32 combine)
+    against the fixture the REFERENCE's modeling_mixtral_gritlm.py produced in fp32: EVERY token takes the fp32 reference's experts in
+    every layer wherever the reference's own 2nd-vs-3rd margin is not a tie, hidden states at least 10x closer than the bf16 policy,
+    embeddings within 1e-5 (north-star 1e-4), packed == padded bit for bit, no overflow; 'f16_stream' / 'fp32_residual' are refused."""
+    from gritlm_amd._lib import GritHipError
+    g = np.load(os.path.join(GOLDEN, f"encoder_{cfg_name}.npz"))
+    eng, cfg, w = build_engine(cfg_name, int(g["seed_w"]))
+    ids, mask = g["input_ids"], g["attention_mask"]
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    valid = mask.astype(bool)
+    ref32 = g["last_hidden_state"]
+    rel = lambda a, b: float(np.linalg.norm((a - b)[valid]) / np.linalg.norm(b[valid]))
+    r_b = rel(f32(eng.forward(tid, tm)), ref32)
+    eng.set_precision("f16_operands")
+    _f16_flag()
+    eng.record_routing = []
+    h = f32(eng.forward(tid, tm))
+    routing = np.sort(np.stack([r.cpu().numpy() for r in eng.record_routing]).reshape(len(eng.layers), *ids.shape, 2), axis=-1)
+    eng.record_routing = None
+    agree = float((routing == np.sort(g["routing"], axis=-1)).all(-1)[:, valid].mean())
+    r_f = rel(h, ref32)
+    out = dict(rel_hidden_bf16=r_b, rel_hidden_f16_operands=r_f, routing_agree_with_fp32_ref=agree,
+               routing_agree_of_bf16_ref=_yard()[f"encoder_{cfg_name}/routing_agree_of_bf16_ref"])
+    ok = agree >= 0.999 and r_f < 0.1 * r_b and not np.isnan(h).any()
+    for method in ("mean", "weightedmean"):
+        e = eng.encode_pooled(tid, tm, method, True, packed=False)
+        ep = eng.encode_pooled(tid, tm, method, True, packed=True)
+        c32 = float(np.max(1 - np.sum(f32(e).astype(np.float64) * g[f"emb_{method}"].astype(np.float64), axis=1)))
+        out[f"{method}_1-cos"] = c32
+        ok &= c32 < 1e-5 and bool(torch.equal(e, ep))
+    out["overflow_flag"] = _f16_flag()
+    ok &= not out["overflow_flag"] and eng.f16_weight_stats["overflow"] == 0
+    for pol in ("f16_stream", "fp32_residual"):
+        try:
+            eng.set_precision(pol); out[pol + "_refused"] = False
+        except GritHipError:
+            out[pol + "_refused"] = True
+        ok &= out[pol + "_refused"]
+    ok &= eng.supported_precisions() == ("f16_operands", "bf16")
+    return _res(f"mixtral encoder[{cfg_name}] f16_operands policy vs reference fp32", bool(ok), **out)
+
+
+def check_mixtral_layer_true_shape_f16():
+    """ONE layer at the TRUE Mixtral-8x7B layer shape under precision='f16_operands' vs the reference-generated fixture
+    (tests/golden/encoder_8x7b-l1.npz), held to the criteria the bf16 engine's check was FIRST written with and
+    to the north-star's embedding tolerance: (1) every valid token whose router margin in the fp32 run exceeds 1e-2 takes the fp32
+    reference's two experts, overall agreement >= 0.999 (the reference's own bf16 run: 0.984); (2) probe rows that took the reference's
+    experts: relative l2 error of all rows together < 3.5e-2 (the reference's own bf16 run: 2.4e-2; expected here: ~1e-3), per-row median
+    < 2e-3; (3) pooled embeddings within 1e-4 of the fp32 reference's; (4) packed == padded bit for bit; no overflow."""
+    g = np.load(os.path.join(GOLDEN, "encoder_8x7b-l1.npz"))
+    eng, cfg, w = build_engine("8x7b-l1", int(g["seed_w"]))
+    del w
+    eng.set_precision("f16_operands")
+    _f16_flag()
+    ids, mask = g["input_ids"], g["attention_mask"]
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    eng.record_routing = []
+    h = f32(eng.forward(tid, tm))
+    routing = np.sort(eng.record_routing[0].cpu().numpy().reshape(-1, 2), axis=-1)
+    eng.record_routing = None
+    valid = mask.astype(bool).reshape(-1)
+    r32 = np.sort(g["routing"], axis=-1).reshape(-1, 2)
+    agree_tok = (routing == r32).all(-1)
+    margin = g["router_margin_2nd_vs_3rd"].reshape(-1)
+    clear = valid & (margin > 1e-2)
+    out = dict(routing_agree=float(agree_tok[valid].mean()), routing_agree_of_bf16_ref=float((np.sort(g["routing_bf16"], -1).reshape(-1, 2) == r32).all(-1)[valid].mean()),
+               clear_margin_tokens=int(clear.sum()), clear_margin_agree=float(agree_tok[clear].mean()),
+               smallest_margin_of_a_disagreeing_token=float(margin[valid & ~agree_tok].max()) if (valid & ~agree_tok).any() else 0.0)
+    ok = out["clear_margin_agree"] == 1.0 and out["routing_agree"] >= 0.999 and not np.isnan(h).any()
+    probe = g["probe_rows"]
+    pa = agree_tok[probe]
+    hp = h.reshape(-1, h.shape[-1])[probe]
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    out["probe_rows_same_experts"] = int(pa.sum())
+    out["rel_ours_vs_fp32"] = rel(hp[pa], g["probe_hidden"][pa]); out["rel_refbf16_vs_fp32"] = rel(g["probe_hidden_bf16"][pa], g["probe_hidden"][pa])
+    pr = np.linalg.norm(hp[pa] - g["probe_hidden"][pa], axis=1) / np.linalg.norm(g["probe_hidden"][pa], axis=1)
+    out["row_rel_median"], out["row_rel_max"] = float(np.median(pr)), float(pr.max())
+    ok &= pa.sum() >= 60 and out["rel_ours_vs_fp32"] < 3.5e-2 and out["row_rel_median"] < 2e-3
+    for method in ("mean", "weightedmean"):
+        e = eng.encode_pooled(tid, tm, method, True, packed=False)
+        ep = eng.encode_pooled(tid, tm, method, True, packed=True)
+        c32 = float(np.max(1 - np.sum(f32(e).astype(np.float64) * g[f"emb_{method}"].astype(np.float64), axis=1)))
+        out[f"{method}_1-cos"] = c32
+        out[f"{method}_1-cos_of_bf16ref"] = float(np.max(1 - np.sum(g[f"emb_{method}_bf16"] * g[f"emb_{method}"], axis=1)))
+        ok &= c32 < 1e-4 and bool(torch.equal(e, ep))
+    out["overflow_flag"] = _f16_flag()
+    ok &= not out["overflow_flag"]
+    return _res("mixtral layer at the true 8x7B shape, f16_operands, ORIGINAL criteria (margin 1e-2, aggregate 3.5e-2) + embeddings 1e-4", bool(ok), **out)
+
+
+def _train_model_on(bb, cfg, tau=0.02):
+    from gritlm_amd.training.engine import MistralTrainEngine
+    from gritlm_amd.training.model import DistributedContrastiveLoss, GritLMTrainModel
+    m = GritLMTrainModel.__new__(GritLMTrainModel)
+    torch.nn.Module.__init__(m)
+    m.model, m.projection, m.pooling_method, m.normalized, m.attn, m.embedding_attr = bb, None, "mean", True, "bbcc", None
+    m.emb_loss_fn = DistributedContrastiveLoss(tau, False)
+    m.train_engine = MistralTrainEngine(bb, cfg, DEV)
+    return m
+
+
+def check_train_nograd_f16_equals_encoder(cfg_name="gqa", policy="f16_operands"):
+    """The training engine's no-grad forward under an fp16 policy (GradCache pass 1; stacked [gate; up] weights, packed parameters)
+    must produce the bits of the inference engine under the same policy on the same weights -- padded and packed -- and follow an
+    in-place parameter update (the fp16 copies are keyed on the parameters' version counters)."""
+    from gritlm_amd.training.engine import SyntheticBackbone
+    cfg = EncoderConfig.from_dict(synth.CONFIGS[cfg_name])
+    bb = SyntheticBackbone(cfg, DEV, seed=5)
+    sd = {k: v.detach().clone() for k, v in bb.state_dict().items()}
+    m = _train_model_on(bb, cfg)
+    m.train_engine.set_nograd_precision(policy)
+    ids, mask = synth.make_batch(synth.CONFIGS[cfg_name], 6, 150, seed=25, min_len=9)
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    eng = MistralEncoderEngine.from_state_dict(cfg, sd, DEV)
+    eng.set_precision(policy)
+    _f16_flag()
+    out, ok = {}, True
+    for packed in (False, True):
+        m.native_packed = packed
+        with torch.no_grad():
+            r = m.encode({"input_ids": tid, "attention_mask": tm})
+        e = eng.encode_pooled(tid, tm, "mean", True, packed=packed)
+        out[f"equal_packed={packed}"] = bool(torch.equal(r, e))
+        ok &= out[f"equal_packed={packed}"]
+    # an in-place update of one parameter must reach the fp16 copy without weights_updated()
+    with torch.no_grad():
+        bb.layers[0].mlp.down_proj.weight.mul_(0.5)
+        r2 = m.encode({"input_ids": tid, "attention_mask": tm})
+    out["follows_in_place_update"] = not bool(torch.equal(r2, r))
+    sd2 = {k: v.detach().clone() for k, v in bb.state_dict().items()}
+    e2 = MistralEncoderEngine.from_state_dict(cfg, sd2, DEV).set_precision(policy).encode_pooled(tid, tm, "mean", True, packed=True)
+    out["equal_after_update"] = bool(torch.equal(r2, e2))
+    # with grad enabled the forward is the bf16 one (its saved activations feed the bf16 backward kernels)
+    r3 = m.encode({"input_ids": tid, "attention_mask": tm})
+    out["grad_forward_is_bf16"] = bool(r3.requires_grad) and not bool(torch.equal(r3.detach(), r2))
+    out["overflow_flag"] = _f16_flag()
+    ok &= out["follows_in_place_update"] and out["equal_after_update"] and out["grad_forward_is_bf16"] and not out["overflow_flag"]
+    return _res(f"train engine no-grad forward [{policy}] == inference engine, bit for bit [{cfg_name}]", bool(ok), **out)
+
+
+def check_gradcache_f16_pass1():
+    """GradCacheStep(precision='f16_operands' / 'f16_stream') at the TRUE 7B layer shape vs the reference's fp32 step
+    (tests/golden/train_7b-l1.npz): pass 1 (the no-grad forward that defines the representations and the loss) runs on fp16 operands,
+    pass 2 in the reference's bf16 arithmetic.  Held to: pass-1 representations within 1e-5 of the reference's fp32 reps (bf16: 1e-4);
+    |loss - fp32 loss| < 2e-4 (bf16 policy: measured 4.4e-4, bound 1e-3); every parameter's gradient probe and norm within the SAME
+    bounds as the all-bf16 step (1.25x the reference's own bf16 run + floor) -- i.e. feeding pass 2's bf16 forward with rep gradients
+    cached at pass 1's fp16 reps costs nothing measurable against bf16's own gradient error."""
+    import tempfile
+    from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+    g = np.load(os.path.join(GOLDEN, "train_7b-l1.npz"))
+    out, ok = {}, True
+    q = {"input_ids": torch.from_numpy(g["q_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["q_mask"]).to(DEV)}
+    p = {"input_ids": torch.from_numpy(g["p_ids"]).to(DEV), "attention_mask": torch.from_numpy(g["p_mask"]).to(DEV)}
+    ref_loss = float(g["loss"])
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "7b-l1", 0, "bfloat16")
+        for pol in ("bf16", "f16_operands", "f16_stream"):
+            m = GritLMTrainModel(model_name_or_path=d16, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                                 temperature=float(g["tau"]), negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16)
+            m.enable_native()
+            _f16_flag()
+            gc = GradCacheStep(m, chunk_size=2, precision=pol)
+            loss = gc(dict(q), dict(p))
+            m.train_engine.check_f16_overflow()
+            lv = float(loss.item())
+            out[f"loss_minus_f32ref[{pol}]"] = lv - ref_loss
+            for nm, r in zip(("q", "p"), gc.last_reps):
+                c = float(np.max(1 - np.sum(f32(r).astype(np.float64) * g[nm + "_reps"].astype(np.float64), axis=1)))
+                out[f"{nm}_reps_1-cos[{pol}]"] = c
+                ok &= c < (1e-4 if pol == "bf16" else 1e-5)
+            ok &= abs(lv - ref_loss) < (LOSS_VS_F32_REF if pol == "bf16" else 2e-4)
+            worst_ratio = worst_nratio = 0.0
+            for n, t in m._backbone().named_parameters():
+                got = t.grad
+                ref_n = float(g["gnorm/" + n])
+                en = abs(float(got.double().norm().item()) - ref_n) / (ref_n + 1e-20)
+                worst_nratio = max(worst_nratio, en / (1.25 * _yard()[f"train_7b-l1/gnorm_rel_bf16/{n}"] + GRAD_FLOOR))
+                ref = g["probe/" + n]
+                if n == "embed_tokens.weight":
+                    gp = f32(got[torch.from_numpy(g["probe_rows/" + n]).to(DEV)])
+                elif got.dim() == 2:
+                    gp = f32(got[:8])
+                else:
+                    gp = f32(got)
+                e = float(np.linalg.norm(gp - ref) / (np.linalg.norm(ref) + 1e-20))
+                worst_ratio = max(worst_ratio, e / (1.25 * _yard()[f"train_7b-l1/probe_rel_bf16/{n}"] + GRAD_FLOOR))
+            out[f"probe_err_over_bound[{pol}]"] = worst_ratio
+            out[f"norm_err_over_bound[{pol}]"] = worst_nratio
+            ok &= worst_ratio <= 1.0 and worst_nratio <= 1.0
+            del m, gc
+            torch.cuda.empty_cache()
+    return _res("GradCache with an fp16 pass 1 [7b-l1] vs reference fp32 loss + grads", bool(ok), **out)
+
+
+def check_train_nograd_f16_mixtral(cfg_name="moe-tiny"):
+    """MixtralTrainEngine's no-grad forward under 'f16_operands' (fp32 routing on the stream, grouped fp16 expert GEMMs on the fused
+    gate_up_proj / down_proj parameters, fp32 combine) == the inference MoE engine under the same policy, bit for bit, and within 1e-5 of
+    the fixture the reference produced in fp32."""
+    import tempfile
+    from gritlm_amd.training import GritLMTrainModel
+    g = np.load(os.path.join(GOLDEN, f"encoder_{cfg_name}.npz"))
+    ids, mask = g["input_ids"], g["attention_mask"]
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    eng, cfg, w = build_engine(cfg_name, int(g["seed_w"]))
+    eng.set_precision("f16_operands")
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mixtral_dir(os.path.join(td, "x16"), cfg_name, int(g["seed_w"]), "bfloat16")
+        m = GritLMTrainModel(model_name_or_path=d16, mode="embedding", pooling_method="mean", normalized=True, attn="bbcc",
+                             temperature=0.02, negatives_cross_device=False, device="cuda", torch_dtype=torch.bfloat16)
+        m.enable_native()
+        m.train_engine.set_nograd_precision("f16_operands")
+        _f16_flag()
+        for packed in (False, True):
+            m.native_packed = packed
+            with torch.no_grad():
+                r = m.encode({"input_ids": tid, "attention_mask": tm})
+            e = eng.encode_pooled(tid, tm, "mean", True, packed=packed)
+            out[f"equal_packed={packed}"] = bool(torch.equal(r, e))
+            ok &= out[f"equal_packed={packed}"]
+        c = float(np.max(1 - np.sum(f32(r).astype(np.float64) * g["emb_mean"].astype(np.float64), axis=1)))
+        out["1-cos_vs_reference_fp32"] = c
+        out["overflow_flag"] = _f16_flag()
+        ok &= c < 1e-5 and not out["overflow_flag"]
+        try:
+            m.train_engine.set_nograd_precision("f16_stream"); out["f16_stream_refused"] = False
+        except Exception:      # noqa: BLE001
+            out["f16_stream_refused"] = True
+        ok &= out["f16_stream_refused"]
+    return _res(f"mixtral train engine no-grad forward [f16_operands] == inference engine [{cfg_name}]", bool(ok), **out)
+
+
+def check_gritlm_f16_auto_ladder():
+    """precision='auto' on checkpoint-like activations.  At the 7B LAYER shape (H 4096, I 14336, 2 layers), three models:
+    (a) tame N(0, 0.02) weights: 'auto' stays on f16_stream; (b) two residual channels driven to ~1e5 (beyond fp16: 65504) by scaled
+    down_proj rows in both layers: f16_stream flags from the RESIDUAL epilogue / norm, the ladder steps to f16_operands (fp32 stream) and
+    stays; (c) gate / up scaled so the SwiGLU activation itself crosses 65504: f16_operands flags too (the SWIGLU epilogue),
+    the ladder lands on fp32_residual.  In every case encode() RETURNS (never raises), the rows are finite and within 2e-3 of the bf16
+    policy's rows for the same model (1e-5 of the fp16 policy's own rows where no rung was left), the rung is sticky for the next call,
+    and an explicit f16 policy on the same model raises and names the devices.  Also: the flag fires from every kernel class that rounds
+    to fp16 (checked per policy through the engine)."""
+    import tempfile
+    from gritlm_amd import GritLM
+    from gritlm_amd._lib import GritHipError
+    cfgd = dict(synth.CONFIGS["7b-l1"]); cfgd["num_hidden_layers"] = 2
+    sents = [" ".join(synth.WORDS[(7 * i + j) % len(synth.WORDS)] for j in range(20 + 3 * i)) for i in range(6)]
+    out, ok = {}, True
+    # down_proj rows x 1e5: the MLP output of a N(0, 0.02) layer is ~1.2, so channels 7 / 11 of the stream reach ~1e5 (fp16: 65504) while
+    # every MFMA operand stays small (RMSNorm output <= sqrt(H / 2) = 45).  gate / up x 100: pre-activations ~ N(0, 128^2), silu(g) * u up to
+    # ~3e5 -> the SwiGLU epilogue's fp16 rounding overflows under both fp16 policies (and the stream, ~4e4 rms, leaves fp16 as well)
+    cases = {"tame": (None, None, "f16_stream"), "massive_stream": (1.0e5, None, "f16_operands"), "massive_act": (None, 100.0, "fp32_residual")}
+    with tempfile.TemporaryDirectory() as td:
+        for name, (dscale, guscale, want) in cases.items():
+            w = synth.make_weights(cfgd, 3)
+            if dscale:
+                for li in range(2):
+                    k = f"layers.{li}.mlp.down_proj.weight"
+                    d = w[k].copy(); d[7, :] *= dscale; d[11, :] *= dscale
+                    w[k] = O.bf16_round(d)
+            if guscale:
+                for k in list(w):
+                    if "gate_proj" in k or "up_proj" in k:
+                        w[k] = O.bf16_round(w[k] * guscale)
+            d16 = synth.build_mistral_dir(os.path.join(td, name), cfgd, 3, "bfloat16", weights=w)
+            m = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda:0", torch_dtype=torch.bfloat16, precision="auto")
+            ok &= m.engine is not None and m.precision == "f16_stream"
+            e = m.encode(sents, batch_size=4, max_length=64)
+            out[f"{name}_rung"] = m.precision
+            ok &= m.precision == want and bool(np.isfinite(e).all())
+            e_again = m.encode(sents, batch_size=4, max_length=64)
+            ok &= m.precision == want and np.array_equal(e, e_again)                    # sticky rung, deterministic rows
+            m0 = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda:0", torch_dtype=torch.bfloat16)
+            e0 = m0.encode(sents, batch_size=4, max_length=64)
+            c = float(np.max(1 - np.sum(e.astype(np.float64) * e0.astype(np.float64), axis=1)))
+            out[f"{name}_1-cos_vs_bf16_policy"] = c
+            ok &= c < 2e-3
+            if want != "f16_stream":                                                   # the explicit policy raises, names the device, clears
+                mx = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda:0", torch_dtype=torch.bfloat16, precision="f16_stream")
+                try:
+                    mx.encode(sents, batch_size=4, max_length=64); out[f"{name}_explicit_raises"] = False
+                except GritHipError as ex:
+                    out[f"{name}_explicit_raises"] = "fp16 range" in str(ex) and "cuda:0" in str(ex)
+                ok &= out[f"{name}_explicit_raises"] is True
+                mx.set_precision("bf16")
+                ok &= bool(np.isfinite(mx.encode(sents, batch_size=4, max_length=64)).all())       # no stale flag blamed on the next call
+                del mx
+            # stream magnitude actually reached (bf16 policy, residual stream before the final norm)
+            ids = m0.tokenizer(sents, padding=True, truncation=True, return_tensors="pt", max_length=64)
+            hs = m0.engine.forward(ids["input_ids"], ids["attention_mask"], final_norm=False)
+            out[f"{name}_max_abs_residual_stream"] = float(hs.float().abs().max())
+            del m, m0
+            torch.cuda.empty_cache()
+    ok &= out["massive_stream_max_abs_residual_stream"] > 65504.0 > out["tame_max_abs_residual_stream"]
+    return _res("GritLM(precision='auto'): ladder on massive-activation models at the 7B layer shape", bool(ok), **out)
+
+
+def check_get_cache_f16():
+    """encode(get_cache=True) under the fp16 policies: the embeddings keep the policy's accuracy (within 1e-5 of the no-cache call), the
+    cache comes back in the reference's format (bf16 [B,nkv,S,d] per layer) within one bf16 ulp of the fp32-accurate K / V -- closer to
+    the fp32 Hugging Face module's cache than the bf16 policy's cache is --, engine.forward(kv_dtype=None) hands out the fp16 K / V the
+    attention itself read (ONE rounding from the fp32 accumulator), and the native decoder continues from the cache."""
+    import tempfile
+    from gritlm_amd import GritLM
+    g = np.load(os.path.join(GOLDEN, "gritlm_encode.npz"))
+    sents = [str(x) for x in g["sentences"]][:5]
+    out, ok = {}, True
+    get = lambda c, li: (c.layers[li].keys, c.layers[li].values) if hasattr(c, "layers") else (c[li][0], c[li][1])
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        d32 = synth.build_mistral_dir(os.path.join(td, "m32"), "tiny", 0, "float32")
+        hf = GritLM(d32, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.float32, native=False)
+        emb32, cache32 = hf.encode(sents, max_length=48, get_cache=True)
+        mb = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16)
+        _, cache_b = mb.encode(sents, max_length=48, get_cache=True)
+        for pol in ("f16_operands", "f16_stream"):
+            m = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, precision=pol)
+            emb, cache = m.encode(sents, max_length=48, get_cache=True)
+            emb_nc = m.encode(sents, max_length=48)
+            c = float(np.max(1 - np.sum(emb.astype(np.float64) * emb32.astype(np.float64), axis=1)))
+            out[f"emb_1-cos_vs_fp32[{pol}]"] = c
+            ok &= c < 1e-5 and float(np.max(1 - np.sum(emb * emb_nc, axis=1))) < 1e-6
+            worst = worst_b = 0.0
+            for li in range(2):
+                for a, b, r in zip(get(cache, li), get(cache_b, li), get(cache32, li)):
+                    ok &= a.dtype == torch.bfloat16 and tuple(a.shape) == tuple(r.shape)
+                    sc = float(r.float().abs().max()) + 1e-9
+                    worst = max(worst, float((a.float() - r.float()).abs().max()) / sc)
+                    worst_b = max(worst_b, float((b.float() - r.float()).abs().max()) / sc)
+            out[f"kv_max_rel_vs_fp32[{pol}]"], out["kv_max_rel_vs_fp32[bf16]"] = worst, worst_b
+            ok &= worst <= 2.0 ** -8 and worst <= worst_b
+            ids = m.tokenizer(sents, padding=True, truncation=True, return_tensors="pt", max_length=48)
+            _, kv16 = m.engine.forward(ids["input_ids"], ids["attention_mask"], return_kv=True, kv_dtype=None)
+            ok &= kv16[0][0].dtype == torch.float16
+            k16 = kv16[1][0].float(); r = get(cache32, 1)[0].float()
+            out[f"k_fp16_max_rel_vs_fp32[{pol}]"] = float((k16 - r).abs().max() / (r.abs().max() + 1e-9))
+            ok &= out[f"k_fp16_max_rel_vs_fp32[{pol}]"] < 2.0 ** -10
+            if hasattr(m.model, "lm_head"):
+                with torch.no_grad():
+                    q = m.tokenizer([" ".join(synth.WORDS[5:12])], return_tensors="pt", add_special_tokens=False)["input_ids"].to(DEV)
+                    plen = int(m.tokenizer([sents[0]], return_tensors="pt", truncation=True, max_length=48)["input_ids"].shape[1])
+                    one = [(get(cache, li)[0][:1, :, :plen].contiguous(), get(cache, li)[1][:1, :, :plen].contiguous()) for li in range(2)]
+                    toks = m.native_decoder().generate(q, 3, past_key_values=one)
+                    toks2 = m.native_decoder().generate(q, 3)                                  # prompt prefill under an fp16 policy: runs, policy restored
+                ok &= tuple(toks.shape) == (1, 3) and tuple(toks2.shape) == (1, 3) and m.engine.precision == pol
+            del m
+    return _res("encode(get_cache=True) under the fp16 policies", bool(ok), **out)
+
+
 ALL_CHECKS = [
     ("embed", check_embed, {}),
     ("rmsnorm_4096", check_rmsnorm, dict(T=37, H=4096)),
@@ -3171,6 +3649,20 @@ ALL_CHECKS = [
     ("encoder_gqa_f16_stream", check_encoder_f16_operands, dict(cfg_name="gqa", policy="f16_stream")),
     ("encoder_7b_layer_f16_stream", check_encoder_f16_operands, dict(cfg_name="7b-l1", policy="f16_stream")),
     ("f16_policy_raises_on_overflow", check_f16_policy_raises_on_overflow, {}),
+    ("gemm_f16_swiglu_stacked", check_gemm_f16_stacked, {}),
+    ("gemm_f16_grouped_store", check_gemm_f16_grouped, {}),
+    ("gemm_f16_grouped_swiglu", check_gemm_f16_grouped, dict(N=512, epi=EPI_SWIGLU)),
+    ("moe_router_f32", check_moe_router_f32, {}),
+    ("moe_router_f32_16e", check_moe_router_f32, dict(T=300, H=4096, E=16)),
+    ("moe_combine_f32", check_moe_combine_f32, {}),
+    ("mixtral_f16_operands_moe-tiny", check_mixtral_f16_operands, {}),
+    ("mixtral_layer_true_shape_8x7b_f16_original_criteria", check_mixtral_layer_true_shape_f16, {}),
+    ("train_nograd_f16_operands_equals_encoder", check_train_nograd_f16_equals_encoder, {}),
+    ("train_nograd_f16_stream_equals_encoder", check_train_nograd_f16_equals_encoder, dict(policy="f16_stream")),
+    ("train_nograd_f16_mixtral", check_train_nograd_f16_mixtral, {}),
+    ("gradcache_f16_pass1_7b_layer", check_gradcache_f16_pass1, {}),
+    ("gritlm_f16_auto_ladder", check_gritlm_f16_auto_ladder, {}),
+    ("get_cache_f16", check_get_cache_f16, {}),
     ("gritlm_f16_operands", check_gritlm_f16_operands, {}),
     ("gemm_full_swiglu_28672x4096", check_gemm_fullshape, dict(M=4096, N=28672, K=4096, epi=EPI_SWIGLU)),
     ("gemm_full_residual_4096x14336", check_gemm_fullshape, dict(M=4096, N=4096, K=14336, epi=EPI_RESIDUAL)),

@@ -154,14 +154,15 @@ def make_sentences(n: int, seed: int = 5, min_words: int = 3, max_words: int = 1
     return out
 
 
-def build_mistral_dir(path: str, cfg_name: str = "tiny", seed: int = 0, dtype="float32") -> str:
-    """MistralForCausalLM with the synthetic weights of make_weights + tokenizer, saved to ``path``."""
+def build_mistral_dir(path: str, cfg_name="tiny", seed: int = 0, dtype="float32", weights: dict | None = None) -> str:
+    """MistralForCausalLM with the synthetic weights of make_weights (or the given ``weights``) + tokenizer, saved to ``path``;
+    ``cfg_name``: a CONFIGS key or a config dict."""
     import torch
     from transformers import MistralForCausalLM
-    cfg = CONFIGS[cfg_name]
+    cfg = CONFIGS[cfg_name] if isinstance(cfg_name, str) else cfg_name
     hc = hf_config(cfg)
     model = MistralForCausalLM(hc)
-    w = make_weights(cfg, seed)
+    w = make_weights(cfg, seed) if weights is None else weights
     sd = {"model." + k: torch.from_numpy(v) for k, v in w.items()}
     rng = np.random.default_rng(seed + 99)
     sd["lm_head.weight"] = torch.from_numpy(_bf16_round(rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"]), dtype=np.float32) * 0.02))
