@@ -147,7 +147,8 @@ def vendor_gemm_sustained(dev, layers=8, passes=2, M=DOCS * SEQ):
     return out
 
 
-def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, steps=1, warmup=1, ragged_pairs=32):
+def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, steps=1, warmup=1, ragged_pairs=32, pass1_precision="f16_stream",
+                    parity_pairs=16, parity_loss_pairs=64):
     """Second headline metric: contrastive pairs/s on BASELINE configs[2] as stated -- per rank 256 queries + 2048 passages
     (1 positive + 7 negatives each) @ seq512, GradCache chunk 32 (scripts/training/train_gritlm_7b.sh:60-67; gritlm/training/run.py:93-104).
     One step = pass 1 (no grad) -> chunk-wise all-gather of the reps (N > 1) -> fused InfoNCE (similarity [W*256, W*2048] + CE + rep
@@ -163,7 +164,9 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
     m.train_engine = MistralTrainEngine(bb, cfg, dev)
     m.train_engine.cache_transposed_weights = True      # W^T reused by every GradCache chunk of a step (invalidated after AdamW)
     opt = torch.optim.AdamW(bb.parameters(), lr=1e-5, fused=True)
-    gc = GradCacheStep(m, chunk)
+    # pass 1 (the no-grad forward that defines the representations and the loss) under the policy that meets the north-star's loss tolerance
+    # at depth 32 (fp16 MFMA operands, fp16 residual stream; `parity` below holds it -- and the all-bf16 step -- against the fp32 reference)
+    gc = GradCacheStep(m, chunk, precision=pass1_precision)
     gen = torch.Generator(device=dev).manual_seed(4321 + rank)
     mk = lambda n: {"input_ids": torch.randint(3, cfg.vocab_size, (n, SEQ), generator=gen, device=dev, dtype=torch.int64),
                     "attention_mask": torch.ones((n, SEQ), dtype=torch.int64, device=dev)}
@@ -208,6 +211,19 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
         prof["gather_gbps_over_exposed_time"] = (prof["gather_bytes_received"] / (ex * 1e-3) / 1e9) if ex > 0 else None
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     pairs_per_s = world * pairs * steps / dt
+    pass1_overflow = None
+    if pass1_precision != "bf16":
+        from gritlm_amd import ops as _ops
+        pass1_overflow = bool(_ops.f16_overflow_flag(dev))
+    parity = None
+    if parity_pairs:
+        try:
+            pols = ("bf16",) + tuple(x for x in ("f16_stream", "f16_operands") if x == pass1_precision or (pass1_precision == "bf16" and x == "f16_stream"))
+            parity = contrastive_parity(m, bb, cfg, opt, q, p, dev, chunk, group, pairs=min(parity_pairs, pairs), policies=pols,
+                                        loss_pairs=min(parity_loss_pairs, pairs))
+        except Exception as e:  # noqa: BLE001
+            parity = {"error": repr(e)[:300]}
+        gc = GradCacheStep(m, chunk, precision=pass1_precision)          # (the parity leg left the engine on its last policy)
 
     # ragged training batch (rank-local, outside the timed region above, smaller batch): lengths U{64..512} right-padded to 512 --
     # padded rows through every kernel (what the reference's SDPA path does) vs the packed (un-padded) training path
@@ -241,12 +257,174 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
             "pairs_per_gpu_per_step": pairs, "group_size": group, "gradcache_chunk": chunk,
             "gradcache_pass1_rows_per_call": gc.pass1_chunk_size,      # pass 1 keeps nothing: several chunks per call, same bits
             "global_batch": world * pairs, "loss": float(loss), "peak_hbm_gib": peak_gb,
+            "pass1_precision": pass1_precision, "pass1_fp16_overflow_flag": pass1_overflow, "parity": parity,
             "includes": "GradCache pass 1 + rep all-gather + InfoNCE + pass 2 fwd/bwd + grad all-reduce + AdamW",
             "config": f"BASELINE configs[2]: {pairs} (q, pos, 7 neg) per GPU @ seq512, chunk {chunk}, tau 0.02, mean pooling, cross-device negatives"
                       + ("" if pairs == 256 and chunk == 32 else "  [REDUCED from 256 pairs / chunk 32]"),
             "mfma_roofline_frac": pairs_per_s / world * alg_flops_per_pair / (MFMA_BF16_PEAK_TFLOPS * 1e12),
             "per_step_ms": prof,
             **({"ragged_batch": ragged} if ragged is not None else {})}
+
+
+def contrastive_parity(m, bb, cfg, opt, q, p, dev, chunk, group, pairs=16, tau=0.02, policies=("bf16", "f16_stream"), loss_pairs=64):
+    """Full-depth parity datum of BASELINE configs[2] (VERDICT r05 #1a): a sub-batch of `pairs` (query, 1 + 7 passages) units of the timed
+    batch -- on the leg's OWN 32-layer weights, as the timed steps left them -- through (1) the engine's GradCache step (pass 1 under each
+    pass-1 policy, InfoNCE on HIP, pass 2 forward + backward in bf16; no optimizer step) and (2) the reference's training forward
+    (gritlm/training/model.py:134-222: encode -> pool -> normalise -> scores / tau -> CrossEntropy(arange * group)) + backward in FP32 on the
+    stock transformers module loaded from the same weights (oracle/torch_reference.py::encode_with_grad, gradient checkpointing as the
+    reference trains).  Reported per policy: max 1 - cos of the pass-1 representations, |loss - fp32 loss| against the north-star's 1e-3, and
+    the parameter gradients against the fp32 gradients (relative l2 and cosine per weight matrix: median / worst over the 7 x 32 matrices).
+    `loss_pairs` (> pairs): the LOSS datum again on a larger sub-batch, forward only on both sides (engine: pass-1 representations + the
+    HIP InfoNCE kernel; reference: fp32 module + torch cross entropy) -- with 1 / tau = 50 one score moves the loss of n queries by
+    ~50 sqrt(2 (1 - cos)) / (64 sqrt(n)), so the number of queries the loss averages over matters for the 1e-3 (configs[2] has 256 per GPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_reference as TR
+    from gritlm_amd.training.gradcache import GradCacheStep
+    from gritlm_amd.training.model import DistributedContrastiveLoss
+    n_q, n_p = pairs, pairs * group
+    qs = {k: v[:n_q].contiguous() for k, v in q.items()}
+    ps = {k: v[:n_p].contiguous() for k, v in p.items()}
+    names = [n for n, t in bb.named_parameters() if t.dim() == 2 and "embed" not in n]
+    out = {"what": f"{pairs} (query, 1 + {group - 1} passages) units of the timed batch x {SEQ} tokens, the leg's own {cfg.num_hidden_layers}-layer weights after its "
+                   "timed steps: engine GradCache step (pass 1 under the named policy, pass 2 + backward in bf16, no optimizer step) vs the reference's "
+                   "training forward + backward in FP32 on the stock module (gradient checkpointing), same weights, same rows",
+           "pairs": pairs, "tokens": (n_q + n_p) * SEQ, "temperature": tau}
+    # ---- engine side, per pass-1 policy (local loss: the sub-batch is this rank's own rows)
+    keep_loss, eng_side = m.emb_loss_fn, {}
+    m.emb_loss_fn = DistributedContrastiveLoss(tau, False)
+    try:
+        for pol in policies:
+            opt.zero_grad(set_to_none=True)
+            gcp = GradCacheStep(m, chunk, precision=pol)
+            loss = gcp(dict(qs), dict(ps), sync=False)
+            torch.cuda.synchronize()
+            flag = False
+            if pol != "bf16":
+                from gritlm_amd import ops
+                flag = bool(ops.f16_overflow_flag(dev))
+            eng_side[pol] = {"loss": float(loss.item()), "q": gcp.last_reps[0].double().clone(), "p": gcp.last_reps[1].double().clone(),
+                             "grads": {n: dict(bb.named_parameters())[n].grad.detach().clone() for n in names}, "fp16_overflow_flag": flag}
+        opt.zero_grad(set_to_none=True)
+    finally:
+        m.emb_loss_fn = keep_loss
+    m.train_engine._tbuf.clear(); m.train_engine._wT.clear(); m.train_engine._w16.clear(); m.train_engine._ws16.clear()
+    torch.cuda.empty_cache()
+    # ---- reference side: fp32, autograd
+    t0 = time.perf_counter()
+    cfgd = dict(TR.SHAPE_7B, num_hidden_layers=cfg.num_hidden_layers)
+    ref = TR.build_model(cfgd, torch.float32, dev, state_dict={k: v.detach() for k, v in bb.state_dict().items()})
+    ref.train()
+    doc_chunk = 16
+    enc = lambda b: torch.cat([TR.encode_with_grad(ref, b["input_ids"][i:i + doc_chunk], b["attention_mask"][i:i + doc_chunk])
+                               for i in range(0, b["input_ids"].shape[0], doc_chunk)])
+    rq, rp = enc(qs), enc(ps)
+    ref_loss = TR.contrastive_loss(rq, rp, tau)
+    ref_loss.backward()
+    torch.cuda.synchronize()
+    rgrads = dict(ref.named_parameters())
+    out["reference_fp32"] = {"loss": float(ref_loss.item()), "seconds": time.perf_counter() - t0}
+    omc = lambda a, b: float((1.0 - torch.nn.functional.cosine_similarity(a, b.double(), dim=1)).max())
+    for pol, d in eng_side.items():
+        rel, cosg = [], []
+        for n in names:
+            g, r = d["grads"][n].double(), rgrads[n].grad.double()
+            rel.append(float((g - r).norm() / (r.norm() + 1e-30)))
+            cosg.append(float((g * r).sum() / (g.norm() * r.norm() + 1e-30)))
+        rel_t, cos_t = torch.tensor(rel), torch.tensor(cosg)
+        err = abs(d["loss"] - out["reference_fp32"]["loss"])
+        out[pol] = {"pass1_precision": pol, "loss": d["loss"], "loss_abs_err": err, "loss_within_1e-3": bool(err < 1e-3),
+                    "reps_max_one_minus_cos": max(omc(d["q"], rq.detach()), omc(d["p"], rp.detach())),
+                    "grad_rel_l2_median": float(rel_t.median()), "grad_rel_l2_worst": float(rel_t.max()),
+                    "grad_cos_median": float(cos_t.median()), "grad_cos_min": float(cos_t.min()), "weight_matrices_compared": len(names),
+                    "fp16_overflow_flag": d["fp16_overflow_flag"]}
+    del rgrads, rq, rp
+    ref.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+    # ---- the loss datum on `loss_pairs` pairs, forward only
+    if loss_pairs and loss_pairs > pairs:
+        from gritlm_amd import ops
+        t1 = time.perf_counter()
+        nq2, np2 = min(loss_pairs, q["input_ids"].shape[0]), min(loss_pairs, q["input_ids"].shape[0]) * group
+        ql = {k: v[:nq2].contiguous() for k, v in q.items()}
+        pl = {k: v[:np2].contiguous() for k, v in p.items()}
+        ref.eval()
+        with torch.no_grad():
+            renc = lambda b: torch.cat([TR.encode(ref, b["input_ids"][i:i + 32], b["attention_mask"][i:i + 32]) for i in range(0, b["input_ids"].shape[0], 32)])
+            rq2, rp2 = renc(ql), renc(pl)
+            l_ref = float(TR.contrastive_loss(rq2.double(), rp2.double(), tau))
+            big = {"pairs": nq2, "tokens": (nq2 + np2) * SEQ, "reference_fp32_loss": l_ref}
+            for pol in policies:
+                m.train_engine.set_nograd_precision(pol)
+                eenc = lambda b: torch.cat([m.encode({k: v[i:i + 128] for k, v in b.items()}) for i in range(0, b["input_ids"].shape[0], 128)])
+                eq, ep = eenc(ql), eenc(pl)
+                l_eng = float(ops.infonce(eq.float().contiguous(), ep.float().contiguous(), tau, want_grad=False)[0].item())
+                big[pol] = {"loss": l_eng, "loss_abs_err": abs(l_eng - l_ref), "loss_within_1e-3": bool(abs(l_eng - l_ref) < 1e-3),
+                            "reps_max_one_minus_cos": max(omc(eq.double(), rq2), omc(ep.double(), rp2)),
+                            "fp16_overflow_flag": bool(ops.f16_overflow_flag(dev)) if pol != "bf16" else False}
+                del eq, ep
+        big["seconds"] = time.perf_counter() - t1
+        out["loss_on_larger_sub_batch"] = big
+        del rq2, rp2
+    lsrc = out.get("loss_on_larger_sub_batch") or out
+    best = next((pol for pol in policies if pol != "bf16" and lsrc[pol]["loss_within_1e-3"] and out[pol]["loss_abs_err"] < 2e-3
+                 and max(out[pol]["reps_max_one_minus_cos"], lsrc[pol]["reps_max_one_minus_cos"]) < 1e-4
+                 and not out[pol]["fp16_overflow_flag"] and not lsrc[pol]["fp16_overflow_flag"]), None)
+    out["north_star_policy"] = best
+    out["north_star_met"] = best is not None
+    # the leg's headline parity number: |loss - fp32 loss| of the north-star policy on the largest sub-batch measured
+    out["loss_abs_err"] = lsrc[best]["loss_abs_err"] if best else lsrc[policies[-1]]["loss_abs_err"]
+    out["loss_abs_err_pairs"] = lsrc.get("pairs", pairs)
+    del ref, eng_side
+    torch.cuda.empty_cache()
+    return out
+
+
+def compact_summary(line: dict) -> dict:
+    """<= 1500 characters, appended as the LAST key of the JSON line (VERDICT r05 #2b: the driver keeps the last 2000 characters): every
+    headline number of the round -- both metrics, the roofline fractions, the parity data per leg, the same-run comparators."""
+    def g(d, *ks):
+        for k in ks:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    def r(x, n=4):
+        if isinstance(x, float):
+            return float(f"{x:.{n}g}")
+        return x
+    ns, c, mx, rag = line.get("north_star_policy") or {}, line.get("contrastive") or {}, line.get("mixtral_8x7b_seq2048") or {}, line.get("rag_doc_caching") or {}
+    cp = c.get("parity") or {}
+    cpb = cp.get(cp.get("north_star_policy") or "") or {}
+    mp = mx.get("parity") or {}
+    s = {"encode_docs_per_s": r(line.get("value")), "n_gpus": line.get("n_gpus"), "gemm_frac": r(g(line, "roofline", "frac")), "mfu": r(line.get("model_flops_utilisation")),
+         "default_bf16_1mcos": r(g(line, "parity_full_depth", "vs_reference_fp32_same_weights", "engine_bf16_residual_default", "max_one_minus_cos")),
+         "ns_policy": ns.get("precision"), "ns_docs_per_s": r(ns.get("docs_per_s")), "ns_1mcos": r(ns.get("max_one_minus_cos_timed_batch")),
+         "ns_timed_steps": ns.get("timed_steps"), "north_star_met": line.get("north_star_met"),
+         "gemm_over_vendor": [r(line.get("gemm_over_vendor_in_model")), r(line.get("gemm_over_vendor_sustained"))],
+         "vs_rocm_torch": r(line.get("speedup_vs_rocm_torch")),
+         "contrastive": {"pairs_per_s": r(c.get("value")), "frac": r(c.get("mfma_roofline_frac")), "steps": c.get("steps"), "pass1": c.get("pass1_precision"),
+                         "loss_abs_err": r(cp.get("loss_abs_err")), "loss_err_pairs": cp.get("loss_abs_err_pairs"),
+                         "loss_abs_err_bf16": r(g(cp, "loss_on_larger_sub_batch", "bf16", "loss_abs_err") or g(cp, "bf16", "loss_abs_err")),
+                         "reps_1mcos": r(cpb.get("reps_max_one_minus_cos")), "grad_cos_min": r(cpb.get("grad_cos_min")),
+                         "grad_rel_l2_median": r(cpb.get("grad_rel_l2_median")), "north_star_met": cp.get("north_star_met"), "err": (c.get("error") or cp.get("error"))},
+         "mixtral": {"docs_per_s": r(mx.get("value")), "grouped_gemm_frac": r(g(mx, "roofline", "frac")), "f16_docs_per_s": r(g(mx, "north_star_policy", "docs_per_s")),
+                     "f16_e2e_1mcos": r(g(mp, "policies", "f16_operands", "end_to_end", "max_one_minus_cos")),
+                     "f16_routing_agree_min": r(min([v["routing_agree"] for v in (g(mp, "policies", "f16_operands", "teacher_forced_per_layer") or {}).values()] or [0.0])),
+                     "bf16_e2e_1mcos": r(g(mp, "policies", "bf16", "end_to_end", "max_one_minus_cos")),
+                     "ref_bf16_dataflow_e2e_1mcos": r(g(mp, "reference_dataflow_in_bf16_end_to_end", "max_one_minus_cos")),
+                     "north_star_met": mp.get("north_star_met"), "err": mx.get("error")},
+         "rag": {"decode_frac": r(rag.get("decode_frac_of_weight_streaming_roofline")), "encode_frac": r(rag.get("encode_mfma_roofline_frac")),
+                 "decode_logits_1mcos_bf16_level": r(g(rag, "parity", "max_one_minus_cos")),
+                 "encode_get_cache_1mcos": {k: r(g(rag, "parity", "encode_get_cache_by_policy", k, "max_one_minus_cos")) for k in ("bf16", "f16_stream", "f16_operands")},
+                 "err": rag.get("error")}}
+
+    def prune(d):
+        return {k: (prune(v) if isinstance(v, dict) else v) for k, v in d.items() if v is not None and v != {}}
+    s = prune(s)
+    while len(json.dumps(s)) > 1500 and s:                 # never longer than the window: drop the least important tail entries
+        s.pop(next(reversed(s)))
+    return s
 
 
 def secondary_leg(script: str, argv: list, timeout_s: float, keep: tuple) -> dict:
@@ -396,7 +574,7 @@ NORTH_STAR_NOTE = ("north_star asks 1 - cos < 1e-4 against the reference's fp32 
                    "flagged) is the policy held to 1e-4 here; the per-operand error budget it was derived from is profiles/r05_precision_budget.json")
 
 
-def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32, chunk=8, time_steps=3):
+def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32, chunk=8, time_steps=3, north_star_steps=None):
     """`encode()` at configs[1], not a synthetic side case (VERDICT r03 #1a): the engine's embeddings of the first `docs` documents of the TIMED
     batch against the reference-equivalent module (oracle/torch_reference.py: the stock transformers module driven with the reference's mask
     rule -- no mask for an all-valid batch, modeling_mistral_gritlm.py:1017-1020 --, pinned bit for bit on reference-generated fixtures) in
@@ -427,23 +605,33 @@ def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32
            "docs": n, "layers": layers}
     d = omc(emb_default[:n], ref)
     out["engine_bf16_residual_default"] = {**d, "bound": BENCH_BOUND_BF16_RESIDUAL, "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_BF16_RESIDUAL}
-    def opt_in(policy):
+    def opt_in(policy, n_steps=None):
+        """``n_steps``: timed EXACTLY like the headline (VERDICT r05 #2a): one warm-up pass, then n_steps steps with a HIP event at every step
+        boundary on the launch stream, bracketed by synchronize(); rate = docs x steps / wall time of the bracket, per-step median / min from
+        the events."""
+        n_steps = n_steps or time_steps
         eng.set_precision(policy)
         try:
             e = ops.pool_norm(eng.forward(si, sm, borrow=True), sm, "mean", True).float().clone()
             d = omc(e, ref)
             rate, extra = None, {}
-            if time_steps:
+            if n_steps:
                 ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
                 torch.cuda.synchronize()
                 tm = ops.KernelTimer()                 # the same per-launch HIP events as the primary timed region
                 ops.set_timer(tm)
+                marks = []
                 t0 = time.perf_counter()
-                for _ in range(time_steps):
+                for _ in range(n_steps):
+                    marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
                     ops.pool_norm(eng.forward(ids, mask, borrow=True), mask, "mean", True)
+                marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
                 torch.cuda.synchronize()
-                rate = ids.shape[0] * time_steps / (time.perf_counter() - t0)
+                rate = ids.shape[0] * n_steps / (time.perf_counter() - t0)
                 ops.set_timer(None)
+                sm_ = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+                extra["timed_steps"] = n_steps
+                extra["per_step"] = {"median_ms": sm_[len(sm_) // 2], "min_ms": sm_[0], "max_ms": sm_[-1], "mean_ms": 1e3 * ids.shape[0] / rate}
                 extra["kernels"] = {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 3), "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12,
                                         **({"by_shape_tflops": {t: round(x["work"] / (x["total_ms"] * 1e-3) / 1e12, 1) for t, x in v["by_tag"].items()}}
                                            if "by_tag" in v else {})} for k, v in tm.summary().items()}
@@ -459,7 +647,7 @@ def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32
     d, rate, extra = opt_in("fp32_residual")
     out["engine_fp32_residual_opt_in"] = {**d, "bound": BENCH_BOUND_FP32_RESIDUAL, "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_FP32_RESIDUAL,
                                           "docs_per_s": rate, **extra, "how": "GritLM(..., precision='fp32_residual') / engine.set_precision('fp32_residual')"}
-    d, rate, extra = opt_in("f16_operands")
+    d, rate, extra = opt_in("f16_operands", north_star_steps)
     out["engine_f16_operands_opt_in"] = {**d, "bound": BENCH_BOUND_F16_OPERANDS,
                                          "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_F16_OPERANDS and not extra.get("fp16_overflow_flag", True),
                                          "docs_per_s": rate, **extra, "how": "GritLM(..., precision='f16_operands') / engine.set_precision('f16_operands'): "
@@ -467,7 +655,7 @@ def parity_same_weights(eng, hf_sd, ids, mask, emb_default, dev, layers, docs=32
     out["stock_module_bf16_this_gpu"] = {**omc(e_stock, ref), "what": "stock transformers module, bf16, sdpa, the reference's mask rule, same weights, "
                                          "through PyTorch-ROCm: what the reference's Python computes on this GPU (reported; bounds nothing)"}
     out["engine_default_vs_stock_module_bf16"] = omc(emb_default[:n], e_stock)
-    d, rate, extra = opt_in("f16_stream")
+    d, rate, extra = opt_in("f16_stream", north_star_steps)
     out["engine_f16_stream_opt_in"] = {**d, "bound": BENCH_BOUND_F16_OPERANDS,
                                        "within_bound": d["max_one_minus_cos"] < BENCH_BOUND_F16_OPERANDS and not extra.get("fp16_overflow_flag", True),
                                        "docs_per_s": rate, **extra, "how": "GritLM(..., precision='f16_stream'): f16_operands with the residual stream "
@@ -565,6 +753,13 @@ def main():
     ap.add_argument("--pairs", type=int, default=256, help="contrastive pairs per GPU per step (BASELINE configs[2]: 256)")
     ap.add_argument("--chunk", type=int, default=32, help="GradCache chunk size (BASELINE configs[2]: 32)")
     ap.add_argument("--contrastive-steps", type=int, default=3, help="timed contrastive steps (after one warm-up step); ~52 s each at configs[2]")
+    ap.add_argument("--pass1-precision", default="f16_stream", choices=("bf16", "f16_stream", "f16_operands"),
+                    help="precision policy of GradCache pass 1 in the contrastive leg (the pass that defines the loss); default: the policy that "
+                         "meets the north-star's |loss - fp32 loss| < 1e-3 at depth 32")
+    ap.add_argument("--contrastive-parity-pairs", type=int, default=16, help="pairs of the timed batch re-run through the fp32 reference "
+                    "(forward + backward) for the contrastive leg's parity object; 0 = skip")
+    ap.add_argument("--contrastive-parity-loss-pairs", type=int, default=64, help="pairs for the forward-only loss datum of that object "
+                    "(256 = the whole per-GPU batch of configs[2]: ~3 more minutes of fp32 reference)")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm encode on this GPU")
     ap.add_argument("--no-mixtral", action="store_true", help="skip the BASELINE configs[3] leg (Mixtral-8x7B shape, 64 x seq2048)")
     ap.add_argument("--no-rag", action="store_true", help="skip the BASELINE configs[4] leg (512 passages x seq2048 with KV + 128 new tokens)")
@@ -719,7 +914,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             torch_baseline = {"error": repr(e)[:300]}
         try:
-            parity_sw = parity_same_weights(eng, hf_sd, ids, mask, emb_engine, dev, args.layers)
+            parity_sw = parity_same_weights(eng, hf_sd, ids, mask, emb_engine, dev, args.layers, north_star_steps=args.steps)
         except Exception as e:  # noqa: BLE001
             parity_sw = {"error": repr(e)[:300]}
         try:
@@ -784,7 +979,8 @@ def main():
             else:
                 torch.cuda.reset_peak_memory_stats()
                 contrastive = contrastive_leg(cfg, dev, world, rank, dist, pairs=args.pairs, chunk=args.chunk, steps=args.contrastive_steps,
-                                              ragged_pairs=0 if args.no_ragged else 32)
+                                              ragged_pairs=0 if args.no_ragged else 32, pass1_precision=args.pass1_precision,
+                                              parity_pairs=args.contrastive_parity_pairs, parity_loss_pairs=args.contrastive_parity_loss_pairs)
         except Exception as e:  # noqa: BLE001  -- never lose the primary metric line to the secondary leg
             contrastive = {"error": repr(e)[:300]}
 
@@ -838,7 +1034,10 @@ def main():
             ok_c = {k: v for k, v in cands.items() if v.get("within_bound") and (v.get("max_one_minus_cos") or 1.0) < 1e-4}
             best = max(ok_c, key=lambda k: ok_c[k].get("docs_per_s") or 0.0) if ok_c else "f16_operands"
             line["north_star_policy"] = {"precision": best, "max_one_minus_cos_timed_batch": cands[best].get("max_one_minus_cos"),
-                                         "docs_per_s": cands[best].get("docs_per_s"),
+                                         "docs_per_s": cands[best].get("docs_per_s"), "timed_steps": cands[best].get("timed_steps"),
+                                         "per_step": cands[best].get("per_step"),
+                                         "how_timed": "like the headline: one warm-up pass, then --steps steps, a HIP event per step boundary on the launch "
+                                                      "stream, synchronize() on both sides",
                                          "docs_per_s_over_default": (cands[best].get("docs_per_s") or 0.0) / docs_per_s,
                                          "all": {k: {"max_one_minus_cos": v.get("max_one_minus_cos"), "docs_per_s": v.get("docs_per_s"),
                                                      "docs_per_s_over_default": (v.get("docs_per_s") or 0.0) / docs_per_s} for k, v in cands.items()}}
@@ -850,13 +1049,15 @@ def main():
                 line["mixtral_8x7b_seq2048"] = secondary_leg(
                     "mixtral_bench.py", ["--docs", 64, "--seq", 2048, "--steps", 3, "--warmup", 1], 420,
                     ("metric", "value", "unit", "ms_per_step", "tokens_per_s", "config", "roofline", "model_flops_utilisation", "hbm_allocated_gb",
-                     "expert_load_max_over_mean", "finite", "kernels", "parity"))
+                     "expert_load_max_over_mean", "finite", "kernels", "parity", "north_star_policy"))
             if not args.no_rag:
                 line["rag_doc_caching"] = secondary_leg(
                     "rag_cache_bench.py", ["--passages", 512, "--seq", 2048, "--new-tokens", 128, "--queries", 4], 600,
                     ("metric", "passages", "seq", "encode_s", "passages_per_s", "encode_tokens_per_s", "encode_mfma_roofline_frac", "kv_cache_gb",
                      "generate_s_per_query", "decode_tokens_per_s", "decode_path", "native_decode", "decode_frac_of_weight_streaming_roofline", "parity",
                      "hbm_allocated_gb"))
+        if not dry:
+            line["summary"] = compact_summary(line)          # LAST key: the tail of the line the driver keeps holds the round's numbers
         emit(json.dumps(line))
         emitted.append(True)
     if dist is not None:

@@ -48,15 +48,16 @@ def compute() -> dict:
         for n in TRAIN_NAMES:
             ref, ref16 = g[f"grad_{key}/" + n], g[f"grad_{key}_bf16/" + n]
             Y[f"gradcache_tiny/grad_rel_bf16_{key}/{n}"] = float(np.linalg.norm(ref16 - ref) / (np.linalg.norm(ref) + 1e-20))
-    g = ld("train_7b-l1.npz")
-    Y["train_7b-l1/loss_gap_bf16"] = abs(float(g["loss_bf16"]) - float(g["loss"]))
-    for k in g.files:
-        if k.startswith("gnorm/"):
-            n = k[len("gnorm/"):]
-            ref_n, ref_n16 = float(g["gnorm/" + n]), float(g["gnorm_bf16/" + n])
-            Y[f"train_7b-l1/gnorm_rel_bf16/{n}"] = abs(ref_n16 - ref_n) / (ref_n + 1e-20)
-            ref, ref16 = g["probe/" + n], g["probe_bf16/" + n]
-            Y[f"train_7b-l1/probe_rel_bf16/{n}"] = float(np.linalg.norm(ref16 - ref) / (np.linalg.norm(ref) + 1e-20))
+    for fx in ("train_7b-l1", "train_7b-d8"):              # (d8: eight distinct layers, 16 queries -- round 6)
+        g = ld(fx + ".npz")
+        Y[f"{fx}/loss_gap_bf16"] = abs(float(g["loss_bf16"]) - float(g["loss"]))
+        for k in g.files:
+            if k.startswith("gnorm/"):
+                n = k[len("gnorm/"):]
+                ref_n, ref_n16 = float(g["gnorm/" + n]), float(g["gnorm_bf16/" + n])
+                Y[f"{fx}/gnorm_rel_bf16/{n}"] = abs(ref_n16 - ref_n) / (ref_n + 1e-20)
+                ref, ref16 = g["probe/" + n], g["probe_bf16/" + n]
+                Y[f"{fx}/probe_rel_bf16/{n}"] = float(np.linalg.norm(ref16 - ref) / (np.linalg.norm(ref) + 1e-20))
     return Y
 
 

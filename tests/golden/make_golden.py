@@ -357,6 +357,60 @@ def gen_train_7b_l1():
     print(f"  train 7b-l1: loss {out.loss.item():.6f}  (reference bf16 run: {out16.loss.item():.6f}, worst probe rel l2 {worst:.3e})")
 
 
+def gen_train_7b_d8(nq=16, group=2, q_len=32, p_len=48):
+    """Contrastive step (direct forward + backward, gritlm/training/model.py:168-222) of the reference at the TRUE 7B layer shape through
+    EIGHT distinct layers, fp32 on CPU (VERDICT r05 #1b: a depth fixture for the training step): 16 queries + 32 passages (group size 2),
+    ragged, tau 0.02, mean pooling -- enough queries for the loss to average the per-score noise.  Stored: loss, reps, per-parameter
+    gradient norms and probe slices of every gradient (first 2 rows of each matrix: 74 tensors), and the reference's OWN bf16 run of the same step
+    (loss, reps, probes): the yardstick a bf16 implementation is measured against.  ~14 GB of host memory, a few minutes on 8 cores."""
+    from gritlm.training.model import GritLMTrainModel, DistributedContrastiveLoss
+    model, cfg = build_ref_model("7b-d8", 0)
+    model.train()
+    m = GritLMTrainModel.__new__(GritLMTrainModel)
+    torch.nn.Module.__init__(m)
+    wrap = torch.nn.Module(); wrap.model = model
+    m.model = wrap; m.embedding_attr = "model"; m.projection = None
+    m.normalized = True; m.pooling_method = "mean"; m.attn = "bbcc"
+    m.emb_loss_fn = DistributedContrastiveLoss(0.02, False)
+    m.gen_loss_fn = None; m.gen_add_kwargs = {}
+    qi, qm = synth.make_batch(cfg, nq, q_len, 51, min_len=12)
+    pi, pm = synth.make_batch(cfg, nq * group, p_len, 52, min_len=20)
+    feed = lambda: dict(query={"input_ids": torch.from_numpy(qi), "attention_mask": torch.from_numpy(qm)},
+                        passage={"input_ids": torch.from_numpy(pi), "attention_mask": torch.from_numpy(pm)})
+    out = m(**feed())
+    out.loss.backward()
+    res = dict(q_ids=qi, q_mask=qm, p_ids=pi, p_mask=pm, tau=np.float32(0.02), group=group, loss=np.float32(out.loss.item()),
+               q_reps=out.q_reps.detach().numpy(), p_reps=out.p_reps.detach().numpy(), generated_on=_host_tag())
+
+    def probes(tag, cast=lambda g: g):
+        for n, p in model.named_parameters():
+            g = cast(p.grad)
+            res[f"gnorm{tag}/" + n] = np.float32(g.double().norm().item())
+            if n == "embed_tokens.weight":
+                if "probe_rows/" + n not in res:
+                    res["probe_rows/" + n] = np.unique(np.concatenate([qi[qm > 0], pi[pm > 0]]))[:16]
+                res[f"probe{tag}/" + n] = g[torch.from_numpy(res["probe_rows/" + n])].numpy().copy()
+            elif g.dim() == 2:
+                res[f"probe{tag}/" + n] = g[:2].numpy().copy()
+            else:
+                res[f"probe{tag}/" + n] = g.numpy().copy()
+    probes("")
+    model.zero_grad(set_to_none=True)
+    model.to(torch.bfloat16)
+    out16 = m(**feed())
+    out16.loss.backward()
+    res["loss_bf16"] = np.float32(out16.loss.item())
+    res["q_reps_bf16"] = out16.q_reps.detach().float().numpy()
+    res["p_reps_bf16"] = out16.p_reps.detach().float().numpy()
+    probes("_bf16", cast=lambda g: g.float())
+    worst = max(float(np.linalg.norm(res["probe_bf16/" + k[6:]] - v) / (np.linalg.norm(v) + 1e-20)) for k, v in res.items() if k.startswith("probe/"))
+    res["ref_bf16_vs_f32_worst_probe_rel_l2"] = np.float32(worst)
+    np.savez_compressed(os.path.join(HERE, "train_7b-d8.npz"), **res)
+    omc = lambda a, b: float(np.max(1 - np.sum(a * b, axis=1)))
+    print(f"  train 7b-d8: loss {out.loss.item():.6f}  (reference bf16 run: {out16.loss.item():.6f}; its reps 1-cos "
+          f"{max(omc(res['q_reps_bf16'], res['q_reps']), omc(res['p_reps_bf16'], res['p_reps'])):.3e}; worst probe rel l2 {worst:.3e})")
+
+
 def gen_train_mixtral(cfg_name="moe-tiny", seed_w=0):
     """Contrastive step of the reference on the bidirectional Mixtral (scripts/modeling_mixtral_gritlm.py: sparse-MoE MLP :815-882,
     autograd through the routing weights) -- GritLMTrainModel.forward + backward, fp32 and bf16 on CPU: loss, reps, every gradient
@@ -764,6 +818,8 @@ if __name__ == "__main__":
         gen_train_7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["gradcache"]:
         gen_gradcache(); sys.exit(0)
+    if sys.argv[1:] == ["train-7b-d8"]:      # only the depth-8 training fixture (~14 GB of host memory, a few minutes)
+        gen_train_7b_d8(); sys.exit(0)
     if sys.argv[1:] == ["mixtral-8x7b-l1"]:  # only the true-shape Mixtral layer fixture (~3 min, 20 GB of host memory)
         gen_mixtral_8x7b_l1(); sys.exit(0)
     if sys.argv[1:] == ["mixtral"]:          # only the Mixtral fixtures (the others are unchanged)
@@ -781,6 +837,7 @@ if __name__ == "__main__":
     print("mixtral"); gen_mixtral("moe-tiny", batch=4, seq=48, min_len=9); gen_mixtral("moe-gqa", batch=3, seq=72, min_len=20)
     print("encoder 7b-l1"); gen_encoder_7b_l1()
     print("train 7b-l1"); gen_train_7b_l1()
+    print("train 7b-d8"); gen_train_7b_d8()
     print("train mixtral"); gen_train_mixtral(); gen_generative_mixtral()
     print("encoder depth 32"); gen_encoder_depth32()
     print("mixtral 8x7b-l1"); gen_mixtral_8x7b_l1()

@@ -18,6 +18,9 @@ CONFIGS = {
     # the true 7B LAYER shape (H 4096, I 14336, 32/8 heads), one layer, small vocabulary: parity fixture at the shape bench.py runs
     "7b-l1": dict(vocab_size=4096, hidden_size=4096, intermediate_size=14336, num_hidden_layers=1,
                   num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=10000.0),
+    # 7B layer shape, EIGHT distinct layers, small vocabulary: the contrastive step at depth (tests/golden/train_7b-d8.npz, round 6)
+    "7b-d8": dict(vocab_size=4096, hidden_size=4096, intermediate_size=14336, num_hidden_layers=8,
+                  num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=10000.0),
     # 7B layer shape, two layers, small vocabulary: decode-path parity at the real GEMV / KV shapes
     "7b-l2s": dict(vocab_size=4096, hidden_size=4096, intermediate_size=14336, num_hidden_layers=2,
                    num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=10000.0),

@@ -20,6 +20,8 @@ ap.add_argument("--seq", type=int, default=512)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--parity-docs", type=int, default=4, help="documents of the timed batch re-computed in fp32 (layer-streamed) for the parity datum; 0 = skip")
+ap.add_argument("--yardstick-docs", type=int, default=2, help="of those, documents also run through the reference's data flow in bf16 (the end-to-end yardstick)")
+ap.add_argument("--no-f16", action="store_true", help="skip the f16_operands policy (timing and parity): bf16 only")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = EncoderConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=a.layers, num_attention_heads=32, num_key_value_heads=8,
@@ -46,18 +48,43 @@ ops.set_timer(None)
 ks = timer.summary()
 counts = torch.stack([torch.bincount(r.reshape(-1).long(), minlength=8) for r in eng.record_routing[:a.layers]]).float()
 eng.record_routing = None
-# ---- PARITY at the leg's own shape (VERDICT r04 #2c), on the ENGINE'S OWN weights widened layer by layer (the 46.7 B-parameter model is
-#      187 GB in fp32: it never fits next to the engine's 93 GB, one layer's 5.6 GB does), against the reference's bidirectional Mixtral
-#      restated in FP32 (oracle/torch_reference.py::mixtral_encode_fp32, pinned on the reference-generated Mixtral fixtures).
-#      Two data.  (1) TEACHER-FORCED, per layer -- the bound: the fp32 run's residual stream entering layers 0, L/2 and L-1 is handed to
-#      the engine (`inputs_embeds`, `layer_range`), and the stream leaving the layer is compared token by token: routing agreement (all
-#      tokens >= 0.97; EVERY token whose router logits separate the 2nd from the 3rd choice by more than 4.0 -- the logits of this
-#      random-init router have a standard deviation of ~30 and bf16 noise in x moves them by ~0.5 -- must take the fp32 run's experts),
-#      per-row relative error on tokens that took the same experts.
-#      (2) END TO END, all layers free-running -- reported, bounds nothing: top-2 routing is a discontinuous function of x, a token that
-#      takes another expert once has a perturbed state from then on and re-decides its routing in every later layer (random-init experts
-#      are unrelated functions), so a bf16 run and an fp32 run of a 32-layer random-init MoE decorrelate token by token; the reference's
-#      own bf16 run re-routes 1.6 % of the tokens of ONE layer at this shape (tests/golden/encoder_8x7b-l1.npz).
+# ---- the policy that meets the north-star tolerance (round 6): precision="f16_operands" on the sparse-MoE engine -- fp32 residual stream,
+#      routing decided in fp32 on the stream itself, expert GEMMs on fp16 copies of w1|w3 / w2 (93 GB more of HBM), fp32 combine --
+#      timed like the default: the same batch, the same number of steps, HIP events at the step boundaries on the launch stream
+f16_rate = None
+if not a.no_f16:
+    eng.set_precision("f16_operands")
+    for _ in range(max(a.warmup, 1)):                   # (the first call converts the weights)
+        eng.encode_pooled(ids, mask, "mean", True)
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True)]
+    marks[0].record()
+    for _ in range(a.steps):
+        e16 = eng.encode_pooled(ids, mask, "mean", True)
+        marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+    torch.cuda.synchronize()
+    ms16 = marks[0].elapsed_time(marks[-1]) / a.steps
+    f16_rate = {"precision": "f16_operands", "docs_per_s": a.docs / ms16 * 1e3, "ms_per_step": ms16, "steps": a.steps,
+                "overflow_flag": bool(ops.f16_overflow_flag(dev)), "finite": bool(torch.isfinite(e16).all()),
+                "weights_subnormal_in_fp16_frac": eng.f16_weight_stats["subnormal"] / max(eng.f16_weight_stats["total"], 1)}
+    eng.set_precision("bf16")
+    eng._ws.clear()
+    torch.cuda.empty_cache()
+# ---- PARITY at the leg's own shape (VERDICT r04 #2c, r05 #1c), on the ENGINE'S OWN weights widened layer by layer (the 46.7 B-parameter
+#      model is 187 GB in fp32: it never fits next to the engine, one layer's 5.6 GB does), against the reference's bidirectional Mixtral
+#      restated in FP32 (oracle/torch_reference.py::mixtral_encode_fp32, pinned on the reference-generated Mixtral fixtures), for BOTH
+#      policies of the engine.
+#      (1) TEACHER-FORCED, per layer: the fp32 run's residual stream entering layers 0, L/2 and L-1 is handed to the engine
+#      (`inputs_embeds`, `layer_range`), and the stream leaving the layer is compared token by token: routing agreement, per-row relative
+#      error on tokens that took the same experts.  bf16 (the reference's arithmetic type): agreement >= 0.97, every token whose router
+#      logits separate the 2nd from the 3rd choice by more than 4.0 agrees (the logits of this random-init router have a standard
+#      deviation of ~30 and bf16 noise in x moves them by ~0.5), row error median < 2e-2.  f16_operands: agreement >= 0.999, every token
+#      with a logit gap above 0.01 agrees, row error median < 2e-3.
+#      (2) END TO END, all layers free-running: 1 - cos of the pooled embeddings.  f16_operands is held to the north-star's 1e-4.  For bf16
+#      it is reported beside a same-run YARDSTICK -- the reference's data flow run in bf16 by plain torch on the same weights and documents
+#      (mixtral_encode_fp32(dtype=bfloat16): what the reference's own bf16 run does to this model): top-2 routing is a discontinuous function
+#      of x, a token that takes another expert once carries a perturbed state and re-decides its routing in every later layer, so ANY bf16
+#      run and the fp32 run of a random-init 32-layer MoE decorrelate token by token.
 parity = None
 if a.parity_docs > 0:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
@@ -65,56 +92,84 @@ if a.parity_docs > 0:
     from gritlm_amd import _lib
     n = min(a.parity_docs, a.docs)
     blk = _lib.load().grit_swiglu_block()
-    e_eng = eng.encode_pooled(ids[:n].contiguous(), mask[:n].contiguous(), "mean", True).double()
+    pols = ("bf16",) if a.no_f16 else ("bf16", "f16_operands")
+    e_eng = {}
+    for pol in pols:
+        eng.set_precision(pol)
+        e_eng[pol] = eng.encode_pooled(ids[:n].contiguous(), mask[:n].contiguous(), "mean", True).double()
     torch.cuda.synchronize()
     eng._ws.clear()
     torch.cuda.empty_cache()
     t0p = time.perf_counter()
     tl = tuple(sorted({0, a.layers // 2, a.layers - 1}))
     wl = lambda li: TR.mixtral_layer_weights_from_engine(eng, li, blk)
-    refs, per_layer = [], {li: {"agree": [], "clear_agree": [], "clear_n": 0, "row_rel": [], "upd_rel": []} for li in tl}
+    GAP = {"bf16": 4.0, "f16_operands": 0.01}
+    refs, yard = [], []
+    per_layer = {pol: {li: {"agree": [], "clear_agree": [], "clear_n": 0, "row_rel": [], "upd_rel": []} for li in tl} for pol in pols}
+    margs = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.rope_theta)
     with torch.no_grad():
         for i in range(n):
             trace = {}
-            refs.append(TR.mixtral_encode_fp32(wl, a.layers, eng.embed, eng.norm, ids[i:i + 1], mask[i:i + 1], cfg.num_attention_heads,
-                                               cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.rope_theta, trace_layers=tl, trace=trace))
-            for li in tl:
-                x_in, x_out, sel, margin = trace[li]
-                eng.record_routing = []
-                got = eng.forward(None, mask[i:i + 1], inputs_embeds=x_in, layer_range=(li, li + 1), final_norm=False).float()
-                r_eng = eng.record_routing[0].view(1, a.seq, 2).sort(-1)[0].to(sel.device)
-                eng.record_routing = None
-                same = (r_eng == sel).all(-1)[0]
-                clear = margin[0] > 4.0
-                d = per_layer[li]
-                d["agree"].append(float(same.float().mean())); d["clear_n"] += int(clear.sum())
-                d["clear_agree"].append(bool(same[clear].all()))
-                xo, xi, g = x_out[0][same], x_in[0][same], got[0][same]
-                d["row_rel"].append(((g - xo).norm(dim=1) / xo.norm(dim=1)).cpu())
-                d["upd_rel"].append(((g - xo).norm(dim=1) / (xo - xi).norm(dim=1)).cpu())
+            refs.append(TR.mixtral_encode_fp32(wl, a.layers, eng.embed, eng.norm, ids[i:i + 1], mask[i:i + 1], *margs, trace_layers=tl, trace=trace))
+            if i < a.yardstick_docs:
+                yard.append(TR.mixtral_encode_fp32(wl, a.layers, eng.embed, eng.norm, ids[i:i + 1], mask[i:i + 1], *margs, dtype=torch.bfloat16))
+            for pol in pols:
+                eng.set_precision(pol)
+                for li in tl:
+                    x_in, x_out, sel, margin = trace[li]
+                    eng.record_routing = []
+                    got = eng.forward(None, mask[i:i + 1], inputs_embeds=x_in, layer_range=(li, li + 1), final_norm=False).float()
+                    r_eng = eng.record_routing[0].view(1, a.seq, 2).sort(-1)[0].to(sel.device)
+                    eng.record_routing = None
+                    same = (r_eng == sel).all(-1)[0]
+                    clear = margin[0] > GAP[pol]
+                    d = per_layer[pol][li]
+                    d["agree"].append(float(same.float().mean())); d["clear_n"] += int(clear.sum())
+                    d["clear_agree"].append(bool(same[clear].all()))
+                    xo, xi, g = x_out[0][same], x_in[0][same], got[0][same]
+                    d["row_rel"].append(((g - xo).norm(dim=1) / xo.norm(dim=1)).cpu())
+                    d["upd_rel"].append(((g - xo).norm(dim=1) / (xo - xi).norm(dim=1)).cpu())
             del trace
+    eng.set_precision("bf16")
     e_ref = torch.cat(refs).double()
     torch.cuda.synchronize()
-    omc = 1.0 - (e_eng * e_ref).sum(1) / (e_eng.norm(dim=1) * e_ref.norm(dim=1))
-    B_AGREE, B_ROW = 0.97, 2.0e-2
-    tf, ok = {}, True
-    for li, d in per_layer.items():
-        rr, ur = torch.cat(d["row_rel"]), torch.cat(d["upd_rel"])
-        tf[str(li)] = {"routing_agree": min(d["agree"]), "clear_gap_tokens": d["clear_n"], "clear_gap_all_agree": all(d["clear_agree"]),
-                       "row_rel_median": float(rr.median()), "row_rel_p90": float(rr.quantile(0.9)), "row_rel_max": float(rr.max()),
-                       "update_rel_median": float(ur.median())}
-        ok = ok and tf[str(li)]["routing_agree"] >= B_AGREE and tf[str(li)]["clear_gap_all_agree"] and tf[str(li)]["row_rel_median"] < B_ROW
-    parity = {"what": f"the first {n} documents of the timed batch ({a.seq} tokens each): HIP engine (bf16, the reference's arithmetic type) vs the reference's "
+    omc_of = lambda e: 1.0 - (e * e_ref[:e.shape[0]]).sum(1) / (e.norm(dim=1) * e_ref[:e.shape[0]].norm(dim=1))
+    BOUNDS = {"bf16": {"routing_agree_min": 0.97, "logit_gap_all_agree_above": 4.0, "row_rel_median_max": 2.0e-2},
+              "f16_operands": {"routing_agree_min": 0.999, "logit_gap_all_agree_above": 0.01, "row_rel_median_max": 2.0e-3, "end_to_end_one_minus_cos_max": 1e-4}}
+    by_pol, all_ok = {}, True
+    for pol in pols:
+        tf, ok = {}, True
+        for li, d in per_layer[pol].items():
+            rr, ur = torch.cat(d["row_rel"]), torch.cat(d["upd_rel"])
+            tf[str(li)] = {"routing_agree": min(d["agree"]), "clear_gap_tokens": d["clear_n"], "clear_gap_all_agree": all(d["clear_agree"]),
+                           "row_rel_median": float(rr.median()), "row_rel_p90": float(rr.quantile(0.9)), "row_rel_max": float(rr.max()),
+                           "update_rel_median": float(ur.median())}
+            ok = ok and tf[str(li)]["routing_agree"] >= BOUNDS[pol]["routing_agree_min"] and tf[str(li)]["clear_gap_all_agree"] \
+                and tf[str(li)]["row_rel_median"] < BOUNDS[pol]["row_rel_median_max"]
+        omc = omc_of(e_eng[pol])
+        e2e = {"max_one_minus_cos": float(omc.max()), "mean_one_minus_cos": float(omc.mean())}
+        if pol == "f16_operands":
+            ok = ok and e2e["max_one_minus_cos"] < 1e-4
+        by_pol[pol] = {"teacher_forced_per_layer": tf, "end_to_end": e2e, "bounds": BOUNDS[pol], "within_bound": bool(ok and torch.isfinite(e_eng[pol]).all())}
+        all_ok = all_ok and by_pol[pol]["within_bound"]
+    yard_omc = omc_of(torch.cat(yard).double()) if yard else None
+    parity = {"what": f"the first {n} documents of the timed batch ({a.seq} tokens each): HIP engine under each precision policy vs the reference's "
                       "bidirectional Mixtral restated in FP32 on the engine's own weights (oracle/torch_reference.py, pinned on the reference-generated "
                       "fixtures).  teacher_forced_per_layer: the fp32 run's residual stream entering the layer is given to the engine, the stream "
                       "leaving it compared per token (row_rel = |engine - fp32| / |fp32| on tokens that took the same experts; update_rel relates the "
-                      "same difference to the layer's own update) -- this is the bound.  end_to_end: all layers free-running, 1 - cos of the pooled "
-                      "embeddings -- reported only: top-2 routing is discontinuous, a re-routed token re-decides every later layer, and a bf16 and an "
-                      "fp32 run of a random-init 32-layer MoE decorrelate token by token (the reference's own bf16 run re-routes 1.6 % of the tokens of "
-                      "ONE layer at this shape: tests/golden/encoder_8x7b-l1.npz)",
-              "docs": n, "teacher_forced_per_layer": tf, "bounds": {"routing_agree_min": B_AGREE, "tokens_with_logit_gap_above_4_all_agree": True, "row_rel_median_max": B_ROW},
-              "end_to_end": {"max_one_minus_cos": float(omc.max()), "mean_one_minus_cos": float(omc.mean())},
-              "within_bound": bool(ok and torch.isfinite(e_eng).all()), "fp32_reference_seconds": time.perf_counter() - t0p}
+                      "same difference to the layer's own update).  end_to_end: all layers free-running, 1 - cos of the pooled embeddings: bounded by "
+                      "the north-star's 1e-4 for f16_operands; for bf16 reported beside the same-run yardstick (the reference's data flow in bf16 by "
+                      "plain torch, same weights and documents): any bf16 run of a random-init 32-layer top-2 MoE decorrelates from the fp32 run "
+                      "token by token once tokens re-route",
+              "docs": n, "policies": by_pol,
+              "reference_dataflow_in_bf16_end_to_end": None if yard_omc is None else
+              {"docs": len(yard), "max_one_minus_cos": float(yard_omc.max()), "mean_one_minus_cos": float(yard_omc.mean()),
+               "what": "mixtral_encode_fp32(dtype=bfloat16): the reference's own bf16 arithmetic on this model, vs its fp32 run"},
+              "north_star_policy": "f16_operands" if "f16_operands" in by_pol else None,
+              "north_star_met": bool(by_pol.get("f16_operands", {}).get("within_bound", False)),
+              # (kept for readers of the round-5 layout: the default policy's data)
+              "teacher_forced_per_layer": by_pol["bf16"]["teacher_forced_per_layer"], "end_to_end": by_pol["bf16"]["end_to_end"],
+              "within_bound": bool(all_ok), "fp32_reference_seconds": time.perf_counter() - t0p}
     del refs, e_ref
     torch.cuda.empty_cache()
 docs_per_s = a.docs * a.steps / dt
@@ -129,7 +184,7 @@ print(json.dumps({
                  "frac": ks["gemm_bf16_nt_grouped"]["work"] / (ks["gemm_bf16_nt_grouped"]["total_ms"] * 1e-3) / 1e12 / 2500.0,
                  "whole_step_frac": docs_per_s * flops_doc / 2.5e15},
     "tokens_per_s": docs_per_s * a.seq, "weights_init_s": t_init, "hbm_allocated_gb": torch.cuda.max_memory_allocated() / 1e9,
-    "parity": parity,
+    "north_star_policy": f16_rate, "parity": parity,
     "expert_load_max_over_mean": float((counts.max(dim=1)[0] / counts.mean(dim=1)).mean()), "finite": bool(torch.isfinite(e).all()),
     "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 2), "tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12}
                 for k, v in ks.items()}}))
