@@ -132,3 +132,16 @@ def test_comm_entry_points_validate_without_a_gpu():
     assert b"null communicator" in lib.grit_last_error_string()
     assert lib.grit_comm_destroy(None) == 0 and lib.grit_stream_destroy(None) == 0
     assert lib.grit_stream_create_cu_mask(0, ctypes.byref(h)) == B
+
+
+def test_every_tracked_profile_json_parses():
+    """profiles/*.json are the summaries the round's numbers are judged from: each must be ONE valid JSON document (VERDICT r05 #13 found
+    two with a stderr line / two concatenated objects in them); tools/summarize_profiles.py asserts the same after writing."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*.json")))
+    assert files
+    for f in files:
+        with open(f) as fh:
+            json.load(fh)

@@ -57,3 +57,18 @@ def test_under_a_launcher_environment_bench_does_not_relaunch():
     assert "starting 2 ranks" not in r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["collectives"]["ranks"] == 2
+
+
+def test_gpus_8_dry_run_is_the_eight_rank_job_the_driver_will_launch():
+    """``python bench.py --gpus 8``: eight ranks, one line, ``collectives.ranks == 8``, the cross-rank GradCache step on a
+    global batch of 8 x 4 pairs with one gather per chunk and identical averaged gradients on every rank -- so that the first run on an
+    8-GPU node is a re-run of something that has executed."""
+    line, r = _run("--gpus", "8")
+    assert "starting 8 ranks" in r.stderr
+    assert line["n_gpus"] == 8 and line["collectives"]["ranks"] == 8 and line["collectives"]["encode_data_path_collectives"] == 0
+    assert line["config"]["parallelism"].startswith("replicas x8") and line["scaling"] == "weak" and "INVALID" in line
+    c = line["contrastive"]
+    assert "error" not in c, c
+    assert c["global_batch"] == 32 and c["n_gpus"] == 8
+    assert c["per_step_ms"]["gather_collectives"] == 2 + 4
+    assert c["grad_norm_spread_over_ranks"] < 1e-6 * max(1.0, c["grad_norm_after_averaging"])

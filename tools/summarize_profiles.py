@@ -77,3 +77,8 @@ print("avg traffic per launch (GB):", avg / 1e9)
 rows = list(csv.DictReader(open(f"profiles/{tag}_bench_kernel_stats.csv"))) if os.path.exists(f"profiles/{tag}_bench_kernel_stats.csv") else []
 for r in rows[:8]:
     print(r["Name"][:60].ljust(60), r["Calls"].rjust(5), f'{float(r["TotalDurationNs"])/1e6:9.1f} ms', r["Percentage"])
+# every tracked summary must be one valid JSON document (tests/test_abi.py::test_every_tracked_profile_json_parses holds the tree to it)
+import glob
+for _f in sorted(glob.glob("profiles/*.json")):
+    with open(_f) as _fh:
+        json.load(_fh)
