@@ -148,7 +148,7 @@ def vendor_gemm_sustained(dev, layers=8, passes=2, M=DOCS * SEQ):
 
 
 def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, steps=1, warmup=1, ragged_pairs=32, pass1_precision="f16_stream",
-                    parity_pairs=16, parity_loss_pairs=64):
+                    parity_pairs=16, parity_loss_pairs=256):
     """Second headline metric: contrastive pairs/s on BASELINE configs[2] as stated -- per rank 256 queries + 2048 passages
     (1 positive + 7 negatives each) @ seq512, GradCache chunk 32 (scripts/training/train_gritlm_7b.sh:60-67; gritlm/training/run.py:93-104).
     One step = pass 1 (no grad) -> chunk-wise all-gather of the reps (N > 1) -> fused InfoNCE (similarity [W*256, W*2048] + CE + rep
@@ -758,8 +758,8 @@ def main():
                          "meets the north-star's |loss - fp32 loss| < 1e-3 at depth 32")
     ap.add_argument("--contrastive-parity-pairs", type=int, default=16, help="pairs of the timed batch re-run through the fp32 reference "
                     "(forward + backward) for the contrastive leg's parity object; 0 = skip")
-    ap.add_argument("--contrastive-parity-loss-pairs", type=int, default=64, help="pairs for the forward-only loss datum of that object "
-                    "(256 = the whole per-GPU batch of configs[2]: ~3 more minutes of fp32 reference)")
+    ap.add_argument("--contrastive-parity-loss-pairs", type=int, default=256, help="pairs for the forward-only loss datum of that object "
+                    "(default 256 = the whole per-GPU batch of configs[2]: ~2.5 minutes of fp32 reference; 64: ~40 s)")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm encode on this GPU")
     ap.add_argument("--no-mixtral", action="store_true", help="skip the BASELINE configs[3] leg (Mixtral-8x7B shape, 64 x seq2048)")
     ap.add_argument("--no-rag", action="store_true", help="skip the BASELINE configs[4] leg (512 passages x seq2048 with KV + 128 new tokens)")

@@ -1104,8 +1104,14 @@ static unsigned int* next_counter_set(hipStream_t st) {
       for (int i = 0; i < CTR_STREAMS; ++i) {
         if (rings[i].dev != dev || rings[i].last_use >= best) continue;
         const hipError_t q = hipStreamQuery(rings[i].st);
-        if (q == hipErrorNotReady) continue;          // work in flight: its counters may be live
-        if (q != hipSuccess) (void)hipGetLastError();  // invalid handle: the stream was destroyed
+        // reclaim ONLY a stream that is idle (its kernels are done, its counters dead) or provably gone (an invalid handle: a destroyed
+        // side stream).  Everything else is "busy": not-ready, and in particular the capture-related errors -- a live stream that is being
+        // graph-captured also fails the query, and a graph already captured on it would replay on counter sets handed to another stream
+        // 
+        if (q != hipSuccess) {
+          (void)hipGetLastError();
+          if (q != hipErrorInvalidHandle && q != hipErrorInvalidResourceHandle && q != hipErrorContextIsDestroyed) continue;
+        }
         best = rings[i].last_use;
         slot = i;
       }
@@ -1120,10 +1126,12 @@ static unsigned int* next_counter_set(hipStream_t st) {
     }
     rings[slot].last_use = ++tick;
     idx = rings[slot].next++ % CTR_PER_STREAM;
+    // the clearing memset is enqueued while the table is still locked: from the moment the slot is assigned the stream has work pending,
+    // so a concurrent reclaim (hipStreamQuery under the same mutex) can never see it idle between the assignment and the launch
+    unsigned int* set = b + ((size_t)slot * CTR_PER_STREAM + idx) * 8;
+    if (hipMemsetAsync(set, 0, 8 * sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return set;
   }
-  unsigned int* set = b + ((size_t)slot * CTR_PER_STREAM + idx) * 8;
-  if (hipMemsetAsync(set, 0, 8 * sizeof(unsigned int), st) != hipSuccess) return nullptr;
-  return set;
 }
 
 // the 128 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (instantiation, device)
