@@ -453,10 +453,22 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
   const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
   const char* seq_qkv = reinterpret_cast<const char*>(qkv + row0 * qkv_stride);
   const char* k_base = seq_qkv + (int64_t)(nq + hk) * AB_D * 2;
-  const char* v_base = k_base + (int64_t)nkv * AB_D * 2;
+  // buffer-addressed LDS-DMA (round 6, cf. attn_bwd_dkdv_k): ONE descriptor serves K and V (same row stride; V sits v_delta bytes behind
+  // K, a scalar), rows past the sequence are zero-filled by the range check (their keys are masked by the tile's key word)
+  const uint32_t v_delta_b = (uint32_t)nkv * AB_D * 2u;
+  const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(k_base), (short)0, (int)((uint32_t)(S - 1) * qkv_stride_b + 256u + v_delta_b), 0x00020000);
   auto stage = [&](int t, int buf) {
-    stage_img(k_base, qkv_stride_b, t * 64, S, smem + buf * AB_STAGE, wv, lane);
-    stage_img(v_base, qkv_stride_b, t * 64, S, smem + buf * AB_STAGE + AB_IMG, wv, lane);
+    char* sb = smem + buf * AB_STAGE + wv * 4096;
+    const uint32_t off_k = (uint32_t)__builtin_amdgcn_readfirstlane(t * 64 + 16 * wv) * qkv_stride_b;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const uint32_t xk = (uint32_t)(ln >> 4) * qkv_stride_b + (uint32_t)(((ln & 15) ^ (((ln >> 4) & 3) << 2)) << 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t vo = xk ^ (uint32_t)(i << 4), so = off_k + 4u * i * qkv_stride_b;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (ab_lptr_t)(sb + i * 1024), 16, (int)vo, (int)so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (ab_lptr_t)(sb + AB_IMG + i * 1024), 16, (int)vo, (int)(so + v_delta_b), 0, 0);
+    }
   };
   // first K/V tile: 0 (always exists: S > 0), or the one holding the first key of the block's first query's window
   const int t_first = window > 0 && qblk * 128 - window + 1 > 0 ? (qblk * 128 - window + 1) >> 6 : 0;

@@ -24,6 +24,6 @@ for pass in "pmc_sq:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY S
   mkdir -p $OUT/$name; cp $(find $RAW/$name -name "*counter_collection.csv" | head -1) $OUT/$name/gemm_counter_collection.csv
 done
 [ -n "$SKIP_CONTRASTIVE" ] && { du -sh $OUT; exit 0; }     # SKIP_CONTRASTIVE=1: encode stats + GEMM counters only (~3 min instead of ~8)
-rocprofv3 --kernel-trace --stats -d $RAW/bench_contrastive -o bench --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ragged --no-torch-baseline --no-mixtral --no-rag --contrastive-steps 1 --pairs ${PAIRS:-256} --chunk 32 > $OUT/bench_contrastive.json 2> $OUT/bench_contrastive.err
+rocprofv3 --kernel-trace --stats -d $RAW/bench_contrastive -o bench --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ragged --no-torch-baseline --no-mixtral --no-rag --contrastive-parity-pairs 0 --contrastive-steps 1 --pairs ${PAIRS:-256} --chunk 32 > $OUT/bench_contrastive.json 2> $OUT/bench_contrastive.err
 mkdir -p $OUT/bench_contrastive; cp $(find $RAW/bench_contrastive -name "*kernel_stats.csv" | head -1) $OUT/bench_contrastive/bench_kernel_stats.csv
 du -sh $OUT; find $OUT -type f | xargs ls -la
