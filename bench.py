@@ -1047,7 +1047,7 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_mixtral:
                 line["mixtral_8x7b_seq2048"] = secondary_leg(
-                    "mixtral_bench.py", ["--docs", 64, "--seq", 2048, "--steps", 3, "--warmup", 1], 420,
+                    "mixtral_bench.py", ["--docs", 64, "--seq", 2048, "--steps", 3, "--warmup", 1], 600,
                     ("metric", "value", "unit", "ms_per_step", "tokens_per_s", "config", "roofline", "model_flops_utilisation", "hbm_allocated_gb",
                      "expert_load_max_over_mean", "finite", "kernels", "parity", "north_star_policy"))
             if not args.no_rag:
