@@ -178,8 +178,24 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
         m.train_engine.weights_updated()
         return loss
 
+    # PARITY first, on the leg's INITIAL weights (random init, no optimizer step yet): the timed steps below train on ONE synthetic batch,
+    # which the 7B model memorises within four updates (loss 7.6 -> 0.15: a saturated softmax whose loss no longer moves with the scores),
+    # so a loss comparison taken AFTER them would pass for any arithmetic; at initialisation the softmax over the 2048 passages is wide
+    # open and every score counts
+    parity = None
+    if parity_pairs:
+        try:
+            pols = ("bf16",) + tuple(x for x in ("f16_stream", "f16_operands") if x == pass1_precision or (pass1_precision == "bf16" and x == "f16_stream"))
+            parity = contrastive_parity(m, bb, cfg, opt, q, p, dev, chunk, group, pairs=min(parity_pairs, pairs), policies=pols,
+                                        loss_pairs=min(parity_loss_pairs, pairs))
+        except Exception as e:  # noqa: BLE001
+            parity = {"error": repr(e)[:300]}
+        gc = GradCacheStep(m, chunk, precision=pass1_precision)          # (the parity leg left the engine on its last policy)
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
     for _ in range(warmup):
-        step()
+        step(gc)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -189,7 +205,7 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
     t0 = time.perf_counter()
     marks[0].record()
     for _ in range(steps):
-        loss = step()
+        loss = step(gc)
         marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -215,15 +231,6 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
     if pass1_precision != "bf16":
         from gritlm_amd import ops as _ops
         pass1_overflow = bool(_ops.f16_overflow_flag(dev))
-    parity = None
-    if parity_pairs:
-        try:
-            pols = ("bf16",) + tuple(x for x in ("f16_stream", "f16_operands") if x == pass1_precision or (pass1_precision == "bf16" and x == "f16_stream"))
-            parity = contrastive_parity(m, bb, cfg, opt, q, p, dev, chunk, group, pairs=min(parity_pairs, pairs), policies=pols,
-                                        loss_pairs=min(parity_loss_pairs, pairs))
-        except Exception as e:  # noqa: BLE001
-            parity = {"error": repr(e)[:300]}
-        gc = GradCacheStep(m, chunk, precision=pass1_precision)          # (the parity leg left the engine on its last policy)
 
     # ragged training batch (rank-local, outside the timed region above, smaller batch): lengths U{64..512} right-padded to 512 --
     # padded rows through every kernel (what the reference's SDPA path does) vs the packed (un-padded) training path
@@ -268,7 +275,7 @@ def contrastive_leg(cfg, dev, world, rank, dist, pairs=256, group=8, chunk=32, s
 
 def contrastive_parity(m, bb, cfg, opt, q, p, dev, chunk, group, pairs=16, tau=0.02, policies=("bf16", "f16_stream"), loss_pairs=64):
     """Full-depth parity datum of BASELINE configs[2] (VERDICT r05 #1a): a sub-batch of `pairs` (query, 1 + 7 passages) units of the timed
-    batch -- on the leg's OWN 32-layer weights, as the timed steps left them -- through (1) the engine's GradCache step (pass 1 under each
+    batch -- on the leg's OWN 32-layer weights, as initialised (the caller runs this BEFORE the training steps) -- through (1) the engine's GradCache step (pass 1 under each
     pass-1 policy, InfoNCE on HIP, pass 2 forward + backward in bf16; no optimizer step) and (2) the reference's training forward
     (gritlm/training/model.py:134-222: encode -> pool -> normalise -> scores / tau -> CrossEntropy(arange * group)) + backward in FP32 on the
     stock transformers module loaded from the same weights (oracle/torch_reference.py::encode_with_grad, gradient checkpointing as the
@@ -285,8 +292,8 @@ def contrastive_parity(m, bb, cfg, opt, q, p, dev, chunk, group, pairs=16, tau=0
     qs = {k: v[:n_q].contiguous() for k, v in q.items()}
     ps = {k: v[:n_p].contiguous() for k, v in p.items()}
     names = [n for n, t in bb.named_parameters() if t.dim() == 2 and "embed" not in n]
-    out = {"what": f"{pairs} (query, 1 + {group - 1} passages) units of the timed batch x {SEQ} tokens, the leg's own {cfg.num_hidden_layers}-layer weights after its "
-                   "timed steps: engine GradCache step (pass 1 under the named policy, pass 2 + backward in bf16, no optimizer step) vs the reference's "
+    out = {"what": f"{pairs} (query, 1 + {group - 1} passages) units of the timed batch x {SEQ} tokens, the leg's own {cfg.num_hidden_layers}-layer weights as "
+                   "initialised (before any optimizer step: the softmax over the passages is wide open): engine GradCache step (pass 1 under the named policy, pass 2 + backward in bf16, no optimizer step) vs the reference's "
                    "training forward + backward in FP32 on the stock module (gradient checkpointing), same weights, same rows",
            "pairs": pairs, "tokens": (n_q + n_p) * SEQ, "temperature": tau}
     # ---- engine side, per pass-1 policy (local loss: the sub-batch is this rank's own rows)

@@ -193,6 +193,7 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     key_ok = key_ok && ((key_bits[(int64_t)b * W + (key >> 6)] >> (key & 63)) & 1ull);
   }
   const int key_ld = key < S ? key : S - 1;
+  const bool all_keys_ok = __builtin_amdgcn_ballot_w64(!key_ok) == 0ull;               // wave-uniform
   const float scale_log2 = scale * 1.4426950408889634f;
   const uint32_t qkv_stride_b = (uint32_t)qkv_stride * 2u, out_stride_b = (uint32_t)out_stride * 2u;
   const char* seq_qkv = reinterpret_cast<const char*>(qkv + row0 * qkv_stride);      // workgroup-uniform bases, 32-bit per-lane offsets
@@ -257,9 +258,9 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
   const TrLane trl = tr_lane(lane);
 
-  // statistics of a tile's 64 queries: every wave keeps its own copy, lane l <-> query qt*64 + l (one coalesced load per array); a lane
-  // fetches the value of "its" query of an accumulator register with ds_bpermute (no LDS memory, no barrier).  Rows past the sequence
-  // get lse = +inf -> P = 0.
+  // statistics of a tile's 64 queries: every wave keeps its own copy, lane l <-> query qt*64 + l (one coalesced load per array), and
+  // hands it to the lanes that need it through its 512-byte LDS table (DK_STATS below; rounds 1-5: 32 ds_bpermute per half).  Rows past the
+  // sequence get lse = +inf -> P = 0.
   auto load_stats = [&](int n_, float& l_, float& d_) {
     int h_s, qt_s;
     tile_of(n_, h_s, qt_s);
@@ -306,6 +307,10 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
       for (int db = 0; db < 4; ++db) { t0[db] = img_b + (uint32_t)(trl.o0 ^ (db << 6)); t1[db] = img_b + (uint32_t)(trl.o1 ^ (db << 6)); }
       bf16x8_t fa0[3], fa1[3];
       ab_s16x4_t fbr[2][4][2][2];                                // [group c][db][operand][half]
+      f32x4_t lq[4], dq4[4];                                     // statistics of the half's rows 8j + 4hi .. +3
+      const uint32_t st_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(smem + AB_RING)) + (uint32_t)wv * 512u;
+      const uint32_t st_w = st_base + (uint32_t)lane * 4u;
+      const uint32_t st_r = st_base + (uint32_t)hi * 16u;
       const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16_t s, dp;
 #define DK_A_READ(QB, KS)                                                                                                         \
@@ -356,27 +361,45 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     DK_MFMA_A(dv[db], f1_, pb[C]);                                                                                                \
     DK_MFMA_A(dk[db], f0_, dsb[C]);                                                                                               \
   }
-#define DK_SOFTMAX(QB)                                                                                                            \
+// The 64 queries' statistics (lse, delta) reach the lanes that need them -- 16 rows per half and lane, the same for every key column --
+// through a 512-byte per-wave LDS table (round 6): lane l writes the pair of query l once per tile, every lane reads its 4 + 4 aligned
+// 16-byte groups per half (queries 8j + 4hi .. +3) with ds_read_b128.  8 LDS instructions per half instead of 32 ds_bpermute, requested
+// IN FRONT of the half's transposing reads and waited for with a counted lgkmcnt, so those stay in flight under the softmax.
+// Inline asm like every LDS access of the loop (a C++ LDS load behind an LDS-DMA gets a vmcnt(0) from hipcc's wait-count pass).
+#define DK_ST1(QB, J)                                                                                                             \
+  do {                                                                                                                            \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lq[J]) : "v"(st_r), "i"((QB) * 128 + (J) * 32));                          \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dq4[J]) : "v"(st_r), "i"((QB) * 128 + (J) * 32 + 256));                   \
+  } while (0)
+#define DK_STATS(QB)                                                                                                              \
   do {                                                                                                                            \
     if ((QB) == 0) {                                                                                                              \
       my_l = q_in ? raw_l * 1.4426950408889634f : INFINITY;                                                                       \
       my_d = q_in ? raw_d : 0.f;                                                                                                  \
+      asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:256" : : "v"(st_w), "v"(my_l), "v"(my_d) : "memory");       \
     }                                                                                                                             \
-    float lv[16], dl[16];                                                                                                         \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                              \
-      const int src = ((QB) * 32 + 8 * (r >> 2) + (r & 3) + 4 * hi) << 2;                                                         \
-      lv[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_l)));                                            \
-      dl[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_d)));                                            \
-    }                                                                                                                             \
-    AB_SCHED_FENCE();                                                                                                             \
+    DK_ST1(QB, 0); DK_ST1(QB, 1); DK_ST1(QB, 2); DK_ST1(QB, 3);                                                                   \
+  } while (0)
+#define DK_SOFTMAX(QB)                                                                                                            \
+  do {                                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(15)"      /* (the counter saturates at 15) 16 transposing reads were requested behind the statistics */ \
+                 : "+v"(lq[0]), "+v"(lq[1]), "+v"(lq[2]), "+v"(lq[3]), "+v"(dq4[0]), "+v"(dq4[1]), "+v"(dq4[2]), "+v"(dq4[3]) : : "memory"); \
+    if (!CW && all_keys_ok) {             /* every key of the wave is valid (all blocks but a ragged last one): no select per score */ \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                            \
+        const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lq[r >> 2][r & 3]);                                            \
+        s[r] = e;                                                                                                                 \
+        dp[r] = e * (dp[r] - dq4[r >> 2][r & 3]);                                                                                 \
+      }                                                                                                                           \
+    } else {                                                                                                                      \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                              \
       const int ql = (QB) * 32 + 8 * (r >> 2) + (r & 3);                                                                          \
       const int qd = qt * 64 + ql + 4 * hi - key;                                                                                 \
       const bool seen = CW ? (key_ok & ((causal == 0) | (qd >= 0)) & ((window == 0) | (qd < window))) : key_ok;                   \
-      const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lv[r]);                                                          \
+      const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lq[r >> 2][r & 3]);                                              \
       const float p = seen ? e : 0.f;                                                                                             \
       s[r] = p;                                                                                                                   \
-      dp[r] = p * (dp[r] - dl[r]);                                                                                                \
+      dp[r] = p * (dp[r] - dq4[r >> 2][r & 3]);                                                                                   \
+    }                                                                                                                             \
     }                                                                                                                             \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) { pb[c] = pack8(s, c); dsb[c] = pack8(dp, c); }                                 \
   } while (0)
@@ -389,7 +412,8 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
     DK_A_READ(QB, 6); DK_A_MMA(4, 4);                                                                                             \
     DK_A_READ(QB, 7); DK_A_MMA(5, 4);                                                                                             \
     DK_A_MMA(6, 2); DK_A_MMA(7, 0);                                                                                               \
-    DK_B_READ(QB, 0);                      /* 16 transposing reads in flight under the softmax */                                 \
+    DK_STATS(QB);                          /* the rows' statistics, then ... */                                                   \
+    DK_B_READ(QB, 0);                      /* ... 16 transposing reads in flight under the softmax */                             \
     bf16x8_t pb[2], dsb[2];                                                                                                       \
     DK_SOFTMAX(QB);                                                                                                               \
     DK_B_WAIT(0, 0);                                                                                                              \
@@ -412,6 +436,8 @@ attn_bwd_dkdv_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ k
 #undef DK_FRAG
 #undef DK_B_MMA
 #undef DK_SOFTMAX
+#undef DK_STATS
+#undef DK_ST1
 #undef DK_HALF
     }
   }
@@ -536,6 +562,8 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
         word &= lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
       }
     }
+    // wave-uniform: without causal bounds `word` is the tile's key word (a scalar); with them it is per lane
+    const bool all_keys = !causal && __builtin_amdgcn_readfirstlane((int)(word == ~0ull)) != 0;
     const uint32_t wlo = (uint32_t)(word >> (4 * hi)), whi = (uint32_t)(word >> (32 + 4 * hi));
     // (The same inline-asm read scheme as attn_bwd_dkdv_k -- row fragments two k-slices ahead, the transposing reads in one counted group,
     //  the next tile's DMA at the tile top -- was built for this loop too: bit-identical, 1.017 / 1.000 / 0.996 / 0.994 of this form on
@@ -587,12 +615,20 @@ attn_bwd_dq_k(const uint16_t* __restrict__ qkv, const uint64_t* __restrict__ key
       // ds_read_b64_tr_b16 that follows an LDS-DMA)
       if (kb == 1 && t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
       const uint32_t wsel = kb ? whi : wlo;
+      if (all_keys) {             // (round 6) every key of the tile is visible to every query of the wave -- all tiles of a bidirectional
+#pragma unroll                    // pass but a ragged last one: no per-score bit test (a shift, a compare and a select per score: ~40 % of
+        for (int r = 0; r < 16; ++r) {                 // the loop's VALU instructions); same bits as the masked form with all bits set
+          const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse2);
+          dp[r] = e * (dp[r] - dlt);
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kbit = (r & 3) + 8 * (r >> 2);
-        const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse2);   // unconditional: a select, not a branch per element
-        const float p = ((wsel >> kbit) & 1u) ? e : 0.f;
-        dp[r] = p * (dp[r] - dlt);
+        for (int r = 0; r < 16; ++r) {
+          const int kbit = (r & 3) + 8 * (r >> 2);
+          const float e = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse2);   // unconditional: a select, not a branch per element
+          const float p = ((wsel >> kbit) & 1u) ? e : 0.f;
+          dp[r] = p * (dp[r] - dlt);
+        }
       }
       bf16x8_t dsb[2];
 #pragma unroll
@@ -625,7 +661,7 @@ static int attn_bwd_launch(bool varlen, int causal, int window, const void* qkv,
   hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((items * 16 + 255) / 256)), dim3(256), 0, st, (const uint16_t*)out,
                      (const uint16_t*)dout, delta, T, varlen ? 0 : S_or_maxlen, nq, out_stride);
   GRIT_CHECK_LAUNCH("grit_attn_bidir_bwd: delta");
-  const int lds_kv = AB_RING;
+  const int lds_kv = AB_RING + 4 * 512;          // ring + the four waves' statistics tables (attn_bwd_dkdv_k)
   static std::atomic<uint64_t> optin{0};                       // per-device function attribute
   {
     int dev = 0;
