@@ -427,7 +427,14 @@ def compact_summary(line: dict) -> dict:
                  "err": rag.get("error")}}
 
     def prune(d):
-        return {k: (prune(v) if isinstance(v, dict) else v) for k, v in d.items() if v is not None and v != {}}
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                v = prune(v)
+            if v is None or v == {} or (isinstance(v, list) and all(x is None for x in v)) or (k.endswith("routing_agree_min") and v == 0.0):
+                continue
+            out[k] = v
+        return out
     s = prune(s)
     while len(json.dumps(s)) > 1500 and s:                 # never longer than the window: drop the least important tail entries
         s.pop(next(reversed(s)))

@@ -48,6 +48,9 @@ class CustomTrainingArguments(TrainingArguments):
     split_emb_full: bool = field(default=False)
     emb_q_only: bool = field(default=False)
     emb_p_only: bool = field(default=False)
+    pass1_precision: Optional[str] = field(default=None, metadata={"help": "(not a reference flag; native engine + GradCache only) precision "
+                                           "policy of GradCache pass 1, the no-grad forward that defines the loss: bf16 | f16_operands | f16_stream "
+                                           "(default: GRIT_PASS1_PRECISION or bf16, the reference's arithmetic)"})
     shard_optimizer: bool = field(default=False, metadata={"help": "(not a reference flag) AdamW state sharded over the data-parallel ranks: every "
                                   "parameter has one owner rank that updates and broadcasts it (training/sharded_optim.py); what the "
                                   "reference's FSDP configs buy for the 8x7B model, with whole bf16 replicas kept for the kernels"})

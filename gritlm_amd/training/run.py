@@ -139,7 +139,7 @@ def main(argv=None):
     total = args.max_steps if args.max_steps > 0 else int(steps_per_epoch * args.num_train_epochs)
     sched = get_scheduler(args.lr_scheduler_type, opt.local if sharded else opt, num_warmup_steps=args.get_warmup_steps(total),
                           num_training_steps=total)
-    gc = GradCacheStep(model, gc_chunk) if gc_chunk else None
+    gc = GradCacheStep(model, gc_chunk, precision=getattr(args, "pass1_precision", None)) if gc_chunk else None
 
     def save_checkpoint(step_):
         """checkpoint-<step>/: weights under the reference parameter names + optimizer / scheduler / step (HF Trainer layout)."""

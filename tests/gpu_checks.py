@@ -2723,8 +2723,14 @@ def check_cli_native(arch="mistral"):
         l1 = main(common + ["--max_steps", "1"])
         l8 = main(common + ["--max_steps", "8"])
         files = os.listdir(out)
+        # --pass1_precision (round 6, not a reference flag): GradCache pass 1 on fp16 operands -- the first step's loss moves by the bf16
+        # policy's rep error only, training still converges
+        l1h = main(common + ["--max_steps", "1", "--pass1_precision", "f16_operands"])
+        l8h = main(common + ["--max_steps", "8", "--pass1_precision", "f16_operands"])
     ok = np.isfinite(l1) and np.isfinite(l8) and l8 < l1 and "config.json" in files
-    return _res(f"CLI gritlm.training.run native [{arch}] (loss decreases over 8 steps)", ok, loss_step1=float(l1), loss_step8=float(l8))
+    ok = ok and np.isfinite(l1h) and np.isfinite(l8h) and l8h < l1h and abs(l1h - l1) < 5e-2 * max(1.0, abs(l1))
+    return _res(f"CLI gritlm.training.run native [{arch}] (loss decreases over 8 steps; --pass1_precision f16_operands)", ok, loss_step1=float(l1),
+                loss_step8=float(l8), loss_step1_f16_pass1=float(l1h), loss_step8_f16_pass1=float(l8h))
 
 
 def check_cli_unified_native(arch="mistral"):

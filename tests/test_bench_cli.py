@@ -72,3 +72,20 @@ def test_gpus_8_dry_run_is_the_eight_rank_job_the_driver_will_launch():
     assert c["global_batch"] == 32 and c["n_gpus"] == 8
     assert c["per_step_ms"]["gather_collectives"] == 2 + 4
     assert c["grad_norm_spread_over_ranks"] < 1e-6 * max(1.0, c["grad_norm_after_averaging"])
+
+
+def test_summary_is_compact_and_covers_every_leg():
+    """bench.compact_summary (VERDICT r05 #2b): built from a full line it stays under 1500 characters, carries both headline metrics, the
+    north-star policy's rate, and the parity datum of every leg; missing legs are dropped, never a crash."""
+    sys.path.insert(0, ROOT)
+    import bench
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+    line.pop("summary")
+    s = bench.compact_summary(line)
+    assert len(json.dumps(s)) <= 1500
+    assert s["encode_docs_per_s"] > 0 and s["ns_policy"] in ("f16_stream", "f16_operands") and s["ns_timed_steps"] == line["steps"]
+    assert s["contrastive"]["loss_abs_err"] < 1e-3 and s["contrastive"]["pass1"] == line["contrastive"]["pass1_precision"]
+    assert "f16_e2e_1mcos" in s["mixtral"] and "ref_bf16_dataflow_e2e_1mcos" in s["mixtral"] and s["rag"]["decode_frac"] > 0
+    assert list(json.loads(json.dumps({**line, "summary": s})))[-1] == "summary"
+    bare = bench.compact_summary({"value": 1.0, "n_gpus": 8, "roofline": {"frac": 0.5}})
+    assert bare["encode_docs_per_s"] == 1.0 and "mixtral" not in bare and "contrastive" not in bare

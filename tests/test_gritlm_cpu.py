@@ -229,3 +229,60 @@ def test_precision_keyword_is_validated(dirs):
     assert GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", residual_fp32=True)._precision == "fp32_residual"
     assert GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", precision="f16_operands")._precision == "f16_operands"
     assert GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu")._precision == "bf16"
+
+
+class _LadderEngine(_FakeEngine):
+    """_FakeEngine with a precision policy and a sticky overflow flag: the flag is raised by every encode under a policy in `overflows_under`"""
+
+    def __init__(self, tag, overflows_under=()):
+        super().__init__(tag)
+        self.precision, self.flag, self.overflows_under, self.cleared = "bf16", False, tuple(overflows_under), 0
+        self.policies_run = []
+
+    def supported_precisions(self):
+        return ("f16_stream", "f16_operands", "fp32_residual", "bf16")
+
+    def set_precision(self, p):
+        self.precision = p
+
+    def encode_pooled(self, ids, mask, method, normalize, instr_len=None):
+        self.policies_run.append(self.precision)
+        if self.precision in self.overflows_under:
+            self.flag = True
+        return super().encode_pooled(ids, mask, method, normalize, instr_len)
+
+    def f16_overflowed(self, clear=True):
+        f = self.flag
+        if clear:
+            self.flag = False
+            self.cleared += 1
+        return f
+
+
+def test_auto_ladder_reruns_the_call_one_rung_down_and_never_raises(dirs):
+    """precision='auto' (host logic; the kernels' side is tests/gpu_checks.py::check_gritlm_f16_auto_ladder): a flag set during the call
+    re-runs the WHOLE call one rung down -- twice if the next rung overflows too --, the rung is sticky, every replica's flag is read and
+    cleared (also a stale one at the start of a call), and an explicit fp16 policy raises naming the flagged devices."""
+    from gritlm_amd._lib import GritHipError
+    m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", precision="auto")
+    sents = synth.make_sentences(7, seed=6, min_words=3, max_words=20)
+    e0, e1 = _LadderEngine(0, overflows_under=("f16_stream", "f16_operands")), _LadderEngine(1)
+    m.engine, m.engines, m.num_gpus = e0, [e0, e1], 2
+    m.set_precision("auto")
+    assert m.precision == "f16_stream" and e1.precision == "f16_stream"
+    e1.flag = True                                           # a stale flag from an earlier, unchecked forward on the second replica
+    out = m.encode(sents, batch_size=2, max_length=32)
+    assert out.shape[0] == 7 and m.precision == "fp32_residual" and e1.precision == "fp32_residual"      # two rungs down, all replicas together
+    assert e0.policies_run[:2] == ["f16_stream", "f16_stream"] and "f16_operands" in e0.policies_run and e0.policies_run[-1] == "fp32_residual"
+    n_calls = len(e0.policies_run)
+    out2 = m.encode(sents, batch_size=2, max_length=32)      # sticky: straight on the rung, one pass
+    assert len(e0.policies_run) == n_calls + (n_calls // 3) and set(e0.policies_run[n_calls:]) == {"fp32_residual"}
+    np.testing.assert_array_equal(out[:, :2], out2[:, :2])
+    # explicit policy: raises, names the device, leaves no flag behind
+    m.set_precision("f16_stream")
+    assert not m._auto and e0.precision == e1.precision == "f16_stream"
+    with pytest.raises(GritHipError, match="fp16 range"):
+        m.encode(sents, batch_size=2, max_length=32)
+    assert not e0.flag and not e1.flag
+    m.set_precision("bf16")
+    assert m.encode(sents, batch_size=2, max_length=32).shape[0] == 7

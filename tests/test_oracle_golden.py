@@ -400,3 +400,30 @@ def test_numeric_bounds_match_committed_fixtures(golden_dir):
         pat = re.escape(lit)
         pat = re.sub(r'\\\{[a-z_]+\\\}', r'[^/]+' if lit.startswith(("encoder_", "gritlm_")) else r'.+', pat)
         assert any(re.fullmatch(pat, k) for k in frozen["values"]), lit
+
+
+def test_torch_reference_training_forward_is_the_encode_with_exact_gradients():
+    """oracle/torch_reference.py::encode_with_grad / contrastive_loss (the reference side of bench.py's contrastive parity object): the
+    differentiable encode equals the no-grad `encode` bit for bit, gradient checkpointing changes no gradient, and the loss is the oracle's
+    InfoNCE (gritlm/training/model.py:36-47) on the same representations."""
+    import torch
+    import torch_reference as TR
+    import gritlm_oracle as O
+    cfg = synth.CONFIGS["tiny"]
+    model = TR.build_model(cfg, torch.float32, "cpu", seed=3)
+    ids, mask = synth.make_batch(cfg, 6, 20, seed=8, min_len=5)
+    tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    ref = TR.encode(model, tid, tm)
+    grads = {}
+    for ck in (False, True):
+        model.zero_grad(set_to_none=True)
+        model.train()
+        e = TR.encode_with_grad(model, tid, tm, checkpoint=ck)
+        assert torch.equal(e.detach(), ref)
+        loss = TR.contrastive_loss(e[:2], e[2:], 0.02)
+        loss.backward()
+        grads[ck] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        l_oracle = O.infonce(e[:2].detach().numpy(), e[2:].detach().numpy(), 0.02)[0]
+        assert abs(float(loss.detach()) - l_oracle) < 2e-5
+    for n in grads[False]:
+        assert torch.allclose(grads[False][n], grads[True][n], rtol=0, atol=1e-7 * float(grads[False][n].abs().max() + 1e-30)), n
