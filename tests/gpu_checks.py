@@ -2222,6 +2222,9 @@ def check_train_recompute(cfg_name="gqa"):
             if rc:
                 m.gradient_checkpointing_enable()
                 assert m.train_engine.recompute
+            import gc
+            gc.collect()                                 # garbage of the previous configuration freed INSIDE the forward would hide the peak
+            torch.cuda.synchronize()
             torch.cuda.reset_peak_memory_stats()
             base = torch.cuda.memory_allocated()
             o = m(query=dict(q), passage=dict(p))
