@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRIT_HIP_LIB") or os.path.join(_HERE, "libgritlm_hip.so")      # GRIT_HIP_LIB: A/B builds (tools/ubench)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gritlm_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 GRIT_OK, GRIT_E_BADARG, GRIT_E_UNSUPPORTED, GRIT_E_LAUNCH, GRIT_E_RCCL = 0, -1, -2, -3, -4
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_ROPE, EPI_SWIGLU_STACKED, EPI_SWIGLU_STACKED_SAVE, EPI_SWIGLU_BWD, EPI_RESIDUAL_F32 = 0, 1, 2, 3, 4, 5, 6, 7
 POOL_MODES = {"mean": 0, "weightedmean": 1, "cls": 2, "lasttoken": 3}
@@ -65,6 +65,10 @@ _SIGNATURES = {
     "grit_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_attn_decode_rope": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_argmax_advance": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _i, _p]),
+    "grit_gemv_f16": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p, _l, _p]),
+    "grit_rmsnorm_gemv_f16_deferred": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p]),
+    "grit_attn_decode_rope_f16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_argmax_advance_f32": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _i, _p]),
     "grit_knn_workspace_bytes": (_l, [_i, _l, _i]),
     "grit_knn_topk": (_i, [_p, _p, _i, _l, _i, _l, _l, _i, _p, _p, _p, _p]),
     "grit_ce_fwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _p]),

@@ -7,6 +7,12 @@
 //   attn_decode one query row per (sequence, head) against cache[:, :lens[b]+1] (flash-decoding split over the keys) + combine
 //   argmax      greedy next token (lowest index on ties) and lens[b] += 1
 // Every kernel reads its dynamic sizes (lens) from DEVICE memory so that a whole step can be captured in one HIP graph.
+//
+// F16 (round 6): the same kernels on IEEE fp16 weights and an fp16 KV cache, around an fp32 residual stream -- the decode half of the
+// encoder's "f16_operands" policy (the RAG flow continues from the fp16 K/V of encode(get_cache=True)).  Formats under F16: the stream h,
+// the fused q|k|v row and the logits are fp32 (residual adds, the rotation of q and the argmax see unrounded values); every GEMV operand
+// -- the stream's copy h16 in front of a norm, ctx, act -- is fp16, rounded once from fp32; K / V are rounded to fp16 once when they
+// enter the cache.  Values beyond the fp16 range raise the per-device flag word every fp16 kernel of the library reports through (common.h).
 #include "common.h"
 
 namespace grit {
@@ -16,6 +22,14 @@ __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
   return bflo(a.x) * bflo(b.x) + bfhi(a.x) * bfhi(b.x) + bflo(a.y) * bflo(b.y) + bfhi(a.y) * bfhi(b.y) + bflo(a.z) * bflo(b.z) +
          bfhi(a.z) * bfhi(b.z) + bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
 }
+// eight 16-bit values of the operand format -> fp32
+template <bool F16>
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+  f[0] = lo16_op<F16>(v.x); f[1] = hi16_op<F16>(v.x); f[2] = lo16_op<F16>(v.y); f[3] = hi16_op<F16>(v.y);
+  f[4] = lo16_op<F16>(v.z); f[5] = hi16_op<F16>(v.z); f[6] = lo16_op<F16>(v.w); f[7] = hi16_op<F16>(v.w);
+}
+// one fp32 value -> the 16 bits of its fp16 rounding (RNE; beyond 65504: inf, reported by the caller)
+__device__ __forceinline__ uint16_t f2h_bits(float f) { return (uint16_t)(pack2h_hw(f, 0.f) & 0xffffu); }
 
 // All-reduce of NG independent values over the 64 lanes in registers: four row rotations by DPP (all-reduce inside every 16-lane row),
 // then v_permlane16_swap / v_permlane32_swap for the rows (gfx950) -- no LDS-queue instruction.  (`wave_max` / `wave_sum` of common.h
@@ -50,6 +64,11 @@ __device__ __forceinline__ void wave_allreduce(float (&v)[NG]) {
 #define GRIT_GV_ROWS 4      // (A/B builds: tools/decode_variants.sh)
 #endif
 constexpr int GV_ROWS = GRIT_GV_ROWS;  // weight rows per workgroup; its 4 waves each take a quarter of K (split-K, LDS reduce)
+#ifndef GRIT_GV_ROWS_SWIGLU
+#define GRIT_GV_ROWS_SWIGLU GRIT_GV_ROWS
+#endif
+constexpr int GV_ROWS_SW = GRIT_GV_ROWS_SWIGLU;   // the same for the gate|up launches (SwiGLU epilogue: rows come in (gate, up) pairs);
+                                                  // 4 / 8 / 16 rows: 2.757 / 2.798 / 2.824 ms per token (profiles/r06_decode_f16_ab.log)
 
 // MODE 0: store, 1: + residual, 2: SwiGLU pairs (rows r, r+16 of the interleaved layout).
 // PRENORM 1: x is the raw residual stream and the kernel applies MistralRMSNorm on the fly (x_n = bf16(w_ln * bf16(x * rsqrt(mean x^2 + eps))),
@@ -60,10 +79,16 @@ constexpr int GV_ROWS = GRIT_GV_ROWS;  // weight rows per workgroup; its 4 waves
 // product, the sum of squares is accumulated from the x pieces the lane loads for the product anyway (the four waves' split-K quarters
 // cover the row exactly once) and reduced beside it: no second pass over x, no dependency in front of the weight stream.  x_n is never
 // rounded to bf16 (the reference rounds it twice): one rounding fewer than the reference's arithmetic, not the same bits.
-template <int NB, int MODE, int PRENORM, int R>
+// F16: W and x in fp16; MODE 0 / 1 write fp32 (q|k|v row, logits / the stream: out = res + dot, nothing rounded), MODE 2 writes the fp16
+// activation (one rounding of silu(g) * u).  MODE 1 additionally writes out16 = fp16(out): the operand copy of the stream the next
+// norm + GEMV reads (an fp32 x would double the x traffic of the 7168 gate|up workgroups: measured +2.8 us per launch, 3 % of a token).
+// PRENORM 1 (the exact bf16 form) has no fp16 counterpart.  ld* are in elements of the respective format.
+template <int NB, int MODE, int PRENORM, int R, bool F16 = false>
 __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
                                                    const uint16_t* __restrict__ res, const uint16_t* __restrict__ ln_w, float eps, int B, int N,
-                                                   int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr) {
+                                                   int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr, unsigned int* __restrict__ flag,
+                                                   uint16_t* __restrict__ out16, int64_t ldo16) {
+  static_assert(!(F16 && PRENORM == 1), "the exact fused norm rounds to bf16: bf16 only");
   __shared__ float red[4][R][NB];
   __shared__ float red_ss[4][NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -92,6 +117,10 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W + (int64_t)rows[i] * ldw) + c);
     return make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  // eight x values of row b at chunk c, as fp32
+  auto xload = [&](int b, int c, float (&xf)[8]) {
+    unpack8<F16>(reinterpret_cast<const uint4*>(x + (int64_t)(b < B ? b : 0) * ldx)[c], xf);
   };
   const int c0 = wave * 64 + lane;
   uint4 wv[R];
@@ -132,21 +161,23 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
     if (PRENORM) lw = reinterpret_cast<const uint4*>(ln_w)[c];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      uint4 xv = reinterpret_cast<const uint4*>(x + (int64_t)(b < B ? b : 0) * ldx)[c];
-      if (PRENORM == 2) {
-        const float xf[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
-        const float lf[8] = {bflo(lw.x), bfhi(lw.x), bflo(lw.y), bfhi(lw.y), bflo(lw.z), bfhi(lw.z), bflo(lw.w), bfhi(lw.w)};
+      if (PRENORM == 2 || F16) {
         float xs[8];
+        xload(b, c, xs);
+        if (PRENORM == 2) {
+          const float lf[8] = {bflo(lw.x), bfhi(lw.x), bflo(lw.y), bfhi(lw.y), bflo(lw.z), bfhi(lw.z), bflo(lw.w), bfhi(lw.w)};   // (norm weights stay bf16)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ssq[b] += xf[e] * xf[e]; xs[e] = xf[e] * lf[e]; }
+          for (int e = 0; e < 8; ++e) { ssq[b] += xs[e] * xs[e]; xs[e] = xs[e] * lf[e]; }
+        }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           const uint4 w = wv[i];
-          acc[i][b] += bflo(w.x) * xs[0] + bfhi(w.x) * xs[1] + bflo(w.y) * xs[2] + bfhi(w.y) * xs[3] + bflo(w.z) * xs[4] + bfhi(w.z) * xs[5] +
-                       bflo(w.w) * xs[6] + bfhi(w.w) * xs[7];
+          acc[i][b] += lo16_op<F16>(w.x) * xs[0] + hi16_op<F16>(w.x) * xs[1] + lo16_op<F16>(w.y) * xs[2] + hi16_op<F16>(w.y) * xs[3] +
+                       lo16_op<F16>(w.z) * xs[4] + hi16_op<F16>(w.z) * xs[5] + lo16_op<F16>(w.w) * xs[6] + hi16_op<F16>(w.w) * xs[7];
         }
         continue;
       }
+      uint4 xv = reinterpret_cast<const uint4*>(x + (int64_t)(b < B ? b : 0) * ldx)[c];
       if (PRENORM == 1) {
         const float s_ = inv[b];
         xv.x = pack2bf(round_bf(bflo(xv.x) * s_) * bflo(lw.x), round_bf(bfhi(xv.x) * s_) * bfhi(lw.x));
@@ -196,15 +227,31 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
         const float rs = row_scale(b);
         const float g = (red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b]) * rs;
         const float u = (red[0][2 * i + 1][b] + red[1][2 * i + 1][b] + red[2][2 * i + 1][b] + red[3][2 * i + 1][b]) * rs;
-        out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_f(round_bf(g))) * round_bf(u));
+        if constexpr (F16) {
+          const uint16_t hb = f2h_bits(silu_f(g) * u);
+          if ((hb & 0x7c00u) == 0x7c00u) atomicOr(flag, 1u);
+          out[(int64_t)b * ldo + p] = hb;
+        } else {
+          out[(int64_t)b * ldo + p] = (uint16_t)f2bf(round_bf(silu_f(round_bf(g))) * round_bf(u));
+        }
       }
     }
   } else if (t < R * NB) {
     const int i = t / NB, b = t - i * NB, n = unit * R + i;
     if (n < N && b < B) {
       float v = (red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b]) * row_scale(b);
-      if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
-      out[(int64_t)b * ldo + n] = (uint16_t)f2bf(v);
+      if constexpr (F16) {
+        if (MODE == 1) v += reinterpret_cast<const float*>(res)[(int64_t)b * ldr + n];
+        reinterpret_cast<float*>(out)[(int64_t)b * ldo + n] = v;
+        if (MODE == 1 && out16) {
+          const uint16_t hb = f2h_bits(v);
+          if ((hb & 0x7c00u) == 0x7c00u) atomicOr(flag, 1u);
+          out16[(int64_t)b * ldo16 + n] = hb;
+        }
+      } else {
+        if (MODE == 1) v = round_bf(v) + bf2f(res[(int64_t)b * ldr + n]);
+        out[(int64_t)b * ldo + n] = (uint16_t)f2bf(v);
+      }
     }
   }
 }
@@ -281,11 +328,13 @@ constexpr int AD_D = 128, AD_CH = 64, AD_G = 8;   // up to 8 query heads per kv 
 // are gq workgroups that read the same K / V slice (the duplicates hit L2) and each does a quarter of the arithmetic: the kernel is one
 // wave deep and bound by its own instruction stream (a slice of 64 keys x 4 heads is ~2000 dependent-free FMAs per lane), not by the
 // 32 KB it reads.  Every one of them rotates the new key itself; they write identical cache rows.
-template <bool ROPE, int G, bool PH = false>
+// F16: the q (ROPE: q|k|v) row is fp32 -- q is rotated and scaled without a rounding, the new k / v are rounded to fp16 once, on their way
+// into the cache -- and the cache is fp16.
+template <bool ROPE, int G, bool PH = false, bool F16 = false>
 __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__ q, uint16_t* __restrict__ ck, uint16_t* __restrict__ cv,
                                                     const int32_t* __restrict__ lens, float* __restrict__ part, const float* __restrict__ cos_tab,
                                                     const float* __restrict__ sin_tab, int nq, int nkv, int Lmax, int64_t q_stride, float scale,
-                                                    int max_splits) {
+                                                    int max_splits, unsigned int* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) float qs[G][AD_D];   // query heads of this kv head, pre-scaled
   __shared__ float ps[G][64];                                  // probabilities of the 64 keys
   __shared__ __attribute__((aligned(16))) uint16_t newk[AD_D]; // ROPE, owner workgroup: the new key (rotated) and value rows, handed to the
@@ -327,24 +376,35 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     const int pos = L - 1;
     const float c = cos_tab[(int64_t)pos * 64 + lane], sn = sin_tab[(int64_t)pos * 64 + lane];     // lane <-> pair (e, e + 64)
     const uint16_t* row = q + (int64_t)b * q_stride;
+    const float* rowf = reinterpret_cast<const float*>(q) + (int64_t)b * q_stride;       // F16: the fp32 q|k|v row
+    auto qk_at = [&](int64_t i) -> float { if constexpr (F16) return rowf[i]; else return bf2f(row[i]); };
     float x1[G], x2[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {                             // all 2 G loads in flight before the first use
-      x1[g] = bf2f(row[(int64_t)(hk * gq + g0 + g) * AD_D + lane]); x2[g] = bf2f(row[(int64_t)(hk * gq + g0 + g) * AD_D + 64 + lane]);
+      x1[g] = qk_at((int64_t)(hk * gq + g0 + g) * AD_D + lane); x2[g] = qk_at((int64_t)(hk * gq + g0 + g) * AD_D + 64 + lane);
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const uint32_t r = pack2bf(rope_lo(x1[g], x2[g], c, sn), rope_hi(x1[g], x2[g], c, sn));         // one rounding, as rope_k
-      qs[g][lane] = bflo(r) * scale; qs[g][64 + lane] = bfhi(r) * scale;
+      if constexpr (F16) {
+        qs[g][lane] = rope_lo(x1[g], x2[g], c, sn) * scale; qs[g][64 + lane] = rope_hi(x1[g], x2[g], c, sn) * scale;
+      } else {
+        const uint32_t r = pack2bf(rope_lo(x1[g], x2[g], c, sn), rope_hi(x1[g], x2[g], c, sn));         // one rounding, as rope_k
+        qs[g][lane] = bflo(r) * scale; qs[g][64 + lane] = bfhi(r) * scale;
+      }
     }
     if (owner) {                                          // this workgroup owns the new key: rotate k, append k and v
-      const uint16_t* kr = row + (int64_t)(nq + hk) * AD_D;
-      const uint16_t* vr = row + (int64_t)(nq + nkv + hk) * AD_D;
-      const float y1 = bf2f(kr[lane]), y2 = bf2f(kr[64 + lane]);
-      const uint32_t r = pack2bf(rope_lo(y1, y2, c, sn), rope_hi(y1, y2, c, sn));
+      const int64_t ko = (int64_t)(nq + hk) * AD_D, vo = (int64_t)(nq + nkv + hk) * AD_D;
+      const float y1 = qk_at(ko + lane), y2 = qk_at(ko + 64 + lane);
+      const uint32_t r = F16 ? pack2h_hw(rope_lo(y1, y2, c, sn), rope_hi(y1, y2, c, sn)) : pack2bf(rope_lo(y1, y2, c, sn), rope_hi(y1, y2, c, sn));
       uint16_t* kd = ck + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D;
       kd[lane] = (uint16_t)(r & 0xffff); kd[64 + lane] = (uint16_t)(r >> 16);
-      const uint32_t vw = reinterpret_cast<const uint32_t*>(vr)[lane];
+      uint32_t vw;
+      if constexpr (F16) {
+        vw = pack2h_hw(rowf[vo + 2 * lane], rowf[vo + 2 * lane + 1]);
+        if (h2_nonfinite(r) | h2_nonfinite(vw)) atomicOr(flag, 1u);
+      } else {
+        vw = reinterpret_cast<const uint32_t*>(row + vo)[lane];
+      }
       reinterpret_cast<uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D)[lane] = vw;
       newk[lane] = (uint16_t)(r & 0xffff); newk[64 + lane] = (uint16_t)(r >> 16);
       newv[lane] = vw;
@@ -352,7 +412,8 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
   } else {
     for (int i = lane; i < G * AD_D; i += 64) {
       const int g = i / AD_D, e = i - g * AD_D;
-      qs[g][e] = bf2f(q[(int64_t)b * q_stride + (int64_t)(hk * gq + g0 + g) * AD_D + e]) * scale;
+      const int64_t qi = (int64_t)b * q_stride + (int64_t)(hk * gq + g0 + g) * AD_D + e;
+      qs[g][e] = (F16 ? reinterpret_cast<const float*>(q)[qi] : bf2f(q[qi])) * scale;
     }
   }
   __syncthreads();
@@ -372,8 +433,8 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
   for (int g = 0; g < G; ++g) s[g] = 0.f;
 #pragma unroll
   for (int c = 0; c < AD_D / 8; ++c) {
-    const uint4 kv = kreg[c];
-    const float kf[8] = {bflo(kv.x), bfhi(kv.x), bflo(kv.y), bfhi(kv.y), bflo(kv.z), bfhi(kv.z), bflo(kv.w), bfhi(kv.w)};
+    float kf[8];
+    unpack8<F16>(kreg[c], kf);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const float4 qa = *reinterpret_cast<const float4*>(&qs[g][c * 8]), qb = *reinterpret_cast<const float4*>(&qs[g][c * 8 + 4]);
@@ -401,8 +462,8 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
     for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const uint4 v = vreg[j];
-    const float vf[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+    float vf[8];
+    unpack8<F16>(vreg[j], vf);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const float p = ps[g][kg * 16 + j];            // 0 for keys past the sequence
@@ -428,6 +489,7 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
   }
 }
 
+template <bool F16 = false>
 __global__ void __launch_bounds__(128) attn_decode_combine_k(const float* __restrict__ part, uint16_t* __restrict__ out, int nq, int nkv,
                                                              int max_splits, int64_t out_stride) {
   // (round 5) every wave derives the global maximum and the denominator for itself, in registers: the (m_s, l_s) pairs of all splits
@@ -470,10 +532,13 @@ __global__ void __launch_bounds__(128) attn_decode_combine_k(const float* __rest
   for (int sp = 0; sp < 64; ++sp) acc += pv[sp] * (sp < max_splits ? fs[wave][sp] : 0.f);      // same order as the loop below
 #pragma unroll 8
   for (int sp = 64; sp < max_splits; ++sp) acc += base[sp * sstride + 2 + e] * fs[wave][sp];
-  out[(int64_t)b * out_stride + (int64_t)h * AD_D + e] = (uint16_t)f2bf(l[0] > 0.f ? acc / l[0] : 0.f);
+  const float o = l[0] > 0.f ? acc / l[0] : 0.f;                    // a convex combination of cached values: inside their range
+  out[(int64_t)b * out_stride + (int64_t)h * AD_D + e] = F16 ? f2h_bits(o) : (uint16_t)f2bf(o);
 }
 
 // ---- greedy sampling + advance: next[b] = argmax_v logits[b, v] (lowest index on ties), lens[b] += 1
+// L32: fp32 logits (the fp16-operand decode step keeps them unrounded)
+template <bool L32 = false>
 __global__ void __launch_bounds__(256) argmax_advance_k(const uint16_t* __restrict__ logits, int64_t ld, int V, int64_t* __restrict__ next,
                                                         int32_t* __restrict__ lens, int64_t* __restrict__ history, int64_t hist_stride,
                                                         const int32_t* __restrict__ step) {
@@ -483,16 +548,22 @@ __global__ void __launch_bounds__(256) argmax_advance_k(const uint16_t* __restri
   float best = -INFINITY;
   int idx = 0x7fffffff;
   const uint16_t* row = logits + (int64_t)b * ld;
-  const int VC = V >> 3;                                      // 16-byte chunks (ld % 8 == 0 keeps the rows aligned)
+  const float* rowf = reinterpret_cast<const float*>(logits) + (int64_t)b * ld;
+  const int VC = V >> 3;                                      // chunks of 8 (ld % 8 == 0 keeps the rows aligned)
   for (int c = tid; c < VC; c += 256) {
-    const uint4 u = reinterpret_cast<const uint4*>(row)[c];
-    const float x[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+    float x[8];
+    if constexpr (L32) {
+      const float4 u = reinterpret_cast<const float4*>(rowf)[2 * c], w = reinterpret_cast<const float4*>(rowf)[2 * c + 1];
+      x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+    } else {
+      unpack8<false>(reinterpret_cast<const uint4*>(row)[c], x);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (x[e] > best) { best = x[e]; idx = c * 8 + e; }      // ascending index inside a thread: first maximum wins
   }
   for (int v = (VC << 3) + tid; v < V; v += 256) {
-    const float x = bf2f(row[v]);
+    const float x = L32 ? rowf[v] : bf2f(row[v]);
     if (x > best || (x == best && v < idx)) { best = x; idx = v; }
   }
 #pragma unroll
@@ -518,17 +589,44 @@ __global__ void bump_k(int32_t* v) { v[0] += 1; }
 
 using namespace grit;
 
-template <int MODE, int PRENORM, int R = GV_ROWS>
+template <int MODE, int PRENORM, bool F16 = false, int R = (MODE == 2 ? GV_ROWS_SW : GV_ROWS)>
 static int launch_gemv(const void* x, const void* W, void* out, const void* res, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
-                       int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st) {
+                       int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st, void* out16 = nullptr, int64_t ldo16 = 0) {
   const int units = MODE == 2 ? (N / 2 + R / 2 - 1) / (R / 2) : (N + R - 1) / R;
   const dim3 grid((unsigned)units);
+  unsigned int* flag = F16 ? f16_flag_ptr() : nullptr;
+  if (F16 && !flag) return GRIT_E_LAUNCH;
 #define GRIT_GEMV(NB_)                                                                                                                    \
-  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM, R>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out,   \
-                     (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr)
+  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM, R, F16>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out, \
+                     (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr, flag, (uint16_t*)out16, ldo16)
   if (B == 1) GRIT_GEMV(1); else if (B == 2) GRIT_GEMV(2); else if (B <= 4) GRIT_GEMV(4); else GRIT_GEMV(8);
 #undef GRIT_GEMV
-  GRIT_CHECK_LAUNCH("grit_gemv_bf16");
+  GRIT_CHECK_LAUNCH(F16 ? "grit_gemv_f16" : "grit_gemv_bf16");
+  return GRIT_OK;
+}
+
+// the fp16-operand forms (formats in the kernel's header comment); ln_w: the deferred norm
+static int gemv_entry_f16(const char* name, const void* x, const void* W, void* out, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
+                          int64_t ldw, int64_t ldo, int epilogue, const void* residual, int64_t ldr, void* out16, int64_t ldo16, void* stream) {
+  if (B == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && W && out, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && B <= 8, GRIT_E_UNSUPPORTED, "%s: B=%d rows (1..8; larger batches use grit_gemm_f16_nt)", name, B);
+  GRIT_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(aligned16(x) && aligned16(W) && (!ln_w || aligned16(ln_w)), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  hipStream_t st = (hipStream_t)stream;
+  const bool pn = ln_w != nullptr;
+  switch (epilogue) {
+    case GRIT_EPI_STORE: GRIT_REQUIRE(ldo >= N, GRIT_E_BADARG, "%s: ldo < N", name);
+      return pn ? launch_gemv<0, 2, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                : launch_gemv<0, 0, true>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+    case GRIT_EPI_RESIDUAL: GRIT_REQUIRE(residual && ldo >= N && ldr >= N && !pn, GRIT_E_BADARG, "%s: RESIDUAL needs residual, ldo, ldr >= N (no pre-norm)", name);
+      GRIT_REQUIRE(!out16 || ldo16 >= N, GRIT_E_BADARG, "%s: ldo16 < N", name);
+      return launch_gemv<1, 0, true>(x, W, out, residual, nullptr, 0.f, B, N, K, ldx, ldw, ldo, ldr, st, out16, ldo16);
+    case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "%s: SWIGLU needs N %% 32 == 0, ldo >= N/2", name);
+      return pn ? launch_gemv<2, 2, true>(x, W, out, nullptr, ln_w, eps, B, N, K, ldx, ldw, ldo, 0, st)
+                : launch_gemv<2, 0, true>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st);
+    default: GRIT_REQUIRE(false, GRIT_E_BADARG, "%s: unknown epilogue %d", name, epilogue);
+  }
   return GRIT_OK;
 }
 
@@ -571,6 +669,19 @@ extern "C" int grit_rmsnorm_gemv_bf16(const void* x, const void* ln_weight, floa
   return gemv_entry("grit_rmsnorm_gemv_bf16", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream);
 }
 
+extern "C" int grit_gemv_f16(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int epilogue,
+                             const void* residual, int64_t ldr, void* out16, int64_t ldo16, void* stream) {
+  GRIT_REQUIRE(!out16 || epilogue == GRIT_EPI_RESIDUAL, GRIT_E_BADARG, "grit_gemv_f16: out16 goes with the RESIDUAL epilogue");
+  return gemv_entry_f16("grit_gemv_f16", x, W, out, nullptr, 0.f, B, N, K, ldx, ldw, ldo, epilogue, residual, ldr, out16, ldo16, stream);
+}
+
+extern "C" int grit_rmsnorm_gemv_f16_deferred(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K,
+                                              int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
+  GRIT_REQUIRE(ln_weight, GRIT_E_BADARG, "grit_rmsnorm_gemv_f16_deferred: null pointer");
+  GRIT_REQUIRE(epilogue != GRIT_EPI_RESIDUAL, GRIT_E_BADARG, "grit_rmsnorm_gemv_f16_deferred: STORE or SWIGLU");
+  return gemv_entry_f16("grit_rmsnorm_gemv_f16_deferred", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, nullptr, 0, stream);
+}
+
 // the DEFERRED form of the fused norm (PRENORM 2 above): one launch, no second pass over x; x_n is not rounded to bf16
 extern "C" int grit_rmsnorm_gemv_bf16_deferred(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K,
                                                int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
@@ -609,6 +720,7 @@ extern "C" int64_t grit_attn_decode_workspace_floats(int B, int nq, int nkv, int
   return (int64_t)B * nkv * splits * (nq / nkv) * (AD_D + 2);
 }
 
+template <bool F16>
 static int attn_decode_launch(const char* name, const void* q, void* cache_k, void* cache_v, const int32_t* lens, void* out, float* workspace,
                               const float* cos_tab, const float* sin_tab, int B, int nq, int nkv, int d, int Lmax, int64_t q_stride,
                               int64_t out_stride, float scale, void* stream) {
@@ -621,21 +733,23 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
   const int splits = (Lmax + AD_CH - 1) / AD_CH;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)splits, (unsigned)nkv, (unsigned)B);
+  unsigned int* flag = F16 ? f16_flag_ptr() : nullptr;
+  if (F16 && !flag) return GRIT_E_LAUNCH;
   // one workgroup per query head (PH above) for GQA models: 8.74 -> 7.52 us per launch at L = 2 k, 32 / 8 heads (kernel trace,
   // profiles/r05_decode_kernel_stats_perhead.csv); GRIT_ATTN_DECODE_PER_HEAD=0 is the A/B knob
   static const int per_head = getenv("GRIT_ATTN_DECODE_PER_HEAD") ? atoi(getenv("GRIT_ATTN_DECODE_PER_HEAD")) : 1;
   if (per_head && nq / nkv > 1) {
     const dim3 gridh((unsigned)splits, (unsigned)nq, (unsigned)B);
     if (cos_tab)
-      hipLaunchKernelGGL((attn_decode_k<true, 1, true>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
-                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits);
+      hipLaunchKernelGGL((attn_decode_k<true, 1, true, F16>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
+                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag);
     else
-      hipLaunchKernelGGL((attn_decode_k<false, 1, true>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
-                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits);
+      hipLaunchKernelGGL((attn_decode_k<false, 1, true, F16>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
+                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag);
   } else {
 #define GRIT_AD_LAUNCH(R, GG)                                                                                                           \
-  hipLaunchKernelGGL((attn_decode_k<R, GG>), grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace, \
-                     cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits)
+  hipLaunchKernelGGL((attn_decode_k<R, GG, false, F16>), grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace, \
+                     cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag)
 #define GRIT_AD_BY_G(R)                                                                                                                 \
   switch (nq / nkv) {                                                                                                                   \
     case 1: GRIT_AD_LAUNCH(R, 1); break;                                                                                                \
@@ -649,7 +763,7 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
 #undef GRIT_AD_LAUNCH
   }
   GRIT_CHECK_LAUNCH(name);
-  hipLaunchKernelGGL(attn_decode_combine_k, dim3((unsigned)nq, (unsigned)B), dim3(AD_D), 0, st, (const float*)workspace, (uint16_t*)out, nq, nkv,
+  hipLaunchKernelGGL(attn_decode_combine_k<F16>, dim3((unsigned)nq, (unsigned)B), dim3(AD_D), 0, st, (const float*)workspace, (uint16_t*)out, nq, nkv,
                      splits, out_stride);
   GRIT_CHECK_LAUNCH(name);
   return GRIT_OK;
@@ -657,7 +771,7 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
 
 extern "C" int grit_attn_decode(const void* q, const void* cache_k, const void* cache_v, const int32_t* lens, void* out, float* workspace, int B,
                                 int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale, void* stream) {
-  return attn_decode_launch("grit_attn_decode", q, (void*)cache_k, (void*)cache_v, lens, out, workspace, nullptr, nullptr, B, nq, nkv, d, Lmax,
+  return attn_decode_launch<false>("grit_attn_decode", q, (void*)cache_k, (void*)cache_v, lens, out, workspace, nullptr, nullptr, B, nq, nkv, d, Lmax,
                             q_stride, out_stride, scale, stream);
 }
 
@@ -667,22 +781,45 @@ extern "C" int grit_attn_decode_rope(const void* qkv, const float* cos_tab, cons
   GRIT_REQUIRE(cos_tab && sin_tab, GRIT_E_BADARG, "grit_attn_decode_rope: null pointer");
   GRIT_REQUIRE(nq > 0 && nkv > 0 && nq <= 65535 && nkv <= 65535 && d > 0 && d <= 65535, GRIT_E_BADARG, "grit_attn_decode_rope: bad sizes");
   GRIT_REQUIRE(qkv_stride >= ((int64_t)nq + 2 * (int64_t)nkv) * d, GRIT_E_BADARG, "grit_attn_decode_rope: qkv_stride too small");
-  return attn_decode_launch("grit_attn_decode_rope", qkv, cache_k, cache_v, lens, out, workspace, cos_tab, sin_tab, B, nq, nkv, d, Lmax, qkv_stride,
-                            out_stride, scale, stream);
+  return attn_decode_launch<false>("grit_attn_decode_rope", qkv, cache_k, cache_v, lens, out, workspace, cos_tab, sin_tab, B, nq, nkv, d, Lmax, qkv_stride,
+                                   out_stride, scale, stream);
+}
+
+// fp16-operand form: qkv is the fp32 fused projection row of the new token, the caches and out (ctx) are fp16
+extern "C" int grit_attn_decode_rope_f16(const void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens,
+                                         void* out, float* workspace, int B, int nq, int nkv, int d, int Lmax, int64_t qkv_stride,
+                                         int64_t out_stride, float scale, void* stream) {
+  GRIT_REQUIRE(cos_tab && sin_tab, GRIT_E_BADARG, "grit_attn_decode_rope_f16: null pointer");
+  GRIT_REQUIRE(nq > 0 && nkv > 0 && nq <= 65535 && nkv <= 65535 && d > 0 && d <= 65535, GRIT_E_BADARG, "grit_attn_decode_rope_f16: bad sizes");
+  GRIT_REQUIRE(qkv_stride >= ((int64_t)nq + 2 * (int64_t)nkv) * d, GRIT_E_BADARG, "grit_attn_decode_rope_f16: qkv_stride too small");
+  return attn_decode_launch<true>("grit_attn_decode_rope_f16", qkv, cache_k, cache_v, lens, out, workspace, cos_tab, sin_tab, B, nq, nkv, d, Lmax,
+                                  qkv_stride, out_stride, scale, stream);
+}
+
+template <bool L32>
+static int argmax_launch(const char* name, const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history, int64_t hist_stride,
+                         int32_t* step, int B, void* stream) {
+  if (B == 0) return GRIT_OK;
+  GRIT_REQUIRE(logits && next, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(V > 0 && ld >= V && ld % 8 == 0 && B > 0 && (!history || step), GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(aligned16(logits), GRIT_E_BADARG, "%s: logits must be 16-byte aligned", name);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(argmax_advance_k<L32>, dim3((unsigned)B), dim3(256), 0, st, (const uint16_t*)logits, ld, V, next, lens, history, hist_stride, step);
+  GRIT_CHECK_LAUNCH(name);
+  if (step) {
+    hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, st, step);
+    GRIT_CHECK_LAUNCH(name);
+  }
+  return GRIT_OK;
 }
 
 extern "C" int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history, int64_t hist_stride,
                                    int32_t* step, int B, void* stream) {
-  if (B == 0) return GRIT_OK;
-  GRIT_REQUIRE(logits && next, GRIT_E_BADARG, "grit_argmax_advance: null pointer");
-  GRIT_REQUIRE(V > 0 && ld >= V && ld % 8 == 0 && B > 0 && (!history || step), GRIT_E_BADARG, "grit_argmax_advance: bad sizes");
-  GRIT_REQUIRE(aligned16(logits), GRIT_E_BADARG, "grit_argmax_advance: logits must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(argmax_advance_k, dim3((unsigned)B), dim3(256), 0, st, (const uint16_t*)logits, ld, V, next, lens, history, hist_stride, step);
-  GRIT_CHECK_LAUNCH("grit_argmax_advance");
-  if (step) {
-    hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, st, step);
-    GRIT_CHECK_LAUNCH("grit_argmax_advance: step");
-  }
-  return GRIT_OK;
+  return argmax_launch<false>("grit_argmax_advance", logits, ld, V, next, lens, history, hist_stride, step, B, stream);
+}
+
+// fp32 logits (the fp16-operand decode step)
+extern "C" int grit_argmax_advance_f32(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history, int64_t hist_stride,
+                                       int32_t* step, int B, void* stream) {
+  return argmax_launch<true>("grit_argmax_advance_f32", logits, ld, V, next, lens, history, hist_stride, step, B, stream);
 }

@@ -5,6 +5,11 @@ Replaces, for the RAG doc-caching flow of the reference (rag/eval.py:237-302: ``
 decode step is an HBM-bound GEMV (``grit_gemv_bf16``), attention reads the sequence's KV once (``grit_attn_decode``), the new token's
 K/V are appended in place, sampling is a device-side argmax -- and the whole step (5 launches per layer) is captured in ONE HIP
 graph, so the host only replays it.  Greedy decoding only (``do_sample=False``), batch <= 8, head_dim 128.
+
+Precision (round 6): the decoder follows its engine's policy.  Under ``"bf16"`` / ``"fp32_residual"`` the step is the reference's bf16
+arithmetic (teacher-forced logits within ~1e-3 (1 - cos) of the fp32 module: the bf16 level).  Under ``"f16_operands"`` / ``"f16_stream"`` it
+runs on the engine's fp16 weight copies around an fp32 residual stream (``grit_gemv_f16`` ...; formats in include/gritlm_hip.h): the
+continuation of ``encode(get_cache=True)`` at the north-star's own level (fp16 K/V: same bytes per token as bf16).
 """
 from __future__ import annotations
 
@@ -12,9 +17,10 @@ import torch
 
 from . import ops
 from ._lib import EPI_RESIDUAL, EPI_SWIGLU
-from .encoder import MistralEncoderEngine, rope_tables
+from ._lib import GritHipError
+from .encoder import F16_POLICIES, MistralEncoderEngine, rope_tables
 
-BF16, I32, I64 = torch.bfloat16, torch.int32, torch.int64
+BF16, F16, F32, I32, I64 = torch.bfloat16, torch.float16, torch.float32, torch.int32, torch.int64
 
 
 def _layers_of(cache):
@@ -46,9 +52,47 @@ class MistralDecoder:
         # tokens of the reference fixtures, teacher-forced logits vs fp32) -- GRIT_DECODE_FUSE_NORM=qkv restores the exact bits; both are
         # the same arithmetic at every batch size 1..8.
         self.fuse_norm = os.environ.get("GRIT_DECODE_FUSE_NORM", "deferred")
+        # None: follow the engine's policy (fp16 operands under its fp16 policies); "bf16" / "f16" pin the decode arithmetic
+        self.precision = os.environ.get("GRIT_DECODE_PRECISION") or None
+        self._lm_head16 = None
+        self.last_precision = None                # what the last generate() call ran in ("bf16" | "f16"; "bf16 (f16 overflow)" after a fallback)
+
+    def _f16(self) -> bool:
+        if self.precision not in (None, "bf16", "f16"):
+            raise ValueError(f"MistralDecoder.precision={self.precision!r}: None (follow the engine), 'bf16' or 'f16'")
+        return self.precision == "f16" or (self.precision is None and self.eng.precision in F16_POLICIES)
+
+    def _lm_head_f16(self):
+        key = (self.lm_head.data_ptr(), self.lm_head._version)
+        if self._lm_head16 is None or self._lm_head16[0] != key:
+            w = self.lm_head.to(F16)
+            if bool(torch.isinf(w).any()):
+                raise GritHipError("native decode on fp16 operands: lm_head weights exceed the fp16 range")
+            self._lm_head16 = (key, w)
+        return self._lm_head16[1]
+
+    def _step_f16(self, st):
+        """One decode step on fp16 operands: fp32 stream / q|k|v row / logits; fp16 weights, K/V and GEMV operand rows (h16 = the stream's
+        rounding, written by the residual epilogues; ctx; act); every norm in the deferred form (the row scale multiplies fp32 dot products)."""
+        c, e = self.cfg, self.eng
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        h, h16, qkv, ctx, act = st["h"], st["h16"], st["qkv"], st["ctx"], st["act"]
+        ops.embed_gather(e.embed, st["next"], out=h)
+        h16.copy_(h)                                   # (bf16 embedding rows: exact in fp16 inside its range)
+        for li, L in enumerate(e.layers):
+            wqkv, wo, wgu, wdown = e._f16_weights(L)
+            ck, cv = st["cache"][li]
+            ops.rmsnorm_gemv(h16, L.ln1, eps, wqkv, out=qkv, deferred=True)
+            ops.attn_decode_rope(qkv, st["cos"], st["sin"], ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)
+            ops.gemv(ctx, wo, out=h, epilogue=EPI_RESIDUAL, residual=h, out16=h16)
+            ops.rmsnorm_gemv(h16, L.ln2, eps, wgu, out=act, epilogue=EPI_SWIGLU, deferred=True)
+            ops.gemv(act, wdown, out=h, epilogue=EPI_RESIDUAL, residual=h, out16=h16)
+        ops.rmsnorm_gemv(h16, e.norm, eps, self._lm_head_f16(), out=st["logits"], deferred=True)
 
     # ------------------------------------------------------------------ one decode step (all sizes static, lengths on the device)
     def _step(self, st):
+        if st["f16"]:
+            return self._step_f16(st)
         c, e = self.cfg, self.eng
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         h, qkv, ctx, act = st["h"], st["qkv"], st["ctx"], st["act"]
@@ -100,27 +144,41 @@ class MistralDecoder:
     def _sample(self, st):
         ops.argmax_advance(st["logits"], st["next"], st["lens"], st["history"], st["step"])
 
-    def _state(self, B: int, Lmax: int):
+    def _state(self, B: int, Lmax: int, f16: bool = False):
         c, dev = self.cfg, self.device
         nq, nkv, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
-        mk = lambda n: torch.empty((B, n), dtype=BF16, device=dev)
-        cos, sin = rope_tables(Lmax, d, c.rope_theta, self.eng.rope_bf16, dev)
-        return dict(h=mk(c.hidden_size), x=mk(c.hidden_size), qkv=mk((nq + 2 * nkv) * d), ctx=mk(nq * d), act=mk(c.intermediate_size),
-                    logits=mk(self.lm_head.shape[0]), next=torch.zeros((B,), dtype=I64, device=dev), lens=torch.zeros((B,), dtype=I32, device=dev),
-                    step=torch.zeros((1,), dtype=I32, device=dev), cos=cos, sin=sin, ws=ops.attn_decode_workspace(B, nq, nkv, Lmax, dev),
-                    cache=[(torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev), torch.zeros((B, nkv, Lmax, d), dtype=BF16, device=dev))
+        op = F16 if f16 else BF16                      # operand rows and the K/V cache
+        wide = F32 if f16 else BF16                    # the stream, the q|k|v row, the logits
+        mk = lambda n, dt: torch.empty((B, n), dtype=dt, device=dev)
+        # (the fp16 policies rotate with the unrounded fp32 tables, like the encoder's fp16 forward)
+        cos, sin = rope_tables(Lmax, d, c.rope_theta, self.eng.rope_bf16 and not f16, dev)
+        return dict(f16=f16, h=mk(c.hidden_size, wide), h16=mk(c.hidden_size, F16) if f16 else None, x=mk(c.hidden_size, BF16), qkv=mk((nq + 2 * nkv) * d, wide), ctx=mk(nq * d, op),
+                    act=mk(c.intermediate_size, op), logits=mk(self.lm_head.shape[0], wide), next=torch.zeros((B,), dtype=I64, device=dev),
+                    lens=torch.zeros((B,), dtype=I32, device=dev), step=torch.zeros((1,), dtype=I32, device=dev), cos=cos, sin=sin,
+                    ws=ops.attn_decode_workspace(B, nq, nkv, Lmax, dev),
+                    cache=[(torch.zeros((B, nkv, Lmax, d), dtype=op, device=dev), torch.zeros((B, nkv, Lmax, d), dtype=op, device=dev))
                            for _ in range(c.num_hidden_layers)])
 
     # ------------------------------------------------------------------ API
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, max_new_tokens: int, attention_mask: torch.Tensor | None = None, past_key_values=None,
-                 past_lens: torch.Tensor | None = None, eos_token_id: int | None = None, return_logits: bool = False):
+                 past_lens: torch.Tensor | None = None, eos_token_id: int | None = None, return_logits: bool = False,
+                 on_overflow: str = "raise", _force_bf16: bool = False):
         """Greedy continuation.  ``input_ids`` [B,P]: the NEW prompt tokens (right-padded rows need ``attention_mask``; with
         ``past_key_values`` all rows must be full length).  ``past_key_values``: per-layer K/V [B,nkv,S,d] of an already encoded
         prefix, e.g. the bidirectional document pass of ``encode(get_cache=True)``; ``past_lens`` [B] = valid prefix tokens per row
         (default S).  Returns the generated ids [B, max_new_tokens] (int64; positions after ``eos_token_id`` keep that id) and, with
-        ``return_logits``, the bf16 logits of every generated position [B, max_new_tokens, V]."""
+        ``return_logits``, the logits of every generated position [B, max_new_tokens, V] (bf16; fp32 on fp16 operands).
+
+        On fp16 operands (module docstring) a value beyond the fp16 range invalidates the call: ``on_overflow="raise"`` raises
+        ``GritHipError``, ``"bf16"`` repeats the whole call in the bf16 arithmetic (what ``GritLM(precision="auto")`` stands for)."""
         dev, c = self.device, self.cfg
+        f16 = self._f16() and not _force_bf16
+        if on_overflow not in ("raise", "bf16"):
+            raise ValueError(f"on_overflow={on_overflow!r}: 'raise' or 'bf16'")
+        if f16:
+            ops.f16_overflow_flag(dev, clear=True)        # a stale flag of an earlier call is not this call's
+            self.eng._f16_weights(self.eng.layers[0])     # (refuses weights beyond the fp16 range before anything runs)
         ids = input_ids.to(device=dev, dtype=I64)
         B, P = ids.shape
         if B > 8:
@@ -134,14 +192,16 @@ class MistralDecoder:
             raise NotImplementedError(f"native decode past the sliding window ({self.eng.window_keys} keys) is built for the sdpa semantics "
                                       "only (window_keys = 0: full causal attention over the cache)")
         Lmax = (S0 + P + max_new_tokens + 255) // 256 * 256
-        st = self._state(B, Lmax)
+        st = self._state(B, Lmax, f16)
         st["history"] = torch.zeros((B, max_new_tokens), dtype=I64, device=dev)
-        logits_all = torch.empty((B, max_new_tokens, self.lm_head.shape[0]), dtype=BF16, device=dev) if return_logits else None
+        logits_all = torch.empty((B, max_new_tokens, self.lm_head.shape[0]), dtype=st["logits"].dtype, device=dev) if return_logits else None
         if past is None:
             # prefill: one causal pass over the prompt that also emits the post-RoPE K/V (the encoder engine's forward)
             mask = torch.ones((B, P), dtype=I64, device=dev) if attention_mask is None else attention_mask.to(device=dev, dtype=I64)
             # (the fp16 policies are built for the bidirectional embedding pass: the causal prompt pass of a unified model runs in the
-            # reference's bf16 arithmetic -- what the decode kernels continue in -- and the engine's policy is restored afterwards)
+            # reference's bf16 arithmetic and the engine's policy is restored afterwards; an fp16 decode continues from its K/V widened
+            # to fp16, exactly -- the prompt's own arithmetic stays at the bf16 level.  A prompt that must be held to the fp16 level
+            # rides on the decode path: pass it with ``past_key_values`` of an empty or document prefix)
             was, pol = self.eng.causal, self.eng.precision
             if pol in ("f16_operands", "f16_stream"):
                 self.eng.precision = "bf16"
@@ -152,15 +212,22 @@ class MistralDecoder:
                 self.eng.causal, self.eng.precision = was, pol
             for li, (k, v) in enumerate(kv):
                 st["cache"][li][0][:, :, :P].copy_(k); st["cache"][li][1][:, :, :P].copy_(v)
+            if f16:
+                self._flag_nonfinite_cache(st, P)
             plen = mask.sum(dim=1).to(I32)
             st["lens"].copy_(plen)
             last = hidden[torch.arange(B, device=dev), (plen - 1).long()].contiguous()              # [B,H] final-norm output of the last prompt token
-            ops.gemv(last, self.lm_head, out=st["logits"])
+            if f16:
+                ops.gemv(last.to(F16), self._lm_head_f16(), out=st["logits"])
+            else:
+                ops.gemv(last, self.lm_head, out=st["logits"])
         else:
             if attention_mask is not None and not bool((attention_mask != 0).all()):
                 raise NotImplementedError("native decode: padded prompt rows on top of past_key_values")
             for li, (k, v) in enumerate(past):
                 st["cache"][li][0][:, :, :S0].copy_(k.to(dev)); st["cache"][li][1][:, :, :S0].copy_(v.to(dev))
+            if f16 and any(k.dtype != F16 or v.dtype != F16 for k, v in past):
+                self._flag_nonfinite_cache(st, S0)        # (a bf16 / fp32 cache narrowed to fp16: values beyond 65504 became inf)
             st["lens"].copy_(torch.full((B,), S0, dtype=I32, device=dev) if past_lens is None else past_lens.to(device=dev, dtype=I32))
             # the prompt rides on the decode path, one token per step (teacher forced): its K/V land behind the cached prefix
             for t in range(P):
@@ -185,10 +252,27 @@ class MistralDecoder:
                         self._step(st)
                         self._sample(st)
         out = st["history"]
+        self.last_precision = "f16" if f16 else ("bf16 (f16 overflow)" if _force_bf16 else "bf16")
+        if f16 and (ops.f16_overflow_flag(dev, clear=True) or bool(st.get("cache_bad", False))):
+            if on_overflow == "bf16":
+                return self.generate(input_ids, max_new_tokens, attention_mask=attention_mask, past_key_values=past_key_values, past_lens=past_lens,
+                                     eos_token_id=eos_token_id, return_logits=return_logits, _force_bf16=True)
+            raise GritHipError("native decode on fp16 operands: a value exceeded the fp16 range (activation, K/V or a cached K/V that was "
+                               "already inf); the tokens of this call are invalid -- decode with precision 'bf16' (MistralDecoder.precision, "
+                               "or on_overflow='bf16')")
         if eos_token_id is not None:
             hit = (out == eos_token_id).long().cumsum(dim=1) > 0
             out = torch.where(hit, torch.full_like(out, eos_token_id), out)
         return (out, logits_all) if return_logits else out
+
+    def _flag_nonfinite_cache(self, st, n: int):
+        """K/V narrowed to fp16 on their way into the cache: a value beyond the range would surface as nan logits without touching the
+        device's overflow flag (the fp32 outputs are not range-checked) -- raise it here."""
+        bad = torch.zeros((), dtype=torch.bool, device=self.device)
+        for ck, cv in st["cache"]:
+            bad |= ~torch.isfinite(ck[:, :, :n]).all()
+            bad |= ~torch.isfinite(cv[:, :, :n]).all()
+        st["cache_bad"] = bad
 
     def _sample_step(self, st, logits_all, t):
         if logits_all is not None:

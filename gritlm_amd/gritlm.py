@@ -105,6 +105,9 @@ class GritLM(torch.nn.Module):
         self.num_gpus = 1
         self.engines = []            # in-process multi-GPU encode: one engine replica per GPU (set by _parallelize)
         self._precision = precision
+        # encode(get_cache=True): False = bf16 K/V (the reference's cache format, for a Hugging Face generate()); True = the K/V of the
+        # engine's policy as its attention read them -- fp16 under the fp16 policies -- for native_decoder().generate(past_key_values=...)
+        self.native_kv_cache = False
         self.embed_eos = embed_eos
         self.attn = attn
         if (attn is not None) and attn not in _VALID_ATTN:
@@ -304,7 +307,10 @@ class GritLM(torch.nn.Module):
             # native pass that also emits the per-layer post-RoPE K / V (doc caching for RAG), packaged as the cache type the
             # installed transformers hands back for use_cache=True
             from transformers import DynamicCache
-            hidden, kv = self.engine.forward(inputs["input_ids"], inputs["attention_mask"], borrow=True, return_kv=True)
+            # (bf16 K/V -- the reference's cache format, what a Hugging Face generate() continues from -- unless ``native_kv_cache``: then
+            # the K/V of the engine's policy as the attention read them, fp16 under the fp16 policies, for the native decoder)
+            hidden, kv = self.engine.forward(inputs["input_ids"], inputs["attention_mask"], borrow=True, return_kv=True,
+                                             kv_dtype=None if getattr(self, "native_kv_cache", False) else torch.bfloat16)
             cache = DynamicCache()
             for li, (k, v) in enumerate(kv):
                 cache.update(k, v, li)

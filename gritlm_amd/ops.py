@@ -610,11 +610,22 @@ def attn_bidir_varlen_bwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: 
 
 
 def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE,
-         residual: torch.Tensor | None = None) -> torch.Tensor:
-    """out[B,N] = x[B,K] @ w[N,K]^T for B <= 8 rows (decode); same epilogues as gemm_nt."""
+         residual: torch.Tensor | None = None, out16: torch.Tensor | None = None) -> torch.Tensor:
+    """out[B,N] = x[B,K] @ w[N,K]^T for B <= 8 rows (decode); same epilogues as gemm_nt.  fp16 ``w`` (and ``x``): the fp16-operand form --
+    STORE / RESIDUAL write fp32 (``residual`` is the fp32 stream; ``out16``: additionally its fp16 rounding, the next GEMV's operand),
+    SWIGLU writes the fp16 activation."""
     B, K = x.shape
     N = w.shape[0]
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if w.dtype == F16:
+        odt = F16 if epilogue == EPI_SWIGLU else F32
+        if out is None:
+            out = torch.empty((B, n_out), dtype=odt, device=x.device)
+        check(_lib.load().grit_gemv_f16(_chk2d(x, F16, "x"), _chk2d(w, F16, "w"), _chk2d(out, odt, "out"), B, N, K, x.stride(0), w.stride(0),
+                                        out.stride(0), epilogue, 0 if residual is None else _chk2d(residual, F32, "residual"),
+                                        0 if residual is None else residual.stride(0), 0 if out16 is None else _chk2d(out16, F16, "out16"),
+                                        0 if out16 is None else out16.stride(0), _stream()), "grit_gemv_f16")
+        return out
     if out is None:
         out = torch.empty((B, n_out), dtype=BF16, device=x.device)
     check(_lib.load().grit_gemv_bf16(_chk2d(x, BF16, "x"), _chk2d(w, BF16, "w"), _chk2d(out, BF16, "out"), B, N, K, x.stride(0), w.stride(0),
@@ -626,10 +637,21 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epil
 def rmsnorm_gemv(x: torch.Tensor, ln_w: torch.Tensor, eps: float, w: torch.Tensor, out: torch.Tensor | None = None,
                  epilogue: int = EPI_STORE, deferred: bool = False) -> torch.Tensor:
     """gemv(rmsnorm(x, ln_w, eps), w) in one launch (decode step).  ``deferred``: the row scale multiplies the finished dot products
-    (no pass over x in front of the weight stream; x_n is not rounded to bf16: not the bits of the two launches)."""
+    (no pass over x in front of the weight stream; x_n is not rounded to bf16: not the bits of the two launches).  fp16 ``w``: x is the
+    fp16 copy of the residual stream, the deferred form only; STORE writes fp32, SWIGLU the fp16 activation."""
     B, K = x.shape
     N = w.shape[0]
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if w.dtype == F16:
+        if not deferred:
+            raise ValueError("rmsnorm_gemv on fp16 weights: the deferred form only")
+        odt = F16 if epilogue == EPI_SWIGLU else F32
+        if out is None:
+            out = torch.empty((B, n_out), dtype=odt, device=x.device)
+        check(_lib.load().grit_rmsnorm_gemv_f16_deferred(_chk2d(x, F16, "x"), _chk(ln_w, BF16, "ln_w"), float(eps), _chk2d(w, F16, "w"),
+                                                         _chk2d(out, odt, "out"), B, N, K, x.stride(0), w.stride(0), out.stride(0), epilogue,
+                                                         _stream()), "grit_rmsnorm_gemv_f16_deferred")
+        return out
     if out is None:
         out = torch.empty((B, n_out), dtype=BF16, device=x.device)
     fn = _lib.load().grit_rmsnorm_gemv_bf16_deferred if deferred else _lib.load().grit_rmsnorm_gemv_bf16
@@ -671,6 +693,12 @@ def attn_decode_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, ca
     """rope_kv_append + attn_decode in one launch (qkv: the raw fused projection of the new token; the caches are appended to)."""
     B, _, Lmax, _ = cache_k.shape
     assert cos.shape[0] >= Lmax
+    if cache_k.dtype == F16:    # fp16-operand form: fp32 q|k|v row, fp16 caches and ctx
+        check(_lib.load().grit_attn_decode_rope_f16(_chk2d(qkv, F32, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"), _chk(cache_k, F16, "cache_k"),
+                                                    _chk(cache_v, F16, "cache_v"), _chk(lens, I32, "lens"), _chk2d(out, F16, "out"),
+                                                    _chk(workspace, F32, "workspace"), B, nq, nkv, d, Lmax, qkv.stride(0), out.stride(0),
+                                                    float(d ** -0.5 if scale is None else scale), _stream()), "grit_attn_decode_rope_f16")
+        return out
     check(_lib.load().grit_attn_decode_rope(_chk2d(qkv, BF16, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"), _chk(cache_k, BF16, "cache_k"),
                                             _chk(cache_v, BF16, "cache_v"), _chk(lens, I32, "lens"), _chk2d(out, BF16, "out"),
                                             _chk(workspace, F32, "workspace"), B, nq, nkv, d, Lmax, qkv.stride(0), out.stride(0),
@@ -681,6 +709,12 @@ def attn_decode_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, ca
 def argmax_advance(logits: torch.Tensor, next_ids: torch.Tensor, lens: torch.Tensor | None = None, history: torch.Tensor | None = None,
                    step: torch.Tensor | None = None):
     B, V = logits.shape
+    if logits.dtype == F32:
+        check(_lib.load().grit_argmax_advance_f32(_chk2d(logits, F32, "logits"), logits.stride(0), V, _chk(next_ids, I64, "next"),
+                                                  0 if lens is None else _chk(lens, I32, "lens"), 0 if history is None else _chk(history, I64, "history"),
+                                                  0 if history is None else history.stride(0), 0 if step is None else _chk(step, I32, "step"), B,
+                                                  _stream()), "grit_argmax_advance_f32")
+        return next_ids
     check(_lib.load().grit_argmax_advance(_chk2d(logits, BF16, "logits"), logits.stride(0), V, _chk(next_ids, I64, "next"),
                                           0 if lens is None else _chk(lens, I32, "lens"), 0 if history is None else _chk(history, I64, "history"),
                                           0 if history is None else history.stride(0), 0 if step is None else _chk(step, I32, "step"), B,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GRIT_ABI_VERSION 4
+#define GRIT_ABI_VERSION 5
 
 enum {
   GRIT_OK = 0,
@@ -429,6 +429,29 @@ int grit_attn_decode_rope(const void* qkv, const float* cos_tab, const float* si
  * *step += 1 and lens[b] += 1 -- all on the device, so a whole decode step is one HIP graph. */
 int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history,
                         int64_t hist_stride, int32_t* step, int B, void* stream);
+
+/* The decode step on fp16 operands (ABI 5): the continuation of encode(get_cache=True) under the encoder's "f16_operands" / "f16_stream"
+ * policies (gritlm.py:131-140 hands the document K/V to model.generate, rag/eval.py:237-302).  Formats: the residual stream, the fused
+ * q|k|v row of the new token and the logits are fp32 (residual adds, q's rotation and the argmax see unrounded values); the weights, the
+ * K/V cache and every GEMV operand row (the stream's copy in front of a norm, ctx, act) are IEEE fp16, rounded once from fp32.  Values
+ * beyond the fp16 range raise grit_f16_overflow_flag().
+ *   grit_gemv_f16: x fp16 [B,K], W fp16 [N,K]; STORE: out fp32 [B,N]; RESIDUAL: out fp32 = residual fp32 + x W^T and, if out16 is given,
+ *                  out16 = fp16(out) (the operand copy the next norm + GEMV reads); SWIGLU: out fp16 [B,N/2] = fp16(silu(g) * u), one
+ *                  rounding.  ld* in elements of the respective format.
+ *   grit_rmsnorm_gemv_f16_deferred: x = the fp16 copy of the stream, ln_weight bf16 (as stored), W fp16; out = rsqrt(mean x^2 + eps) *
+ *                  (W (x * ln_weight)) accumulated in fp32; STORE -> fp32, SWIGLU -> fp16.
+ *   grit_attn_decode_rope_f16: qkv fp32 [B, qkv_stride]; q is rotated and scaled without a rounding; k (rotated) and v are rounded to fp16
+ *                  once, into caches [B, nkv, Lmax, d] fp16; out (ctx) fp16.  Workspace as grit_attn_decode.
+ *   grit_argmax_advance_f32: grit_argmax_advance on fp32 logits. */
+int grit_gemv_f16(const void* x, const void* W, void* out, int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo,
+                  int epilogue, const void* residual, int64_t ldr, void* out16, int64_t ldo16, void* stream);
+int grit_rmsnorm_gemv_f16_deferred(const void* x, const void* ln_weight, float eps, const void* W, void* out, int B, int N, int K,
+                                   int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
+int grit_attn_decode_rope_f16(const void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v,
+                              const int32_t* lens, void* out, float* workspace, int B, int nq, int nkv, int d, int Lmax,
+                              int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+int grit_argmax_advance_f32(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history,
+                            int64_t hist_stride, int32_t* step, int B, void* stream);
 
 /* ---- RAG index search: rag/index.py:97-104 (scores = queries @ embeddings; torch.topk) ------------------------ */
 

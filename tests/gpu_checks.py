@@ -2631,6 +2631,192 @@ def check_native_generate(cfg_name="tiny", P=21, new=10, rows=2, tol=0.06, fuse_
     return _res(f"native greedy generation [{cfg_name}] vs oracle (prompt prefill, document-KV prefix, graph replay)", bool(ok), **out)
 
 
+def check_gemv_f16(N=1030, K=512, seed=185):
+    """The fp16-operand GEMV forms (grit_gemv_f16, grit_rmsnorm_gemv_f16_deferred) against fp64 on the SAME fp16 operands, for 1 / 2 / 3 / 8
+    rows: STORE and RESIDUAL write fp32 (only the fp32 accumulation separates them from fp64), RESIDUAL's out16 is the fp16 rounding of
+    exactly that fp32 value, SWIGLU writes fp16(silu(g) u) -- one rounding; an activation beyond 65504 raises the device's overflow flag."""
+    ok, det = True, {}
+    h16 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(torch.float16)
+    w = h16(rnd((N, K), seed + 1, 0.05))
+    Ns = N // 32 * 32
+    wi = swiglu_interleave(w[:Ns // 2], w[Ns // 2:Ns])
+    lnw = bf(1.0 + 0.1 * rnd((K,), seed + 2))
+    ops.f16_overflow_flag(DEV, clear=True)
+    for B in (1, 2, 3, 8):
+        x16 = h16(rnd((B, K), seed + 10 + B))
+        x32 = h16(3.0 * np.random.default_rng(seed + 20 + B).standard_normal((B, K)).astype(np.float32))       # (the stream's fp16 copy)
+        r32 = torch.from_numpy(np.random.default_rng(seed + 30 + B).standard_normal((B, N)).astype(np.float32)).to(DEV)
+        ref = x16.double() @ w.double().T
+        sc = float(ref.pow(2).mean().sqrt())
+        got = ops.gemv(x16, w)
+        e_store = float(((got.double() - ref).abs() / (4e-6 * ref.abs() + 4e-6 * sc)).max())
+        got = ops.gemv(x16, w, epilogue=EPI_RESIDUAL, residual=r32)
+        e_res = float(((got.double() - (ref + r32.double())).abs() / (4e-6 * (ref.abs() + r32.abs().double()) + 4e-6 * sc)).max())
+        rr = r32.clone(); r16 = torch.empty((B, N), dtype=torch.float16, device=DEV)
+        ops.gemv(x16, w, out=rr, epilogue=EPI_RESIDUAL, residual=rr, out16=r16)                      # in place + the fp16 copy, as the decode step runs it
+        same = bool(torch.equal(rr, got)) and bool(torch.equal(r16, got.to(torch.float16)))
+        g, u = ref[:, :Ns // 2], ref[:, Ns // 2:Ns]
+        ref_sw = torch.nn.functional.silu(g) * u
+        got_sw = ops.gemv(x16, wi, epilogue=EPI_SWIGLU)
+        e_sw = float(((got_sw.double() - ref_sw).abs() / (2.0 ** -11 * 1.02 * ref_sw.abs() + 1e-5 * float(ref_sw.pow(2).mean().sqrt()) + 6e-8)).max())
+        # deferred norm on the fp32 stream
+        xd = x32.double()
+        inv = torch.rsqrt((xd * xd).mean(dim=1, keepdim=True) + 1e-5)
+        refn = ((xd * lnw.double()) @ w.double().T) * inv
+        scn = float(refn.pow(2).mean().sqrt())
+        gotn = ops.rmsnorm_gemv(x32, lnw, 1e-5, w, deferred=True)
+        e_n = float(((gotn.double() - refn).abs() / (8e-6 * refn.abs() + 8e-6 * scn)).max())
+        refn_sw = torch.nn.functional.silu(refn[:, :Ns // 2]) * refn[:, Ns // 2:Ns]
+        gotn_sw = ops.rmsnorm_gemv(x32, lnw, 1e-5, wi, epilogue=EPI_SWIGLU, deferred=True)
+        e_nsw = float(((gotn_sw.double() - refn_sw).abs() / (2.0 ** -11 * 1.02 * refn_sw.abs() + 1e-5 * float(refn_sw.pow(2).mean().sqrt()) + 6e-8)).max())
+        det[f"B{B}"] = dict(store=e_store, residual=e_res, swiglu=e_sw, norm_store=e_n, norm_swiglu=e_nsw)
+        ok &= max(e_store, e_res, e_sw, e_n, e_nsw) < 1.0 and same and got.dtype == torch.float32 and got_sw.dtype == torch.float16
+    clean = not ops.f16_overflow_flag(DEV, clear=True)
+    big = ops.gemv(h16(np.full((1, K), 60.0, dtype=np.float32)), swiglu_interleave(h16(np.full((16, K), 8.0)), h16(np.full((16, K), 8.0))), epilogue=EPI_SWIGLU)
+    raised = ops.f16_overflow_flag(DEV, clear=True) and bool(torch.isinf(big).any())
+    ok &= clean and raised
+    return _res(f"gemv on fp16 operands [N={N},K={K}] vs fp64 (err over tol; fp32 out 4e-6, fp16 out one rounding)", ok, flag_clean=clean,
+                flag_raised=raised, **{k: max(v.values()) for k, v in det.items()})
+
+
+def check_attn_decode_f16(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
+    """grit_attn_decode_rope_f16: fp32 q|k|v row, fp16 caches.  The appended rows are fp16(rope(k)) and fp16(v) -- ONE rounding from the
+    fp32 row --, the context equals fp64 attention of the UNROUNDED rotated q over the cache as it then stands, up to the fp16 output
+    rounding; slots behind the new token are NaN before the call and nothing of them leaks."""
+    from gritlm_amd.encoder import rope_tables
+    d = 128
+    G = nq // nkv
+    cos, sin = rope_tables(Lmax, d, 10000.0, False, DEV)
+    rng = np.random.default_rng(287)
+    ck = torch.from_numpy(rng.standard_normal((B, nkv, Lmax, d)).astype(np.float32) * 0.7).to(DEV).to(torch.float16)
+    cv = torch.from_numpy(rng.standard_normal((B, nkv, Lmax, d)).astype(np.float32)).to(DEV).to(torch.float16)
+    qkv = torch.from_numpy(rng.standard_normal((B, (nq + 2 * nkv) * d)).astype(np.float32) * 0.7).to(DEV)
+    tl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    for b in range(B):
+        ck[b, :, lens[b]:] = float("nan"); cv[b, :, lens[b]:] = float("nan")
+    out = torch.empty((B, nq * d), dtype=torch.float16, device=DEV)
+    ops.f16_overflow_flag(DEV, clear=True)
+    ops.attn_decode_rope(qkv, cos, sin, ck, cv, tl, out, ops.attn_decode_workspace(B, nq, nkv, Lmax, DEV), nq, nkv, d)
+    got = out.double().cpu().numpy().reshape(B, nq, d)
+    c64, s64 = cos.double().cpu().numpy(), sin.double().cpu().numpy()
+    row = qkv.double().cpu().numpy()
+
+    def rot(x, pos):            # x*cos + rotate_half(x)*sin
+        x1, x2 = x[..., :d // 2], x[..., d // 2:]
+        return np.concatenate([x1 * c64[pos] - x2 * s64[pos], x2 * c64[pos] + x1 * s64[pos]], axis=-1)
+
+    worst, worst_k, worst_v, ok = 0.0, 0.0, 0.0, True
+    K, V = ck.double().cpu().numpy(), cv.double().cpu().numpy()
+    for b in range(B):
+        pos = lens[b]
+        kn = rot(row[b, nq * d:(nq + nkv) * d].reshape(nkv, d), pos)
+        vn = row[b, (nq + nkv) * d:].reshape(nkv, d)
+        worst_k = max(worst_k, float(np.max(np.abs(K[b, :, pos] - kn.astype(np.float16).astype(np.float64)))))      # RNE of the fp64 rotation: at most
+        worst_v = max(worst_v, float(np.max(np.abs(V[b, :, pos] - vn.astype(np.float16).astype(np.float64)))))      # one fp16 ulp from fp16(fp32 rotation)
+        ok &= bool(np.isfinite(K[b, :, :pos + 1]).all()) and bool(np.isnan(K[b, :, pos + 1:]).all())
+        for h in range(nq):
+            qh = rot(row[b, h * d:(h + 1) * d], pos)
+            sc = K[b, h // G, :pos + 1] @ qh / np.sqrt(d)
+            p = np.exp(sc - sc.max()); p /= p.sum()
+            worst = max(worst, float(np.max(np.abs(got[b, h] - p @ V[b, h // G, :pos + 1]))))
+    ok &= worst < 1.5e-3 and worst_k < 4e-3 and worst_v == 0.0 and not np.isnan(got).any() and not ops.f16_overflow_flag(DEV, clear=True)
+    # a new key beyond the fp16 range raises the flag
+    q2 = qkv.clone(); q2[0, nq * d] = 1e6
+    ops.attn_decode_rope(q2, cos, sin, ck, cv, tl, out, ops.attn_decode_workspace(B, nq, nkv, Lmax, DEV), nq, nkv, d)
+    raised = ops.f16_overflow_flag(DEV, clear=True)
+    return _res(f"attn_decode_rope on fp16 K/V [B={B},nq={nq},nkv={nkv},lens={list(lens)}] vs fp64", bool(ok and raised), ctx_max_abs=worst,
+                new_k_max_abs=worst_k, new_v_max_abs=worst_v, flag_raised=raised)
+
+
+def check_argmax_f32(B=3, V=32003):
+    lg = torch.from_numpy(np.random.default_rng(311).standard_normal((B, (V + 7) // 8 * 8)).astype(np.float32)).to(DEV)[:, :V]
+    lg[0, 17] = lg[0, 4000] = 9.0                 # a tie: the lower index wins
+    lg[1, V - 1] = 11.0                           # the tail beyond the last full chunk of 8
+    nxt = torch.zeros((B,), dtype=torch.int64, device=DEV); lens = torch.tensor([5, 6, 7][:B], dtype=torch.int32, device=DEV)
+    hist = torch.zeros((B, 4), dtype=torch.int64, device=DEV); step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    ops.argmax_advance(lg, nxt, lens, hist, step)
+    ref = lg.argmax(dim=1); ref[0] = 17
+    ok = bool(torch.equal(nxt, ref)) and lens.tolist() == [6, 7, 8][:B] and bool(torch.equal(hist[:, 2], ref)) and int(step) == 3
+    return _res("argmax_advance on fp32 logits (ties, tail, history, lens)", ok)
+
+
+def check_native_generate_f16(cfg_name="tiny", P=21, new=10, rows=2, policy="f16_operands", cos_bound=1e-5):
+    """The decoder on fp16 operands (engine policy ``f16_operands`` / ``f16_stream``): teacher-forced logits of every generated position against
+    the fp32 oracle at the NORTH-STAR's level -- 1 - cos(logits row) < ``cos_bound`` (<= 1e-4 / 10), at least 10x below the bf16 decoder on
+    the same weights and tokens -- (a) from a prompt (bf16 causal prefill, K/V widened), (b) on top of the fp16 document K/V of
+    encode(get_cache=True) under the policy (kv_dtype=None), the RAG flow; greedy tokens agree wherever the oracle's margin is clear;
+    graph replay == eager; rows 1..3; overflow: on_overflow='bf16' falls back, 'raise' raises."""
+    from gritlm_amd._lib import GritHipError
+    from gritlm_amd.decoder import MistralDecoder
+    eng, cfg, w = build_engine(cfg_name, 6)
+    rng = np.random.default_rng(97)
+    lm = O.bf16_round((rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"])) * 0.05).astype(np.float32))
+    dec = MistralDecoder(eng, torch.from_numpy(lm))
+    prompt = rng.integers(3, cfg["vocab_size"], size=(rows, P)).astype(np.int64)
+    doc = rng.integers(3, cfg["vocab_size"], size=(1, 70)).astype(np.int64)
+    ok, out = True, {}
+    omc = lambda a, b: float(np.max(1.0 - np.sum(a * b, axis=-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))))
+    res = {}
+    for pol in ("bf16", policy):
+        eng.set_precision(pol)
+        ones = torch.ones((1, 70), dtype=torch.int64, device=DEV)
+        _, kv = eng.forward(torch.from_numpy(doc).to(DEV), ones, return_kv=True, kv_dtype=None)
+        toks2, lg2 = dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, past_key_values=kv, return_logits=True)
+        ok &= dec.last_precision == ("bf16" if pol == "bf16" else "f16") and kv[0][0].dtype == (torch.bfloat16 if pol == "bf16" else torch.float16)
+        ok &= lg2.dtype == (torch.bfloat16 if pol == "bf16" else torch.float32)
+        toks2, lg2 = toks2.cpu().numpy()[0], f32(lg2)[0].astype(np.float64)
+        _, kv_ref = O.mistral_encode(w, cfg, doc, np.ones_like(doc), return_layers="kv")
+        ref2 = O.mistral_continue(w, cfg, kv_ref, 70, np.concatenate([prompt[0], toks2]), lm)[P - 1:P - 1 + new].astype(np.float64)
+        res[pol] = dict(doc=omc(lg2, ref2), doc_abs=float(np.max(np.abs(lg2 - ref2))), std=float(ref2.std()))
+        srt = np.sort(ref2, axis=-1)
+        clear = (srt[..., -1] - srt[..., -2]) > 4 * res[pol]["doc_abs"] + 1e-4
+        ok &= bool((toks2 == ref2.argmax(-1))[clear].all())
+        res[pol]["clear_frac"] = float(clear.mean())
+        if pol != "bf16":
+            dec.use_graph = False
+            ok &= np.array_equal(dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, past_key_values=kv).cpu().numpy()[0], toks2)
+            dec.use_graph = True
+            ok &= np.array_equal(dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, past_key_values=kv).cpu().numpy()[0], toks2)
+            # the same prefix handed over as the reference's bf16 cache: narrowed exactly, decode continues on fp16 operands
+            _, kvb = eng.forward(torch.from_numpy(doc).to(DEV), ones, return_kv=True)
+            _, lgb = dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, past_key_values=kvb, return_logits=True)
+            res[pol]["doc_bf16_cache"] = omc(f32(lgb)[0].astype(np.float64), ref2)
+            # several rows on top of no prefix: the prompt rides on the decode path (empty past), every row against the oracle
+            empty = [(torch.zeros((rows, cfg["num_key_value_heads"], 0, eng.cfg.head_dim), dtype=torch.float16, device=DEV),) * 2] * cfg["num_hidden_layers"]
+            toks, lg = dec.generate(torch.from_numpy(prompt).to(DEV), new, past_key_values=empty, return_logits=True)
+            toks, lg = toks.cpu().numpy(), f32(lg).astype(np.float64)
+            worst = 0.0
+            for b in range(rows):
+                seq = np.concatenate([prompt[b], toks[b]])[None]
+                hh = O.mistral_encode(w, cfg, seq, np.ones_like(seq), causal=True)
+                worst = max(worst, omc(lg[b], (hh[0] @ lm.T)[P - 1:P - 1 + new].astype(np.float64)))
+            res[pol]["prompt_on_decode_path"] = worst
+            # plain prompt: bf16 causal prefill + fp16 decode (documented: the prompt's own arithmetic stays bf16)
+            toks_p, lg_p = dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, return_logits=True)
+            seq = np.concatenate([prompt[0], toks_p.cpu().numpy()[0]])[None]
+            hh = O.mistral_encode(w, cfg, seq, np.ones_like(seq), causal=True)
+            res[pol]["bf16_prefill_then_f16"] = omc(f32(lg_p)[0].astype(np.float64), (hh[0] @ lm.T)[P - 1:P - 1 + new].astype(np.float64))
+    f, b = res[policy], res["bf16"]
+    ok &= f["doc"] < cos_bound and f["prompt_on_decode_path"] < cos_bound and f["doc"] * 10 < b["doc"] and f["doc_bf16_cache"] < 1e-4
+    # overflow: a huge lm_head-independent activation -- scale one layer's down_proj so that act * W stays finite but the NEXT act overflows
+    eng2, cfg2, w2 = build_engine(cfg_name, 6)
+    eng2.set_precision(policy)
+    dec2 = MistralDecoder(eng2, torch.from_numpy(lm))
+    eng2.layers[0].wgu.mul_(400.0)                 # |gate|, |up| x 400: silu(g) u beyond 65504 for some elements
+    fell = raised = False
+    try:
+        dec2.generate(torch.from_numpy(prompt[:1]).to(DEV), 3, past_key_values=[(k[:, :, :0], v[:, :, :0]) for k, v in kv])
+    except GritHipError:
+        raised = True
+    t_fb = dec2.generate(torch.from_numpy(prompt[:1]).to(DEV), 3, past_key_values=[(k[:, :, :0], v[:, :, :0]) for k, v in kv], on_overflow="bf16")
+    fell = dec2.last_precision == "bf16 (f16 overflow)" and t_fb.shape == (1, 3)
+    ok &= raised and fell
+    return _res(f"native decode on fp16 operands [{cfg_name}, {policy}] vs fp32 oracle: 1-cos of the logits", bool(ok), f16_doc=f["doc"], bf16_doc=b["doc"],
+                f16_prompt_on_decode_path=f["prompt_on_decode_path"], f16_doc_from_bf16_cache=f["doc_bf16_cache"],
+                bf16_prefill_then_f16=f["bf16_prefill_then_f16"], f16_logit_abs_err=f["doc_abs"], bf16_logit_abs_err=b["doc_abs"], logit_std=f["std"],
+                clear_frac=f["clear_frac"], overflow_raised=raised, overflow_fell_back=fell)
+
+
 def check_knn_topk(Q=5, N=10000, H=256, k=10, transposed=False):
     """Index search (rag/index.py:97-104: queries @ embeddings, torch.topk) on the f32-MFMA similarity GEMM + chunked bitonic top-k vs
     numpy: same neighbours (scores compared; indices wherever the score has no tie), descending order, both index layouts."""
@@ -3771,6 +3957,14 @@ ALL_CHECKS = [
     # bf16 model vs the FP32 oracle at H = 4096 / I = 14336 (K = 14336 bf16 activations): measured 6.6 % of the logit spread, against
     # 1.5 % per layer for the reference's own bf16 run at this shape (encoder_7b-l1 fixture); greedy tokens must still agree
     ("native_generate_7b_layer_shape", check_native_generate, dict(cfg_name="7b-l2s", P=12, new=6, rows=1, tol=0.10)),
+    ("gemv_f16", check_gemv_f16, {}),
+    ("gemv_f16_7b", check_gemv_f16, dict(N=6144, K=4096)),
+    ("attn_decode_f16", check_attn_decode_f16, {}),
+    ("attn_decode_f16_gqa4_b1", check_attn_decode_f16, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
+    ("argmax_f32", check_argmax_f32, {}),
+    ("native_generate_f16", check_native_generate_f16, {}),
+    ("native_generate_f16_stream_gqa", check_native_generate_f16, dict(cfg_name="gqa", P=9, new=6, rows=3, policy="f16_stream")),
+    ("native_generate_f16_7b_layer_shape", check_native_generate_f16, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
     ("wgrad_accumulation_drift", check_wgrad_accumulation_drift, {}),
     ("knn_topk", check_knn_topk, {}),
     ("knn_topk_transposed_big", check_knn_topk, dict(Q=3, N=300000, H=128, k=100, transposed=True)),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Decode-step microbenchmark at the GritLM-7B shape: ms per generated token on top of a cached prefix (native decoder, HIP graph).
-python tools/decode_bench.py [--prefix 2048 --new 128 --batch 1]"""
+python tools/decode_bench.py [--prefix 2048 --new 128 --batch 1 --precision bf16|f16_operands|f16_stream]"""
 import argparse
 import json
 import os
@@ -18,6 +18,7 @@ ap.add_argument("--prefix", type=int, default=2048)
 ap.add_argument("--new", type=int, default=128)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--layers", type=int, default=32)
+ap.add_argument("--precision", default="bf16", help="engine policy; the decoder follows it (fp16 operands under f16_operands / f16_stream)")
 ap.add_argument("--no-graph", action="store_true", help="eager launches (rocprofv3 --pmc cannot follow HIP-graph launches)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -29,13 +30,14 @@ if a.no_graph:
     dec.use_graph = False
 g = torch.Generator(device=dev).manual_seed(3)
 doc = torch.randint(3, 32000, (a.batch, a.prefix), generator=g, device=dev)
-_, kv = eng.forward(doc, torch.ones_like(doc), return_kv=True)
+eng.set_precision(a.precision)
+_, kv = eng.forward(doc, torch.ones_like(doc), return_kv=True, kv_dtype=None)
 q = torch.randint(3, 32000, (a.batch, 4), generator=g, device=dev)
 dec.generate(q, 8, past_key_values=kv)
 torch.cuda.synchronize()
 # ms per token = the slope between a run of n and a run of 3n new tokens (prefill of the query and launch set-up cancel); the median of three
 # such pairs: one slow first run (a box hiccup) used to show up as an impossibly FAST token rate
-slopes = []
+slopes, raw = [], []
 for _ in range(3):
     res = {}
     for n in (a.new, 3 * a.new):
@@ -44,7 +46,8 @@ for _ in range(3):
         torch.cuda.synchronize()
         res[n] = time.perf_counter() - t0
     slopes.append((res[3 * a.new] - res[a.new]) / (2 * a.new) * 1e3)
+    raw.append([res[a.new], res[3 * a.new]])
 ms = sorted(slopes)[1]
 wbytes = (sum(sum(getattr(L, k).numel() for k in ("wqkv", "wo", "wgu", "wdown")) for L in eng.layers) + lm_head.numel()) * 2
-print(json.dumps({"metric": "native decode ms per token (7B shape)", "ms_per_token": ms, "tokens_per_s": a.batch * 1e3 / ms, "batch": a.batch,
-                  "prefix": a.prefix, "ms_per_token_runs": slopes, "weight_gb_per_token": wbytes / 1e9, "hbm_roofline_ms": wbytes / 8e12 * 1e3, "frac_of_hbm_roofline": wbytes / 8e12 * 1e3 / ms}))
+print(json.dumps({"metric": "native decode ms per token (7B shape)", "precision": a.precision, "decode_arithmetic": dec.last_precision, "ms_per_token": ms, "tokens_per_s": a.batch * 1e3 / ms, "batch": a.batch,
+                  "prefix": a.prefix, "ms_per_token_runs": slopes, "raw_s_n_3n": raw, "weight_gb_per_token": wbytes / 1e9, "hbm_roofline_ms": wbytes / 8e12 * 1e3, "frac_of_hbm_roofline": wbytes / 8e12 * 1e3 / ms}))

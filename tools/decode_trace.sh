@@ -1,9 +1,11 @@
 #!/bin/bash
-# Per-kernel durations of the native decode step (rocprofv3 --kernel-trace --stats): bash tools/decode_trace.sh <tag>  ->  gpurun_out/<tag>_decode_kernel_stats.csv
+# Per-kernel durations of the native decode step (rocprofv3 --kernel-trace --stats): bash tools/decode_trace.sh <tag> [decode_bench.py flags, e.g. --precision f16_stream]  ->  gpurun_out/<tag>_decode_kernel_stats.csv
 cd "$(dirname "$0")/.."
 TAG=${1:-r05}
+shift
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rocprofv3 --kernel-trace --stats -d gpurun_out/dprof -o dec --output-format csv -- python tools/decode_bench.py --new 64 > gpurun_out/${TAG}_decode_bench_under_rocprof.json 2> gpurun_out/dprof.err
+rm -rf gpurun_out/dprof
+rocprofv3 --kernel-trace --stats -d gpurun_out/dprof -o dec --output-format csv -- python tools/decode_bench.py --new 64 "$@" > gpurun_out/${TAG}_decode_bench_under_rocprof.json 2> gpurun_out/dprof.err
 f=$(find gpurun_out/dprof -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/${TAG}_decode_kernel_stats.csv
 python - "$f" <<'PY'

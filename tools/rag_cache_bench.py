@@ -144,18 +144,21 @@ if m.engine is not None:
     lm32 = copy.deepcopy(lm).float()
     ks = [k for k in (1, 7, q_ids.shape[1]) if k <= q_ids.shape[1]]
     with torch.no_grad():
-        def module_logits(mod, dt):
-            pc = passage_cache(0)
-            if dt != dtype:
-                pc32 = DynamicCache()
-                for li, (k_, v_) in enumerate(slices(0)):
-                    pc32.update(k_.to(dt).clone(), v_.to(dt).clone(), li)
-                pc = pc32
+        def module_logits(mod, dt, kv=None):
+            pc = DynamicCache()
+            for li, (k_, v_) in enumerate(slices(0) if kv is None else kv):
+                pc.update(k_.to(dt).clone(), v_.to(dt).clone(), li)
             plen = pc.get_seq_length()
             return mod(input_ids=q_ids[:1], past_key_values=pc, attention_mask=torch.ones((1, plen + q_ids.shape[1]), dtype=torch.long, device=dev),
                        position_ids=torch.arange(plen, plen + q_ids.shape[1], device=dev).unsqueeze(0)).logits[0].float()
         ref_logits = module_logits(lm32, torch.float32)              # [query tokens, V]: position k-1 = next-token logits after k tokens
         hf_logits_all = module_logits(lm, dtype)
+
+    def cmp(x, r):
+        x, r = x.double() - x.double().mean(), r.double() - r.double().mean()
+        top = lambda t: set(torch.topk(t, 10).indices.tolist())
+        return {"one_minus_cos": float(1 - torch.nn.functional.cosine_similarity(x, r, dim=0)), "rel_l2": float((x - r).norm() / r.norm()),
+                "top10_overlap": len(top(x) & top(r)) / 10.0, "argmax_equal": bool(x.argmax() == r.argmax())}
     # the ENCODE half of the flow at the north-star tolerance (round 6): encode(get_cache=True) under each precision policy on two of the
     # passages, embeddings against the reference-equivalent module in FP32 (same weights, same token ids)
     enc_parity = None
@@ -167,26 +170,53 @@ if m.engine is not None:
         e32 = TR.encode(lm32.model, tk["input_ids"].to(dev), tk["attention_mask"].to(dev)).double()
         enc_parity = {"what": f"encode(get_cache=True) of 2 passages x {a.seq} tokens under each precision policy: pooled embeddings vs the "
                               "reference-equivalent module in FP32 on the same weights; max 1 - cos (north-star: 1e-4)"}
+        f16_flow = {"what": "the whole flow under an fp16 policy: encode(get_cache=True) with native_kv_cache (fp16 K/V as the attention read them) "
+                            "-> native decoder on fp16 operands (fp32 stream, grit_gemv_f16 / grit_attn_decode_rope_f16).  decode parity: "
+                            "teacher-forced next-token logits after k query tokens vs the reference-equivalent module in FP32 on the same cached "
+                            "K/V (widened, exact) and the same prefix -- the definition of the bf16 leg above"}
         for pol in ("bf16", "f16_stream", "f16_operands"):
             m.set_precision(pol)
+            m.native_kv_cache = pol != "bf16"
             e_, c_ = m.encode(sub, batch_size=2, max_length=a.seq, get_cache=True, convert_to_tensor=True, add_special_tokens=False)
             l0 = c_.layers[0] if hasattr(c_, "layers") else None
             enc_parity[pol] = {"max_one_minus_cos": float((1 - torch.nn.functional.cosine_similarity(e_.double(), e32, dim=1)).max()),
                                "cache_dtype": str((l0.keys if l0 is not None else c_[0][0]).dtype)}
+            if pol != "bf16":
+                kv16 = [((l.keys, l.values) if hasattr(l, "keys") else (l[0], l[1])) for l in (c_.layers if hasattr(c_, "layers") else c_)]
+                kv16 = [(k_[:1], v_[:1]) for k_, v_ in kv16]
+                with torch.no_grad():
+                    ref16 = module_logits(lm32, torch.float32, kv16)
+                pk = {}
+                for k in ks:
+                    _, nl = dec.generate(q_ids[:1, :k], 1, past_key_values=kv16, return_logits=True)
+                    pk[str(k)] = cmp(nl[0, 0].float(), ref16[k - 1])
+                assert dec.last_precision == "f16", dec.last_precision
+                dec.generate(q_ids[:1], 4, past_key_values=kv16)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                dec.generate(q_ids[:1], a.new_tokens, past_key_values=kv16)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                dec.generate(q_ids[:1], 4 * a.new_tokens, past_key_values=kv16)
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                ms = ((t2 - t1) - (t1 - t0)) / (3 * a.new_tokens) * 1e3
+                f16_flow[pol] = {"decode_native_vs_fp32": pk, "max_one_minus_cos": max(v["one_minus_cos"] for v in pk.values()),
+                                 "max_rel_l2": max(v["rel_l2"] for v in pk.values()), "decode_ms_per_token": ms,
+                                 "decode_frac_of_weight_streaming_roofline": sum(p.numel() for p in lm.parameters()) * 2 / 8e12 * 1e3 / ms,
+                                 "encode_max_one_minus_cos": enc_parity[pol]["max_one_minus_cos"], "kv_cache_dtype": enc_parity[pol]["cache_dtype"]}
+                del kv16
             del e_, c_
         enc_parity["north_star_met"] = bool(min(enc_parity["f16_stream"]["max_one_minus_cos"], enc_parity["f16_operands"]["max_one_minus_cos"]) < 1e-4)
+        f16_flow["north_star_met"] = bool(all(max(f16_flow[p_]["max_one_minus_cos"], f16_flow[p_]["encode_max_one_minus_cos"]) < 1e-4
+                                              for p_ in ("f16_stream", "f16_operands")))
     except Exception as ex:  # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
         enc_parity = {"error": repr(ex)[:300]}
+        f16_flow = {"error": repr(ex)[:300]}
     finally:
         m.set_precision("bf16")
+        m.native_kv_cache = False
     del lm32
     torch.cuda.empty_cache()
-
-    def cmp(x, r):
-        x, r = x.double() - x.double().mean(), r.double() - r.double().mean()
-        top = lambda t: set(torch.topk(t, 10).indices.tolist())
-        return {"one_minus_cos": float(1 - torch.nn.functional.cosine_similarity(x, r, dim=0)), "rel_l2": float((x - r).norm() / r.norm()),
-                "top10_overlap": len(top(x) & top(r)) / 10.0, "argmax_equal": bool(x.argmax() == r.argmax())}
     per_k, per_k_hf = {}, {}
     for k in ks:
         _, nl = dec.generate(q_ids[:1, :k], 1, past_key_values=slices(0), return_logits=True)
@@ -199,10 +229,10 @@ if m.engine is not None:
                       "and the same prefix", "prefix_lengths": ks, "native_vs_fp32": per_k, "stock_bf16_module_vs_fp32": per_k_hf,
               "max_one_minus_cos": worst_cos, "max_rel_l2": worst_l2, "bound_one_minus_cos": BOUND_COS, "bound_rel_l2": BOUND_L2,
               "logits_std": float(ref_logits[-1].std()), "within_bound": bool(worst_cos < BOUND_COS and worst_l2 < BOUND_L2),
-              "level": f"bf16 arithmetic (the reference's decode dtype): the decode path's logits sit {worst_cos / 1e-4:.0f}x above the 1e-4 the north-star "
-                       "states for encode() -- the level of the stock bf16 module on the same cache (stock_bf16_module_vs_fp32); the native decoder has "
-                       "no fp16-operand policy.  The ENCODE half of the flow meets 1e-4 under the fp16 policies: encode_get_cache_by_policy",
-              "encode_get_cache_by_policy": enc_parity}
+              "level": f"bf16 arithmetic (the reference's decode dtype, the default policy): the decode path's logits sit {worst_cos / 1e-4:.0f}x above "
+                       "the 1e-4 the north-star states for encode() -- the level of the stock bf16 module on the same cache "
+                       "(stock_bf16_module_vs_fp32).  Under the fp16 policies BOTH halves of the flow meet 1e-4: f16_flow",
+              "encode_get_cache_by_policy": enc_parity, "f16_flow": f16_flow}
     native = {"generate_s_per_query": t_nat / a.queries, "parity": parity,
               "tokens_per_s_incl_prompt_and_cache_copy": a.new_tokens * a.queries / t_nat,
               "decode_ms_per_token": (t_long - t_nat / a.queries) / (3 * a.new_tokens) * 1e3,
