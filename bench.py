@@ -423,6 +423,9 @@ def compact_summary(line: dict) -> dict:
                      "north_star_met": mp.get("north_star_met"), "err": mx.get("error")},
          "rag": {"decode_frac": r(rag.get("decode_frac_of_weight_streaming_roofline")), "encode_frac": r(rag.get("encode_mfma_roofline_frac")),
                  "decode_logits_1mcos_bf16_level": r(g(rag, "parity", "max_one_minus_cos")),
+                 "f16_decode_logits_1mcos": r(g(rag, "parity", "f16_flow", "f16_stream", "max_one_minus_cos")),
+                 "f16_decode_frac": r(g(rag, "parity", "f16_flow", "f16_stream", "decode_frac_of_weight_streaming_roofline")),
+                 "f16_flow_north_star_met": g(rag, "parity", "f16_flow", "north_star_met"),
                  "encode_get_cache_1mcos": {k: r(g(rag, "parity", "encode_get_cache_by_policy", k, "max_one_minus_cos")) for k in ("bf16", "f16_stream", "f16_operands")},
                  "err": rag.get("error")}}
 

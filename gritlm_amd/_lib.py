@@ -33,6 +33,8 @@ _SIGNATURES = {
     "grit_gemm_f16_nt_rope": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _p, _p, _p, _i, _i, _i, _p]),
     "grit_attn_bidir_f16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_attn_bidir_varlen_f16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
+    "grit_attn_causal_f16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
+    "grit_attn_causal_varlen_f16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
     "grit_f16_overflow_flag": (_i, [C.POINTER(C.c_int), _i, _p]),
     "grit_rope_qk_inplace": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _l, _i, _p]),
     "grit_rope_qk_inplace_pos": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _l, _i, _p]),

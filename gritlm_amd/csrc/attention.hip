@@ -654,7 +654,10 @@ static int attn_fwd_padded(const char* name, bool causal, int window, const void
                "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
   const AttnGeom g = attn_geom(B, S, nq, nkv, causal);
   const dim3 grid(g.grid);
-  if (causal)
+  if (causal && f16)
+    attn_launch<false, true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
+                                   out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, window);
+  else if (causal)
     attn_launch<false, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, key_bits, nullptr, (uint16_t*)out, lse, S, nq, nkv, qkv_stride,
                              out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   else if (f16)
@@ -682,7 +685,10 @@ static int attn_fwd_varlen(const char* name, bool causal, int window, const void
                "%s: one sequence spans more than 2 GiB (32-bit row offsets)", name);
   const AttnGeom g = attn_geom(B, max_len, nq, nkv, causal);
   const dim3 grid(g.grid);
-  if (causal)
+  if (causal && f16)
+    attn_launch<true, true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
+                                  out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, window);
+  else if (causal)
     attn_launch<true, true>(grid, (hipStream_t)stream, (const uint16_t*)qkv, nullptr, cu_seqlens, (uint16_t*)out, lse, max_len, nq, nkv, qkv_stride,
                             out_stride, scale * 1.4426950408889634f, g.qpw, g.ngx, g.n_sets, causal ? window : 0);
   else if (f16)
@@ -699,7 +705,17 @@ extern "C" int grit_attn_bidir_fwd(const void* qkv, const uint64_t* key_bits, vo
                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   return attn_fwd_padded("grit_attn_bidir_fwd", false, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream);
 }
-// fp16-operand policy: qkv and out hold IEEE fp16 (bidirectional attention only: the embedding path)
+// fp16-operand policy: qkv and out hold IEEE fp16.  Bidirectional (the embedding path) and -- ABI 5 -- causal, optionally with a sliding
+// window of `window` keys (0: none): the causal prompt pass of a unified / generative model and the 'cc' embedding attention
+extern "C" int grit_attn_causal_f16_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
+                                        int d, int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream) {
+  return attn_fwd_padded("grit_attn_causal_f16_fwd", true, window, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream, true);
+}
+extern "C" int grit_attn_causal_varlen_f16_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq,
+                                               int nkv, int d, int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream) {
+  return attn_fwd_varlen("grit_attn_causal_varlen_f16_fwd", true, window, qkv, cu_seqlens, out, lse, B, max_len, nq, nkv, d, qkv_stride, out_stride,
+                         scale, stream, true);
+}
 extern "C" int grit_attn_bidir_f16_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv,
                                        int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream) {
   return attn_fwd_padded("grit_attn_bidir_f16_fwd", false, 0, qkv, key_bits, out, lse, B, S, nq, nkv, d, qkv_stride, out_stride, scale, stream, true);

@@ -54,6 +54,7 @@ class MistralDecoder:
         self.fuse_norm = os.environ.get("GRIT_DECODE_FUSE_NORM", "deferred")
         # None: follow the engine's policy (fp16 operands under its fp16 policies); "bf16" / "f16" pin the decode arithmetic
         self.precision = os.environ.get("GRIT_DECODE_PRECISION") or None
+        self.on_overflow = "raise"                # fp16 operands, a value beyond the range: "raise" | "bf16" (repeat the call in bf16)
         self._lm_head16 = None
         self.last_precision = None                # what the last generate() call ran in ("bf16" | "f16"; "bf16 (f16 overflow)" after a fallback)
 
@@ -163,7 +164,7 @@ class MistralDecoder:
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, max_new_tokens: int, attention_mask: torch.Tensor | None = None, past_key_values=None,
                  past_lens: torch.Tensor | None = None, eos_token_id: int | None = None, return_logits: bool = False,
-                 on_overflow: str = "raise", _force_bf16: bool = False):
+                 on_overflow: str | None = None, _force_bf16: bool = False):
         """Greedy continuation.  ``input_ids`` [B,P]: the NEW prompt tokens (right-padded rows need ``attention_mask``; with
         ``past_key_values`` all rows must be full length).  ``past_key_values``: per-layer K/V [B,nkv,S,d] of an already encoded
         prefix, e.g. the bidirectional document pass of ``encode(get_cache=True)``; ``past_lens`` [B] = valid prefix tokens per row
@@ -171,9 +172,11 @@ class MistralDecoder:
         ``return_logits``, the logits of every generated position [B, max_new_tokens, V] (bf16; fp32 on fp16 operands).
 
         On fp16 operands (module docstring) a value beyond the fp16 range invalidates the call: ``on_overflow="raise"`` raises
-        ``GritHipError``, ``"bf16"`` repeats the whole call in the bf16 arithmetic (what ``GritLM(precision="auto")`` stands for)."""
+        ``GritHipError``, ``"bf16"`` repeats the whole call in the bf16 arithmetic; default ``self.on_overflow`` ("raise";
+        ``GritLM(precision="auto").native_decoder()`` sets "bf16": the ladder's last rung)."""
         dev, c = self.device, self.cfg
         f16 = self._f16() and not _force_bf16
+        on_overflow = self.on_overflow if on_overflow is None else on_overflow
         if on_overflow not in ("raise", "bf16"):
             raise ValueError(f"on_overflow={on_overflow!r}: 'raise' or 'bf16'")
         if f16:
@@ -198,29 +201,29 @@ class MistralDecoder:
         if past is None:
             # prefill: one causal pass over the prompt that also emits the post-RoPE K/V (the encoder engine's forward)
             mask = torch.ones((B, P), dtype=I64, device=dev) if attention_mask is None else attention_mask.to(device=dev, dtype=I64)
-            # (the fp16 policies are built for the bidirectional embedding pass: the causal prompt pass of a unified model runs in the
-            # reference's bf16 arithmetic and the engine's policy is restored afterwards; an fp16 decode continues from its K/V widened
-            # to fp16, exactly -- the prompt's own arithmetic stays at the bf16 level.  A prompt that must be held to the fp16 level
-            # rides on the decode path: pass it with ``past_key_values`` of an empty or document prefix)
+            # fp16 operands: the prompt pass runs under the engine's fp16 policy as well (causal fp16 attention, grit_attn_causal_f16_fwd); its
+            # fp16 K/V go into the cache as they are and the first token's logits come from the un-normalised stream of the last prompt
+            # token through the same deferred norm + lm_head launch the decode steps use.  A decoder pinned to "f16" on a bf16 engine
+            # (or the reverse) switches the engine's policy for the pass and restores it.
             was, pol = self.eng.causal, self.eng.precision
-            if pol in ("f16_operands", "f16_stream"):
+            if f16 and pol not in F16_POLICIES:
+                self.eng.precision = "f16_operands"
+            elif not f16 and pol in F16_POLICIES:
                 self.eng.precision = "bf16"
             self.eng.causal = True
             try:
-                hidden, kv = self.eng.forward(ids, mask, borrow=True, return_kv=True)
+                hidden, kv = self.eng.forward(ids, mask, borrow=True, return_kv=True, final_norm=not f16, kv_dtype=None if f16 else BF16)
             finally:
                 self.eng.causal, self.eng.precision = was, pol
             for li, (k, v) in enumerate(kv):
                 st["cache"][li][0][:, :, :P].copy_(k); st["cache"][li][1][:, :, :P].copy_(v)
-            if f16:
-                self._flag_nonfinite_cache(st, P)
             plen = mask.sum(dim=1).to(I32)
             st["lens"].copy_(plen)
-            last = hidden[torch.arange(B, device=dev), (plen - 1).long()].contiguous()              # [B,H] final-norm output of the last prompt token
+            last = hidden[torch.arange(B, device=dev), (plen - 1).long()].contiguous()              # [B,H] of the last prompt token
             if f16:
-                ops.gemv(last.to(F16), self._lm_head_f16(), out=st["logits"])
+                ops.rmsnorm_gemv(last.to(F16), self.eng.norm, c.rms_norm_eps, self._lm_head_f16(), out=st["logits"], deferred=True)
             else:
-                ops.gemv(last, self.lm_head, out=st["logits"])
+                ops.gemv(last, self.lm_head, out=st["logits"])                                       # (final-norm output, bf16)
         else:
             if attention_mask is not None and not bool((attention_mask != 0).all()):
                 raise NotImplementedError("native decode: padded prompt rows on top of past_key_values")

@@ -175,11 +175,9 @@ class MistralEncoderEngine:
 
     def supported_precisions(self) -> tuple:
         """The policies this engine's model kind / attention mode is built for, in AUTO_LADDER order."""
-        if self.causal:
-            return ("fp32_residual", "bf16") if not self.cfg.num_local_experts else ("bf16",)
         if self.cfg.num_local_experts:
             return ("f16_operands", "bf16")
-        return AUTO_LADDER
+        return AUTO_LADDER              # (bidirectional and -- round 6, grit_attn_causal_f16_fwd -- causal attention alike)
 
     def set_precision(self, precision: str):
         if precision not in PRECISIONS:
@@ -188,8 +186,6 @@ class MistralEncoderEngine:
             if self.cfg.num_local_experts and precision != "f16_operands":
                 raise GritHipError(f"native encoder: precision='{precision}' is built for the dense (Mistral) MLP only "
                                    "(the sparse-MoE engine routes on the fp32 residual stream: use 'f16_operands')")
-            if self.causal:
-                raise GritHipError(f"native encoder: precision='{precision}' is built for bidirectional attention only")
         if precision == "fp32_residual" and self.cfg.num_local_experts:
             raise GritHipError("native encoder: precision='fp32_residual' is built for the dense (Mistral) MLP only")
         self.precision = precision

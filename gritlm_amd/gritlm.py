@@ -284,6 +284,9 @@ class GritLM(torch.nn.Module):
         if getattr(self, "_decoder", None) is None:
             from .decoder import MistralDecoder
             self._decoder = MistralDecoder(self.engine, self.model.lm_head.weight)
+        # the decoder follows the engine's policy (fp16 operands under the fp16 policies); under "auto" a value beyond the fp16 range
+        # repeats the generate() call in bf16 instead of raising, like encode() steps down its ladder
+        self._decoder.on_overflow = "bf16" if self._precision == "auto" else "raise"
         return self._decoder
 
     # ------------------------------------------------------------------ API

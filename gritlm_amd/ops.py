@@ -187,10 +187,10 @@ def attn_bidir_varlen(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
         ev[0].record()
     fn, wa = _attn_entry("varlen_fwd", causal, window)
     odt = BF16
-    if qkv.dtype == F16:            # f16_operands policy (bidirectional only)
-        if causal:
-            raise _lib.GritHipError("attn_bidir_varlen: fp16 operands are built for the bidirectional (embedding) attention only")
-        fn, wa, odt = _lib.load().grit_attn_bidir_varlen_f16_fwd, (), F16
+    if qkv.dtype == F16:            # the fp16-operand policies
+        if window and window > 0 and not causal:
+            raise ValueError("a sliding window applies to causal attention only")
+        fn, wa, odt = (_lib.load().grit_attn_causal_varlen_f16_fwd, (int(window or 0),), F16) if causal else (_lib.load().grit_attn_bidir_varlen_f16_fwd, (), F16)
     check(fn(_chk(qkv, odt, "qkv"), _chk(cu_seqlens, I32, "cu_seqlens"), _chk(out, odt, "out"),
              0 if lse is None else _chk(lse, F32, "lse"), B, int(max_len), nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()),
           "grit_attn_bidir_varlen_fwd")
@@ -474,10 +474,10 @@ def attn_bidir(qkv: torch.Tensor, key_bits: torch.Tensor, B: int, S: int, nq: in
         ev[0].record()
     fn, wa = _attn_entry("fwd", causal, window)
     odt = BF16
-    if qkv.dtype == F16:            # f16_operands policy (bidirectional only)
-        if causal:
-            raise _lib.GritHipError("attn_bidir: fp16 operands are built for the bidirectional (embedding) attention only")
-        fn, wa, odt = _lib.load().grit_attn_bidir_f16_fwd, (), F16
+    if qkv.dtype == F16:            # the fp16-operand policies
+        if window and window > 0 and not causal:
+            raise ValueError("a sliding window applies to causal attention only")
+        fn, wa, odt = (_lib.load().grit_attn_causal_f16_fwd, (int(window or 0),), F16) if causal else (_lib.load().grit_attn_bidir_f16_fwd, (), F16)
     check(fn(_chk(qkv, odt, "qkv"), _chk(key_bits, I64, "key_bits"), _chk(out, odt, "out"),
              0 if lse is None else _chk(lse, F32, "lse"), B, S, nq, nkv, d, stride, out.stride(0), float(scale), *wa, _stream()), "grit_attn_bidir_fwd")
     if ev:

@@ -163,6 +163,13 @@ int grit_attn_bidir_f16_fwd(const void* qkv, const uint64_t* key_bits, void* out
                             int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
 int grit_attn_bidir_varlen_f16_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq, int nkv,
                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, void* stream);
+/* The same attention on fp16 operands with is_causal=True (ABI 5), optionally under a sliding window of `window` keys (0: none; meaning as
+ * grit_attn_causal_window_fwd): the causal prompt pass of a unified / generative model and the 'cc' embedding attention under the fp16
+ * policies (mask :1005-1031). */
+int grit_attn_causal_f16_fwd(const void* qkv, const uint64_t* key_bits, void* out, float* lse, int B, int S, int nq, int nkv, int d,
+                             int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream);
+int grit_attn_causal_varlen_f16_fwd(const void* qkv, const int32_t* cu_seqlens, void* out, float* lse, int B, int max_len, int nq, int nkv,
+                                    int d, int64_t qkv_stride, int64_t out_stride, float scale, int window, void* stream);
 
 /* "f16_stream" (the same policy with the residual stream itself in fp16 instead of fp32: 16-bit epilogue and norm traffic, 0.975 of
  * the default's docs/s instead of 0.955; 1 - cos 6e-6 emulated): grit_embed_gather on an fp16 copy of the table (a 16-bit row copy),

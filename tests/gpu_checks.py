@@ -1383,10 +1383,11 @@ def check_f16_stream_norm_and_gather(T=37, H=4096):
     return _res(f"f16 stream: rmsnorm_f16in + gather [T={T},H={H}]", ok, **det)
 
 
-def check_attention_f16(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=211, packed_lens=None):
-    """grit_attn_bidir_f16_fwd / _varlen_f16_fwd vs the fp64 oracle on the same fp16 inputs: the output carries one fp16 rounding of P
-    (2^-12 relative per term, averaging down) and one of O; LSE is fp32.  With packed_lens: the packed launch must reproduce the padded
-    rows bit for bit (what keeps packed == padded in the f16 policy)."""
+def check_attention_f16(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=211, packed_lens=None, causal=False, window=0):
+    """grit_attn_bidir_f16_fwd / _varlen_f16_fwd (and, ``causal``, grit_attn_causal_f16_fwd / _varlen_f16_fwd, optionally windowed) vs the
+    fp64 oracle on the same fp16 inputs: the output carries one fp16 rounding of P (2^-12 relative per term, averaging down) and one of
+    O; LSE is fp32.  With packed_lens: the packed launch must reproduce the padded rows bit for bit (what keeps packed == padded in the
+    f16 policy)."""
     d = 128
     width = (nq + 2 * nkv) * d
     rng = np.random.default_rng(seed)
@@ -1402,29 +1403,66 @@ def check_attention_f16(B=2, S=200, nq=4, nkv=2, mask_kind="ragged", seed=211, p
         mask = (rng.random((B, S)) < 0.7).astype(np.int64); mask[:, 0] = 1
     x = qkv.reshape(B, S, nq + 2 * nkv, d).transpose(0, 2, 1, 3)
     q, k, v = x[:, :nq], x[:, nq:nq + nkv], x[:, nq + nkv:]
-    ref = O.attention_bidirectional(q, k, v, mask)
+    ref = O.attention_bidirectional(q, k, v, mask, causal=causal, window=window)
     lse_t = torch.empty((B, nq, S), dtype=torch.float32, device=DEV)
     bits = ops.mask_pack(torch.from_numpy(mask).to(DEV))
     t = fh(qkv)
-    out_t = ops.attn_bidir(t, bits, B, S, nq, nkv, d, lse=lse_t)
+    out_t = ops.attn_bidir(t, bits, B, S, nq, nkv, d, lse=lse_t, causal=causal, window=window)
     out = out_t.float().cpu().numpy().reshape(B, S, nq * d)
     kk = np.repeat(k, nq // nkv, axis=1)
     sc = np.einsum("bhqd,bhkd->bhqk", q.astype(np.float64), kk.astype(np.float64)) / np.sqrt(d)
-    sc = np.where(np.broadcast_to(mask.astype(bool)[:, None, None, :], sc.shape), sc, -np.inf)
-    mx = sc.max(-1, keepdims=True)
-    lse_ref = mx[..., 0] + np.log(np.exp(sc - mx).sum(-1))
+    allowed = np.broadcast_to(mask.astype(bool)[:, None, None, :], sc.shape)
+    if causal:
+        allowed = allowed & O.causal_window_mask(S, window)[None, None]
+    sc = np.where(allowed, sc, -np.inf)
+    sees = allowed.any(-1)                      # (a padding query behind a sliding window sees no key: output 0, lse -inf)
+    mx = np.where(sees, sc.max(-1), 0.0)[..., None]
+    with np.errstate(divide="ignore"):
+        lse_ref = mx[..., 0] + np.log(np.exp(sc - mx).sum(-1))
     err = float(np.max(np.abs(out - ref)))
-    lerr = float(np.max(np.abs(f32(lse_t) - lse_ref)))
+    lerr = float(np.max(np.abs(f32(lse_t) - lse_ref)[sees]))
     det = dict(max_abs=err, lse_abs=lerr)
     ok = err < 2.5e-3 and lerr < 2e-3 and not np.isnan(out).any() and out_t.dtype == torch.float16      # (bf16 kernel: 2e-2)
     if packed_lens is not None:
         keep = torch.from_numpy(mask.astype(bool).reshape(-1)).to(DEV)
         cu = torch.zeros((B + 1,), dtype=torch.int32, device=DEV)
         cu[1:] = torch.cumsum(torch.tensor(packed_lens, dtype=torch.int32, device=DEV), 0)
-        po = ops.attn_bidir_varlen(t[keep].contiguous(), cu, max(packed_lens), nq, nkv, d)
+        po = ops.attn_bidir_varlen(t[keep].contiguous(), cu, max(packed_lens), nq, nkv, d, causal=causal, window=window)
         det["packed_identical"] = bool(torch.equal(po, out_t[keep]))
         ok &= det["packed_identical"]
-    return _res(f"attention_f16[B={B},S={S},nq={nq},nkv={nkv},{mask_kind if packed_lens is None else 'packed'}]", ok, **det)
+    return _res(f"attention_f16[B={B},S={S},nq={nq},nkv={nkv},{mask_kind if packed_lens is None else 'packed'},causal={int(causal)},window={window}]", ok, **det)
+
+
+def check_encoder_causal_f16(cfg_name="gqa", B=3, S=96):
+    """The engine with CAUSAL attention ('cc' embedding attention; the prompt pass of a unified / generative model) under the fp16
+    policies against the fp32 oracle: hidden states at least 10x closer than the bf16 policy on the same inputs, pooled lasttoken /
+    weightedmean embeddings within 1e-5 (1 - cos), padded == packed bit for bit, K/V handed out in fp16."""
+    eng, cfg, w = build_engine(cfg_name, 4)
+    ids, mask = synth.make_batch(cfg, B, S, seed=61, min_len=S // 3)
+    tid, tm = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    ref = O.mistral_encode(w, cfg, ids, mask, causal=True)
+    valid = mask.astype(bool)
+    rel = lambda a: float(np.linalg.norm((a - ref)[valid]) / np.linalg.norm(ref[valid]))
+    eng.causal = True
+    out, ok = {}, True
+    eng.set_precision("bf16")
+    out["rel_hidden_bf16"] = rel(f32(eng.forward(tid, tm)))
+    emb_ref = {m: O.l2_normalize(O.pooling(ref, mask, m)) for m in ("lasttoken", "weightedmean")}
+    for pol in ("f16_operands", "f16_stream"):
+        eng.set_precision(pol)
+        _f16_flag()
+        h, kv = eng.forward(tid, tm, return_kv=True, kv_dtype=None)
+        out[f"rel_hidden_{pol}"] = rel(f32(h))
+        ok &= kv[0][0].dtype == torch.float16 and not _f16_flag()
+        for m in ("lasttoken", "weightedmean"):
+            e_pad = eng.encode_pooled(tid, tm, m, True, packed=False)
+            e_pack = eng.encode_pooled(tid, tm, m, True, packed=True)
+            dcos = float(np.max(1 - np.sum(f32(e_pad).astype(np.float64) * emb_ref[m].astype(np.float64), axis=1)))
+            out[f"{m}_1-cos_{pol}"] = dcos
+            ok &= dcos < 1e-5 and bool(torch.equal(e_pad, e_pack))
+    # last_hidden_state is bf16 under every policy (the pooling kernels' input format): its rounding floors the per-element error
+    ok &= out["rel_hidden_f16_operands"] <= out["rel_hidden_bf16"] and out["rel_hidden_f16_stream"] <= out["rel_hidden_bf16"]
+    return _res(f"causal engine under the fp16 policies [{cfg_name}] vs the fp32 oracle", bool(ok), **out)
 
 
 def check_encoder_f16_operands(cfg_name, policy="f16_operands"):
@@ -1478,7 +1516,8 @@ def check_encoder_f16_operands(cfg_name, policy="f16_operands"):
 def check_f16_policy_raises_on_overflow():
     """An activation beyond the fp16 range must surface as an error, not as a saturated embedding: the tiny model with its down_proj input
     scaled up (gate / up weights x 300 -> SwiGLU activations ~1e5) raises from check_f16_overflow() and from GritLM.encode(); the default
-    policy on the same weights is unaffected; causal engines refuse the policy, sparse-MoE engines take 'f16_operands' only."""
+    policy on the same weights is unaffected; causal engines take the policy (round 6: grit_attn_causal_f16_fwd) and raise alike,
+    sparse-MoE engines take 'f16_operands' only."""
     from gritlm_amd._lib import GritHipError
     cfg = synth.CONFIGS["tiny"]
     w = synth.make_weights(cfg, 3)
@@ -1508,18 +1547,20 @@ def check_f16_policy_raises_on_overflow():
         det["cleared_after_raise"] = False
     ok &= det["cleared_after_raise"]
     eng.causal = True
+    eng.set_precision("f16_operands")
+    eng.encode_pooled(ids, mask, "lasttoken", True)
     try:
-        eng.set_precision("f16_operands"); det["causal_refused"] = False
+        eng.check_f16_overflow(); det["causal_raised"] = False
     except GritHipError:
-        det["causal_refused"] = True
-    ok &= det["causal_refused"]
+        det["causal_raised"] = True
+    ok &= det["causal_raised"] and eng.supported_precisions()[0] == "f16_stream"
     meng, _, _ = build_engine("moe-tiny", 0)
     try:
         meng.set_precision("f16_stream"); det["moe_refuses_f16_stream"] = False          # (the sparse-MoE engine routes on the fp32 stream:
     except GritHipError:                                                                  #  'f16_operands' only, round 6)
         det["moe_refuses_f16_stream"] = True
     ok &= det["moe_refuses_f16_stream"]
-    return _res("f16_operands: overflow raises, causal engines refuse the policy, MoE engines refuse f16_stream", ok, **det)
+    return _res("f16_operands: overflow raises (bidirectional and causal engines), MoE engines refuse f16_stream", ok, **det)
 
 
 def check_gritlm_f16_operands():
@@ -2743,7 +2784,7 @@ def check_argmax_f32(B=3, V=32003):
 def check_native_generate_f16(cfg_name="tiny", P=21, new=10, rows=2, policy="f16_operands", cos_bound=1e-5):
     """The decoder on fp16 operands (engine policy ``f16_operands`` / ``f16_stream``): teacher-forced logits of every generated position against
     the fp32 oracle at the NORTH-STAR's level -- 1 - cos(logits row) < ``cos_bound`` (<= 1e-4 / 10), at least 10x below the bf16 decoder on
-    the same weights and tokens -- (a) from a prompt (bf16 causal prefill, K/V widened), (b) on top of the fp16 document K/V of
+    the same weights and tokens -- (a) from a prompt (one causal pass under the policy), (b) on top of the fp16 document K/V of
     encode(get_cache=True) under the policy (kv_dtype=None), the RAG flow; greedy tokens agree wherever the oracle's margin is clear;
     graph replay == eager; rows 1..3; overflow: on_overflow='bf16' falls back, 'raise' raises."""
     from gritlm_amd._lib import GritHipError
@@ -2791,13 +2832,15 @@ def check_native_generate_f16(cfg_name="tiny", P=21, new=10, rows=2, policy="f16
                 hh = O.mistral_encode(w, cfg, seq, np.ones_like(seq), causal=True)
                 worst = max(worst, omc(lg[b], (hh[0] @ lm.T)[P - 1:P - 1 + new].astype(np.float64)))
             res[pol]["prompt_on_decode_path"] = worst
-            # plain prompt: bf16 causal prefill + fp16 decode (documented: the prompt's own arithmetic stays bf16)
+            # plain prompt: ONE causal pass under the fp16 policy (grit_attn_causal_f16_fwd), fp16 K/V straight into the cache, then decode
             toks_p, lg_p = dec.generate(torch.from_numpy(prompt[:1]).to(DEV), new, return_logits=True)
             seq = np.concatenate([prompt[0], toks_p.cpu().numpy()[0]])[None]
             hh = O.mistral_encode(w, cfg, seq, np.ones_like(seq), causal=True)
-            res[pol]["bf16_prefill_then_f16"] = omc(f32(lg_p)[0].astype(np.float64), (hh[0] @ lm.T)[P - 1:P - 1 + new].astype(np.float64))
+            res[pol]["prompt_prefill"] = omc(f32(lg_p)[0].astype(np.float64), (hh[0] @ lm.T)[P - 1:P - 1 + new].astype(np.float64))
+            ok &= eng.precision == pol and not eng.causal
     f, b = res[policy], res["bf16"]
     ok &= f["doc"] < cos_bound and f["prompt_on_decode_path"] < cos_bound and f["doc"] * 10 < b["doc"] and f["doc_bf16_cache"] < 1e-4
+    ok &= f["prompt_prefill"] < cos_bound
     # overflow: a huge lm_head-independent activation -- scale one layer's down_proj so that act * W stays finite but the NEXT act overflows
     eng2, cfg2, w2 = build_engine(cfg_name, 6)
     eng2.set_precision(policy)
@@ -2813,7 +2856,7 @@ def check_native_generate_f16(cfg_name="tiny", P=21, new=10, rows=2, policy="f16
     ok &= raised and fell
     return _res(f"native decode on fp16 operands [{cfg_name}, {policy}] vs fp32 oracle: 1-cos of the logits", bool(ok), f16_doc=f["doc"], bf16_doc=b["doc"],
                 f16_prompt_on_decode_path=f["prompt_on_decode_path"], f16_doc_from_bf16_cache=f["doc_bf16_cache"],
-                bf16_prefill_then_f16=f["bf16_prefill_then_f16"], f16_logit_abs_err=f["doc_abs"], bf16_logit_abs_err=b["doc_abs"], logit_std=f["std"],
+                f16_prompt_prefill=f["prompt_prefill"], f16_logit_abs_err=f["doc_abs"], bf16_logit_abs_err=b["doc_abs"], logit_std=f["std"],
                 clear_frac=f["clear_frac"], overflow_raised=raised, overflow_fell_back=fell)
 
 
@@ -3726,7 +3769,17 @@ def check_get_cache_f16():
                     plen = int(m.tokenizer([sents[0]], return_tensors="pt", truncation=True, max_length=48)["input_ids"].shape[1])
                     one = [(get(cache, li)[0][:1, :, :plen].contiguous(), get(cache, li)[1][:1, :, :plen].contiguous()) for li in range(2)]
                     toks = m.native_decoder().generate(q, 3, past_key_values=one)
+                    ok &= m.native_decoder().last_precision == "f16"                           # the decoder follows the engine's policy (round 6)
                     toks2 = m.native_decoder().generate(q, 3)                                  # prompt prefill under an fp16 policy: runs, policy restored
+                    # native_kv_cache: the fp16 K/V the attention read, handed to the native decoder as they are
+                    m.native_kv_cache = True
+                    _, cache_n = m.encode(sents, max_length=48, get_cache=True)
+                    m.native_kv_cache = False
+                    ok &= get(cache_n, 0)[0].dtype == torch.float16 and bool(torch.equal(get(cache_n, 1)[0], kv16[1][0]))
+                    one_n = [(get(cache_n, li)[0][:1, :, :plen].contiguous(), get(cache_n, li)[1][:1, :, :plen].contiguous()) for li in range(2)]
+                    _, lg_n = m.native_decoder().generate(q, 3, past_key_values=one_n, return_logits=True)
+                    _, lg_b = m.native_decoder().generate(q, 3, past_key_values=one, return_logits=True)
+                    ok &= lg_n.dtype == torch.float32 and float((1 - torch.nn.functional.cosine_similarity(lg_n[0].double(), lg_b[0].double(), dim=1)).max()) < 1e-4
                 ok &= tuple(toks.shape) == (1, 3) and tuple(toks2.shape) == (1, 3) and m.engine.precision == pol
             del m
     return _res("encode(get_cache=True) under the fp16 policies", bool(ok), **out)
@@ -3869,6 +3922,10 @@ ALL_CHECKS = [
     ("attn_f16_holes", check_attention_f16, dict(mask_kind="holes", S=257)),
     ("attn_f16_full_512", check_attention_f16, dict(B=1, S=512, nq=8, nkv=2, mask_kind="none")),
     ("attn_f16_packed", check_attention_f16, dict(B=4, S=513, nq=4, nkv=2, packed_lens=(513, 1, 129, 300))),
+    ("attn_f16_causal", check_attention_f16, dict(B=2, S=513, nq=4, nkv=2, mask_kind="ragged", seed=213, causal=True)),
+    ("attn_f16_causal_window", check_attention_f16, dict(B=2, S=330, nq=4, nkv=2, mask_kind="ragged", seed=215, causal=True, window=100)),
+    ("attn_f16_causal_packed", check_attention_f16, dict(B=4, S=513, nq=4, nkv=2, packed_lens=(513, 1, 129, 300), causal=True, seed=217)),
+    ("encoder_causal_f16", check_encoder_causal_f16, {}),
     ("encoder_tiny_f16_operands", check_encoder_f16_operands, dict(cfg_name="tiny")),
     ("encoder_gqa_f16_operands", check_encoder_f16_operands, dict(cfg_name="gqa")),
     ("encoder_7b_layer_f16_operands", check_encoder_f16_operands, dict(cfg_name="7b-l1")),

@@ -194,7 +194,7 @@ def test_parallelize_replicates_in_a_single_task_slurm_job(dirs, monkeypatch):
 
 def test_precision_auto_ladder_is_host_logic(dirs):
     """precision='auto' (round 6): validated, and GritLM.set_precision walks gritlm_amd.encoder.AUTO_LADDER restricted to what the engine's
-    model kind supports (dense bidirectional: all four rungs; sparse-MoE: f16_operands then bf16; causal: no fp16 rung)."""
+    model kind supports (dense, bidirectional or causal: all four rungs; sparse-MoE: f16_operands then bf16)."""
     from gritlm_amd.encoder import AUTO_LADDER
     assert AUTO_LADDER == ("f16_stream", "f16_operands", "fp32_residual", "bf16")
     m = GritLM(dirs["m32"], pooling_method="mean", attn="bbcc", device="cpu", precision="auto")
