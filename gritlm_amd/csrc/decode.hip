@@ -83,14 +83,14 @@ constexpr int GV_ROWS_SW = GRIT_GV_ROWS_SWIGLU;   // the same for the gate|up la
 // activation (one rounding of silu(g) * u).  MODE 1 additionally writes out16 = fp16(out): the operand copy of the stream the next
 // norm + GEMV reads (an fp32 x would double the x traffic of the 7168 gate|up workgroups: measured +2.8 us per launch, 3 % of a token).
 // PRENORM 1 (the exact bf16 form) has no fp16 counterpart.  ld* are in elements of the respective format.
-template <int NB, int MODE, int PRENORM, int R, bool F16 = false>
-__global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
+template <int NB, int MODE, int PRENORM, int R, bool F16 = false, int WV = 4>
+__global__ void __launch_bounds__(64 * WV) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
                                                    const uint16_t* __restrict__ res, const uint16_t* __restrict__ ln_w, float eps, int B, int N,
                                                    int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr, unsigned int* __restrict__ flag,
                                                    uint16_t* __restrict__ out16, int64_t ldo16) {
   static_assert(!(F16 && PRENORM == 1), "the exact fused norm rounds to bf16: bf16 only");
-  __shared__ float red[4][R][NB];
-  __shared__ float red_ss[4][NB];
+  __shared__ float red[WV][R][NB];                            // WV waves per workgroup, each takes 1 / WV of K (split-K, LDS reduce)
+  __shared__ float red_ss[WV][NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int unit = blockIdx.x;                                // one unit = R weight rows
   int rows[R];
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
   for (int i = 0; i < R; ++i)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
-  for (int c = c0; c < KC; c += 256) {
+  for (int c = c0; c < KC; c += 64 * WV) {
     // (a one-step software pipeline of the weight loads -- next iteration's pieces requested before this iteration's arithmetic -- was
     //  measured 8 % SLOWER at the 7B shape: 16 more registers per lane, fewer workgroups in flight; profiles/r03_decode_ab.log)
     if (c != c0) {
@@ -218,15 +218,25 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
   // thread t < R*NB finishes output (row i, batch b)
   const int t = threadIdx.x;
   auto row_scale = [&](int b) -> float {
-    return PRENORM == 2 ? rsqrtf((red_ss[0][b] + red_ss[1][b] + red_ss[2][b] + red_ss[3][b]) / (float)K + eps) : 1.0f;
+    if (PRENORM != 2) return 1.0f;
+    float ss = red_ss[0][b];
+#pragma unroll
+    for (int w = 1; w < WV; ++w) ss += red_ss[w][b];
+    return rsqrtf(ss / (float)K + eps);
+  };
+  auto total = [&](int i, int b) -> float {                   // the waves' partial sums, in wave order
+    float v = red[0][i][b];
+#pragma unroll
+    for (int w = 1; w < WV; ++w) v += red[w][i][b];
+    return v;
   };
   if (MODE == 2) {
     if (t < (R / 2) * NB) {
       const int i = t / NB, b = t - i * NB, p = unit * (R / 2) + i;
       if (p < N / 2 && b < B) {
         const float rs = row_scale(b);
-        const float g = (red[0][2 * i][b] + red[1][2 * i][b] + red[2][2 * i][b] + red[3][2 * i][b]) * rs;
-        const float u = (red[0][2 * i + 1][b] + red[1][2 * i + 1][b] + red[2][2 * i + 1][b] + red[3][2 * i + 1][b]) * rs;
+        const float g = total(2 * i, b) * rs;
+        const float u = total(2 * i + 1, b) * rs;
         if constexpr (F16) {
           const uint16_t hb = f2h_bits(silu_f(g) * u);
           if ((hb & 0x7c00u) == 0x7c00u) atomicOr(flag, 1u);
@@ -239,7 +249,7 @@ __global__ void __launch_bounds__(256) gemv_bf16_k(const uint16_t* __restrict__ 
   } else if (t < R * NB) {
     const int i = t / NB, b = t - i * NB, n = unit * R + i;
     if (n < N && b < B) {
-      float v = (red[0][i][b] + red[1][i][b] + red[2][i][b] + red[3][i][b]) * row_scale(b);
+      float v = total(i, b) * row_scale(b);
       if constexpr (F16) {
         if (MODE == 1) v += reinterpret_cast<const float*>(res)[(int64_t)b * ldr + n];
         reinterpret_cast<float*>(out)[(int64_t)b * ldo + n] = v;
@@ -596,11 +606,20 @@ static int launch_gemv(const void* x, const void* W, void* out, const void* res,
   const dim3 grid((unsigned)units);
   unsigned int* flag = F16 ? f16_flag_ptr() : nullptr;
   if (F16 && !flag) return GRIT_E_LAUNCH;
-#define GRIT_GEMV(NB_)                                                                                                                    \
-  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM, R, F16>), grid, dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)W, (uint16_t*)out, \
-                     (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr, flag, (uint16_t*)out16, ldo16)
+#define GRIT_GEMV_W(NB_, WV_)                                                                                                             \
+  hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM, R, F16, WV_>), grid, dim3(64 * WV_), 0, st, (const uint16_t*)x, (const uint16_t*)W,       \
+                     (uint16_t*)out, (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr, flag, (uint16_t*)out16, ldo16)
+  // GRIT_GV_WAVES_SHORT_K (A/B builds): workgroups of 8 waves where K <= 4096 (q|k|v, o_proj: every lane then covers its share of the row in
+  // ONE iteration -- one memory latency instead of two -- at twice the requests in flight per workgroup); 1- and 2-row steps only.
+  // Measured (profiles/r06_decode_f16_ab.log, block 4): 2.754 -> 2.747 ms per token on bf16, 2.766 -> 2.743 on fp16 operands: not the default.
+#ifdef GRIT_GV_WAVES_SHORT_K
+#define GRIT_GEMV(NB_) do { if (K <= 4096 && NB_ <= 2 && PRENORM != 1) GRIT_GEMV_W(NB_, GRIT_GV_WAVES_SHORT_K); else GRIT_GEMV_W(NB_, 4); } while (0)
+#else
+#define GRIT_GEMV(NB_) GRIT_GEMV_W(NB_, 4)
+#endif
   if (B == 1) GRIT_GEMV(1); else if (B == 2) GRIT_GEMV(2); else if (B <= 4) GRIT_GEMV(4); else GRIT_GEMV(8);
 #undef GRIT_GEMV
+#undef GRIT_GEMV_W
   GRIT_CHECK_LAUNCH(F16 ? "grit_gemv_f16" : "grit_gemv_bf16");
   return GRIT_OK;
 }

@@ -286,3 +286,38 @@ def test_auto_ladder_reruns_the_call_one_rung_down_and_never_raises(dirs):
     assert not e0.flag and not e1.flag
     m.set_precision("bf16")
     assert m.encode(sents, batch_size=2, max_length=32).shape[0] == 7
+
+
+def test_native_decoder_follows_the_engine_policy_host_logic():
+    """MistralDecoder (round 6): the decode arithmetic follows the engine's precision policy -- fp16 operands under the fp16 policies --,
+    `decoder.precision` pins it, invalid pins / on_overflow values raise before any kernel is launched, and GritLM(precision="auto") makes
+    the bf16 repeat the decoder's overflow behaviour (the ladder's last rung)."""
+    from types import SimpleNamespace
+    from gritlm_amd.decoder import MistralDecoder
+    eng = SimpleNamespace(cfg=SimpleNamespace(num_local_experts=0, num_attention_heads=2, num_key_value_heads=1, head_dim=128, hidden_size=256,
+                                              intermediate_size=512, num_hidden_layers=1, rms_norm_eps=1e-5, rope_theta=1e4),
+                          device=torch.device("cpu"), precision="bf16", window_keys=0)
+    dec = MistralDecoder(eng, torch.zeros((8, 256)))
+    assert dec.on_overflow == "raise" and dec.last_precision is None
+    for pol, want in (("bf16", False), ("fp32_residual", False), ("f16_operands", True), ("f16_stream", True)):
+        eng.precision = pol
+        assert dec._f16() is want
+    dec.precision = "bf16"
+    assert dec._f16() is False
+    eng.precision, dec.precision = "bf16", "f16"
+    assert dec._f16() is True
+    dec.precision = "fp8"
+    with pytest.raises(ValueError):
+        dec._f16()
+    dec.precision = "bf16"
+    with pytest.raises(ValueError):
+        dec.generate(torch.zeros((1, 2), dtype=torch.long), 2, on_overflow="ignore")
+    with pytest.raises(NotImplementedError):
+        MistralDecoder(SimpleNamespace(cfg=SimpleNamespace(num_local_experts=8), device=torch.device("cpu")), torch.zeros((8, 256)))
+    # GritLM.native_decoder(): "auto" -> on_overflow "bf16"
+    m = GritLM.__new__(GritLM)
+    torch.nn.Module.__init__(m)
+    m.engine, m.model, m._precision, m._decoder = eng, SimpleNamespace(lm_head=SimpleNamespace(weight=torch.zeros((8, 256)))), "auto", None
+    assert m.native_decoder().on_overflow == "bf16"
+    m._precision = "f16_stream"
+    assert m.native_decoder().on_overflow == "raise"

@@ -35,11 +35,11 @@ def _resources(src):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src,needle,count", [("gemm_bf16.hip", "gemm_bf16_nt_k", 28), ("attention.hip", "attn_bidir_fwd_k", 6)])
+@pytest.mark.parametrize("src,needle,count", [("gemm_bf16.hip", "gemm_bf16_nt_k", 28), ("attention.hip", "attn_bidir_fwd_k", 8)])
 def test_mfma_kernels_do_not_spill(src, needle, count):
     """(counts: 8 epilogues x {per-tile, persistent} bf16 GEMMs + the 6 forward epilogues x 2 of the fp16-operand policies
     -- STORE, ROPE, RESIDUAL, SWIGLU, SWIGLU_STACKED (round 6: GradCache pass 1), RESIDUAL_F32; 4 bf16 attention
-    forwards + the 2 bidirectional fp16 ones)"""
+    forwards + the 4 fp16 ones: bidirectional and -- round 6 -- causal, padded and packed)"""
     ks = [k for k in _resources(src) if needle in k["name"]]
     assert len(ks) == count, [k["name"] for k in ks]
     for k in ks:
