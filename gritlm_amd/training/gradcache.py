@@ -18,6 +18,8 @@ from typing import Dict, List
 import torch
 import torch.distributed as dist
 
+from .._lib import GritHipError
+
 
 def dist_active() -> bool:
     """Data-parallel collectives needed?  True for world_size > 1; GRIT_DIST_WORLD1=1 keeps every collective in the step on a
@@ -215,9 +217,19 @@ class GradCacheStep:
         tests/gpu_checks.py::check_gradcache_f16_pass1 and bench.py's contrastive `parity` object."""
         self.model = model
         eng = getattr(model, "train_engine", None)
+        explicit = precision is not None
         precision = precision or os.environ.get("GRIT_PASS1_PRECISION")
         if precision and eng is not None:
-            eng.set_nograd_precision(precision)
+            try:
+                eng.set_nograd_precision(precision)
+            except GritHipError:
+                # a process-wide default (the environment variable) that this model kind does not take -- the sparse-MoE engine routes on
+                # the fp32 residual stream -- lands on the fp16 policy it does take; an explicit argument is refused as it stands
+                if explicit or precision != "f16_stream":
+                    raise
+                print(f"GradCacheStep: GRIT_PASS1_PRECISION={precision} is not built for this model kind; pass 1 runs under 'f16_operands'",
+                      flush=True)
+                eng.set_nograd_precision("f16_operands")
         self.precision = getattr(eng, "nograd_precision", "bf16") if eng is not None else "bf16"
         self.chunk_size = int(chunk_size)
         self.pass1_chunk_size = int(pass1_chunk_size) if pass1_chunk_size else pass1_chunk_rows(model, self.chunk_size)

@@ -321,3 +321,26 @@ def test_native_decoder_follows_the_engine_policy_host_logic():
     assert m.native_decoder().on_overflow == "bf16"
     m._precision = "f16_stream"
     assert m.native_decoder().on_overflow == "raise"
+
+
+def test_env_pass1_precision_lands_on_the_policy_the_model_kind_takes(monkeypatch):
+    """GRIT_PASS1_PRECISION is a process-wide default: 'f16_stream' on a sparse-MoE engine (which routes on the fp32 stream and refuses it)
+    lands on 'f16_operands' with a line on stdout; the same value as an explicit argument is refused as it stands."""
+    from types import SimpleNamespace
+    from gritlm_amd._lib import GritHipError
+    from gritlm_amd.training.gradcache import GradCacheStep
+
+    class _MoeEngine:
+        nograd_precision = "bf16"
+
+        def set_nograd_precision(self, p):
+            if p == "f16_stream":
+                raise GritHipError("the sparse-MoE block routes on the fp32 residual stream")
+            self.nograd_precision = p
+    m = SimpleNamespace(train_engine=_MoeEngine())
+    monkeypatch.setenv("GRIT_PASS1_PRECISION", "f16_stream")
+    assert GradCacheStep(m, 2, pass1_chunk_size=2).precision == "f16_operands"
+    with pytest.raises(GritHipError):
+        GradCacheStep(m, 2, pass1_chunk_size=2, precision="f16_stream")
+    monkeypatch.setenv("GRIT_PASS1_PRECISION", "bf16")
+    assert GradCacheStep(m, 2, pass1_chunk_size=2).precision == "bf16"
