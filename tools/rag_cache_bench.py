@@ -121,6 +121,19 @@ if m.engine is not None:
         return [((layers[li].keys if layers is not None else c[li][0])[j:j + 1], (layers[li].values if layers is not None else c[li][1])[j:j + 1])
                 for li in range(hc.num_hidden_layers)]
 
+    def decode_ms_per_token(kv):
+        """Decode-only rate: the slope between a run of n and a run of 4 n new tokens on the same prefix (prompt, cache copy and launch
+        set-up cancel); the MEDIAN of three such pairs -- one host-side hiccup in one run (seen: +35 ms) otherwise moves the figure by 3 %."""
+        slopes = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            dec.generate(q_ids[:1], a.new_tokens, past_key_values=kv)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            dec.generate(q_ids[:1], 4 * a.new_tokens, past_key_values=kv)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            slopes.append(((t2 - t1) - (t1 - t0)) / (3 * a.new_tokens) * 1e3)
+        return sorted(slopes)[1], slopes
+
     dec.generate(q_ids[:1], 4, past_key_values=slices(0))            # warm-up (allocations, kernel load)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -130,11 +143,7 @@ if m.engine is not None:
             first = toks[0]
     torch.cuda.synchronize()
     t_nat = time.perf_counter() - t0
-    # decode-only rate: a longer run amortises the prompt and the cache copy
-    t0 = time.perf_counter()
-    dec.generate(q_ids[:1], 4 * a.new_tokens, past_key_values=slices(0))
-    torch.cuda.synchronize()
-    t_long = time.perf_counter() - t0
+    ms_bf16, ms_bf16_runs = decode_ms_per_token(slices(0))
     # PARITY of the decode path (VERDICT r04 #2c): TEACHER-FORCED next-token logits of the native decoder against the reference-equivalent
     # module IN FP32 (the same weights widened, exact) on the SAME cached passage KV and the same query prefix, at several prefix lengths.
     # Random-init weights give nearly flat logits, so greedy-token identity says nothing (a 2 % match is the expected outcome of two
@@ -192,14 +201,9 @@ if m.engine is not None:
                     pk[str(k)] = cmp(nl[0, 0].float(), ref16[k - 1])
                 assert dec.last_precision == "f16", dec.last_precision
                 dec.generate(q_ids[:1], 4, past_key_values=kv16)
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                dec.generate(q_ids[:1], a.new_tokens, past_key_values=kv16)
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-                dec.generate(q_ids[:1], 4 * a.new_tokens, past_key_values=kv16)
-                torch.cuda.synchronize(); t2 = time.perf_counter()
-                ms = ((t2 - t1) - (t1 - t0)) / (3 * a.new_tokens) * 1e3
+                ms, ms_runs = decode_ms_per_token(kv16)
                 f16_flow[pol] = {"decode_native_vs_fp32": pk, "max_one_minus_cos": max(v["one_minus_cos"] for v in pk.values()),
-                                 "max_rel_l2": max(v["rel_l2"] for v in pk.values()), "decode_ms_per_token": ms,
+                                 "max_rel_l2": max(v["rel_l2"] for v in pk.values()), "decode_ms_per_token": ms, "decode_ms_per_token_runs": ms_runs,
                                  "decode_frac_of_weight_streaming_roofline": sum(p.numel() for p in lm.parameters()) * 2 / 8e12 * 1e3 / ms,
                                  "encode_max_one_minus_cos": enc_parity[pol]["max_one_minus_cos"], "kv_cache_dtype": enc_parity[pol]["cache_dtype"]}
                 del kv16
@@ -235,7 +239,7 @@ if m.engine is not None:
               "encode_get_cache_by_policy": enc_parity, "f16_flow": f16_flow}
     native = {"generate_s_per_query": t_nat / a.queries, "parity": parity,
               "tokens_per_s_incl_prompt_and_cache_copy": a.new_tokens * a.queries / t_nat,
-              "decode_ms_per_token": (t_long - t_nat / a.queries) / (3 * a.new_tokens) * 1e3,
+              "decode_ms_per_token": ms_bf16, "decode_ms_per_token_runs": ms_bf16_runs,
               "hbm_roofline_ms_per_token": sum(p.numel() for p in lm.parameters()) * 2 / 8e12 * 1e3}
 tokens = a.passages * a.seq
 kv_gb = sum(sum(x.numel() * x.element_size() for x in ((l.keys, l.values) if hasattr(l, "keys") else l)) for c in caches
