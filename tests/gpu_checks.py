@@ -2771,13 +2771,13 @@ def check_attn_decode_f16(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
 
 def check_argmax_f32(B=3, V=32003):
     lg = torch.from_numpy(np.random.default_rng(311).standard_normal((B, (V + 7) // 8 * 8)).astype(np.float32)).to(DEV)[:, :V]
-    lg[0, 17] = lg[0, 4000] = 9.0                 # a tie: the lower index wins
+    lg[0, 17] = lg[0, V // 2 + 3] = 9.0           # a tie: the lower index wins
     lg[1, V - 1] = 11.0                           # the tail beyond the last full chunk of 8
-    nxt = torch.zeros((B,), dtype=torch.int64, device=DEV); lens = torch.tensor([5, 6, 7][:B], dtype=torch.int32, device=DEV)
+    nxt = torch.zeros((B,), dtype=torch.int64, device=DEV); lens = torch.arange(5, 5 + B, dtype=torch.int32, device=DEV)
     hist = torch.zeros((B, 4), dtype=torch.int64, device=DEV); step = torch.tensor([2], dtype=torch.int32, device=DEV)
     ops.argmax_advance(lg, nxt, lens, hist, step)
     ref = lg.argmax(dim=1); ref[0] = 17
-    ok = bool(torch.equal(nxt, ref)) and lens.tolist() == [6, 7, 8][:B] and bool(torch.equal(hist[:, 2], ref)) and int(step) == 3
+    ok = bool(torch.equal(nxt, ref)) and lens.tolist() == list(range(6, 6 + B)) and bool(torch.equal(hist[:, 2], ref)) and int(step) == 3
     return _res("argmax_advance on fp32 logits (ties, tail, history, lens)", ok)
 
 
@@ -4018,10 +4018,15 @@ ALL_CHECKS = [
     ("gemv_f16_7b", check_gemv_f16, dict(N=6144, K=4096)),
     ("attn_decode_f16", check_attn_decode_f16, {}),
     ("attn_decode_f16_gqa4_b1", check_attn_decode_f16, dict(B=1, nq=32, nkv=8, Lmax=2304, lens=(2100,))),
+    ("attn_decode_f16_mha", check_attn_decode_f16, dict(B=2, nq=4, nkv=4, Lmax=512, lens=(300, 64))),              # one query head per kv head: the non-per-head launch
+    ("attn_decode_f16_gqa8", check_attn_decode_f16, dict(B=1, nq=16, nkv=2, Lmax=512, lens=(511,))),               # 8 query heads per kv head; the last slot of the cache
+    ("attn_decode_f16_long", check_attn_decode_f16, dict(B=1, nq=8, nkv=2, Lmax=8192, lens=(8000,))),              # 126 splits: the combine's tail loop beyond 64 splits
     ("argmax_f32", check_argmax_f32, {}),
+    ("argmax_f32_b8", check_argmax_f32, dict(B=8, V=1001)),
     ("native_generate_f16", check_native_generate_f16, {}),
     ("native_generate_f16_stream_gqa", check_native_generate_f16, dict(cfg_name="gqa", P=9, new=6, rows=3, policy="f16_stream")),
     ("native_generate_f16_7b_layer_shape", check_native_generate_f16, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
+    ("native_generate_f16_rows8", check_native_generate_f16, dict(cfg_name="tiny", P=5, new=4, rows=8)),          # the 8-row instantiations of every GEMV form
     ("wgrad_accumulation_drift", check_wgrad_accumulation_drift, {}),
     ("knn_topk", check_knn_topk, {}),
     ("knn_topk_transposed_big", check_knn_topk, dict(Q=3, N=300000, H=128, k=100, transposed=True)),
