@@ -281,8 +281,6 @@ class MistralTrainEngine:
         """The no-grad forward under an fp16-operand policy: the encoder engine's data flow (gritlm_amd/encoder.py) on this engine's packed
         parameters.  Returns last_hidden_state rows [T,H] bf16 (the pooling kernels' input; one rounding of the final RMSNorm)."""
         c, pol = self.cfg, self.nograd_precision
-        if geom.causal:
-            raise GritHipError(f"nograd_precision='{pol}' is built for the bidirectional embedding pass only")
         nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
         T = geom.T
         t = self._rope.get((S, "f32"))
@@ -304,10 +302,10 @@ class MistralTrainEngine:
             ops.rmsnorm(h, L.ln1.data, eps, out=x)
             if geom.packed:
                 ops.gemm_nt_rope(x, w16[0], cos, sin, (nq + nkv) * d, positions=geom.pos, out=qkv)
-                ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx)
+                ops.attn_bidir_varlen(qkv, geom.cu, geom.max_len, nq, nkv, d, out=ctx, causal=geom.causal, window=geom.window)
             else:
                 ops.gemm_nt_rope(x, w16[0], cos, sin, (nq + nkv) * d, S=S, out=qkv)
-                ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx)
+                ops.attn_bidir(qkv, geom.bits, B, S, nq, nkv, d, out=ctx, causal=geom.causal, window=geom.window)
             ops.gemm_nt(ctx, w16[1], out=h, epilogue=epi, residual=h)
             ops.rmsnorm(h, L.ln2.data, eps, out=x)
             self._mlp_fwd_f16(li, L, x, h, ws, w16)
@@ -427,7 +425,7 @@ class MistralTrainEngine:
         H, I = c.hidden_size, c.intermediate_size
         saved = SavedForward()
         saved.ids, saved.mask, saved.geom, saved.B, saved.S, saved.layers = ids, mask, geom, B, S, []
-        if not save and not causal and self.nograd_precision in F16_POLICIES and self._router_log is None:
+        if not save and self.nograd_precision in F16_POLICIES and self._router_log is None:
             xf = self._forward_nograd_f16(ids, geom, B, S)
             return (xf if geom.packed else xf.view(B, S, H)), saved
         cos, sin = self._rope_tables(S)
@@ -454,9 +452,10 @@ class MistralTrainEngine:
         return (xf if geom.packed else xf.view(B, S, H)), saved
 
     def forward_pooled(self, input_ids, attention_mask, method: str, normalize: bool, instr_len=None, save: bool = False,
-                       packed: bool = True):
-        """reps [B,H] fp32 = normalise(pool(encoder(ids))) (gritlm/training/model.py:134-165) + what backward_pooled needs."""
-        hidden, saved = self.forward(input_ids, attention_mask, save=save, packed=packed)
+                       packed: bool = True, causal: bool = False):
+        """reps [B,H] fp32 = normalise(pool(encoder(ids))) (gritlm/training/model.py:134-165) + what backward_pooled needs.  ``causal``: the
+        'cc' embedding attention of the reference's attn string (the stock forward without ``is_causal=False``, :146-148)."""
+        hidden, saved = self.forward(input_ids, attention_mask, save=save, packed=packed, causal=causal)
         inv = torch.empty((saved.B,), dtype=F32, device=self.device)
         if saved.geom.packed:
             reps = ops.pool_norm_varlen(hidden, saved.geom.cu, method, normalize, instr_len, inv_norm=inv)

@@ -159,7 +159,7 @@ class _NativeEncodeFn(torch.autograd.Function):
         eng = model.train_engine
         grad = bool(want_grad)
         reps, state = eng.forward_pooled(input_ids, attention_mask, model.pooling_method, bool(model.normalized), instr_len, save=grad,
-                                         packed=getattr(model, "native_packed", True))
+                                         packed=getattr(model, "native_packed", True), causal=model.attn[:2] == "cc")
         if grad:
             ctx.model, ctx.state = model, state
         return reps
@@ -229,8 +229,10 @@ class GritLMTrainModel(GritLM):
         dev = torch.device(device if device is not None else self.device)
         cfg = self.model.config
         mtype = getattr(cfg, "model_type", "")
-        if not (dev.type == "cuda" and mtype in ("mistral", "mixtral") and self.attn[:2] == "bb" and self.model.dtype == torch.bfloat16):
-            raise RuntimeError(f"native training engine needs a bf16 Mistral / Mixtral on a HIP device with 'bb' attention "
+        # ('bb..': the bidirectional embedding attention of GritLM; 'cc..': causal embedding attention, e.g. lasttoken / weightedmean models
+        #  -- round 6: the engine's causal attention forward / backward serve the embedding tower as they serve the generative branch)
+        if not (dev.type == "cuda" and mtype in ("mistral", "mixtral") and self.attn[:2] in ("bb", "cc") and self.model.dtype == torch.bfloat16):
+            raise RuntimeError(f"native training engine needs a bf16 Mistral / Mixtral on a HIP device with 'bb' or 'cc' embedding attention "
                                f"(got device={dev}, model_type={getattr(cfg, 'model_type', None)}, attn={self.attn}, dtype={self.model.dtype})")
         self.model.to(dev)
         # a causal-LM wrapper (mode unified / generative) also hands its lm_head to the engine: generative branch on HIP kernels

@@ -109,7 +109,7 @@ def main(argv=None):
                              attn_implementation=model_args.attn_implementation, torch_dtype=dtype, device=device)
     model.model.to(device)
     model.model.train()
-    if use_cuda and dtype == torch.bfloat16 and getattr(model.model.config, "model_type", "") in ("mistral", "mixtral") and model_args.attn[:2] == "bb":
+    if use_cuda and dtype == torch.bfloat16 and getattr(model.model.config, "model_type", "") in ("mistral", "mixtral") and model_args.attn[:2] in ("bb", "cc"):
         model.enable_native(device).cache_transposed_weights = True      # invalidated by weights_updated() after every step
         logger.info("native MI355X engine bound to %s", model_args.model_name_or_path)
     if args.gradient_checkpointing:

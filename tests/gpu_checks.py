@@ -1848,6 +1848,73 @@ def check_train_step(mode="direct"):
     return _res(f"native train step [{mode}] vs reference loss+grads", ok, **out)
 
 
+def check_train_causal_embedding(pooling="weightedmean"):
+    """'cc' embedding attention (the reference's attn='cccc' / 'cc': the stock causal forward, gritlm/training/model.py:146-148 without
+    ``is_causal=False``) on the native training engine -- round 6 -- against the SAME model class on its Hugging Face path in fp32 (the
+    reference's own steps on the stock module, autograd): representations, loss, every parameter's gradient, for the direct step and for
+    GradCache with a bf16 and an fp16 pass 1 (the fp16 one must land closer to the fp32 loss)."""
+    import tempfile
+    from gritlm_amd.training import GradCacheStep, GritLMTrainModel
+    cfg = synth.CONFIGS["tiny"]
+    qi, qm = synth.make_batch(cfg, 4, 24, seed=71, min_len=6)
+    pi, pm = synth.make_batch(cfg, 8, 40, seed=72, min_len=9)
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        d32 = synth.build_mistral_dir(os.path.join(td, "m32"), "tiny", 0, "float32")
+        mk = lambda d, dt: GritLMTrainModel(model_name_or_path=d, mode="embedding", pooling_method=pooling, normalized=True, attn="cccc",
+                                            temperature=0.02, negatives_cross_device=False, device="cuda", torch_dtype=dt)
+        feats = lambda: ({"input_ids": torch.from_numpy(qi).to(DEV), "attention_mask": torch.from_numpy(qm).to(DEV)},
+                         {"input_ids": torch.from_numpy(pi).to(DEV), "attention_mask": torch.from_numpy(pm).to(DEV)})
+        ref = mk(d32, torch.float32)
+        ref.model.to(DEV)
+        q, p = feats()
+        o = ref(query=q, passage=p)
+        o.loss.backward()
+        ref_g = {n: f32(t.grad) for n, t in ref._backbone().named_parameters()}
+        ref_loss, ref_q, ref_p = float(o.loss.detach()), f32(o.q_reps), f32(o.p_reps)
+        # and the bidirectional forward of the same weights must NOT match: the check would pass vacuously if 'cc' were ignored
+        m = mk(d16, torch.bfloat16)
+        m.enable_native()
+        q, p = feats()
+        o2 = m(query=q, passage=p)
+        o2.loss.backward()
+        omc = lambda a, b: float(np.max(1 - np.sum(a * b, axis=1)))
+        out["q_reps_1-cos"], out["p_reps_1-cos"] = omc(f32(o2.q_reps), ref_q), omc(f32(o2.p_reps), ref_p)
+        out["loss_ref_fp32"], out["loss_direct"] = ref_loss, float(o2.loss.detach())
+        sd = dict(m._backbone().named_parameters())
+
+        def grads_vs_ref(tag):
+            worst_rel, worst_cos = 0.0, 1.0
+            for n, g0 in ref_g.items():
+                got = f32(sd[n].grad)
+                worst_rel = max(worst_rel, float(np.linalg.norm(got - g0) / (np.linalg.norm(g0) + 1e-20)))
+                worst_cos = min(worst_cos, float(np.sum(got * g0) / (np.linalg.norm(got) * np.linalg.norm(g0) + 1e-20)))
+            out[f"grad_rel_l2_worst[{tag}]"], out[f"grad_cos_min[{tag}]"] = worst_rel, worst_cos
+            return worst_rel < 0.04 and worst_cos > 0.999            # (measured 1.4e-2 / 0.9999)
+        ok &= out["q_reps_1-cos"] < 1e-4 and out["p_reps_1-cos"] < 1e-4 and abs(out["loss_direct"] - ref_loss) < 2e-2 and grads_vs_ref("direct")
+        m.attn = "bbcc"
+        with torch.no_grad():
+            q, p = feats()
+            out["bidirectional_q_reps_1-cos"] = omc(f32(m.encode(q)), ref_q)
+        m.attn = "cccc"
+        ok &= out["bidirectional_q_reps_1-cos"] > 20 * out["q_reps_1-cos"]
+        for pol in ("bf16", "f16_operands"):
+            for t in sd.values():
+                t.grad = None
+            m.train_engine.prepare_grads() if hasattr(m.train_engine, "prepare_grads") else None
+            q, p = feats()
+            step = GradCacheStep(m, chunk_size=2, precision=pol)
+            loss = float(step(q, p))
+            out[f"loss_gradcache[{pol}]"] = loss
+            ok &= grads_vs_ref(f"gradcache_{pol}") and abs(loss - ref_loss) < 2e-2
+            if pol != "bf16":
+                out["reps_1-cos_f16_pass1"] = max(omc(f32(step.last_reps[0]), ref_q), omc(f32(step.last_reps[1]), ref_p)) if getattr(step, "last_reps", None) else -1.0
+        ok &= abs(out["loss_gradcache[f16_operands]"] - ref_loss) <= abs(out["loss_gradcache[bf16]"] - ref_loss) + 1e-4
+        ok &= 0 <= out["reps_1-cos_f16_pass1"] < 2e-5
+    return _res(f"'cc' embedding attention on the native training engine [{pooling}] vs the stock module in fp32", bool(ok), **out)
+
+
 def check_train_step_7b_layer():
     """One contrastive step at the TRUE 7B layer shape (H 4096, 32/8 heads, I 14336, one layer; every dgrad/wgrad GEMM at the bench's
     N and K) vs the reference's direct forward + backward in fp32 (tests/golden/train_7b-l1.npz, from GritLMTrainModel.forward).
@@ -4027,6 +4094,8 @@ ALL_CHECKS = [
     ("native_generate_f16_stream_gqa", check_native_generate_f16, dict(cfg_name="gqa", P=9, new=6, rows=3, policy="f16_stream")),
     ("native_generate_f16_7b_layer_shape", check_native_generate_f16, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
     ("native_generate_f16_rows8", check_native_generate_f16, dict(cfg_name="tiny", P=5, new=4, rows=8)),          # the 8-row instantiations of every GEMV form
+    ("train_causal_embedding_weightedmean", check_train_causal_embedding, {}),
+    ("train_causal_embedding_lasttoken", check_train_causal_embedding, dict(pooling="lasttoken")),
     ("wgrad_accumulation_drift", check_wgrad_accumulation_drift, {}),
     ("knn_topk", check_knn_topk, {}),
     ("knn_topk_transposed_big", check_knn_topk, dict(Q=3, N=300000, H=128, k=100, transposed=True)),
