@@ -7,12 +7,14 @@ pooling_method, normalized, attn, embed_eos, num_gpus, embedding_attr``, error b
 (``ValueError`` for mixed attention strings, ``NotImplementedError`` for unknown pooling methods).
 
 What runs where:
-  * CUDA(HIP) device + Mistral backbone in bf16 + bidirectional attention ('bb..'): tokenise on the host,
-    then ``MistralEncoderEngine`` (HIP kernels through the C ABI) + fused pool/normalise kernel.
-    A missing ``libgritlm_hip.so`` raises -- there is no silent fallback on this path.
-  * anything else (CPU plumbing config "SGPT-125M weightedmean", non-Mistral backbones, causal 'cc'
-    embedding, ``get_cache=True``): the Hugging Face module computes the hidden states exactly as in the
-    reference; pooling still uses the HIP kernel when the hidden states are bf16 on the GPU.
+  * CUDA(HIP) device + Mistral / Mixtral backbone in bf16 + 'bb..' (bidirectional) or 'cc..' (causal) embedding attention: tokenise
+    on the host, then ``MistralEncoderEngine`` (HIP kernels through the C ABI) + fused pool/normalise kernel, under the precision
+    policy of ``precision=`` (``get_cache=True`` included: the engine emits the per-layer K/V).  A missing ``libgritlm_hip.so``
+    raises -- there is no silent fallback on this path.  (With a ``projection`` head the engine computes the hidden states; the
+    Linear and the pooling after it are the reference's torch ops.)
+  * anything else (CPU plumbing config "SGPT-125M weightedmean", non-Mistral backbones, other dtypes): the Hugging Face module
+    computes the hidden states exactly as in the reference; pooling still uses the HIP kernel when the hidden states are bf16 on
+    the GPU.
 """
 from __future__ import annotations
 
