@@ -28,6 +28,12 @@ __device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
   f[0] = lo16_op<F16>(v.x); f[1] = hi16_op<F16>(v.x); f[2] = lo16_op<F16>(v.y); f[3] = hi16_op<F16>(v.y);
   f[4] = lo16_op<F16>(v.z); f[5] = hi16_op<F16>(v.z); f[6] = lo16_op<F16>(v.w); f[7] = hi16_op<F16>(v.w);
 }
+// two fp32 values -> one 32-bit word of the operand format, RNE: the bit-trick bf16 pack every RoPE kernel of the library uses, or fp16
+template <bool F16>
+__device__ __forceinline__ uint32_t pack2_rne(float lo, float hi) {
+  if constexpr (F16) return pack2h_hw(lo, hi);
+  else return pack2bf(lo, hi);
+}
 // one fp32 value -> the 16 bits of its fp16 rounding (RNE; beyond 65504: inf, reported by the caller)
 __device__ __forceinline__ uint16_t f2h_bits(float f) { return (uint16_t)(pack2h_hw(f, 0.f) & 0xffffu); }
 
@@ -164,6 +170,27 @@ __global__ void __launch_bounds__(64 * WV) gemv_bf16_k(const uint16_t* __restric
       if (PRENORM == 2 || F16) {
         float xs[8];
         xload(b, c, xs);
+        if constexpr (F16) {
+          // The fp16-operand forms PIN their contraction (one product, then an fma chain): left to the compiler, the NB = 1 / 4 and the
+          // NB = 2 / 8 instantiations of the deferred-norm form contracted differently and a row's bits depended on how many rows shared
+          // the launch (tools/gemv_rows_probe.py) -- the prompt chunk (8 rows per launch) must reproduce the token-by-token prompt.
+#pragma clang fp contract(off)
+          if (PRENORM == 2) {
+            const float lf[8] = {bflo(lw.x), bfhi(lw.x), bflo(lw.y), bfhi(lw.y), bflo(lw.z), bfhi(lw.z), bflo(lw.w), bfhi(lw.w)};   // (norm weights stay bf16)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssq[b] = __builtin_fmaf(xs[e], xs[e], ssq[b]); xs[e] = xs[e] * lf[e]; }
+          }
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            float wf[8];
+            unpack8<true>(wv[i], wf);
+            float t = wf[0] * xs[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) t = __builtin_fmaf(wf[e], xs[e], t);
+            acc[i][b] = acc[i][b] + t;
+          }
+          continue;
+        }
         if (PRENORM == 2) {
           const float lf[8] = {bflo(lw.x), bfhi(lw.x), bflo(lw.y), bfhi(lw.y), bflo(lw.z), bfhi(lw.z), bflo(lw.w), bfhi(lw.w)};   // (norm weights stay bf16)
 #pragma unroll
@@ -268,43 +295,72 @@ __global__ void __launch_bounds__(64 * WV) gemv_bf16_k(const uint16_t* __restric
 
 // ---- RoPE of the new token's q, k (at position lens[b]) + append of its k, v to the cache, one launch.
 //      qkv [B, qkv_stride] (q rotated in place), cache [B, nkv, Lmax, d], tables [Lmax, d/2] fp32 (rounded like the encoder's).
+//      cache_row (nullable): row b of qkv belongs to sequence cache_row[b] of the cache -- several rows may be consecutive tokens of ONE
+//      sequence (a prompt chunk on top of a cached prefix: lens[b] = prefix + its index in the chunk).
+//      F16: the row is fp32 (q is rotated in place without a rounding), k (rotated) and v are rounded to fp16 once, into fp16 caches.
+template <bool F16 = false>
 __global__ void __launch_bounds__(256) rope_kv_append_k(uint16_t* __restrict__ qkv, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
-                                                        uint16_t* __restrict__ ck, uint16_t* __restrict__ cv, const int32_t* __restrict__ lens, int nq,
-                                                        int nkv, int d, int Lmax, int64_t qkv_stride) {
+                                                        uint16_t* __restrict__ ck, uint16_t* __restrict__ cv, const int32_t* __restrict__ lens,
+                                                        const int32_t* __restrict__ cache_row, int nq, int nkv, int d, int Lmax, int64_t qkv_stride,
+                                                        unsigned int* __restrict__ flag) {
   const int b = blockIdx.x;
   const int pos = lens[b];
   if (pos >= Lmax) return;
-  const int half = d >> 1, jc_n = d >> 4;               // 16-B chunks per half head
+  const int cb = cache_row ? cache_row[b] : b;
+  const int half = d >> 1, jc_n = d >> 4;               // chunks of 8 elements per half head
   uint16_t* row = qkv + (int64_t)b * qkv_stride;
+  float* rowf = reinterpret_cast<float*>(qkv) + (int64_t)b * qkv_stride;
   const int rot_items = (nq + nkv) * jc_n, cp_items = nkv * (d >> 3);
+  uint32_t bad = 0;
   for (int i = threadIdx.x; i < rot_items + cp_items; i += 256) {
     if (i < rot_items) {
       const int head = i / jc_n, jc = i - head * jc_n;
-      uint16_t* base = row + (int64_t)head * d + jc * 8;
-      const uint4 x1 = *reinterpret_cast<const uint4*>(base), x2 = *reinterpret_cast<const uint4*>(base + half);
+      const int64_t off = (int64_t)head * d + jc * 8;
       const float* ct = cos_tab + (int64_t)pos * half + jc * 8;
       const float* stb = sin_tab + (int64_t)pos * half + jc * 8;
-      const uint32_t a[4] = {x1.x, x1.y, x1.z, x1.w}, bb[4] = {x2.x, x2.y, x2.z, x2.w};
-      uint32_t o1[4], o2[4];
+      float a[8], bb[8], lo[8], hi[8];
+      if constexpr (F16) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float c0 = ct[2 * e], c1 = ct[2 * e + 1], s0 = stb[2 * e], s1 = stb[2 * e + 1];
-        const float a0 = bflo(a[e]), a1 = bfhi(a[e]), b0 = bflo(bb[e]), b1 = bfhi(bb[e]);
-        o1[e] = pack2bf(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));      // x*cos + rotate_half(x)*sin, first half: -x2 * sin
-        o2[e] = pack2bf(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));      // second half: +x1 * sin
-      }
-      const uint4 r1 = make_uint4(o1[0], o1[1], o1[2], o1[3]), r2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
-      if (head < nq) {
-        *reinterpret_cast<uint4*>(base) = r1; *reinterpret_cast<uint4*>(base + half) = r2;
+        for (int e = 0; e < 8; ++e) { a[e] = rowf[off + e]; bb[e] = rowf[off + half + e]; }
       } else {
-        uint16_t* dst = ck + (((int64_t)b * nkv + (head - nq)) * Lmax + pos) * d + jc * 8;
+        unpack8<false>(*reinterpret_cast<const uint4*>(row + off), a);
+        unpack8<false>(*reinterpret_cast<const uint4*>(row + off + half), bb);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        lo[e] = rope_lo(a[e], bb[e], ct[e], stb[e]);       // x*cos + rotate_half(x)*sin, first half: -x2 * sin
+        hi[e] = rope_hi(a[e], bb[e], ct[e], stb[e]);       // second half: +x1 * sin
+      }
+      if (F16 && head < nq) {                              // q: rotated in place, fp32
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { rowf[off + e] = lo[e]; rowf[off + half + e] = hi[e]; }
+        continue;
+      }
+      const uint4 r1 = make_uint4(pack2_rne<F16>(lo[0], lo[1]), pack2_rne<F16>(lo[2], lo[3]), pack2_rne<F16>(lo[4], lo[5]), pack2_rne<F16>(lo[6], lo[7]));
+      const uint4 r2 = make_uint4(pack2_rne<F16>(hi[0], hi[1]), pack2_rne<F16>(hi[2], hi[3]), pack2_rne<F16>(hi[4], hi[5]), pack2_rne<F16>(hi[6], hi[7]));
+      if (head < nq) {
+        *reinterpret_cast<uint4*>(row + off) = r1; *reinterpret_cast<uint4*>(row + off + half) = r2;
+      } else {
+        if constexpr (F16) bad |= h2_nonfinite(r1.x) | h2_nonfinite(r1.y) | h2_nonfinite(r1.z) | h2_nonfinite(r1.w) | h2_nonfinite(r2.x) |
+                                  h2_nonfinite(r2.y) | h2_nonfinite(r2.z) | h2_nonfinite(r2.w);
+        uint16_t* dst = ck + (((int64_t)cb * nkv + (head - nq)) * Lmax + pos) * d + jc * 8;
         *reinterpret_cast<uint4*>(dst) = r1; *reinterpret_cast<uint4*>(dst + half) = r2;
       }
     } else {
       const int j = i - rot_items, h = j / (d >> 3), c = j - h * (d >> 3);
-      const uint4 v = reinterpret_cast<const uint4*>(row + (int64_t)(nq + nkv + h) * d)[c];
-      reinterpret_cast<uint4*>(cv + (((int64_t)b * nkv + h) * Lmax + pos) * d)[c] = v;
+      uint4 v;
+      if constexpr (F16) {
+        const float* vs = rowf + (int64_t)(nq + nkv + h) * d + c * 8;
+        v = make_uint4(pack2h_hw(vs[0], vs[1]), pack2h_hw(vs[2], vs[3]), pack2h_hw(vs[4], vs[5]), pack2h_hw(vs[6], vs[7]));
+        bad |= h2_nonfinite(v.x) | h2_nonfinite(v.y) | h2_nonfinite(v.z) | h2_nonfinite(v.w);
+      } else {
+        v = reinterpret_cast<const uint4*>(row + (int64_t)(nq + nkv + h) * d)[c];
+      }
+      reinterpret_cast<uint4*>(cv + (((int64_t)cb * nkv + h) * Lmax + pos) * d)[c] = v;
     }
+  }
+  if constexpr (F16) {
+    if (bad) atomicOr(flag, 1u);
   }
 }
 
@@ -344,7 +400,7 @@ template <bool ROPE, int G, bool PH = false, bool F16 = false>
 __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__ q, uint16_t* __restrict__ ck, uint16_t* __restrict__ cv,
                                                     const int32_t* __restrict__ lens, float* __restrict__ part, const float* __restrict__ cos_tab,
                                                     const float* __restrict__ sin_tab, int nq, int nkv, int Lmax, int64_t q_stride, float scale,
-                                                    int max_splits, unsigned int* __restrict__ flag) {
+                                                    int max_splits, unsigned int* __restrict__ flag, const int32_t* __restrict__ cache_row) {
   __shared__ __attribute__((aligned(16))) float qs[G][AD_D];   // query heads of this kv head, pre-scaled
   __shared__ float ps[G][64];                                  // probabilities of the 64 keys
   __shared__ __attribute__((aligned(16))) uint16_t newk[AD_D]; // ROPE, owner workgroup: the new key (rotated) and value rows, handed to the
@@ -353,6 +409,7 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
   const int split = blockIdx.x, hk = PH ? (int)blockIdx.y / gq : (int)blockIdx.y, b = blockIdx.z;
   const int g0 = PH ? (int)blockIdx.y - hk * gq : 0;      // this workgroup's first (PH: only) head inside the group
   const int lane = threadIdx.x;
+  const int cb = cache_row ? cache_row[b] : b;   // the sequence whose cache row b attends to (several rows may be tokens of one sequence)
   const int L = lens[b] + 1;                 // keys 0 .. lens[b] (the new token was appended)
   const int k0 = split * AD_CH;
   float* pbase = part + ((((int64_t)b * nkv + hk) * max_splits + split) * gq + g0) * (AD_D + 2);
@@ -370,10 +427,10 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
   const int nk = min(64, L - k0);
   uint4 kreg[AD_D / 8], vreg[16];
   auto load_kv = [&]() {
-    const uint4* kr = reinterpret_cast<const uint4*>(ck + (((int64_t)b * nkv + hk) * Lmax + (live ? key : L - 1)) * AD_D);
+    const uint4* kr = reinterpret_cast<const uint4*>(ck + (((int64_t)cb * nkv + hk) * Lmax + (live ? key : L - 1)) * AD_D);
 #pragma unroll
     for (int c = 0; c < AD_D / 8; ++c) kreg[c] = kr[c];       // 16 independent loads in flight
-    const uint16_t* vbase = cv + (((int64_t)b * nkv + hk) * Lmax + k0) * AD_D;
+    const uint16_t* vbase = cv + (((int64_t)cb * nkv + hk) * Lmax + k0) * AD_D;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int kk = kg * 16 + j;
@@ -406,7 +463,7 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
       const int64_t ko = (int64_t)(nq + hk) * AD_D, vo = (int64_t)(nq + nkv + hk) * AD_D;
       const float y1 = qk_at(ko + lane), y2 = qk_at(ko + 64 + lane);
       const uint32_t r = F16 ? pack2h_hw(rope_lo(y1, y2, c, sn), rope_hi(y1, y2, c, sn)) : pack2bf(rope_lo(y1, y2, c, sn), rope_hi(y1, y2, c, sn));
-      uint16_t* kd = ck + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D;
+      uint16_t* kd = ck + (((int64_t)cb * nkv + hk) * Lmax + pos) * AD_D;
       kd[lane] = (uint16_t)(r & 0xffff); kd[64 + lane] = (uint16_t)(r >> 16);
       uint32_t vw;
       if constexpr (F16) {
@@ -415,7 +472,7 @@ __global__ void __launch_bounds__(64) attn_decode_k(const uint16_t* __restrict__
       } else {
         vw = reinterpret_cast<const uint32_t*>(row + vo)[lane];
       }
-      reinterpret_cast<uint32_t*>(cv + (((int64_t)b * nkv + hk) * Lmax + pos) * AD_D)[lane] = vw;
+      reinterpret_cast<uint32_t*>(cv + (((int64_t)cb * nkv + hk) * Lmax + pos) * AD_D)[lane] = vw;
       newk[lane] = (uint16_t)(r & 0xffff); newk[64 + lane] = (uint16_t)(r >> 16);
       newv[lane] = vw;
     }
@@ -708,16 +765,41 @@ extern "C" int grit_rmsnorm_gemv_bf16_deferred(const void* x, const void* ln_wei
   return gemv_entry("grit_rmsnorm_gemv_bf16_deferred", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, stream, true);
 }
 
+template <bool F16>
+static int rope_kv_append_launch(const char* name, void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v,
+                                 const int32_t* lens, const int32_t* cache_row, int B, int nq, int nkv, int d, int Lmax, int64_t qkv_stride,
+                                 void* stream) {
+  if (B == 0) return GRIT_OK;
+  GRIT_REQUIRE(qkv && cos_tab && sin_tab && cache_k && cache_v && lens, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && nq > 0 && nkv > 0 && d % 16 == 0 && Lmax > 0 && qkv_stride % 8 == 0, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(qkv_stride >= ((int64_t)nq + 2 * (int64_t)nkv) * d, GRIT_E_BADARG, "%s: qkv_stride too small", name);
+  GRIT_REQUIRE(aligned16(qkv) && aligned16(cache_k) && aligned16(cache_v), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  unsigned int* flag = F16 ? f16_flag_ptr() : nullptr;
+  if (F16 && !flag) return GRIT_E_LAUNCH;
+  hipLaunchKernelGGL(rope_kv_append_k<F16>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv, cos_tab, sin_tab, (uint16_t*)cache_k,
+                     (uint16_t*)cache_v, lens, cache_row, nq, nkv, d, Lmax, qkv_stride, flag);
+  GRIT_CHECK_LAUNCH(name);
+  return GRIT_OK;
+}
+
 extern "C" int grit_rope_kv_append(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens, int B,
                                    int nq, int nkv, int d, int Lmax, int64_t qkv_stride, void* stream) {
-  if (B == 0) return GRIT_OK;
-  GRIT_REQUIRE(qkv && cos_tab && sin_tab && cache_k && cache_v && lens, GRIT_E_BADARG, "grit_rope_kv_append: null pointer");
-  GRIT_REQUIRE(B > 0 && nq > 0 && nkv > 0 && d % 16 == 0 && Lmax > 0 && qkv_stride % 8 == 0, GRIT_E_BADARG, "grit_rope_kv_append: bad sizes");
-  GRIT_REQUIRE(aligned16(qkv) && aligned16(cache_k) && aligned16(cache_v), GRIT_E_BADARG, "grit_rope_kv_append: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(rope_kv_append_k, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv, cos_tab, sin_tab, (uint16_t*)cache_k,
-                     (uint16_t*)cache_v, lens, nq, nkv, d, Lmax, qkv_stride);
-  GRIT_CHECK_LAUNCH("grit_rope_kv_append");
-  return GRIT_OK;
+  return rope_kv_append_launch<false>("grit_rope_kv_append", qkv, cos_tab, sin_tab, cache_k, cache_v, lens, nullptr, B, nq, nkv, d, Lmax, qkv_stride,
+                                      stream);
+}
+
+// Prompt chunk on top of a cached prefix (ABI 5): V rows that are tokens of B <= V sequences -- row v belongs to sequence cache_row[v] and sits
+// at position lens[v] of it (consecutive tokens of one sequence: lens = prefix, prefix + 1, ...).  First every row's k / v is appended
+// (grit_rope_kv_append_rows), then every row attends to keys 0 .. lens[v] of ITS sequence (grit_attn_decode_rows): causal attention over
+// the prefix and the chunk without a token-by-token loop.  f16 != 0: the fp16-operand formats (fp32 q|k|v rows, fp16 caches and ctx).
+extern "C" int grit_rope_kv_append_rows(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens,
+                                        const int32_t* cache_row, int V, int nq, int nkv, int d, int Lmax, int64_t qkv_stride, int f16,
+                                        void* stream) {
+  GRIT_REQUIRE(cache_row, GRIT_E_BADARG, "grit_rope_kv_append_rows: null pointer");
+  return f16 ? rope_kv_append_launch<true>("grit_rope_kv_append_rows", qkv, cos_tab, sin_tab, cache_k, cache_v, lens, cache_row, V, nq, nkv, d, Lmax,
+                                           qkv_stride, stream)
+             : rope_kv_append_launch<false>("grit_rope_kv_append_rows", qkv, cos_tab, sin_tab, cache_k, cache_v, lens, cache_row, V, nq, nkv, d, Lmax,
+                                            qkv_stride, stream);
 }
 
 extern "C" int grit_kv_append(const void* qkv, void* cache_k, void* cache_v, const int32_t* lens, int B, int nq, int nkv, int d, int Lmax,
@@ -742,7 +824,7 @@ extern "C" int64_t grit_attn_decode_workspace_floats(int B, int nq, int nkv, int
 template <bool F16>
 static int attn_decode_launch(const char* name, const void* q, void* cache_k, void* cache_v, const int32_t* lens, void* out, float* workspace,
                               const float* cos_tab, const float* sin_tab, int B, int nq, int nkv, int d, int Lmax, int64_t q_stride,
-                              int64_t out_stride, float scale, void* stream) {
+                              int64_t out_stride, float scale, void* stream, const int32_t* cache_row = nullptr) {
   if (B == 0) return GRIT_OK;
   GRIT_REQUIRE(q && cache_k && cache_v && lens && out && workspace, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(d == AD_D, GRIT_E_UNSUPPORTED, "%s: head_dim=%d (only 128 is built)", name, d);
@@ -761,14 +843,14 @@ static int attn_decode_launch(const char* name, const void* q, void* cache_k, vo
     const dim3 gridh((unsigned)splits, (unsigned)nq, (unsigned)B);
     if (cos_tab)
       hipLaunchKernelGGL((attn_decode_k<true, 1, true, F16>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
-                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag);
+                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag, cache_row);
     else
       hipLaunchKernelGGL((attn_decode_k<false, 1, true, F16>), gridh, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace,
-                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag);
+                         cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag, cache_row);
   } else {
 #define GRIT_AD_LAUNCH(R, GG)                                                                                                           \
   hipLaunchKernelGGL((attn_decode_k<R, GG, false, F16>), grid, dim3(64), 0, st, (const uint16_t*)q, (uint16_t*)cache_k, (uint16_t*)cache_v, lens, workspace, \
-                     cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag)
+                     cos_tab, sin_tab, nq, nkv, Lmax, q_stride, scale, splits, flag, cache_row)
 #define GRIT_AD_BY_G(R)                                                                                                                 \
   switch (nq / nkv) {                                                                                                                   \
     case 1: GRIT_AD_LAUNCH(R, 1); break;                                                                                                \
@@ -792,6 +874,16 @@ extern "C" int grit_attn_decode(const void* q, const void* cache_k, const void* 
                                 int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale, void* stream) {
   return attn_decode_launch<false>("grit_attn_decode", q, (void*)cache_k, (void*)cache_v, lens, out, workspace, nullptr, nullptr, B, nq, nkv, d, Lmax,
                             q_stride, out_stride, scale, stream);
+}
+
+extern "C" int grit_attn_decode_rows(const void* q, const void* cache_k, const void* cache_v, const int32_t* lens, const int32_t* cache_row, void* out,
+                                     float* workspace, int V, int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale,
+                                     int f16, void* stream) {
+  GRIT_REQUIRE(cache_row, GRIT_E_BADARG, "grit_attn_decode_rows: null pointer");
+  return f16 ? attn_decode_launch<true>("grit_attn_decode_rows", q, (void*)cache_k, (void*)cache_v, lens, out, workspace, nullptr, nullptr, V, nq, nkv, d,
+                                        Lmax, q_stride, out_stride, scale, stream, cache_row)
+             : attn_decode_launch<false>("grit_attn_decode_rows", q, (void*)cache_k, (void*)cache_v, lens, out, workspace, nullptr, nullptr, V, nq, nkv, d,
+                                         Lmax, q_stride, out_stride, scale, stream, cache_row);
 }
 
 extern "C" int grit_attn_decode_rope(const void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens,

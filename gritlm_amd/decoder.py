@@ -55,6 +55,11 @@ class MistralDecoder:
         # None: follow the engine's policy (fp16 operands under its fp16 policies); "bf16" / "f16" pin the decode arithmetic
         self.precision = os.environ.get("GRIT_DECODE_PRECISION") or None
         self.on_overflow = "raise"                # fp16 operands, a value beyond the range: "raise" | "bf16" (repeat the call in bf16)
+        # prompt tokens on top of past_key_values: all at once through the step's kernels (same bits as one token per step; False or
+        # GRIT_DECODE_PROMPT_CHUNK=0: the token-by-token loop).  Above `prompt_chunk_max_rows` rows (the attention workspace grows with
+        # rows x splits) the loop is used.
+        self.prompt_chunk = os.environ.get("GRIT_DECODE_PROMPT_CHUNK", "1") != "0"
+        self.prompt_chunk_max_rows = 512
         self._lm_head16 = None
         self.last_precision = None                # what the last generate() call ran in ("bf16" | "f16"; "bf16 (f16 overflow)" after a fallback)
 
@@ -141,6 +146,54 @@ class MistralDecoder:
             ops.gemv(act, L.wdown, out=h, epilogue=EPI_RESIDUAL, residual=h)
         ops.rmsnorm(h, e.norm, eps, out=x)
         ops.gemv(x, self.lm_head, out=st["logits"])
+
+    # ------------------------------------------------------------------ a prompt chunk on top of the cache, all its tokens at once
+    def _prompt_rows(self, st, ids: torch.Tensor):
+        """The P prompt tokens of every sequence in ONE pass over the weights per 8 rows instead of P decode steps (round 6): the V = B P
+        rows go through the decode step's own kernels -- the GEMVs in groups of 8 rows, then every row's k / v appended at position
+        lens + i (grit_rope_kv_append_rows), then every row attending to keys 0 .. lens + i of its sequence (grit_attn_decode_rows) --
+        so the arithmetic per row is the token-by-token path's, bit for bit (tests: native_generate_prompt_chunk).  Leaves the logits after
+        the last prompt token in st["logits"] and advances lens by P.  Built for the default (deferred-norm) step and the fp16 one."""
+        c, e, dev = self.cfg, self.eng, self.device
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        f16 = st["f16"]
+        B, P = ids.shape
+        V = B * P
+        op, wide = (F16, F32) if f16 else (BF16, BF16)
+        mk = lambda n, dt: torch.empty((V, n), dtype=dt, device=dev)
+        h, qkv, ctx, act = mk(c.hidden_size, wide), mk((nq + 2 * nkv) * d, wide), mk(nq * d, op), mk(c.intermediate_size, op)
+        h16 = mk(c.hidden_size, F16) if f16 else None
+        lens_v = (st["lens"].view(B, 1) + torch.arange(P, dtype=I32, device=dev).view(1, P)).reshape(V).contiguous()
+        rows_v = torch.arange(B, dtype=I32, device=dev).repeat_interleave(P).contiguous()
+        Lmax = st["cache"][0][0].shape[2]
+        ws = ops.attn_decode_workspace(V, nq, nkv, Lmax, dev)
+        ops.embed_gather(e.embed, ids.reshape(-1).contiguous(), out=h)
+        if f16:
+            h16.copy_(h)
+        groups = [(a, min(a + 8, V)) for a in range(0, V, 8)]
+        x_in = h16 if f16 else h                       # what a norm + GEMV launch reads
+        for li, L in enumerate(e.layers):
+            wqkv, wo, wgu, wdown = e._f16_weights(L) if f16 else (L.wqkv, L.wo, L.wgu, L.wdown)
+            ck, cv = st["cache"][li]
+            for a, b in groups:
+                ops.rmsnorm_gemv(x_in[a:b], L.ln1, eps, wqkv, out=qkv[a:b], deferred=True)
+            ops.rope_kv_append_rows(qkv, st["cos"], st["sin"], ck, cv, lens_v, rows_v, nq, nkv, d)
+            ops.attn_decode_rows(qkv, ck, cv, lens_v, rows_v, ctx, ws, nq, nkv, d)
+            for a, b in groups:
+                if f16:
+                    ops.gemv(ctx[a:b], wo, out=h[a:b], epilogue=EPI_RESIDUAL, residual=h[a:b], out16=h16[a:b])
+                else:
+                    ops.gemv(ctx[a:b], wo, out=h[a:b], epilogue=EPI_RESIDUAL, residual=h[a:b])
+            for a, b in groups:
+                ops.rmsnorm_gemv(x_in[a:b], L.ln2, eps, wgu, out=act[a:b], epilogue=EPI_SWIGLU, deferred=True)
+            for a, b in groups:
+                if f16:
+                    ops.gemv(act[a:b], wdown, out=h[a:b], epilogue=EPI_RESIDUAL, residual=h[a:b], out16=h16[a:b])
+                else:
+                    ops.gemv(act[a:b], wdown, out=h[a:b], epilogue=EPI_RESIDUAL, residual=h[a:b])
+        last = x_in.view(B, P, -1)[:, P - 1].contiguous()                  # the stream of every sequence's last prompt token
+        ops.rmsnorm_gemv(last, e.norm, eps, self._lm_head_f16() if f16 else self.lm_head, out=st["logits"], deferred=True)
+        st["lens"] += P
 
     def _sample(self, st):
         ops.argmax_advance(st["logits"], st["next"], st["lens"], st["history"], st["step"])
@@ -232,11 +285,15 @@ class MistralDecoder:
             if f16 and any(k.dtype != F16 or v.dtype != F16 for k, v in past):
                 self._flag_nonfinite_cache(st, S0)        # (a bf16 / fp32 cache narrowed to fp16: values beyond 65504 became inf)
             st["lens"].copy_(torch.full((B,), S0, dtype=I32, device=dev) if past_lens is None else past_lens.to(device=dev, dtype=I32))
-            # the prompt rides on the decode path, one token per step (teacher forced): its K/V land behind the cached prefix
-            for t in range(P):
-                st["next"].copy_(ids[:, t])
-                self._step(st)
-                st["lens"] += 1
+            # the prompt rides on the decode path: all its tokens at once (_prompt_rows: the step's own kernels over B P rows), or, for the
+            # exact-norm forms and very long prompts, one token per step (teacher forced); its K/V land behind the cached prefix
+            if P > 0 and self.prompt_chunk and (f16 or self.fuse_norm == "deferred") and B * P <= self.prompt_chunk_max_rows:
+                self._prompt_rows(st, ids)
+            else:
+                for t in range(P):
+                    st["next"].copy_(ids[:, t])
+                    self._step(st)
+                    st["lens"] += 1
         # first generated token from the prefill logits, then decode steps (graph replay)
         if return_logits:
             logits_all[:, 0].copy_(st["logits"])

@@ -706,6 +706,33 @@ def attn_decode_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, ca
     return out
 
 
+def rope_kv_append_rows(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor,
+                        cache_row: torch.Tensor, nq: int, nkv: int, d: int):
+    """rope_kv_append for V rows that are tokens of the caches' B <= V sequences (row v: sequence cache_row[v], position lens[v]); fp16
+    caches: the fp16-operand formats (fp32 rows)."""
+    V = qkv.shape[0]
+    _, _, Lmax, _ = cache_k.shape
+    f16 = cache_k.dtype == F16
+    assert cos.shape[0] >= Lmax and lens.numel() == V and cache_row.numel() == V
+    check(_lib.load().grit_rope_kv_append_rows(_chk2d(qkv, F32 if f16 else BF16, "qkv"), _chk(cos, F32, "cos"), _chk(sin, F32, "sin"),
+                                               _chk(cache_k, cache_k.dtype, "cache_k"), _chk(cache_v, cache_k.dtype, "cache_v"), _chk(lens, I32, "lens"),
+                                               _chk(cache_row, I32, "cache_row"), V, nq, nkv, d, Lmax, qkv.stride(0), int(f16), _stream()),
+          "grit_rope_kv_append_rows")
+
+
+def attn_decode_rows(q: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor, lens: torch.Tensor, cache_row: torch.Tensor, out: torch.Tensor,
+                     workspace: torch.Tensor, nq: int, nkv: int, d: int, scale: float | None = None):
+    """attn_decode for V rows that are tokens of the caches' sequences: row v attends to keys 0 .. lens[v] of sequence cache_row[v]."""
+    V = q.shape[0]
+    _, _, Lmax, _ = cache_k.shape
+    f16 = cache_k.dtype == F16
+    check(_lib.load().grit_attn_decode_rows(_chk2d(q, F32 if f16 else BF16, "q"), _chk(cache_k, cache_k.dtype, "cache_k"), _chk(cache_v, cache_k.dtype, "cache_v"),
+                                            _chk(lens, I32, "lens"), _chk(cache_row, I32, "cache_row"), _chk2d(out, F16 if f16 else BF16, "out"),
+                                            _chk(workspace, F32, "workspace"), V, nq, nkv, d, Lmax, q.stride(0), out.stride(0),
+                                            float(d ** -0.5 if scale is None else scale), int(f16), _stream()), "grit_attn_decode_rows")
+    return out
+
+
 def argmax_advance(logits: torch.Tensor, next_ids: torch.Tensor, lens: torch.Tensor | None = None, history: torch.Tensor | None = None,
                    step: torch.Tensor | None = None):
     B, V = logits.shape

@@ -460,6 +460,19 @@ int grit_attn_decode_rope_f16(const void* qkv, const float* cos_tab, const float
 int grit_argmax_advance_f32(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history,
                             int64_t hist_stride, int32_t* step, int B, void* stream);
 
+/* A prompt chunk on top of a cached prefix without a token-by-token loop (ABI 5): what model.generate() does with the query tokens it is
+ * handed next to past_key_values (rag/eval.py:277-302 -- the attention mask covers the cache, the new tokens attend to it and causally to
+ * each other).  V rows are tokens of B <= V sequences: row v belongs to sequence cache_row[v] of the caches [B, nkv, Lmax, d] and sits at
+ * position lens[v] of it (consecutive tokens of one sequence: prefix, prefix + 1, ...).  grit_rope_kv_append_rows rotates q (in place) and
+ * k at position lens[v] and appends every row's k, v to its sequence's cache; grit_attn_decode_rows then lets every row attend to keys
+ * 0 .. lens[v] of its sequence.  f16 = 0: bf16 rows and caches (grit_rope_kv_append / grit_attn_decode arithmetic, bit for bit);
+ * f16 != 0: the fp16-operand formats (fp32 q|k|v rows, fp16 caches and ctx).  Workspace: grit_attn_decode_workspace_floats(V, ...). */
+int grit_rope_kv_append_rows(void* qkv, const float* cos_tab, const float* sin_tab, void* cache_k, void* cache_v, const int32_t* lens,
+                             const int32_t* cache_row, int V, int nq, int nkv, int d, int Lmax, int64_t qkv_stride, int f16, void* stream);
+int grit_attn_decode_rows(const void* q, const void* cache_k, const void* cache_v, const int32_t* lens, const int32_t* cache_row, void* out,
+                          float* workspace, int V, int nq, int nkv, int d, int Lmax, int64_t q_stride, int64_t out_stride, float scale,
+                          int f16, void* stream);
+
 /* ---- RAG index search: rag/index.py:97-104 (scores = queries @ embeddings; torch.topk) ------------------------ */
 
 /* Brute-force kNN by inner product.  queries [Q,H] fp32 (contiguous); embeddings: element (n,h) at n*emb_stride_n + h*emb_stride_h, so

@@ -2927,6 +2927,45 @@ def check_native_generate_f16(cfg_name="tiny", P=21, new=10, rows=2, policy="f16
                 clear_frac=f["clear_frac"], overflow_raised=raised, overflow_fell_back=fell)
 
 
+def check_native_generate_prompt_chunk(cfg_name="gqa", B=2, P=11, new=5, policy="bf16"):
+    """The prompt tokens handed to generate() next to past_key_values, all at once (MistralDecoder._prompt_rows: the decode step's kernels
+    over B x P rows, grit_rope_kv_append_rows + grit_attn_decode_rows) against the token-by-token loop: the SAME bits -- the logits of every
+    generated position, the tokens, and through them the K/V the chunk appended -- for sequences with different prefix lengths, row
+    counts that are not a multiple of 8, and both decode arithmetics; and against the fp32 oracle for one sequence."""
+    from gritlm_amd.decoder import MistralDecoder
+    eng, cfg, w = build_engine(cfg_name, 6)
+    eng.set_precision(policy)
+    rng = np.random.default_rng(131)
+    lm = O.bf16_round((rng.standard_normal((cfg["vocab_size"], cfg["hidden_size"])) * 0.05).astype(np.float32))
+    dec = MistralDecoder(eng, torch.from_numpy(lm))
+    doc = rng.integers(3, cfg["vocab_size"], size=(B, 70)).astype(np.int64)
+    plens = np.array([70, 41, 55, 70][:B], dtype=np.int32)
+    dmask = (np.arange(70)[None] < plens[:, None]).astype(np.int64)
+    _, kv = eng.forward(torch.from_numpy(doc).to(DEV), torch.from_numpy(dmask).to(DEV), return_kv=True, kv_dtype=None)
+    prompt = torch.from_numpy(rng.integers(3, cfg["vocab_size"], size=(B, P)).astype(np.int64)).to(DEV)
+    pl = torch.from_numpy(plens).to(DEV)
+    out, ok = {}, True
+    res = {}
+    for chunk in (True, False):
+        dec.prompt_chunk = chunk
+        toks, lg = dec.generate(prompt, new, past_key_values=kv, past_lens=pl, return_logits=True)
+        dec.use_graph = True
+        toks_g = dec.generate(prompt, new, past_key_values=kv, past_lens=pl)
+        res[chunk] = (toks, lg, toks_g)
+    out["logits_identical"] = bool(torch.equal(res[True][1], res[False][1]))
+    out["tokens_identical"] = bool(torch.equal(res[True][0], res[False][0])) and bool(torch.equal(res[True][2], res[False][2])) \
+        and bool(torch.equal(res[True][0], res[True][2]))
+    ok &= out["logits_identical"] and out["tokens_identical"] and dec.last_precision == ("bf16" if policy == "bf16" else "f16")
+    # one sequence against the fp32 oracle (its own fp32 document K/V): the chunk path is a correct continuation, not merely a consistent one
+    _, kv_ref = O.mistral_encode(w, cfg, doc[:1], dmask[:1], return_layers="kv")
+    seq = np.concatenate([prompt[0].cpu().numpy(), res[True][0][0].cpu().numpy()])
+    ref = O.mistral_continue(w, cfg, kv_ref, int(plens[0]), seq, lm)[P - 1:P - 1 + new].astype(np.float64)
+    got = f32(res[True][1])[0].astype(np.float64)
+    out["1-cos_vs_fp32_oracle"] = float(np.max(1.0 - np.sum(got * ref, axis=-1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(ref, axis=-1))))
+    ok &= out["1-cos_vs_fp32_oracle"] < (2e-4 if policy == "bf16" else 1e-5)
+    return _res(f"prompt chunk on cached K/V == token-by-token prompt [{cfg_name}, B={B}, P={P}, {policy}]", bool(ok), **out)
+
+
 def check_knn_topk(Q=5, N=10000, H=256, k=10, transposed=False):
     """Index search (rag/index.py:97-104: queries @ embeddings, torch.topk) on the f32-MFMA similarity GEMM + chunked bitonic top-k vs
     numpy: same neighbours (scores compared; indices wherever the score has no tie), descending order, both index layouts."""
@@ -4094,6 +4133,10 @@ ALL_CHECKS = [
     ("native_generate_f16_stream_gqa", check_native_generate_f16, dict(cfg_name="gqa", P=9, new=6, rows=3, policy="f16_stream")),
     ("native_generate_f16_7b_layer_shape", check_native_generate_f16, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
     ("native_generate_f16_rows8", check_native_generate_f16, dict(cfg_name="tiny", P=5, new=4, rows=8)),          # the 8-row instantiations of every GEMV form
+    ("native_generate_prompt_chunk", check_native_generate_prompt_chunk, {}),
+    ("native_generate_prompt_chunk_f16", check_native_generate_prompt_chunk, dict(policy="f16_stream")),
+    ("native_generate_prompt_chunk_b1_p37", check_native_generate_prompt_chunk, dict(cfg_name="tiny", B=1, P=37, new=3)),
+    ("native_generate_prompt_chunk_7b_layer_shape_f16", check_native_generate_prompt_chunk, dict(cfg_name="7b-l2s", B=1, P=9, new=3, policy="f16_operands")),
     ("train_causal_embedding_weightedmean", check_train_causal_embedding, {}),
     ("train_causal_embedding_lasttoken", check_train_causal_embedding, dict(pooling="lasttoken")),
     ("wgrad_accumulation_drift", check_wgrad_accumulation_drift, {}),
