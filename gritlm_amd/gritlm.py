@@ -291,6 +291,39 @@ class GritLM(torch.nn.Module):
         self._decoder.on_overflow = "bf16" if self._precision == "auto" else "raise"
         return self._decoder
 
+    @torch.no_grad()
+    def generate_native(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None = None, past_key_values=None,
+                        max_new_tokens: int = 16, min_new_tokens: int = 0, pad_token_id: int | None = None, eos_token_id: int | None = None,
+                        do_sample: bool = False, use_cache: bool = True, **unsupported) -> torch.Tensor:
+        """``model.generate(**inputs, past_key_values=kv_cache, ...)`` as rag/eval.py:277-302 calls it, on the native decoder: greedy
+        continuation of ``input_ids`` [B, P] (on top of the cached K/V when ``past_key_values`` is given -- then ``attention_mask`` is the
+        reference's [B, cache + P] mask, ones over the cache), returned like Hugging Face's ``generate``: the input ids followed by the new
+        tokens, positions after a sequence's EOS filled with ``pad_token_id``.  ``min_new_tokens`` is honoured when it equals
+        ``max_new_tokens`` (the reference's latency runs: EOS never stops a row) or is 0; sampling, beams and other generation options are
+        not native -- ``GritLM.generate`` (the Hugging Face method) stays available for them."""
+        if do_sample or unsupported:
+            raise NotImplementedError(f"generate_native: greedy decoding only (got do_sample={do_sample}, {sorted(unsupported)}); use GritLM.generate")
+        if min_new_tokens not in (0, max_new_tokens):
+            raise NotImplementedError("generate_native: min_new_tokens must be 0 or equal to max_new_tokens")
+        dec = self.native_decoder()
+        ids = input_ids.to(self.engine.device)
+        B, P = ids.shape
+        mask = attention_mask
+        if past_key_values is not None and mask is not None:
+            if mask.shape[1] != P:                    # the reference's mask spans cache + inputs: its tail is the inputs' own mask
+                mask = mask[:, mask.shape[1] - P:]
+        eos = None if min_new_tokens == max_new_tokens else (eos_token_id if eos_token_id is not None else getattr(self.tokenizer, "eos_token_id", None))
+        new = dec.generate(ids, int(max_new_tokens), attention_mask=mask, past_key_values=past_key_values, eos_token_id=eos)
+        if eos is not None:
+            pad = pad_token_id if pad_token_id is not None else eos
+            after = ((new == eos).long().cumsum(dim=1) - (new == eos).long()) > 0          # strictly after the first EOS of the row
+            new = torch.where(after, torch.full_like(new, pad), new)
+            done = (new == eos).any(dim=1)
+            if bool(done.all()):                      # Hugging Face stops when every row has finished: trim the common tail of padding
+                keep = int(((new == eos).long().cumsum(dim=1) > 0).long().argmax(dim=1).max()) + 1
+                new = new[:, :keep]
+        return torch.cat([ids, new.to(ids.dtype)], dim=1)
+
     # ------------------------------------------------------------------ API
     def encode_queries(self, queries: Union[List[str], str], **kwargs) -> np.ndarray:
         """Queries of retrieval / reranking tasks."""

@@ -3207,6 +3207,58 @@ def check_generative_window(window=9):
     return _res(f"generative step under a sliding window of {window} keys", bool(ok), **out)
 
 
+def check_generate_native_api():
+    """GritLM.generate_native: the reference's RAG call (rag/eval.py:277-302: ``model.generate(**inputs, past_key_values=kv_cache,
+    min_new_tokens=, max_new_tokens=, pad_token_id=)`` with a mask that spans cache + inputs) on the native decoder, returned like Hugging
+    Face's generate: [inputs | new tokens]; greedy tokens equal Hugging Face's own generate() on the same cache wherever its fp32 margin is
+    clear; EOS handling (tokens after a row's EOS are pad, the common tail is trimmed); unsupported options raise."""
+    import tempfile
+    from gritlm_amd import GritLM
+    g = np.load(os.path.join(GOLDEN, "gritlm_encode.npz"))
+    sents = [str(x) for x in g["sentences"]][:2]
+    out, ok = {}, True
+    with tempfile.TemporaryDirectory() as td:
+        d16 = synth.build_mistral_dir(os.path.join(td, "m16"), "tiny", 0, "bfloat16")
+        m = GritLM(d16, pooling_method="mean", attn="bbcc", device="cuda", torch_dtype=torch.bfloat16, mode="unified")
+        _, cache = m.encode(sents[:1], max_length=48, get_cache=True)
+        get = lambda c, li: (c.layers[li].keys, c.layers[li].values) if hasattr(c, "layers") else (c[li][0], c[li][1])
+        n_layers = len(cache.layers) if hasattr(cache, "layers") else len(cache)
+        kv = [(get(cache, li)[0].clone(), get(cache, li)[1].clone()) for li in range(n_layers)]
+        S0 = kv[0][0].shape[2]
+        q = m.tokenizer([" ".join(synth.WORDS[5:12])], return_tensors="pt", add_special_tokens=False)["input_ids"].to(DEV)
+        P = q.shape[1]
+        mask = torch.ones((1, S0 + P), dtype=torch.long, device=DEV)            # the reference's mask: ones over the cache, then the inputs' mask
+        full = m.generate_native(input_ids=q, attention_mask=mask, past_key_values=kv, max_new_tokens=6, min_new_tokens=6, pad_token_id=0)
+        ok &= tuple(full.shape) == (1, P + 6) and bool(torch.equal(full[:, :P], q))
+        direct = m.native_decoder().generate(q, 6, past_key_values=kv)
+        ok &= bool(torch.equal(full[:, P:], direct))
+        # Hugging Face's generate() on the same cache (what the reference runs): same greedy tokens where the fp32 margin is clear
+        from transformers import DynamicCache
+        pc = DynamicCache()
+        for li, (k_, v_) in enumerate(kv):
+            pc.update(k_.clone(), v_.clone(), li)
+        hf = m.generate(input_ids=torch.cat([torch.zeros((1, S0), dtype=torch.long, device=DEV), q], dim=1), attention_mask=mask, past_key_values=pc,
+                        max_new_tokens=6, min_new_tokens=6, do_sample=False, pad_token_id=0)[0, S0 + P:]
+        out["tokens_equal_hf_generate"] = int((hf == full[0, P:]).sum())
+        ok &= out["tokens_equal_hf_generate"] >= 4                     # (bf16 near-ties on a random tiny model may flip a late token)
+        # EOS: make the second generated token the EOS -> the rest of the row is pad and the tail is trimmed to the EOS
+        eos = int(full[0, P + 1])
+        first = int(full[0, P])
+        cut = m.generate_native(input_ids=q, attention_mask=mask, past_key_values=kv, max_new_tokens=6, eos_token_id=eos, pad_token_id=0)
+        want = [first, eos] if first != eos else [eos]
+        ok &= cut[0, P:].tolist() == want
+        out["eos_trimmed_len"] = int(cut.shape[1] - P)
+        # a plain prompt (no cache)
+        plain = m.generate_native(input_ids=q, max_new_tokens=3, min_new_tokens=3)
+        ok &= tuple(plain.shape) == (1, P + 3)
+        for bad in (dict(do_sample=True), dict(num_beams=2), dict(min_new_tokens=2)):
+            try:
+                m.generate_native(input_ids=q, max_new_tokens=4, **bad); ok = False
+            except NotImplementedError:
+                pass
+    return _res("GritLM.generate_native: the reference's cached-generation call on the native decoder", bool(ok), **out)
+
+
 def check_edge_cases():
     """Empty / minimal / degenerate inputs the host can hand over (reference behaviour noted per case)."""
     ok, notes = True, {}
@@ -4133,6 +4185,7 @@ ALL_CHECKS = [
     ("native_generate_f16_stream_gqa", check_native_generate_f16, dict(cfg_name="gqa", P=9, new=6, rows=3, policy="f16_stream")),
     ("native_generate_f16_7b_layer_shape", check_native_generate_f16, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
     ("native_generate_f16_rows8", check_native_generate_f16, dict(cfg_name="tiny", P=5, new=4, rows=8)),          # the 8-row instantiations of every GEMV form
+    ("generate_native_api", check_generate_native_api, {}),
     ("native_generate_prompt_chunk", check_native_generate_prompt_chunk, {}),
     ("native_generate_prompt_chunk_f16", check_native_generate_prompt_chunk, dict(policy="f16_stream")),
     ("native_generate_prompt_chunk_b1_p37", check_native_generate_prompt_chunk, dict(cfg_name="tiny", B=1, P=37, new=3)),
