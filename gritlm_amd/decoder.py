@@ -300,6 +300,10 @@ class MistralDecoder:
         ops.argmax_advance(st["logits"], st["next"], None, st["history"], st["step"])
         graph = None
         for t in range(1, max_new_tokens):
+            # Hugging Face's generate() stops once every row has emitted EOS; here the host only replays a graph, so it looks every 16
+            # tokens (one small D2H) instead of after each one: at most 15 tokens of wasted steps, none of them returned
+            if eos_token_id is not None and t % 16 == 0 and bool((st["history"][:, :t] == eos_token_id).any(dim=1).all()):
+                break
             if graph is not None:
                 graph.replay()
             else:

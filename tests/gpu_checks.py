@@ -3248,6 +3248,11 @@ def check_generate_native_api():
         want = [first, eos] if first != eos else [eos]
         ok &= cut[0, P:].tolist() == want
         out["eos_trimmed_len"] = int(cut.shape[1] - P)
+        # a long budget: the decoder stops replaying once every row has emitted EOS (checked every 16 tokens); same result
+        cut40 = m.generate_native(input_ids=q, attention_mask=mask, past_key_values=kv, max_new_tokens=40, eos_token_id=eos, pad_token_id=0)
+        ok &= bool(torch.equal(cut40, cut))
+        raw = m.native_decoder().generate(q, 40, past_key_values=kv, eos_token_id=eos)
+        ok &= tuple(raw.shape) == (1, 40) and raw[0, :len(want)].tolist() == want and bool((raw[0, len(want):] == eos).all())
         # a plain prompt (no cache)
         plain = m.generate_native(input_ids=q, max_new_tokens=3, min_new_tokens=3)
         ok &= tuple(plain.shape) == (1, P + 3)
