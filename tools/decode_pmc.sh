@@ -1,12 +1,13 @@
 #!/bin/bash
 # HBM-side traffic of the decode step's kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each in its own run with --kernel-trace only):
-#   bash tools/decode_pmc.sh <tag>  ->  gpurun_out/<tag>_decode_pmc.json   (FETCH_SIZE x 2 on gfx950, KB units: the guide's HBM section)
+#   bash tools/decode_pmc.sh <tag> [decode_bench.py flags, e.g. --precision f16_stream]  ->  gpurun_out/<tag>_decode_pmc.json   (FETCH_SIZE x 2 on gfx950, KB units: the guide's HBM section)
 cd "$(dirname "$0")/.."
 TAG=${1:-r05}
+shift
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/dpmc_$c
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/dpmc_$c -o dec --output-format csv -- python tools/decode_bench.py --new 8 --no-graph > /tmp/dpmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/dpmc_$c -o dec --output-format csv -- python tools/decode_bench.py --new 8 --no-graph "$@" > /tmp/dpmc_$c.log 2>&1
 done
 python - "$TAG" <<'PY'
 import collections, csv, glob, json, sys
