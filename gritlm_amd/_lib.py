@@ -71,6 +71,8 @@ _SIGNATURES = {
     "grit_rmsnorm_gemv_f16_deferred": (_i, [_p, _p, _f, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p]),
     "grit_attn_decode_rope_f16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _p]),
     "grit_argmax_advance_f32": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _i, _p]),
+    "grit_gemv_bf16_expert": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _l, _l, _l, _i, _p]),
+    "grit_gemv_f16_expert": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _l, _l, _l, _i, _p]),
     "grit_rope_kv_append_rows": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _i, _p]),
     "grit_attn_decode_rows": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
     "grit_knn_workspace_bytes": (_l, [_i, _l, _i]),

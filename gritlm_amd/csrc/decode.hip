@@ -93,8 +93,11 @@ template <int NB, int MODE, int PRENORM, int R, bool F16 = false, int WV = 4>
 __global__ void __launch_bounds__(64 * WV) gemv_bf16_k(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W, uint16_t* __restrict__ out,
                                                    const uint16_t* __restrict__ res, const uint16_t* __restrict__ ln_w, float eps, int B, int N,
                                                    int K, int64_t ldx, int64_t ldw, int64_t ldo, int64_t ldr, unsigned int* __restrict__ flag,
-                                                   uint16_t* __restrict__ out16, int64_t ldo16) {
+                                                   uint16_t* __restrict__ out16, int64_t ldo16, const int32_t* __restrict__ widx, int64_t w_estride) {
   static_assert(!(F16 && PRENORM == 1), "the exact fused norm rounds to bf16: bf16 only");
+  // widx (nullable): W is a stack of matrices [E, N, K] and this launch multiplies by matrix widx[0] -- the expert a sparse-MoE decode step
+  // routed the row to, read from DEVICE memory so that the step stays one HIP graph
+  if (widx) W += (int64_t)widx[0] * w_estride;
   __shared__ float red[WV][R][NB];                            // WV waves per workgroup, each takes 1 / WV of K (split-K, LDS reduce)
   __shared__ float red_ss[WV][NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -658,14 +661,16 @@ using namespace grit;
 
 template <int MODE, int PRENORM, bool F16 = false, int R = (MODE == 2 ? GV_ROWS_SW : GV_ROWS)>
 static int launch_gemv(const void* x, const void* W, void* out, const void* res, const void* ln_w, float eps, int B, int N, int K, int64_t ldx,
-                       int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st, void* out16 = nullptr, int64_t ldo16 = 0) {
+                       int64_t ldw, int64_t ldo, int64_t ldr, hipStream_t st, void* out16 = nullptr, int64_t ldo16 = 0,
+                       const int32_t* widx = nullptr, int64_t w_estride = 0) {
   const int units = MODE == 2 ? (N / 2 + R / 2 - 1) / (R / 2) : (N + R - 1) / R;
   const dim3 grid((unsigned)units);
   unsigned int* flag = F16 ? f16_flag_ptr() : nullptr;
   if (F16 && !flag) return GRIT_E_LAUNCH;
 #define GRIT_GEMV_W(NB_, WV_)                                                                                                             \
   hipLaunchKernelGGL((gemv_bf16_k<NB_, MODE, PRENORM, R, F16, WV_>), grid, dim3(64 * WV_), 0, st, (const uint16_t*)x, (const uint16_t*)W,       \
-                     (uint16_t*)out, (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr, flag, (uint16_t*)out16, ldo16)
+                     (uint16_t*)out, (const uint16_t*)res, (const uint16_t*)ln_w, eps, B, N, K, ldx, ldw, ldo, ldr, flag, (uint16_t*)out16, ldo16,   \
+                     widx, w_estride)
   // GRIT_GV_WAVES_SHORT_K (A/B builds): workgroups of 8 waves where K <= 4096 (q|k|v, o_proj: every lane then covers its share of the row in
   // ONE iteration -- one memory latency instead of two -- at twice the requests in flight per workgroup); 1- and 2-row steps only.
   // Measured (profiles/r06_decode_f16_ab.log, block 4): 2.754 -> 2.747 ms per token on bf16, 2.766 -> 2.743 on fp16 operands: not the default.
@@ -756,6 +761,40 @@ extern "C" int grit_rmsnorm_gemv_f16_deferred(const void* x, const void* ln_weig
   GRIT_REQUIRE(ln_weight, GRIT_E_BADARG, "grit_rmsnorm_gemv_f16_deferred: null pointer");
   GRIT_REQUIRE(epilogue != GRIT_EPI_RESIDUAL, GRIT_E_BADARG, "grit_rmsnorm_gemv_f16_deferred: STORE or SWIGLU");
   return gemv_entry_f16("grit_rmsnorm_gemv_f16_deferred", x, W, out, ln_weight, eps, B, N, K, ldx, ldw, ldo, epilogue, nullptr, 0, nullptr, 0, stream);
+}
+
+// Sparse-MoE decode (ABI 5): x [B,K] times ONE matrix of a stack W [E,N,K] -- matrix expert[0], an index in DEVICE memory (the router's
+// choice for the row; w_expert_stride = elements between consecutive matrices) -- with the STORE or SWIGLU epilogue.  f16: the fp16-operand
+// formats of grit_gemv_f16 (STORE writes fp32, SWIGLU fp16).
+static int gemv_expert_entry(const char* name, bool f16, const void* x, const void* W, void* out, const int32_t* expert, int64_t w_expert_stride,
+                             int B, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
+  if (B == 0) return GRIT_OK;
+  GRIT_REQUIRE(x && W && out && expert, GRIT_E_BADARG, "%s: null pointer", name);
+  GRIT_REQUIRE(B > 0 && B <= 8, GRIT_E_UNSUPPORTED, "%s: B=%d rows (1..8)", name, B);
+  GRIT_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && w_expert_stride % 8 == 0 &&
+               w_expert_stride >= (int64_t)N * ldw, GRIT_E_BADARG, "%s: bad sizes", name);
+  GRIT_REQUIRE(aligned16(x) && aligned16(W), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case GRIT_EPI_STORE: GRIT_REQUIRE(ldo >= N, GRIT_E_BADARG, "%s: ldo < N", name);
+      return f16 ? launch_gemv<0, 0, true>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st, nullptr, 0, expert, w_expert_stride)
+                 : launch_gemv<0, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st, nullptr, 0, expert, w_expert_stride);
+    case GRIT_EPI_SWIGLU: GRIT_REQUIRE(N % 32 == 0 && ldo >= N / 2, GRIT_E_UNSUPPORTED, "%s: SWIGLU needs N %% 32 == 0, ldo >= N/2", name);
+      return f16 ? launch_gemv<2, 0, true>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st, nullptr, 0, expert, w_expert_stride)
+                 : launch_gemv<2, 0>(x, W, out, nullptr, nullptr, 0.f, B, N, K, ldx, ldw, ldo, 0, st, nullptr, 0, expert, w_expert_stride);
+    default: GRIT_REQUIRE(false, GRIT_E_BADARG, "%s: epilogue %d (STORE or SWIGLU)", name, epilogue);
+  }
+  return GRIT_OK;
+}
+
+extern "C" int grit_gemv_bf16_expert(const void* x, const void* W, void* out, const int32_t* expert, int64_t w_expert_stride, int B, int N, int K,
+                                     int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
+  return gemv_expert_entry("grit_gemv_bf16_expert", false, x, W, out, expert, w_expert_stride, B, N, K, ldx, ldw, ldo, epilogue, stream);
+}
+
+extern "C" int grit_gemv_f16_expert(const void* x, const void* W, void* out, const int32_t* expert, int64_t w_expert_stride, int B, int N, int K,
+                                    int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream) {
+  return gemv_expert_entry("grit_gemv_f16_expert", true, x, W, out, expert, w_expert_stride, B, N, K, ldx, ldw, ldo, epilogue, stream);
 }
 
 // the DEFERRED form of the fused norm (PRENORM 2 above): one launch, no second pass over x; x_n is not rounded to bf16

@@ -32,9 +32,8 @@ def _layers_of(cache):
 
 class MistralDecoder:
     def __init__(self, engine: MistralEncoderEngine, lm_head: torch.Tensor):
-        if engine.cfg.num_local_experts:
-            raise NotImplementedError("native decode is built for the dense (Mistral) MLP")
         self.eng, self.cfg, self.device = engine, engine.cfg, engine.device
+        self.moe = bool(engine.cfg.num_local_experts)      # sparse-MoE (Mixtral) layers: router + the two chosen experts per row (_step_moe)
         self.lm_head = lm_head.detach().to(device=self.device, dtype=BF16).contiguous()
         self.use_graph = True
         # which RMSNorms ride inside the following GEMV (grit_rmsnorm_gemv_bf16): "all" (input_layernorm -> q|k|v, post_attention_layernorm
@@ -58,7 +57,7 @@ class MistralDecoder:
         # prompt tokens on top of past_key_values: all at once through the step's kernels (same bits as one token per step; False or
         # GRIT_DECODE_PROMPT_CHUNK=0: the token-by-token loop).  Above `prompt_chunk_max_rows` rows (the attention workspace grows with
         # rows x splits) the loop is used.
-        self.prompt_chunk = os.environ.get("GRIT_DECODE_PROMPT_CHUNK", "1") != "0"
+        self.prompt_chunk = os.environ.get("GRIT_DECODE_PROMPT_CHUNK", "1") != "0" and not self.moe
         self.prompt_chunk_max_rows = 512
         self._lm_head16 = None
         self.last_precision = None                # what the last generate() call ran in ("bf16" | "f16"; "bf16 (f16 overflow)" after a fallback)
@@ -95,8 +94,53 @@ class MistralDecoder:
             ops.gemv(act, wdown, out=h, epilogue=EPI_RESIDUAL, residual=h, out16=h16)
         ops.rmsnorm_gemv(h16, e.norm, eps, self._lm_head_f16(), out=st["logits"], deferred=True)
 
+    def _step_moe(self, st):
+        """One decode step of a sparse-MoE (Mixtral) model, MixtralSparseMoeBlock.forward (scripts/modeling_mixtral_gritlm.py:839-882) at 1..8
+        rows: the attention half as in the dense step; then the router's top-2 decision ON THE DEVICE (experts [B,2], weights [B,2]) and,
+        per row and choice, the two GEMVs of the chosen expert -- ``grit_gemv_*_expert`` reads the expert index from device memory, so the
+        step is still one HIP graph and streams 2 of the 8 experts' weights per row -- and the weighted combine.
+        bf16: the reference's arithmetic (exact RMSNorm for the block input, router on those bf16 rows, ``grit_moe_combine`` rounding
+        points).  fp16 operands: the router reads the fp32 stream (norm folded in, nothing rounded), the experts run on fp16 copies, the
+        combine adds fp32 expert outputs into the fp32 stream."""
+        c, e = self.cfg, self.eng
+        nq, nkv, d, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        f16 = st["f16"]
+        h, h16, qkv, ctx, x, act2, y2 = st["h"], st["h16"], st["qkv"], st["ctx"], st["x"], st["act2"], st["y2"]
+        experts, weights, rows_c = st["experts"], st["weights"], st["rows_c"]
+        B = h.shape[0]
+        ops.embed_gather(e.embed, st["next"], out=h)
+        if f16:
+            h16.copy_(h)
+        xin = h16 if f16 else h
+        for li, L in enumerate(e.layers):
+            wqkv, wo, w13, w2 = e._f16_weights(L) if f16 else (L.wqkv, L.wo, L.w13, L.w2)
+            ck, cv = st["cache"][li]
+            ops.rmsnorm_gemv(xin, L.ln1, eps, wqkv, out=qkv, deferred=True)
+            ops.attn_decode_rope(qkv, st["cos"], st["sin"], ck, cv, st["lens"], ctx, st["ws"], nq, nkv, d)
+            if f16:
+                ops.gemv(ctx, wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+                ops.moe_router_top2(h, L.wgate, experts, weights, ln_w=L.ln2, eps=eps)
+            else:
+                ops.gemv(ctx, wo, out=h, epilogue=EPI_RESIDUAL, residual=h)
+            ops.rmsnorm(h, L.ln2, eps, out=x)              # (bf16 rows: the reference's x_n; fp16 rows under fp16 operands)
+            if not f16:
+                ops.moe_router_top2(x, L.wgate, experts, weights)
+            for b in range(B):
+                for k in (0, 1):
+                    r = 2 * b + k
+                    ops.gemv_expert(x[b:b + 1], w13, experts[b, k:k + 1], out=act2[r:r + 1], epilogue=EPI_SWIGLU)
+                    ops.gemv_expert(act2[r:r + 1], w2, experts[b, k:k + 1], out=y2[r:r + 1])
+            if f16:
+                h.add_((y2.view(B, 2, -1) * weights.unsqueeze(-1)).sum(dim=1))
+                h16.copy_(h)
+            else:
+                ops.moe_combine(y2, rows_c, weights, h, out=h)
+        ops.rmsnorm_gemv(xin, e.norm, eps, self._lm_head_f16() if f16 else self.lm_head, out=st["logits"], deferred=True)
+
     # ------------------------------------------------------------------ one decode step (all sizes static, lengths on the device)
     def _step(self, st):
+        if self.moe:
+            return self._step_moe(st)
         if st["f16"]:
             return self._step_f16(st)
         c, e = self.cfg, self.eng
@@ -206,7 +250,12 @@ class MistralDecoder:
         mk = lambda n, dt: torch.empty((B, n), dtype=dt, device=dev)
         # (the fp16 policies rotate with the unrounded fp32 tables, like the encoder's fp16 forward)
         cos, sin = rope_tables(Lmax, d, c.rope_theta, self.eng.rope_bf16 and not f16, dev)
-        return dict(f16=f16, h=mk(c.hidden_size, wide), h16=mk(c.hidden_size, F16) if f16 else None, x=mk(c.hidden_size, BF16), qkv=mk((nq + 2 * nkv) * d, wide), ctx=mk(nq * d, op),
+        moe = {}
+        if self.moe:
+            moe = dict(act2=torch.empty((2 * B, c.intermediate_size), dtype=op, device=dev), y2=torch.empty((2 * B, c.hidden_size), dtype=wide, device=dev),
+                       experts=torch.zeros((B, 2), dtype=I32, device=dev), weights=torch.zeros((B, 2), dtype=F32, device=dev),
+                       rows_c=torch.arange(2 * B, dtype=I32, device=dev).view(B, 2).contiguous())
+        return dict(**moe, f16=f16, h=mk(c.hidden_size, wide), h16=mk(c.hidden_size, F16) if f16 else None, x=mk(c.hidden_size, op), qkv=mk((nq + 2 * nkv) * d, wide), ctx=mk(nq * d, op),
                     act=mk(c.intermediate_size, op), logits=mk(self.lm_head.shape[0], wide), next=torch.zeros((B,), dtype=I64, device=dev),
                     lens=torch.zeros((B,), dtype=I32, device=dev), step=torch.zeros((1,), dtype=I32, device=dev), cos=cos, sin=sin,
                     ws=ops.attn_decode_workspace(B, nq, nkv, Lmax, dev),

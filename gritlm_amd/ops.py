@@ -634,6 +634,40 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None, epil
     return out
 
 
+def gemv_expert(x: torch.Tensor, w_stack: torch.Tensor, expert: torch.Tensor, out: torch.Tensor | None = None, epilogue: int = EPI_STORE) -> torch.Tensor:
+    """x [B,K] @ w_stack[expert[0]]^T for a stack [E,N,K]: the expert index is read on the DEVICE (``expert``: an int32 tensor or view whose
+    first element is the index), so a sparse-MoE decode step can be captured in a graph.  STORE / SWIGLU; fp16 stack: the fp16 formats."""
+    B, K = x.shape
+    E, N, _ = w_stack.shape
+    f16 = w_stack.dtype == F16
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    odt = (F16 if epilogue == EPI_SWIGLU else F32) if f16 else BF16
+    if out is None:
+        out = torch.empty((B, n_out), dtype=odt, device=x.device)
+    if expert.dtype != I32 or not expert.is_cuda:
+        raise TypeError("gemv_expert: expert must be an int32 CUDA tensor")
+    fn = _lib.load().grit_gemv_f16_expert if f16 else _lib.load().grit_gemv_bf16_expert
+    check(fn(_chk2d(x, F16 if f16 else BF16, "x"), _chk3d(w_stack, F16 if f16 else BF16, "w_stack"), _chk2d(out, odt, "out"), expert.data_ptr(),
+             w_stack.stride(0), B, N, K, x.stride(0), w_stack.stride(1), out.stride(0), epilogue, _stream()), "grit_gemv_expert")
+    return out
+
+
+def moe_router_top2(x: torch.Tensor, gate_w: torch.Tensor, experts: torch.Tensor, weights: torch.Tensor, ln_w: torch.Tensor | None = None,
+                    eps: float = 0.0):
+    """The routing decision alone into caller-owned buffers (experts [T,2] int32, weights [T,2] fp32) -- no index building, no host
+    round trip: the sparse-MoE decode step.  bf16 x: the reference's router on the normalised bf16 rows; fp32 x with ``ln_w``: the
+    fp16-operand policy's router on the residual stream itself (norm folded in, nothing rounded)."""
+    T, H = x.shape
+    E = gate_w.shape[0]
+    if x.dtype == F32:
+        check(_lib.load().grit_moe_router_top2_f32(_chk(x, F32, "h"), _chk(ln_w, BF16, "ln_w"), float(eps), _chk(gate_w, BF16, "gate_w"),
+                                                   _chk(experts, I32, "experts"), _chk(weights, F32, "weights"), T, H, E, _stream()),
+              "grit_moe_router_top2_f32")
+    else:
+        check(_lib.load().grit_moe_router_top2(_chk(x, BF16, "x"), _chk(gate_w, BF16, "gate_w"), _chk(experts, I32, "experts"),
+                                               _chk(weights, F32, "weights"), T, H, E, _stream()), "grit_moe_router_top2")
+
+
 def rmsnorm_gemv(x: torch.Tensor, ln_w: torch.Tensor, eps: float, w: torch.Tensor, out: torch.Tensor | None = None,
                  epilogue: int = EPI_STORE, deferred: bool = False) -> torch.Tensor:
     """gemv(rmsnorm(x, ln_w, eps), w) in one launch (decode step).  ``deferred``: the row scale multiplies the finished dot products

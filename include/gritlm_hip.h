@@ -460,6 +460,15 @@ int grit_attn_decode_rope_f16(const void* qkv, const float* cos_tab, const float
 int grit_argmax_advance_f32(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history,
                             int64_t hist_stride, int32_t* step, int B, void* stream);
 
+/* Sparse-MoE decode (ABI 5; MixtralSparseMoeBlock.forward, scripts/modeling_mixtral_gritlm.py:839-882, at 1..8 rows): x [B,K] times ONE
+ * matrix of the stack W [E,N,K] -- matrix expert[0], an int32 in DEVICE memory (the router's choice for the row, so that the decode step
+ * stays one HIP graph); w_expert_stride = elements between consecutive matrices.  Epilogues STORE and SWIGLU; formats of grit_gemv_bf16 /
+ * grit_gemv_f16 (f16 STORE writes fp32). */
+int grit_gemv_bf16_expert(const void* x, const void* W, void* out, const int32_t* expert, int64_t w_expert_stride, int B, int N, int K,
+                          int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
+int grit_gemv_f16_expert(const void* x, const void* W, void* out, const int32_t* expert, int64_t w_expert_stride, int B, int N, int K,
+                         int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
+
 /* A prompt chunk on top of a cached prefix without a token-by-token loop (ABI 5): what model.generate() does with the query tokens it is
  * handed next to past_key_values (rag/eval.py:277-302 -- the attention mask covers the cache, the new tokens attend to it and causally to
  * each other).  V rows are tokens of B <= V sequences: row v belongs to sequence cache_row[v] of the caches [B, nkv, Lmax, d] and sits at

@@ -263,7 +263,10 @@ def mistral_continue(weights: dict, cfg: dict, prefix_kv: list, prefix_len: int,
         a = np.matmul(pr, vv).transpose(0, 2, 1, 3).reshape(1, P, nh * d).astype(F32)
         h = h + a @ weights[p + "self_attn.o_proj.weight"].T
         x = rmsnorm(h, weights[p + "post_attention_layernorm.weight"], eps)
-        m = (silu(x @ weights[p + "mlp.gate_proj.weight"].T) * (x @ weights[p + "mlp.up_proj.weight"].T)) @ weights[p + "mlp.down_proj.weight"].T
+        if cfg.get("num_local_experts"):                                                 # MixtralSparseMoeBlock (modeling_mixtral_gritlm.py:839-882)
+            m = moe_block(x.reshape(P, H), weights, p + "block_sparse_moe.", cfg.get("num_experts_per_tok", 2))[0].reshape(1, P, H)
+        else:
+            m = (silu(x @ weights[p + "mlp.gate_proj.weight"].T) * (x @ weights[p + "mlp.up_proj.weight"].T)) @ weights[p + "mlp.down_proj.weight"].T
         h = (h + m).astype(F32)
     out = rmsnorm(h, weights["norm.weight"], eps)
     return (out[0] @ lm_head.T).astype(F32)

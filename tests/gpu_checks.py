@@ -2912,7 +2912,7 @@ def check_native_generate_f16(cfg_name="tiny", P=21, new=10, rows=2, policy="f16
     eng2, cfg2, w2 = build_engine(cfg_name, 6)
     eng2.set_precision(policy)
     dec2 = MistralDecoder(eng2, torch.from_numpy(lm))
-    eng2.layers[0].wgu.mul_(400.0)                 # |gate|, |up| x 400: silu(g) u beyond 65504 for some elements
+    (eng2.layers[0].w13 if cfg.get("num_local_experts") else eng2.layers[0].wgu).mul_(400.0)       # |gate|, |up| x 400: silu(g) u beyond 65504 for some elements
     fell = raised = False
     try:
         dec2.generate(torch.from_numpy(prompt[:1]).to(DEV), 3, past_key_values=[(k[:, :, :0], v[:, :, :0]) for k, v in kv])
@@ -4190,6 +4190,8 @@ ALL_CHECKS = [
     ("native_generate_f16_stream_gqa", check_native_generate_f16, dict(cfg_name="gqa", P=9, new=6, rows=3, policy="f16_stream")),
     ("native_generate_f16_7b_layer_shape", check_native_generate_f16, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
     ("native_generate_f16_rows8", check_native_generate_f16, dict(cfg_name="tiny", P=5, new=4, rows=8)),          # the 8-row instantiations of every GEMV form
+    ("native_generate_moe", check_native_generate, dict(cfg_name="moe-tiny", P=9, new=6, rows=2, tol=0.08)),
+    ("native_generate_moe_f16", check_native_generate_f16, dict(cfg_name="moe-tiny", P=9, new=6, rows=2, policy="f16_operands", cos_bound=2e-5)),
     ("generate_native_api", check_generate_native_api, {}),
     ("native_generate_prompt_chunk", check_native_generate_prompt_chunk, {}),
     ("native_generate_prompt_chunk_f16", check_native_generate_prompt_chunk, dict(policy="f16_stream")),

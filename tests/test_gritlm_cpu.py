@@ -312,8 +312,8 @@ def test_native_decoder_follows_the_engine_policy_host_logic():
     dec.precision = "bf16"
     with pytest.raises(ValueError):
         dec.generate(torch.zeros((1, 2), dtype=torch.long), 2, on_overflow="ignore")
-    with pytest.raises(NotImplementedError):
-        MistralDecoder(SimpleNamespace(cfg=SimpleNamespace(num_local_experts=8), device=torch.device("cpu")), torch.zeros((8, 256)))
+    moe = MistralDecoder(SimpleNamespace(cfg=SimpleNamespace(num_local_experts=8), device=torch.device("cpu"), precision="bf16"), torch.zeros((8, 256)))
+    assert moe.moe and not moe.prompt_chunk and not dec.moe          # sparse-MoE engines decode too (round 6); their prompt rides token by token
     # GritLM.native_decoder(): "auto" -> on_overflow "bf16"
     m = GritLM.__new__(GritLM)
     torch.nn.Module.__init__(m)
