@@ -772,7 +772,7 @@ static int gemv_expert_entry(const char* name, bool f16, const void* x, const vo
   GRIT_REQUIRE(x && W && out && expert, GRIT_E_BADARG, "%s: null pointer", name);
   GRIT_REQUIRE(B > 0 && B <= 8, GRIT_E_UNSUPPORTED, "%s: B=%d rows (1..8)", name, B);
   GRIT_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && w_expert_stride % 8 == 0 &&
-               w_expert_stride >= (int64_t)N * ldw, GRIT_E_BADARG, "%s: bad sizes", name);
+               ldw <= w_expert_stride / N, GRIT_E_BADARG, "%s: bad sizes", name);       // (stride >= N * ldw, without the product: fuzzed ldw overflows it)
   GRIT_REQUIRE(aligned16(x) && aligned16(W), GRIT_E_BADARG, "%s: pointers must be 16-byte aligned", name);
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
