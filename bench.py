@@ -420,6 +420,7 @@ def compact_summary(line: dict) -> dict:
                      "f16_routing_agree_min": r(min([v["routing_agree"] for v in (g(mp, "policies", "f16_operands", "teacher_forced_per_layer") or {}).values()] or [0.0])),
                      "bf16_e2e_1mcos": r(g(mp, "policies", "bf16", "end_to_end", "max_one_minus_cos")),
                      "ref_bf16_dataflow_e2e_1mcos": r(g(mp, "reference_dataflow_in_bf16_end_to_end", "max_one_minus_cos")),
+                     "decode_frac": r(g(mx, "native_decode", "frac_of_weight_streaming_roofline")),
                      "north_star_met": mp.get("north_star_met"), "err": mx.get("error")},
          "rag": {"decode_frac": r(rag.get("decode_frac_of_weight_streaming_roofline")), "encode_frac": r(rag.get("encode_mfma_roofline_frac")),
                  "decode_logits_1mcos_bf16_level": r(g(rag, "parity", "max_one_minus_cos")),
@@ -1066,7 +1067,7 @@ def main():
                 line["mixtral_8x7b_seq2048"] = secondary_leg(
                     "mixtral_bench.py", ["--docs", 64, "--seq", 2048, "--steps", 3, "--warmup", 1], 600,
                     ("metric", "value", "unit", "ms_per_step", "tokens_per_s", "config", "roofline", "model_flops_utilisation", "hbm_allocated_gb",
-                     "expert_load_max_over_mean", "finite", "kernels", "parity", "north_star_policy"))
+                     "expert_load_max_over_mean", "finite", "kernels", "parity", "north_star_policy", "native_decode"))
             if not args.no_rag:
                 line["rag_doc_caching"] = secondary_leg(
                     "rag_cache_bench.py", ["--passages", 512, "--seq", 2048, "--new-tokens", 128, "--queries", 4], 600,
