@@ -73,6 +73,7 @@ _SIGNATURES = {
     "grit_argmax_advance_f32": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _i, _p]),
     "grit_gemv_bf16_expert": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _l, _l, _l, _i, _p]),
     "grit_gemv_f16_expert": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _l, _l, _l, _i, _p]),
+    "grit_moe_decode_combine_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "grit_rope_kv_append_rows": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _i, _p]),
     "grit_attn_decode_rows": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
     "grit_knn_workspace_bytes": (_l, [_i, _l, _i]),

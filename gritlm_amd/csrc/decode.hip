@@ -655,6 +655,23 @@ __global__ void __launch_bounds__(256) argmax_advance_k(const uint16_t* __restri
 
 __global__ void bump_k(int32_t* v) { v[0] += 1; }
 
+// Sparse-MoE decode on fp16 operands: h[b] += w[b,0] y[2b] + w[b,1] y[2b+1] in fp32 (y: the two chosen experts' fp32 outputs of row b) and
+// h16 = fp16(h), the operand copy the next norm + GEMV reads -- one launch for the four elementwise passes a host-side combine would take.
+__global__ void __launch_bounds__(256) moe_decode_combine_f32_k(float* __restrict__ h, uint16_t* __restrict__ h16, const float* __restrict__ y,
+                                                                const float* __restrict__ w, int H, unsigned int* __restrict__ flag) {
+  const int b = blockIdx.y;
+  const float w0 = w[2 * b], w1 = w[2 * b + 1];
+  uint32_t bad = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256) {
+    const float v = h[(int64_t)b * H + i] + (w0 * y[(int64_t)(2 * b) * H + i] + w1 * y[(int64_t)(2 * b + 1) * H + i]);
+    h[(int64_t)b * H + i] = v;
+    const uint16_t hb = f2h_bits(v);
+    bad |= ((hb & 0x7c00u) == 0x7c00u);
+    h16[(int64_t)b * H + i] = hb;
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+
 }  // namespace grit
 
 using namespace grit;
@@ -966,6 +983,18 @@ static int argmax_launch(const char* name, const void* logits, int64_t ld, int V
 extern "C" int grit_argmax_advance(const void* logits, int64_t ld, int V, int64_t* next, int32_t* lens, int64_t* history, int64_t hist_stride,
                                    int32_t* step, int B, void* stream) {
   return argmax_launch<false>("grit_argmax_advance", logits, ld, V, next, lens, history, hist_stride, step, B, stream);
+}
+
+extern "C" int grit_moe_decode_combine_f32(float* h, void* h16, const float* y, const float* weights, int B, int H, void* stream) {
+  if (B == 0) return GRIT_OK;
+  GRIT_REQUIRE(h && h16 && y && weights, GRIT_E_BADARG, "grit_moe_decode_combine_f32: null pointer");
+  GRIT_REQUIRE(B > 0 && B <= 65535 && H > 0, GRIT_E_BADARG, "grit_moe_decode_combine_f32: bad sizes");
+  unsigned int* flag = f16_flag_ptr();
+  if (!flag) return GRIT_E_LAUNCH;
+  hipLaunchKernelGGL(moe_decode_combine_f32_k, dim3((unsigned)((H + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, h, (uint16_t*)h16, y,
+                     weights, H, flag);
+  GRIT_CHECK_LAUNCH("grit_moe_decode_combine_f32");
+  return GRIT_OK;
 }
 
 // fp32 logits (the fp16-operand decode step)

@@ -131,8 +131,7 @@ class MistralDecoder:
                     ops.gemv_expert(x[b:b + 1], w13, experts[b, k:k + 1], out=act2[r:r + 1], epilogue=EPI_SWIGLU)
                     ops.gemv_expert(act2[r:r + 1], w2, experts[b, k:k + 1], out=y2[r:r + 1])
             if f16:
-                h.add_((y2.view(B, 2, -1) * weights.unsqueeze(-1)).sum(dim=1))
-                h16.copy_(h)
+                ops.moe_decode_combine_f32(h, h16, y2, weights)
             else:
                 ops.moe_combine(y2, rows_c, weights, h, out=h)
         ops.rmsnorm_gemv(xin, e.norm, eps, self._lm_head_f16() if f16 else self.lm_head, out=st["logits"], deferred=True)

@@ -652,6 +652,13 @@ def gemv_expert(x: torch.Tensor, w_stack: torch.Tensor, expert: torch.Tensor, ou
     return out
 
 
+def moe_decode_combine_f32(h: torch.Tensor, h16: torch.Tensor, y: torch.Tensor, weights: torch.Tensor):
+    """h[b] += weights[b,0] y[2b] + weights[b,1] y[2b+1] (fp32, in place) and h16 = fp16(h): the sparse-MoE decode step on fp16 operands."""
+    B, H = h.shape
+    check(_lib.load().grit_moe_decode_combine_f32(_chk(h, F32, "h"), _chk(h16, F16, "h16"), _chk(y, F32, "y"), _chk(weights, F32, "weights"), B, H,
+                                                  _stream()), "grit_moe_decode_combine_f32")
+
+
 def moe_router_top2(x: torch.Tensor, gate_w: torch.Tensor, experts: torch.Tensor, weights: torch.Tensor, ln_w: torch.Tensor | None = None,
                     eps: float = 0.0):
     """The routing decision alone into caller-owned buffers (experts [T,2] int32, weights [T,2] fp32) -- no index building, no host

@@ -468,6 +468,9 @@ int grit_gemv_bf16_expert(const void* x, const void* W, void* out, const int32_t
                           int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
 int grit_gemv_f16_expert(const void* x, const void* W, void* out, const int32_t* expert, int64_t w_expert_stride, int B, int N, int K,
                          int64_t ldx, int64_t ldw, int64_t ldo, int epilogue, void* stream);
+/* ... and its combine on fp16 operands (:876-880 in fp32): h[b] += weights[b,0] y[2b] + weights[b,1] y[2b+1] (h [B,H] the fp32 residual stream,
+ * y [2B,H] the chosen experts' fp32 outputs), h16 = fp16(h) (the operand copy the next norm + GEMV reads; beyond the range: the overflow flag). */
+int grit_moe_decode_combine_f32(float* h, void* h16, const float* y, const float* weights, int B, int H, void* stream);
 
 /* A prompt chunk on top of a cached prefix without a token-by-token loop (ABI 5): what model.generate() does with the query tokens it is
  * handed next to past_key_values (rag/eval.py:277-302 -- the attention mask covers the cache, the new tokens attend to it and causally to
