@@ -2787,6 +2787,44 @@ def check_gemv_f16(N=1030, K=512, seed=185):
                 flag_raised=raised, **{k: max(v.values()) for k, v in det.items()})
 
 
+def check_gemv_expert(E=5, N=1024, K=512, big=False):
+    """grit_gemv_{bf16,f16}_expert: x times the matrix of an [E,N,K] stack chosen by an int32 in DEVICE memory == the plain GEMV on that
+    slice, bit for bit, for every expert, both operand formats, STORE and SWIGLU, 1 and 3 rows; ``big``: the Mixtral-8x7B w13 stack's
+    strides (8 x 28672 x 4096: the index times 117 M elements).  And grit_moe_decode_combine_f32 against the same expression in torch."""
+    if big:
+        E, N, K = 8, 28672, 4096
+    ok, det = True, {}
+    g = torch.Generator(device=DEV).manual_seed(9)
+    stack_bf = (torch.randn((E, N, K), generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    for dt in (torch.bfloat16, torch.float16):
+        stack = stack_bf if dt == torch.bfloat16 else stack_bf.to(torch.float16)
+        for B in (1, 3):
+            x = torch.randn((B, K), generator=g, device=DEV).to(dt)
+            idx = torch.zeros((E, 2), dtype=torch.int32, device=DEV)
+            for e in (range(E) if not big else (0, E - 1)):
+                idx[e, 1] = e
+                for epi in (EPI_STORE, EPI_SWIGLU):
+                    got = ops.gemv_expert(x, stack, idx[e, 1:2], epilogue=epi)
+                    ref = ops.gemv(x, stack[e], epilogue=epi)
+                    same = bool(torch.equal(got, ref)) and got.dtype == ref.dtype
+                    ok &= same
+                    det[f"{str(dt)[6:]}_B{B}_e{e}_epi{epi}"] = same
+    del stack_bf, stack
+    B, H = 3, 1000
+    h = torch.randn((B, H), generator=g, device=DEV); y = torch.randn((2 * B, H), generator=g, device=DEV); w = torch.rand((B, 2), generator=g, device=DEV)
+    want = h + (y.view(B, 2, H) * w.unsqueeze(-1)).sum(dim=1)
+    h2, h16 = h.clone(), torch.empty((B, H), dtype=torch.float16, device=DEV)
+    ops.f16_overflow_flag(DEV, clear=True)
+    ops.moe_decode_combine_f32(h2, h16, y, w)
+    comb = float((h2 - want).abs().max()) < 1e-6 and bool(torch.equal(h16, h2.to(torch.float16))) and not ops.f16_overflow_flag(DEV, clear=True)
+    h3 = h.clone(); h3[1, 7] = 1e6
+    ops.moe_decode_combine_f32(h3, h16, y, w)
+    comb &= ops.f16_overflow_flag(DEV, clear=True)
+    ok &= comb
+    return _res(f"gemv_expert[E={E},N={N},K={K}] == gemv on the slice (bit for bit); moe_decode_combine_f32", bool(ok), all_equal=all(det.values()), cases=len(det),
+                combine_ok=comb)
+
+
 def check_attn_decode_f16(B=3, nq=8, nkv=2, Lmax=768, lens=(700, 0, 255)):
     """grit_attn_decode_rope_f16: fp32 q|k|v row, fp16 caches.  The appended rows are fp16(rope(k)) and fp16(v) -- ONE rounding from the
     fp32 row --, the context equals fp64 attention of the UNROUNDED rotated q over the cache as it then stands, up to the fp16 output
@@ -4190,6 +4228,8 @@ ALL_CHECKS = [
     ("native_generate_f16_stream_gqa", check_native_generate_f16, dict(cfg_name="gqa", P=9, new=6, rows=3, policy="f16_stream")),
     ("native_generate_f16_7b_layer_shape", check_native_generate_f16, dict(cfg_name="7b-l2s", P=12, new=6, rows=1)),
     ("native_generate_f16_rows8", check_native_generate_f16, dict(cfg_name="tiny", P=5, new=4, rows=8)),          # the 8-row instantiations of every GEMV form
+    ("gemv_expert", check_gemv_expert, {}),
+    ("gemv_expert_8x7b_w13_strides", check_gemv_expert, dict(big=True)),
     ("native_generate_moe", check_native_generate, dict(cfg_name="moe-tiny", P=9, new=6, rows=2, tol=0.08)),
     ("native_generate_moe_f16", check_native_generate_f16, dict(cfg_name="moe-tiny", P=9, new=6, rows=2, policy="f16_operands", cos_bound=2e-5)),
     ("generate_native_api", check_generate_native_api, {}),
