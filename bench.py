@@ -427,6 +427,8 @@ def compact_summary(line: dict) -> dict:
                  "f16_decode_logits_1mcos": r(g(rag, "parity", "f16_flow", "f16_stream", "max_one_minus_cos")),
                  "f16_decode_frac": r(g(rag, "parity", "f16_flow", "f16_stream", "decode_frac_of_weight_streaming_roofline")),
                  "f16_flow_north_star_met": g(rag, "parity", "f16_flow", "north_star_met"),
+                 "latency16_native_s": r(g(rag, "native_decode", "latency_16_new_tokens", "native_s")),
+                 "latency16_hf_s": r(g(rag, "native_decode", "latency_16_new_tokens", "hugging_face_generate_s")),
                  "encode_get_cache_1mcos": {k: r(g(rag, "parity", "encode_get_cache_by_policy", k, "max_one_minus_cos")) for k in ("bf16", "f16_stream", "f16_operands")},
                  "err": rag.get("error")}}
 
